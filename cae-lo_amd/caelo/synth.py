@@ -1,0 +1,144 @@
+"""Seeded synthetic KITTI-shaped LiDAR scans (no KITTI data exists in this environment).
+
+SURVEY.md section 8(d): a fixed scene (ground plane + axis-aligned boxes + thin poles) is
+ray-cast by a 64-beam (+2.0 .. -24.8 deg) x 2000-azimuth spinning sensor that moves
+~0.9 m / frame with a small yaw, sigma = 1 cm range noise, U(0,1) intensity.
+
+The generator is written so that the produced float32 cloud is bit-identical under
+NumPy 1.26 (the conda python3.9 used to import the reference for the goldens) and
+NumPy 2.x (tests / bench): only scalar libm calls through ``math`` and element-wise
+IEEE +,-,*,/ and comparisons are used (no vectorised transcendental functions, no
+reductions whose order could differ), and the legacy ``RandomState`` streams.
+``cloud_sha256`` lets a test verify that a regenerated cloud equals the one the goldens
+were made from.
+"""
+import hashlib
+import math
+
+import numpy as np
+
+SCENE_SEED = 1234
+GROUND_Z = -1.73
+MAX_RANGE = 80.0
+
+
+def _scene(seed=SCENE_SEED):
+    rs = np.random.RandomState(seed)
+    boxes = []
+    nbox = 60
+    for _ in range(nbox):
+        # centre on a ring 6..60 m away, footprint 1.5..12 m, height 1..9 m
+        ang = rs.uniform(0.0, 2.0 * math.pi)
+        dist = rs.uniform(6.0, 60.0)
+        sx = rs.uniform(1.5, 12.0)
+        sy = rs.uniform(1.5, 12.0)
+        h = rs.uniform(1.0, 9.0)
+        cx = dist * math.cos(ang)
+        cy = dist * math.sin(ang)
+        # keep every box at least 4 m from the sensor track (x in [-5, 40], |y| < 3)
+        if (cx - sx / 2 < 45.0 and cx + sx / 2 > -6.0) and abs(cy) - sy / 2 < 4.0:
+            continue
+        boxes.append((cx - sx / 2, cx + sx / 2, cy - sy / 2, cy + sy / 2, GROUND_Z, GROUND_Z + h))
+    for _ in range(40):
+        ang = rs.uniform(0.0, 2.0 * math.pi)
+        dist = rs.uniform(5.0, 45.0)
+        h = rs.uniform(2.0, 7.0)
+        cx = dist * math.cos(ang)
+        cy = dist * math.sin(ang)
+        if (cx < 45.0 and cx > -6.0) and abs(cy) < 4.0:
+            continue
+        boxes.append((cx - 0.15, cx + 0.15, cy - 0.15, cy + 0.15, GROUND_Z, GROUND_Z + h))
+    return np.array(boxes, dtype=np.float64)
+
+
+_SCENE_CACHE = {}
+
+
+def scene(seed=SCENE_SEED):
+    if seed not in _SCENE_CACHE:
+        _SCENE_CACHE[seed] = _scene(seed)
+    return _SCENE_CACHE[seed]
+
+
+def sensor_pose(frame, step=(0.9, 0.05, 0.0), yaw_step=0.01):
+    """World pose of the sensor at frame index ``frame`` (translation, yaw)."""
+    return (step[0] * frame, step[1] * frame, step[2] * frame), yaw_step * frame
+
+
+def make_scan(frame=0, n_beams=64, n_az=2000, seed=None, scene_seed=SCENE_SEED,
+              pose=None, noise_sigma=0.01):
+    """Return a [N,4] float32 cloud (x,y,z,intensity) in the sensor frame, file order
+    beam-major (all azimuths of beam 0, then beam 1, ...)."""
+    if seed is None:
+        seed = frame
+    (tx, ty, tz), yaw = sensor_pose(frame) if pose is None else pose
+    cy_, sy_ = math.cos(yaw), math.sin(yaw)
+    # direction table in the sensor frame via scalar libm
+    elev = [math.radians(2.0 + (-24.8 - 2.0) * i / (n_beams - 1)) for i in range(n_beams)]
+    az = [2.0 * math.pi * (j + 0.5) / n_az - math.pi for j in range(n_az)]
+    ce = np.array([math.cos(e) for e in elev])
+    se = np.array([math.sin(e) for e in elev])
+    ca = np.array([math.cos(a) for a in az])
+    sa = np.array([math.sin(a) for a in az])
+    dx = (ce[:, None] * ca[None, :]).reshape(-1)
+    dy = (ce[:, None] * sa[None, :]).reshape(-1)
+    dz = (se[:, None] * np.ones(n_az)[None, :]).reshape(-1)
+    # rotate directions into the world frame (yaw about z)
+    wx = cy_ * dx - sy_ * dy
+    wy = sy_ * dx + cy_ * dy
+    wz = dz
+    t = np.full(dx.shape, np.inf)
+    # ground plane z = GROUND_Z
+    down = wz < 0.0
+    tg = np.where(down, (GROUND_Z - tz) / np.where(down, wz, -1.0), np.inf)
+    t = np.minimum(t, tg)
+    big = 1e30
+    for b in scene(scene_seed):
+        x0, x1, y0, y1, z0, z1 = b
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ix = 1.0 / wx
+            iy = 1.0 / wy
+            iz = 1.0 / wz
+            ta = (x0 - tx) * ix
+            tb = (x1 - tx) * ix
+            tmin = np.minimum(ta, tb)
+            tmax = np.maximum(ta, tb)
+            ta = (y0 - ty) * iy
+            tb = (y1 - ty) * iy
+            tmin = np.maximum(tmin, np.minimum(ta, tb))
+            tmax = np.minimum(tmax, np.maximum(ta, tb))
+            ta = (z0 - tz) * iz
+            tb = (z1 - tz) * iz
+            tmin = np.maximum(tmin, np.minimum(ta, tb))
+            tmax = np.minimum(tmax, np.maximum(ta, tb))
+        hit = (tmax >= tmin) & (tmin > 0.5) & (tmin < big)
+        t = np.where(hit, np.minimum(t, tmin), t)
+    rs = np.random.RandomState(seed)
+    noise = rs.normal(0.0, 1.0, size=t.shape) * noise_sigma
+    inten = rs.uniform(0.0, 1.0, size=t.shape)
+    keep = t < MAX_RANGE
+    r = t + noise
+    pc = np.empty((int(keep.sum()), 4), dtype=np.float32)
+    pc[:, 0] = (r * dx)[keep]
+    pc[:, 1] = (r * dy)[keep]
+    pc[:, 2] = (r * dz)[keep]
+    pc[:, 3] = inten[keep]
+    return pc
+
+
+def cloud_sha256(pc):
+    return hashlib.sha256(np.ascontiguousarray(pc).tobytes()).hexdigest()
+
+
+def relative_pose_gt(frame0, frame1):
+    """Ground-truth (R, T) with P0 ~ R @ P1 + T for clouds of frame0 / frame1."""
+    (t0, y0), (t1, y1) = sensor_pose(frame0), sensor_pose(frame1)
+
+    def rot(a):
+        c, s = math.cos(a), math.sin(a)
+        return np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+
+    R0, R1 = rot(y0), rot(y1)
+    R = R0.T @ R1
+    T = R0.T @ (np.array(t1) - np.array(t0))
+    return R, T.reshape(3, 1)

@@ -1,0 +1,306 @@
+"""Python face of the CPU oracle (TEST INFRASTRUCTURE ONLY -- see caelo_oracle.c header).
+
+Mirrors the reference's function-level call surface on NumPy arrays so
+parity tests read like calls into the reference:
+
+    ProjectPC2SphericalRing   SphericalRing.py:72      GetPatchesList          Voxel.py:177
+    GetKeyPtsByAE             SphericalRing.py:113     GetFeaturesFromPatches  Match.py:130
+    Voxelization              Voxel.py:100             SolveRT / RANSAC4RT / SolveRelativePose
+                                                        Match.py:138 / :162 / :241
+
+Heavy loops live in caelo_oracle.c (ctypes); the 3x3 SVD and RANSAC control flow are NumPy
+(LAPACK), exactly like the reference.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+IMG_H, IMG_W, RING_C = 69, 1800, 5
+NET_H, NET_W = 64, 1792
+VIS = np.array([99.84, 99.84, 14.72], dtype=np.float64)  # Voxel.py:50-52
+VOXEL_SIZES = [0.02, 0.02 * 8, 0.02 * 32]               # Voxel.py:31
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or (
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "caelo_oracle.c"))):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_num_threads.restype = C.c_int
+    return _lib
+
+
+def _p(a, t=C.c_void_p):
+    return a.ctypes.data_as(t)
+
+
+def num_threads():
+    return lib().orc_num_threads()
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
+
+
+# ---------------------------------------------------------------------------------------------
+def ProjectPC2SphericalRing(PC):
+    """SphericalRing.py:72-94 -> (Image_float [69,1800,5] f32, GridCounter [69,1800] i32)."""
+    assert PC.shape[0] > 3 and PC.shape[1] == 4  # :73
+    PC = np.ascontiguousarray(PC, dtype=np.float32)
+    ring = np.empty((IMG_H, IMG_W, RING_C), dtype=np.float32)
+    cnt = np.empty((IMG_H, IMG_W), dtype=np.int32)
+    rc = lib().orc_project(_p(PC), C.c_int64(PC.shape[0]), _p(ring), _p(cnt))
+    if rc != 0:
+        raise IndexError("index 1800 is out of bounds for axis 1 with size 1800")
+    return ring, cnt
+
+
+class RespondLayer:
+    """Stand-in for keras ``load_model(SphericalRingPCRespondLayer.h5)``; ``predict`` follows
+    the h5 model_config (Conv2D 3->32 3x3 same relu, Conv2D 32->8 1x1 relu)."""
+
+    def __init__(self, w1, b1, w2, b2):
+        self.w1 = np.ascontiguousarray(w1, np.float32).reshape(3, 3, 3, 32)
+        self.b1 = np.ascontiguousarray(b1, np.float32)
+        self.w2 = np.ascontiguousarray(w2, np.float32).reshape(32, 8)
+        self.b2 = np.ascontiguousarray(b2, np.float32)
+
+    def predict(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        assert x.ndim == 4 and x.shape[1:] == (NET_H, NET_W, 3)
+        out = np.empty((x.shape[0], NET_H, NET_W, 8), dtype=np.float32)
+        for b in range(x.shape[0]):
+            lib().orc_respond(_p(x[b]), C.c_int(NET_W), C.c_int(3), _p(self.w1), _p(self.b1),
+                              _p(self.w2), _p(self.b2), _p(out[b]))
+        return out
+
+
+def GetKeyPtsByAE(SphericalRing, GridCounter, RespondImg, return_score=False):
+    """SphericalRing.py:113-291.  Demo mode: full [69,1800,5] ring; batch mode: cropped
+    [64,1792,3] ring (BatchPreprocess.py:97-98,131-136)."""
+    ring = np.ascontiguousarray(SphericalRing, dtype=np.float32)
+    cnt = np.ascontiguousarray(GridCounter, dtype=np.int32)
+    resp = np.ascontiguousarray(RespondImg, dtype=np.float32)
+    assert resp.shape == (NET_H, NET_W, 8)
+    kpix = np.zeros((1024, 2), dtype=np.int64)
+    kpts = np.zeros((1024, 3), dtype=np.float32)
+    score = np.zeros((NET_H, NET_W), dtype=np.float32) if return_score else None
+    k = lib().orc_keypoints(_p(ring), C.c_int(ring.shape[1]), C.c_int(ring.shape[2]), _p(cnt),
+                            C.c_int(cnt.shape[1]), _p(resp), _p(kpix), _p(kpts),
+                            _p(score) if return_score else None)
+    assert k > 50  # :286
+    out = (kpts[:k].copy(), kpix[:k].copy(), np.array([], dtype=np.float32))
+    return out + (score,) if return_score else out
+
+
+def Voxelization(PC):
+    """Voxel.py:100-173.  Returns the reference's 9-tuple; only AllVoxels0/1/2 (the members the
+    hot path consumes) are populated, the block structures are None."""
+    PC = np.ascontiguousarray(PC, dtype=np.float32)
+    n, stride = PC.shape
+    a0 = np.empty((n, 3), np.int16)
+    a1 = np.empty((n, 3), np.int16)
+    a2 = np.empty((n, 3), np.int16)
+    cnt = np.zeros(3, np.int64)
+    rc = lib().orc_voxelize(_p(PC), C.c_int64(n), C.c_int(stride), _p(a0), _p(a1), _p(a2), _p(cnt))
+    if rc != 0:
+        raise IndexError("voxel index out of bounds for its block")
+    return (None, None, None, None, None, None,
+            a0[:cnt[0]].copy(), a1[:cnt[1]].copy(), a2[:cnt[2]].copy())
+
+
+def patches_bits(Pts, AllVoxels, scale):
+    """One scale of GetPatchesList as bit-packed patches [K,64] u64 + flags [K] u8."""
+    Pts = np.ascontiguousarray(Pts, dtype=np.float32)
+    vox = np.ascontiguousarray(AllVoxels, dtype=np.int16)
+    bits = np.zeros((Pts.shape[0], 64), dtype=np.uint64)
+    flags = np.zeros(Pts.shape[0], dtype=np.uint8)
+    rc = lib().orc_patches(_p(Pts), C.c_int64(Pts.shape[0]), _p(vox), C.c_int64(vox.shape[0]),
+                           C.c_int(scale), _p(bits), _p(flags))
+    if rc != 0:
+        raise ValueError("Expected n_neighbors <= n_samples,  but n_samples = %d, n_neighbors = 496"
+                         % vox.shape[0])
+    return bits, flags
+
+
+def unpack_patches(bits):
+    """[K,64] u64 -> [K,16,16,16,1] f32 (the reference's dense layout)."""
+    b = np.ascontiguousarray(bits, dtype="<u8").view(np.uint8).reshape(bits.shape[0], 512)
+    d = np.unpackbits(b, axis=1, bitorder="little")
+    return d.reshape(bits.shape[0], 16, 16, 16, 1).astype(np.float32)
+
+
+def pack_patches(dense):
+    """[K,16,16,16(,1)] {0,1} -> [K,64] u64."""
+    d = (np.asarray(dense).reshape(dense.shape[0], 4096) != 0).astype(np.uint8)
+    return np.packbits(d, axis=1, bitorder="little").view("<u8").reshape(dense.shape[0], 64)
+
+
+def GetPatchesList(Pts, AllVoxels0, AllVoxels1, AllVoxels2, return_flags=False):
+    """Voxel.py:177-216 -> (Pts, [P0,P1,P2]) with P_s [K,16,16,16,1] f32."""
+    out, flags = [], []
+    for s, vox in enumerate((AllVoxels0, AllVoxels1, AllVoxels2)):
+        b, f = patches_bits(Pts, vox, s)
+        out.append(unpack_patches(b))
+        flags.append(f)
+    return (Pts, out, flags) if return_flags else (Pts, out)
+
+
+class _EncW(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("w1", "b1", "w2", "b2", "w3", "b3", "wd1", "bd1", "wd2", "bd2")]
+
+
+class PatchEncoder:
+    """Stand-in for keras ``load_model(EncoderModel4VoxelPatch.h5)`` (all-tanh)."""
+
+    def __init__(self, weights):
+        self.w = [np.ascontiguousarray(a, np.float32) for a in weights]
+        assert [a.size for a in self.w] == [216, 8, 3456, 16, 13824, 32, 409600, 200, 4000, 20]
+        self._s = _EncW(*[a.ctypes.data for a in self.w])
+
+    def predict_bits(self, bits):
+        bits = np.ascontiguousarray(bits, dtype=np.uint64)
+        out = np.empty((bits.shape[0], 20), dtype=np.float32)
+        lib().orc_encode(_p(bits), C.c_int64(bits.shape[0]), C.byref(self._s), _p(out),
+                         C.c_int(20), C.c_int(0))
+        return out
+
+    def predict(self, patches):
+        return self.predict_bits(pack_patches(patches))
+
+
+def GetFeaturesFromPatches(PatchEncoder_, PatchesList):
+    """Match.py:130-135."""
+    return np.c_[PatchEncoder_.predict(PatchesList[0]), PatchEncoder_.predict(PatchesList[1]),
+                 PatchEncoder_.predict(PatchesList[2])]
+
+
+def load_models(respond_h5, encoder_h5):
+    """Read both Keras .h5 files (through caelo.h5lite -- file parsing only, no compute)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(_HERE), "cae-lo_amd"))
+    from caelo.h5lite import H5File
+    r = H5File(respond_h5)
+    g = lambda h, l, n: h.dataset("/model_weights/%s/%s/%s:0" % (l, l, n))
+    resp = RespondLayer(g(r, "conv2d_1", "kernel"), g(r, "conv2d_1", "bias"),
+                        g(r, "conv2d_2", "kernel"), g(r, "conv2d_2", "bias"))
+    e = H5File(encoder_h5)
+    ws = []
+    for l in ("conv3d_1", "conv3d_2", "conv3d_3", "dense_1", "dense_2"):
+        ws += [g(e, l, "kernel"), g(e, l, "bias")]
+    return resp, PatchEncoder(ws)
+
+
+# ---------------------------------------------------------------------------------------------
+def match(Codes0, Codes1):
+    """Match.py:257-258: argmin over frame-0 descriptors for every frame-1 keypoint (f64)."""
+    f0 = np.ascontiguousarray(Codes0, np.float32)
+    f1 = np.ascontiguousarray(Codes1, np.float32)
+    idx = np.empty(f1.shape[0], np.int64)
+    dist = np.empty(f1.shape[0], np.float64)
+    lib().orc_match(_p(f0), C.c_int64(f0.shape[0]), _p(f1), C.c_int64(f1.shape[0]),
+                    C.c_int(f0.shape[1]), _p(idx), _p(dist))
+    return idx, dist
+
+
+def SolveRT(Pairs0, Pairs1):
+    """Match.py:138-158 (same NumPy/LAPACK calls, incl. the Vh column flip at :154)."""
+    isCredible = 1
+    mean0 = np.mean(Pairs0, axis=0).reshape(1, 3)
+    mean1 = np.mean(Pairs1, axis=0).reshape(1, 3)
+    P0 = Pairs0 - mean0
+    P1 = Pairs1 - mean1
+    H = np.dot(P1.T, P0)
+    U, S, V = np.linalg.svd(H)
+    R = np.dot(V.T, U.T)
+    if np.linalg.det(R) < 0:
+        isCredible = -1
+        V[:, 2] = V[:, 2] * (-1)
+        R = np.dot(V.T, U.T)
+    T = mean0.T - np.dot(R, mean1.T)
+    return R, T, isCredible
+
+
+def draw_sample_indices(rng, n_pairs):
+    """The 4 indices one RANSAC iteration consumes (Match.py:182-184)."""
+    return np.array(rng.random_sample((4,)) * n_pairs, dtype=np.int32)
+
+
+def RANSAC4RT(Pairs0, Pairs1, Weights0=None, Weights1=None, rng=None, trace=None):
+    """Match.py:162-218.  ``rng``: a ``np.random.RandomState`` standing for the reference's
+    global NumPy RNG (``np.random.seed(s)`` before the call == ``RandomState(s)`` here)."""
+    if rng is None:
+        rng = np.random.mtrand._rand
+    N = Pairs0.shape[0]
+    leastInliers = min(100, int(0.2 * N))
+    minSuccessInliers = 0.25 * N
+    minTrails, maxTrails = 100, 500
+    residualThreshold = 0.4
+    isSuccess = False
+    cntIters = 0
+    curNumInliers = 0
+    R_star = np.eye(3, dtype=np.float64)
+    T_star = np.zeros((3, 1), dtype=np.float64)
+    inlierIdx_star = np.zeros((N,), dtype=bool)
+    while True:
+        while (cntIters < minTrails) or (cntIters >= minTrails and cntIters < maxTrails
+                                         and curNumInliers < minSuccessInliers):
+            RandIdxes = draw_sample_indices(rng, N)
+            R, T, _ = SolveRT(Pairs0[RandIdxes, :], Pairs1[RandIdxes, :])
+            Pairs1_ = (np.dot(R, Pairs1.T) + T).T
+            dists = np.linalg.norm(Pairs0 - Pairs1_, axis=1)
+            inlierIdx = dists < residualThreshold
+            nInliers = int(inlierIdx.sum())
+            if trace is not None:
+                trace.append((RandIdxes.copy(), nInliers, float(residualThreshold)))
+            if nInliers < leastInliers:
+                cntIters += 1
+                continue
+            if nInliers > curNumInliers:
+                curNumInliers = nInliers
+                inlierIdx_star = inlierIdx
+                R_star, T_star = R, T
+            cntIters += 1
+            isSuccess = True
+        if isSuccess:
+            break
+        cntIters = 0
+        residualThreshold = 2 * residualThreshold
+        if residualThreshold > 2.0:
+            residualThreshold = residualThreshold / 2
+            break
+    return R_star, T_star, isSuccess, inlierIdx_star, residualThreshold
+
+
+def SolveRelativePose(OriPC0, OriCodes0, Weights0, OriPC1, OriCodes1, Weights1, rng=None,
+                      trace=None):
+    """Match.py:241-283."""
+    pairIdx, _ = match(OriCodes0, OriCodes1)
+    Pairs0 = OriPC0[pairIdx, :]
+    Pairs1 = OriPC1
+    idxPairs1 = np.arange(OriPC1.shape[0])
+    R, T, isSuccess, inlierIdx, thr = RANSAC4RT(Pairs0, Pairs1, None, None, rng=rng, trace=trace)
+    inliersIdx0 = pairIdx[inlierIdx]
+    inliersIdx1 = idxPairs1[inlierIdx]
+    if inliersIdx0.shape[0] == 0:
+        return R, T, isSuccess, inliersIdx0, inliersIdx1, thr
+    R, T, _ = SolveRT(OriPC0[inliersIdx0, :], OriPC1[inliersIdx1, :])
+    return R, T, isSuccess, inliersIdx0, inliersIdx1, thr

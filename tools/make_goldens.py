@@ -1,0 +1,225 @@
+#!/opt/conda/bin/python3.9
+"""Generate tests/golden/*.npz by IMPORTING THE REFERENCE (read-only, /root/reference).
+
+Run in the build container only:   PYTHONDONTWRITEBYTECODE=1 /opt/conda/bin/python3.9 tools/make_goldens.py
+
+Interpreter: the conda python3.9 (NumPy 1.26 = legacy type promotion like the reference's
+NumPy 1.18; SciPy 1.7; scikit-learn 0.24) -- NOT the default python3 (NumPy 2 changes
+Voxel.py:118-120).  Stubs: mayavi (plots), cupy -> NumPy shim with a stable
+argsort (Thrust's sort is stable), np.bool alias.  Keras/TensorFlow do not exist here: the two
+``model.predict`` calls are served by the oracle's restatement (PARITY UNPINNED for the CNN math,
+see oracle/caelo_oracle.c), everything else is the reference's own code.
+
+The script also asserts, stage by stage, that the oracle (oracle/oracle.py) reproduces what
+the reference computed -- this is the pin.  tests/test_oracle_golden.py re-checks the oracle
+against the stored fixtures without the reference.
+"""
+import contextlib
+import hashlib
+import io
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+
+if not hasattr(np, "bool"):
+    np.bool = bool  # Match.py:179,193
+for n in ("mayavi", "mayavi.mlab"):
+    sys.modules[n] = types.ModuleType(n)
+sys.modules["mayavi"].mlab = sys.modules["mayavi.mlab"]
+cp = types.ModuleType("cupy")  # every CuPy symbol used in SphericalRing.py:137-206
+for k in ("array", "zeros", "min", "sum", "squeeze", "int32", "float32"):
+    setattr(cp, k, getattr(np, k))
+cp.bool = bool
+cp.asnumpy = np.asarray
+cp.argsort = lambda a: np.argsort(a, kind="stable")
+sys.modules["cupy"] = cp
+mpl = types.ModuleType("matplotlib"); mpl.pyplot = types.ModuleType("matplotlib.pyplot")
+sys.modules.setdefault("matplotlib", mpl); sys.modules.setdefault("matplotlib.pyplot", mpl.pyplot)
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+sys.path.insert(0, os.path.join(REPO, "cae-lo_amd"))
+
+import warnings
+warnings.filterwarnings("ignore")
+import SphericalRing as RefSR  # noqa: E402
+import Voxel as RefVoxel       # noqa: E402
+import Match as RefMatch       # noqa: E402
+from scipy.spatial.distance import cdist  # noqa: E402
+
+import oracle as orc           # noqa: E402
+from caelo import synth        # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def quiet(fn, *a, **k):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        r = fn(*a, **k)
+    return r, buf.getvalue()
+
+
+resp_model, enc_model = orc.load_models(os.path.join(REPO, "weights", "SphericalRingPCRespondLayer.h5"),
+                                         os.path.join(REPO, "weights", "EncoderModel4VoxelPatch.h5"))
+
+
+def frame_golden(frame, n_beams=64, n_az=2000, n_patch_kp=None, tag=None):
+    t0 = time.time()
+    g = {}
+    pc = synth.make_scan(frame, n_beams=n_beams, n_az=n_az)
+    g["cloud_sha256"] = synth.cloud_sha256(pc)
+    g["n_points"] = pc.shape[0]
+    g["scan_params"] = np.array([frame, n_beams, n_az])
+    # -- projection (reference) vs oracle
+    ring, cnt = RefSR.ProjectPC2SphericalRing(pc)
+    o_ring, o_cnt = orc.ProjectPC2SphericalRing(pc)
+    assert np.array_equal(ring, o_ring) and np.array_equal(cnt, o_cnt), "oracle projection != reference"
+    g["ring_sha256"], g["counter_sha256"] = sha(ring), sha(cnt)
+    g["counter_nnz"] = int((cnt > 0).sum()); g["counter_max"] = int(cnt.max())
+    g["counter_bits"] = np.packbits(cnt > 0)
+    # -- response image: oracle restatement of the Keras layer (unpinned)
+    x = ring[0:64, 0:1792, :][:, :, [0, 1, 2]]
+    resp = np.squeeze(resp_model.predict(x.reshape(1, 64, 1792, 3)))
+    g["respond_sha256"] = sha(resp)
+    g["respond_sample"] = resp[20:24, 100:132, :].copy()
+    # -- keypoints (reference, both calling modes) vs oracle
+    (kp_d, kpix_d, _), _ = quiet(RefSR.GetKeyPtsByAE, ring, cnt, resp)
+    ring_b = np.ascontiguousarray(ring[0:64, 0:1792, :][:, :, [0, 1, 2]])
+    cnt_b = np.array(cnt[0:64, 0:1792], dtype=np.int8)  # BatchPreprocess.py:98
+    (kp_b, kpix_b, _), _ = quiet(RefSR.GetKeyPtsByAE, ring_b, cnt_b, resp)
+    o_kp, o_kpix, _ = orc.GetKeyPtsByAE(ring, cnt, resp)
+    assert np.array_equal(o_kpix, kpix_d) and np.array_equal(o_kp, kp_d), "oracle keypoints (demo) != reference"
+    o_kp2, o_kpix2, _ = orc.GetKeyPtsByAE(ring_b, cnt_b.astype(np.int32), resp)
+    assert np.array_equal(o_kpix2, kpix_b) and np.array_equal(o_kp2, kp_b), "oracle keypoints (batch) != reference"
+    g["keypixels_demo"] = kpix_d.astype(np.int16); g["keypixels_batch"] = kpix_b.astype(np.int16)
+    g["keypts_demo"] = kp_d.astype(np.float32)
+    print("  frame %s: K=%d/%d shared=%d  (%.1fs)" % (tag or frame, len(kpix_d), len(kpix_b),
+          len(set(map(tuple, kpix_d)) & set(map(tuple, kpix_b))), time.time() - t0))
+    # -- voxelization (reference) vs oracle
+    tv = time.time()
+    vout = RefVoxel.Voxelization(pc[:, 0:3])
+    A0, A1, A2 = vout[6], vout[7], vout[8]
+    o = orc.Voxelization(pc[:, 0:3])
+    for a, b, nm in ((A0, o[6], "AllVoxels0"), (A1, o[7], "AllVoxels1"), (A2, o[8], "AllVoxels2")):
+        assert a.dtype == np.int16 and np.array_equal(a, b), "oracle %s != reference" % nm
+    g["voxel_counts"] = np.array([len(A0), len(A1), len(A2)])
+    g["voxels0_sha256"], g["voxels1_sha256"], g["voxels2_sha256"] = sha(A0), sha(A1), sha(A2)
+    g["voxels2"] = A2  # small: keep one full list as a fixture
+    print("    voxels %s (%.1fs)" % (g["voxel_counts"], time.time() - tv))
+    # -- patches (reference) vs oracle
+    kp = kp_d if n_patch_kp is None else kp_d[-n_patch_kp:]
+    tp = time.time()
+    _, plist = RefVoxel.GetPatchesList(kp, A0, A1, A2)
+    bits = np.stack([orc.pack_patches(p) for p in plist], axis=1)  # [K,3,64]
+    o_bits, o_flags = [], []
+    for s, A in enumerate((A0, A1, A2)):
+        b, f = orc.patches_bits(kp, A, s)
+        o_bits.append(b); o_flags.append(f)
+    o_bits = np.stack(o_bits, 1); o_flags = np.stack(o_flags, 1)
+    diff = (o_bits != bits).any(axis=2)
+    amb = (o_flags & 2) != 0
+    assert not (diff & ~amb).any(), "oracle patches != reference on a non-ambiguous patch"
+    g["patch_bits"] = bits; g["patch_flags"] = o_flags
+    g["patch_kp"] = kp.astype(np.float32)
+    print("    patches: set voxels mean %s, truncated %s, ambiguous %s, ambiguous&differ %d (%.1fs)" % (
+        np.round(np.unpackbits(bits.view(np.uint8), axis=2).sum(axis=2).mean(axis=0), 1),
+        ((o_flags & 1) != 0).sum(axis=0), amb.sum(axis=0), int((diff & amb).sum()), time.time() - tp))
+    # -- descriptors: oracle restatement of the Keras encoder on the reference's patches
+    feats = RefMatch.GetFeaturesFromPatches(enc_model, plist)
+    g["features"] = feats.astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "frame_%s.npz" % (tag or frame)), **g)
+    return dict(pc=pc, kp=kp_d, feats=feats, A=(A0, A1, A2))
+
+
+def pair_golden(f0, f1, seeds=(0, 1, 2, 3)):
+    g = {}
+    kp0, F0, kp1, F1 = f0["kp"], f0["feats"], f1["kp"], f1["feats"]
+    W0 = np.ones((kp0.shape[0], 1), np.float32); W1 = np.ones((kp1.shape[0], 1), np.float32)
+    D = cdist(F0, F1, metric="euclidean")
+    pairIdx = np.argmin(D, axis=0)
+    o_idx, o_dist = orc.match(F0, F1)
+    assert np.array_equal(o_idx, pairIdx) and np.array_equal(o_dist, D.min(axis=0)), "oracle match != reference"
+    g["pair_idx"] = pairIdx.astype(np.int32)
+    part = np.partition(D, 1, axis=0)
+    g["match_margin_min"] = float(((part[1] - part[0]) / part[0]).min())
+    for s in seeds:
+        np.random.seed(s)
+        (R, T, ok, i0, i1, thr), log = quiet(RefMatch.SolveRelativePose, kp0, F0, W0, kp1, F1, W1)
+        iters = int(log.split("cntItersRANSAC =")[1].split()[0])
+        trace = []
+        oR, oT, ook, oi0, oi1, othr = orc.SolveRelativePose(kp0, F0, W0, kp1, F1, W1,
+                                                             rng=np.random.RandomState(s), trace=trace)
+        assert ook == ok and othr == thr and np.array_equal(oi0, i0) and np.array_equal(oi1, i1)
+        assert np.allclose(oR, R, atol=1e-6) and np.allclose(oT, T, atol=1e-5), "oracle pose != reference"
+        g["s%d_R" % s] = np.asarray(R, np.float64); g["s%d_T" % s] = np.asarray(T, np.float64)
+        g["s%d_ok" % s] = bool(ok); g["s%d_thr" % s] = float(thr); g["s%d_iters" % s] = iters
+        g["s%d_idx0" % s] = i0.astype(np.int32); g["s%d_idx1" % s] = i1.astype(np.int32)
+        g["s%d_trace_idx" % s] = np.array([t[0] for t in trace], np.int32)
+        g["s%d_trace_cnt" % s] = np.array([t[1] for t in trace], np.int32)
+        print("  pair seed %d: ok=%s thr=%.1f iters=%d inliers=%d T=%s" % (s, ok, thr, iters, len(i0), np.round(T.ravel(), 3)))
+    # hard cases: few correspondences -> escalation / failure (Match.py:207-214)
+    rs = np.random.RandomState(99)
+    P1 = rs.uniform(-30, 30, (300, 3)).astype(np.float32)
+    Rg, Tg = synth.relative_pose_gt(0, 1)
+    for name, frac, noise in (("esc", 0.8, 0.45), ("fail", 0.0, 0.0)):
+        P0 = (P1 @ Rg.T + Tg.T).astype(np.float32)
+        bad = rs.uniform(size=300) >= frac
+        P0[bad] = rs.uniform(-30, 30, (int(bad.sum()), 3)).astype(np.float32)
+        P0 += rs.normal(0, noise, P0.shape).astype(np.float32)
+        np.random.seed(7)
+        (R, T, ok, mask, thr), log = quiet(RefMatch.RANSAC4RT, P0, P1, None, None)
+        oR, oT, ook, omask, othr = orc.RANSAC4RT(P0, P1, rng=np.random.RandomState(7))
+        assert ook == ok and othr == thr and np.array_equal(omask, mask)
+        g[name + "_P0"] = P0; g[name + "_P1"] = P1; g[name + "_ok"] = bool(ok); g[name + "_thr"] = float(thr)
+        g[name + "_mask"] = np.asarray(mask, bool); g[name + "_R"] = np.asarray(R, np.float64); g[name + "_T"] = np.asarray(T, np.float64)
+        print("  ransac %s: ok=%s thr=%.1f inliers=%d" % (name, ok, thr, int(np.sum(mask))))
+    np.savez_compressed(os.path.join(GOLD, "pair_0_1.npz"), **g)
+
+
+def trunc_golden():
+    """Crafted dense voxel clouds: force the 496-NN cap of Voxel.py:182,195-196 to bite."""
+    g = {}
+    rs = np.random.RandomState(5)
+    c = np.array([600, 640, 90])
+    for name, p in (("sparse", 0.04), ("mid", 0.12), ("dense", 0.45)):
+        occ = rs.uniform(size=(40, 40, 40)) < p
+        vox = (np.argwhere(occ) + (c - 20)).astype(np.int16)
+        vox = vox[rs.permutation(len(vox))]
+        kv = c + rs.randint(-5, 6, size=(48, 3))
+        pts = (kv * 0.16 - orc.VIS + rs.uniform(0.01, 0.15, size=(48, 3))).astype(np.float32)
+        _, plist = RefVoxel.GetPatchesList(pts, vox, vox, vox)
+        bits = orc.pack_patches(plist[1])
+        ob, of = orc.patches_bits(pts, vox, 1)
+        diff = (ob != bits).any(axis=1); amb = (of & 2) != 0
+        assert not (diff & ~amb).any(), "oracle truncated patches != reference (non-ambiguous)"
+        # on ambiguous patches the two may only differ inside the cut class
+        print("  trunc %-6s: nvox=%d truncated=%d ambiguous=%d differ=%d setbits ref/oracle=%d/%d" % (
+            name, len(vox), int(((of & 1) != 0).sum()), int(amb.sum()), int(diff.sum()),
+            int(np.unpackbits(bits.view(np.uint8)).sum()), int(np.unpackbits(ob.view(np.uint8)).sum())))
+        g[name + "_vox"] = vox; g[name + "_pts"] = pts; g[name + "_bits"] = bits; g[name + "_flags"] = of
+    np.savez_compressed(os.path.join(GOLD, "patch_truncation.npz"), **g)
+
+
+if __name__ == "__main__":
+    t0 = time.time()
+    trunc_golden()
+    f0 = frame_golden(0)
+    f1 = frame_golden(1)
+    pair_golden(f0, f1)
+    # dense 128-beam scan: exercises the 496-NN truncation of GetPatchesList
+    frame_golden(0, n_beams=128, n_az=4000, n_patch_kp=192, tag="dense128")
+    print("done in %.1fs" % (time.time() - t0))
+    for f in sorted(os.listdir(GOLD)):
+        print("  %-24s %8.1f KB" % (f, os.path.getsize(os.path.join(GOLD, f)) / 1024))
