@@ -1,0 +1,76 @@
+"""ctypes binding of libcaelo.so (include/caelo.h).  The only place the C ABI is touched.
+
+There is deliberately no fallback: if the shared library is missing or no HIP device exists the
+import / context creation fails loudly (the oracle under oracle/ is test infrastructure and is
+never reachable from here).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcaelo.so")
+
+c_vp, c_i64, c_i32, c_int = C.c_void_p, C.c_int64, C.c_int32, C.c_int
+
+
+class CaeloError(RuntimeError):
+    pass
+
+
+class PoseResult(C.Structure):
+    _fields_ = [("R", C.c_float * 9), ("T", C.c_float * 3), ("R_ransac", C.c_float * 9),
+                ("T_ransac", C.c_float * 3), ("threshold", C.c_float), ("success", c_i32),
+                ("iterations", c_i32), ("n_inliers", c_i32), ("best_trial", c_i32), ("n_pairs", c_i32)]
+
+
+# (name, restype, argtypes) -- must list every symbol include/caelo.h declares
+SIGNATURES = [
+    ("caelo_abi_version", c_int, []),
+    ("caelo_last_error", C.c_char_p, []),
+    ("caelo_create", c_int, [C.POINTER(c_vp), c_int]),
+    ("caelo_destroy", None, [c_vp]),
+    ("caelo_set_respond_weights", c_int, [c_vp] + [c_vp] * 4),
+    ("caelo_set_encoder_weights", c_int, [c_vp] + [c_vp] * 10),
+    ("caelo_project", c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    ("caelo_respond", c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    ("caelo_keypoints", c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    ("caelo_voxmap_create", c_int, [c_vp, c_i64, C.POINTER(c_vp)]),
+    ("caelo_voxmap_destroy", None, [c_vp]),
+    ("caelo_voxelize", c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
+    ("caelo_voxmap_export", c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    ("caelo_voxmap_from_lists", c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    ("caelo_patches", c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    ("caelo_unpack_patches", c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    ("caelo_pack_patches", c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    ("caelo_encode_ws_bytes", c_i64, [c_i64]),
+    ("caelo_encode", c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp]),
+    ("caelo_match", c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_vp]),
+    ("caelo_solve_rt", c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    ("caelo_ransac_ws_bytes", c_i64, []),
+    ("caelo_ransac", c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+]
+
+_lib = None
+
+
+def load():
+    """dlopen libcaelo.so and type every entry point.  Raises if the library was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CaeloError("libcaelo.so not built (%s); run `python __graft_entry__.py` or "
+                             "`make -C cae-lo_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, res, args in SIGNATURES:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.caelo_abi_version() != 1:
+            raise CaeloError("libcaelo.so ABI mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise CaeloError("libcaelo error %d: %s" % (rc, load().caelo_last_error().decode()))

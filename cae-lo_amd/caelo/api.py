@@ -1,0 +1,206 @@
+"""Drop-in call surface: the reference's hot-path functions, same names / argument order / return
+tuples / dtypes, served by the HIP engine.
+
+    reference                                   here
+    SphericalRing.ProjectPC2SphericalRing :72   ProjectPC2SphericalRing(PC)
+    SphericalRing.GetKeyPtsByAE           :113  GetKeyPtsByAE(SphericalRing, GridCounter, RespondImg)
+    SphericalRing.GetKeyPtsFromRawFileName:389  GetKeyPtsFromRawFileName(rawFileFullPath, RespondLayer)
+    Voxel.Voxelization                    :100  Voxelization(PC)
+    Voxel.GetPatchesList                  :177  GetPatchesList(Pts, AllVoxels0, AllVoxels1, AllVoxels2)
+    Match.GetFeaturesFromPatches          :130  GetFeaturesFromPatches(PatchEncoder, PatchesList)
+    Match.SolveRT / RANSAC4RT             :138/:162
+    Match.SolveRelativePose               :241  SolveRelativePose(PC0, F0, W0, PC1, F1, W1)
+    keras.models.load_model (Match.py:313,324)  load_model(h5_path) -> object with .predict
+
+Arguments may be NumPy arrays (results come back as NumPy, like the reference) or torch tensors on
+the GPU (results stay on the GPU).  Every array-level function runs on the GPU; there is no CPU
+path.  Errors follow the reference: AssertionError / IndexError / ValueError for the conditions
+listed in SURVEY 8b, RANSAC failure as a return value.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import engine as _eng
+from .engine import default_engine, raise_status
+
+nLines, ImgW, ImgH, CropWidth_SphericalRing = 64, 1800, 69, 8
+Channels4AE = [0, 1, 2]
+
+
+def _is_np(x):
+    return isinstance(x, np.ndarray)
+
+
+def _dev(x, dtype):
+    e = default_engine()
+    if isinstance(x, torch.Tensor):
+        return x.to(device=e.device, dtype=dtype).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(x, dtype={torch.float32: np.float32, torch.int32: np.int32,
+                                                            torch.int16: np.int16, torch.int64: np.int64,
+                                                            torch.float64: np.float64}[dtype])).to(e.device)
+
+
+def _out(t, as_np):
+    return t.cpu().numpy() if as_np else t
+
+
+# ---------------------------------------------------------------------------------------------
+def ProjectPC2SphericalRing(PC):
+    """SphericalRing.py:72-94 -> (Image_float [69,1800,5] f32, GridCounter [69,1800] i32)."""
+    assert PC.shape[0] > 3 and PC.shape[1] == 4
+    e = default_engine()
+    ring, cnt, st = e.project(_dev(PC, torch.float32))
+    raise_status(int(st.item()))
+    return _out(ring, _is_np(PC)), _out(cnt, _is_np(PC))
+
+
+class _Model:
+    """What ``load_model`` returns: only ``.predict(ndarray) -> ndarray`` is part of the contract
+    (SphericalRing.py:407, Match.py:131)."""
+
+    def __init__(self, kind, path):
+        self.kind, self.path = kind, path
+
+    def predict(self, x):
+        e = default_engine()
+        as_np = _is_np(x)
+        xd = _dev(x, torch.float32)
+        if self.kind == "respond":
+            assert xd.dim() == 4 and tuple(xd.shape[1:]) == (64, 1792, 3), "expected [B,64,1792,3]"
+            out = torch.stack([e.respond(xd[b]) for b in range(xd.shape[0])])
+        else:
+            assert xd.dim() == 5 and tuple(xd.shape[1:]) == (16, 16, 16, 1), "expected [K,16,16,16,1]"
+            out = e.encode(e.pack_patches(xd), group=1)
+        return _out(out, as_np)
+
+
+def load_model(path):
+    """Replacement for keras.models.load_model on the two shipped .h5 files (Dirs.py:29-30)."""
+    kind = default_engine().load_weights(path)
+    return _Model(kind, path)
+
+
+def GetKeyPtsByAE(SphericalRing, GridCounter, RespondImg):
+    """SphericalRing.py:113-291 -> (KeyPts [K,3] f32, KeyPixels [K,2] i64, PlanarPts [0] f32).
+    A 5-channel ring = demo mode (:414); a cropped 3-channel ring = batch mode
+    (BatchPreprocess.py:97-98,131-136)."""
+    e = default_engine()
+    as_np = _is_np(SphericalRing)
+    ring = _dev(SphericalRing, torch.float32)
+    cnt = _dev(np.asarray(GridCounter, dtype=np.int32) if _is_np(GridCounter) else GridCounter, torch.int32)
+    resp = _dev(RespondImg, torch.float32)
+    kpts, kpix, nkey, st = e.keypoints(ring, cnt, resp)
+    k = int(nkey.item())
+    raise_status(int(st.item()))
+    planar = np.array([], dtype=np.float32) if as_np else torch.empty(0, dtype=torch.float32, device=e.device)
+    return _out(kpts[:k], as_np), _out(kpix[:k], as_np), planar
+
+
+def GetKeyPtsFromRawFileName(rawFileFullPath, RespondLayer):
+    """SphericalRing.py:389-416: reads <seq>/SphericalRing/<name>.mat written by BatchPreprocess."""
+    from scipy import io
+    baseDir = os.path.dirname(os.path.dirname(rawFileFullPath))
+    mat = io.loadmat(os.path.join(baseDir, "SphericalRing", os.path.basename(rawFileFullPath) + ".mat"))
+    SphericalRing, GridCounter = mat["SphericalRing"], mat["GridCounter"]
+    x = SphericalRing[0:nLines, 0:ImgW - CropWidth_SphericalRing, :][:, :, Channels4AE]
+    RespondImg = np.squeeze(RespondLayer.predict(np.ascontiguousarray(x).reshape((1,) + x.shape)))
+    return GetKeyPtsByAE(SphericalRing, GridCounter, RespondImg)
+
+
+def Voxelization(PC):
+    """Voxel.py:100-173.  Returns the reference's 9-tuple; AllVoxels0/1/2 (indices 6,7,8) are exact
+    (values and order), the Python block structures at 0..5 -- consumed only by code outside the hot
+    path -- are None."""
+    e = default_engine()
+    as_np = _is_np(PC)
+    pc = _dev(PC, torch.float32)
+    vmap, st = e.voxelize(pc)
+    raise_status(int(st.item()) & ~_eng.ST_FEW_VOXELS)  # the reference only complains later, in GetPatchesList
+    a0, a1, a2 = e.voxmap_export(vmap, pc.shape[0])
+    return (None, None, None, None, None, None, _out(a0, as_np), _out(a1, as_np), _out(a2, as_np))
+
+
+def GetPatchesBits(Pts, AllVoxels0, AllVoxels1, AllVoxels2):
+    """GetPatchesList without the dense expansion: (bits [K,3,64] int64, flags [K,3] uint8) on device."""
+    e = default_engine()
+    vmap, st = e.voxmap_from_lists(_dev(AllVoxels0, torch.int16), _dev(AllVoxels1, torch.int16),
+                                   _dev(AllVoxels2, torch.int16))
+    bits, flags = e.patches(vmap, _dev(Pts, torch.float32), None, st)
+    raise_status(int(st.item()))
+    return bits, flags
+
+
+def GetPatchesList(Pts, AllVoxels0, AllVoxels1, AllVoxels2):
+    """Voxel.py:177-216 -> (Pts, [P0, P1, P2]) with P_s [K,16,16,16,1] f32 in {0,1}."""
+    e = default_engine()
+    as_np = _is_np(Pts)
+    bits, _ = GetPatchesBits(Pts, AllVoxels0, AllVoxels1, AllVoxels2)
+    out = [_out(e.unpack_patches(bits[:, s, :].contiguous()), as_np) for s in range(3)]
+    return Pts, out
+
+
+def GetFeaturesFromPatches(PatchEncoder, PatchesList):
+    """Match.py:130-135."""
+    f = [PatchEncoder.predict(p) for p in PatchesList]
+    return np.c_[f[0], f[1], f[2]] if _is_np(f[0]) else torch.cat(f, dim=1)
+
+
+def SolveRT(Pairs0, Pairs1):
+    """Match.py:138-158 -> (R [3,3], T [3,1], isCredible)."""
+    e = default_engine()
+    as_np = _is_np(Pairs0)
+    R, T, cred = e.solve_rt(_dev(Pairs0, torch.float32), _dev(Pairs1, torch.float32))
+    return _out(R, as_np), _out(T, as_np), int(cred.item())
+
+
+def _ransac(pc0, pc1, pair_idx, rng):
+    """Shared by RANSAC4RT / SolveRelativePose.  ``rng``: RandomState or None (NumPy's global RNG,
+    like the reference).  The stream is advanced by exactly the draws the reference's loop would
+    have consumed (4 per iteration), whatever was pre-drawn for the GPU."""
+    e = default_engine()
+    rs = np.random.mtrand._rand if rng is None else rng
+    state = rs.get_state()
+    draws = rs.random_sample(6000)
+    res, mask = e.ransac(pc0, pc1, pair_idx, torch.from_numpy(draws).to(e.device))
+    r = e.pose_result(res)
+    used = 4 * (r.best_trial // 500 * 500 + r.iterations if r.success else 1500)
+    rs.set_state(state)
+    rs.random_sample(used)
+    return r, mask
+
+
+def RANSAC4RT(Pairs0, Pairs1, Weights0=None, Weights1=None, rng=None):
+    """Match.py:162-218 -> (R, T, isSuccess, inlierIdx bool[N], residualThreshold)."""
+    e = default_engine()
+    as_np = _is_np(Pairs0)
+    p0, p1 = _dev(Pairs0, torch.float32), _dev(Pairs1, torch.float32)
+    idx = torch.arange(p1.shape[0], device=e.device, dtype=torch.int64)
+    r, mask = _ransac(p0, p1, idx, rng)
+    R = np.array(r.R_ransac, dtype=np.float32).reshape(3, 3)
+    T = np.array(r.T_ransac, dtype=np.float32).reshape(3, 1)
+    m = mask.bool()
+    thr = {0: 0.4, 1: 0.8, 2: 1.6}[int(round(np.log2(r.threshold / 0.4)))]
+    if as_np:
+        return R, T, bool(r.success), m.cpu().numpy(), thr
+    return torch.from_numpy(R).to(e.device), torch.from_numpy(T).to(e.device), bool(r.success), m, thr
+
+
+def SolveRelativePose(OriPC0, OriCodes0, Weights0, OriPC1, OriCodes1, Weights1, rng=None):
+    """Match.py:241-283 -> (R, T, isSuccess, inliersIdx0, inliersIdx1, residualThreshold)."""
+    e = default_engine()
+    as_np = _is_np(OriPC0)
+    pc0, pc1 = _dev(OriPC0, torch.float32), _dev(OriPC1, torch.float32)
+    f0, f1 = _dev(OriCodes0, torch.float32), _dev(OriCodes1, torch.float32)
+    pair_idx = e.match(f0, f1)
+    r, mask = _ransac(pc0, pc1, pair_idx, rng)
+    m = mask.bool()
+    i1 = torch.nonzero(m).flatten()
+    i0 = pair_idx[i1]
+    thr = {0: 0.4, 1: 0.8, 2: 1.6}[int(round(np.log2(r.threshold / 0.4)))]
+    R = np.array(r.R, dtype=np.float32).reshape(3, 3)
+    T = np.array(r.T, dtype=np.float32).reshape(3, 1)
+    if as_np:
+        return R, T, bool(r.success), i0.cpu().numpy(), i1.cpu().numpy(), thr
+    return torch.from_numpy(R).to(e.device), torch.from_numpy(T).to(e.device), bool(r.success), i0, i1, thr

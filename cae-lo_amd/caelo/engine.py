@@ -1,0 +1,318 @@
+"""Device engine: one HIP context + weights + reusable buffers per process (one process per GPU).
+
+``Engine`` owns the libcaelo context, loads the two Keras ``.h5`` files through ``h5lite`` and
+exposes (a) stage methods on device tensors, one per C-ABI entry point, and (b) the fused hot
+path ``extract`` (scan -> keypoints + 60-d descriptors) and ``match_pose`` (two frames -> rigid
+pose) that run without any host synchronisation until the caller reads a result.
+
+PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .h5lite import H5File
+
+RING_H, RING_W, RING_C = 69, 1800, 5
+NET_H, NET_W = 64, 1792
+MAX_K = 1024
+
+ST_COL_OOB, ST_VOXEL_OOB, ST_MAP_FULL, ST_FEW_VOXELS, ST_FEW_KEYPTS = 1, 2, 4, 8, 16
+
+_DEFAULT_WEIGHTS = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "weights")
+RESPOND_H5 = os.path.join(_DEFAULT_WEIGHTS, "SphericalRingPCRespondLayer.h5")
+ENCODER_H5 = os.path.join(_DEFAULT_WEIGHTS, "EncoderModel4VoxelPatch.h5")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _hptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def raise_status(st):
+    """Map device status bits to the exception the reference would raise (SURVEY 8b 'Errors')."""
+    if st & ST_COL_OOB:
+        raise IndexError("index 1800 is out of bounds for axis 1 with size 1800")  # SphericalRing.py:91
+    if st & ST_VOXEL_OOB:
+        raise IndexError("voxel index out of bounds for axis with size 64")        # Voxel.py:139
+    if st & ST_FEW_VOXELS:
+        raise ValueError("Expected n_neighbors <= n_samples (n_neighbors = 496)")  # Voxel.py:195-196
+    if st & ST_FEW_KEYPTS:
+        raise AssertionError("KeyPts.shape[0] > 50")                               # SphericalRing.py:286
+    if st & ST_MAP_FULL:
+        raise _ffi.CaeloError("voxel map overflow")
+
+
+def read_keras_weights(path):
+    """-> ("respond", [w1,b1,w2,b2]) or ("encoder", [10 arrays]) from a Keras 2.2 .h5 file."""
+    import json
+    h = H5File(path)
+    cfg = json.loads(h.attrs("/")["model_config"].decode("utf8"))
+    classes = [l["class_name"] for l in cfg["config"]["layers"]]
+    names = [n.decode() for n in h.attrs("/model_weights")["layer_names"]]
+    ws = []
+    for ln in names:
+        for wn in h.attrs("/model_weights/" + ln).get("weight_names", []):
+            ws.append(np.ascontiguousarray(h.dataset("/model_weights/%s/%s" % (ln, wn.decode())), np.float32))
+    if "Conv2D" in classes and [w.size for w in ws] == [864, 32, 256, 8]:
+        return "respond", ws
+    if "Conv3D" in classes and [w.size for w in ws] == [216, 8, 3456, 16, 13824, 32, 409600, 200, 4000, 20]:
+        acts = [l["config"].get("activation") for l in cfg["config"]["layers"] if "activation" in l["config"]]
+        if acts != ["tanh"] * 5:
+            raise ValueError("unexpected encoder activations %s (the shipped model is all-tanh)" % acts)
+        return "encoder", ws
+    raise ValueError("%s: not one of the two CAE-LO inference models" % path)
+
+
+class VoxelMap:
+    def __init__(self, eng, max_points):
+        self.eng, self.max_points = eng, int(max_points)
+        h = C.c_void_p()
+        _ffi.check(eng.lib.caelo_voxmap_create(eng.ctx, self.max_points, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.eng.lib.caelo_voxmap_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class FrameFeatures:
+    """Device-resident result of Engine.extract for one scan."""
+    __slots__ = ("key_pts", "key_pixels", "features", "n_key", "status", "flags")
+
+    def __init__(self, key_pts, key_pixels, features, n_key, status, flags):
+        self.key_pts, self.key_pixels, self.features = key_pts, key_pixels, features
+        self.n_key, self.status, self.flags = n_key, status, flags
+
+
+class Engine:
+    def __init__(self, respond_h5=RESPOND_H5, encoder_h5=ENCODER_H5, device=None, max_points=1 << 18):
+        if not torch.cuda.is_available():
+            raise _ffi.CaeloError("no HIP device visible: libcaelo has no CPU fallback")
+        self.lib = _ffi.load()
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        torch.cuda.set_device(self.device)
+        ctx = C.c_void_p()
+        _ffi.check(self.lib.caelo_create(C.byref(ctx), self.device_index))
+        self.ctx = ctx
+        self.max_points = int(max_points)
+        self._maps = {}
+        self._enc_ws = None
+        self._ransac_ws = torch.empty(int(self.lib.caelo_ransac_ws_bytes()), dtype=torch.uint8, device=self.device)
+        if respond_h5:
+            self.load_weights(respond_h5)
+        if encoder_h5:
+            self.load_weights(encoder_h5)
+
+    def __del__(self):
+        try:
+            self._maps.clear()
+            if self.ctx:
+                self.lib.caelo_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # ---- plumbing ----------------------------------------------------------------------------
+    @property
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def load_weights(self, path):
+        kind, ws = read_keras_weights(path)
+        if kind == "respond":
+            _ffi.check(self.lib.caelo_set_respond_weights(self.ctx, *[_hptr(w) for w in ws]))
+        else:
+            _ffi.check(self.lib.caelo_set_encoder_weights(self.ctx, *[_hptr(w) for w in ws]))
+        return kind
+
+    def voxmap(self, max_points=None, slot=0):
+        n = self.max_points if max_points is None else int(max_points)
+        key = (slot, n)
+        if key not in self._maps:
+            self._maps[key] = VoxelMap(self, n)
+        return self._maps[key]
+
+    def _encode_ws(self, n_patches):
+        need = int(self.lib.caelo_encode_ws_bytes(int(n_patches)))
+        if self._enc_ws is None or self._enc_ws.numel() < need:
+            self._enc_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._enc_ws
+
+    # ---- stages (device tensors in, device tensors out, no sync) ---------------------------------
+    def project(self, pc, status=None):
+        assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] == 4 and pc.is_contiguous()
+        ring = self.empty((RING_H, RING_W, RING_C), torch.float32)
+        counter = self.empty((RING_H, RING_W), torch.int32)
+        winner = self.empty((RING_H * RING_W,), torch.int32)
+        status = self.zeros((1,), torch.int32) if status is None else status
+        _ffi.check(self.lib.caelo_project(self.ctx, _ptr(pc), pc.shape[0], _ptr(ring), _ptr(counter), _ptr(winner),
+                                          _ptr(status), self.stream))
+        return ring, counter, status
+
+    def respond(self, img):
+        """img [rows>=64, w>=1792, c>=3] f32 -> [64,1792,8]."""
+        assert img.dtype == torch.float32 and img.dim() == 3 and img.is_contiguous()
+        resp = self.empty((NET_H, NET_W, 8), torch.float32)
+        _ffi.check(self.lib.caelo_respond(self.ctx, _ptr(img), img.shape[1], img.shape[2], _ptr(resp), self.stream))
+        return resp
+
+    def keypoints(self, ring, counter, resp, status=None):
+        assert ring.dtype == torch.float32 and counter.dtype == torch.int32 and resp.dtype == torch.float32
+        assert ring.is_contiguous() and counter.is_contiguous() and resp.is_contiguous()
+        cand = self.empty((NET_H * NET_W,), torch.int64)
+        kpix = self.zeros((MAX_K, 2), torch.int64)
+        kpts = self.zeros((MAX_K, 3), torch.float32)
+        nkey = self.empty((1,), torch.int32)
+        status = self.zeros((1,), torch.int32) if status is None else status
+        _ffi.check(self.lib.caelo_keypoints(self.ctx, _ptr(ring), ring.shape[1], ring.shape[2], _ptr(counter),
+                                            counter.shape[1], _ptr(resp), _ptr(cand), _ptr(kpix), _ptr(kpts),
+                                            _ptr(nkey), _ptr(status), self.stream))
+        return kpts, kpix, nkey, status
+
+    def voxelize(self, pc, vmap=None, status=None):
+        assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] >= 3 and pc.is_contiguous()
+        vmap = vmap or self.voxmap(max(self.max_points, pc.shape[0]))
+        status = self.zeros((1,), torch.int32) if status is None else status
+        _ffi.check(self.lib.caelo_voxelize(self.ctx, vmap.h, _ptr(pc), pc.shape[0], pc.shape[1], _ptr(status), self.stream))
+        return vmap, status
+
+    def voxmap_export(self, vmap, capacity):
+        outs = [self.empty((capacity, 3), torch.int16) for _ in range(3)]
+        counts = self.empty((3,), torch.int64)
+        _ffi.check(self.lib.caelo_voxmap_export(self.ctx, vmap.h, _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]),
+                                                capacity, _ptr(counts), self.stream))
+        n = counts.cpu().tolist()
+        return [o[:k] for o, k in zip(outs, n)]
+
+    def voxmap_from_lists(self, a0, a1, a2, vmap=None, status=None):
+        for a in (a0, a1, a2):
+            assert a.dtype == torch.int16 and a.dim() == 2 and a.shape[1] == 3 and a.is_contiguous()
+        vmap = vmap or self.voxmap(max(self.max_points, a0.shape[0], a1.shape[0], a2.shape[0]), slot=1)
+        status = self.zeros((1,), torch.int32) if status is None else status
+        _ffi.check(self.lib.caelo_voxmap_from_lists(self.ctx, vmap.h, _ptr(a0), a0.shape[0], _ptr(a1), a1.shape[0],
+                                                    _ptr(a2), a2.shape[0], _ptr(status), self.stream))
+        return vmap, status
+
+    def patches(self, vmap, pts, n_key=None, status=None):
+        """-> bits [K,3,64] int64 (bit-packed 16^3 patches), flags [K,3] uint8."""
+        assert pts.dtype == torch.float32 and pts.dim() == 2 and pts.shape[1] == 3 and pts.is_contiguous()
+        k = pts.shape[0]
+        bits = self.empty((k, 3, 64), torch.int64)
+        flags = self.empty((k, 3), torch.uint8)
+        status = self.zeros((1,), torch.int32) if status is None else status
+        _ffi.check(self.lib.caelo_patches(self.ctx, vmap.h, _ptr(pts), k, _ptr(n_key), _ptr(bits), _ptr(flags),
+                                          _ptr(status), self.stream))
+        return bits, flags
+
+    def unpack_patches(self, bits):
+        n = bits.numel() // 64
+        dense = self.empty((n, 16, 16, 16, 1), torch.float32)
+        _ffi.check(self.lib.caelo_unpack_patches(self.ctx, _ptr(bits), n, _ptr(dense), self.stream))
+        return dense
+
+    def pack_patches(self, dense):
+        assert dense.dtype == torch.float32 and dense.is_contiguous()
+        n = dense.numel() // 4096
+        bits = self.empty((n, 64), torch.int64)
+        _ffi.check(self.lib.caelo_pack_patches(self.ctx, _ptr(dense), n, _ptr(bits), self.stream))
+        return bits
+
+    def encode(self, bits, group=1):
+        """bits [..., 64] int64 -> features [n/group, 20*group] f32."""
+        assert bits.dtype == torch.int64 and bits.is_contiguous()
+        n = bits.numel() // 64
+        assert n % group == 0
+        out = self.empty((n // group, 20 * group), torch.float32)
+        ws = self._encode_ws(n)
+        _ffi.check(self.lib.caelo_encode(self.ctx, _ptr(bits), n, group, _ptr(out), 20 * group, _ptr(ws), self.stream))
+        return out
+
+    def match(self, f0, f1, n0=None, n1=None):
+        assert f0.dtype == torch.float32 and f1.dtype == torch.float32 and f0.is_contiguous() and f1.is_contiguous()
+        idx = self.zeros((f1.shape[0],), torch.int64)
+        _ffi.check(self.lib.caelo_match(self.ctx, _ptr(f0), f0.shape[0], _ptr(n0), _ptr(f1), f1.shape[0], _ptr(n1),
+                                        f0.shape[1], _ptr(idx), self.stream))
+        return idx
+
+    def solve_rt(self, p0, p1):
+        assert p0.shape == p1.shape and p0.dtype == torch.float32 and p0.is_contiguous() and p1.is_contiguous()
+        R = self.empty((3, 3), torch.float32)
+        T = self.empty((3, 1), torch.float32)
+        cred = self.empty((1,), torch.int32)
+        _ffi.check(self.lib.caelo_solve_rt(self.ctx, _ptr(p0), _ptr(p1), p0.shape[0], _ptr(R), _ptr(T), _ptr(cred), self.stream))
+        return R, T, cred
+
+    def ransac(self, pc0, pc1, pair_idx, rand, n1=None):
+        """rand: [1500,4] f64 uniform draws (device).  -> (result bytes tensor, mask [k1] uint8)."""
+        assert pc0.dtype == torch.float32 and pc1.dtype == torch.float32 and pair_idx.dtype == torch.int64
+        assert rand.dtype == torch.float64 and rand.numel() >= 6000 and rand.is_contiguous()
+        res = self.zeros((C.sizeof(_ffi.PoseResult),), torch.uint8)
+        mask = self.empty((pc1.shape[0],), torch.uint8)
+        _ffi.check(self.lib.caelo_ransac(self.ctx, _ptr(pc0), _ptr(pc1), _ptr(pair_idx), pc1.shape[0], _ptr(n1),
+                                         _ptr(rand), _ptr(res), _ptr(mask), _ptr(self._ransac_ws), self.stream))
+        return res, mask
+
+    @staticmethod
+    def pose_result(res):
+        """Synchronising read of a caelo_pose_result."""
+        return _ffi.PoseResult.from_buffer_copy(res.cpu().numpy().tobytes())
+
+    # ---- fused hot path ------------------------------------------------------------------------------
+    def extract(self, pc, dist_channels=5, vmap=None):
+        """scan [N,4] f32 (device) -> FrameFeatures, all on device, no host sync.
+        project -> response CNN -> keypoints -> voxelize -> patch gather -> 3x encoder.
+        dist_channels: 5 = demo calling mode (SphericalRing.py:414), 3 = batch mode
+        (BatchPreprocess.py:97-98,131-136)."""
+        status = self.zeros((1,), torch.int32)
+        ring, counter, _ = self.project(pc, status)
+        resp = self.respond(ring)
+        if dist_channels == 5:
+            kpts, kpix, nkey, _ = self.keypoints(ring, counter, resp, status)
+        else:
+            ring3 = ring[0:NET_H, 0:NET_W, 0:3].contiguous()
+            cnt3 = counter[0:NET_H, 0:NET_W].contiguous()
+            kpts, kpix, nkey, _ = self.keypoints(ring3, cnt3, resp, status)
+        vmap, _ = self.voxelize(pc, vmap, status)
+        bits, flags = self.patches(vmap, kpts, nkey, status)
+        feats = self.encode(bits, group=3)
+        return FrameFeatures(kpts, kpix, feats, nkey, status, flags)
+
+    def match_pose(self, fa, fb, rand):
+        """Relative pose between two FrameFeatures (frame0 = fa, frame1 = fb), Match.py:241-283."""
+        idx = self.match(fa.features, fb.features, fa.n_key, fb.n_key)
+        res, mask = self.ransac(fa.key_pts, fb.key_pts, idx, rand, fb.n_key)
+        return res, mask, idx
+
+
+_default = None
+
+
+def default_engine():
+    global _default
+    if _default is None:
+        _default = Engine()
+    return _default
+
+
+def ransac_draws(seed_or_rng, n=6000):
+    """The uniform doubles RANSAC4RT would pull from NumPy's Mersenne Twister (Match.py:182)."""
+    rng = seed_or_rng if hasattr(seed_or_rng, "random_sample") else np.random.RandomState(seed_or_rng)
+    return rng.random_sample(n)

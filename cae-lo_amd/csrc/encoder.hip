@@ -1,0 +1,421 @@
+// encoder.hip -- 3D-CAE voxel-patch descriptor encoder on f32 MFMA (gfx950).
+//
+// Reference behaviour restated here (never its code): PatchEncoder.predict via
+// GetFeaturesFromPatches (Match.py:130-135) with the shipped EncoderModel4VoxelPatch.h5:
+//   Conv3D(1->8,3^3,same) tanh -> MaxPool3D(2) -> Conv3D(8->16) tanh -> MaxPool3D(2)
+//   -> Conv3D(16->32) tanh -> Flatten(x,y,z,c) -> Dense(200) tanh -> Dense(20) tanh
+// (Keras channels-last, zero 'same' padding, cross-correlation; the stale relu/linear script
+// AE4VoxelPatch.py:177-197 is NOT what ships).  7.905 MFLOP per patch, 24.28 GFLOP
+// per 3072-patch frame: MFMA-bound (157 TFLOP/s f32 matrix peak).
+//
+// Kernels
+//   k_enc_stage1  one workgroup per patch: bit-packed patch -> conv1+pool1 evaluated only where the
+//                 4^3 receptive field holds a set voxel (binary input: a sum of weight rows) ->
+//                 P1 in LDS (two 4-channel planes, halo) -> conv2 as implicit GEMM on
+//                 v_mfma_f32_16x16x4_f32, all 54 B-fragments of W2 resident in VGPRs -> pool2 in
+//                 registers (tanh(max) == max(tanh)) -> P2 [patch][4][4][4][16] to HBM (4 KB).
+//   k_enc_conv3   conv3 implicit GEMM, 2 patches per workgroup, W3 n-tile resident in 108 VGPRs,
+//                 A fragments by conflict-free ds_read_b128 from four 4-channel LDS planes.
+//   k_enc_dense1  split-K GEMM [patches,2048]x[2048,208] through LDS tiles.
+//   k_enc_head    split-K reduce + bias + tanh + Dense(20) + tanh, scatter into Features rows.
+#include "caelo_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------
+#define DENSE_N 200
+#define DENSE_NP 208  // padded to 13 MFMA n-tiles
+#define DENSE_K 2048
+
+CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const float *b1, const float *w2,
+                                        const float *b2, const float *w3, const float *b3, const float *wd1,
+                                        const float *bd1, const float *wd2, const float *bd2) {
+    CAELO_REQUIRE(c && w1 && b1 && w2 && b2 && w3 && b3 && wd1 && bd1 && wd2 && bd2, "null argument");
+    struct { float **dst; const float *src; size_t n; } plain[] = {
+        {&c->enc_w1, w1, 27 * 8}, {&c->enc_b1, b1, 8},   {&c->enc_w2, w2, 27 * 8 * 16}, {&c->enc_b2, b2, 16},
+        {&c->enc_w3, w3, 27 * 16 * 32}, {&c->enc_b3, b3, 32}, {&c->enc_wd2, wd2, 200 * 20}, {&c->enc_bd2, bd2, 20}};
+    for (auto &p : plain) {
+        if (!*p.dst) CAELO_HIP(hipMalloc(p.dst, p.n * sizeof(float)));
+        CAELO_HIP(hipMemcpy(*p.dst, p.src, p.n * sizeof(float), hipMemcpyHostToDevice));
+    }
+    float *pad = (float *)calloc((size_t)DENSE_K * DENSE_NP + DENSE_NP, sizeof(float));
+    if (!pad) { caelo_set_error("out of host memory"); return CAELO_ERR_ARG; }
+    for (int k = 0; k < DENSE_K; ++k) memcpy(pad + (size_t)k * DENSE_NP, wd1 + (size_t)k * DENSE_N, DENSE_N * sizeof(float));
+    memcpy(pad + (size_t)DENSE_K * DENSE_NP, bd1, DENSE_N * sizeof(float));
+    if (!c->enc_wd1) CAELO_HIP(hipMalloc(&c->enc_wd1, (size_t)DENSE_K * DENSE_NP * sizeof(float)));
+    if (!c->enc_bd1) CAELO_HIP(hipMalloc(&c->enc_bd1, DENSE_NP * sizeof(float)));
+    CAELO_HIP(hipMemcpy(c->enc_wd1, pad, (size_t)DENSE_K * DENSE_NP * sizeof(float), hipMemcpyHostToDevice));
+    CAELO_HIP(hipMemcpy(c->enc_bd1, pad + (size_t)DENSE_K * DENSE_NP, DENSE_NP * sizeof(float), hipMemcpyHostToDevice));
+    free(pad);
+    c->has_enc = true;
+    return CAELO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 1: conv1 + pool1 (VALU, sparse) -> conv2 (MFMA) -> pool2 -> P2
+// ------------------------------------------------------------------------------------------------
+// P1 in LDS: two planes of 4 channels; plane p, padded position q (0..799), channel c:
+//   P1[p*P1_PLANE + (P1_FRONT + q)*4 + c],   q = (xp*10 + yp)*8 + z,  xp,yp in 0..9 (1-cell halo), z in 0..7
+// (no z halo: the two out-of-range z taps are predicated).  An MFMA m-tile is 16 consecutive q, so a
+// ds_read_b64 by 32 lanes covers 64 consecutive dwords: bank-conflict free.
+#define P1_FRONT 2
+#define P1_PLANE ((800 + 2 * P1_FRONT) * 4)
+
+struct Stage1Lds {
+    float p1[2 * P1_PLANE];
+    float w1[27 * 8];
+    float b1[8];
+    float bg[8];
+    unsigned short rows[256];
+};
+
+__global__ void __launch_bounds__(256) k_enc_stage1(const unsigned long long *__restrict__ bits, int64_t n_patches,
+                                                    const float *__restrict__ w1g, const float *__restrict__ b1g,
+                                                    const float *__restrict__ w2g, const float *__restrict__ b2g,
+                                                    float *__restrict__ p2out) {
+    __shared__ __attribute__((aligned(16))) Stage1Lds L;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int g = lane >> 4;   // MFMA k-group
+    const int n = lane & 15;   // MFMA column (output channel) for B/C, row for A
+    // ---- one-time: weights.  B fragment for k-step (tap t, h): W2[t][cin = 2g + h][n]
+    float breg[27][2];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        breg[t][0] = w2g[(t * 8 + 2 * g) * 16 + n];
+        breg[t][1] = w2g[(t * 8 + 2 * g + 1) * 16 + n];
+    }
+    const float bias2 = b2g[n];
+    for (int i = tid; i < 27 * 8; i += 256) L.w1[i] = w1g[i];
+    if (tid < 8) { L.b1[tid] = b1g[tid]; L.bg[tid] = tanhf(b1g[tid]); }
+    for (int i = tid; i < 2 * P1_PLANE; i += 256) L.p1[i] = 0.0f;  // halo + pads stay zero for good
+    __syncthreads();
+
+    for (int64_t patch = blockIdx.x; patch < n_patches; patch += gridDim.x) {
+        // ---- load the 512-byte patch as 256 u16 rows (row = ix*16 + iy, bit = iz)
+        if (tid < 64) {
+            const unsigned long long w = bits[patch * 64 + tid];
+            L.rows[tid * 4 + 0] = (unsigned short)(w & 0xFFFF);
+            L.rows[tid * 4 + 1] = (unsigned short)((w >> 16) & 0xFFFF);
+            L.rows[tid * 4 + 2] = (unsigned short)((w >> 32) & 0xFFFF);
+            L.rows[tid * 4 + 3] = (unsigned short)(w >> 48);
+        }
+        __syncthreads();
+        // ---- conv1 + pool1 + tanh: 512 pooled cells, 2 per thread
+#pragma unroll 1
+        for (int rep = 0; rep < 2; ++rep) {
+            const int cell = tid + rep * 256;
+            const int px = cell >> 6, py = (cell >> 3) & 7, pz = cell & 7;
+            // 4x4x4 input neighbourhood of the 2x2x2 pooling block, as a 64-bit mask: bit a*16 + b*4 + j
+            unsigned long long mask = 0ull;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int x = 2 * px - 1 + a;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int y = 2 * py - 1 + b;
+                    unsigned int row = 0;
+                    if (x >= 0 && x < 16 && y >= 0 && y < 16) row = L.rows[x * 16 + y];
+                    const unsigned int nib = ((row << 1) >> (2 * pz)) & 0xFu;  // z = 2pz-1 .. 2pz+2
+                    mask |= (unsigned long long)nib << (a * 16 + b * 4);
+                }
+            }
+            float o[8];
+            if (mask == 0ull) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) o[c] = L.bg[c];
+            } else {
+                float mx[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) mx[c] = -3.0e38f;
+#pragma unroll 1
+                for (int sub = 0; sub < 8; ++sub) {
+                    const int sa = sub >> 2, sb = (sub >> 1) & 1, sc = sub & 1;
+                    unsigned int taps = 0;  // bit (ka*3+kb)*3+kc
+#pragma unroll
+                    for (int ka = 0; ka < 3; ++ka)
+#pragma unroll
+                        for (int kb = 0; kb < 3; ++kb)
+                            taps |= ((unsigned int)(mask >> ((sa + ka) * 16 + (sb + kb) * 4 + sc)) & 7u) << ((ka * 3 + kb) * 3);
+                    float acc[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[c] = L.b1[c];
+                    while (taps) {  // ascending tap order == the oracle's (kx,ky,kz) order
+                        const int t = __ffs((int)taps) - 1;
+                        taps &= taps - 1;
+                        const float4 wa = *(const float4 *)&L.w1[t * 8], wb = *(const float4 *)&L.w1[t * 8 + 4];
+                        acc[0] += wa.x; acc[1] += wa.y; acc[2] += wa.z; acc[3] += wa.w;
+                        acc[4] += wb.x; acc[5] += wb.y; acc[6] += wb.z; acc[7] += wb.w;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) mx[c] = fmaxf(mx[c], acc[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) o[c] = tanhf(mx[c]);
+            }
+            const int q = ((px + 1) * 10 + (py + 1)) * 8 + pz;
+            *(float4 *)&L.p1[(P1_FRONT + q) * 4] = make_float4(o[0], o[1], o[2], o[3]);
+            *(float4 *)&L.p1[P1_PLANE + (P1_FRONT + q) * 4] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        __syncthreads();
+        // ---- conv2 (8->16) on MFMA: wave w owns x in {2w, 2w+1}; per y0 pair-of-rows one m-tile each
+        {
+            const int yl = n >> 3, z = n & 7;  // A row m = yl*8 + z
+            const float *plane = L.p1 + (g >> 1) * P1_PLANE + 2 * (g & 1);
+            const bool zlo = z >= 1, zhi = z <= 6;
+#pragma unroll 1
+            for (int y0 = 0; y0 < 8; y0 += 2) {
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                // padded position of (x = 2w, y = y0 + yl, z) for tap (0,0,1): xp = x + ka, yp = y + kb
+                const int qbase = ((2 * wave) * 10 + (y0 + yl)) * 8 + z;
+                const float *a_ptr = plane + (P1_FRONT + qbase) * 4;
+#pragma unroll
+                for (int t = 0; t < 27; ++t) {
+                    const int ka = t / 9, kb = (t / 3) % 3, kc = t % 3;
+                    const int off = ((ka * 10 + kb) * 8 + (kc - 1)) * 4;
+                    float2 a0 = *(const float2 *)(a_ptr + off);
+                    float2 a1 = *(const float2 *)(a_ptr + off + 80 * 4);
+                    if (kc == 0) { if (!zlo) { a0 = make_float2(0.f, 0.f); a1 = a0; } }
+                    if (kc == 2) { if (!zhi) { a0 = make_float2(0.f, 0.f); a1 = a0; } }
+                    acc0 = MFMA16(a0.x, breg[t][0], acc0);
+                    acc1 = MFMA16(a1.x, breg[t][0], acc1);
+                    acc0 = MFMA16(a0.y, breg[t][1], acc0);
+                    acc1 = MFMA16(a1.y, breg[t][1], acc1);
+                }
+                // ---- pool2: x pair in registers, z pairs in registers, y pair across lanes g <-> g^2
+                float v0 = fmaxf(fmaxf(acc0[0], acc0[1]), fmaxf(acc1[0], acc1[1]));  // pz = 2*(g&1)
+                float v1 = fmaxf(fmaxf(acc0[2], acc0[3]), fmaxf(acc1[2], acc1[3]));  // pz = 2*(g&1)+1
+                v0 = fmaxf(v0, __shfl_xor(v0, 32));
+                v1 = fmaxf(v1, __shfl_xor(v1, 32));
+                if (g < 2) {
+                    // C column = n (channel), rows 4g..4g+3 -> z = 4*(g&1)+r ; pooled cell (wave, y0/2, 2*(g&1)+{0,1})
+                    float *dst = p2out + (size_t)patch * 1024 + (size_t)(((wave * 4 + (y0 >> 1)) * 4 + 2 * (g & 1)) * 16 + n);
+                    dst[0] = tanhf(v0 + bias2);
+                    dst[16] = tanhf(v1 + bias2);
+                }
+            }
+        }
+        __syncthreads();  // p1 / rows are rewritten by the next patch
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv3 (16->32) implicit GEMM: M = 64 positions/patch, N = 32, K = 27*16
+// ------------------------------------------------------------------------------------------------
+// P2 in LDS per patch slot: four 4-channel planes; plane p, padded position q, channel c:
+//   S[p*P2_PLANE + (P2_FRONT + q)*4 + c],  q = (xp*6 + yp)*4 + z, xp,yp in 0..5 (halo), z in 0..3.
+// P2_PLANE is a multiple of 64 dwords so the two planes met by one ds_read_b128 lane group fall on
+// complementary bank halves (MI355X_MICROARCH LDS table): conflict free.
+#define P2_FRONT 8
+#define P2_PLANE (160 * 4)
+#define P2_SLOT (4 * P2_PLANE)
+
+__global__ void __launch_bounds__(256) k_enc_conv3(const float *__restrict__ p2, int64_t n_patches,
+                                                   const float *__restrict__ w3g, const float *__restrict__ b3g,
+                                                   float *__restrict__ f3) {
+    __shared__ __attribute__((aligned(16))) float S[2 * P2_SLOT];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const int ntile = wave & 1, slot = wave >> 1;
+    // B fragment for k-step (tap t, h): W3[t][cin = 4g + h][16*ntile + n]
+    float breg[27][4];
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) breg[t][h] = w3g[(t * 16 + 4 * g + h) * 32 + 16 * ntile + n];
+    const float bias = b3g[16 * ntile + n];
+    for (int i = tid; i < 2 * P2_SLOT; i += 256) S[i] = 0.0f;
+    __syncthreads();
+    const int64_t n_pairs = (n_patches + 1) / 2;
+    for (int64_t pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+        // ---- stage two patches: 2 x 64 positions x 16 channels = 512 float4, 2 per thread
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = tid + r * 256;           // float4 index over [slot][pos][plane]
+            const int sl = i >> 8, rem = i & 255;  // rem = pos*4 + plane
+            const int pos = rem >> 2, pl = rem & 3;
+            const int64_t patch = pair * 2 + sl;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (patch < n_patches) v = *(const float4 *)(p2 + (size_t)patch * 1024 + pos * 16 + pl * 4);
+            const int x = pos >> 4, y = (pos >> 2) & 3, z = pos & 3;
+            const int q = ((x + 1) * 6 + (y + 1)) * 4 + z;
+            *(float4 *)&S[sl * P2_SLOT + pl * P2_PLANE + (P2_FRONT + q) * 4] = v;
+        }
+        __syncthreads();
+        const int64_t patch = pair * 2 + slot;
+        {
+            const int yl = n >> 2, z = n & 3;  // A row m = yl*4 + z ; m-tile index = x
+            const float *plane = S + slot * P2_SLOT + g * P2_PLANE;
+            const bool zlo = z >= 1, zhi = z <= 2;
+            f32x4 acc[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int qbase = (0 * 6 + yl) * 4 + z;
+            const float *a_ptr = plane + (P2_FRONT + qbase) * 4;
+#pragma unroll
+            for (int t = 0; t < 27; ++t) {
+                const int ka = t / 9, kb = (t / 3) % 3, kc = t % 3;
+                const int off = ((ka * 6 + kb) * 4 + (kc - 1)) * 4;
+                float4 a[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    a[x] = *(const float4 *)(a_ptr + off + x * 24 * 4);
+                    if (kc == 0) { if (!zlo) a[x] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                    if (kc == 2) { if (!zhi) a[x] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) acc[x] = MFMA16(a[x].x, breg[t][0], acc[x]);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) acc[x] = MFMA16(a[x].y, breg[t][1], acc[x]);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) acc[x] = MFMA16(a[x].z, breg[t][2], acc[x]);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) acc[x] = MFMA16(a[x].w, breg[t][3], acc[x]);
+            }
+            if (patch < n_patches) {
+                // C rows 4g + r -> (yl = g, z = r); flatten index (x,y,z,c) = ((x*4 + y)*4 + z)*32 + c
+                float *dst = f3 + (size_t)patch * 2048 + 16 * ntile + n;
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[((x * 4 + g) * 4 + r) * 32] = tanhf(acc[x][r] + bias);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense1: split-K GEMM  part[s][row][208] = F3[row][k0:k0+256] x Wd1p[k0:k0+256][208]
+// ------------------------------------------------------------------------------------------------
+#define D1_BM 64
+#define D1_BK 32
+#define D1_SPLIT 8
+#define D1_KCHUNK (DENSE_K / D1_SPLIT)
+#define D1_APITCH 34  // conflict-free ds_read_b32 of A[m][k] for 16 rows x 2 k per lane group
+
+__global__ void __launch_bounds__(256) k_enc_dense1(const float *__restrict__ f3, int64_t n_rows_pad,
+                                                    const float *__restrict__ wd1p, float *__restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float As[D1_BM * D1_APITCH];
+    __shared__ __attribute__((aligned(16))) float Bs[D1_BK * DENSE_NP];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const int64_t row0 = (int64_t)blockIdx.x * D1_BM;
+    const int split = blockIdx.y;
+    const int kbeg = split * D1_KCHUNK;
+    f32x4 acc[13];
+#pragma unroll
+    for (int j = 0; j < 13; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = kbeg; k0 < kbeg + D1_KCHUNK; k0 += D1_BK) {
+        // A tile: 64 rows x 32 k = 512 float4
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = tid + r * 256;
+            const int m = i >> 3, kq = i & 7;
+            const float4 v = *(const float4 *)(f3 + (size_t)(row0 + m) * DENSE_K + k0 + kq * 4);
+            float *d = &As[m * D1_APITCH + kq * 4];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        // B tile: 32 k x 208 n = 1664 float4
+        for (int i = tid; i < D1_BK * DENSE_NP / 4; i += 256) {
+            const int k = i / (DENSE_NP / 4), c4 = i % (DENSE_NP / 4);
+            *(float4 *)&Bs[k * DENSE_NP + c4 * 4] = *(const float4 *)(wd1p + (size_t)(k0 + k) * DENSE_NP + c4 * 4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < D1_BK / 4; ++s) {
+            const float a = As[(wave * 16 + n) * D1_APITCH + 4 * s + g];
+#pragma unroll
+            for (int j = 0; j < 13; ++j) acc[j] = MFMA16(a, Bs[(4 * s + g) * DENSE_NP + 16 * j + n], acc[j]);
+        }
+        __syncthreads();
+    }
+    // C rows 4g + r of this wave's m-tile
+    float *dst = part + ((size_t)split * n_rows_pad + row0 + wave * 16) * DENSE_NP;
+#pragma unroll
+    for (int j = 0; j < 13; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(size_t)(4 * g + r) * DENSE_NP + 16 * j + n] = acc[j][r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// head: reduce split-K partials + bias + tanh -> Dense(20) + tanh -> scatter
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part, int64_t n_patches, int64_t n_rows_pad,
+                                                  const float *__restrict__ bd1p, const float *__restrict__ wd2,
+                                                  const float *__restrict__ bd2, int group, float *__restrict__ out,
+                                                  int out_stride) {
+    __shared__ float h[4][DENSE_NP];
+    const int tid = threadIdx.x;
+    const int64_t p0 = (int64_t)blockIdx.x * 4;
+    for (int i = tid; i < 4 * DENSE_NP; i += 256) {
+        const int pl = i / DENSE_NP, j = i % DENSE_NP;
+        const int64_t p = p0 + pl;
+        float v = 0.0f;
+        if (p < n_patches && j < DENSE_N) {
+            float s = bd1p[j];
+#pragma unroll
+            for (int sp = 0; sp < D1_SPLIT; ++sp) s += part[((size_t)sp * n_rows_pad + p) * DENSE_NP + j];
+            v = tanhf(s);
+        }
+        h[pl][j] = v;
+    }
+    __syncthreads();
+    if (tid < 80) {
+        const int pl = tid / 20, o = tid % 20;
+        const int64_t p = p0 + pl;
+        if (p < n_patches) {
+            float s = bd2[o];
+            for (int i = 0; i < DENSE_N; ++i) s += h[pl][i] * wd2[i * 20 + o];
+            out[(size_t)(p / group) * out_stride + (size_t)(p % group) * 20 + o] = tanhf(s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host entry
+// ------------------------------------------------------------------------------------------------
+static inline int64_t pad64(int64_t n) { return (n + 63) / 64 * 64; }
+
+CAELO_API int64_t caelo_encode_ws_bytes(int64_t n_patches) {
+    const int64_t np = pad64(n_patches);
+    return (np * 1024 + np * 2048 + (int64_t)D1_SPLIT * np * DENSE_NP) * (int64_t)sizeof(float);
+}
+
+CAELO_API int caelo_encode(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out,
+                           int out_stride, void *ws, void *stream) {
+    CAELO_REQUIRE(c && bits && out && ws, "null argument");
+    CAELO_REQUIRE(c->has_enc, "encoder weights not set (caelo_set_encoder_weights)");
+    CAELO_REQUIRE(n_patches > 0 && group >= 1 && out_stride >= group * 20, "bad shape");
+    hipStream_t s = caelo_stream(stream);
+    const int64_t np = pad64(n_patches);
+    float *p2 = (float *)ws;
+    float *f3 = p2 + np * 1024;
+    float *part = f3 + np * 2048;
+    const int64_t cap = 256 * 4;  // persistent-ish grids: weights stay in registers across patches
+    const unsigned g1 = (unsigned)(n_patches < cap ? n_patches : cap);
+    k_enc_stage1<<<g1, 256, 0, s>>>((const unsigned long long *)bits, n_patches, c->enc_w1, c->enc_b1, c->enc_w2,
+                                    c->enc_b2, p2);
+    CAELO_LAUNCH_CHECK();
+    const int64_t pairs = (n_patches + 1) / 2;
+    const unsigned g3 = (unsigned)(pairs < 512 ? pairs : 512);
+    k_enc_conv3<<<g3, 256, 0, s>>>(p2, n_patches, c->enc_w3, c->enc_b3, f3);
+    CAELO_LAUNCH_CHECK();
+    if (np > n_patches)  // rows of the last 64-row tile that no patch wrote
+        CAELO_HIP(hipMemsetAsync(f3 + n_patches * 2048, 0, (size_t)(np - n_patches) * 2048 * sizeof(float), s));
+    dim3 gd((unsigned)(np / D1_BM), D1_SPLIT);
+    k_enc_dense1<<<gd, 256, 0, s>>>(f3, np, c->enc_wd1, part);
+    CAELO_LAUNCH_CHECK();
+    k_enc_head<<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(part, n_patches, np, c->enc_bd1, c->enc_wd2, c->enc_bd2,
+                                                                group, out, out_stride);
+    CAELO_LAUNCH_CHECK();
+    return CAELO_OK;
+}

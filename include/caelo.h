@@ -1,0 +1,154 @@
+/*
+ * caelo.h -- C ABI of libcaelo.so, the MI355X-native (gfx950, HIP) CAE-LO feature-and-matching
+ * engine.  The reference (SRainGit/CAE-LO) has no FFI: its boundary is a set of module-level
+ * Python functions on NumPy arrays.  Each entry point below replaces the
+ * device work behind one of those functions; caelo/api.py (ctypes) keeps the Python names,
+ * argument order and return tuples.
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer unless the name ends in _host; the caller owns all
+ *     buffers (torch allocates them); no hidden allocation outside caelo_create /
+ *     caelo_voxmap_create / caelo_set_*_weights;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - return value: 0 on success, negative caelo_status otherwise; caelo_last_error() gives text;
+ *   - data-dependent conditions the reference reports as Python exceptions are written to a
+ *     device-side int32 status word (CAELO_ST_* bit flags) so no call forces a host sync.
+ */
+#ifndef CAELO_H
+#define CAELO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAELO_ABI_VERSION 1
+
+/* geometry fixed by the reference: SphericalRing.py:28-58, Voxel.py:15-52 */
+#define CAELO_RING_H 69
+#define CAELO_RING_W 1800
+#define CAELO_RING_C 5
+#define CAELO_NET_H 64
+#define CAELO_NET_W 1792
+#define CAELO_RESP_C 8
+#define CAELO_MAX_KEYPTS 1024
+#define CAELO_PATCH_WORDS 64 /* 16^3 bits = 64 x u64, bit ((iy&3)*16+iz) of word (ix*4+iy/4) */
+#define CAELO_DESC_DIM 20    /* per scale; 3 scales -> 60 */
+#define CAELO_RANSAC_MAX_TRIALS 500
+#define CAELO_RANSAC_LEVELS 3
+
+typedef enum {
+    CAELO_OK = 0,
+    CAELO_ERR_ARG = -1,     /* bad argument (shape, null pointer, missing weights) */
+    CAELO_ERR_HIP = -2,     /* a HIP runtime call failed */
+    CAELO_ERR_CAPACITY = -3 /* voxel map too small for the cloud */
+} caelo_status;
+
+/* device-side status bits (int32 word, OR-ed by kernels) */
+#define CAELO_ST_COL_OOB 1        /* a point projects to column 1800: IndexError at SphericalRing.py:91 */
+#define CAELO_ST_VOXEL_OOB 2      /* voxel index outside its block: IndexError at Voxel.py:139 */
+#define CAELO_ST_MAP_FULL 4       /* voxel hash table overflow (capacity bug, never data) */
+#define CAELO_ST_FEW_VOXELS 8     /* a scale holds < 496 voxels: sklearn ValueError at Voxel.py:195-196 */
+#define CAELO_ST_FEW_KEYPTS 16    /* K <= 50: assert at SphericalRing.py:286 */
+
+typedef struct caelo_ctx caelo_ctx;
+typedef struct caelo_voxmap caelo_voxmap;
+
+int caelo_abi_version(void);
+const char *caelo_last_error(void);
+int caelo_create(caelo_ctx **ctx, int device);
+void caelo_destroy(caelo_ctx *ctx);
+
+/* Weights (HOST pointers, Keras layouts as stored in the .h5).  Replaces
+ * keras.models.load_model(...) at Match.py:313,324 / Dirs.py:29-30. */
+int caelo_set_respond_weights(caelo_ctx *ctx, const float *w1_host /*[3][3][3][32]*/, const float *b1_host /*[32]*/,
+                              const float *w2_host /*[32][8]*/, const float *b2_host /*[8]*/);
+int caelo_set_encoder_weights(caelo_ctx *ctx, const float *w1_host /*[27][1][8]*/, const float *b1_host,
+                              const float *w2_host /*[27][8][16]*/, const float *b2_host,
+                              const float *w3_host /*[27][16][32]*/, const float *b3_host,
+                              const float *wd1_host /*[2048][200]*/, const float *bd1_host,
+                              const float *wd2_host /*[200][20]*/, const float *bd2_host);
+
+/* ProjectPC2SphericalRing  (SphericalRing.py:72-94)
+ * pc [n][4] f32 -> ring [69][1800][5] f32, counter [69][1800] i32.  workspace: winner [69*1800] i32. */
+int caelo_project(caelo_ctx *ctx, const float *pc, int64_t n, float *ring, int32_t *counter, int32_t *winner_ws,
+                  int32_t *status, void *stream);
+
+/* RespondLayer.predict  (SphericalRing.py:405-408; SphericalRingPCRespondLayer.h5)
+ * in [rows>=64][in_w][in_c] (channels 0..2 of rows 0..63, cols 0..1791) -> resp [64][1792][8] */
+int caelo_respond(caelo_ctx *ctx, const float *in, int in_w, int in_c, float *resp, void *stream);
+
+/* GetKeyPtsByAE  (SphericalRing.py:113-291).  ring_c = 5: demo mode (:414); 3: batch mode
+ * (BatchPreprocess.py:97-98,131-136).  workspace: cand_ws [64*1792] u64.
+ * outputs: key_pixels [1024][2] i64 (row,col), key_pts [1024][3] f32, n_key [1] i32. */
+int caelo_keypoints(caelo_ctx *ctx, const float *ring, int ring_w, int ring_c, const int32_t *counter, int cnt_w,
+                    const float *resp, uint64_t *cand_ws, int64_t *key_pixels, float *key_pts, int32_t *n_key,
+                    int32_t *status, void *stream);
+
+/* Voxelization  (Voxel.py:100-173) into a device voxel map (3 scales of 8^3-voxel bricks). */
+int caelo_voxmap_create(caelo_ctx *ctx, int64_t max_points, caelo_voxmap **map);
+void caelo_voxmap_destroy(caelo_voxmap *map);
+int caelo_voxelize(caelo_ctx *ctx, caelo_voxmap *map, const float *pc, int64_t n, int stride, int32_t *status,
+                   void *stream);
+/* AllVoxels0/1/2 in the reference's order (first touch; scale 0 block-grouped, Voxel.py:161-165).
+ * out [capacity][3] i16 per scale, counts [3] i64 (device).  Valid after caelo_voxelize. */
+int caelo_voxmap_export(caelo_ctx *ctx, caelo_voxmap *map, int16_t *all0, int16_t *all1, int16_t *all2,
+                        int64_t capacity, int64_t *counts, void *stream);
+/* Build the map from reference-format lists instead (GetPatchesList called with arrays). */
+int caelo_voxmap_from_lists(caelo_ctx *ctx, caelo_voxmap *map, const int16_t *all0, int64_t n0, const int16_t *all1,
+                            int64_t n1, const int16_t *all2, int64_t n2, int32_t *status, void *stream);
+
+/* GetPatchesList  (Voxel.py:177-216): pts [k][3] f32 (k read from n_key when non-null, else k_max)
+ * -> bits [k_max][3][64] u64, flags [k_max][3] u8 (bit0 truncated by the 496-NN cap, bit1 cut
+ * falls inside an equidistant class: kd-tree tie order dependent). */
+int caelo_patches(caelo_ctx *ctx, const caelo_voxmap *map, const float *pts, int64_t k_max, const int32_t *n_key,
+                  uint64_t *bits, uint8_t *flags, int32_t *status, void *stream);
+/* dense <-> packed conversion for callers that want the reference's [K,16,16,16,1] f32 arrays */
+int caelo_unpack_patches(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches, float *dense, void *stream);
+int caelo_pack_patches(caelo_ctx *ctx, const float *dense, int64_t n_patches, uint64_t *bits, void *stream);
+
+/* PatchEncoder.predict / GetFeaturesFromPatches  (Match.py:130-135; EncoderModel4VoxelPatch.h5)
+ * bits [n_patches][64] u64 -> out[(p / group) * out_stride + (p % group) * 20 + j].
+ * group = 1, out_stride = 20: plain predict; group = 3, out_stride = 60 on [K][3][64]: Features [K][60].
+ * workspace: ws of caelo_encode_ws_bytes(n_patches) bytes. */
+int64_t caelo_encode_ws_bytes(int64_t n_patches);
+int caelo_encode(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
+                 void *ws, void *stream);
+
+/* NN match  (Match.py:257-258): pair_idx[j] = argmin_i ||f0[i]-f1[j]|| (f64, first minimum).
+ * k0/k1 read from n0/n1 device words when non-null. */
+int caelo_match(caelo_ctx *ctx, const float *f0, int64_t k0_max, const int32_t *n0, const float *f1, int64_t k1_max,
+                const int32_t *n1, int dim, int64_t *pair_idx, void *stream);
+
+/* SolveRT  (Match.py:138-158): p0 ~ R p1 + T over n point pairs.  R [9], T [3] f32 (device);
+ * credible [1] i32 (optional): the reference's isCredible, -1 when det(R) < 0 was met. */
+int caelo_solve_rt(caelo_ctx *ctx, const float *p0, const float *p1, int64_t n, float *R, float *T,
+                   int32_t *credible, void *stream);
+
+/* RANSAC4RT + SolveRelativePose tail  (Match.py:162-218, :260-283).
+ * pc0 [k0][3], pc1 [k1][3], pair_idx [k1]; rand [3*500][4] f64 = the uniform doubles the
+ * reference's np.random.random((4,)) would return, in consumption order.
+ * result (device, caelo_pose_result) + inlier mask [k1_max] u8.  workspace ws:
+ * caelo_ransac_ws_bytes() bytes. */
+typedef struct {
+    float R[9];           /* final refit rotation, row-major */
+    float T[3];
+    float R_ransac[9];    /* best hypothesis before the refit (RANSAC4RT's R_star) */
+    float T_ransac[3];
+    float threshold;      /* residualThreshold returned (0.4 / 0.8 / 1.6) */
+    int32_t success;      /* isSuccess */
+    int32_t iterations;   /* cntIters of the last level */
+    int32_t n_inliers;
+    int32_t best_trial;   /* index into rand of the winning hypothesis, -1 if none */
+    int32_t n_pairs;
+} caelo_pose_result;
+int64_t caelo_ransac_ws_bytes(void);
+int caelo_ransac(caelo_ctx *ctx, const float *pc0, const float *pc1, const int64_t *pair_idx, int64_t k1_max,
+                 const int32_t *n1, const double *rand, caelo_pose_result *result, uint8_t *inlier_mask, void *ws,
+                 void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAELO_H */
