@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py -- end-to-end CAE-LO hot path on MI355X: frames/s for
+project -> response CNN -> keypoints -> voxelize -> patch gather -> 3D-CAE descriptors -> NN match -> RANSAC pose.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one KITTI-shaped scan (64 beams x 2000 azimuths, ~126k points, already resident in HBM)
+taken through the whole path on every rank.  Frames shard across ranks (weak scaling: K frames per
+rank); the timed region per rank is
+    K x extract  ->  ONE RCCL all-gather of the per-frame rows [K,1024,64] f32  ->  K x (match + RANSAC),
+each frame matched against its predecessor (a rank's first frame against the previous rank's last
+one, taken from the gathered rows; rank 0's first frame against the last warm-up frame).
+Rank 0 prints one JSON line (contract in the task statement) including
+    roofline      the dominant kernel (k_enc_stage1, conv1+conv2 of the 3D-CAE encoder), algorithmic
+                  FLOPs / HIP-event time measured live through caelo_encode_profile
+    cpu_baseline  the CPU oracle (oracle/, the reference restated in C/NumPy) on the host cores,
+                  bounded sample, rank 0 at N == 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "cae-lo_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from caelo import synth  # noqa: E402
+from caelo import dist as cdist  # noqa: E402
+from caelo.engine import Engine, FrameFeatures, ransac_draws  # noqa: E402
+
+POOL = 6  # distinct consecutive synthetic frames per rank, cycled
+
+# algorithmic FLOPs per patch (SURVEY.md 8d / BASELINE.md section 4): 2 x MACs
+FLOP_CONV1 = 2 * 4096 * 27 * 8
+FLOP_CONV2 = 2 * 512 * 216 * 16
+FLOP_CONV3 = 2 * 64 * 432 * 32
+FLOP_DENSE1 = 2 * 2048 * 200
+FLOP_DENSE2 = 2 * 200 * 20
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 matrix peak
+
+
+def cpu_baseline(n_frames=3, max_seconds=40.0):
+    """CPU oracle end to end (all host cores via OpenMP) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle as orc
+    resp_m, enc_m = orc.load_models(os.path.join(REPO, "weights", "SphericalRingPCRespondLayer.h5"),
+                                    os.path.join(REPO, "weights", "EncoderModel4VoxelPatch.h5"))
+    cores = orc.num_threads()
+    clouds = [synth.make_scan(f) for f in range(n_frames + 1)]
+
+    def extract(pc):
+        ring, cnt = orc.ProjectPC2SphericalRing(pc)
+        resp = resp_m.predict(ring[None, 0:64, 0:1792, 0:3])[0]
+        kp, _, _ = orc.GetKeyPtsByAE(ring, cnt, resp)
+        v = orc.Voxelization(pc[:, 0:3])
+        feats = np.concatenate([enc_m.predict_bits(orc.patches_bits(kp, v[6 + s], s)[0]) for s in range(3)], axis=1)
+        return kp, feats
+
+    prev = extract(clouds[0])
+    t0 = time.time()
+    done = 0
+    for f in range(1, n_frames + 1):
+        cur = extract(clouds[f])
+        orc.SolveRelativePose(prev[0], prev[1], None, cur[0], cur[1], None, rng=np.random.RandomState(f))
+        prev = cur
+        done += 1
+        if time.time() - t0 > max_seconds:
+            break
+    dt = time.time() - t0
+    return {"value": round(done / dt, 4), "unit": "frames/s", "cores": int(cores), "kind": "port",
+            "sample": "%d synthetic frames (64x2000 scan, 1024 keypoints, 3072 patches each), full path incl. "
+                      "match+RANSAC, oracle C/NumPy restatement with OpenMP on %d threads, %.1f s" % (done, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+
+    eng = Engine(device=local_rank)
+    K, W = args.steps, args.warmup
+    # synthetic scans of this rank's stretch of the trajectory, uploaded before the clock starts
+    base = rank * K
+    pool = [torch.from_numpy(synth.make_scan((base + i) % 997)).to(dev) for i in range(POOL)]
+    rand = [torch.from_numpy(ransac_draws(1000 + rank * 7919 + i)).to(dev) for i in range(POOL)]
+    n_points = int(np.mean([p.shape[0] for p in pool]))
+
+    def rows_of(ff):
+        return cdist.pack_rows(ff.key_pts, ff.features, ff.n_key)
+
+    def ff_from_rows(rows):
+        kp, ft, nk = cdist.unpack_rows(rows)
+        return FrameFeatures(kp, None, ft, nk, None, None)
+
+    def run(steps, prev):
+        """extract `steps` frames, all-gather their rows, match each frame with its predecessor."""
+        feats = [eng.extract(pool[i % POOL]) for i in range(steps)]
+        local = torch.stack([rows_of(f) for f in feats])              # [steps, 1024, 64]
+        if world > 1:
+            allrows = cdist.all_gather_frames(local, steps * world)    # ONE collective over xGMI
+            if rank > 0:
+                prev = ff_from_rows(allrows[rank * steps - 1])
+        results = []
+        for i in range(steps):
+            res, mask, _ = eng.match_pose(prev, feats[i], rand[i % POOL])
+            results.append(res)
+            prev = feats[i]
+        return prev, results
+
+    prev = eng.extract(pool[POOL - 1])
+    prev, _ = run(W, prev) if W > 0 else (prev, None)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    prev, results = run(K, prev)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    # sanity: every pose solved (not timed)
+    ok = sum(int(eng.pose_result(r).success) for r in results)
+    status = int(prev.status.item()) if prev.status is not None else 0
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel, HIP events on the launch stream ----------------------
+        bits, _ = eng.patches(eng.voxelize(pool[0])[0], eng.extract(pool[0]).key_pts)
+        n_patches = bits.numel() // 64
+        for _ in range(3):
+            eng.encode_profile(bits, group=3)
+        ms = np.array([eng.encode_profile(bits, group=3)[1] for _ in range(20)])
+        ms_avg = ms.mean(axis=0)
+        flops = n_patches * np.array([FLOP_CONV1 + FLOP_CONV2, FLOP_CONV3, FLOP_DENSE1, FLOP_DENSE2])
+        dom = int(np.argmax(ms_avg))
+        names = ["k_enc_stage1", "k_enc_conv3", "k_enc_dense1", "k_enc_head"]
+        achieved = flops[dom] / (ms_avg[dom] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": names[dom], "achieved": round(float(achieved), 3),
+                    "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(float(achieved / F32_MFMA_PEAK_TFLOPS), 4),
+                    "traffic": None,
+                    "launch_ms": round(float(ms_avg[dom]), 4), "flops_per_launch": int(flops[dom]),
+                    "encoder_kernels_ms": {n: round(float(m), 4) for n, m in zip(names, ms_avg)},
+                    "encoder_total_tflops": round(float(flops.sum() / (ms_avg.sum() * 1e-3) / 1e12), 3)}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+        out = {
+            "metric": "KITTI frames/sec end-to-end (keypts+desc+match+RANSAC)",
+            "value": round(world * K / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: KITTI-seq-00-shaped full odometry (extract + NN match + RANSAC pose) on "
+                                   "synthetic 64-beam x 2000-azimuth scans",
+                       "points_per_frame": n_points, "keypoints": 1024, "patches_per_frame": 3072,
+                       "frames_per_gpu": K, "parallelism": "frames sharded x%d, one RCCL all-gather of [K,1024,64] f32 rows" % world,
+                       "poses_solved": "%d/%d" % (ok, K), "status_bits": status},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,6 +44,7 @@ SIGNATURES = [
     ("caelo_pack_patches", c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     ("caelo_encode_ws_bytes", c_i64, [c_i64]),
     ("caelo_encode", c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp]),
+    ("caelo_encode_profile", c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     ("caelo_match", c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_vp]),
     ("caelo_solve_rt", c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     ("caelo_ransac_ws_bytes", c_i64, []),
@@ -60,6 +61,9 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise CaeloError("libcaelo.so not built (%s); run `python __graft_entry__.py` or "
                              "`make -C cae-lo_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+        # torch bundles its own HIP runtime: load it first so libcaelo.so binds to the same libamdhip64
+        # (two runtimes in one process cannot both own the device)
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, res, args in SIGNATURES:
             fn = getattr(lib, name)

@@ -1,0 +1,116 @@
+"""Frame sharding across GPUs: one process per GPU, torch.distributed (backend "nccl" == RCCL on
+ROCm, "gloo" in the CPU tests).
+
+The path shards by frames: feature extraction is independent per frame
+(the reference fans frames out to worker processes: BatchPreprocess.py:215-228,
+PoseEstimation.py:79-99) and matching needs consecutive frames only (PoseEstimation.py:241-251).
+Each rank extracts a contiguous block of frames, ONE all-gather moves the per-frame rows
+(key point xyz | 60-d descriptor | valid flag) over xGMI, then every rank matches the pairs whose
+second frame it owns -- the pair straddling a block boundary takes its first frame from the
+gathered rows of the previous rank.  Pose chaining (PoseEstimation.py:253-267) is a prefix product
+of the gathered per-pair (R, T) on rank 0 (host, 3x4 algebra).
+
+Nothing here is device specific: the same code runs under gloo on CPU tensors in tests/.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROW = 64  # floats per key point row: xyz (3) + descriptor (60) + valid (1)
+
+
+def shard_frames(n_frames, rank, world):
+    """Contiguous block [lo, hi) of frame indices owned by ``rank`` (sizes differ by at most 1)."""
+    base, rem = divmod(n_frames, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def owner_of(frame, n_frames, world):
+    base, rem = divmod(n_frames, world)
+    cut = rem * (base + 1)
+    return frame // (base + 1) if frame < cut else rem + (frame - cut) // max(base, 1)
+
+
+def pack_rows(key_pts, features, n_key):
+    """[K,3] f32, [K,60] f32, n_key (int or 0-d/1-elem tensor) -> [K,64] rows with a valid column."""
+    k = key_pts.shape[0]
+    nk = n_key if torch.is_tensor(n_key) else torch.tensor([n_key], device=key_pts.device)
+    valid = (torch.arange(k, device=key_pts.device) < nk.reshape(-1)[0]).to(key_pts.dtype).unsqueeze(1)
+    return torch.cat([key_pts, features, valid], dim=1)
+
+
+def unpack_rows(rows):
+    """[K,64] -> (key_pts [K,3], features [K,60], n_key int32[1]) -- contiguous copies."""
+    n_key = rows[:, 63].sum().round().to(torch.int32).reshape(1)
+    return rows[:, 0:3].contiguous(), rows[:, 3:63].contiguous(), n_key
+
+
+def all_gather_frames(local_rows, n_frames, group=None):
+    """local_rows [F_local, K, 64] -> [n_frames, K, 64] on every rank (ONE collective).
+    Blocks are padded to the largest block so a single all_gather_into_tensor suffices."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local_rows
+    rank = dist.get_rank(group)
+    fmax = -(-n_frames // world)
+    lo, hi = shard_frames(n_frames, rank, world)
+    assert local_rows.shape[0] == hi - lo
+    k = local_rows.shape[1]
+    send = local_rows
+    if hi - lo < fmax:
+        send = torch.cat([local_rows, local_rows.new_zeros((fmax - (hi - lo), k, ROW))], dim=0)
+    recv = local_rows.new_empty((world * fmax, k, ROW))
+    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    parts = []
+    for r in range(world):
+        rlo, rhi = shard_frames(n_frames, r, world)
+        parts.append(recv[r * fmax: r * fmax + (rhi - rlo)])
+    return torch.cat(parts, dim=0)
+
+
+def local_pairs(n_frames, rank, world):
+    """Pairs (f-1, f) matched by ``rank``: those whose second frame it owns (frame 0 has none)."""
+    lo, hi = shard_frames(n_frames, rank, world)
+    return [(f - 1, f) for f in range(max(lo, 1), hi)]
+
+
+def gather_poses(local_rt, n_frames, group=None):
+    """local_rt [P_local, 12] f32 rows (R row-major | T) of this rank's pairs -> [n_frames-1, 12]
+    on every rank (second collective, 48 B per pair)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local_rt
+    pmax = -(-n_frames // world)
+    send = local_rt.new_zeros((pmax, 12))
+    send[: local_rt.shape[0]] = local_rt
+    recv = local_rt.new_empty((world * pmax, 12))
+    dist.all_gather_into_tensor(recv, send, group=group)
+    parts = []
+    for r in range(world):
+        parts.append(recv[r * pmax: r * pmax + len(local_pairs(n_frames, r, world))])
+    return torch.cat(parts, dim=0)
+
+
+def chain_poses(rel_rt, Tr=None):
+    """PoseEstimation.py:230-267: prefix product of per-pair LiDAR motions into camera-frame KITTI
+    poses [F,12].  rel_rt [F-1,12] (R row-major | T); Tr [3,4] calibration (identity if None)."""
+    rel = np.asarray(rel_rt, dtype=np.float32).reshape(-1, 12)
+    # float32 end to end, like the reference (Tr, SolveRT's R/T and pose0 are all float32 there)
+    Tr = np.c_[np.eye(3), np.zeros(3)] if Tr is None else np.asarray(Tr)
+    Tr = np.array(Tr.reshape(3, 4), dtype=np.float32)                       # :203
+    R_Tr = Tr[:, 0:3]
+    R_Tr_inv = np.linalg.inv(R_Tr)                                          # :205
+    T_Tr = Tr[:, 3].reshape(3, 1)
+    T_Tr_inv = -np.dot(R_Tr_inv, T_Tr)                                      # :207
+    poses = [np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float32).reshape(12, 1)]  # :232
+    for row in rel:
+        relativeR, relativeT = row[:9].reshape(3, 3), row[9:].reshape(3, 1)
+        pose0 = poses[-1].reshape(3, 4)                                     # Transformations.py:164-168
+        R0, T0 = pose0[:, 0:3], pose0[:, 3].reshape(3, 1)
+        R_poseDiff = np.dot(R_Tr, np.dot(relativeR, R_Tr_inv))             # :259
+        T_poseDiff = np.dot(R_Tr, np.dot(relativeR, T_Tr_inv) + relativeT) + T_Tr  # :260
+        R = np.dot(R0, R_poseDiff)                                          # :261
+        T = np.dot(R0, T_poseDiff) + T0                                     # :262
+        poses.append(np.c_[R, T].reshape((12, 1)))                          # :265-267
+    return np.array(poses, dtype=np.float32).reshape(len(poses), 12)       # :273-274

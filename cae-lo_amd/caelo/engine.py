@@ -245,6 +245,16 @@ class Engine:
         _ffi.check(self.lib.caelo_encode(self.ctx, _ptr(bits), n, group, _ptr(out), 20 * group, _ptr(ws), self.stream))
         return out
 
+    def encode_profile(self, bits, group=1):
+        """encode + per-kernel HIP-event timings (ms): stage1, conv3, dense1, head.  Synchronises."""
+        n = bits.numel() // 64
+        out = self.empty((n // group, 20 * group), torch.float32)
+        ws = self._encode_ws(n)
+        ms = (C.c_float * 4)()
+        _ffi.check(self.lib.caelo_encode_profile(self.ctx, _ptr(bits), n, group, _ptr(out), 20 * group, _ptr(ws),
+                                                 self.stream, C.cast(ms, C.c_void_p)))
+        return out, list(ms)
+
     def match(self, f0, f1, n0=None, n1=None):
         assert f0.dtype == torch.float32 and f1.dtype == torch.float32 and f0.is_contiguous() and f1.is_contiguous()
         idx = self.zeros((f1.shape[0],), torch.int64)

@@ -390,32 +390,58 @@ CAELO_API int64_t caelo_encode_ws_bytes(int64_t n_patches) {
     return (np * 1024 + np * 2048 + (int64_t)D1_SPLIT * np * DENSE_NP) * (int64_t)sizeof(float);
 }
 
-CAELO_API int caelo_encode(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out,
-                           int out_stride, void *ws, void *stream) {
+static int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
+                       void *ws, hipStream_t s, hipEvent_t *ev /* 5 events or null */) {
     CAELO_REQUIRE(c && bits && out && ws, "null argument");
     CAELO_REQUIRE(c->has_enc, "encoder weights not set (caelo_set_encoder_weights)");
     CAELO_REQUIRE(n_patches > 0 && group >= 1 && out_stride >= group * 20, "bad shape");
-    hipStream_t s = caelo_stream(stream);
     const int64_t np = pad64(n_patches);
     float *p2 = (float *)ws;
     float *f3 = p2 + np * 1024;
     float *part = f3 + np * 2048;
+    if (np > n_patches)  // rows of the last 64-row tile that no patch writes
+        CAELO_HIP(hipMemsetAsync(f3 + n_patches * 2048, 0, (size_t)(np - n_patches) * 2048 * sizeof(float), s));
     const int64_t cap = 256 * 4;  // persistent-ish grids: weights stay in registers across patches
     const unsigned g1 = (unsigned)(n_patches < cap ? n_patches : cap);
+    if (ev) CAELO_HIP(hipEventRecord(ev[0], s));
     k_enc_stage1<<<g1, 256, 0, s>>>((const unsigned long long *)bits, n_patches, c->enc_w1, c->enc_b1, c->enc_w2,
                                     c->enc_b2, p2);
     CAELO_LAUNCH_CHECK();
+    if (ev) CAELO_HIP(hipEventRecord(ev[1], s));
     const int64_t pairs = (n_patches + 1) / 2;
     const unsigned g3 = (unsigned)(pairs < 512 ? pairs : 512);
     k_enc_conv3<<<g3, 256, 0, s>>>(p2, n_patches, c->enc_w3, c->enc_b3, f3);
     CAELO_LAUNCH_CHECK();
-    if (np > n_patches)  // rows of the last 64-row tile that no patch wrote
-        CAELO_HIP(hipMemsetAsync(f3 + n_patches * 2048, 0, (size_t)(np - n_patches) * 2048 * sizeof(float), s));
+    if (ev) CAELO_HIP(hipEventRecord(ev[2], s));
     dim3 gd((unsigned)(np / D1_BM), D1_SPLIT);
     k_enc_dense1<<<gd, 256, 0, s>>>(f3, np, c->enc_wd1, part);
     CAELO_LAUNCH_CHECK();
+    if (ev) CAELO_HIP(hipEventRecord(ev[3], s));
     k_enc_head<<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(part, n_patches, np, c->enc_bd1, c->enc_wd2, c->enc_bd2,
                                                                 group, out, out_stride);
     CAELO_LAUNCH_CHECK();
+    if (ev) CAELO_HIP(hipEventRecord(ev[4], s));
     return CAELO_OK;
+}
+
+CAELO_API int caelo_encode(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out,
+                           int out_stride, void *ws, void *stream) {
+    return encode_impl(c, bits, n_patches, group, out, out_stride, ws, caelo_stream(stream), nullptr);
+}
+
+// Same launches as caelo_encode with a HIP event between kernels on the launch stream; synchronises and
+// returns the four kernel durations in ms (stage1, conv3, dense1, head).  Measurement aid for bench.py.
+CAELO_API int caelo_encode_profile(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out,
+                                   int out_stride, void *ws, void *stream, float *ms_host) {
+    CAELO_REQUIRE(ms_host != nullptr, "null argument");
+    hipStream_t s = caelo_stream(stream);
+    hipEvent_t ev[5];
+    for (int i = 0; i < 5; ++i) CAELO_HIP(hipEventCreate(&ev[i]));
+    int rc = encode_impl(c, bits, n_patches, group, out, out_stride, ws, s, ev);
+    if (rc == CAELO_OK) {
+        CAELO_HIP(hipEventSynchronize(ev[4]));
+        for (int i = 0; i < 4; ++i) CAELO_HIP(hipEventElapsedTime(&ms_host[i], ev[i], ev[i + 1]));
+    }
+    for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
 }

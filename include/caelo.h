@@ -116,6 +116,11 @@ int64_t caelo_encode_ws_bytes(int64_t n_patches);
 int caelo_encode(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
                  void *ws, void *stream);
 
+/* caelo_encode with a HIP event between its four kernels (stage1 = conv1+pool1+conv2+pool2, conv3,
+ * dense1, head) on the launch stream; synchronises, writes the durations in ms to ms_host[4]. */
+int caelo_encode_profile(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches, int group, float *out,
+                         int out_stride, void *ws, void *stream, float *ms_host);
+
 /* NN match  (Match.py:257-258): pair_idx[j] = argmin_i ||f0[i]-f1[j]|| (f64, first minimum).
  * k0/k1 read from n0/n1 device words when non-null. */
 int caelo_match(caelo_ctx *ctx, const float *f0, int64_t k0_max, const int32_t *n0, const float *f1, int64_t k1_max,

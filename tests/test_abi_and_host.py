@@ -1,0 +1,94 @@
+"""CPU: the C-ABI library loads and exports every declared symbol; host-side logic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO, WEIGHTS
+
+
+def test_library_exports_every_declared_symbol():
+    from caelo import _ffi
+    lib = _ffi.load()
+    hdr = open(os.path.join(REPO, "include", "caelo.h")).read()
+    declared = set(re.findall(r"\b(caelo_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    typed = {name for name, _, _ in _ffi.SIGNATURES}
+    assert declared == typed, "header vs ctypes table: %s" % sorted(declared ^ typed)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.caelo_abi_version() == 1
+    assert ctypes.sizeof(_ffi.PoseResult) == (9 + 3 + 9 + 3 + 1) * 4 + 5 * 4
+
+
+def test_no_cpu_fallback():
+    import torch
+    from caelo import _ffi
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ctx = ctypes.c_void_p()
+    rc = _ffi.load().caelo_create(ctypes.byref(ctx), 0)
+    assert rc != 0 and _ffi.load().caelo_last_error()
+    from caelo.engine import Engine
+    with pytest.raises(_ffi.CaeloError):
+        Engine()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "cae-lo_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(root, f), errors="ignore").read()
+                assert "import oracle" not in txt and "liboracle" not in txt and "/root/reference" not in txt, f
+
+
+def test_h5lite_reads_keras_models():
+    from caelo.engine import read_keras_weights
+    kind, ws = read_keras_weights(os.path.join(WEIGHTS, "SphericalRingPCRespondLayer.h5"))
+    assert kind == "respond" and [w.shape for w in ws] == [(3, 3, 3, 32), (32,), (1, 1, 32, 8), (8,)]
+    kind, ws = read_keras_weights(os.path.join(WEIGHTS, "EncoderModel4VoxelPatch.h5"))
+    assert kind == "encoder" and ws[6].shape == (2048, 200) and ws[0].dtype == np.float32
+    # spot values pinned from h5py in the build container
+    assert abs(float(np.abs(ws[6]).max()) - 0.18720529973506927) < 1e-9
+    assert abs(float(np.abs(ws[8]).max()) - 0.7936325073242188) < 1e-9
+    import hashlib
+    sums = {"SphericalRingPCRespondLayer.h5": "34c9762bbe51f0c9a689943c6a71f4a258ddedb3da3ecb71818b9f1d6b349d45",
+            "EncoderModel4VoxelPatch.h5": "89d923f7ae625fda1e60e67d5fcbe6785539166f4401ac9138a24e64aa5ec527"}
+    for f, s in sums.items():
+        assert hashlib.sha256(open(os.path.join(WEIGHTS, f), "rb").read()).hexdigest() == s
+
+
+def test_frame_sharding_helpers():
+    from caelo import dist as cd
+    for n, w in ((10, 4), (8, 8), (4541, 8), (7, 3), (3, 4)):
+        blocks = [cd.shard_frames(n, r, w) for r in range(w)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == n
+        assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
+        assert max(b[1] - b[0] for b in blocks) - min(b[1] - b[0] for b in blocks) <= 1
+        for f in range(n):
+            r = cd.owner_of(f, n, w)
+            assert blocks[r][0] <= f < blocks[r][1]
+        pairs = sum((cd.local_pairs(n, r, w) for r in range(w)), [])
+        assert pairs == [(f - 1, f) for f in range(1, n)]
+
+
+def test_pose_chaining_matches_float32_reference_formula():
+    from caelo import dist as cd
+    from caelo import synth
+    rel = []
+    for f in range(5):
+        R, T = synth.relative_pose_gt(f, f + 1)
+        rel.append(np.r_[R.reshape(9), T.reshape(3)])
+    poses = cd.chain_poses(np.array(rel, np.float32))
+    assert poses.shape == (6, 12) and poses.dtype == np.float32
+    # with Tr = I the chained pose of frame f is the sensor pose of frame f
+    (t, yaw) = synth.sensor_pose(5)
+    assert np.allclose(poses[5].reshape(3, 4)[:, 3], t, atol=1e-4)
+    assert abs(np.arctan2(poses[5][4], poses[5][0]) - yaw) < 1e-5
+    # a non-trivial calibration conjugates the motion (PoseEstimation.py:259-262)
+    Tr = np.array([[0, -1, 0, 0.1], [0, 0, -1, -0.2], [1, 0, 0, 0.3]], np.float32)
+    p2 = cd.chain_poses(np.array(rel, np.float32), Tr)
+    assert np.allclose(p2[1].reshape(3, 4)[:, :3] @ p2[1].reshape(3, 4)[:, :3].T, np.eye(3), atol=1e-5)

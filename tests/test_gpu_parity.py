@@ -1,0 +1,288 @@
+"""GPU parity tests proper: the HIP path, called through the reference-shaped API (caelo.api ->
+ctypes -> C ABI), against the CPU oracle on the same seeded inputs and against the golden fixtures
+generated from the reference.  Bar: bit-exact for indices / bytes / integer work, <= 1e-4 relative
+for descriptors and poses (BASELINE.json north_star)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, WEIGHTS
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4  # north_star: descriptors / poses within 1e-4 relative
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def api(engine):
+    from caelo import api as _api
+    return _api
+
+
+@pytest.fixture(scope="module")
+def f0(orc, models, scans):
+    pc = scans(0)
+    ring, cnt = orc.ProjectPC2SphericalRing(pc)
+    resp = models[0].predict(ring[None, 0:64, 0:1792, 0:3])[0]
+    kp, kpix, _ = orc.GetKeyPtsByAE(ring, cnt, resp)
+    vox = orc.Voxelization(pc[:, 0:3])
+    return dict(pc=pc, ring=ring, cnt=cnt, resp=resp, kp=kp, kpix=kpix, A=(vox[6], vox[7], vox[8]),
+                g=np.load(os.path.join(GOLDEN, "frame_0.npz")))
+
+
+# ---- projection -----------------------------------------------------------------------------------
+def test_project_bit_exact(api, f0):
+    ring, cnt = api.ProjectPC2SphericalRing(f0["pc"])
+    assert ring.dtype == np.float32 and ring.shape == (69, 1800, 5) and cnt.dtype == np.int32
+    assert np.array_equal(ring, f0["ring"]) and np.array_equal(cnt, f0["cnt"])
+    assert sha(ring) == str(f0["g"]["ring_sha256"]) and sha(cnt) == str(f0["g"]["counter_sha256"])
+
+
+def test_project_edge_cases(api, orc, scans):
+    pc = scans(0)[:5000].copy()
+    pc[10] = 0.0               # zero range dropped
+    pc[11, 0:3] = (0.0, 0.0, 5.0)   # straight up: row < 0, skipped
+    pc[12:20] = pc[20]         # duplicates: overwrite + counter
+    ring, cnt = api.ProjectPC2SphericalRing(pc)
+    o_ring, o_cnt = orc.ProjectPC2SphericalRing(pc)
+    assert np.array_equal(ring, o_ring) and np.array_equal(cnt, o_cnt) and cnt.max() >= 9
+    pc[7, 0:3] = (-10.0, -0.0, 0.0)  # column 1800
+    with pytest.raises(IndexError):
+        api.ProjectPC2SphericalRing(pc)
+    with pytest.raises(AssertionError):
+        api.ProjectPC2SphericalRing(pc[:3])
+
+
+def test_project_dense_scan(api, orc, scans):
+    pc = scans(0, 128, 4000)  # 504k points, many pixels hit several times
+    ring, cnt = api.ProjectPC2SphericalRing(pc)
+    g = np.load(os.path.join(GOLDEN, "frame_dense128.npz"))
+    assert sha(ring) == str(g["ring_sha256"]) and sha(cnt) == str(g["counter_sha256"])
+
+
+# ---- response layer + keypoints ---------------------------------------------------------------------
+def test_load_model_and_response_layer_bit_exact(api, f0):
+    net = api.load_model(os.path.join(WEIGHTS, "SphericalRingPCRespondLayer.h5"))
+    x = np.ascontiguousarray(f0["ring"][0:64, 0:1792, 0:3]).reshape(1, 64, 1792, 3)
+    resp = net.predict(x)
+    assert resp.shape == (1, 64, 1792, 8) and resp.dtype == np.float32
+    assert np.array_equal(resp[0], f0["resp"])
+    assert sha(resp[0]) == str(f0["g"]["respond_sha256"])
+
+
+def test_keypoints_bit_exact_both_modes(api, f0):
+    kp, kpix, planar = api.GetKeyPtsByAE(f0["ring"], f0["cnt"], f0["resp"])
+    assert kpix.dtype == np.int64 and kp.dtype == np.float32 and planar.size == 0
+    assert np.array_equal(kpix, f0["g"]["keypixels_demo"].astype(np.int64))   # golden from the reference
+    assert np.array_equal(kp, f0["g"]["keypts_demo"])
+    ring3 = np.ascontiguousarray(f0["ring"][0:64, 0:1792, 0:3])
+    cnt3 = np.array(f0["cnt"][0:64, 0:1792], dtype=np.int8)                   # BatchPreprocess.py:98
+    _, kpix_b, _ = api.GetKeyPtsByAE(ring3, cnt3, f0["resp"])
+    assert np.array_equal(kpix_b, f0["g"]["keypixels_batch"].astype(np.int64))
+
+
+def test_keypoints_ragged_and_too_few(api, orc, f0):
+    # thin the scan: fewer than 1025 candidates -> K = candidates - 1 (SphericalRing.py:216)
+    for cut in (100, 80, 70, 60):
+        cnt = f0["cnt"].copy()
+        cnt[:, cut:] = 0
+        o = orc.GetKeyPtsByAE(f0["ring"], cnt, f0["resp"])
+        if len(o[1]) < 1024:
+            break
+    kp, kpix, _ = api.GetKeyPtsByAE(f0["ring"], cnt, f0["resp"])
+    assert 50 < len(kpix) < 1024 and np.array_equal(kpix, o[1]) and np.array_equal(kp, o[0])
+    cnt[:, 9:] = 0  # one usable column: at most 48 candidates
+    with pytest.raises(AssertionError):
+        api.GetKeyPtsByAE(f0["ring"], cnt, f0["resp"])
+
+
+def test_keypoints_dense_scan_golden(api, orc, models, scans):
+    g = np.load(os.path.join(GOLDEN, "frame_dense128.npz"))
+    ring, cnt = api.ProjectPC2SphericalRing(scans(0, 128, 4000))
+    resp = api.load_model(os.path.join(WEIGHTS, "SphericalRingPCRespondLayer.h5")).predict(
+        np.ascontiguousarray(ring[0:64, 0:1792, 0:3]).reshape(1, 64, 1792, 3))[0]
+    assert sha(resp) == str(g["respond_sha256"])
+    _, kpix, _ = api.GetKeyPtsByAE(ring, cnt, resp)
+    assert np.array_equal(kpix, g["keypixels_demo"].astype(np.int64))
+
+
+# ---- voxelization + patches ---------------------------------------------------------------------------
+def test_voxelization_lists_bit_exact_incl_order(api, f0):
+    out = api.Voxelization(f0["pc"][:, 0:3])
+    assert len(out) == 9
+    for a, b in zip(out[6:9], f0["A"]):
+        assert a.dtype == np.int16 and np.array_equal(a, b)
+    assert sha(out[6]) == str(f0["g"]["voxels0_sha256"]) and sha(out[7]) == str(f0["g"]["voxels1_sha256"])
+
+
+def test_voxelization_dense_scan_golden(api, scans):
+    g = np.load(os.path.join(GOLDEN, "frame_dense128.npz"))
+    out = api.Voxelization(scans(0, 128, 4000)[:, 0:3])
+    assert [len(out[6]), len(out[7]), len(out[8])] == g["voxel_counts"].tolist()
+    assert sha(out[6]) == str(g["voxels0_sha256"]) and sha(out[7]) == str(g["voxels1_sha256"])
+    assert np.array_equal(out[8], g["voxels2"])
+
+
+def test_voxelization_filters_far_points(api, orc, scans):
+    pc = scans(1)[:20000, 0:3].copy()
+    pc[5] = (150.0, 0.0, 0.0)
+    pc[6] = (0.0, 0.0, 20.0)
+    pc[7] = (99.83, -99.83, 14.71)
+    out = api.Voxelization(pc)
+    o = orc.Voxelization(pc)
+    for a, b in zip(out[6:9], o[6:9]):
+        assert np.array_equal(a, b)
+
+
+def test_patches_bit_exact(api, orc, f0):
+    g = f0["g"]
+    pts, plist = api.GetPatchesList(g["patch_kp"], *f0["A"])
+    assert len(plist) == 3 and plist[0].shape == (1024, 16, 16, 16, 1) and plist[0].dtype == np.float32
+    for s in range(3):
+        assert np.array_equal(orc.pack_patches(plist[s]), g["patch_bits"][:, s]), "scale %d vs reference golden" % s
+    assert set(np.unique(plist[1])) <= {0.0, 1.0}
+
+
+def test_patches_truncation_taxonomy(api, orc):
+    g = np.load(os.path.join(GOLDEN, "patch_truncation.npz"))
+    for name in ("sparse", "mid", "dense"):
+        vox, pts = g[name + "_vox"], g[name + "_pts"]
+        bits, flags = api.GetPatchesBits(pts, vox, vox, vox)
+        b = bits[:, 1].cpu().numpy().view(np.uint64)
+        fl = flags[:, 1].cpu().numpy()
+        ob, of = orc.patches_bits(pts, vox, 1)
+        assert np.array_equal(fl, of) and np.array_equal(b, ob)            # oracle, incl. canonical tie rule
+        unamb = (of & 2) == 0
+        assert np.array_equal(b[unamb], g[name + "_bits"][unamb])           # reference (sklearn 496-NN)
+    with pytest.raises(ValueError):
+        api.GetPatchesList(g["sparse_pts"], g["sparse_vox"][:100], g["sparse_vox"], g["sparse_vox"])
+
+
+def test_patch_pack_unpack_round_trip(engine, f0):
+    import torch
+    bits = torch.from_numpy(f0["g"]["patch_bits"].view(np.int64)).to(engine.device)
+    dense = engine.unpack_patches(bits)
+    assert float(dense.sum()) == float(np.unpackbits(f0["g"]["patch_bits"].view(np.uint8)).sum())
+    assert torch.equal(engine.pack_patches(dense).reshape(bits.shape), bits)
+
+
+# ---- encoder -----------------------------------------------------------------------------------------
+def test_descriptors_within_tolerance(api, orc, models, f0):
+    g = f0["g"]
+    enc = api.load_model(os.path.join(WEIGHTS, "EncoderModel4VoxelPatch.h5"))
+    plist = [orc.unpack_patches(g["patch_bits"][:, s]) for s in range(3)]
+    feats = api.GetFeaturesFromPatches(enc, plist)
+    assert feats.shape == (1024, 60) and feats.dtype == np.float32
+    err = np.abs(feats - g["features"]).max() / np.abs(g["features"]).max()
+    assert err <= REL_TOL, err
+    assert np.abs(feats).max() < 1.0  # tanh output layer (the shipped .h5, not the stale script)
+
+
+def test_encoder_edge_patches_and_batch_independence(engine, models):
+    import torch
+    rs = np.random.RandomState(3)
+    bits = np.zeros((70, 64), np.uint64)
+    bits[1] = ~np.uint64(0)                                   # full patch
+    bits[2, 0] = 1                                            # single voxel at [0,0,0]
+    bits[3, 63] = np.uint64(1) << np.uint64(63)               # single voxel at [15,15,15]
+    for i in range(4, 70):
+        dense = rs.uniform(size=4096) < rs.choice([0.002, 0.02, 0.2])
+        bits[i] = np.packbits(dense, bitorder="little").view(np.uint64)
+    of = models[1].predict_bits(bits)
+    gb = torch.from_numpy(bits.view(np.int64)).to(engine.device)
+    f = engine.encode(gb, group=1)
+    assert np.abs(f.cpu().numpy() - of).max() <= REL_TOL * np.abs(of).max()
+    perm = torch.from_numpy(rs.permutation(70)).to(engine.device)
+    f2 = engine.encode(gb[perm].contiguous(), group=1)
+    assert torch.equal(f2, f[perm])                           # position in the batch never matters, bitwise
+    f3 = engine.encode(gb[:69].contiguous(), group=3)         # grouped scatter == plain predict
+    assert torch.equal(f3.reshape(69, 20), f[:69])
+
+
+# ---- match + pose ---------------------------------------------------------------------------------------
+def test_match_bit_exact_and_ties(engine, orc):
+    import torch
+    f0 = np.load(os.path.join(GOLDEN, "frame_0.npz"))["features"]
+    f1 = np.load(os.path.join(GOLDEN, "frame_1.npz"))["features"]
+    g = np.load(os.path.join(GOLDEN, "pair_0_1.npz"))
+    idx = engine.match(torch.from_numpy(f0).to(engine.device), torch.from_numpy(f1).to(engine.device)).cpu().numpy()
+    assert np.array_equal(idx, g["pair_idx"].astype(np.int64))          # reference cdist + argmin
+    # ragged sizes and exact ties (duplicated rows -> first minimum wins, Match.py:258)
+    a = np.concatenate([f0[:300], f0[:50]])
+    b = f0[:77]
+    idx = engine.match(torch.from_numpy(a).to(engine.device), torch.from_numpy(b).to(engine.device)).cpu().numpy()
+    assert np.array_equal(idx, orc.match(a, b)[0]) and np.array_equal(idx[:50], np.arange(50))
+
+
+def test_relative_pose_vs_reference_golden(api):
+    f0 = np.load(os.path.join(GOLDEN, "frame_0.npz"))
+    f1 = np.load(os.path.join(GOLDEN, "frame_1.npz"))
+    g = np.load(os.path.join(GOLDEN, "pair_0_1.npz"))
+    for s in range(4):
+        rng = np.random.RandomState(s)
+        R, T, ok, i0, i1, thr = api.SolveRelativePose(f0["keypts_demo"], f0["features"], None, f1["keypts_demo"],
+                                                      f1["features"], None, rng=rng)
+        assert ok == bool(g["s%d_ok" % s]) and thr == float(g["s%d_thr" % s])
+        assert np.array_equal(i0, g["s%d_idx0" % s]) and np.array_equal(i1, g["s%d_idx1" % s])  # inlier sets, bit-exact
+        assert np.abs(R - g["s%d_R" % s]).max() <= REL_TOL
+        assert np.abs(T - g["s%d_T" % s]).max() <= REL_TOL * max(1.0, np.abs(g["s%d_T" % s]).max())
+        # the RNG stream advanced exactly as the reference's loop would have (4 draws per iteration)
+        ref = np.random.RandomState(s)
+        ref.random_sample(4 * int(g["s%d_iters" % s]))
+        assert rng.random_sample() == ref.random_sample()
+
+
+def test_ransac_escalation_failure_and_round_trip(api, orc):
+    g = np.load(os.path.join(GOLDEN, "pair_0_1.npz"))
+    for name in ("esc", "fail"):
+        R, T, ok, mask, thr = api.RANSAC4RT(g[name + "_P0"], g[name + "_P1"], None, None, rng=np.random.RandomState(7))
+        assert ok == bool(g[name + "_ok"]) and thr == float(g[name + "_thr"]) and np.array_equal(mask, g[name + "_mask"])
+        if ok:
+            assert np.abs(R - g[name + "_R"]).max() <= 1e-4 and np.abs(T - g[name + "_T"]).max() <= 1e-3
+        else:
+            assert np.array_equal(R, np.eye(3, dtype=np.float32)) and not T.any()
+    # round trip: a known rigid motion of 1024 points + 40 % outliers is recovered
+    from caelo import synth
+    rs = np.random.RandomState(11)
+    P1 = rs.uniform(-40, 40, (1024, 3)).astype(np.float32)
+    Rg, Tg = synth.relative_pose_gt(0, 3)
+    P0 = (P1 @ Rg.T + Tg.T).astype(np.float32)
+    bad = rs.uniform(size=1024) < 0.4
+    P0[bad] = rs.uniform(-40, 40, (int(bad.sum()), 3)).astype(np.float32)
+    R, T, ok, mask, thr = api.RANSAC4RT(P0, P1, None, None, rng=np.random.RandomState(1))
+    assert ok and thr == 0.4 and np.array_equal(mask, ~bad)
+    Rr, Tr, cred = api.SolveRT(P0[mask], P1[mask])
+    assert cred == 1 and np.abs(Rr - Rg).max() < 1e-5 and np.abs(Tr - Tg).max() < 1e-4
+    oR, oT, _ = orc.SolveRT(P0[mask], P1[mask])
+    assert np.abs(Rr - oR).max() <= REL_TOL and np.abs(Tr - oT).max() <= REL_TOL * max(1.0, np.abs(oT).max())
+
+
+def test_solve_rt_reflection_quirk(api, orc):
+    # mirrored point sets: det(R) < 0 -> the reference flips a COLUMN of Vh (Match.py:151-155)
+    rs = np.random.RandomState(5)
+    P1 = rs.uniform(-5, 5, (50, 3)).astype(np.float32)
+    P0 = P1 * np.array([1, 1, -1], np.float32) + 0.5
+    R, T, cred = api.SolveRT(P0, P1)
+    oR, oT, oc = orc.SolveRT(P0, P1)
+    assert cred == oc == -1
+    assert np.abs(R - oR).max() <= 1e-4 and np.abs(T - oT).max() <= 1e-3
+
+
+# ---- fused path ---------------------------------------------------------------------------------------
+def test_fused_extract_equals_staged_path(engine, orc, models, f0):
+    import torch
+    ff = engine.extract(torch.from_numpy(f0["pc"]).to(engine.device))
+    k = int(ff.n_key.item())
+    assert k == 1024 and int(ff.status.item()) == 0
+    assert np.array_equal(ff.key_pixels.cpu().numpy(), f0["kpix"])
+    assert np.array_equal(ff.key_pts.cpu().numpy(), f0["kp"])
+    err = np.abs(ff.features.cpu().numpy() - f0["g"]["features"]).max() / np.abs(f0["g"]["features"]).max()
+    assert err <= REL_TOL
+    ffb = engine.extract(torch.from_numpy(f0["pc"]).to(engine.device), dist_channels=3)
+    assert np.array_equal(ffb.key_pixels.cpu().numpy(), f0["g"]["keypixels_batch"].astype(np.int64))
