@@ -107,21 +107,14 @@ def main():
     rand = [torch.from_numpy(ransac_draws(1000 + rank * 7919 + i)).to(dev) for i in range(POOL)]
     n_points = int(np.mean([p.shape[0] for p in pool]))
 
-    def rows_of(ff):
-        return cdist.pack_rows(ff.key_pts, ff.features, ff.n_key)
-
-    def ff_from_rows(rows):
-        kp, ft, nk = cdist.unpack_rows(rows)
-        return FrameFeatures(kp, None, ft, nk, None, None)
-
     def run(steps, prev):
         """extract `steps` frames, all-gather their rows, match each frame with its predecessor."""
-        feats = [eng.extract(pool[i % POOL]) for i in range(steps)]
-        local = torch.stack([rows_of(f) for f in feats])              # [steps, 1024, 64]
+        local = eng.empty((steps, 1024, 64), torch.float32)             # the all-gather payload, written in place
+        feats = [eng.extract(pool[i % POOL], rows=local[i]) for i in range(steps)]
         if world > 1:
             allrows = cdist.all_gather_frames(local, steps * world)    # ONE collective over xGMI
             if rank > 0:
-                prev = ff_from_rows(allrows[rank * steps - 1])
+                prev = FrameFeatures.from_rows(allrows[rank * steps - 1])
         results = []
         for i in range(steps):
             res, mask, _ = eng.match_pose(prev, feats[i], rand[i % POOL])
@@ -148,12 +141,12 @@ def main():
         dt = float(tmax.item())
     # sanity: every pose solved (not timed)
     ok = sum(int(eng.pose_result(r).success) for r in results)
-    status = int(prev.status.item()) if prev.status is not None else 0
+    status = int(prev.status[0].item()) if prev.status is not None else 0
 
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel, HIP events on the launch stream ----------------------
-        bits, _ = eng.patches(eng.voxelize(pool[0])[0], eng.extract(pool[0]).key_pts)
+        bits, _ = eng.patches(eng.voxelize(pool[0])[0], eng.extract(pool[0]).key_pts.contiguous())
         n_patches = bits.numel() // 64
         for _ in range(3):
             eng.encode_profile(bits, group=3)

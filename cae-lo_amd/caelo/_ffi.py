@@ -33,6 +33,7 @@ SIGNATURES = [
     ("caelo_set_encoder_weights", c_int, [c_vp] + [c_vp] * 10),
     ("caelo_project", c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("caelo_respond", c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    ("caelo_keypoints_ws_bytes", c_i64, []),
     ("caelo_keypoints", c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("caelo_voxmap_create", c_int, [c_vp, c_i64, C.POINTER(c_vp)]),
     ("caelo_voxmap_destroy", None, [c_vp]),
@@ -45,10 +46,13 @@ SIGNATURES = [
     ("caelo_encode_ws_bytes", c_i64, [c_i64]),
     ("caelo_encode", c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp]),
     ("caelo_encode_profile", c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
-    ("caelo_match", c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_vp]),
+    ("caelo_match", c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_vp]),
     ("caelo_solve_rt", c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     ("caelo_ransac_ws_bytes", c_i64, []),
-    ("caelo_ransac", c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    ("caelo_ransac", c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    ("caelo_extract_ws_bytes", c_i64, []),
+    ("caelo_extract", c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp,
+                              c_vp, c_vp]),
 ]
 
 _lib = None

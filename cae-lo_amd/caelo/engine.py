@@ -20,7 +20,7 @@ RING_H, RING_W, RING_C = 69, 1800, 5
 NET_H, NET_W = 64, 1792
 MAX_K = 1024
 
-ST_COL_OOB, ST_VOXEL_OOB, ST_MAP_FULL, ST_FEW_VOXELS, ST_FEW_KEYPTS = 1, 2, 4, 8, 16
+ST_COL_OOB, ST_VOXEL_OOB, ST_MAP_FULL, ST_FEW_VOXELS, ST_FEW_KEYPTS, ST_VOXEL_INEXACT = 1, 2, 4, 8, 16, 32
 
 _DEFAULT_WEIGHTS = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "weights")
 RESPOND_H5 = os.path.join(_DEFAULT_WEIGHTS, "SphericalRingPCRespondLayer.h5")
@@ -87,16 +87,25 @@ class VoxelMap:
 
 
 class FrameFeatures:
-    """Device-resident result of Engine.extract for one scan."""
-    __slots__ = ("key_pts", "key_pixels", "features", "n_key", "status", "flags")
+    """Device-resident result of Engine.extract for one scan.  ``rows`` [1024,64] f32 holds
+    xyz (cols 0:3) | 60-d descriptor (3:63) | valid flag (63): the unit the multi-GPU all-gather
+    moves; key_pts / features are strided views into it."""
+    __slots__ = ("rows", "key_pts", "key_pixels", "features", "n_key", "status", "flags")
 
-    def __init__(self, key_pts, key_pixels, features, n_key, status, flags):
-        self.key_pts, self.key_pixels, self.features = key_pts, key_pixels, features
-        self.n_key, self.status, self.flags = n_key, status, flags
+    def __init__(self, rows, key_pixels, n_key, status, flags):
+        self.rows = rows
+        self.key_pts, self.features = rows[:, 0:3], rows[:, 3:63]
+        self.key_pixels, self.n_key, self.status, self.flags = key_pixels, n_key, status, flags
+
+    @classmethod
+    def from_rows(cls, rows):
+        """Rebuild from gathered rows (another rank's frame): n_key = number of valid rows."""
+        n_key = rows[:, 63].sum().round().to(torch.int32).reshape(1)
+        return cls(rows, None, n_key, None, None)
 
 
 class Engine:
-    def __init__(self, respond_h5=RESPOND_H5, encoder_h5=ENCODER_H5, device=None, max_points=1 << 18):
+    def __init__(self, respond_h5=RESPOND_H5, encoder_h5=ENCODER_H5, device=None, max_points=1 << 17):
         if not torch.cuda.is_available():
             raise _ffi.CaeloError("no HIP device visible: libcaelo has no CPU fallback")
         self.lib = _ffi.load()
@@ -110,6 +119,8 @@ class Engine:
         self._maps = {}
         self._enc_ws = None
         self._ransac_ws = torch.empty(int(self.lib.caelo_ransac_ws_bytes()), dtype=torch.uint8, device=self.device)
+        self._kp_ws = torch.empty(int(self.lib.caelo_keypoints_ws_bytes()), dtype=torch.uint8, device=self.device)
+        self._extract_ws = None
         if respond_h5:
             self.load_weights(respond_h5)
         if encoder_h5:
@@ -177,13 +188,12 @@ class Engine:
     def keypoints(self, ring, counter, resp, status=None):
         assert ring.dtype == torch.float32 and counter.dtype == torch.int32 and resp.dtype == torch.float32
         assert ring.is_contiguous() and counter.is_contiguous() and resp.is_contiguous()
-        cand = self.empty((NET_H * NET_W,), torch.int64)
         kpix = self.zeros((MAX_K, 2), torch.int64)
         kpts = self.zeros((MAX_K, 3), torch.float32)
         nkey = self.empty((1,), torch.int32)
         status = self.zeros((1,), torch.int32) if status is None else status
         _ffi.check(self.lib.caelo_keypoints(self.ctx, _ptr(ring), ring.shape[1], ring.shape[2], _ptr(counter),
-                                            counter.shape[1], _ptr(resp), _ptr(cand), _ptr(kpix), _ptr(kpts),
+                                            counter.shape[1], _ptr(resp), _ptr(self._kp_ws), _ptr(kpix), _ptr(kpts),
                                             _ptr(nkey), _ptr(status), self.stream))
         return kpts, kpix, nkey, status
 
@@ -255,11 +265,16 @@ class Engine:
                                                  self.stream, C.cast(ms, C.c_void_p)))
         return out, list(ms)
 
+    @staticmethod
+    def _ld(t):
+        assert t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1
+        return int(t.stride(0))
+
     def match(self, f0, f1, n0=None, n1=None):
-        assert f0.dtype == torch.float32 and f1.dtype == torch.float32 and f0.is_contiguous() and f1.is_contiguous()
+        """f0 [k0,dim], f1 [k1,dim] (row-strided views allowed) -> pair_idx [k1] int64."""
         idx = self.zeros((f1.shape[0],), torch.int64)
-        _ffi.check(self.lib.caelo_match(self.ctx, _ptr(f0), f0.shape[0], _ptr(n0), _ptr(f1), f1.shape[0], _ptr(n1),
-                                        f0.shape[1], _ptr(idx), self.stream))
+        _ffi.check(self.lib.caelo_match(self.ctx, _ptr(f0), self._ld(f0), f0.shape[0], _ptr(n0), _ptr(f1), self._ld(f1),
+                                        f1.shape[0], _ptr(n1), f0.shape[1], _ptr(idx), self.stream))
         return idx
 
     def solve_rt(self, p0, p1):
@@ -272,12 +287,13 @@ class Engine:
 
     def ransac(self, pc0, pc1, pair_idx, rand, n1=None):
         """rand: [1500,4] f64 uniform draws (device).  -> (result bytes tensor, mask [k1] uint8)."""
-        assert pc0.dtype == torch.float32 and pc1.dtype == torch.float32 and pair_idx.dtype == torch.int64
+        assert pair_idx.dtype == torch.int64 and pair_idx.is_contiguous()
         assert rand.dtype == torch.float64 and rand.numel() >= 6000 and rand.is_contiguous()
-        res = self.zeros((C.sizeof(_ffi.PoseResult),), torch.uint8)
+        res = self.empty((C.sizeof(_ffi.PoseResult),), torch.uint8)
         mask = self.empty((pc1.shape[0],), torch.uint8)
-        _ffi.check(self.lib.caelo_ransac(self.ctx, _ptr(pc0), _ptr(pc1), _ptr(pair_idx), pc1.shape[0], _ptr(n1),
-                                         _ptr(rand), _ptr(res), _ptr(mask), _ptr(self._ransac_ws), self.stream))
+        _ffi.check(self.lib.caelo_ransac(self.ctx, _ptr(pc0), self._ld(pc0), _ptr(pc1), self._ld(pc1), _ptr(pair_idx),
+                                         pc1.shape[0], _ptr(n1), _ptr(rand), _ptr(res), _ptr(mask),
+                                         _ptr(self._ransac_ws), self.stream))
         return res, mask
 
     @staticmethod
@@ -286,24 +302,40 @@ class Engine:
         return _ffi.PoseResult.from_buffer_copy(res.cpu().numpy().tobytes())
 
     # ---- fused hot path ------------------------------------------------------------------------------
-    def extract(self, pc, dist_channels=5, vmap=None):
-        """scan [N,4] f32 (device) -> FrameFeatures, all on device, no host sync.
+    def extract(self, pc, dist_channels=5, vmap=None, rows=None, exact_voxels=False):
+        """scan [N,4] f32 (device) -> FrameFeatures, ONE C-ABI call (caelo_extract), no host sync:
         project -> response CNN -> keypoints -> voxelize -> patch gather -> 3x encoder.
         dist_channels: 5 = demo calling mode (SphericalRing.py:414), 3 = batch mode
-        (BatchPreprocess.py:97-98,131-136)."""
-        status = self.zeros((1,), torch.int32)
-        ring, counter, _ = self.project(pc, status)
-        resp = self.respond(ring)
-        if dist_channels == 5:
-            kpts, kpix, nkey, _ = self.keypoints(ring, counter, resp, status)
-        else:
-            ring3 = ring[0:NET_H, 0:NET_W, 0:3].contiguous()
-            cnt3 = counter[0:NET_H, 0:NET_W].contiguous()
-            kpts, kpix, nkey, _ = self.keypoints(ring3, cnt3, resp, status)
-        vmap, _ = self.voxelize(pc, vmap, status)
-        bits, flags = self.patches(vmap, kpts, nkey, status)
-        feats = self.encode(bits, group=3)
-        return FrameFeatures(kpts, kpix, feats, nkey, status, flags)
+        (BatchPreprocess.py:97-98,131-136).  ``rows``: optional [1024,64] f32 output slot.
+        The default one-pass voxelization flags (status bit ST_VOXEL_INEXACT) the ~1e-10-probability
+        frame in which a point lies within an ulp of a voxel face; ``checked()`` re-runs such a frame
+        with ``exact_voxels=True`` (the two-pass first-touch rule of Voxel.py:139-141)."""
+        assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] == 4 and pc.is_contiguous()
+        if self._extract_ws is None:
+            self._extract_ws = torch.empty(int(self.lib.caelo_extract_ws_bytes()), dtype=torch.uint8, device=self.device)
+        vmap = vmap or self.voxmap(max(self.max_points, pc.shape[0]))
+        rows = self.empty((MAX_K, 64), torch.float32) if rows is None else rows
+        assert rows.shape == (MAX_K, 64) and rows.is_contiguous()
+        kpix = self.empty((MAX_K, 2), torch.int64)
+        nkey = self.empty((1,), torch.int32)
+        flags = self.empty((MAX_K, 3), torch.uint8)
+        status = self.empty((4,), torch.int32)
+        base = rows.data_ptr()
+        _ffi.check(self.lib.caelo_extract(self.ctx, vmap.h, _ptr(pc), pc.shape[0], dist_channels, 1 if exact_voxels else 0,
+                                          C.c_void_p(base), 64, C.c_void_p(base + 12), 64, C.c_void_p(base + 252), 64,
+                                          _ptr(kpix), _ptr(nkey), _ptr(flags), _ptr(status), _ptr(self._extract_ws),
+                                          self.stream))
+        return FrameFeatures(rows, kpix, nkey, status, flags)
+
+    def checked(self, ff, pc, dist_channels=5):
+        """Synchronising status check of an extract() result: raises what the reference would raise,
+        transparently re-extracts with exact voxelization when the fast path flagged the frame."""
+        st = int(ff.status[0].item())
+        if st & ST_VOXEL_INEXACT:
+            ff = self.extract(pc, dist_channels, rows=ff.rows, exact_voxels=True)
+            st = int(ff.status[0].item())
+        raise_status(st)
+        return ff
 
     def match_pose(self, fa, fb, rand):
         """Relative pose between two FrameFeatures (frame0 = fa, frame1 = fb), Match.py:241-283."""

@@ -49,6 +49,7 @@ struct caelo_ctx {
     float *enc_b1;   // [8]
     float *enc_w2;   // [27][8][16] (Keras order)
     float *enc_b2;   // [16]
+    float *enc_c0;   // [512][16] conv2 response of the all-background patch incl. bias, then bg[8]
     float *enc_w3;   // [27][16][32]
     float *enc_b3;   // [32]
     float *enc_wd1;  // [2048][208] (N padded 200 -> 208 with zeros)
@@ -73,15 +74,54 @@ struct caelo_brick_table {
 struct caelo_voxmap {
     int64_t max_points;
     caelo_brick_table brick[3];
-    // voxel-level first-touch tables (value = smallest inserting point index)
+    // voxel-level first-touch tables (value = smallest inserting point index, 0xFFFFFFFF = none)
     unsigned long long *vkeys[3];
-    int32_t *vfirst[3];
+    uint32_t *vfirst[3];
     uint32_t vmask[3];
-    int32_t *counts;  // [4] device: unique voxels per scale, [3] = spare
+    int32_t *counts;  // [16] device ints: [0..2] unique voxels per scale, [4],[5] lengths of list0/list1
+    uint32_t *list0, *list1;  // slots of the occupied scale-0 / scale-1 bricks, in insertion order (fast path)
+    // One allocation, two clear regions (MI355X: two large fills instead of thirteen small ones):
+    //   ff region (cleared to 0xFF): brick keys x3 | vkeys0 | vfirst0 || vkeys1 | vkeys2 | vfirst1 | vfirst2
+    //   zero region (cleared to 0):  brick bits x3 | counts
+    // Without first-touch order tracking only the part of the ff region before `||` is cleared.
+    char *base;
+    size_t ff_bytes_keys, ff_bytes_min, ff_bytes_all, zero_off, zero_bytes, total_bytes;
     // export scratch
     void *scratch;
     int64_t scratch_bytes;
 };
+
+// a (pointer, bytes, byte value) triple for the multi-buffer clear kernel (frame.hip)
+struct caelo_clear_item {
+    void *ptr;
+    size_t bytes;  // multiple of 16
+    uint32_t pattern;
+};
+#define CAELO_CLEAR_MAX 8
+struct caelo_clear_list {
+    caelo_clear_item item[CAELO_CLEAR_MAX];
+    int n;
+};
+int caelo_clear_many(const caelo_clear_list &list, hipStream_t s);
+
+// internal launchers shared by the staged entry points and the fused caelo_extract (no clears inside)
+int ring_project_launch(const float *pc, int64_t n, float *ring, int32_t *counter, int32_t *winner, int32_t *status,
+                        hipStream_t s);
+int ring_respond_launch(caelo_ctx *c, const float *in, int in_w, int in_c, float *resp, hipStream_t s);
+int ring_keypoints_launch(const float *ring, int ring_w, int ring_c, int dist_c, const int32_t *counter, int cnt_w,
+                          const float *resp, unsigned long long *cand, uint32_t *hist, int32_t *cand_count,
+                          int64_t *key_pixels, float *key_pts, int kp_ld, float *valid, int valid_ld, int32_t *n_key,
+                          int32_t *status, hipStream_t s);
+void vox_clear_items(caelo_voxmap *m, int level, caelo_clear_list &list);  // 0 brick keys only, 1 + scale-0 first-touch table, 2 everything
+int vox_build_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, bool track_order, int32_t *status,
+                     hipStream_t s);
+int vox_build_fast_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, int32_t *status, hipStream_t s);
+int vox_patches_launch(const caelo_voxmap *m, const float *pts, int pts_ld, int64_t k_max, const int32_t *n_key,
+                       uint64_t *bits, uint8_t *flags, int32_t *status, bool check_counts, hipStream_t s);
+int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride, void *ws,
+                hipStream_t s, hipEvent_t *ev);
+
+#define CAELO_KP_HIST_BINS 65536
 
 __host__ __device__ inline unsigned long long caelo_pack3(int x, int y, int z) {
     return ((unsigned long long)(unsigned)(x & 0xFFFFF) << 40) | ((unsigned long long)(unsigned)(y & 0xFFFFF) << 20) |

@@ -18,6 +18,8 @@
 //                 A fragments by conflict-free ds_read_b128 from four 4-channel LDS planes.
 //   k_enc_dense1  split-K GEMM [patches,2048]x[2048,208] through LDS tiles.
 //   k_enc_head    split-K reduce + bias + tanh + Dense(20) + tanh, scatter into Features rows.
+#include <math.h>
+
 #include "caelo_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -42,6 +44,25 @@ CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const flo
         if (!*p.dst) CAELO_HIP(hipMalloc(p.dst, p.n * sizeof(float)));
         CAELO_HIP(hipMemcpy(*p.dst, p.src, p.n * sizeof(float), hipMemcpyHostToDevice));
     }
+    {
+        // C0[pos][ch] = b2[ch] + conv2(BG)[pos][ch], BG = tanh(b1) in every valid 8^3 cell, zero padding outside;
+        // entries 8192..8199 carry bg itself (the kernel subtracts the same float it was built from)
+        float c0[512 * 16 + 8], bg[8];
+        for (int ch = 0; ch < 8; ++ch) bg[ch] = tanhf(b1[ch]);
+        for (int x = 0; x < 8; ++x) for (int y = 0; y < 8; ++y) for (int z = 0; z < 8; ++z)
+            for (int o = 0; o < 16; ++o) {
+                float acc = b2[o];
+                for (int ka = 0; ka < 3; ++ka) for (int kb = 0; kb < 3; ++kb) for (int kc = 0; kc < 3; ++kc) {
+                    const int xx = x + ka - 1, yy = y + kb - 1, zz = z + kc - 1;
+                    if (xx < 0 || xx >= 8 || yy < 0 || yy >= 8 || zz < 0 || zz >= 8) continue;
+                    for (int ci = 0; ci < 8; ++ci) acc += bg[ci] * w2[(((ka * 3 + kb) * 3 + kc) * 8 + ci) * 16 + o];
+                }
+                c0[((x * 8 + y) * 8 + z) * 16 + o] = acc;
+            }
+        for (int ch = 0; ch < 8; ++ch) c0[512 * 16 + ch] = bg[ch];
+        if (!c->enc_c0) CAELO_HIP(hipMalloc(&c->enc_c0, sizeof(c0)));
+        CAELO_HIP(hipMemcpy(c->enc_c0, c0, sizeof(c0), hipMemcpyHostToDevice));
+    }
     float *pad = (float *)calloc((size_t)DENSE_K * DENSE_NP + DENSE_NP, sizeof(float));
     if (!pad) { caelo_set_error("out of host memory"); return CAELO_ERR_ARG; }
     for (int k = 0; k < DENSE_K; ++k) memcpy(pad + (size_t)k * DENSE_NP, wd1 + (size_t)k * DENSE_N, DENSE_N * sizeof(float));
@@ -56,10 +77,19 @@ CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const flo
 }
 
 // ------------------------------------------------------------------------------------------------
-// stage 1: conv1 + pool1 (VALU, sparse) -> conv2 (MFMA) -> pool2 -> P2
+// stage 1: conv1 + pool1 (VALU, sparse) -> conv2 (MFMA, sparse over background) -> pool2 -> P2
 // ------------------------------------------------------------------------------------------------
-// P1 in LDS: two planes of 4 channels; plane p, padded position q (0..799), channel c:
-//   P1[p*P1_PLANE + (P1_FRONT + q)*4 + c],   q = (xp*10 + yp)*8 + z,  xp,yp in 0..9 (1-cell halo), z in 0..7
+// A voxel patch is mostly empty (2 / 54 / 67 set voxels of 4096 at the three scales), so after
+// conv1+pool1 most of the 8^3 cells hold the constant background vector bg = tanh(b1).  conv2 is
+// linear before its tanh:  conv2(P1) = conv2(BG) + conv2(P1 - BG),  BG = bg in every valid cell.
+//   * C0 = b2 + conv2(BG) is a [512][16] table computed once per model (host, at weight load);
+//   * D = P1 - BG is zero except in the few cells whose 4^3 receptive field holds a set voxel.
+// The kernel keeps D in LDS (two 4-channel planes with a 1-cell halo), starts every MFMA accumulator
+// from C0 and skips -- exactly, a skipped product is an added zero -- every (m-tile, x-tap plane)
+// whose 4 x 8 input rows are all-zero in D: 71 % of the conv2 MFMAs on KITTI-shaped scans.
+//
+// D layout: plane p, padded position q (0..799), channel c:
+//   D[p*P1_PLANE + (P1_FRONT + q)*4 + c],   q = (xp*10 + yp)*8 + z,  xp,yp in 0..9 (1-cell halo), z in 0..7
 // (no z halo: the two out-of-range z taps are predicated).  An MFMA m-tile is 16 consecutive q, so a
 // ds_read_b64 by 32 lanes covers 64 consecutive dwords: bank-conflict free.
 #define P1_FRONT 2
@@ -70,12 +100,29 @@ struct Stage1Lds {
     float w1[27 * 8];
     float b1[8];
     float bg[8];
+    unsigned long long list_mask[512];
+    unsigned short list_cell[512];
     unsigned short rows[256];
+    unsigned int nzrow[12];  // per padded xp: bit yp set when some cell (xp, yp, *) is non-background
+    int list_n;
 };
+
+// 9 taps (one x-tap plane ka) of one m-tile: 18 MFMAs on two interleaved accumulators
+#define CONV2_PLANE(ACC_A, ACC_B, APTR, KA)                                                        \
+    _Pragma("unroll") for (int kb = 0; kb < 3; ++kb) {                                             \
+        _Pragma("unroll") for (int kc = 0; kc < 3; ++kc) {                                         \
+            const int t = (KA) * 9 + kb * 3 + kc;                                                   \
+            float2 av = *(const float2 *)((APTR) + (((KA) * 10 + kb) * 8 + (kc - 1)) * 4);          \
+            if (kc == 0) { if (!zlo) av = make_float2(0.f, 0.f); }                                  \
+            if (kc == 2) { if (!zhi) av = make_float2(0.f, 0.f); }                                  \
+            ACC_A = MFMA16(av.x, breg[t][0], ACC_A);                                                \
+            ACC_B = MFMA16(av.y, breg[t][1], ACC_B);                                                \
+        }                                                                                           \
+    }
 
 __global__ void __launch_bounds__(256) k_enc_stage1(const unsigned long long *__restrict__ bits, int64_t n_patches,
                                                     const float *__restrict__ w1g, const float *__restrict__ b1g,
-                                                    const float *__restrict__ w2g, const float *__restrict__ b2g,
+                                                    const float *__restrict__ w2g, const float *__restrict__ c0g,
                                                     float *__restrict__ p2out) {
     __shared__ __attribute__((aligned(16))) Stage1Lds L;
     const int tid = threadIdx.x;
@@ -90,10 +137,11 @@ __global__ void __launch_bounds__(256) k_enc_stage1(const unsigned long long *__
         breg[t][0] = w2g[(t * 8 + 2 * g) * 16 + n];
         breg[t][1] = w2g[(t * 8 + 2 * g + 1) * 16 + n];
     }
-    const float bias2 = b2g[n];
     for (int i = tid; i < 27 * 8; i += 256) L.w1[i] = w1g[i];
-    if (tid < 8) { L.b1[tid] = b1g[tid]; L.bg[tid] = tanhf(b1g[tid]); }
-    for (int i = tid; i < 2 * P1_PLANE; i += 256) L.p1[i] = 0.0f;  // halo + pads stay zero for good
+    if (tid < 8) { L.b1[tid] = b1g[tid]; L.bg[tid] = c0g[512 * 16 + tid]; }  // bg = tanh(b1), from the host table
+    for (int i = tid; i < 2 * P1_PLANE; i += 256) L.p1[i] = 0.0f;  // D == 0: halo, pads, background cells
+    if (tid == 0) L.list_n = 0;
+    if (tid < 12) L.nzrow[tid] = 0u;
     __syncthreads();
 
     for (int64_t patch = blockIdx.x; patch < n_patches; patch += gridDim.x) {
@@ -106,7 +154,7 @@ __global__ void __launch_bounds__(256) k_enc_stage1(const unsigned long long *__
             L.rows[tid * 4 + 3] = (unsigned short)(w >> 48);
         }
         __syncthreads();
-        // ---- conv1 + pool1 + tanh: 512 pooled cells, 2 per thread
+        // ---- B1: receptive-field mask of each pooled cell; queue the non-background ones
 #pragma unroll 1
         for (int rep = 0; rep < 2; ++rep) {
             const int cell = tid + rep * 256;
@@ -125,42 +173,59 @@ __global__ void __launch_bounds__(256) k_enc_stage1(const unsigned long long *__
                     mask |= (unsigned long long)nib << (a * 16 + b * 4);
                 }
             }
-            float o[8];
-            if (mask == 0ull) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) o[c] = L.bg[c];
-            } else {
-                float mx[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) mx[c] = -3.0e38f;
-#pragma unroll 1
-                for (int sub = 0; sub < 8; ++sub) {
-                    const int sa = sub >> 2, sb = (sub >> 1) & 1, sc = sub & 1;
-                    unsigned int taps = 0;  // bit (ka*3+kb)*3+kc
-#pragma unroll
-                    for (int ka = 0; ka < 3; ++ka)
-#pragma unroll
-                        for (int kb = 0; kb < 3; ++kb)
-                            taps |= ((unsigned int)(mask >> ((sa + ka) * 16 + (sb + kb) * 4 + sc)) & 7u) << ((ka * 3 + kb) * 3);
-                    float acc[8];
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[c] = L.b1[c];
-                    while (taps) {  // ascending tap order == the oracle's (kx,ky,kz) order
-                        const int t = __ffs((int)taps) - 1;
-                        taps &= taps - 1;
-                        const float4 wa = *(const float4 *)&L.w1[t * 8], wb = *(const float4 *)&L.w1[t * 8 + 4];
-                        acc[0] += wa.x; acc[1] += wa.y; acc[2] += wa.z; acc[3] += wa.w;
-                        acc[4] += wb.x; acc[5] += wb.y; acc[6] += wb.z; acc[7] += wb.w;
-                    }
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) mx[c] = fmaxf(mx[c], acc[c]);
-                }
-#pragma unroll
-                for (int c = 0; c < 8; ++c) o[c] = tanhf(mx[c]);
+            if (mask != 0ull) {
+                const int idx = atomicAdd(&L.list_n, 1);
+                L.list_mask[idx] = mask;
+                L.list_cell[idx] = (unsigned short)cell;
+                atomicOr(&L.nzrow[px + 1], 1u << (py + 1));
             }
-            const int q = ((px + 1) * 10 + (py + 1)) * 8 + pz;
-            *(float4 *)&L.p1[(P1_FRONT + q) * 4] = make_float4(o[0], o[1], o[2], o[3]);
-            *(float4 *)&L.p1[P1_PLANE + (P1_FRONT + q) * 4] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        __syncthreads();
+        const int nlist = L.list_n;
+        // ---- B2: conv1 + pool1 + tanh on the queued cells; 8 lanes = the 8 positions of a pooling block
+        for (int base = wave * 8; base < nlist; base += 32) {
+            const int item = base + (lane >> 3);
+            const int sub = lane & 7;
+            float acc[8];
+            int cell = 0;
+            if (item < nlist) {
+                const unsigned long long mask = L.list_mask[item];
+                cell = L.list_cell[item];
+                const int sa = sub >> 2, sb = (sub >> 1) & 1, sc = sub & 1;
+                unsigned int taps = 0;  // bit (ka*3+kb)*3+kc
+#pragma unroll
+                for (int ka = 0; ka < 3; ++ka)
+#pragma unroll
+                    for (int kb = 0; kb < 3; ++kb)
+                        taps |= ((unsigned int)(mask >> ((sa + ka) * 16 + (sb + kb) * 4 + sc)) & 7u) << ((ka * 3 + kb) * 3);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] = L.b1[c];
+                while (taps) {  // ascending tap order == the oracle's (kx,ky,kz) order
+                    const int t = __ffs((int)taps) - 1;
+                    taps &= taps - 1;
+                    const float4 wa = *(const float4 *)&L.w1[t * 8], wb = *(const float4 *)&L.w1[t * 8 + 4];
+                    acc[0] += wa.x; acc[1] += wa.y; acc[2] += wa.z; acc[3] += wa.w;
+                    acc[4] += wb.x; acc[5] += wb.y; acc[6] += wb.z; acc[7] += wb.w;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] = -3.0e38f;
+            }
+            // max over the pooling block (tanh is monotone: pool the pre-activations)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                acc[c] = fmaxf(acc[c], __shfl_xor(acc[c], 1));
+                acc[c] = fmaxf(acc[c], __shfl_xor(acc[c], 2));
+                acc[c] = fmaxf(acc[c], __shfl_xor(acc[c], 4));
+            }
+            if (item < nlist) {
+                float mine = acc[0];  // lane `sub` finishes channel `sub`
+#pragma unroll
+                for (int c = 1; c < 8; ++c) mine = (sub == c) ? acc[c] : mine;
+                const int px = cell >> 6, py = (cell >> 3) & 7, pz = cell & 7;
+                const int q = ((px + 1) * 10 + (py + 1)) * 8 + pz;
+                L.p1[(sub >> 2) * P1_PLANE + (P1_FRONT + q) * 4 + (sub & 3)] = tanhf(mine) - L.bg[sub];
+            }
         }
         __syncthreads();
         // ---- conv2 (8->16) on MFMA: wave w owns x in {2w, 2w+1}; per y0 pair-of-rows one m-tile each
@@ -168,25 +233,35 @@ __global__ void __launch_bounds__(256) k_enc_stage1(const unsigned long long *__
             const int yl = n >> 3, z = n & 7;  // A row m = yl*8 + z
             const float *plane = L.p1 + (g >> 1) * P1_PLANE + 2 * (g & 1);
             const bool zlo = z >= 1, zhi = z <= 6;
+            const unsigned int nz0 = L.nzrow[2 * wave], nz1 = L.nzrow[2 * wave + 1], nz2 = L.nzrow[2 * wave + 2],
+                               nz3 = L.nzrow[2 * wave + 3];
 #pragma unroll 1
             for (int y0 = 0; y0 < 8; y0 += 2) {
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                // accumulators start from C0 = b2 + conv2(BG); two per tile to keep the MFMA chains independent
+                const float *c0a = c0g + (size_t)((((2 * wave) * 8 + y0 + (g >> 1)) * 8 + 4 * (g & 1)) * 16 + n);
+                f32x4 acc0 = {c0a[0], c0a[16], c0a[32], c0a[48]};
+                f32x4 acc1 = {c0a[1024], c0a[1024 + 16], c0a[1024 + 32], c0a[1024 + 48]};
+                f32x4 acc0b = {0.f, 0.f, 0.f, 0.f}, acc1b = {0.f, 0.f, 0.f, 0.f};
                 // padded position of (x = 2w, y = y0 + yl, z) for tap (0,0,1): xp = x + ka, yp = y + kb
                 const int qbase = ((2 * wave) * 10 + (y0 + yl)) * 8 + z;
-                const float *a_ptr = plane + (P1_FRONT + qbase) * 4;
-#pragma unroll
-                for (int t = 0; t < 27; ++t) {
-                    const int ka = t / 9, kb = (t / 3) % 3, kc = t % 3;
-                    const int off = ((ka * 10 + kb) * 8 + (kc - 1)) * 4;
-                    float2 a0 = *(const float2 *)(a_ptr + off);
-                    float2 a1 = *(const float2 *)(a_ptr + off + 80 * 4);
-                    if (kc == 0) { if (!zlo) { a0 = make_float2(0.f, 0.f); a1 = a0; } }
-                    if (kc == 2) { if (!zhi) { a0 = make_float2(0.f, 0.f); a1 = a0; } }
-                    acc0 = MFMA16(a0.x, breg[t][0], acc0);
-                    acc1 = MFMA16(a1.x, breg[t][0], acc1);
-                    acc0 = MFMA16(a0.y, breg[t][1], acc0);
-                    acc1 = MFMA16(a1.y, breg[t][1], acc1);
-                }
+                const float *a0 = plane + (P1_FRONT + qbase) * 4;
+                const float *a1 = a0 + 80 * 4;
+                const unsigned int rows4 = 0xFu << y0;  // input rows yp = y0 .. y0+3
+                // wave-uniform: which x-tap planes of the two tiles hold anything but background
+                const bool t0k0 = __builtin_amdgcn_readfirstlane((int)(nz0 & rows4)) != 0;
+                const bool t0k1 = __builtin_amdgcn_readfirstlane((int)(nz1 & rows4)) != 0;
+                const bool t0k2 = __builtin_amdgcn_readfirstlane((int)(nz2 & rows4)) != 0;
+                const bool t1k0 = t0k1;
+                const bool t1k1 = t0k2;
+                const bool t1k2 = __builtin_amdgcn_readfirstlane((int)(nz3 & rows4)) != 0;
+                if (t0k0) { CONV2_PLANE(acc0, acc0b, a0, 0) }
+                if (t1k0) { CONV2_PLANE(acc1, acc1b, a1, 0) }
+                if (t0k1) { CONV2_PLANE(acc0, acc0b, a0, 1) }
+                if (t1k1) { CONV2_PLANE(acc1, acc1b, a1, 1) }
+                if (t0k2) { CONV2_PLANE(acc0, acc0b, a0, 2) }
+                if (t1k2) { CONV2_PLANE(acc1, acc1b, a1, 2) }
+                acc0 += acc0b;
+                acc1 += acc1b;
                 // ---- pool2: x pair in registers, z pairs in registers, y pair across lanes g <-> g^2
                 float v0 = fmaxf(fmaxf(acc0[0], acc0[1]), fmaxf(acc1[0], acc1[1]));  // pz = 2*(g&1)
                 float v1 = fmaxf(fmaxf(acc0[2], acc0[3]), fmaxf(acc1[2], acc1[3]));  // pz = 2*(g&1)+1
@@ -195,12 +270,22 @@ __global__ void __launch_bounds__(256) k_enc_stage1(const unsigned long long *__
                 if (g < 2) {
                     // C column = n (channel), rows 4g..4g+3 -> z = 4*(g&1)+r ; pooled cell (wave, y0/2, 2*(g&1)+{0,1})
                     float *dst = p2out + (size_t)patch * 1024 + (size_t)(((wave * 4 + (y0 >> 1)) * 4 + 2 * (g & 1)) * 16 + n);
-                    dst[0] = tanhf(v0 + bias2);
-                    dst[16] = tanhf(v1 + bias2);
+                    dst[0] = tanhf(v0);
+                    dst[16] = tanhf(v1);
                 }
             }
         }
-        __syncthreads();  // p1 / rows are rewritten by the next patch
+        __syncthreads();
+        // ---- back to D == 0 for the next patch
+        for (int i = tid; i < nlist * 2; i += 256) {
+            const int cell = L.list_cell[i >> 1];
+            const int px = cell >> 6, py = (cell >> 3) & 7, pz = cell & 7;
+            const int q = ((px + 1) * 10 + (py + 1)) * 8 + pz;
+            *(float4 *)&L.p1[(i & 1) * P1_PLANE + (P1_FRONT + q) * 4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid == 0) L.list_n = 0;
+        if (tid < 12) L.nzrow[tid] = 0u;
+        __syncthreads();
     }
 }
 
@@ -390,7 +475,7 @@ CAELO_API int64_t caelo_encode_ws_bytes(int64_t n_patches) {
     return (np * 1024 + np * 2048 + (int64_t)D1_SPLIT * np * DENSE_NP) * (int64_t)sizeof(float);
 }
 
-static int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
+int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
                        void *ws, hipStream_t s, hipEvent_t *ev /* 5 events or null */) {
     CAELO_REQUIRE(c && bits && out && ws, "null argument");
     CAELO_REQUIRE(c->has_enc, "encoder weights not set (caelo_set_encoder_weights)");
@@ -401,11 +486,19 @@ static int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, in
     float *part = f3 + np * 2048;
     if (np > n_patches)  // rows of the last 64-row tile that no patch writes
         CAELO_HIP(hipMemsetAsync(f3 + n_patches * 2048, 0, (size_t)(np - n_patches) * 2048 * sizeof(float), s));
-    const int64_t cap = 256 * 4;  // persistent-ish grids: weights stay in registers across patches
-    const unsigned g1 = (unsigned)(n_patches < cap ? n_patches : cap);
+    // persistent grid = exactly the resident workgroup slots (weights stay in registers across patches,
+    // no second partially filled round)
+    static int slots1 = 0;
+    if (!slots1) {
+        int per_cu = 0, cus = 0;
+        CAELO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_enc_stage1, 256, 0));
+        CAELO_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        slots1 = per_cu * cus > 0 ? per_cu * cus : 1024;
+    }
+    const unsigned g1 = (unsigned)(n_patches < slots1 ? n_patches : slots1);
     if (ev) CAELO_HIP(hipEventRecord(ev[0], s));
     k_enc_stage1<<<g1, 256, 0, s>>>((const unsigned long long *)bits, n_patches, c->enc_w1, c->enc_b1, c->enc_w2,
-                                    c->enc_b2, p2);
+                                    c->enc_c0, p2);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[1], s));
     const int64_t pairs = (n_patches + 1) / 2;

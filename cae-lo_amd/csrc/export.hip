@@ -34,8 +34,8 @@ __device__ static inline unsigned long long block_of(unsigned long long vkey) {
 }
 
 __global__ void __launch_bounds__(256) k_exp_block_first(const unsigned long long *__restrict__ vkeys,
-                                                         const int32_t *__restrict__ vfirst, uint32_t vmask,
-                                                         unsigned long long *bkeys, int32_t *bfirst) {
+                                                         const uint32_t *__restrict__ vfirst, uint32_t vmask,
+                                                         unsigned long long *bkeys, uint32_t *bfirst) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > vmask) return;
     const unsigned long long k = vkeys[i];
@@ -45,9 +45,9 @@ __global__ void __launch_bounds__(256) k_exp_block_first(const unsigned long lon
 }
 
 __global__ void __launch_bounds__(256) k_exp_compact(const unsigned long long *__restrict__ vkeys,
-                                                     const int32_t *__restrict__ vfirst, uint32_t vmask,
+                                                     const uint32_t *__restrict__ vfirst, uint32_t vmask,
                                                      const unsigned long long *__restrict__ bkeys,
-                                                     const int32_t *__restrict__ bfirst, int use_block,
+                                                     const uint32_t *__restrict__ bfirst, int use_block,
                                                      unsigned long long *skeys, unsigned long long *svals, int32_t *count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > vmask) return;
@@ -94,8 +94,8 @@ CAELO_API int caelo_voxmap_export(caelo_ctx *c, caelo_voxmap *m, int16_t *all0, 
     char *base = (char *)m->scratch;
     unsigned long long *bkeys = (unsigned long long *)base;
     unsigned long long *k_in = bkeys + vs, *k_out = k_in + vs, *v_in = k_out + vs, *v_out = v_in + vs;
-    int32_t *bfirst = (int32_t *)(v_out + vs);
-    int32_t *count = bfirst + vs;
+    uint32_t *bfirst = (uint32_t *)(v_out + vs);
+    int32_t *count = (int32_t *)(bfirst + vs);
     void *temp = (void *)(count + 16);
     int16_t *outs[3] = {all0, all1, all2};
     int64_t host_counts[3];
@@ -104,7 +104,7 @@ CAELO_API int caelo_voxmap_export(caelo_ctx *c, caelo_voxmap *m, int16_t *all0, 
         CAELO_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), s));
         if (sc == 0) {
             CAELO_HIP(hipMemsetAsync(bkeys, 0xFF, vs * 8, s));
-            CAELO_HIP(hipMemsetAsync(bfirst, 0x7F, vs * 4, s));
+            CAELO_HIP(hipMemsetAsync(bfirst, 0xFF, vs * 4, s));
             k_exp_block_first<<<grid, 256, 0, s>>>(m->vkeys[0], m->vfirst[0], m->vmask[0], bkeys, bfirst);
             CAELO_LAUNCH_CHECK();
         }

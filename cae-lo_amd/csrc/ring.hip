@@ -41,7 +41,7 @@ CAELO_API int caelo_create(caelo_ctx **out, int device) {
 
 CAELO_API void caelo_destroy(caelo_ctx *c) {
     if (!c) return;
-    float *ptrs[] = {c->resp_w, c->enc_w1, c->enc_b1, c->enc_w2, c->enc_b2, c->enc_w3,
+    float *ptrs[] = {c->resp_w, c->enc_c0, c->enc_w1, c->enc_b1, c->enc_w2, c->enc_b2, c->enc_w3,
                      c->enc_b3, c->enc_wd1, c->enc_bd1, c->enc_wd2, c->enc_bd2};
     for (float *p : ptrs)
         if (p) (void)hipFree(p);
@@ -113,14 +113,9 @@ __global__ void __launch_bounds__(256) k_ring_fill(const float4 *__restrict__ pc
     for (int c = 0; c < 5; ++c) o[c] = v[c];
 }
 
-CAELO_API int caelo_project(caelo_ctx *c, const float *pc, int64_t n, float *ring, int32_t *counter,
-                            int32_t *winner_ws, int32_t *status, void *stream) {
-    CAELO_REQUIRE(c && pc && ring && counter && winner_ws && status, "null argument");
-    CAELO_REQUIRE(n > 3, "PC.shape[0] > 3 (SphericalRing.py:73)");
-    hipStream_t s = caelo_stream(stream);
+int ring_project_launch(const float *pc, int64_t n, float *ring, int32_t *counter, int32_t *winner_ws, int32_t *status,
+                        hipStream_t s) {
     const int npix = CAELO_RING_H * CAELO_RING_W;
-    CAELO_HIP(hipMemsetAsync(winner_ws, 0xFF, sizeof(int32_t) * npix, s));
-    CAELO_HIP(hipMemsetAsync(counter, 0, sizeof(int32_t) * npix, s));
     ProjConst k;
     k.pi = 3.14159265358979323846;
     const double d2r = k.pi / 180.0;                        // SphericalRing.py:28
@@ -133,6 +128,21 @@ CAELO_API int caelo_project(caelo_ctx *c, const float *pc, int64_t n, float *rin
     k_ring_fill<<<(npix + 255) / 256, 256, 0, s>>>((const float4 *)pc, winner_ws, ring);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
+}
+
+CAELO_API int caelo_project(caelo_ctx *c, const float *pc, int64_t n, float *ring, int32_t *counter,
+                            int32_t *winner_ws, int32_t *status, void *stream) {
+    CAELO_REQUIRE(c && pc && ring && counter && winner_ws && status, "null argument");
+    CAELO_REQUIRE(n > 3, "PC.shape[0] > 3 (SphericalRing.py:73)");
+    hipStream_t s = caelo_stream(stream);
+    const size_t npix = CAELO_RING_H * CAELO_RING_W;
+    caelo_clear_list cl;
+    cl.n = 0;
+    cl.item[cl.n++] = {winner_ws, npix * sizeof(int32_t), 0xFFFFFFFFu};
+    cl.item[cl.n++] = {counter, npix * sizeof(int32_t), 0u};
+    int rc = caelo_clear_many(cl, s);
+    if (rc) return rc;
+    return ring_project_launch(pc, n, ring, counter, winner_ws, status, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -183,14 +193,18 @@ __global__ void __launch_bounds__(256) k_respond(const float *__restrict__ in, i
     dst[1] = make_float4(o[4], o[5], o[6], o[7]);
 }
 
+int ring_respond_launch(caelo_ctx *c, const float *in, int in_w, int in_c, float *resp, hipStream_t s) {
+    dim3 grid((CAELO_NET_W + 255) / 256, CAELO_NET_H);
+    k_respond<<<grid, 256, 0, s>>>(in, in_w, in_c, c->resp_w, resp);
+    CAELO_LAUNCH_CHECK();
+    return CAELO_OK;
+}
+
 CAELO_API int caelo_respond(caelo_ctx *c, const float *in, int in_w, int in_c, float *resp, void *stream) {
     CAELO_REQUIRE(c && in && resp, "null argument");
     CAELO_REQUIRE(c->has_resp, "response-layer weights not set (caelo_set_respond_weights)");
     CAELO_REQUIRE(in_w >= CAELO_NET_W && in_c >= 3, "input must hold >= 1792 columns and >= 3 channels");
-    dim3 grid((CAELO_NET_W + 255) / 256, CAELO_NET_H);
-    k_respond<<<grid, 256, 0, caelo_stream(stream)>>>(in, in_w, in_c, c->resp_w, resp);
-    CAELO_LAUNCH_CHECK();
-    return CAELO_OK;
+    return ring_respond_launch(c, in, in_w, in_c, resp, caelo_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -199,10 +213,10 @@ CAELO_API int caelo_respond(caelo_ctx *c, const float *in, int in_w, int in_c, f
 // the 5x5 window; append key = (float bits of score << 32 | flat index) to a compact list.
 // f32 norm in NumPy's 8-lane pairwise order (SURVEY 8a-3'), no FMA contraction.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_kp_score(const float *__restrict__ ring, int ring_w, int ring_c,
+__global__ void __launch_bounds__(256) k_kp_score(const float *__restrict__ ring, int ring_w, int ring_c, int dist_c,
                                                   const int32_t *__restrict__ counter, int cnt_w,
                                                   const float *__restrict__ resp, unsigned long long *__restrict__ cand,
-                                                  int32_t *cand_count) {
+                                                  uint32_t *__restrict__ hist, int32_t *cand_count) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y + 8;  // rows 8..55 only
     if (x < 8 || x >= CAELO_NET_W - 8) return;
@@ -242,62 +256,106 @@ __global__ void __launch_bounds__(256) k_kp_score(const float *__restrict__ ring
     if (!((double)best > 0.2)) return;     // :126,:199
     const float *px = ring + ((int64_t)y * ring_w + x) * ring_c;
     float d2 = __fmul_rn(px[0], px[0]);
-    for (int c = 1; c < ring_c; ++c) d2 = __fadd_rn(d2, __fmul_rn(px[c], px[c]));  // :197
+    for (int c = 1; c < dist_c; ++c) d2 = __fadd_rn(d2, __fmul_rn(px[c], px[c]));  // :197
     if (!(sqrtf(d2) >= 10.0f)) return;                                        // :198 VisibleBottom
     const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(y * CAELO_NET_W + x);
     const int pos = atomicAdd(cand_count, 1);
     cand[pos] = key;
+    atomicAdd(&hist[__float_as_uint(best) >> 16], 1u);  // 16-bit score histogram for the top-k cut
 }
 
 // ------------------------------------------------------------------------------------------------
 // K4: stable top-(1025) select.  Keys are unique, so "ascending by (score, flat index)" (the stable
-// argsort of :194) is plain ascending key order.  One 1024-thread workgroup: 8-bit MSD radix
-// select of the 1025th largest key, gather, bitonic sort in LDS, emit sorted[-1025:-1] (:216,:218).
+// argsort of :194) is plain ascending key order.  One 1024-thread workgroup:
+//   1. suffix-scan the 65536-bin histogram of the score's top 16 bits (built by k_kp_score) to find
+//      the bin holding the 1025th largest key;
+//   2. gather every key from that bin upwards (1025 + a few) into LDS;  bitonic sort;
+//   3. emit sorted[-1025:-1] (:216,:218).
+// If more than 2048 keys share the cut bin and above (pathological ties) an 8-bit MSD radix select
+// over the full keys finds the exact threshold instead.
 // ------------------------------------------------------------------------------------------------
 #define SEL_THREADS 1024
 #define SEL_N 2048
 
+__device__ unsigned long long radix_select_threshold(const unsigned long long *cand, int M, int keep, unsigned int *hist,
+                                                     unsigned long long *s_prefix, int *s_want) {
+    const int tid = threadIdx.x;
+    if (tid == 0) { *s_prefix = 0ull; *s_want = keep; }
+    __syncthreads();
+    for (int byte = 7; byte >= 0; --byte) {
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = *s_prefix;
+        const int hi_shift = (byte + 1) * 8;
+        for (int i = tid; i < M; i += SEL_THREADS) {
+            const unsigned long long k = cand[i];
+            const bool match = (byte == 7) ? true : ((k >> hi_shift) == (prefix >> hi_shift));
+            if (match) atomicAdd(&hist[(unsigned)(k >> (byte * 8)) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int want = *s_want;
+            int b = 255;
+            for (; b > 0; --b) {
+                const int cnt = (int)hist[b];
+                if (cnt >= want) break;
+                want -= cnt;
+            }
+            *s_want = want;
+            *s_prefix = prefix | ((unsigned long long)b << (byte * 8));
+        }
+        __syncthreads();
+    }
+    return *s_prefix;
+}
+
 __global__ void __launch_bounds__(SEL_THREADS) k_kp_select(const unsigned long long *__restrict__ cand,
-                                                           const int32_t *__restrict__ cand_count,
+                                                           const uint32_t *__restrict__ ghist, const int32_t *cand_count,
                                                            const float *__restrict__ ring, int ring_w, int ring_c,
                                                            int64_t *__restrict__ key_pixels, float *__restrict__ key_pts,
-                                                           int32_t *__restrict__ n_key, int32_t *status) {
-    __shared__ unsigned long long sel[SEL_N];
+                                                           int kp_ld, float *__restrict__ valid, int valid_ld,
+                                                           int32_t *n_key, int32_t *status) {
+    __shared__ __attribute__((aligned(16))) unsigned long long sel[SEL_N];
     __shared__ unsigned int hist[256];
+    __shared__ unsigned int part[SEL_THREADS];
     __shared__ unsigned long long s_prefix;
-    __shared__ int s_want, s_nsel;
+    __shared__ int s_want, s_nsel, s_cutbin;
     const int tid = threadIdx.x;
     const int M = *cand_count;
     const int keep = M < 1025 ? M : 1025;
     unsigned long long thresh = 0ull;
     if (M > 1025) {
-        if (tid == 0) { s_prefix = 0ull; s_want = keep; }
+        // ---- bin of the keep-th largest key: suffix sums over 64 bins per thread
+        unsigned int loc = 0;
+        for (int b = 0; b < 64; ++b) loc += ghist[tid * 64 + b];
+        part[tid] = loc;
         __syncthreads();
-        for (int byte = 7; byte >= 0; --byte) {
-            if (tid < 256) hist[tid] = 0u;
+        // inclusive suffix scan (Hillis-Steele over 1024 entries)
+        for (int off = 1; off < SEL_THREADS; off <<= 1) {
+            const unsigned int add = (tid + off < SEL_THREADS) ? part[tid + off] : 0u;
             __syncthreads();
-            const unsigned long long prefix = s_prefix;
-            const int hi_shift = (byte + 1) * 8;
-            for (int i = tid; i < M; i += SEL_THREADS) {
-                const unsigned long long k = cand[i];
-                const bool match = (byte == 7) ? true : ((k >> hi_shift) == (prefix >> hi_shift));
-                if (match) atomicAdd(&hist[(unsigned)(k >> (byte * 8)) & 255u], 1u);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int want = s_want;
-                int b = 255;
-                for (; b > 0; --b) {
-                    const int cnt = (int)hist[b];
-                    if (cnt >= want) break;
-                    want -= cnt;
-                }
-                s_want = want;
-                s_prefix = prefix | ((unsigned long long)b << (byte * 8));
-            }
+            part[tid] += add;
             __syncthreads();
         }
-        thresh = s_prefix;
+        const unsigned int above = (tid + 1 < SEL_THREADS) ? part[tid + 1] : 0u;  // keys in higher thread ranges
+        if (above < (unsigned)keep && part[tid] >= (unsigned)keep) {
+            unsigned int cum = above;
+            int b = 63;
+            for (; b > 0; --b) {
+                cum += ghist[tid * 64 + b];
+                if (cum >= (unsigned)keep) break;
+            }
+            if (b == 0) cum += ghist[tid * 64];
+            s_cutbin = tid * 64 + b;
+            s_nsel = (int)cum;  // keys with top16 >= cut bin
+        }
+        __syncthreads();
+        if (s_nsel <= SEL_N) {
+            thresh = (unsigned long long)s_cutbin << 48;
+        } else {
+            thresh = radix_select_threshold(cand, M, keep, hist, &s_prefix, &s_want);
+        }
+        __syncthreads();
     }
     if (tid == 0) s_nsel = 0;
     for (int i = tid; i < SEL_N; i += SEL_THREADS) sel[i] = ~0ull;
@@ -310,27 +368,36 @@ __global__ void __launch_bounds__(SEL_THREADS) k_kp_select(const unsigned long l
         }
     }
     __syncthreads();
-    // bitonic sort ascending, 2048 elements, 1024 threads
-    for (int k = 2; k <= SEL_N; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const int i = ((tid & ~(j - 1)) << 1) | (tid & (j - 1));
-            const int p = i | j;
-            const unsigned long long a = sel[i], b = sel[p];
-            const bool up = ((i & k) == 0);
-            if ((a > b) == up) { sel[i] = b; sel[p] = a; }
-            __syncthreads();
+    const int nsel = s_nsel < SEL_N ? s_nsel : SEL_N;  // >= keep real keys
+    // rank sort: keys are unique, so rank = number of smaller keys; one pass over LDS (broadcast reads),
+    // no barriers inside (a 2048-element bitonic network needs 66 of them)
+    __shared__ unsigned long long sorted[SEL_N];
+    for (int i = tid; i < nsel; i += SEL_THREADS) {
+        const unsigned long long mine = sel[i];
+        int rank = 0;
+        const ulonglong2 *s2 = (const ulonglong2 *)sel;  // entries >= nsel hold ~0 (never smaller)
+#pragma unroll 8
+        for (int j = 0; j < (nsel + 1) / 2; ++j) {
+            const ulonglong2 v = s2[j];
+            rank += (v.x < mine ? 1 : 0) + (v.y < mine ? 1 : 0);
         }
+        sorted[rank] = mine;
     }
+    __syncthreads();
     const int K = keep > 0 ? keep - 1 : 0;  // drop the single best (:216,:218)
-    for (int i = tid; i < K; i += SEL_THREADS) {
-        const unsigned idx = (unsigned)(sel[i] & 0xFFFFFFFFull);
-        const int y = idx / CAELO_NET_W, x = idx % CAELO_NET_W;
-        key_pixels[2 * i] = y;
-        key_pixels[2 * i + 1] = x;
-        const float *px = ring + ((int64_t)y * ring_w + x) * ring_c;
-        key_pts[3 * i] = px[0];
-        key_pts[3 * i + 1] = px[1];
-        key_pts[3 * i + 2] = px[2];
+    const int first = nsel - keep;           // the keep largest real keys are sel[first .. nsel)
+    for (int i = tid; i < CAELO_MAX_KEYPTS; i += SEL_THREADS) {
+        if (i < K) {
+            const unsigned idx = (unsigned)(sorted[first + i] & 0xFFFFFFFFull);
+            const int y = idx / CAELO_NET_W, x = idx % CAELO_NET_W;
+            key_pixels[2 * i] = y;
+            key_pixels[2 * i + 1] = x;
+            const float *px = ring + ((int64_t)y * ring_w + x) * ring_c;
+            key_pts[(size_t)kp_ld * i] = px[0];
+            key_pts[(size_t)kp_ld * i + 1] = px[1];
+            key_pts[(size_t)kp_ld * i + 2] = px[2];
+        }
+        if (valid) valid[(size_t)valid_ld * i] = i < K ? 1.0f : 0.0f;
     }
     if (tid == 0) {
         *n_key = K;
@@ -338,19 +405,37 @@ __global__ void __launch_bounds__(SEL_THREADS) k_kp_select(const unsigned long l
     }
 }
 
-CAELO_API int caelo_keypoints(caelo_ctx *c, const float *ring, int ring_w, int ring_c, const int32_t *counter,
-                              int cnt_w, const float *resp, uint64_t *cand_ws, int64_t *key_pixels, float *key_pts,
-                              int32_t *n_key, int32_t *status, void *stream) {
-    CAELO_REQUIRE(c && ring && counter && resp && cand_ws && key_pixels && key_pts && n_key && status, "null argument");
-    CAELO_REQUIRE(ring_w >= CAELO_NET_W && cnt_w >= CAELO_NET_W && ring_c >= 3 && ring_c <= 5, "bad ring shape");
-    hipStream_t s = caelo_stream(stream);
-    // n_key doubles as the candidate counter while scoring
-    CAELO_HIP(hipMemsetAsync(n_key, 0, sizeof(int32_t), s));
+int ring_keypoints_launch(const float *ring, int ring_w, int ring_c, int dist_c, const int32_t *counter, int cnt_w,
+                          const float *resp, unsigned long long *cand, uint32_t *hist, int32_t *cand_count,
+                          int64_t *key_pixels, float *key_pts, int kp_ld, float *valid, int valid_ld, int32_t *n_key,
+                          int32_t *status, hipStream_t s) {
     dim3 grid((CAELO_NET_W + 255) / 256, 48);
-    k_kp_score<<<grid, 256, 0, s>>>(ring, ring_w, ring_c, counter, cnt_w, resp, (unsigned long long *)cand_ws, n_key);
+    k_kp_score<<<grid, 256, 0, s>>>(ring, ring_w, ring_c, dist_c, counter, cnt_w, resp, cand, hist, cand_count);
     CAELO_LAUNCH_CHECK();
-    k_kp_select<<<1, SEL_THREADS, 0, s>>>((const unsigned long long *)cand_ws, n_key, ring, ring_w, ring_c, key_pixels,
-                                          key_pts, n_key, status);
+    k_kp_select<<<1, SEL_THREADS, 0, s>>>(cand, hist, cand_count, ring, ring_w, ring_c, key_pixels, key_pts, kp_ld, valid,
+                                          valid_ld, n_key, status);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
+}
+
+CAELO_API int64_t caelo_keypoints_ws_bytes(void) {
+    return (int64_t)CAELO_NET_H * CAELO_NET_W * 8 + (int64_t)CAELO_KP_HIST_BINS * 4 + 64;
+}
+
+CAELO_API int caelo_keypoints(caelo_ctx *c, const float *ring, int ring_w, int ring_c, const int32_t *counter,
+                              int cnt_w, const float *resp, void *ws, int64_t *key_pixels, float *key_pts,
+                              int32_t *n_key, int32_t *status, void *stream) {
+    CAELO_REQUIRE(c && ring && counter && resp && ws && key_pixels && key_pts && n_key && status, "null argument");
+    CAELO_REQUIRE(ring_w >= CAELO_NET_W && cnt_w >= CAELO_NET_W && ring_c >= 3 && ring_c <= 5, "bad ring shape");
+    hipStream_t s = caelo_stream(stream);
+    unsigned long long *cand = (unsigned long long *)ws;
+    uint32_t *hist = (uint32_t *)(cand + CAELO_NET_H * CAELO_NET_W);
+    int32_t *cand_count = (int32_t *)(hist + CAELO_KP_HIST_BINS);
+    caelo_clear_list cl;
+    cl.n = 0;
+    cl.item[cl.n++] = {hist, (size_t)CAELO_KP_HIST_BINS * 4 + 64, 0u};
+    int rc = caelo_clear_many(cl, s);
+    if (rc) return rc;
+    return ring_keypoints_launch(ring, ring_w, ring_c, ring_c, counter, cnt_w, resp, cand, hist, cand_count, key_pixels,
+                                 key_pts, 3, nullptr, 0, n_key, status, s);
 }

@@ -35,47 +35,63 @@ CAELO_API int caelo_voxmap_create(caelo_ctx *c, int64_t max_points, caelo_voxmap
     caelo_voxmap *m = new caelo_voxmap();
     memset(m, 0, sizeof(*m));
     m->max_points = max_points;
-    const uint32_t bslots = pow2ceil((uint64_t)max_points);      // #bricks <= #voxels <= #points
-    const uint32_t vslots = pow2ceil(2 * (uint64_t)max_points);  // load factor <= 0.5
+    // Open addressing wants load factors well under 1/2 (at 3/4 the longest probe chain in a wavefront
+    // set the pace: 190 us for the insert kernel).  Scale 0 can hold one brick per point; scales 1 and 2
+    // are sized for 1/4 and 1/16 of that (a LiDAR scan fills ~1/5 and ~1/30); a cloud that overflows
+    // them reports CAELO_ST_MAP_FULL and the caller retries with a larger map.
+    const size_t vslots = pow2ceil(2 * (uint64_t)max_points);
+    const size_t bslots[3] = {vslots, vslots / 4, vslots / 16};
+    size_t off = 0;
+    size_t o_bkeys[3], o_vkeys[3], o_vfirst[3], o_bits[3];
+    for (int s = 0; s < 3; ++s) { o_bkeys[s] = off; off += bslots[s] * 8; }
+    m->ff_bytes_keys = off;
+    o_vkeys[0] = off; off += vslots * 8;
+    o_vfirst[0] = off; off += vslots * 4;
+    m->ff_bytes_min = off;
+    for (int s = 1; s < 3; ++s) { o_vkeys[s] = off; off += vslots * 8; }
+    for (int s = 1; s < 3; ++s) { o_vfirst[s] = off; off += vslots * 4; }
+    m->ff_bytes_all = off;
+    m->zero_off = off;
+    for (int s = 0; s < 3; ++s) { o_bits[s] = off; off += bslots[s] * 64; }
+    const size_t o_counts = off;
+    off += 64;
+    m->zero_bytes = off - m->zero_off;
+    const size_t o_list0 = off; off += bslots[0] * 4;
+    const size_t o_list1 = off; off += bslots[1] * 4;
+    m->total_bytes = off;
+    CAELO_HIP(hipMalloc(&m->base, m->total_bytes));
     for (int s = 0; s < 3; ++s) {
-        m->brick[s].mask = bslots - 1;
-        CAELO_HIP(hipMalloc(&m->brick[s].keys, sizeof(unsigned long long) * bslots));
-        CAELO_HIP(hipMalloc(&m->brick[s].bits, sizeof(unsigned long long) * 8 * bslots));
-        m->vmask[s] = vslots - 1;
-        CAELO_HIP(hipMalloc(&m->vkeys[s], sizeof(unsigned long long) * vslots));
-        CAELO_HIP(hipMalloc(&m->vfirst[s], sizeof(int32_t) * vslots));
+        m->brick[s].mask = (uint32_t)(bslots[s] - 1);
+        m->brick[s].keys = (unsigned long long *)(m->base + o_bkeys[s]);
+        m->brick[s].bits = (unsigned long long *)(m->base + o_bits[s]);
+        m->vmask[s] = (uint32_t)(vslots - 1);
+        m->vkeys[s] = (unsigned long long *)(m->base + o_vkeys[s]);
+        m->vfirst[s] = (uint32_t *)(m->base + o_vfirst[s]);
     }
-    CAELO_HIP(hipMalloc(&m->counts, sizeof(int32_t) * 4));
+    m->counts = (int32_t *)(m->base + o_counts);
+    m->list0 = (uint32_t *)(m->base + o_list0);
+    m->list1 = (uint32_t *)(m->base + o_list1);
     *out = m;
     return CAELO_OK;
 }
 
 CAELO_API void caelo_voxmap_destroy(caelo_voxmap *m) {
     if (!m) return;
-    for (int s = 0; s < 3; ++s) {
-        (void)hipFree(m->brick[s].keys);
-        (void)hipFree(m->brick[s].bits);
-        (void)hipFree(m->vkeys[s]);
-        (void)hipFree(m->vfirst[s]);
-    }
-    (void)hipFree(m->counts);
+    if (m->base) (void)hipFree(m->base);
     if (m->scratch) (void)hipFree(m->scratch);
     delete m;
 }
 
-static int voxmap_clear(caelo_voxmap *m, bool with_vtables, hipStream_t s) {
-    for (int i = 0; i < 3; ++i) {
-        const size_t bs = (size_t)m->brick[i].mask + 1;
-        CAELO_HIP(hipMemsetAsync(m->brick[i].keys, 0xFF, sizeof(unsigned long long) * bs, s));
-        CAELO_HIP(hipMemsetAsync(m->brick[i].bits, 0, sizeof(unsigned long long) * 8 * bs, s));
-        if (with_vtables || i == 0) {
-            const size_t vs = (size_t)m->vmask[i] + 1;
-            CAELO_HIP(hipMemsetAsync(m->vkeys[i], 0xFF, sizeof(unsigned long long) * vs, s));
-            CAELO_HIP(hipMemsetAsync(m->vfirst[i], 0x7F, sizeof(int32_t) * vs, s));
-        }
-    }
-    CAELO_HIP(hipMemsetAsync(m->counts, 0, sizeof(int32_t) * 4, s));
-    return CAELO_OK;
+void vox_clear_items(caelo_voxmap *m, int level, caelo_clear_list &list) {
+    list.item[list.n++] = {m->base, level >= 2 ? m->ff_bytes_all : (level == 1 ? m->ff_bytes_min : m->ff_bytes_keys), 0xFFFFFFFFu};
+    list.item[list.n++] = {m->base + m->zero_off, m->zero_bytes, 0u};
+}
+
+static int voxmap_clear(caelo_voxmap *m, bool track_order, hipStream_t s) {
+    caelo_clear_list list;
+    list.n = 0;
+    vox_clear_items(m, track_order ? 2 : 1, list);
+    return caelo_clear_many(list, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -112,8 +128,55 @@ __device__ inline int brick_set(caelo_brick_table t, int x, int y, int z) {
     const int slot = table_insert(t.keys, t.mask, caelo_pack3(x >> 3, y >> 3, z >> 3));
     if (slot < 0) return -1;
     const unsigned long long bit = 1ull << (((y & 7) << 3) | (z & 7));
-    const unsigned long long old = atomicOr(&t.bits[(size_t)slot * 8 + (x & 7)], bit);
+    unsigned long long *w = &t.bits[(size_t)slot * 8 + (x & 7)];
+    // Thousands of near-range points share one coarse voxel: test before the atomic so the word is
+    // not hammered by read-modify-writes that change nothing (a stale 0 only costs one extra atomic).
+    if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) return 0;
+    const unsigned long long old = atomicOr(w, bit);
     return (old & bit) ? 0 : 1;
+}
+
+// find-or-insert that also reports whether THIS call created the entry
+__device__ inline int table_insert_new(unsigned long long *keys, uint32_t mask, unsigned long long key, bool *is_new) {
+    uint32_t h = caelo_hash64(key) & mask;
+    *is_new = false;
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+        unsigned long long k = keys[h];
+        if (k == key) return (int)h;
+        if (k == CAELO_EMPTY_KEY) {
+            k = atomicCAS(&keys[h], CAELO_EMPTY_KEY, key);
+            if (k == CAELO_EMPTY_KEY) { *is_new = true; return (int)h; }
+            if (k == key) return (int)h;
+        }
+        h = (h + 1) & mask;
+    }
+    return -1;
+}
+
+// brick_mark that appends a newly created brick's slot to a compact list (so the next pass runs on
+// dense wavefronts instead of scanning a 90 %-empty table)
+__device__ inline bool brick_mark_list(caelo_brick_table t, int x, int y, int z, uint32_t *list, int32_t *list_n) {
+    bool is_new;
+    const int slot = table_insert_new(t.keys, t.mask, caelo_pack3(x >> 3, y >> 3, z >> 3), &is_new);
+    if (slot < 0) return false;
+    if (is_new) list[atomicAdd(list_n, 1)] = (uint32_t)slot;
+    const unsigned long long bit = 1ull << (((y & 7) << 3) | (z & 7));
+    unsigned long long *w = &t.bits[(size_t)slot * 8 + (x & 7)];
+    if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit))
+        (void)__hip_atomic_fetch_or(w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
+// fire-and-forget variant: no returned value -> a non-returning L2 atomic, no round trip.
+// returns false only when the table is full.
+__device__ inline bool brick_mark(caelo_brick_table t, int x, int y, int z) {
+    const int slot = table_insert(t.keys, t.mask, caelo_pack3(x >> 3, y >> 3, z >> 3));
+    if (slot < 0) return false;
+    const unsigned long long bit = 1ull << (((y & 7) << 3) | (z & 7));
+    unsigned long long *w = &t.bits[(size_t)slot * 8 + (x & 7)];
+    if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit))
+        (void)__hip_atomic_fetch_or(w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
 }
 
 struct VoxIdx {
@@ -149,7 +212,7 @@ __device__ inline VoxIdx voxel_indices(float fx, float fy, float fz) {
 // -- a later duplicate never reaches layers 1/2 in the reference either (`continue` at :140).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_vox_first(const float *__restrict__ pc, int64_t n, int stride,
-                                                   unsigned long long *vkeys, int32_t *vfirst, uint32_t vmask,
+                                                   unsigned long long *vkeys, uint32_t *vfirst, uint32_t vmask,
                                                    int32_t *status) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -159,36 +222,50 @@ __global__ void __launch_bounds__(256) k_vox_first(const float *__restrict__ pc,
     if (!v.ok) return;
     const int slot = table_insert(vkeys, vmask, caelo_pack3(v.g[0], v.g[1], v.g[2]));
     if (slot < 0) { atomicOr(status, CAELO_ST_MAP_FULL); return; }
-    atomicMin(&vfirst[slot], (int32_t)i);
+    atomicMin(&vfirst[slot], (uint32_t)i);
+}
+
+// one atomic per wavefront instead of one per lane (120k same-address atomics serialise in L2)
+__device__ inline void wave_count(int32_t *counter, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (pred && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(counter, __popcll(m));
 }
 
 __global__ void __launch_bounds__(256) k_vox_insert(const float *__restrict__ pc, int64_t n, int stride,
                                                     const unsigned long long *__restrict__ vkeys0,
-                                                    const int32_t *__restrict__ vfirst0, uint32_t vmask0,
+                                                    const uint32_t *__restrict__ vfirst0, uint32_t vmask0,
                                                     caelo_brick_table b0, caelo_brick_table b1, caelo_brick_table b2,
-                                                    unsigned long long *vkeys1, int32_t *vfirst1,
-                                                    unsigned long long *vkeys2, int32_t *vfirst2, uint32_t vmask12,
+                                                    unsigned long long *vkeys1, uint32_t *vfirst1,
+                                                    unsigned long long *vkeys2, uint32_t *vfirst2, uint32_t vmask12,
                                                     int track_order, int32_t *counts, int32_t *status) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float *p = pc + i * stride;
-    const VoxIdx v = voxel_indices(p[0], p[1], p[2]);
-    if (!v.ok) return;
-    const int slot = table_find(vkeys0, vmask0, caelo_pack3(v.g[0], v.g[1], v.g[2]));
-    if (slot < 0 || vfirst0[slot] != (int32_t)i) return;  // not the first touch
-    int full = 0;
-    int r = brick_set(b0, v.g[0], v.g[1], v.g[2]);
-    if (r < 0) full = 1; else atomicAdd(&counts[0], 1);
-    r = brick_set(b1, v.v1[0], v.v1[1], v.v1[2]);
-    if (r < 0) full = 1; else if (r) atomicAdd(&counts[1], 1);
-    r = brick_set(b2, v.v2[0], v.v2[1], v.v2[2]);
-    if (r < 0) full = 1; else if (r) atomicAdd(&counts[2], 1);
-    if (track_order) {
-        int s1 = table_insert(vkeys1, vmask12, caelo_pack3(v.v1[0], v.v1[1], v.v1[2]));
-        if (s1 >= 0) atomicMin(&vfirst1[s1], (int32_t)i); else full = 1;
-        int s2 = table_insert(vkeys2, vmask12, caelo_pack3(v.v2[0], v.v2[1], v.v2[2]));
-        if (s2 >= 0) atomicMin(&vfirst2[s2], (int32_t)i); else full = 1;
+    bool first = false;
+    VoxIdx v;
+    v.ok = false;
+    if (i < n) {
+        const float *p = pc + i * stride;
+        v = voxel_indices(p[0], p[1], p[2]);
+        if (v.ok) {
+            const int slot = table_find(vkeys0, vmask0, caelo_pack3(v.g[0], v.g[1], v.g[2]));
+            first = slot >= 0 && vfirst0[slot] == (uint32_t)i;  // the reference's first touch
+        }
     }
+    int full = 0, r0 = 0, r1 = 0, r2 = 0;
+    if (first) {
+        r0 = brick_set(b0, v.g[0], v.g[1], v.g[2]);
+        r1 = brick_set(b1, v.v1[0], v.v1[1], v.v1[2]);
+        r2 = brick_set(b2, v.v2[0], v.v2[1], v.v2[2]);
+        full = (r0 < 0) | (r1 < 0) | (r2 < 0);
+        if (track_order) {
+            const int s1 = table_insert(vkeys1, vmask12, caelo_pack3(v.v1[0], v.v1[1], v.v1[2]));
+            if (s1 >= 0) atomicMin(&vfirst1[s1], (uint32_t)i); else full = 1;
+            const int s2 = table_insert(vkeys2, vmask12, caelo_pack3(v.v2[0], v.v2[1], v.v2[2]));
+            if (s2 >= 0) atomicMin(&vfirst2[s2], (uint32_t)i); else full = 1;
+        }
+    }
+    wave_count(&counts[0], first && r0 >= 0);
+    wave_count(&counts[1], first && r1 > 0);
+    wave_count(&counts[2], first && r2 > 0);
     if (full) atomicOr(status, CAELO_ST_MAP_FULL);
 }
 
@@ -196,6 +273,118 @@ __global__ void k_or_status(int32_t *status, int32_t bit) { atomicOr(status, bit
 
 __global__ void k_vox_check(const int32_t *counts, int32_t *status) {
     if (counts[0] < 496 || counts[1] < 496 || counts[2] < 496) atomicOr(status, CAELO_ST_FEW_VOXELS);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 fast path (fused extract): one pass over the points + one pass over the scale-0 bricks.
+// A scale-0 brick (8 x 0.02 m) IS a scale-1 voxel (0.16 m) and 4 of those a scale-2 voxel
+// (Voxel.py:15-31), so scales 1/2 follow from the set of scale-0 bricks -- provided every point's
+// own int(x_/0.16), int(x_/0.64) (Voxel.py:147-152) agree with its scale-0 index >> 3, >> 5.  They do
+// unless x_ sits within an ulp of a voxel face; such a point raises CAELO_ST_VOXEL_INEXACT and the
+// caller re-runs the frame through the exact first-touch kernels above.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_vox_points(const float *__restrict__ pc, int64_t n, int stride,
+                                                    caelo_brick_table b0, uint32_t *list0, int32_t *counts,
+                                                    int32_t *status) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = pc + i * stride;
+    const VoxIdx v = voxel_indices(p[0], p[1], p[2]);
+    if (v.oob) atomicOr(status, CAELO_ST_VOXEL_OOB);
+    if (!v.ok) return;
+    bool consistent = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) consistent &= (v.v1[a] == (v.g[a] >> 3)) && (v.v2[a] == (v.g[a] >> 5));
+    if (!consistent) atomicOr(status, CAELO_ST_VOXEL_INEXACT);
+    if (!brick_mark_list(b0, v.g[0], v.g[1], v.g[2], list0, &counts[4])) atomicOr(status, CAELO_ST_MAP_FULL);
+}
+
+// grid-stride over the occupied scale-0 bricks: a brick is a scale-1 voxel, and counts its own voxels
+__global__ void __launch_bounds__(256) k_vox_coarse(caelo_brick_table b0, caelo_brick_table b1, const uint32_t *list0,
+                                                    uint32_t *list1, int32_t *counts, int32_t *status) {
+    const int nb = counts[4];
+    int pop = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+        const uint32_t slot = list0[i];
+        const unsigned long long k = b0.keys[slot];
+        const ulonglong2 *w = (const ulonglong2 *)(b0.bits + (size_t)slot * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const ulonglong2 u = w[q]; pop += __popcll(u.x) + __popcll(u.y); }
+        const int x = (int)((k >> 40) & 0xFFFFF), y = (int)((k >> 20) & 0xFFFFF), z = (int)(k & 0xFFFFF);
+        if (!brick_mark_list(b1, x, y, z, list1, &counts[5])) atomicOr(status, CAELO_ST_MAP_FULL);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pop += __shfl_xor(pop, o);
+    if ((threadIdx.x & 63) == 0 && pop) atomicAdd(&counts[0], pop);
+}
+
+// grid-stride over the occupied scale-1 bricks: count their voxels and mark the scale-2 voxels under
+// them (a scale-1 brick spans 2x2x2 scale-2 voxels: scale-2 index = scale-1 index >> 2)
+__global__ void __launch_bounds__(256) k_vox_coarse2(caelo_brick_table b1, caelo_brick_table b2, const uint32_t *list1,
+                                                     int32_t *counts, int32_t *status) {
+    const int nb = counts[5];
+    int pop = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+        const uint32_t slot = list1[i];
+        const unsigned long long k = b1.keys[slot];
+        const int bx = (int)((k >> 40) & 0xFFFFF) << 3, by = (int)((k >> 20) & 0xFFFFF) << 3, bz = (int)(k & 0xFFFFF) << 3;
+        const unsigned long long *w = b1.bits + (size_t)slot * 8;
+        // octant (hx, hy, hz): words x in [4hx, 4hx+4), bits y in [4hy, ..), z in [4hz, ..)
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+            const unsigned long long m = w[4 * hx] | w[4 * hx + 1] | w[4 * hx + 2] | w[4 * hx + 3];
+            pop += __popcll(w[4 * hx]) + __popcll(w[4 * hx + 1]) + __popcll(w[4 * hx + 2]) + __popcll(w[4 * hx + 3]);
+#pragma unroll
+            for (int hy = 0; hy < 2; ++hy)
+#pragma unroll
+                for (int hz = 0; hz < 2; ++hz) {
+                    const unsigned long long sel = (0x0F0F0F0Full << (4 * hz)) << (32 * hy);
+                    if (m & sel)
+                        if (!brick_mark(b2, (bx >> 2) + hx, (by >> 2) + hy, (bz >> 2) + hz)) atomicOr(status, CAELO_ST_MAP_FULL);
+                }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pop += __shfl_xor(pop, o);
+    if ((threadIdx.x & 63) == 0 && pop) atomicAdd(&counts[1], pop);
+}
+
+// one thread per scale-2 brick slot: count
+__global__ void __launch_bounds__(256) k_vox_count2(caelo_brick_table b2, int32_t *counts) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int pop = 0;
+    if (i <= b2.mask && b2.keys[i] != CAELO_EMPTY_KEY) {
+        const unsigned long long *w = b2.bits + (size_t)i * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pop += __popcll(w[q]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pop += __shfl_xor(pop, o);
+    if ((threadIdx.x & 63) == 0 && pop) atomicAdd(&counts[2], pop);
+}
+
+int vox_build_fast_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, int32_t *status, hipStream_t s) {
+    k_vox_points<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(pc, n, stride, m->brick[0], m->list0, m->counts, status);
+    CAELO_LAUNCH_CHECK();
+    k_vox_coarse<<<256, 256, 0, s>>>(m->brick[0], m->brick[1], m->list0, m->list1, m->counts, status);
+    CAELO_LAUNCH_CHECK();
+    k_vox_coarse2<<<64, 256, 0, s>>>(m->brick[1], m->brick[2], m->list1, m->counts, status);
+    CAELO_LAUNCH_CHECK();
+    k_vox_count2<<<(m->brick[2].mask + 256) / 256, 256, 0, s>>>(m->brick[2], m->counts);
+    CAELO_LAUNCH_CHECK();
+    return CAELO_OK;
+}
+
+int vox_build_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, bool track_order, int32_t *status,
+                     hipStream_t s) {
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    k_vox_first<<<grid, 256, 0, s>>>(pc, n, stride, m->vkeys[0], m->vfirst[0], m->vmask[0], status);
+    CAELO_LAUNCH_CHECK();
+    k_vox_insert<<<grid, 256, 0, s>>>(pc, n, stride, m->vkeys[0], m->vfirst[0], m->vmask[0], m->brick[0], m->brick[1],
+                                      m->brick[2], m->vkeys[1], m->vfirst[1], m->vkeys[2], m->vfirst[2], m->vmask[1],
+                                      track_order ? 1 : 0, m->counts, status);
+    CAELO_LAUNCH_CHECK();
+    return CAELO_OK;
 }
 
 CAELO_API int caelo_voxelize(caelo_ctx *c, caelo_voxmap *m, const float *pc, int64_t n, int stride, int32_t *status,
@@ -209,13 +398,8 @@ CAELO_API int caelo_voxelize(caelo_ctx *c, caelo_voxmap *m, const float *pc, int
     hipStream_t s = caelo_stream(stream);
     int rc = voxmap_clear(m, true, s);
     if (rc) return rc;
-    const unsigned grid = (unsigned)((n + 255) / 256);
-    k_vox_first<<<grid, 256, 0, s>>>(pc, n, stride, m->vkeys[0], m->vfirst[0], m->vmask[0], status);
-    CAELO_LAUNCH_CHECK();
-    k_vox_insert<<<grid, 256, 0, s>>>(pc, n, stride, m->vkeys[0], m->vfirst[0], m->vmask[0], m->brick[0], m->brick[1],
-                                      m->brick[2], m->vkeys[1], m->vfirst[1], m->vkeys[2], m->vfirst[2], m->vmask[1], 1,
-                                      m->counts, status);
-    CAELO_LAUNCH_CHECK();
+    rc = vox_build_launch(m, pc, n, stride, true, status, s);
+    if (rc) return rc;
     k_vox_check<<<1, 1, 0, s>>>(m->counts, status);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
@@ -280,11 +464,14 @@ __device__ inline int wave_sum(int v) {
     return v;
 }
 
-__global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restrict__ pts, int64_t k_max,
+__global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restrict__ pts, int pts_ld, int64_t k_max,
                                                            const int32_t *__restrict__ n_key, caelo_brick_table t0,
                                                            caelo_brick_table t1, caelo_brick_table t2,
                                                            unsigned long long *__restrict__ bits,
-                                                           uint8_t *__restrict__ flags) {
+                                                           uint8_t *__restrict__ flags, const int32_t *counts,
+                                                           int32_t *status) {
+    if (counts && blockIdx.x == 0 && threadIdx.x == 0 && (counts[0] < 496 || counts[1] < 496 || counts[2] < 496))
+        atomicOr(status, CAELO_ST_FEW_VOXELS);  // sklearn ValueError at Voxel.py:195-196
     __shared__ PatchWaveLds lds_all[PW_WAVES];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -303,9 +490,9 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
     const caelo_brick_table tab = scale == 0 ? t0 : (scale == 1 ? t1 : t2);
     const double vs = scale == 0 ? VOX_SIZE : (scale == 1 ? VOX_SIZE * 8 : VOX_SIZE * 32);  // Voxel.py:31
     // Voxel.py:185,:193  KeyVoxels = int32((Pts + Visible*) / VoxelSizes[s])  (f64)
-    const int kx = (int)(((double)pts[3 * kp] + VIS_L) / vs);
-    const int ky = (int)(((double)pts[3 * kp + 1] + VIS_W) / vs);
-    const int kz = (int)(((double)pts[3 * kp + 2] + VIS_H) / vs);
+    const int kx = (int)(((double)pts[(size_t)pts_ld * kp] + VIS_L) / vs);
+    const int ky = (int)(((double)pts[(size_t)pts_ld * kp + 1] + VIS_W) / vs);
+    const int kz = (int)(((double)pts[(size_t)pts_ld * kp + 2] + VIS_H) / vs);
     const int bx0 = (kx - BALL_R) >> 3, by0 = (ky - BALL_R) >> 3, bz0 = (kz - BALL_R) >> 3;
     const int nbx = ((kx + BALL_R) >> 3) - bx0 + 1, nby = ((ky + BALL_R) >> 3) - by0 + 1, nbz = ((kz + BALL_R) >> 3) - bz0 + 1;
     // ---- stage <= 125 bricks in LDS (one 64-byte line each); popcount gives a cheap bound on the ball
@@ -446,15 +633,21 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
     if (lane == 0) flags[pw] = (uint8_t)fl;
 }
 
+int vox_patches_launch(const caelo_voxmap *m, const float *pts, int pts_ld, int64_t k_max, const int32_t *n_key,
+                       uint64_t *bits, uint8_t *flags, int32_t *status, bool check_counts, hipStream_t s) {
+    const int64_t waves = k_max * 3;
+    k_patches<<<(unsigned)((waves + PW_WAVES - 1) / PW_WAVES), 64 * PW_WAVES, 0, s>>>(
+        pts, pts_ld, k_max, n_key, m->brick[0], m->brick[1], m->brick[2], (unsigned long long *)bits, flags,
+        check_counts ? m->counts : nullptr, status);
+    CAELO_LAUNCH_CHECK();
+    return CAELO_OK;
+}
+
 CAELO_API int caelo_patches(caelo_ctx *c, const caelo_voxmap *m, const float *pts, int64_t k_max, const int32_t *n_key,
                             uint64_t *bits, uint8_t *flags, int32_t *status, void *stream) {
     CAELO_REQUIRE(c && m && pts && bits && flags && status, "null argument");
     CAELO_REQUIRE(k_max > 0, "k_max must be positive");
-    const int64_t waves = k_max * 3;
-    k_patches<<<(unsigned)((waves + PW_WAVES - 1) / PW_WAVES), 64 * PW_WAVES, 0, caelo_stream(stream)>>>(
-        pts, k_max, n_key, m->brick[0], m->brick[1], m->brick[2], (unsigned long long *)bits, flags);
-    CAELO_LAUNCH_CHECK();
-    return CAELO_OK;
+    return vox_patches_launch(m, pts, 3, k_max, n_key, bits, flags, status, false, caelo_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -51,6 +51,9 @@ typedef enum {
 #define CAELO_ST_MAP_FULL 4       /* voxel hash table overflow (capacity bug, never data) */
 #define CAELO_ST_FEW_VOXELS 8     /* a scale holds < 496 voxels: sklearn ValueError at Voxel.py:195-196 */
 #define CAELO_ST_FEW_KEYPTS 16    /* K <= 50: assert at SphericalRing.py:286 */
+#define CAELO_ST_VOXEL_INEXACT 32 /* caelo_extract's one-pass voxelization met a point within an ulp of a voxel
+                                     face: re-run the frame with CAELO_EXTRACT_EXACT_VOXELS (never data loss) */
+#define CAELO_EXTRACT_EXACT_VOXELS 1 /* caelo_extract mode bit: two-pass first-touch voxelization (Voxel.py:139-141) */
 
 typedef struct caelo_ctx caelo_ctx;
 typedef struct caelo_voxmap caelo_voxmap;
@@ -80,10 +83,11 @@ int caelo_project(caelo_ctx *ctx, const float *pc, int64_t n, float *ring, int32
 int caelo_respond(caelo_ctx *ctx, const float *in, int in_w, int in_c, float *resp, void *stream);
 
 /* GetKeyPtsByAE  (SphericalRing.py:113-291).  ring_c = 5: demo mode (:414); 3: batch mode
- * (BatchPreprocess.py:97-98,131-136).  workspace: cand_ws [64*1792] u64.
+ * (BatchPreprocess.py:97-98,131-136).  workspace: ws of caelo_keypoints_ws_bytes() bytes, 16-byte aligned.
  * outputs: key_pixels [1024][2] i64 (row,col), key_pts [1024][3] f32, n_key [1] i32. */
+int64_t caelo_keypoints_ws_bytes(void);
 int caelo_keypoints(caelo_ctx *ctx, const float *ring, int ring_w, int ring_c, const int32_t *counter, int cnt_w,
-                    const float *resp, uint64_t *cand_ws, int64_t *key_pixels, float *key_pts, int32_t *n_key,
+                    const float *resp, void *ws, int64_t *key_pixels, float *key_pts, int32_t *n_key,
                     int32_t *status, void *stream);
 
 /* Voxelization  (Voxel.py:100-173) into a device voxel map (3 scales of 8^3-voxel bricks). */
@@ -122,9 +126,10 @@ int caelo_encode_profile(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches
                          int out_stride, void *ws, void *stream, float *ms_host);
 
 /* NN match  (Match.py:257-258): pair_idx[j] = argmin_i ||f0[i]-f1[j]|| (f64, first minimum).
- * k0/k1 read from n0/n1 device words when non-null. */
-int caelo_match(caelo_ctx *ctx, const float *f0, int64_t k0_max, const int32_t *n0, const float *f1, int64_t k1_max,
-                const int32_t *n1, int dim, int64_t *pair_idx, void *stream);
+ * f0 [k0][ld0], f1 [k1][ld1] (leading dimensions in floats, >= dim); k0/k1 read from the n0/n1
+ * device words when non-null. */
+int caelo_match(caelo_ctx *ctx, const float *f0, int ld0, int64_t k0_max, const int32_t *n0, const float *f1, int ld1,
+                int64_t k1_max, const int32_t *n1, int dim, int64_t *pair_idx, void *stream);
 
 /* SolveRT  (Match.py:138-158): p0 ~ R p1 + T over n point pairs.  R [9], T [3] f32 (device);
  * credible [1] i32 (optional): the reference's isCredible, -1 when det(R) < 0 was met. */
@@ -132,7 +137,7 @@ int caelo_solve_rt(caelo_ctx *ctx, const float *p0, const float *p1, int64_t n, 
                    int32_t *credible, void *stream);
 
 /* RANSAC4RT + SolveRelativePose tail  (Match.py:162-218, :260-283).
- * pc0 [k0][3], pc1 [k1][3], pair_idx [k1]; rand [3*500][4] f64 = the uniform doubles the
+ * pc0 [k0][ld0], pc1 [k1][ld1] (xyz in the first 3 columns), pair_idx [k1]; rand [3*500][4] f64 = the uniform doubles the
  * reference's np.random.random((4,)) would return, in consumption order.
  * result (device, caelo_pose_result) + inlier mask [k1_max] u8.  workspace ws:
  * caelo_ransac_ws_bytes() bytes. */
@@ -149,9 +154,21 @@ typedef struct {
     int32_t n_pairs;
 } caelo_pose_result;
 int64_t caelo_ransac_ws_bytes(void);
-int caelo_ransac(caelo_ctx *ctx, const float *pc0, const float *pc1, const int64_t *pair_idx, int64_t k1_max,
-                 const int32_t *n1, const double *rand, caelo_pose_result *result, uint8_t *inlier_mask, void *ws,
-                 void *stream);
+int caelo_ransac(caelo_ctx *ctx, const float *pc0, int ld0, const float *pc1, int ld1, const int64_t *pair_idx,
+                 int64_t k1_max, const int32_t *n1, const double *rand, caelo_pose_result *result,
+                 uint8_t *inlier_mask, void *ws, void *stream);
+
+/* Fused per-scan hot path: ProjectPC2SphericalRing -> RespondLayer.predict -> GetKeyPtsByAE ->
+ * Voxelization -> GetPatchesList -> GetFeaturesFromPatches in one call, one stream, no host sync.
+ * pc [n][4] f32.  dist_channels 5 = demo calling mode (SphericalRing.py:414), 3 = batch mode
+ * (BatchPreprocess.py:97-98,131-136).  Outputs (device): key_pts rows [1024][kp_ld], features rows
+ * [1024][feat_ld] (60 used), valid (optional) [1024] with stride valid_ld = 1.0 for rows < K,
+ * key_pixels [1024][2], n_key [1], flags [1024][3] (caelo_patches), status int32[4] 16-byte aligned
+ * (word 0 = CAELO_ST_* bits, cleared by the call).  ws: caelo_extract_ws_bytes() bytes, 256-byte aligned. */
+int64_t caelo_extract_ws_bytes(void);
+int caelo_extract(caelo_ctx *ctx, caelo_voxmap *map, const float *pc, int64_t n, int dist_channels, int mode, float *key_pts,
+                  int kp_ld, float *features, int feat_ld, float *valid, int valid_ld, int64_t *key_pixels,
+                  int32_t *n_key, uint8_t *flags, int32_t *status, void *ws, void *stream);
 
 #ifdef __cplusplus
 }

@@ -89,7 +89,7 @@ def test_keypoints_bit_exact_both_modes(api, f0):
 
 def test_keypoints_ragged_and_too_few(api, orc, f0):
     # thin the scan: fewer than 1025 candidates -> K = candidates - 1 (SphericalRing.py:216)
-    for cut in (100, 80, 70, 60):
+    for cut in (60, 45, 35, 28, 22, 16):
         cnt = f0["cnt"].copy()
         cnt[:, cut:] = 0
         o = orc.GetKeyPtsByAE(f0["ring"], cnt, f0["resp"])
@@ -279,7 +279,7 @@ def test_fused_extract_equals_staged_path(engine, orc, models, f0):
     import torch
     ff = engine.extract(torch.from_numpy(f0["pc"]).to(engine.device))
     k = int(ff.n_key.item())
-    assert k == 1024 and int(ff.status.item()) == 0
+    assert k == 1024 and int(ff.status[0].item()) == 0
     assert np.array_equal(ff.key_pixels.cpu().numpy(), f0["kpix"])
     assert np.array_equal(ff.key_pts.cpu().numpy(), f0["kp"])
     err = np.abs(ff.features.cpu().numpy() - f0["g"]["features"]).max() / np.abs(f0["g"]["features"]).max()

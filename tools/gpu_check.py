@@ -169,7 +169,7 @@ def _():
     k = int(fa.n_key.item())
     okk = np.array_equal(fa.key_pixels[:k].cpu().numpy(), o_kpix)
     err = np.abs(fa.features[:k].cpu().numpy() - S["ofeats"]).max()
-    return "%s K=%d kp_exact=%s feat_err=%.3g status=%d/%d" % ("ok" if okk and err < 1e-4 else "FAIL", k, okk, err, int(fa.status.item()), int(fb.status.item()))
+    return "%s K=%d kp_exact=%s feat_err=%.3g status=%d/%d" % ("ok" if okk and err < 1e-4 else "FAIL", k, okk, err, int(fa.status[0].item()), int(fb.status[0].item()))
 
 
 @stage("match")
