@@ -35,6 +35,7 @@ SIGNATURES = [
     ("caelo_respond", c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     ("caelo_keypoints_ws_bytes", c_i64, []),
     ("caelo_keypoints", c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    ("caelo_debug_read", c_int, [c_vp]),
     ("caelo_voxmap_create", c_int, [c_vp, c_i64, C.POINTER(c_vp)]),
     ("caelo_voxmap_destroy", None, [c_vp]),
     ("caelo_voxelize", c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
@@ -46,7 +47,8 @@ SIGNATURES = [
     ("caelo_encode_ws_bytes", c_i64, [c_i64]),
     ("caelo_encode", c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp]),
     ("caelo_encode_profile", c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
-    ("caelo_match", c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_vp]),
+    ("caelo_match_ws_bytes", c_i64, [c_i64]),
+    ("caelo_match", c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_vp, c_vp]),
     ("caelo_solve_rt", c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     ("caelo_ransac_ws_bytes", c_i64, []),
     ("caelo_ransac", c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

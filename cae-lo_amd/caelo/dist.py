@@ -5,7 +5,7 @@ The path shards by frames: feature extraction is independ
 (the reference fans frames out to worker processes: BatchPreprocess.py:215-228,
 PoseEstimation.py:79-99) and matching needs consecutive frames only (PoseEstimation.py:241-251).
 Each rank extracts a contiguous block of frames, ONE all-gather moves the per-frame rows
-(key point xyz | 60-d descriptor | valid flag) over xGMI, then every rank matches the pairs whose
+(60-d descriptor | key point xyz | valid flag) over xGMI, then every rank matches the pairs whose
 second frame it owns -- the pair straddling a block boundary takes its first frame from the
 gathered rows of the previous rank.  Pose chaining (PoseEstimation.py:253-267) is a prefix product
 of the gathered per-pair (R, T) on rank 0 (host, 3x4 algebra).
@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-ROW = 64  # floats per key point row: xyz (3) + descriptor (60) + valid (1)
+ROW = 64  # floats per key point row: descriptor (60) + xyz (3) + valid (1)
 
 
 def shard_frames(n_frames, rank, world):
@@ -37,13 +37,13 @@ def pack_rows(key_pts, features, n_key):
     k = key_pts.shape[0]
     nk = n_key if torch.is_tensor(n_key) else torch.tensor([n_key], device=key_pts.device)
     valid = (torch.arange(k, device=key_pts.device) < nk.reshape(-1)[0]).to(key_pts.dtype).unsqueeze(1)
-    return torch.cat([key_pts, features, valid], dim=1)
+    return torch.cat([features, key_pts, valid], dim=1)
 
 
 def unpack_rows(rows):
     """[K,64] -> (key_pts [K,3], features [K,60], n_key int32[1]) -- contiguous copies."""
     n_key = rows[:, 63].sum().round().to(torch.int32).reshape(1)
-    return rows[:, 0:3].contiguous(), rows[:, 3:63].contiguous(), n_key
+    return rows[:, 60:63].contiguous(), rows[:, 0:60].contiguous(), n_key
 
 
 def all_gather_frames(local_rows, n_frames, group=None):

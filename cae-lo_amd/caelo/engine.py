@@ -87,14 +87,14 @@ class VoxelMap:
 
 
 class FrameFeatures:
-    """Device-resident result of Engine.extract for one scan.  ``rows`` [1024,64] f32 holds
-    xyz (cols 0:3) | 60-d descriptor (3:63) | valid flag (63): the unit the multi-GPU all-gather
-    moves; key_pts / features are strided views into it."""
+    """Device-resident result of Engine.extract for one scan.  ``rows`` [1024,64] f32 holds the
+    60-d descriptor (cols 0:60, 16-byte aligned rows for the match kernel's vector loads) | xyz (60:63)
+    | valid flag (63): the unit the multi-GPU all-gather moves; key_pts / features are strided views."""
     __slots__ = ("rows", "key_pts", "key_pixels", "features", "n_key", "status", "flags")
 
     def __init__(self, rows, key_pixels, n_key, status, flags):
         self.rows = rows
-        self.key_pts, self.features = rows[:, 0:3], rows[:, 3:63]
+        self.key_pts, self.features = rows[:, 60:63], rows[:, 0:60]
         self.key_pixels, self.n_key, self.status, self.flags = key_pixels, n_key, status, flags
 
     @classmethod
@@ -121,6 +121,7 @@ class Engine:
         self._ransac_ws = torch.empty(int(self.lib.caelo_ransac_ws_bytes()), dtype=torch.uint8, device=self.device)
         self._kp_ws = torch.empty(int(self.lib.caelo_keypoints_ws_bytes()), dtype=torch.uint8, device=self.device)
         self._extract_ws = None
+        self._match_ws = None
         if respond_h5:
             self.load_weights(respond_h5)
         if encoder_h5:
@@ -273,8 +274,11 @@ class Engine:
     def match(self, f0, f1, n0=None, n1=None):
         """f0 [k0,dim], f1 [k1,dim] (row-strided views allowed) -> pair_idx [k1] int64."""
         idx = self.zeros((f1.shape[0],), torch.int64)
+        need = int(self.lib.caelo_match_ws_bytes(f1.shape[0]))
+        if self._match_ws is None or self._match_ws.numel() < need:
+            self._match_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         _ffi.check(self.lib.caelo_match(self.ctx, _ptr(f0), self._ld(f0), f0.shape[0], _ptr(n0), _ptr(f1), self._ld(f1),
-                                        f1.shape[0], _ptr(n1), f0.shape[1], _ptr(idx), self.stream))
+                                        f1.shape[0], _ptr(n1), f0.shape[1], _ptr(idx), _ptr(self._match_ws), self.stream))
         return idx
 
     def solve_rt(self, p0, p1):
@@ -322,7 +326,7 @@ class Engine:
         status = self.empty((4,), torch.int32)
         base = rows.data_ptr()
         _ffi.check(self.lib.caelo_extract(self.ctx, vmap.h, _ptr(pc), pc.shape[0], dist_channels, 1 if exact_voxels else 0,
-                                          C.c_void_p(base), 64, C.c_void_p(base + 12), 64, C.c_void_p(base + 252), 64,
+                                          C.c_void_p(base + 240), 64, C.c_void_p(base), 64, C.c_void_p(base + 252), 64,
                                           _ptr(kpix), _ptr(nkey), _ptr(flags), _ptr(status), _ptr(self._extract_ws),
                                           self.stream))
         return FrameFeatures(rows, kpix, nkey, status, flags)

@@ -121,7 +121,7 @@ int vox_patches_launch(const caelo_voxmap *m, const float *pts, int pts_ld, int6
 int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride, void *ws,
                 hipStream_t s, hipEvent_t *ev);
 
-#define CAELO_KP_HIST_BINS 65536
+#define CAELO_KP_HIST_BINS 2048
 
 __host__ __device__ inline unsigned long long caelo_pack3(int x, int y, int z) {
     return ((unsigned long long)(unsigned)(x & 0xFFFFF) << 40) | ((unsigned long long)(unsigned)(y & 0xFFFFF) << 20) |
@@ -150,3 +150,33 @@ __device__ inline int caelo_brick_find(const caelo_brick_table &t, unsigned long
 }
 
 static inline hipStream_t caelo_stream(void *s) { return (hipStream_t)s; }
+
+// ---- one global atomic per WORKGROUP ------------------------------------------------------------------
+// Device-scope atomics execute at the memory side on MI355X (8 XCDs, non-coherent L2s): ~10 ns each when
+// they hit the same address, i.e. 2000 per-wavefront appends to one counter cost 20+ us whatever else the
+// kernel does.  These helpers funnel a workgroup's appends / sums through LDS first.  Every thread of the
+// workgroup must call them (two barriers inside); s_tmp is a caller-provided __shared__ int[2].
+#ifdef __HIPCC__
+__device__ inline int caelo_block_reserve(int32_t *gcounter, bool pred, int *s_tmp) {
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) s_tmp[0] = 0;
+    __syncthreads();
+    const unsigned long long m = __ballot(pred);
+    int wbase = 0;
+    if (m && lane == __ffsll((long long)m) - 1) wbase = atomicAdd(&s_tmp[0], __popcll(m));
+    if (m) wbase = __shfl(wbase, __ffsll((long long)m) - 1);
+    __syncthreads();
+    if (threadIdx.x == 0) s_tmp[1] = s_tmp[0] ? atomicAdd(gcounter, s_tmp[0]) : 0;
+    __syncthreads();
+    return s_tmp[1] + wbase + __popcll(m & ((1ull << lane) - 1ull));
+}
+__device__ inline void caelo_block_add(int32_t *gcounter, int value, int *s_tmp) {
+    if (threadIdx.x == 0) s_tmp[0] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) value += __shfl_xor(value, o);
+    if ((threadIdx.x & 63) == 0 && value) atomicAdd(&s_tmp[0], value);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_tmp[0]) atomicAdd(gcounter, s_tmp[0]);
+}
+#endif

@@ -95,6 +95,14 @@ CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const flo
 #define P1_FRONT 2
 #define P1_PLANE ((800 + 2 * P1_FRONT) * 4)
 
+// phase timestamps (100 MHz) of workgroup 0's first patch in the last k_enc_stage1 launch (debug aid)
+__device__ unsigned long long g_enc_stamp[16];
+#define ENC_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && patch == 0) g_enc_stamp[i] = wall_clock64(); } while (0)
+int enc_debug_copy(unsigned long long *out_host) {
+    CAELO_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_enc_stamp), sizeof(unsigned long long) * 16));
+    return CAELO_OK;
+}
+
 struct Stage1Lds {
     float p1[2 * P1_PLANE];
     float w1[27 * 8];
@@ -107,20 +115,30 @@ struct Stage1Lds {
     int list_n;
 };
 
-// 9 taps (one x-tap plane ka) of one m-tile: 18 MFMAs on two interleaved accumulators
-#define CONV2_PLANE(ACC_A, ACC_B, APTR, KA)                                                        \
-    _Pragma("unroll") for (int kb = 0; kb < 3; ++kb) {                                             \
-        _Pragma("unroll") for (int kc = 0; kc < 3; ++kc) {                                         \
-            const int t = (KA) * 9 + kb * 3 + kc;                                                   \
-            float2 av = *(const float2 *)((APTR) + (((KA) * 10 + kb) * 8 + (kc - 1)) * 4);          \
-            if (kc == 0) { if (!zlo) av = make_float2(0.f, 0.f); }                                  \
-            if (kc == 2) { if (!zhi) av = make_float2(0.f, 0.f); }                                  \
-            ACC_A = MFMA16(av.x, breg[t][0], ACC_A);                                                \
-            ACC_B = MFMA16(av.y, breg[t][1], ACC_B);                                                \
-        }                                                                                           \
+// 3 taps (one (ka, kb) pair of input rows) of one m-tile: 6 MFMAs on two interleaved accumulators
+#define CONV2_ROW(ACC_A, ACC_B, APTR, KA, KB)                                                      \
+    _Pragma("unroll") for (int kc = 0; kc < 3; ++kc) {                                             \
+        const int t = (KA) * 9 + (KB) * 3 + kc;                                                     \
+        float2 av = *(const float2 *)((APTR) + (((KA) * 10 + (KB)) * 8 + (kc - 1)) * 4);            \
+        if (kc == 0) { if (!zlo) av = make_float2(0.f, 0.f); }                                      \
+        if (kc == 2) { if (!zhi) av = make_float2(0.f, 0.f); }                                      \
+        ACC_A = MFMA16(av.x, breg[t][0], ACC_A);                                                    \
+        ACC_B = MFMA16(av.y, breg[t][1], ACC_B);                                                    \
     }
+// all 9 (ka, kb) row pairs of one tile; NZk = occupancy bits of padded plane x + k, shifted down by y0:
+// tap row kb reads input rows y0 + kb and y0 + kb + 1
+#define CONV2_TILE(ACC_A, ACC_B, APTR, NZ0, NZ1, NZ2)                                               \
+    if ((NZ0) & 0x3u) { CONV2_ROW(ACC_A, ACC_B, APTR, 0, 0) }                                       \
+    if ((NZ0) & 0x6u) { CONV2_ROW(ACC_A, ACC_B, APTR, 0, 1) }                                       \
+    if ((NZ0) & 0xCu) { CONV2_ROW(ACC_A, ACC_B, APTR, 0, 2) }                                       \
+    if ((NZ1) & 0x3u) { CONV2_ROW(ACC_A, ACC_B, APTR, 1, 0) }                                       \
+    if ((NZ1) & 0x6u) { CONV2_ROW(ACC_A, ACC_B, APTR, 1, 1) }                                       \
+    if ((NZ1) & 0xCu) { CONV2_ROW(ACC_A, ACC_B, APTR, 1, 2) }                                       \
+    if ((NZ2) & 0x3u) { CONV2_ROW(ACC_A, ACC_B, APTR, 2, 0) }                                       \
+    if ((NZ2) & 0x6u) { CONV2_ROW(ACC_A, ACC_B, APTR, 2, 1) }                                       \
+    if ((NZ2) & 0xCu) { CONV2_ROW(ACC_A, ACC_B, APTR, 2, 2) }
 
-__global__ void __launch_bounds__(256) k_enc_stage1(const unsigned long long *__restrict__ bits, int64_t n_patches,
+__global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long *__restrict__ bits, int64_t n_patches,
                                                     const float *__restrict__ w1g, const float *__restrict__ b1g,
                                                     const float *__restrict__ w2g, const float *__restrict__ c0g,
                                                     float *__restrict__ p2out) {
@@ -137,6 +155,27 @@ __global__ void __launch_bounds__(256) k_enc_stage1(const unsigned long long *__
         breg[t][0] = w2g[(t * 8 + 2 * g) * 16 + n];
         breg[t][1] = w2g[(t * 8 + 2 * g + 1) * 16 + n];
     }
+    // Tile pairs are dealt to the 4 waves so that a 2x2 cluster of occupied pairs lands on 4 different
+    // waves: wave w owns, for every row pair yi, the x pair xp = (w - 2 yi) mod 4.
+    // C0 = b2 + conv2(BG) accumulator fragments of this lane's 8 m-tiles are patch independent: loaded once,
+    // together with the outputs tanh(pool2(C0)) of a pair that sees nothing but background.
+    f32x4 c0r[4][2];
+    float bgout[4][2];
+#pragma unroll
+    for (int yi = 0; yi < 4; ++yi) {
+        const int xp = (wave - 2 * yi) & 3;
+#pragma unroll
+        for (int xt = 0; xt < 2; ++xt) {
+            const float *c0a = c0g + (size_t)((((2 * xp + xt) * 8 + 2 * yi + (g >> 1)) * 8 + 4 * (g & 1)) * 16 + n);
+            c0r[yi][xt] = (f32x4){c0a[0], c0a[16], c0a[32], c0a[48]};
+        }
+        float v0 = fmaxf(fmaxf(c0r[yi][0][0], c0r[yi][0][1]), fmaxf(c0r[yi][1][0], c0r[yi][1][1]));
+        float v1 = fmaxf(fmaxf(c0r[yi][0][2], c0r[yi][0][3]), fmaxf(c0r[yi][1][2], c0r[yi][1][3]));
+        v0 = fmaxf(v0, __shfl_xor(v0, 32));
+        v1 = fmaxf(v1, __shfl_xor(v1, 32));
+        bgout[yi][0] = tanhf(v0);
+        bgout[yi][1] = tanhf(v1);
+    }
     for (int i = tid; i < 27 * 8; i += 256) L.w1[i] = w1g[i];
     if (tid < 8) { L.b1[tid] = b1g[tid]; L.bg[tid] = c0g[512 * 16 + tid]; }  // bg = tanh(b1), from the host table
     for (int i = tid; i < 2 * P1_PLANE; i += 256) L.p1[i] = 0.0f;  // D == 0: halo, pads, background cells
@@ -145,6 +184,7 @@ __global__ void __launch_bounds__(256) k_enc_stage1(const unsigned long long *__
     __syncthreads();
 
     for (int64_t patch = blockIdx.x; patch < n_patches; patch += gridDim.x) {
+        ENC_STAMP(0);
         // ---- load the 512-byte patch as 256 u16 rows (row = ix*16 + iy, bit = iz)
         if (tid < 64) {
             const unsigned long long w = bits[patch * 64 + tid];
@@ -154,6 +194,7 @@ __global__ void __launch_bounds__(256) k_enc_stage1(const unsigned long long *__
             L.rows[tid * 4 + 3] = (unsigned short)(w >> 48);
         }
         __syncthreads();
+        ENC_STAMP(1);
         // ---- B1: receptive-field mask of each pooled cell; queue the non-background ones
 #pragma unroll 1
         for (int rep = 0; rep < 2; ++rep) {
@@ -181,6 +222,7 @@ __global__ void __launch_bounds__(256) k_enc_stage1(const unsigned long long *__
             }
         }
         __syncthreads();
+        ENC_STAMP(2);
         const int nlist = L.list_n;
         // ---- B2: conv1 + pool1 + tanh on the queued cells; 8 lanes = the 8 positions of a pooling block
         for (int base = wave * 8; base < nlist; base += 32) {
@@ -228,38 +270,37 @@ __global__ void __launch_bounds__(256) k_enc_stage1(const unsigned long long *__
             }
         }
         __syncthreads();
-        // ---- conv2 (8->16) on MFMA: wave w owns x in {2w, 2w+1}; per y0 pair-of-rows one m-tile each
+        ENC_STAMP(3);
+        // ---- conv2 (8->16) on MFMA: per row pair yi this wave owns the x pair xp = (wave - 2 yi) mod 4
         {
             const int yl = n >> 3, z = n & 7;  // A row m = yl*8 + z
             const float *plane = L.p1 + (g >> 1) * P1_PLANE + 2 * (g & 1);
             const bool zlo = z >= 1, zhi = z <= 6;
-            const unsigned int nz0 = L.nzrow[2 * wave], nz1 = L.nzrow[2 * wave + 1], nz2 = L.nzrow[2 * wave + 2],
-                               nz3 = L.nzrow[2 * wave + 3];
-#pragma unroll 1
-            for (int y0 = 0; y0 < 8; y0 += 2) {
+#pragma unroll
+            for (int yi = 0; yi < 4; ++yi) {
+                const int y0 = 2 * yi;
+                const int xp = (wave - 2 * yi) & 3;
+                // wave-uniform occupancy of the input rows yp = y0 .. y0+3 in the padded planes 2xp .. 2xp+3
+                const unsigned int r0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((L.nzrow[2 * xp] >> y0) & 0xFu));
+                const unsigned int r1 = (unsigned)__builtin_amdgcn_readfirstlane((int)((L.nzrow[2 * xp + 1] >> y0) & 0xFu));
+                const unsigned int r2 = (unsigned)__builtin_amdgcn_readfirstlane((int)((L.nzrow[2 * xp + 2] >> y0) & 0xFu));
+                const unsigned int r3 = (unsigned)__builtin_amdgcn_readfirstlane((int)((L.nzrow[2 * xp + 3] >> y0) & 0xFu));
+                // C column = n (channel), rows 4g..4g+3 -> z = 4*(g&1)+r ; pooled cell (xp, yi, 2*(g&1)+{0,1})
+                float *dst = p2out + (size_t)patch * 1024 + (size_t)(((xp * 4 + yi) * 4 + 2 * (g & 1)) * 16 + n);
+                if ((r0 | r1 | r2 | r3) == 0u) {  // nothing but background feeds this pair: per-model constants
+                    if (g < 2) { dst[0] = bgout[yi][0]; dst[16] = bgout[yi][1]; }
+                    continue;
+                }
                 // accumulators start from C0 = b2 + conv2(BG); two per tile to keep the MFMA chains independent
-                const float *c0a = c0g + (size_t)((((2 * wave) * 8 + y0 + (g >> 1)) * 8 + 4 * (g & 1)) * 16 + n);
-                f32x4 acc0 = {c0a[0], c0a[16], c0a[32], c0a[48]};
-                f32x4 acc1 = {c0a[1024], c0a[1024 + 16], c0a[1024 + 32], c0a[1024 + 48]};
+                f32x4 acc0 = c0r[yi][0];
+                f32x4 acc1 = c0r[yi][1];
                 f32x4 acc0b = {0.f, 0.f, 0.f, 0.f}, acc1b = {0.f, 0.f, 0.f, 0.f};
-                // padded position of (x = 2w, y = y0 + yl, z) for tap (0,0,1): xp = x + ka, yp = y + kb
-                const int qbase = ((2 * wave) * 10 + (y0 + yl)) * 8 + z;
+                // padded position of (x = 2xp, y = y0 + yl, z) for tap (0,0,1): xp' = x + ka, yp = y + kb
+                const int qbase = ((2 * xp) * 10 + (y0 + yl)) * 8 + z;
                 const float *a0 = plane + (P1_FRONT + qbase) * 4;
                 const float *a1 = a0 + 80 * 4;
-                const unsigned int rows4 = 0xFu << y0;  // input rows yp = y0 .. y0+3
-                // wave-uniform: which x-tap planes of the two tiles hold anything but background
-                const bool t0k0 = __builtin_amdgcn_readfirstlane((int)(nz0 & rows4)) != 0;
-                const bool t0k1 = __builtin_amdgcn_readfirstlane((int)(nz1 & rows4)) != 0;
-                const bool t0k2 = __builtin_amdgcn_readfirstlane((int)(nz2 & rows4)) != 0;
-                const bool t1k0 = t0k1;
-                const bool t1k1 = t0k2;
-                const bool t1k2 = __builtin_amdgcn_readfirstlane((int)(nz3 & rows4)) != 0;
-                if (t0k0) { CONV2_PLANE(acc0, acc0b, a0, 0) }
-                if (t1k0) { CONV2_PLANE(acc1, acc1b, a1, 0) }
-                if (t0k1) { CONV2_PLANE(acc0, acc0b, a0, 1) }
-                if (t1k1) { CONV2_PLANE(acc1, acc1b, a1, 1) }
-                if (t0k2) { CONV2_PLANE(acc0, acc0b, a0, 2) }
-                if (t1k2) { CONV2_PLANE(acc1, acc1b, a1, 2) }
+                CONV2_TILE(acc0, acc0b, a0, r0, r1, r2)
+                CONV2_TILE(acc1, acc1b, a1, r1, r2, r3)
                 acc0 += acc0b;
                 acc1 += acc1b;
                 // ---- pool2: x pair in registers, z pairs in registers, y pair across lanes g <-> g^2
@@ -268,14 +309,14 @@ __global__ void __launch_bounds__(256) k_enc_stage1(const unsigned long long *__
                 v0 = fmaxf(v0, __shfl_xor(v0, 32));
                 v1 = fmaxf(v1, __shfl_xor(v1, 32));
                 if (g < 2) {
-                    // C column = n (channel), rows 4g..4g+3 -> z = 4*(g&1)+r ; pooled cell (wave, y0/2, 2*(g&1)+{0,1})
-                    float *dst = p2out + (size_t)patch * 1024 + (size_t)(((wave * 4 + (y0 >> 1)) * 4 + 2 * (g & 1)) * 16 + n);
                     dst[0] = tanhf(v0);
                     dst[16] = tanhf(v1);
                 }
             }
         }
         __syncthreads();
+        ENC_STAMP(4);
+        if (threadIdx.x == 0 && blockIdx.x == 0 && patch == 0) g_enc_stamp[8] = (unsigned long long)nlist;
         // ---- back to D == 0 for the next patch
         for (int i = tid; i < nlist * 2; i += 256) {
             const int cell = L.list_cell[i >> 1];
@@ -286,6 +327,7 @@ __global__ void __launch_bounds__(256) k_enc_stage1(const unsigned long long *__
         if (tid == 0) L.list_n = 0;
         if (tid < 12) L.nzrow[tid] = 0u;
         __syncthreads();
+        ENC_STAMP(5);
     }
 }
 
@@ -319,21 +361,34 @@ __global__ void __launch_bounds__(256) k_enc_conv3(const float *__restrict__ p2,
     for (int i = tid; i < 2 * P2_SLOT; i += 256) S[i] = 0.0f;
     __syncthreads();
     const int64_t n_pairs = (n_patches + 1) / 2;
+    // register staging: the next pair's 2 x 4 KB are fetched while this pair's MFMAs run
+    float4 pre0, pre1;
+#define C3_FETCH(PAIR)                                                                                        \
+    {                                                                                                         \
+        const int64_t pr_ = (PAIR);                                                                           \
+        const int i0_ = tid, i1_ = tid + 256; /* float4 index over [slot][pos][plane], rem = pos*4 + plane */ \
+        const int64_t pa0_ = pr_ * 2 + (i0_ >> 8), pa1_ = pr_ * 2 + (i1_ >> 8);                               \
+        pre0 = make_float4(0.f, 0.f, 0.f, 0.f);                                                               \
+        pre1 = pre0;                                                                                          \
+        if (pr_ < n_pairs && pa0_ < n_patches)                                                                \
+            pre0 = *(const float4 *)(p2 + (size_t)pa0_ * 1024 + ((i0_ & 255) >> 2) * 16 + (i0_ & 3) * 4);    \
+        if (pr_ < n_pairs && pa1_ < n_patches)                                                                \
+            pre1 = *(const float4 *)(p2 + (size_t)pa1_ * 1024 + ((i1_ & 255) >> 2) * 16 + (i1_ & 3) * 4);    \
+    }
+    C3_FETCH((int64_t)blockIdx.x)
     for (int64_t pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
         // ---- stage two patches: 2 x 64 positions x 16 channels = 512 float4, 2 per thread
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int i = tid + r * 256;           // float4 index over [slot][pos][plane]
-            const int sl = i >> 8, rem = i & 255;  // rem = pos*4 + plane
+            const int i = tid + r * 256;
+            const int sl = i >> 8, rem = i & 255;
             const int pos = rem >> 2, pl = rem & 3;
-            const int64_t patch = pair * 2 + sl;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (patch < n_patches) v = *(const float4 *)(p2 + (size_t)patch * 1024 + pos * 16 + pl * 4);
             const int x = pos >> 4, y = (pos >> 2) & 3, z = pos & 3;
             const int q = ((x + 1) * 6 + (y + 1)) * 4 + z;
-            *(float4 *)&S[sl * P2_SLOT + pl * P2_PLANE + (P2_FRONT + q) * 4] = v;
+            *(float4 *)&S[sl * P2_SLOT + pl * P2_PLANE + (P2_FRONT + q) * 4] = r ? pre1 : pre0;
         }
         __syncthreads();
+        C3_FETCH(pair + gridDim.x)
         const int64_t patch = pair * 2 + slot;
         {
             const int yl = n >> 2, z = n & 3;  // A row m = yl*4 + z ; m-tile index = x
@@ -380,12 +435,16 @@ __global__ void __launch_bounds__(256) k_enc_conv3(const float *__restrict__ p2,
 // ------------------------------------------------------------------------------------------------
 // dense1: split-K GEMM  part[s][row][208] = F3[row][k0:k0+256] x Wd1p[k0:k0+256][208]
 // ------------------------------------------------------------------------------------------------
-#define D1_BM 64
+#define D1_BM 32
 #define D1_BK 32
 #define D1_SPLIT 8
 #define D1_KCHUNK (DENSE_K / D1_SPLIT)
 #define D1_APITCH 34  // conflict-free ds_read_b32 of A[m][k] for 16 rows x 2 k per lane group
+#define D1_BVEC ((D1_BK * DENSE_NP / 4 + 255) / 256)  // float4 of the B tile per thread
 
+// 32 rows x 208 columns per workgroup (768 workgroups = 3 per CU, all co-resident); wave w owns m-tile
+// (w & 1) and n-tiles [0,7) or [7,13).  The next k-stage is fetched into registers while the current
+// one is multiplied, so the L2 latency of the 30 KB stage hides behind the MFMAs.
 __global__ void __launch_bounds__(256) k_enc_dense1(const float *__restrict__ f3, int64_t n_rows_pad,
                                                     const float *__restrict__ wd1p, float *__restrict__ part) {
     __shared__ __attribute__((aligned(16))) float As[D1_BM * D1_APITCH];
@@ -393,42 +452,53 @@ __global__ void __launch_bounds__(256) k_enc_dense1(const float *__restrict__ f3
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, n = lane & 15;
+    const int mt = wave & 1, jbeg = (wave >> 1) ? 7 : 0, jcnt = (wave >> 1) ? 6 : 7;
     const int64_t row0 = (int64_t)blockIdx.x * D1_BM;
     const int split = blockIdx.y;
     const int kbeg = split * D1_KCHUNK;
-    f32x4 acc[13];
+    f32x4 acc[7];
 #pragma unroll
-    for (int j = 0; j < 13; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 7; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 a_pre, b_pre[D1_BVEC];
+    const int am = tid >> 3, akq = tid & 7;  // A tile: 32 rows x 8 float4
+#define D1_FETCH(K0)                                                                                         \
+    {                                                                                                        \
+        a_pre = *(const float4 *)(f3 + (size_t)(row0 + am) * DENSE_K + (K0) + akq * 4);                      \
+        _Pragma("unroll") for (int r = 0; r < D1_BVEC; ++r) {                                                \
+            const int i = tid + r * 256;                                                                     \
+            b_pre[r] = make_float4(0.f, 0.f, 0.f, 0.f);                                                      \
+            if (i < D1_BK * DENSE_NP / 4) b_pre[r] = *(const float4 *)(wd1p + (size_t)(K0) * DENSE_NP + (size_t)i * 4); \
+        }                                                                                                    \
+    }
+    D1_FETCH(kbeg)
     for (int k0 = kbeg; k0 < kbeg + D1_KCHUNK; k0 += D1_BK) {
-        // A tile: 64 rows x 32 k = 512 float4
+        {
+            float *d = &As[am * D1_APITCH + akq * 4];
+            d[0] = a_pre.x; d[1] = a_pre.y; d[2] = a_pre.z; d[3] = a_pre.w;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int i = tid + r * 256;
-            const int m = i >> 3, kq = i & 7;
-            const float4 v = *(const float4 *)(f3 + (size_t)(row0 + m) * DENSE_K + k0 + kq * 4);
-            float *d = &As[m * D1_APITCH + kq * 4];
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
-        // B tile: 32 k x 208 n = 1664 float4
-        for (int i = tid; i < D1_BK * DENSE_NP / 4; i += 256) {
-            const int k = i / (DENSE_NP / 4), c4 = i % (DENSE_NP / 4);
-            *(float4 *)&Bs[k * DENSE_NP + c4 * 4] = *(const float4 *)(wd1p + (size_t)(k0 + k) * DENSE_NP + c4 * 4);
+            for (int r = 0; r < D1_BVEC; ++r) {
+                const int i = tid + r * 256;
+                if (i < D1_BK * DENSE_NP / 4) *(float4 *)&Bs[i * 4] = b_pre[r];  // tile rows are contiguous: [32][208]
+            }
         }
         __syncthreads();
+        if (k0 + D1_BK < kbeg + D1_KCHUNK) D1_FETCH(k0 + D1_BK)
 #pragma unroll
         for (int s = 0; s < D1_BK / 4; ++s) {
-            const float a = As[(wave * 16 + n) * D1_APITCH + 4 * s + g];
+            const float a = As[(mt * 16 + n) * D1_APITCH + 4 * s + g];
 #pragma unroll
-            for (int j = 0; j < 13; ++j) acc[j] = MFMA16(a, Bs[(4 * s + g) * DENSE_NP + 16 * j + n], acc[j]);
+            for (int j = 0; j < 7; ++j)
+                if (j < jcnt) acc[j] = MFMA16(a, Bs[(4 * s + g) * DENSE_NP + 16 * (jbeg + j) + n], acc[j]);
         }
         __syncthreads();
     }
     // C rows 4g + r of this wave's m-tile
-    float *dst = part + ((size_t)split * n_rows_pad + row0 + wave * 16) * DENSE_NP;
+    float *dst = part + ((size_t)split * n_rows_pad + row0 + mt * 16) * DENSE_NP;
 #pragma unroll
-    for (int j = 0; j < 13; ++j)
+    for (int j = 0; j < 7; ++j)
+        if (j < jcnt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[(size_t)(4 * g + r) * DENSE_NP + 16 * j + n] = acc[j][r];
+            for (int r = 0; r < 4; ++r) dst[(size_t)(4 * g + r) * DENSE_NP + 16 * (jbeg + j) + n] = acc[j][r];
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -16,59 +16,7 @@
 
 #include "caelo_internal.h"
 
-// ------------------------------------------------------------------------------------------------
-// NN match: exact f64 distances (the f32 GEMM form cannot guarantee the f64 argmin).
-// Block = 4 waves, 16 frame-1 descriptors per block; F0 streamed through LDS in 64-row tiles.
-// ------------------------------------------------------------------------------------------------
-#define MT_J 4
-#define MT_I 64
 #define MT_MAXDIM 64
-
-__global__ void __launch_bounds__(256) k_match(const float *__restrict__ f0, int ld0, int64_t k0_max, const int32_t *n0p,
-                                               const float *__restrict__ f1, int ld1, int64_t k1_max, const int32_t *n1p,
-                                               int dim, int64_t *__restrict__ pair_idx) {
-    __shared__ float s0[MT_I * (MT_MAXDIM + 1)];
-    __shared__ float s1[MT_J * MT_MAXDIM];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k0 = n0p ? *n0p : (int)k0_max;
-    const int k1 = n1p ? *n1p : (int)k1_max;
-    const int j0 = blockIdx.x * MT_J;
-    if (j0 >= k1) return;
-    for (int i = tid; i < MT_J * dim; i += 256) {
-        const int j = i / dim, c = i % dim;
-        s1[j * MT_MAXDIM + c] = (j0 + j < k1) ? f1[(size_t)(j0 + j) * ld1 + c] : 0.0f;
-    }
-    double best = 1.0e300;
-    int besti = 0x7FFFFFFF;
-    const int pitch = MT_MAXDIM + 1;
-    for (int i0 = 0; i0 < k0; i0 += MT_I) {
-        __syncthreads();
-        for (int i = tid; i < MT_I * dim; i += 256) {
-            const int r = i / dim, c = i % dim;
-            s0[r * pitch + c] = (i0 + r < k0) ? f0[(size_t)(i0 + r) * ld0 + c] : 0.0f;
-        }
-        __syncthreads();
-        if (i0 + lane < k0) {
-            // this lane owns frame-0 row i0+lane; the wave owns frame-1 descriptor j0+wave
-            double acc = 0.0;
-            for (int c = 0; c < dim; ++c) {
-                const double d = __dsub_rn((double)s0[lane * pitch + c], (double)s1[wave * MT_MAXDIM + c]);
-                acc = __dadd_rn(acc, __dmul_rn(d, d));  // SciPy: s += d*d (no FMA)
-            }
-            const double dd = sqrt(acc);
-            if (dd < best) { best = dd; besti = i0 + lane; }  // ascending i: first minimum kept
-        }
-    }
-    // argmin across lanes (ties -> smaller index, i.e. the first minimum of np.argmin)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ob = __shfl_xor(best, o);
-        const int obi = __shfl_xor(besti, o);
-        if (ob < best || (ob == best && obi < besti)) { best = ob; besti = obi; }
-    }
-    const int j = j0 + wave;
-    if (lane == 0 && j < k1) pair_idx[j] = besti;
-}
 
 // ------------------------------------------------------------------------------------------------
 // NN match, fast path: the all-pairs matrix on the f64 matrix cores, the argmin certified afterwards.
@@ -80,13 +28,48 @@ __global__ void __launch_bounds__(256) k_match(const float *__restrict__ f0, int
 //   is ~1e-13 wide: one row per column survives unless descriptors are duplicated.
 //   (An f32 MFMA version of the same filter keeps ~100 rows per column on these descriptors -- the
 //   |a|^2+|b|^2-2ab form cancels ~4 digits -- and was slower than the plain f64 scan.)
-// Workgroup = 16 waves = one tile of 16 frame-1 descriptors; wave w scans frame-0 row tiles w, w+16, ...
-// Each lane tracks the three smallest lower bounds of its stream; if a third one still passes the test
-// the column is re-scanned exactly by the whole workgroup.
+// Grid = (column tiles of 16 frame-1 descriptors) x MM_RS row slices; a workgroup's 16 waves take one
+// 16-row tile of frame 0 each (more slices of 256 rows when k0 > 1024).  Every workgroup reduces its
+// rows to the three smallest lower bounds per column and publishes them; the last slice to arrive (agent
+// -scope release / ticket / acquire) merges the slices and certifies.  If a third bound still passes the
+// test the column is re-scanned exactly by that workgroup.
 // ------------------------------------------------------------------------------------------------
 typedef double mm_f64x4 __attribute__((ext_vector_type(4)));
 #define MM_WAVES 16
 #define MM_KSTEPS 16  // dim <= 64
+#define MM_RS 4       // row slices per column tile
+
+struct MmPartial {
+    double L1, L2, L3, U;
+    int I1, I2;
+};
+// Cross-workgroup hand-off without fences (cdna_hip_programming.md G16, "8-B agent atomics both
+// sides"): relaxed agent-scope stores are write-through (sc1), relaxed agent-scope loads bypass the L1.
+__device__ inline void mm_publish(MmPartial *dst, const MmPartial &p) {
+    unsigned long long *d = (unsigned long long *)dst;
+    __hip_atomic_store(d + 0, (unsigned long long)__double_as_longlong(p.L1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d + 1, (unsigned long long)__double_as_longlong(p.L2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d + 2, (unsigned long long)__double_as_longlong(p.L3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d + 3, (unsigned long long)__double_as_longlong(p.U), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d + 4, ((unsigned long long)(unsigned)p.I2 << 32) | (unsigned)p.I1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline MmPartial mm_consume(const MmPartial *src) {
+    unsigned long long *s = (unsigned long long *)src;
+    MmPartial p;
+    p.L1 = __longlong_as_double((long long)__hip_atomic_load(s + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    p.L2 = __longlong_as_double((long long)__hip_atomic_load(s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    p.L3 = __longlong_as_double((long long)__hip_atomic_load(s + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    p.U = __longlong_as_double((long long)__hip_atomic_load(s + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const unsigned long long ii = __hip_atomic_load(s + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p.I1 = (int)(unsigned)(ii & 0xFFFFFFFFull);
+    p.I2 = (int)(unsigned)(ii >> 32);
+    return p;
+}
+
+CAELO_API int64_t caelo_match_ws_bytes(int64_t k1_max) {
+    const int64_t tiles = (k1_max + 15) / 16;
+    return 256 + ((tiles * 4 + 255) / 256) * 256 + tiles * MM_RS * 16 * (int64_t)sizeof(MmPartial);
+}
 
 __device__ inline double exact_dist(const float *a, const float *b, int dim) {
     double acc = 0.0;
@@ -97,48 +80,73 @@ __device__ inline double exact_dist(const float *a, const float *b, int dim) {
     return sqrt(acc);
 }
 
+// insert (lo, i) into an ascending top-3 (indices kept for the first two)
+__device__ inline void top3_insert(double lo, int i, double &L1, double &L2, double &L3, int &I1, int &I2) {
+    if (lo < L1) { L3 = L2; L2 = L1; I2 = I1; L1 = lo; I1 = i; }
+    else if (lo < L2) { L3 = L2; L2 = lo; I2 = i; }
+    else if (lo < L3) { L3 = lo; }
+}
+
+// 16 channels [16g, 16g+16) of one descriptor row as doubles (zero beyond dim / for an invalid row)
+template <bool VEC>
+__device__ inline void load_frag(const float *row, bool valid, int g, int dim, double out[MM_KSTEPS]) {
+    if (VEC) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = 16 * g + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid && c < dim) v = *(const float4 *)(row + c);  // dim % 4 == 0 on this path
+            out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < MM_KSTEPS; ++s) {
+            const int c = 16 * g + s;
+            out[s] = (valid && c < dim) ? (double)row[c] : 0.0;
+        }
+    }
+}
+
+template <bool VEC>
 __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const float *__restrict__ f0, int ld0, int64_t k0_max,
                                                               const int32_t *n0p, const float *__restrict__ f1, int ld1,
                                                               int64_t k1_max, const int32_t *n1p, int dim,
-                                                              int64_t *__restrict__ pair_idx) {
-    __shared__ double sL[3][MM_WAVES * 4][16];  // three smallest lower bounds per (wave, g) stream and column
-    __shared__ int sI[2][MM_WAVES * 4][16];     // rows of the two smallest
-    __shared__ double sU[MM_WAVES * 4][16];     // smallest upper bound per stream
+                                                              int64_t *__restrict__ pair_idx, int32_t *tickets,
+                                                              MmPartial *parts, int32_t *stats) {
+    __shared__ double sL[3][MM_WAVES][16];
+    __shared__ int sI[2][MM_WAVES][16];
+    __shared__ double sU[MM_WAVES][16];
     __shared__ int s_rescan[16];
     __shared__ double s_rd[MM_WAVES];
     __shared__ int s_ri[MM_WAVES];
+    __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, x = lane & 15;
     const int k0 = n0p ? *n0p : (int)k0_max;
     const int k1 = n1p ? *n1p : (int)k1_max;
-    const int j0 = blockIdx.x * 16;
-    if (j0 >= k1) return;
+    const int ctile = blockIdx.x, rs = blockIdx.y;
+    const int j0 = ctile * 16;
+    if (j0 >= k1) return;  // uniform over the column tile's slices: no ticket needed
     const double kappa = (4.0 * (double)dim + 64.0) * 1.1102230246251565e-16;  // >= 2x the worst-case bound (dim + 20) 2^-53
     const double BIG = 1.0e300;
-    // B fragments (this column tile) and |f1_j|^2
+    // B fragments (this column tile) and |f1_j|^2.  k-step s of lane group g <-> channel 16 g + s.
     double b[MM_KSTEPS];
+    load_frag<VEC>(f1 + (size_t)(j0 + x) * ld1, j0 + x < k1, g, dim, b);
     double n1 = 0.0;
 #pragma unroll
-    for (int s = 0; s < MM_KSTEPS; ++s) {
-        const int c = 4 * s + g;
-        b[s] = (j0 + x < k1 && c < dim) ? (double)f1[(size_t)(j0 + x) * ld1 + c] : 0.0;
-        n1 += b[s] * b[s];
-    }
+    for (int s = 0; s < MM_KSTEPS; ++s) n1 += b[s] * b[s];
     n1 += __shfl_xor(n1, 16);
     n1 += __shfl_xor(n1, 32);
     double L1 = BIG, L2 = BIG, L3 = BIG, U = BIG;
     int I1 = 0x7FFFFFFF, I2 = 0x7FFFFFFF;
     const int ntiles = (k0 + 15) >> 4;
-    for (int t = wave; t < ntiles; t += MM_WAVES) {
+    for (int t = rs * MM_WAVES + wave; t < ntiles; t += MM_RS * MM_WAVES) {
         const int i0 = t << 4;
         double a[MM_KSTEPS];
+        load_frag<VEC>(f0 + (size_t)(i0 + x) * ld0, i0 + x < k0, g, dim, a);
         double p = 0.0;
 #pragma unroll
-        for (int s = 0; s < MM_KSTEPS; ++s) {
-            const int c = 4 * s + g;
-            a[s] = (i0 + x < k0 && c < dim) ? (double)f0[(size_t)(i0 + x) * ld0 + c] : 0.0;
-            p += a[s] * a[s];
-        }
+        for (int s = 0; s < MM_KSTEPS; ++s) p += a[s] * a[s];
         p += __shfl_xor(p, 16);
         p += __shfl_xor(p, 32);  // |f0_{i0+x}|^2 on every lane with this x
         mm_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -152,53 +160,85 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const float *__res
             if (i < k0) {
                 const double v = n0 - 2.0 * acc[r];
                 const double e = kappa * (n0 + n1);
-                const double lo = v - e, up = v + e;
-                U = up < U ? up : U;
-                if (lo < L1) { L3 = L2; L2 = L1; I2 = I1; L1 = lo; I1 = i; }
-                else if (lo < L2) { L3 = L2; L2 = lo; I2 = i; }
-                else if (lo < L3) { L3 = lo; }
+                U = (v + e) < U ? (v + e) : U;
+                top3_insert(v - e, i, L1, L2, L3, I1, I2);
             }
         }
     }
-    const int e = wave * 4 + g;
-    sL[0][e][x] = L1; sL[1][e][x] = L2; sL[2][e][x] = L3;
-    sI[0][e][x] = I1; sI[1][e][x] = I2;
-    sU[e][x] = U;
+    // ---- workgroup top-3 per column: merge the 4 lane groups by shuffles, the 16 waves through LDS
+#define MM_SHFL_MERGE(OFF)                                                                           \
+    {                                                                                                \
+        const double pL1 = __shfl_xor(L1, OFF), pL2 = __shfl_xor(L2, OFF), pL3 = __shfl_xor(L3, OFF); \
+        const double pU = __shfl_xor(U, OFF);                                                        \
+        const int pI1 = __shfl_xor(I1, OFF), pI2 = __shfl_xor(I2, OFF);                              \
+        U = pU < U ? pU : U;                                                                         \
+        top3_insert(pL1, pI1, L1, L2, L3, I1, I2);                                                   \
+        top3_insert(pL2, pI2, L1, L2, L3, I1, I2);                                                   \
+        top3_insert(pL3, 0x7FFFFFFF, L1, L2, L3, I1, I2);                                            \
+    }
+    MM_SHFL_MERGE(16)
+    MM_SHFL_MERGE(32)
+    if (g == 0) {
+        sL[0][wave][x] = L1; sL[1][wave][x] = L2; sL[2][wave][x] = L3;
+        sI[0][wave][x] = I1; sI[1][wave][x] = I2;
+        sU[wave][x] = U;
+    }
     __syncthreads();
-    // ---- one thread per column: certify
+    MmPartial *mine = parts + ((size_t)ctile * MM_RS + rs) * 16;
+    if (wave == 0) {
+        // lane (g, x): merge waves 4g .. 4g+3 of column x, then the 4 lane groups again
+        L1 = BIG; L2 = BIG; L3 = BIG; U = BIG; I1 = 0x7FFFFFFF; I2 = 0x7FFFFFFF;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int w = 4 * g + q;
+            U = sU[w][x] < U ? sU[w][x] : U;
+            top3_insert(sL[0][w][x], sI[0][w][x], L1, L2, L3, I1, I2);
+            top3_insert(sL[1][w][x], sI[1][w][x], L1, L2, L3, I1, I2);
+            top3_insert(sL[2][w][x], 0x7FFFFFFF, L1, L2, L3, I1, I2);
+        }
+        MM_SHFL_MERGE(16)
+        MM_SHFL_MERGE(32)
+        if (g == 0) {
+            MmPartial pt;
+            pt.L1 = L1; pt.L2 = L2; pt.L3 = L3; pt.U = U; pt.I1 = I1; pt.I2 = I2;
+            mm_publish(&mine[x], pt);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have reached L2/memory
+    }
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&tickets[ctile], 1) == MM_RS - 1;  // tid 0 is in wave 0: its stores are drained
+    __syncthreads();
+    if (!s_last) return;
+    // ---- merge the slices and certify: one thread per column
     if (tid < 16) {
         const int j = j0 + tid;
         int rescan = 0;
         if (j < k1) {
-            double Umin = BIG;
-            for (int q = 0; q < MM_WAVES * 4; ++q) Umin = sU[q][tid] < Umin ? sU[q][tid] : Umin;
-            double best = BIG;
-            int besti = 0x7FFFFFFF, ncand = 0, lasti = 0;
-            const float *bj = f1 + (size_t)j * ld1;
-            for (int q = 0; q < MM_WAVES * 4 && !rescan; ++q) {
-                if (sL[2][q][tid] <= Umin) { rescan = 1; break; }
-                for (int w = 0; w < 2; ++w) {
-                    if (sL[w][q][tid] <= Umin) {
-                        const int i = sI[w][q][tid];
-                        if (ncand == 1) {  // a second survivor: evaluate the first one too
-                            best = exact_dist(f0 + (size_t)lasti * ld0, bj, dim);
-                            besti = lasti;
-                        }
-                        if (ncand >= 1) {
-                            const double dd = exact_dist(f0 + (size_t)i * ld0, bj, dim);
-                            if (dd < best || (dd == best && i < besti)) { best = dd; besti = i; }
-                        }
-                        ++ncand;
-                        lasti = i;
-                    }
-                }
+            double a1 = BIG, a2 = BIG, a3 = BIG, Umin = BIG;
+            int i1 = 0x7FFFFFFF, i2 = 0x7FFFFFFF;
+            for (int q = 0; q < MM_RS; ++q) {
+                const MmPartial pt = mm_consume(&parts[((size_t)ctile * MM_RS + q) * 16 + tid]);
+                Umin = pt.U < Umin ? pt.U : Umin;
+                top3_insert(pt.L1, pt.I1, a1, a2, a3, i1, i2);
+                top3_insert(pt.L2, pt.I2, a1, a2, a3, i1, i2);
+                top3_insert(pt.L3, 0x7FFFFFFF, a1, a2, a3, i1, i2);
             }
-            if (!rescan) pair_idx[j] = ncand == 1 ? lasti : besti;
+            if (a3 <= Umin) {
+                rescan = 1;  // three or more rows inside the window
+                atomicAdd(&stats[0], 1);
+            } else if (a2 <= Umin) {
+                atomicAdd(&stats[1], 1);
+                const float *bj = f1 + (size_t)j * ld1;
+                const double d1 = exact_dist(f0 + (size_t)i1 * ld0, bj, dim), d2 = exact_dist(f0 + (size_t)i2 * ld0, bj, dim);
+                pair_idx[j] = (d2 < d1 || (d2 == d1 && i2 < i1)) ? i2 : i1;
+            } else {
+                pair_idx[j] = i1;  // certified without an exact evaluation
+            }
         }
         s_rescan[tid] = rescan;
     }
     __syncthreads();
-    // ---- exact re-scan of a column whose candidate list overflowed (whole workgroup)
+    // ---- exact re-scan of a column whose window holds three or more rows (whole workgroup)
     for (int cidx = 0; cidx < 16; ++cidx) {
         if (!s_rescan[cidx]) continue;  // uniform
         const float *bj = f1 + (size_t)(j0 + cidx) * ld1;
@@ -226,17 +266,22 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const float *__res
 }
 
 CAELO_API int caelo_match(caelo_ctx *c, const float *f0, int ld0, int64_t k0_max, const int32_t *n0, const float *f1,
-                          int ld1, int64_t k1_max, const int32_t *n1, int dim, int64_t *pair_idx, void *stream) {
-    CAELO_REQUIRE(c && f0 && f1 && pair_idx, "null argument");
+                          int ld1, int64_t k1_max, const int32_t *n1, int dim, int64_t *pair_idx, void *ws, void *stream) {
+    CAELO_REQUIRE(c && f0 && f1 && pair_idx && ws, "null argument");
     CAELO_REQUIRE(dim > 0 && dim <= MT_MAXDIM && ld0 >= dim && ld1 >= dim && k0_max > 0 && k1_max > 0, "bad shape");
-    // (dim <= 64 always takes the MFMA path; the plain f64 kernel is kept for wider descriptors)
-    if (dim <= 4 * MM_KSTEPS) {
-        k_match_mfma<<<(unsigned)((k1_max + 15) / 16), 64 * MM_WAVES, 0, caelo_stream(stream)>>>(f0, ld0, k0_max, n0, f1, ld1,
-                                                                                                   k1_max, n1, dim, pair_idx);
-    } else {
-        k_match<<<(unsigned)((k1_max + MT_J - 1) / MT_J), 256, 0, caelo_stream(stream)>>>(f0, ld0, k0_max, n0, f1, ld1,
-                                                                                            k1_max, n1, dim, pair_idx);
-    }
+    hipStream_t s = caelo_stream(stream);
+    const int64_t tiles = (k1_max + 15) / 16;
+    int32_t *tickets = (int32_t *)ws;
+    const size_t tbytes = (size_t)((tiles * 4 + 255) / 256) * 256;
+    MmPartial *parts = (MmPartial *)((char *)ws + 256 + tbytes);
+    int32_t *stats = (int32_t *)((char *)ws + tbytes);  // [0] columns re-scanned exactly, [1] columns decided between two rows
+    CAELO_HIP(hipMemsetAsync(tickets, 0, tbytes + 256, s));
+    const bool vec = (dim % 4 == 0) && (ld0 % 4 == 0) && (ld1 % 4 == 0) && (((uintptr_t)f0 | (uintptr_t)f1) & 15u) == 0;
+    dim3 grid((unsigned)tiles, MM_RS);
+    if (vec)
+        k_match_mfma<true><<<grid, 64 * MM_WAVES, 0, s>>>(f0, ld0, k0_max, n0, f1, ld1, k1_max, n1, dim, pair_idx, tickets, parts, stats);
+    else
+        k_match_mfma<false><<<grid, 64 * MM_WAVES, 0, s>>>(f0, ld0, k0_max, n0, f1, ld1, k1_max, n1, dim, pair_idx, tickets, parts, stats);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }
@@ -246,7 +291,7 @@ CAELO_API int caelo_match(caelo_ctx *c, const float *f0, int ld0, int64_t k0_max
 // one-sided Jacobi SVD in f64: H V = U S ; R = V U^T (the reference's V.T @ U.T with V = Vh);
 // det(R) < 0 -> the reference negates column 2 of Vh, i.e. R <- diag(1,1,-1) R  (:151-155).
 // ------------------------------------------------------------------------------------------------
-__device__ inline int rigid_from_H(const double Hin[9], const double m0[3], const double m1[3], float R[9], float T[3]) {
+__device__ __noinline__ int rigid_from_H_jacobi(const double Hin[9], const double m0[3], const double m1[3], float R[9], float T[3]) {
     double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     for (int i = 0; i < 9; ++i) A[i] = Hin[i];
     for (int sweep = 0; sweep < 12; ++sweep) {
@@ -313,6 +358,54 @@ __device__ inline int rigid_from_H(const double Hin[9], const double m0[3], cons
     for (int i = 0; i < 3; ++i)
         T[i] = (float)(m0[i] - (Rd[3 * i] * m1[0] + Rd[3 * i + 1] * m1[1] + Rd[3 * i + 2] * m1[2]));  // :157
     return det < 0 ? -1 : 1;  // isCredible (:139,:152)
+}
+
+// Fast path: R = V U^T is the orthogonal polar factor of H^T.  Scaled Newton iteration
+// X <- (g X + X^-T / g) / 2 (Higham) converges quadratically in f64 (5-7 steps, no sqrt/div chains of a
+// Jacobi SVD: ~10x shorter dependency chain, and every hypothesis wavefront runs this serially).
+// Rank-deficient or badly conditioned H (repeated sample indices) falls back to the Jacobi SVD above.
+__device__ inline int rigid_from_H(const double H[9], const double m0[3], const double m1[3], float R[9], float T[3]) {
+    double X[9] = {H[0], H[3], H[6], H[1], H[4], H[7], H[2], H[5], H[8]};  // X0 = H^T
+    double fro = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fro += X[i] * X[i];
+    bool ok = fro > 0.0;
+    double det0 = 0.0;
+    for (int it = 0; it < 16 && ok; ++it) {
+        double C[9];  // cofactors: X^-T = C / det
+        C[0] = X[4] * X[8] - X[5] * X[7]; C[1] = X[5] * X[6] - X[3] * X[8]; C[2] = X[3] * X[7] - X[4] * X[6];
+        C[3] = X[2] * X[7] - X[1] * X[8]; C[4] = X[0] * X[8] - X[2] * X[6]; C[5] = X[1] * X[6] - X[0] * X[7];
+        C[6] = X[1] * X[5] - X[2] * X[4]; C[7] = X[2] * X[3] - X[0] * X[5]; C[8] = X[0] * X[4] - X[1] * X[3];
+        const double det = X[0] * C[0] + X[1] * C[1] + X[2] * C[2];
+        double nx = 0.0, nc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { nx += X[i] * X[i]; nc += C[i] * C[i]; }
+        if (it == 0) {
+            det0 = det;
+            // sigma_min / sigma_max >= |det| / |X|_F^3 : refuse anything near rank deficiency
+            if (!(fabs(det) > 1e-9 * nx * sqrt(nx))) { ok = false; break; }
+        }
+        const double inv = 1.0 / det;
+        const double g = sqrt(sqrt(nc) * fabs(inv) / sqrt(nx));  // gamma = sqrt(|X^-1|_F / |X|_F)
+        const double a = 0.5 * g, b = 0.5 * inv / g;
+        double delta = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const double nxt = a * X[i] + b * C[i];
+            delta += (nxt - X[i]) * (nxt - X[i]);
+            X[i] = nxt;
+        }
+        if (delta < 1e-30 * 3.0) break;  // |X_{k+1} - X_k|_F < 1e-15 |Q|_F
+        if (it == 15) ok = false;
+    }
+    if (!ok) return rigid_from_H_jacobi(H, m0, m1, R, T);
+    if (det0 < 0) { X[6] = -X[6]; X[7] = -X[7]; X[8] = -X[8]; }  // Match.py:151-155: Vh[:,2] *= -1  <=>  negate row 2 of R
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = (float)X[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        T[i] = (float)(m0[i] - (X[3 * i] * m1[0] + X[3 * i + 1] * m1[1] + X[3 * i + 2] * m1[2]));  // :157
+    return det0 < 0 ? -1 : 1;
 }
 
 // residual of Match.py:191-192 in f32
@@ -425,7 +518,7 @@ __device__ void ransac_replay(int N, int level, RansacWs *ws, int *s_counts) {
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const int i = lane * PER + q;
-        int v = i < CAELO_RANSAC_MAX_TRIALS ? ws->counts[i] : 0;
+        int v = i < CAELO_RANSAC_MAX_TRIALS ? __hip_atomic_load(&ws->counts[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         v = v >= least ? v : 0;
         c[q] = v;
         run = run > v ? run : v;
@@ -475,8 +568,10 @@ __device__ void ransac_replay(int N, int level, RansacWs *ws, int *s_counts) {
     (void)s_counts;
 }
 
-// one wavefront per hypothesis; the last wavefront of a level to finish replays the accept rules
-__global__ void __launch_bounds__(64) k_ransac_eval(const float *__restrict__ pc0, int ld0, const float *__restrict__ pc1,
+// one wavefront per hypothesis, four per workgroup (one arrival ticket per workgroup: same-address device
+// atomics serialise at ~10 ns); the last workgroup of a level to finish replays the accept rules
+#define RE_WAVES 4
+__global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_eval(const float *__restrict__ pc0, int ld0, const float *__restrict__ pc1,
                                                     int ld1, const int64_t *__restrict__ pair_idx, int64_t k1_max,
                                                     const int32_t *n1p, const double *__restrict__ rnd, int level,
                                                     RansacWs *ws) {
@@ -484,8 +579,8 @@ __global__ void __launch_bounds__(64) k_ransac_eval(const float *__restrict__ pc
     __shared__ int s_last;
     if (__hip_atomic_load(&ws->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const int N = n1p ? *n1p : (int)k1_max;
-    const int trial = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int trial = blockIdx.x * RE_WAVES + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     const float thr = 0.4f * (float)(1 << level);  // 0.4, 0.8, 1.6 (:171,:210)
     const double *r4 = rnd + ((size_t)level * CAELO_RANSAC_MAX_TRIALS + trial) * 4;
     // ---- 4-point sample with replacement (:182-184): idx = int32(u * N)
@@ -531,19 +626,19 @@ __global__ void __launch_bounds__(64) k_ransac_eval(const float *__restrict__ pc
         cnt += __popcll(__ballot(in));
     }
     if (lane == 0) {
-        ws->counts[trial] = cnt;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) ws->Rt[trial][i] = R[i];
+        for (int i = 0; i < 9; ++i) ws->Rt[trial][i] = R[i];  // read by the finish kernel (kernel boundary)
 #pragma unroll
         for (int i = 0; i < 3; ++i) ws->Rt[trial][9 + i] = T[i];
-        __threadfence();  // release the count before the arrival ticket
-        s_last = atomicAdd(&ws->arrived[level], 1) == CAELO_RANSAC_MAX_TRIALS - 1;
+        // the count is read by the last hypothesis of this launch: write-through store, drained before the
+        // arrival ticket; the reader uses agent-scope loads (no release/acquire fences, G16 "atomics both sides")
+        __hip_atomic_store(&ws->counts[trial], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    if (s_last) {
-        __threadfence();  // acquire: every other hypothesis' count is visible
-        ransac_replay(N, level, ws, s_counts);
-    }
+    if (threadIdx.x == 0) s_last = atomicAdd(&ws->arrived[level], 1) == CAELO_RANSAC_MAX_TRIALS / RE_WAVES - 1;
+    __syncthreads();
+    if (s_last && threadIdx.x < 64) ransac_replay(N, level, ws, s_counts);
 }
 
 // inlier mask of the winner, then the refit over all inliers (Match.py:273-282)
@@ -599,7 +694,7 @@ CAELO_API int caelo_ransac(caelo_ctx *c, const float *pc0, int ld0, const float 
     RansacWs *ws = (RansacWs *)wsv;
     CAELO_HIP(hipMemsetAsync(&ws->done, 0, sizeof(RansacWs) - offsetof(RansacWs, done), s));
     for (int level = 0; level < CAELO_RANSAC_LEVELS; ++level) {
-        k_ransac_eval<<<CAELO_RANSAC_MAX_TRIALS, 64, 0, s>>>(pc0, ld0, pc1, ld1, pair_idx, k1_max, n1, rnd, level, ws);
+        k_ransac_eval<<<CAELO_RANSAC_MAX_TRIALS / RE_WAVES, 64 * RE_WAVES, 0, s>>>(pc0, ld0, pc1, ld1, pair_idx, k1_max, n1, rnd, level, ws);
         CAELO_LAUNCH_CHECK();
     }
     k_ransac_finish<<<1, 256, 0, s>>>(pc0, ld0, pc1, ld1, pair_idx, k1_max, n1, ws, result, inlier_mask);

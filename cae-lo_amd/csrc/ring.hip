@@ -213,55 +213,92 @@ CAELO_API int caelo_respond(caelo_ctx *c, const float *in, int in_w, int in_c, f
 // the 5x5 window; append key = (float bits of score << 32 | flat index) to a compact list.
 // f32 norm in NumPy's 8-lane pairwise order (SURVEY 8a-3'), no FMA contraction.
 // ------------------------------------------------------------------------------------------------
+// compact score histogram: bin = clamp((score bits >> 16) - 0x3E00, 0, 2047).  Scores in (0.2, 6.5e4)
+// spread over ~2000 bins of 2^-7 relative width; anything larger shares the last bin.
+#define KP_BIN_BASE 0x3E00u
+__device__ __host__ inline unsigned int kp_bin(unsigned int score_bits) {
+    const unsigned int t = score_bits >> 16;
+    return t <= KP_BIN_BASE ? 0u : (t - KP_BIN_BASE > (unsigned)(CAELO_KP_HIST_BINS - 1) ? (unsigned)(CAELO_KP_HIST_BINS - 1) : t - KP_BIN_BASE);
+}
+
+// Tile = 4 rows x 64 columns of pixels per workgroup; the 8 x 68 halo of response vectors and occupancy
+// flags is staged in LDS with coalesced loads first (the per-neighbour "occupied?" test used to put 24
+// dependent global round trips in front of every pixel).
+#define KS_ROWS 4
+#define KS_COLS 64
+#define KS_HR (KS_ROWS + 4)
+#define KS_HC (KS_COLS + 4)
+
 __global__ void __launch_bounds__(256) k_kp_score(const float *__restrict__ ring, int ring_w, int ring_c, int dist_c,
                                                   const int32_t *__restrict__ counter, int cnt_w,
                                                   const float *__restrict__ resp, unsigned long long *__restrict__ cand,
                                                   uint32_t *__restrict__ hist, int32_t *cand_count) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y + 8;  // rows 8..55 only
-    if (x < 8 || x >= CAELO_NET_W - 8) return;
-    if (x >= 56 && x < 64) return;  // the row/column mix-up of :166-167, reproduced
-    if (!(counter[y * cnt_w + x] > 0)) return;
-    const float4 *rp4 = (const float4 *)(resp + ((int64_t)y * CAELO_NET_W + x) * 8);
-    const float4 pa = rp4[0], pb = rp4[1];
-    int cnt = 0;
-    float best = 0.0f;
-    bool have = false;
-#pragma unroll
-    for (int oy = -2; oy <= 2; ++oy) {
-#pragma unroll
-        for (int ox = -2; ox <= 2; ++ox) {
-            if (oy == 0 && ox == 0) continue;
-            const int yy = y + oy, xx = x + ox;
-            if (!(counter[yy * cnt_w + xx] > 0)) continue;
+    __shared__ float4 sR[KS_HR * KS_HC * 2];
+    __shared__ unsigned char sOcc[KS_HR * KS_HC];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * KS_COLS, y0 = 8 + blockIdx.y * KS_ROWS;  // rows 8..55 only
+    for (int i = tid; i < KS_HR * KS_HC; i += 256) {
+        const int hy = i / KS_HC, hx = i % KS_HC;
+        const int yy = y0 - 2 + hy, xx = x0 - 2 + hx;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        unsigned char occ = 0;
+        if (xx >= 0 && xx < CAELO_NET_W && yy >= 0 && yy < CAELO_NET_H) {
             const float4 *rq4 = (const float4 *)(resp + ((int64_t)yy * CAELO_NET_W + xx) * 8);
-            const float4 qa = rq4[0], qb = rq4[1];
-            float d;
-            d = __fsub_rn(qa.x, pa.x); const float s0 = __fmul_rn(d, d);
-            d = __fsub_rn(qa.y, pa.y); const float s1 = __fmul_rn(d, d);
-            d = __fsub_rn(qa.z, pa.z); const float s2 = __fmul_rn(d, d);
-            d = __fsub_rn(qa.w, pa.w); const float s3 = __fmul_rn(d, d);
-            d = __fsub_rn(qb.x, pb.x); const float s4 = __fmul_rn(d, d);
-            d = __fsub_rn(qb.y, pb.y); const float s5 = __fmul_rn(d, d);
-            d = __fsub_rn(qb.z, pb.z); const float s6 = __fmul_rn(d, d);
-            d = __fsub_rn(qb.w, pb.w); const float s7 = __fmul_rn(d, d);
-            const float t = __fadd_rn(__fadd_rn(__fadd_rn(s0, s1), __fadd_rn(s2, s3)),
-                                      __fadd_rn(__fadd_rn(s4, s5), __fadd_rn(s6, s7)));
-            const float nd = sqrtf(t);
-            if (!have || nd < best) { best = nd; have = true; }
-            ++cnt;
+            a = rq4[0];
+            b = rq4[1];
+            occ = counter[yy * cnt_w + xx] > 0;
+        }
+        sR[2 * i] = a;
+        sR[2 * i + 1] = b;
+        sOcc[i] = occ;
+    }
+    __syncthreads();
+    const int lx = tid & (KS_COLS - 1), ly = tid / KS_COLS;
+    const int x = x0 + lx, y = y0 + ly;
+    float best = 0.0f;
+    bool is_cand = false;
+    const int c = (ly + 2) * KS_HC + lx + 2;
+    if (x >= 8 && x < CAELO_NET_W - 8 && !(x >= 56 && x < 64) && sOcc[c]) {  // :163-167 (incl. the 56..63 quirk), :210-213
+        const float4 pa = sR[2 * c], pb = sR[2 * c + 1];
+        int cnt = 0;
+        bool have = false;
+#pragma unroll
+        for (int oy = -2; oy <= 2; ++oy) {
+#pragma unroll
+            for (int ox = -2; ox <= 2; ++ox) {
+                if (oy == 0 && ox == 0) continue;
+                const int q = c + oy * KS_HC + ox;
+                if (!sOcc[q]) continue;
+                const float4 qa = sR[2 * q], qb = sR[2 * q + 1];
+                float d;
+                d = __fsub_rn(qa.x, pa.x); const float s0 = __fmul_rn(d, d);
+                d = __fsub_rn(qa.y, pa.y); const float s1 = __fmul_rn(d, d);
+                d = __fsub_rn(qa.z, pa.z); const float s2 = __fmul_rn(d, d);
+                d = __fsub_rn(qa.w, pa.w); const float s3 = __fmul_rn(d, d);
+                d = __fsub_rn(qb.x, pb.x); const float s4 = __fmul_rn(d, d);
+                d = __fsub_rn(qb.y, pb.y); const float s5 = __fmul_rn(d, d);
+                d = __fsub_rn(qb.z, pb.z); const float s6 = __fmul_rn(d, d);
+                d = __fsub_rn(qb.w, pb.w); const float s7 = __fmul_rn(d, d);
+                const float t = __fadd_rn(__fadd_rn(__fadd_rn(s0, s1), __fadd_rn(s2, s3)),
+                                          __fadd_rn(__fadd_rn(s4, s5), __fadd_rn(s6, s7)));
+                const float nd = sqrtf(t);
+                if (!have || nd < best) { best = nd; have = true; }
+                ++cnt;
+            }
+        }
+        if (cnt >= 5 && (double)best > 0.2) {  // :186, :126,:199
+            const float *px = ring + ((int64_t)y * ring_w + x) * ring_c;
+            float d2 = __fmul_rn(px[0], px[0]);
+            for (int ch = 1; ch < dist_c; ++ch) d2 = __fadd_rn(d2, __fmul_rn(px[ch], px[ch]));  // :197
+            is_cand = sqrtf(d2) >= 10.0f;                                                       // :198 VisibleBottom
         }
     }
-    if (cnt < 5) return;                   // :186
-    if (!((double)best > 0.2)) return;     // :126,:199
-    const float *px = ring + ((int64_t)y * ring_w + x) * ring_c;
-    float d2 = __fmul_rn(px[0], px[0]);
-    for (int c = 1; c < dist_c; ++c) d2 = __fadd_rn(d2, __fmul_rn(px[c], px[c]));  // :197
-    if (!(sqrtf(d2) >= 10.0f)) return;                                        // :198 VisibleBottom
-    const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(y * CAELO_NET_W + x);
-    const int pos = atomicAdd(cand_count, 1);
-    cand[pos] = key;
-    atomicAdd(&hist[__float_as_uint(best) >> 16], 1u);  // 16-bit score histogram for the top-k cut
+    // one returning global atomic per WORKGROUP reserves the slots of all its candidates
+    __shared__ int s_tmp[2];
+    const int pos = caelo_block_reserve(cand_count, is_cand, s_tmp);
+    if (is_cand) {
+        cand[pos] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(y * CAELO_NET_W + x);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -276,6 +313,10 @@ __global__ void __launch_bounds__(256) k_kp_score(const float *__restrict__ ring
 // ------------------------------------------------------------------------------------------------
 #define SEL_THREADS 1024
 #define SEL_N 2048
+
+// phase timestamps of the last k_kp_select launch (wall_clock64, 100 MHz), read by caelo_debug_read
+__device__ unsigned long long g_sel_stamp[16];
+#define SEL_STAMP(i) do { if (threadIdx.x == 0) g_sel_stamp[i] = wall_clock64(); } while (0)
 
 __device__ unsigned long long radix_select_threshold(const unsigned long long *cand, int M, int keep, unsigned int *hist,
                                                      unsigned long long *s_prefix, int *s_want) {
@@ -321,74 +362,96 @@ __global__ void __launch_bounds__(SEL_THREADS) k_kp_select(const unsigned long l
     __shared__ unsigned long long s_prefix;
     __shared__ int s_want, s_nsel, s_cutbin;
     const int tid = threadIdx.x;
+    SEL_STAMP(0);
     const int M = *cand_count;
     const int keep = M < 1025 ? M : 1025;
     unsigned long long thresh = 0ull;
     if (M > 1025) {
-        // ---- bin of the keep-th largest key: suffix sums over 64 bins per thread
-        unsigned int loc = 0;
-        for (int b = 0; b < 64; ++b) loc += ghist[tid * 64 + b];
-        part[tid] = loc;
+        // ---- score histogram in LDS (2048 bins; a global one funnels 32k device atomics into one
+        //      memory channel: 15 us), then the bin of the keep-th largest key: thread t owns bins 2t, 2t+1
+        unsigned int *lh = (unsigned int *)sel;  // 8 KB of the 16 KB key buffer, free until the gather
+        lh[2 * tid] = 0u;
+        lh[2 * tid + 1] = 0u;
         __syncthreads();
-        // inclusive suffix scan (Hillis-Steele over 1024 entries)
-        for (int off = 1; off < SEL_THREADS; off <<= 1) {
+        for (int i0 = 0; i0 < M; i0 += SEL_THREADS * 8) {
+            unsigned long long kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * SEL_THREADS + tid;
+                kk[u] = i < M ? cand[i] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (kk[u] != 0ull) atomicAdd(&lh[kp_bin((unsigned int)(kk[u] >> 32))], 1u);
+        }
+        __syncthreads();
+        const uint2 hb = make_uint2(lh[2 * tid], lh[2 * tid + 1]);
+        part[tid] = hb.x + hb.y;
+        __syncthreads();
+        SEL_STAMP(1);
+        for (int off = 1; off < SEL_THREADS; off <<= 1) {  // inclusive suffix scan (Hillis-Steele)
             const unsigned int add = (tid + off < SEL_THREADS) ? part[tid + off] : 0u;
             __syncthreads();
             part[tid] += add;
             __syncthreads();
         }
-        const unsigned int above = (tid + 1 < SEL_THREADS) ? part[tid + 1] : 0u;  // keys in higher thread ranges
+        SEL_STAMP(2);
+        const unsigned int above = (tid + 1 < SEL_THREADS) ? part[tid + 1] : 0u;  // keys in higher bins
         if (above < (unsigned)keep && part[tid] >= (unsigned)keep) {
-            unsigned int cum = above;
-            int b = 63;
-            for (; b > 0; --b) {
-                cum += ghist[tid * 64 + b];
-                if (cum >= (unsigned)keep) break;
-            }
-            if (b == 0) cum += ghist[tid * 64];
-            s_cutbin = tid * 64 + b;
-            s_nsel = (int)cum;  // keys with top16 >= cut bin
+            // the cut is bin 2t+1 if that alone reaches `keep`, else bin 2t
+            if (above + hb.y >= (unsigned)keep) { s_cutbin = 2 * tid + 1; s_nsel = (int)(above + hb.y); }
+            else { s_cutbin = 2 * tid; s_nsel = (int)part[tid]; }
         }
         __syncthreads();
         if (s_nsel <= SEL_N) {
-            thresh = (unsigned long long)s_cutbin << 48;
+            thresh = s_cutbin == 0 ? 0ull : ((unsigned long long)(KP_BIN_BASE + s_cutbin) << 48);
         } else {
             thresh = radix_select_threshold(cand, M, keep, hist, &s_prefix, &s_want);
         }
         __syncthreads();
     }
+    SEL_STAMP(3);
     if (tid == 0) s_nsel = 0;
     for (int i = tid; i < SEL_N; i += SEL_THREADS) sel[i] = ~0ull;
     __syncthreads();
-    for (int i = tid; i < M; i += SEL_THREADS) {
-        const unsigned long long k = cand[i];
-        if (k >= thresh) {
-            const int p = atomicAdd(&s_nsel, 1);
-            if (p < SEL_N) sel[p] = k;
+    for (int i0 = 0; i0 < M; i0 += SEL_THREADS * 8) {
+        unsigned long long kk[8];  // 8 independent loads in flight, then the (rare) LDS appends
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * SEL_THREADS + tid;
+            kk[u] = i < M ? cand[i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (kk[u] >= thresh && kk[u] != 0ull) {
+                const int p = atomicAdd(&s_nsel, 1);
+                if (p < SEL_N) sel[p] = kk[u];
+            }
         }
     }
     __syncthreads();
-    const int nsel = s_nsel < SEL_N ? s_nsel : SEL_N;  // >= keep real keys
-    // rank sort: keys are unique, so rank = number of smaller keys; one pass over LDS (broadcast reads),
-    // no barriers inside (a 2048-element bitonic network needs 66 of them)
-    __shared__ unsigned long long sorted[SEL_N];
-    for (int i = tid; i < nsel; i += SEL_THREADS) {
-        const unsigned long long mine = sel[i];
-        int rank = 0;
-        const ulonglong2 *s2 = (const ulonglong2 *)sel;  // entries >= nsel hold ~0 (never smaller)
-#pragma unroll 8
-        for (int j = 0; j < (nsel + 1) / 2; ++j) {
-            const ulonglong2 v = s2[j];
-            rank += (v.x < mine ? 1 : 0) + (v.y < mine ? 1 : 0);
+    SEL_STAMP(4);
+    const int nsel = s_nsel < SEL_N ? s_nsel : SEL_N;  // >= keep real keys, padding (~0) sorts to the end
+    // bitonic sort ascending, 2048 elements, 1024 threads.  For strides j <= 64 a wavefront's 64 threads
+    // only touch their own 128 consecutive elements: no workgroup barrier needed (56 of the 66 steps).
+    for (int k = 2; k <= SEL_N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int i = ((tid & ~(j - 1)) << 1) | (tid & (j - 1));
+            const int p = i | j;
+            const unsigned long long a = sel[i], b = sel[p];
+            const bool up = ((i & k) == 0);
+            if ((a > b) == up) { sel[i] = b; sel[p] = a; }
+            if (j > 64 || (j == 1 && k >= 128)) __syncthreads();  // next step crosses wavefronts
+            else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
         }
-        sorted[rank] = mine;
     }
     __syncthreads();
+    SEL_STAMP(5);
     const int K = keep > 0 ? keep - 1 : 0;  // drop the single best (:216,:218)
     const int first = nsel - keep;           // the keep largest real keys are sel[first .. nsel)
     for (int i = tid; i < CAELO_MAX_KEYPTS; i += SEL_THREADS) {
         if (i < K) {
-            const unsigned idx = (unsigned)(sorted[first + i] & 0xFFFFFFFFull);
+            const unsigned idx = (unsigned)(sel[first + i] & 0xFFFFFFFFull);
             const int y = idx / CAELO_NET_W, x = idx % CAELO_NET_W;
             key_pixels[2 * i] = y;
             key_pixels[2 * i + 1] = x;
@@ -399,6 +462,7 @@ __global__ void __launch_bounds__(SEL_THREADS) k_kp_select(const unsigned long l
         }
         if (valid) valid[(size_t)valid_ld * i] = i < K ? 1.0f : 0.0f;
     }
+    SEL_STAMP(6);
     if (tid == 0) {
         *n_key = K;
         if (K <= 50) atomicOr(status, CAELO_ST_FEW_KEYPTS);  // :286
@@ -409,13 +473,20 @@ int ring_keypoints_launch(const float *ring, int ring_w, int ring_c, int dist_c,
                           const float *resp, unsigned long long *cand, uint32_t *hist, int32_t *cand_count,
                           int64_t *key_pixels, float *key_pts, int kp_ld, float *valid, int valid_ld, int32_t *n_key,
                           int32_t *status, hipStream_t s) {
-    dim3 grid((CAELO_NET_W + 255) / 256, 48);
+    dim3 grid(CAELO_NET_W / KS_COLS, 48 / KS_ROWS);
     k_kp_score<<<grid, 256, 0, s>>>(ring, ring_w, ring_c, dist_c, counter, cnt_w, resp, cand, hist, cand_count);
     CAELO_LAUNCH_CHECK();
     k_kp_select<<<1, SEL_THREADS, 0, s>>>(cand, hist, cand_count, ring, ring_w, ring_c, key_pixels, key_pts, kp_ld, valid,
                                           valid_ld, n_key, status);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
+}
+
+// debug aid: copies the 16 phase timestamps of the last keypoint selection (100 MHz ticks) to the host
+int enc_debug_copy(unsigned long long *out_host);
+CAELO_API int caelo_debug_read(unsigned long long *out_host) {  // out_host[32]: keypoint select | encoder stage 1
+    CAELO_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_sel_stamp), sizeof(unsigned long long) * 16));
+    return enc_debug_copy(out_host + 16);
 }
 
 CAELO_API int64_t caelo_keypoints_ws_bytes(void) {

@@ -153,13 +153,12 @@ __device__ inline int table_insert_new(unsigned long long *keys, uint32_t mask, 
     return -1;
 }
 
-// brick_mark that appends a newly created brick's slot to a compact list (so the next pass runs on
-// dense wavefronts instead of scanning a 90 %-empty table)
-__device__ inline bool brick_mark_list(caelo_brick_table t, int x, int y, int z, uint32_t *list, int32_t *list_n) {
-    bool is_new;
-    const int slot = table_insert_new(t.keys, t.mask, caelo_pack3(x >> 3, y >> 3, z >> 3), &is_new);
+// brick_mark that reports a newly created brick (the caller appends its slot to a compact list, one
+// global atomic per workgroup, so the next pass runs on dense wavefronts)
+__device__ inline bool brick_mark_new(caelo_brick_table t, int x, int y, int z, int *slot_out, bool *is_new) {
+    const int slot = table_insert_new(t.keys, t.mask, caelo_pack3(x >> 3, y >> 3, z >> 3), is_new);
+    *slot_out = slot;
     if (slot < 0) return false;
-    if (is_new) list[atomicAdd(list_n, 1)] = (uint32_t)slot;
     const unsigned long long bit = 1ull << (((y & 7) << 3) | (z & 7));
     unsigned long long *w = &t.bits[(size_t)slot * 8 + (x & 7)];
     if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit))
@@ -287,41 +286,77 @@ __global__ void __launch_bounds__(256) k_vox_points(const float *__restrict__ pc
                                                     caelo_brick_table b0, uint32_t *list0, int32_t *counts,
                                                     int32_t *status) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float *p = pc + i * stride;
-    const VoxIdx v = voxel_indices(p[0], p[1], p[2]);
-    if (v.oob) atomicOr(status, CAELO_ST_VOXEL_OOB);
-    if (!v.ok) return;
-    bool consistent = true;
+    const int lane = threadIdx.x & 63;
+    VoxIdx v;
+    v.ok = false;
+    v.oob = false;
+    if (i < n) {
+        const float *p = pc + i * stride;
+        v = voxel_indices(p[0], p[1], p[2]);
+    }
+    int st = v.oob ? CAELO_ST_VOXEL_OOB : 0;
+    unsigned long long key = CAELO_EMPTY_KEY;
+    if (v.ok) {
+        bool consistent = true;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) consistent &= (v.v1[a] == (v.g[a] >> 3)) && (v.v2[a] == (v.g[a] >> 5));
-    if (!consistent) atomicOr(status, CAELO_ST_VOXEL_INEXACT);
-    if (!brick_mark_list(b0, v.g[0], v.g[1], v.g[2], list0, &counts[4])) atomicOr(status, CAELO_ST_MAP_FULL);
+        for (int a = 0; a < 3; ++a) consistent &= (v.v1[a] == (v.g[a] >> 3)) && (v.v2[a] == (v.g[a] >> 5));
+        if (!consistent) st |= CAELO_ST_VOXEL_INEXACT;
+        key = caelo_pack3(v.g[0] >> 3, v.g[1] >> 3, v.g[2] >> 3);
+    }
+    // Neighbouring points of a scan line fall into the same 16 cm brick: only the first lane of each run of
+    // equal keys walks the hash table (memory-side atomics cost microseconds), the run reuses its slot.
+    const unsigned long long prev = __shfl_up(key, 1);
+    const bool head = v.ok && (lane == 0 || prev != key);
+    int slot = -1;
+    bool is_new = false;
+    if (head) slot = table_insert_new(b0.keys, b0.mask, key, &is_new);
+    if (head && slot < 0) st |= CAELO_ST_MAP_FULL;
+    __shared__ int s_tmp[2];
+    const int lpos = caelo_block_reserve(&counts[4], is_new, s_tmp);  // ONE global atomic per workgroup
+    if (is_new) list0[lpos] = (uint32_t)slot;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    const int src = below ? 63 - __clzll(below) : lane;
+    slot = __shfl(slot, src);
+    if (v.ok && slot >= 0) {
+        const unsigned long long bit = 1ull << (((v.g[1] & 7) << 3) | (v.g[2] & 7));
+        unsigned long long *w = &b0.bits[(size_t)slot * 8 + (v.g[0] & 7)];
+        if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit))
+            (void)__hip_atomic_fetch_or(w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (st) atomicOr(status, st);
 }
 
-// grid-stride over the occupied scale-0 bricks: a brick is a scale-1 voxel, and counts its own voxels
+// the occupied scale-0 bricks (256 per workgroup iteration): a brick is a scale-1 voxel, and counts its voxels
 __global__ void __launch_bounds__(256) k_vox_coarse(caelo_brick_table b0, caelo_brick_table b1, const uint32_t *list0,
                                                     uint32_t *list1, int32_t *counts, int32_t *status) {
+    __shared__ int s_tmp[2];
     const int nb = counts[4];
     int pop = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
-        const uint32_t slot = list0[i];
-        const unsigned long long k = b0.keys[slot];
-        const ulonglong2 *w = (const ulonglong2 *)(b0.bits + (size_t)slot * 8);
+    for (int i0 = blockIdx.x * blockDim.x; i0 < nb; i0 += gridDim.x * blockDim.x) {  // uniform trip count per workgroup
+        const int i = i0 + threadIdx.x;
+        bool is_new = false;
+        int slot1 = -1;
+        if (i < nb) {
+            const uint32_t slot = list0[i];
+            const unsigned long long k = b0.keys[slot];
+            const ulonglong2 *w = (const ulonglong2 *)(b0.bits + (size_t)slot * 8);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const ulonglong2 u = w[q]; pop += __popcll(u.x) + __popcll(u.y); }
-        const int x = (int)((k >> 40) & 0xFFFFF), y = (int)((k >> 20) & 0xFFFFF), z = (int)(k & 0xFFFFF);
-        if (!brick_mark_list(b1, x, y, z, list1, &counts[5])) atomicOr(status, CAELO_ST_MAP_FULL);
+            for (int q = 0; q < 4; ++q) { const ulonglong2 u = w[q]; pop += __popcll(u.x) + __popcll(u.y); }
+            const int x = (int)((k >> 40) & 0xFFFFF), y = (int)((k >> 20) & 0xFFFFF), z = (int)(k & 0xFFFFF);
+            if (!brick_mark_new(b1, x, y, z, &slot1, &is_new)) atomicOr(status, CAELO_ST_MAP_FULL);
+        }
+        const int lpos = caelo_block_reserve(&counts[5], is_new, s_tmp);
+        if (is_new) list1[lpos] = (uint32_t)slot1;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) pop += __shfl_xor(pop, o);
-    if ((threadIdx.x & 63) == 0 && pop) atomicAdd(&counts[0], pop);
+    caelo_block_add(&counts[0], pop, s_tmp);
 }
 
-// grid-stride over the occupied scale-1 bricks: count their voxels and mark the scale-2 voxels under
-// them (a scale-1 brick spans 2x2x2 scale-2 voxels: scale-2 index = scale-1 index >> 2)
+// the occupied scale-1 bricks: count their voxels and mark the scale-2 voxels under them
+// (a scale-1 brick spans 2x2x2 scale-2 voxels: scale-2 index = scale-1 index >> 2)
 __global__ void __launch_bounds__(256) k_vox_coarse2(caelo_brick_table b1, caelo_brick_table b2, const uint32_t *list1,
                                                      int32_t *counts, int32_t *status) {
+    __shared__ int s_tmp[2];
     const int nb = counts[5];
     int pop = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
@@ -344,13 +379,12 @@ __global__ void __launch_bounds__(256) k_vox_coarse2(caelo_brick_table b1, caelo
                 }
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) pop += __shfl_xor(pop, o);
-    if ((threadIdx.x & 63) == 0 && pop) atomicAdd(&counts[1], pop);
+    caelo_block_add(&counts[1], pop, s_tmp);
 }
 
 // one thread per scale-2 brick slot: count
 __global__ void __launch_bounds__(256) k_vox_count2(caelo_brick_table b2, int32_t *counts) {
+    __shared__ int s_tmp[2];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     int pop = 0;
     if (i <= b2.mask && b2.keys[i] != CAELO_EMPTY_KEY) {
@@ -358,9 +392,7 @@ __global__ void __launch_bounds__(256) k_vox_count2(caelo_brick_table b2, int32_
 #pragma unroll
         for (int q = 0; q < 8; ++q) pop += __popcll(w[q]);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) pop += __shfl_xor(pop, o);
-    if ((threadIdx.x & 63) == 0 && pop) atomicAdd(&counts[2], pop);
+    caelo_block_add(&counts[2], pop, s_tmp);
 }
 
 int vox_build_fast_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, int32_t *status, hipStream_t s) {
@@ -449,7 +481,7 @@ CAELO_API int caelo_voxmap_from_lists(caelo_ctx *c, caelo_voxmap *m, const int16
 #define BALL_R 13      // |d| <= 13 per axis covers every voxel with d2 <= 192
 #define BALL_D2 192    // farthest in-window offset (-8,-8,-8)
 #define NN_CAP 496     // Voxel.py:182
-#define CLASS_CAP 512
+#define CLASS_CAP 192   // max #lattice points on a sphere x^2+y^2+z^2 = n, n <= 192
 
 struct PatchWaveLds {
     unsigned long long bricks[125 * 8];
@@ -495,20 +527,49 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
     const int kz = (int)(((double)pts[(size_t)pts_ld * kp + 2] + VIS_H) / vs);
     const int bx0 = (kx - BALL_R) >> 3, by0 = (ky - BALL_R) >> 3, bz0 = (kz - BALL_R) >> 3;
     const int nbx = ((kx + BALL_R) >> 3) - bx0 + 1, nby = ((ky + BALL_R) >> 3) - by0 + 1, nbz = ((kz + BALL_R) >> 3) - bz0 + 1;
-    // ---- stage <= 125 bricks in LDS (one 64-byte line each); popcount gives a cheap bound on the ball
+    // ---- stage <= 125 bricks in LDS (one 64-byte line each); popcount gives a cheap bound on the ball.
+    // Lane l owns bricks l and l + 64: both first probes, then both payloads, are issued together so the
+    // wavefront pays two dependent L2 round trips instead of four (the tables are <= 10 % full: the first
+    // probe almost always decides; collisions continue in the generic loop).
     int pop = 0;
-    for (int l = lane; l < 125; l += 64) {
-        const int ix = l / 25, iy = (l / 5) % 5, iz = l % 5;
-        int slot = -1;
-        if (ix < nbx && iy < nby && iz < nbz && bx0 + ix >= 0 && by0 + iy >= 0 && bz0 + iz >= 0)
-            slot = table_find(tab.keys, tab.mask, caelo_pack3(bx0 + ix, by0 + iy, bz0 + iz));
-        const ulonglong2 *src = (const ulonglong2 *)(tab.bits + (size_t)(slot < 0 ? 0 : slot) * 8);
+    {
+        unsigned long long key[2];
+        uint32_t h[2];
+        bool want[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ulonglong2 v = slot < 0 ? make_ulonglong2(0ull, 0ull) : src[q];
-            L.bricks[l * 8 + 2 * q] = v.x;
-            L.bricks[l * 8 + 2 * q + 1] = v.y;
-            pop += __popcll(v.x) + __popcll(v.y);
+        for (int u = 0; u < 2; ++u) {
+            const int l = lane + 64 * u;
+            const int ix = l / 25, iy = (l / 5) % 5, iz = l % 5;
+            want[u] = l < 125 && ix < nbx && iy < nby && iz < nbz && bx0 + ix >= 0 && by0 + iy >= 0 && bz0 + iz >= 0;
+            key[u] = caelo_pack3(bx0 + ix, by0 + iy, bz0 + iz);
+            h[u] = caelo_hash64(key[u]) & tab.mask;
+        }
+        unsigned long long k0v = want[0] ? tab.keys[h[0]] : CAELO_EMPTY_KEY;
+        unsigned long long k1v = want[1] ? tab.keys[h[1]] : CAELO_EMPTY_KEY;
+        int slot[2];
+        slot[0] = !want[0] || k0v == CAELO_EMPTY_KEY ? -1 : (k0v == key[0] ? (int)h[0] : -2);
+        slot[1] = !want[1] || k1v == CAELO_EMPTY_KEY ? -1 : (k1v == key[1] ? (int)h[1] : -2);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (slot[u] == -2) slot[u] = table_find(tab.keys, tab.mask, key[u]);  // collided: probe on
+        ulonglong2 pay[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const ulonglong2 *src = (const ulonglong2 *)(tab.bits + (size_t)(slot[u] < 0 ? 0 : slot[u]) * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pay[u][q] = slot[u] < 0 ? make_ulonglong2(0ull, 0ull) : src[q];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int l = lane + 64 * u;
+            if (l < 125) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    L.bricks[l * 8 + 2 * q] = pay[u][q].x;
+                    L.bricks[l * 8 + 2 * q + 1] = pay[u][q].y;
+                    pop += __popcll(pay[u][q].x) + __popcll(pay[u][q].y);
+                }
+            }
         }
     }
     pop = wave_sum(pop);

@@ -90,6 +90,10 @@ int caelo_keypoints(caelo_ctx *ctx, const float *ring, int ring_w, int ring_c, c
                     const float *resp, void *ws, int64_t *key_pixels, float *key_pts, int32_t *n_key,
                     int32_t *status, void *stream);
 
+/* debug aid: out_host[32] = 16 phase timestamps (100 MHz ticks) of the last keypoint-selection kernel, then 16 of
+ * the last encoder stage-1 kernel (workgroup 0, first patch) */
+int caelo_debug_read(unsigned long long *out_host);
+
 /* Voxelization  (Voxel.py:100-173) into a device voxel map (3 scales of 8^3-voxel bricks). */
 int caelo_voxmap_create(caelo_ctx *ctx, int64_t max_points, caelo_voxmap **map);
 void caelo_voxmap_destroy(caelo_voxmap *map);
@@ -126,10 +130,12 @@ int caelo_encode_profile(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches
                          int out_stride, void *ws, void *stream, float *ms_host);
 
 /* NN match  (Match.py:257-258): pair_idx[j] = argmin_i ||f0[i]-f1[j]|| (f64, first minimum).
- * f0 [k0][ld0], f1 [k1][ld1] (leading dimensions in floats, >= dim); k0/k1 read from the n0/n1
- * device words when non-null. */
+ * f0 [k0][ld0], f1 [k1][ld1] (leading dimensions in floats, >= dim, dim <= 64); k0/k1 read from the
+ * n0/n1 device words when non-null.
+ * ws: caelo_match_ws_bytes(k1_max) bytes, 256-byte aligned (partial results of the row slices). */
+int64_t caelo_match_ws_bytes(int64_t k1_max);
 int caelo_match(caelo_ctx *ctx, const float *f0, int ld0, int64_t k0_max, const int32_t *n0, const float *f1, int ld1,
-                int64_t k1_max, const int32_t *n1, int dim, int64_t *pair_idx, void *stream);
+                int64_t k1_max, const int32_t *n1, int dim, int64_t *pair_idx, void *ws, void *stream);
 
 /* SolveRT  (Match.py:138-158): p0 ~ R p1 + T over n point pairs.  R [9], T [3] f32 (device);
  * credible [1] i32 (optional): the reference's isCredible, -1 when det(R) < 0 was met. */
