@@ -4,10 +4,12 @@ ROCm, "gloo" in the CPU tests).
 The path shards by frames: feature extraction is independent per frame
 (the reference fans frames out to worker processes: BatchPreprocess.py:215-228,
 PoseEstimation.py:79-99) and matching needs consecutive frames only (PoseEstimation.py:241-251).
-Each rank extracts a contiguous block of frames, ONE all-gather moves the per-frame rows
+Each rank extracts a contiguous block of frames, ONE all-gather moves per-frame rows
 (60-d descriptor | key point xyz | valid flag) over xGMI, then every rank matches the pairs whose
 second frame it owns -- the pair straddling a block boundary takes its first frame from the
-gathered rows of the previous rank.  Pose chaining (PoseEstimation.py:253-267) is a prefix product
+gathered rows of the previous rank.  ``all_gather_frames`` moves every frame (what a global
+loop-closure search would need); ``all_gather_boundary`` moves only each rank's last frame, which is
+all that consecutive-pair odometry (PoseEstimation.py:241-251) reads from another rank.  Pose chaining (PoseEstimation.py:253-267) is a prefix product
 of the gathered per-pair (R, T) on rank 0 (host, 3x4 algebra).
 
 Nothing here is device specific: the same code runs under gloo on CPU tensors in tests/.
@@ -67,6 +69,18 @@ def all_gather_frames(local_rows, n_frames, group=None):
         rlo, rhi = shard_frames(n_frames, r, world)
         parts.append(recv[r * fmax: r * fmax + (rhi - rlo)])
     return torch.cat(parts, dim=0)
+
+
+def all_gather_boundary(last_rows, group=None):
+    """last_rows [K, 64] (this rank's LAST frame) -> [world, K, 64]: the only remote rows consecutive-pair
+    matching needs (rank r matches its first frame against row r-1).  Same single collective as
+    all_gather_frames with 1/F_local of the payload (262 KB per rank instead of F_local x 262 KB)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return last_rows.unsqueeze(0)
+    recv = last_rows.new_empty((world,) + tuple(last_rows.shape))
+    dist.all_gather_into_tensor(recv, last_rows.contiguous(), group=group)
+    return recv
 
 
 def local_pairs(n_frames, rank, world):

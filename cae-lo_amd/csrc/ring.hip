@@ -484,9 +484,11 @@ int ring_keypoints_launch(const float *ring, int ring_w, int ring_c, int dist_c,
 
 // debug aid: copies the 16 phase timestamps of the last keypoint selection (100 MHz ticks) to the host
 int enc_debug_copy(unsigned long long *out_host);
-CAELO_API int caelo_debug_read(unsigned long long *out_host) {  // out_host[32]: keypoint select | encoder stage 1
+int patch_debug_copy(unsigned long long *out_host);
+CAELO_API int caelo_debug_read(unsigned long long *out_host) {  // out_host[40]: keypoint select | encoder stage 1 | patches
     CAELO_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_sel_stamp), sizeof(unsigned long long) * 16));
-    return enc_debug_copy(out_host + 16);
+    int rc = enc_debug_copy(out_host + 16);
+    return rc ? rc : patch_debug_copy(out_host + 32);
 }
 
 CAELO_API int64_t caelo_keypoints_ws_bytes(void) {

@@ -364,7 +364,10 @@ __global__ void __launch_bounds__(256) k_vox_coarse2(caelo_brick_table b1, caelo
         const unsigned long long k = b1.keys[slot];
         const int bx = (int)((k >> 40) & 0xFFFFF) << 3, by = (int)((k >> 20) & 0xFFFFF) << 3, bz = (int)(k & 0xFFFFF) << 3;
         const unsigned long long *w = b1.bits + (size_t)slot * 8;
-        // octant (hx, hy, hz): words x in [4hx, 4hx+4), bits y in [4hy, ..), z in [4hz, ..)
+        // The 2x2x2 scale-2 voxels under this brick all live in ONE scale-2 brick (index >> 2): one table
+        // insert, then one OR per x-half with the (hy, hz) bits gathered -- not eight insert+OR chains of
+        // memory-side atomics.  Octant (hx, hy, hz): words x in [4hx, 4hx+4), bits y in [4hy, ..), z in [4hz, ..)
+        unsigned long long orv[2] = {0ull, 0ull};
 #pragma unroll
         for (int hx = 0; hx < 2; ++hx) {
             const unsigned long long m = w[4 * hx] | w[4 * hx + 1] | w[4 * hx + 2] | w[4 * hx + 3];
@@ -374,9 +377,23 @@ __global__ void __launch_bounds__(256) k_vox_coarse2(caelo_brick_table b1, caelo
 #pragma unroll
                 for (int hz = 0; hz < 2; ++hz) {
                     const unsigned long long sel = (0x0F0F0F0Full << (4 * hz)) << (32 * hy);
-                    if (m & sel)
-                        if (!brick_mark(b2, (bx >> 2) + hx, (by >> 2) + hy, (bz >> 2) + hz)) atomicOr(status, CAELO_ST_MAP_FULL);
+                    const int y2 = (by >> 2) + hy, z2 = (bz >> 2) + hz;
+                    if (m & sel) orv[hx] |= 1ull << (((y2 & 7) << 3) | (z2 & 7));
                 }
+        }
+        if (orv[0] | orv[1]) {
+            const int x2 = bx >> 2;  // even: x2 and x2 + 1 share the scale-2 brick
+            const int slot2 = table_insert(b2.keys, b2.mask, caelo_pack3(x2 >> 3, by >> 5, bz >> 5));
+            if (slot2 < 0) atomicOr(status, CAELO_ST_MAP_FULL);
+            else {
+#pragma unroll
+                for (int hx = 0; hx < 2; ++hx) {
+                    if (!orv[hx]) continue;
+                    unsigned long long *wd = &b2.bits[(size_t)slot2 * 8 + ((x2 + hx) & 7)];
+                    if ((__hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & orv[hx]) != orv[hx])
+                        (void)__hip_atomic_fetch_or(wd, orv[hx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
     }
     caelo_block_add(&counts[1], pop, s_tmp);
@@ -483,8 +500,20 @@ CAELO_API int caelo_voxmap_from_lists(caelo_ctx *c, caelo_voxmap *m, const int16
 #define NN_CAP 496     // Voxel.py:182
 #define CLASS_CAP 192   // max #lattice points on a sphere x^2+y^2+z^2 = n, n <= 192
 
+// debug aid: timestamps (100 MHz) of workgroup 0 / wave 0 of the last k_patches launch
+__device__ unsigned long long g_patch_stamp[8];
+#define PATCH_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_patch_stamp[i] = wall_clock64(); } while (0)
+int patch_debug_copy(unsigned long long *out_host) {
+    CAELO_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_patch_stamp), sizeof(unsigned long long) * 8));
+    return CAELO_OK;
+}
+
+// Per wavefront: only the 3x3x3 bricks the 16^3 window can touch are staged in LDS (1.7 KB); the other
+// bricks of the 5x5x5 ball cube stay in the registers of the lanes that fetched them (they only matter
+// for the 496-NN count).  Small LDS footprint = many resident wavefronts: the kernel is latency bound
+// (two dependent random accesses into tables that live at the memory side after the atomic build).
 struct PatchWaveLds {
-    unsigned long long bricks[125 * 8];
+    unsigned long long win[27 * 8];
     unsigned int hist[BALL_D2 + 1];
     unsigned long long cls[CLASS_CAP];
     int ncls, cut, room;
@@ -507,6 +536,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
     __shared__ PatchWaveLds lds_all[PW_WAVES];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    PATCH_STAMP(0);
     PatchWaveLds &L = lds_all[wave];
     const int64_t pw = (int64_t)blockIdx.x * PW_WAVES + wave;
     if (pw >= k_max * 3) return;
@@ -527,51 +557,58 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
     const int kz = (int)(((double)pts[(size_t)pts_ld * kp + 2] + VIS_H) / vs);
     const int bx0 = (kx - BALL_R) >> 3, by0 = (ky - BALL_R) >> 3, bz0 = (kz - BALL_R) >> 3;
     const int nbx = ((kx + BALL_R) >> 3) - bx0 + 1, nby = ((ky + BALL_R) >> 3) - by0 + 1, nbz = ((kz + BALL_R) >> 3) - bz0 + 1;
-    // ---- stage <= 125 bricks in LDS (one 64-byte line each); popcount gives a cheap bound on the ball.
-    // Lane l owns bricks l and l + 64: both first probes, then both payloads, are issued together so the
-    // wavefront pays two dependent L2 round trips instead of four (the tables are <= 10 % full: the first
-    // probe almost always decides; collisions continue in the generic loop).
-    int pop = 0;
+    // window bricks: first brick of the window per axis, relative to the ball cube (0 or 1)
+    const int wx0 = ((kx - 8) >> 3) - bx0, wy0 = ((ky - 8) >> 3) - by0, wz0 = ((kz - 8) >> 3) - bz0;
+    // ---- fetch <= 125 bricks: lane l owns bricks l and l + 64; both first probes, then both payloads, are
+    //      issued together (two dependent round trips per wavefront; the tables are <= 10 % full)
+    unsigned long long key[2];
+    ulonglong2 pay[2][4];
+    int bix[2], biy[2], biz[2];
+    bool have[2];
     {
-        unsigned long long key[2];
         uint32_t h[2];
         bool want[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int l = lane + 64 * u;
-            const int ix = l / 25, iy = (l / 5) % 5, iz = l % 5;
-            want[u] = l < 125 && ix < nbx && iy < nby && iz < nbz && bx0 + ix >= 0 && by0 + iy >= 0 && bz0 + iz >= 0;
-            key[u] = caelo_pack3(bx0 + ix, by0 + iy, bz0 + iz);
+            bix[u] = l / 25; biy[u] = (l / 5) % 5; biz[u] = l % 5;
+            want[u] = l < 125 && bix[u] < nbx && biy[u] < nby && biz[u] < nbz && bx0 + bix[u] >= 0 && by0 + biy[u] >= 0 &&
+                      bz0 + biz[u] >= 0;
+            key[u] = caelo_pack3(bx0 + bix[u], by0 + biy[u], bz0 + biz[u]);
             h[u] = caelo_hash64(key[u]) & tab.mask;
         }
-        unsigned long long k0v = want[0] ? tab.keys[h[0]] : CAELO_EMPTY_KEY;
-        unsigned long long k1v = want[1] ? tab.keys[h[1]] : CAELO_EMPTY_KEY;
+        const unsigned long long k0v = want[0] ? tab.keys[h[0]] : CAELO_EMPTY_KEY;
+        const unsigned long long k1v = want[1] ? tab.keys[h[1]] : CAELO_EMPTY_KEY;
         int slot[2];
         slot[0] = !want[0] || k0v == CAELO_EMPTY_KEY ? -1 : (k0v == key[0] ? (int)h[0] : -2);
         slot[1] = !want[1] || k1v == CAELO_EMPTY_KEY ? -1 : (k1v == key[1] ? (int)h[1] : -2);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
             if (slot[u] == -2) slot[u] = table_find(tab.keys, tab.mask, key[u]);  // collided: probe on
-        ulonglong2 pay[2][4];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const ulonglong2 *src = (const ulonglong2 *)(tab.bits + (size_t)(slot[u] < 0 ? 0 : slot[u]) * 8);
+            have[u] = slot[u] >= 0;
+            const ulonglong2 *src = (const ulonglong2 *)(tab.bits + (size_t)(have[u] ? slot[u] : 0) * 8);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pay[u][q] = slot[u] < 0 ? make_ulonglong2(0ull, 0ull) : src[q];
+            for (int q = 0; q < 4; ++q) pay[u][q] = have[u] ? src[q] : make_ulonglong2(0ull, 0ull);
         }
+    }
+    int pop = 0;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int l = lane + 64 * u;
-            if (l < 125) {
+    for (int u = 0; u < 2; ++u) {
+        const int l = lane + 64 * u;
+        const int wx = bix[u] - wx0, wy = biy[u] - wy0, wz = biz[u] - wz0;
+        const bool inwin = l < 125 && wx >= 0 && wx < 3 && wy >= 0 && wy < 3 && wz >= 0 && wz < 3;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    L.bricks[l * 8 + 2 * q] = pay[u][q].x;
-                    L.bricks[l * 8 + 2 * q + 1] = pay[u][q].y;
-                    pop += __popcll(pay[u][q].x) + __popcll(pay[u][q].y);
-                }
+        for (int q = 0; q < 4; ++q) {
+            pop += __popcll(pay[u][q].x) + __popcll(pay[u][q].y);
+            if (inwin) {
+                L.win[((wx * 3 + wy) * 3 + wz) * 8 + 2 * q] = pay[u][q].x;
+                L.win[((wx * 3 + wy) * 3 + wz) * 8 + 2 * q + 1] = pay[u][q].y;
             }
         }
     }
+    PATCH_STAMP(1);
     pop = wave_sum(pop);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -580,19 +617,18 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
     {
         const int ix = lane >> 2;
         const int x = kx + (ix < 8 ? ix : ix - 16);
-        const int bxl = (x >> 3) - bx0, xw = x & 7;
+        const int bxl = (x >> 3) - bx0 - wx0, xw = x & 7;
         const int z0 = kz - 8;
-        const int bzl = (z0 >> 3) - bz0, zsh = z0 & 7;
+        const int zsh = z0 & 7;  // the window's first z brick is window-local index 0
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int iy = (lane & 3) * 4 + q;
             const int y = ky + (iy < 8 ? iy : iy - 16);
-            const int byl = (y >> 3) - by0, ysh = (y & 7) << 3;
+            const int byl = (y >> 3) - by0 - wy0, ysh = (y & 7) << 3;
             unsigned int str = 0;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                unsigned int byte = 0;
-                if (bzl + j < 5) byte = (unsigned int)(L.bricks[((bxl * 5 + byl) * 5 + bzl + j) * 8 + xw] >> ysh) & 0xFFu;
+                const unsigned int byte = (unsigned int)(L.win[((bxl * 3 + byl) * 3 + j) * 8 + xw] >> ysh) & 0xFFu;
                 str |= byte << (8 * j);
             }
             const unsigned int r16 = (str >> zsh) & 0xFFFFu;           // bit t <-> dz = t - 8
@@ -600,25 +636,30 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
             word |= (unsigned long long)o16 << (16 * q);
         }
     }
+    PATCH_STAMP(2);
     unsigned int fl = 0;
     if (pop > NN_CAP) {
-        // ---- exact 496-NN semantics (Voxel.py:182,:195-196): histogram the ball by squared distance
+        // ---- exact 496-NN semantics (Voxel.py:182,:195-196): histogram the ball by squared distance,
+        //      every lane walking the set bits of the two bricks it holds in registers
         for (int i = lane; i <= BALL_D2; i += 64) L.hist[i] = 0u;
         if (lane == 0) L.ncls = 0;
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (int j = lane; j < 125 * 8; j += 64) {
-            unsigned long long v = L.bricks[j];
-            if (!v) continue;
-            const int l = j >> 3;
-            const int dx = (bx0 + l / 25) * 8 + (j & 7) - kx;
-            const int ybase = (by0 + (l / 5) % 5) * 8 - ky, zbase = (bz0 + l % 5) * 8 - kz;
-            while (v) {
-                const int t = __ffsll((long long)v) - 1;
-                v &= v - 1;
-                const int dy = ybase + (t >> 3), dz = zbase + (t & 7);
-                const int d2 = dx * dx + dy * dy + dz * dz;
-                if (d2 <= BALL_D2) atomicAdd(&L.hist[d2], 1u);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!have[u]) continue;
+            const int xb = (bx0 + bix[u]) * 8 - kx, ybase = (by0 + biy[u]) * 8 - ky, zbase = (bz0 + biz[u]) * 8 - kz;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                unsigned long long v = (q & 1) ? pay[u][q >> 1].y : pay[u][q >> 1].x;
+                const int dx = xb + q;
+                while (v) {
+                    const int t = __ffsll((long long)v) - 1;
+                    v &= v - 1;
+                    const int dy = ybase + (t >> 3), dz = zbase + (t & 7);
+                    const int d2 = dx * dx + dy * dy + dz * dz;
+                    if (d2 <= BALL_D2) atomicAdd(&L.hist[d2], 1u);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -626,9 +667,9 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
         if (lane == 0) {
             int cum = 0, cut = BALL_D2 + 1, room = 0;
             for (int d2 = 0; d2 <= BALL_D2; ++d2) {
-                const int h = (int)L.hist[d2];
-                if (cum + h > NN_CAP) { cut = d2; room = NN_CAP - cum; break; }
-                cum += h;
+                const int hh = (int)L.hist[d2];
+                if (cum + hh > NN_CAP) { cut = d2; room = NN_CAP - cum; break; }
+                cum += hh;
             }
             L.cut = cut;
             L.room = room;
@@ -639,20 +680,23 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
         if (cut <= BALL_D2) {
             if (room > 0) {
                 // members of the cut class, for the canonical tie rule (ascending (x,y,z) key)
-                for (int j = lane; j < 125 * 8; j += 64) {
-                    unsigned long long v = L.bricks[j];
-                    if (!v) continue;
-                    const int l = j >> 3;
-                    const int x = (bx0 + l / 25) * 8 + (j & 7);
-                    const int yb = (by0 + (l / 5) % 5) * 8, zb = (bz0 + l % 5) * 8;
-                    while (v) {
-                        const int t = __ffsll((long long)v) - 1;
-                        v &= v - 1;
-                        const int y = yb + (t >> 3), z = zb + (t & 7);
-                        const int dx = x - kx, dy = y - ky, dz = z - kz;
-                        if (dx * dx + dy * dy + dz * dz == cut) {
-                            const int p = atomicAdd(&L.ncls, 1);
-                            if (p < CLASS_CAP) L.cls[p] = caelo_pack3(x, y, z);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (!have[u]) continue;
+                    const int xb = (bx0 + bix[u]) * 8, yb = (by0 + biy[u]) * 8, zb = (bz0 + biz[u]) * 8;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        unsigned long long v = (q & 1) ? pay[u][q >> 1].y : pay[u][q >> 1].x;
+                        const int x = xb + q;
+                        while (v) {
+                            const int t = __ffsll((long long)v) - 1;
+                            v &= v - 1;
+                            const int y = yb + (t >> 3), z = zb + (t & 7);
+                            const int dx = x - kx, dy = y - ky, dz = z - kz;
+                            if (dx * dx + dy * dy + dz * dz == cut) {
+                                const int p = atomicAdd(&L.ncls, 1);
+                                if (p < CLASS_CAP) L.cls[p] = caelo_pack3(x, y, z);
+                            }
                         }
                     }
                 }
@@ -674,9 +718,9 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
                 if (d2 == cut) {
                     fl |= (room > 0) ? 2u : 0u;
                     if (room > 0) {
-                        const unsigned long long key = caelo_pack3(kx + dx, ky + dy, kz + dz);
+                        const unsigned long long kk = caelo_pack3(kx + dx, ky + dy, kz + dz);
                         int rank = 0;
-                        for (int q = 0; q < ncls; ++q) rank += (L.cls[q] < key) ? 1 : 0;
+                        for (int q = 0; q < ncls; ++q) rank += (L.cls[q] < kk) ? 1 : 0;
                         keep = rank < room;
                     }
                 }
@@ -692,6 +736,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
     for (int o = 32; o > 0; o >>= 1) fl |= __shfl_xor(fl, o);
     out[lane] = word;
     if (lane == 0) flags[pw] = (uint8_t)fl;
+    PATCH_STAMP(3);
 }
 
 int vox_patches_launch(const caelo_voxmap *m, const float *pts, int pts_ld, int64_t k_max, const int32_t *n_key,

@@ -90,8 +90,8 @@ int caelo_keypoints(caelo_ctx *ctx, const float *ring, int ring_w, int ring_c, c
                     const float *resp, void *ws, int64_t *key_pixels, float *key_pts, int32_t *n_key,
                     int32_t *status, void *stream);
 
-/* debug aid: out_host[32] = 16 phase timestamps (100 MHz ticks) of the last keypoint-selection kernel, then 16 of
- * the last encoder stage-1 kernel (workgroup 0, first patch) */
+/* debug aid: out_host[40] = 16 phase timestamps (100 MHz ticks) of the last keypoint-selection kernel, 16 of the
+ * last encoder stage-1 kernel (workgroup 0, first patch), 8 of the last patch-gather kernel */
 int caelo_debug_read(unsigned long long *out_host);
 
 /* Voxelization  (Voxel.py:100-173) into a device voxel map (3 scales of 8^3-voxel bricks). */

@@ -39,6 +39,11 @@ def _worker(rank, world, n_frames, port, out_dir):
         v = (fa[: int(na)].sum() - 2 * fb[: int(nb)].sum() + kpa.sum()).item()
         rts.append([v] + [float(a), float(b)] + [0.0] * 9)
     rts = torch.tensor(rts, dtype=torch.float32).reshape(-1, 12)
+    # the boundary variant moves only each rank's last frame
+    last = cd.all_gather_boundary(local[-1])
+    assert last.shape == (world, K, cd.ROW)
+    for r in range(world):
+        assert torch.equal(last[r], frame_rows(cd.shard_frames(n_frames, r, world)[1] - 1))
     allrt = cd.gather_poses(rts, n_frames)
     assert allrt.shape == (n_frames - 1, 12)
     assert allrt[:, 1].tolist() == [float(f) for f in range(n_frames - 1)]

@@ -286,3 +286,54 @@ def test_fused_extract_equals_staged_path(engine, orc, models, f0):
     assert err <= REL_TOL
     ffb = engine.extract(torch.from_numpy(f0["pc"]).to(engine.device), dist_channels=3)
     assert np.array_equal(ffb.key_pixels.cpu().numpy(), f0["g"]["keypixels_batch"].astype(np.int64))
+
+
+# ---- RCCL plumbing (single GPU: world 1; the 2-rank logic is covered on CPU by test_dist_gloo.py) ----------
+def test_rccl_all_gather_of_frame_rows(engine):
+    import torch
+    import torch.distributed as dist
+    from caelo import dist as cd
+    if dist.is_initialized():
+        pytest.skip("process group already initialised")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=engine.device)
+    try:
+        rows = torch.rand((3, 1024, 64), device=engine.device)
+        out = torch.empty_like(rows)
+        dist.all_gather_into_tensor(out, rows)          # the collective bench.py issues, on RCCL
+        assert torch.equal(out, rows)
+        assert torch.equal(cd.all_gather_frames(rows, 3), rows)
+        rt = torch.rand((2, 12), device=engine.device)
+        assert torch.equal(cd.gather_poses(rt, 3), rt)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exact_voxel_mode_equals_fast_path(engine, scans):
+    import torch
+    pc = torch.from_numpy(scans(1)).to(engine.device)
+    a = engine.extract(pc)
+    b = engine.extract(pc, exact_voxels=True)
+    assert int(a.status[0].item()) == 0 and int(b.status[0].item()) == 0
+    assert torch.equal(a.key_pixels, b.key_pixels) and torch.equal(a.rows, b.rows)
+
+
+def test_fast_voxelization_flags_a_face_point_and_checked_recovers(engine, orc, models, scans):
+    import torch
+    from caelo.engine import ST_VOXEL_INEXACT
+    pc = scans(0).copy()
+    # x = 4.0 sits on a 16 cm voxel face: int(x_/0.16) != scale-0 index >> 3 (Voxel.py:136-149 in f64)
+    pc[1000, 0:3] = (4.0, 11.0, -1.0)
+    pcd = torch.from_numpy(pc).to(engine.device)
+    ff = engine.extract(pcd)
+    assert int(ff.status[0].item()) & ST_VOXEL_INEXACT
+    ff = engine.checked(ff, pcd)                      # re-extracted with the exact first-touch kernels
+    assert int(ff.status[0].item()) == 0
+    ring, cnt = orc.ProjectPC2SphericalRing(pc)
+    resp = models[0].predict(ring[None, 0:64, 0:1792, 0:3])[0]
+    kp, kpix, _ = orc.GetKeyPtsByAE(ring, cnt, resp)
+    vox = orc.Voxelization(pc[:, 0:3])
+    assert np.array_equal(ff.key_pixels[: len(kpix)].cpu().numpy(), kpix)
+    of = np.concatenate([models[1].predict_bits(orc.patches_bits(kp, vox[6 + s], s)[0]) for s in range(3)], axis=1)
+    assert np.abs(ff.features[: len(kp)].cpu().numpy() - of).max() <= REL_TOL * np.abs(of).max()
