@@ -78,9 +78,9 @@ def all_gather_boundary(last_rows, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return last_rows.unsqueeze(0)
-    recv = last_rows.new_empty((world,) + tuple(last_rows.shape))
+    recv = last_rows.new_empty((world * last_rows.shape[0],) + tuple(last_rows.shape[1:]))  # concatenated form
     dist.all_gather_into_tensor(recv, last_rows.contiguous(), group=group)
-    return recv
+    return recv.view((world,) + tuple(last_rows.shape))
 
 
 def local_pairs(n_frames, rank, world):
