@@ -488,14 +488,14 @@ CAELO_API int caelo_solve_rt(caelo_ctx *c, const float *p0, const float *p1, int
 struct RansacWs {
     int32_t counts[CAELO_RANSAC_MAX_TRIALS];
     float Rt[CAELO_RANSAC_MAX_TRIALS][12];
-    int32_t done;        // 1 once a level succeeded (later levels early-exit)
+    int32_t done;        // 1 once a level succeeded
     int32_t level_used;
     int32_t best_trial;  // within level_used
     int32_t iterations;
     int32_t success;
     float threshold;
-    int32_t arrived[CAELO_RANSAC_LEVELS];  // hypotheses finished per level (last one replays the rules)
-    int32_t pad;
+    int32_t arrived[CAELO_RANSAC_LEVELS];  // workgroups finished per level (the last one replays the rules)
+    int32_t finished;                      // the pose record is complete: later launches return at once
 };
 
 CAELO_API int64_t caelo_ransac_ws_bytes(void) { return (int64_t)sizeof(RansacWs); }
@@ -568,31 +568,19 @@ __device__ void ransac_replay(int N, int level, RansacWs *ws, int *s_counts) {
     (void)s_counts;
 }
 
-// one wavefront per hypothesis, four per workgroup (one arrival ticket per workgroup: same-address device
-// atomics serialise at ~10 ns); the last workgroup of a level to finish replays the accept rules
-#define RE_WAVES 4
-__global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_eval(const float *__restrict__ pc0, int ld0, const float *__restrict__ pc1,
-                                                    int ld1, const int64_t *__restrict__ pair_idx, int64_t k1_max,
-                                                    const int32_t *n1p, const double *__restrict__ rnd, int level,
-                                                    RansacWs *ws) {
-    __shared__ int s_counts[CAELO_RANSAC_MAX_TRIALS];
-    __shared__ int s_last;
-    if (__hip_atomic_load(&ws->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    const int N = n1p ? *n1p : (int)k1_max;
-    const int trial = blockIdx.x * RE_WAVES + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const float thr = 0.4f * (float)(1 << level);  // 0.4, 0.8, 1.6 (:171,:210)
-    const double *r4 = rnd + ((size_t)level * CAELO_RANSAC_MAX_TRIALS + trial) * 4;
-    // ---- 4-point sample with replacement (:182-184): idx = int32(u * N)
+// hypothesis from 4 sampled pairs (SolveRT on the sample, Match.py:141-157; means / centring in f32 like
+// np.mean on f32 rows, covariance in f64)
+__device__ inline void sample_hypothesis(const float *P0, int l0, const int64_t *pidx, const float *P1, int l1, int N,
+                                         const double *r4, float R[9], float T[3]) {
     float s0[4][3], s1[4][3];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int idx = (int)(r4[q] * (double)N);
-        const int64_t i0 = pair_idx[idx];
+        const int idx = (int)(r4[q] * (double)N);  // :182-184 idx = int32(u * N), with replacement
+        const float *a = P0 + (size_t)l0 * (pidx ? pidx[idx] : idx);
+        const float *b = P1 + (size_t)l1 * idx;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { s0[q][a] = pc0[(size_t)ld0 * i0 + a]; s1[q][a] = pc1[(size_t)ld1 * idx + a]; }
+        for (int c = 0; c < 3; ++c) { s0[q][c] = a[c]; s1[q][c] = b[c]; }
     }
-    // SolveRT on the sample (:141-157).  means/centering in f32 like np.mean on f32 rows.
     double m0[3], m1[3], H[9];
     float c0[4][3], c1[4][3];
 #pragma unroll
@@ -612,56 +600,94 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_eval(const float *__re
             for (int q = 0; q < 4; ++q) h += (double)c1[q][i] * (double)c0[q][j];
             H[3 * i + j] = h;
         }
-    float R[9], T[3];
     rigid_from_H(H, m0, m1, R, T);
-    // ---- residuals + inlier count (:191-194): ballot + popcount per 64 pairs
-    int cnt = 0;
-    for (int i = lane; i < ((N + 63) & ~63); i += 64) {
-        bool in = false;
-        if (i < N) {
-            const float *a = pc0 + (size_t)ld0 * pair_idx[i];
-            const float *b = pc1 + (size_t)ld1 * i;
-            in = residual(R, T, a[0], a[1], a[2], b[0], b[1], b[2]) < thr;
-        }
-        cnt += __popcll(__ballot(in));
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) ws->Rt[trial][i] = R[i];  // read by the finish kernel (kernel boundary)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) ws->Rt[trial][9 + i] = T[i];
-        // the count is read by the last hypothesis of this launch: write-through store, drained before the
-        // arrival ticket; the reader uses agent-scope loads (no release/acquire fences, G16 "atomics both sides")
-        __hip_atomic_store(&ws->counts[trial], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&ws->arrived[level], 1) == CAELO_RANSAC_MAX_TRIALS / RE_WAVES - 1;
-    __syncthreads();
-    if (s_last && threadIdx.x < 64) ransac_replay(N, level, ws, s_counts);
 }
 
-// inlier mask of the winner, then the refit over all inliers (Match.py:273-282)
-__global__ void __launch_bounds__(256) k_ransac_finish(const float *__restrict__ pc0, int ld0, const float *__restrict__ pc1,
-                                                       int ld1, const int64_t *__restrict__ pair_idx, int64_t k1_max,
-                                                       const int32_t *n1p, RansacWs *ws, caelo_pose_result *res,
-                                                       uint8_t *mask) {
+// One launch per threshold level (0.4 / 0.8 / 1.6 m).  Workgroup = 4 wavefronts = 4 hypotheses.
+//   1. the matched pairs (P0[pair_idx[i]], P1[i]) are gathered once per workgroup into LDS (coalesced; the
+//      per-hypothesis residual loops then never touch global memory);
+//   2. one wavefront per hypothesis: Kabsch on the 4-sample, residuals, ballot + popcount inlier count;
+//   3. the last workgroup to arrive (one ticket per workgroup; counts published with write-through
+//      stores, read with agent-scope loads) replays the sequential accept rules in parallel;
+//   4. if the level succeeded -- or it was the last one -- the same workgroup finishes the pose in place:
+//      inlier mask of the winner, refit over all inliers (Match.py:273-282), result record.  Later
+//      launches see `finished` and return at once.
+#define RE_WAVES 4
+#define RE_LDS_PAIRS 1024
+__global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_level(const float *__restrict__ pc0, int ld0,
+                                                                const float *__restrict__ pc1, int ld1,
+                                                                const int64_t *__restrict__ pair_idx, int64_t k1_max,
+                                                                const int32_t *n1p, const double *__restrict__ rnd, int level,
+                                                                RansacWs *ws, caelo_pose_result *res, uint8_t *mask) {
+    __shared__ float sP0[RE_LDS_PAIRS * 3], sP1[RE_LDS_PAIRS * 3];
+    __shared__ int s_counts[4];
+    __shared__ int s_last, s_best, s_success, s_nin;
     __shared__ float Rs[9], Ts[3];
-    __shared__ int n_in;
+    if (__hip_atomic_load(&ws->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const int N = n1p ? *n1p : (int)k1_max;
-    const int tid = threadIdx.x;
-    const int best = ws->best_trial;
-    const float thr = ws->threshold;
-    if (tid < 9) Rs[tid] = best >= 0 ? ws->Rt[best][tid] : ((tid % 4 == 0) ? 1.0f : 0.0f);  // :177 identity
-    if (tid < 3) Ts[tid] = best >= 0 ? ws->Rt[best][9 + tid] : 0.0f;
-    if (tid == 0) n_in = 0;
-    __syncthreads();
-    int local = 0;
-    for (int i = tid; i < (int)k1_max; i += 256) {
-        uint8_t in = 0;
-        if (i < N && best >= 0) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float thr = 0.4f * (float)(1 << level);  // 0.4, 0.8, 1.6 (:171,:210)
+    // ---- 1. pairs -> LDS (falls back to the global arrays when they do not fit)
+    const bool in_lds = N <= RE_LDS_PAIRS;
+    if (in_lds) {
+        for (int i = tid; i < N; i += 64 * RE_WAVES) {
             const float *a = pc0 + (size_t)ld0 * pair_idx[i];
             const float *b = pc1 + (size_t)ld1 * i;
+            sP0[3 * i] = a[0]; sP0[3 * i + 1] = a[1]; sP0[3 * i + 2] = a[2];
+            sP1[3 * i] = b[0]; sP1[3 * i + 1] = b[1]; sP1[3 * i + 2] = b[2];
+        }
+    }
+    __syncthreads();
+    const float *P0 = in_lds ? sP0 : pc0, *P1 = in_lds ? sP1 : pc1;
+    const int l0 = in_lds ? 3 : ld0, l1 = in_lds ? 3 : ld1;
+    const int64_t *pidx = in_lds ? nullptr : pair_idx;
+    // ---- 2. this wavefront's hypothesis
+    const int trial = blockIdx.x * RE_WAVES + wave;
+    {
+        float R[9], T[3];
+        sample_hypothesis(P0, l0, pidx, P1, l1, N, rnd + ((size_t)level * CAELO_RANSAC_MAX_TRIALS + trial) * 4, R, T);
+        int cnt = 0;  // residuals + inlier count (:191-194): ballot + popcount per 64 pairs
+        for (int i = lane; i < ((N + 63) & ~63); i += 64) {
+            bool in = false;
+            if (i < N) {
+                const float *a = P0 + (size_t)l0 * (pidx ? pidx[i] : i);
+                const float *b = P1 + (size_t)l1 * i;
+                in = residual(R, T, a[0], a[1], a[2], b[0], b[1], b[2]) < thr;
+            }
+            cnt += __popcll(__ballot(in));
+        }
+        if (lane == 0) {
+            // read by the last workgroup of this launch: write-through store, drained before the arrival ticket;
+            // the reader uses agent-scope loads (no release/acquire fences, G16 "atomics both sides")
+            __hip_atomic_store(&ws->counts[trial], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&ws->arrived[level], 1) == CAELO_RANSAC_MAX_TRIALS / RE_WAVES - 1;
+    __syncthreads();
+    if (!s_last) return;
+    // ---- 3. accept rules
+    if (tid < 64) ransac_replay(N, level, ws, s_counts);
+    __syncthreads();
+    if (tid == 0) { s_success = ws->success; s_best = ws->best_trial; s_nin = 0; }
+    __syncthreads();
+    const int success = s_success, best = s_best;
+    if (!success && level < CAELO_RANSAC_LEVELS - 1) return;  // escalate: the next launch doubles the threshold
+    // ---- 4. finish: the winner is recomputed here (deterministic), identity if every level failed (:177)
+    if (tid < 64) {
+        float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, T[3] = {0.f, 0.f, 0.f};
+        if (best >= 0) sample_hypothesis(P0, l0, pidx, P1, l1, N, rnd + ((size_t)level * CAELO_RANSAC_MAX_TRIALS + best) * 4, R, T);
+        if (tid < 9) Rs[tid] = R[tid];
+        if (tid < 3) Ts[tid] = T[tid];
+    }
+    __syncthreads();
+    int local = 0;
+    for (int i = tid; i < (int)k1_max; i += 64 * RE_WAVES) {
+        uint8_t in = 0;
+        if (i < N && best >= 0) {
+            const float *a = P0 + (size_t)l0 * (pidx ? pidx[i] : i);
+            const float *b = P1 + (size_t)l1 * i;
             in = residual(Rs, Ts, a[0], a[1], a[2], b[0], b[1], b[2]) < thr;
         }
         mask[i] = in;
@@ -669,20 +695,21 @@ __global__ void __launch_bounds__(256) k_ransac_finish(const float *__restrict__
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
-    if ((tid & 63) == 0) atomicAdd(&n_in, local);
+    if (lane == 0) atomicAdd(&s_nin, local);
     __syncthreads();
     if (tid < 9) { res->R_ransac[tid] = Rs[tid]; res->R[tid] = Rs[tid]; }
     if (tid < 3) { res->T_ransac[tid] = Ts[tid]; res->T[tid] = Ts[tid]; }
     if (tid == 0) {
         res->threshold = thr;
-        res->success = ws->success;
+        res->success = success;
         res->iterations = ws->iterations;
-        res->n_inliers = n_in;
-        res->best_trial = best >= 0 ? ws->level_used * CAELO_RANSAC_MAX_TRIALS + best : -1;
+        res->n_inliers = s_nin;
+        res->best_trial = best >= 0 ? level * CAELO_RANSAC_MAX_TRIALS + best : -1;
         res->n_pairs = N;
+        __hip_atomic_store(&ws->finished, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (n_in > 0) fit_block(pc0, ld0, pair_idx, pc1, ld1, mask, N, res->R, res->T, nullptr);  // :277-282
+    if (s_nin > 0) fit_block(P0, l0, pidx, P1, l1, mask, N, res->R, res->T, nullptr);  // :277-282
 }
 
 CAELO_API int caelo_ransac(caelo_ctx *c, const float *pc0, int ld0, const float *pc1, int ld1, const int64_t *pair_idx,
@@ -694,10 +721,9 @@ CAELO_API int caelo_ransac(caelo_ctx *c, const float *pc0, int ld0, const float 
     RansacWs *ws = (RansacWs *)wsv;
     CAELO_HIP(hipMemsetAsync(&ws->done, 0, sizeof(RansacWs) - offsetof(RansacWs, done), s));
     for (int level = 0; level < CAELO_RANSAC_LEVELS; ++level) {
-        k_ransac_eval<<<CAELO_RANSAC_MAX_TRIALS / RE_WAVES, 64 * RE_WAVES, 0, s>>>(pc0, ld0, pc1, ld1, pair_idx, k1_max, n1, rnd, level, ws);
+        k_ransac_level<<<CAELO_RANSAC_MAX_TRIALS / RE_WAVES, 64 * RE_WAVES, 0, s>>>(pc0, ld0, pc1, ld1, pair_idx, k1_max, n1, rnd,
+                                                                                    level, ws, result, inlier_mask);
         CAELO_LAUNCH_CHECK();
     }
-    k_ransac_finish<<<1, 256, 0, s>>>(pc0, ld0, pc1, ld1, pair_idx, k1_max, n1, ws, result, inlier_mask);
-    CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }
