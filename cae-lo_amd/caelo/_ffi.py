@@ -23,6 +23,16 @@ class PoseResult(C.Structure):
                 ("iterations", c_i32), ("n_inliers", c_i32), ("best_trial", c_i32), ("n_pairs", c_i32)]
 
 
+class FrameJob(C.Structure):
+    """caelo_frame_job (include/caelo.h): one frame of the pipeline, device pointers as integers."""
+    _fields_ = [("pc", c_vp), ("n", c_i64), ("dist_channels", c_i32), ("mode", c_i32), ("rows", c_vp),
+                ("key_pixels", c_vp), ("n_key", c_vp), ("flags", c_vp), ("status", c_vp), ("pair", c_i32),
+                ("reserved", c_i32), ("prev_rows", c_vp), ("prev_n_key", c_vp), ("rand", c_vp), ("result", c_vp),
+                ("inlier_mask", c_vp), ("pair_idx", c_vp)]
+
+
+PAIR_NONE, PAIR_CHAIN, PAIR_EXPLICIT = 0, 1, 2
+
 # (name, restype, argtypes) -- must list every symbol include/caelo.h declares
 SIGNATURES = [
     ("caelo_abi_version", c_int, []),
@@ -55,6 +65,12 @@ SIGNATURES = [
     ("caelo_extract_ws_bytes", c_i64, []),
     ("caelo_extract", c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp,
                               c_vp, c_vp]),
+    ("caelo_pipeline_create", c_int, [c_vp, c_int, c_i64, C.POINTER(c_vp)]),
+    ("caelo_pipeline_destroy", None, [c_vp]),
+    ("caelo_pipeline_lanes", c_int, [c_vp]),
+    ("caelo_pipeline_begin", c_int, [c_vp, c_vp]),
+    ("caelo_pipeline_submit", c_int, [c_vp, C.POINTER(FrameJob)]),
+    ("caelo_pipeline_flush", c_int, [c_vp, c_vp]),
 ]
 
 _lib = None

@@ -104,6 +104,82 @@ class FrameFeatures:
         return cls(rows, None, n_key, None, None)
 
 
+class FrameBatch:
+    """Device-resident outputs of Pipeline.run for K frames (one allocation per field)."""
+
+    def __init__(self, eng, k):
+        self.k = k
+        self.rows = eng.empty((k, MAX_K, 64), torch.float32)       # the multi-GPU all-gather payload
+        self.key_pixels = eng.empty((k, MAX_K, 2), torch.int64)
+        self.n_key = eng.empty((k,), torch.int32)
+        self.flags = eng.empty((k, MAX_K, 3), torch.uint8)
+        self.status = eng.empty((k, 4), torch.int32)
+        self.result = eng.zeros((k, C.sizeof(_ffi.PoseResult)), torch.uint8)   # pair (i-1, i) in slot i
+        self.inlier_mask = eng.zeros((k, MAX_K), torch.uint8)
+        self.pair_idx = eng.zeros((k, MAX_K), torch.int64)
+
+    def frame(self, i):
+        return FrameFeatures(self.rows[i], self.key_pixels[i], self.n_key[i:i + 1], self.status[i], self.flags[i])
+
+
+class Pipeline:
+    """caelo_pipeline (include/caelo.h): whole frames round-robin on `lanes` HIP streams, one native
+    host thread per lane.  ``run`` submits K scans and returns without waiting for the GPU."""
+
+    def __init__(self, eng, lanes=3, max_points=None):
+        self.eng = eng
+        h = C.c_void_p()
+        _ffi.check(eng.lib.caelo_pipeline_create(eng.ctx, int(lanes), int(max_points or eng.max_points), C.byref(h)))
+        self.h, self.lanes = h, int(lanes)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.eng.lib.caelo_pipeline_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def run(self, scans, rands, prev=None, dist_channels=5, exact_voxels=False, out=None):
+        """scans: K device tensors [n,4] f32; rands: K device tensors of RANSAC draws ([1500,4] f64).
+        Frame i is matched against frame i-1 (pose in ``result[i]``); frame 0 against ``prev``
+        (FrameFeatures) when given.  Returns a FrameBatch; the current stream has waited for all lanes."""
+        eng, lib, k = self.eng, self.eng.lib, len(scans)
+        out = out or FrameBatch(eng, k)
+        assert out.k >= k and len(rands) >= k
+        stream = eng.stream
+        _ffi.check(lib.caelo_pipeline_begin(self.h, stream))
+        job = _ffi.FrameJob()
+        job.dist_channels, job.mode = int(dist_channels), 1 if exact_voxels else 0
+        p_rows, p_pix, p_nk, p_fl, p_st = (out.rows.data_ptr(), out.key_pixels.data_ptr(), out.n_key.data_ptr(),
+                                           out.flags.data_ptr(), out.status.data_ptr())
+        p_res, p_mask, p_idx = out.result.data_ptr(), out.inlier_mask.data_ptr(), out.pair_idx.data_ptr()
+        res_sz = out.result.shape[1]
+        submit, ref = lib.caelo_pipeline_submit, C.byref(job)
+        try:
+            for i in range(k):
+                pc = scans[i]
+                assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] == 4 and pc.is_contiguous()
+                job.pc, job.n = pc.data_ptr(), pc.shape[0]
+                job.rows, job.key_pixels, job.n_key = p_rows + i * (MAX_K * 256), p_pix + i * (MAX_K * 16), p_nk + i * 4
+                job.flags, job.status = p_fl + i * (MAX_K * 3), p_st + i * 16
+                if i > 0:
+                    job.pair, job.prev_rows, job.prev_n_key = _ffi.PAIR_CHAIN, None, None
+                elif prev is not None:
+                    assert prev.rows.is_contiguous()
+                    job.pair, job.prev_rows = _ffi.PAIR_EXPLICIT, prev.rows.data_ptr()
+                    job.prev_n_key = prev.n_key.data_ptr() if prev.n_key is not None else None
+                else:
+                    job.pair = _ffi.PAIR_NONE
+                job.rand = rands[i].data_ptr()
+                job.result, job.inlier_mask, job.pair_idx = p_res + i * res_sz, p_mask + i * MAX_K, p_idx + i * (MAX_K * 8)
+                _ffi.check(submit(self.h, ref))
+        finally:
+            rc = lib.caelo_pipeline_flush(self.h, stream)
+        _ffi.check(rc)
+        return out
+
+
 class Engine:
     def __init__(self, respond_h5=RESPOND_H5, encoder_h5=ENCODER_H5, device=None, max_points=1 << 17):
         if not torch.cuda.is_available():
@@ -117,11 +193,8 @@ class Engine:
         self.ctx = ctx
         self.max_points = int(max_points)
         self._maps = {}
-        self._enc_ws = None
-        self._ransac_ws = torch.empty(int(self.lib.caelo_ransac_ws_bytes()), dtype=torch.uint8, device=self.device)
-        self._kp_ws = torch.empty(int(self.lib.caelo_keypoints_ws_bytes()), dtype=torch.uint8, device=self.device)
-        self._extract_ws = None
-        self._match_ws = None
+        self._wss = {}      # (HIP stream, kind) -> scratch bytes: workspaces and voxel maps are per stream, so
+                            # frames issued on different streams ("lanes") run concurrently without sharing scratch
         if respond_h5:
             self.load_weights(respond_h5)
         if encoder_h5:
@@ -155,18 +228,30 @@ class Engine:
             _ffi.check(self.lib.caelo_set_encoder_weights(self.ctx, *[_hptr(w) for w in ws]))
         return kind
 
+    def _ws(self, kind, need):
+        """Scratch bytes of the current stream for one entry point (grown on demand, never shared across streams)."""
+        key = (torch.cuda.current_stream(self.device).cuda_stream, kind)
+        t = self._wss.get(key)
+        if t is None or t.numel() < need:
+            t = self._wss[key] = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        return t
+
+    def pipeline(self, lanes=3):
+        """The native frame executor (caelo_pipeline) with `lanes` streams, created once per lane count."""
+        key = ("pipeline", int(lanes))
+        if key not in self._maps:
+            self._maps[key] = Pipeline(self, lanes)
+        return self._maps[key]
+
     def voxmap(self, max_points=None, slot=0):
         n = self.max_points if max_points is None else int(max_points)
-        key = (slot, n)
+        key = (torch.cuda.current_stream(self.device).cuda_stream, slot, n)
         if key not in self._maps:
             self._maps[key] = VoxelMap(self, n)
         return self._maps[key]
 
     def _encode_ws(self, n_patches):
-        need = int(self.lib.caelo_encode_ws_bytes(int(n_patches)))
-        if self._enc_ws is None or self._enc_ws.numel() < need:
-            self._enc_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._enc_ws
+        return self._ws("encode", int(self.lib.caelo_encode_ws_bytes(int(n_patches))))
 
     # ---- stages (device tensors in, device tensors out, no sync) ---------------------------------
     def project(self, pc, status=None):
@@ -194,7 +279,8 @@ class Engine:
         nkey = self.empty((1,), torch.int32)
         status = self.zeros((1,), torch.int32) if status is None else status
         _ffi.check(self.lib.caelo_keypoints(self.ctx, _ptr(ring), ring.shape[1], ring.shape[2], _ptr(counter),
-                                            counter.shape[1], _ptr(resp), _ptr(self._kp_ws), _ptr(kpix), _ptr(kpts),
+                                            counter.shape[1], _ptr(resp), _ptr(self._ws("keypoints", self.lib.caelo_keypoints_ws_bytes())),
+                                            _ptr(kpix), _ptr(kpts),
                                             _ptr(nkey), _ptr(status), self.stream))
         return kpts, kpix, nkey, status
 
@@ -274,11 +360,9 @@ class Engine:
     def match(self, f0, f1, n0=None, n1=None):
         """f0 [k0,dim], f1 [k1,dim] (row-strided views allowed) -> pair_idx [k1] int64."""
         idx = self.zeros((f1.shape[0],), torch.int64)
-        need = int(self.lib.caelo_match_ws_bytes(f1.shape[0]))
-        if self._match_ws is None or self._match_ws.numel() < need:
-            self._match_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = self._ws("match", int(self.lib.caelo_match_ws_bytes(f1.shape[0])))
         _ffi.check(self.lib.caelo_match(self.ctx, _ptr(f0), self._ld(f0), f0.shape[0], _ptr(n0), _ptr(f1), self._ld(f1),
-                                        f1.shape[0], _ptr(n1), f0.shape[1], _ptr(idx), _ptr(self._match_ws), self.stream))
+                                        f1.shape[0], _ptr(n1), f0.shape[1], _ptr(idx), _ptr(ws), self.stream))
         return idx
 
     def solve_rt(self, p0, p1):
@@ -297,7 +381,7 @@ class Engine:
         mask = self.empty((pc1.shape[0],), torch.uint8)
         _ffi.check(self.lib.caelo_ransac(self.ctx, _ptr(pc0), self._ld(pc0), _ptr(pc1), self._ld(pc1), _ptr(pair_idx),
                                          pc1.shape[0], _ptr(n1), _ptr(rand), _ptr(res), _ptr(mask),
-                                         _ptr(self._ransac_ws), self.stream))
+                                         _ptr(self._ws("ransac", self.lib.caelo_ransac_ws_bytes())), self.stream))
         return res, mask
 
     @staticmethod
@@ -315,8 +399,7 @@ class Engine:
         frame in which a point lies within an ulp of a voxel face; ``checked()`` re-runs such a frame
         with ``exact_voxels=True`` (the two-pass first-touch rule of Voxel.py:139-141)."""
         assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] == 4 and pc.is_contiguous()
-        if self._extract_ws is None:
-            self._extract_ws = torch.empty(int(self.lib.caelo_extract_ws_bytes()), dtype=torch.uint8, device=self.device)
+        ws = self._ws("extract", int(self.lib.caelo_extract_ws_bytes()))
         vmap = vmap or self.voxmap(max(self.max_points, pc.shape[0]))
         rows = self.empty((MAX_K, 64), torch.float32) if rows is None else rows
         assert rows.shape == (MAX_K, 64) and rows.is_contiguous()
@@ -327,7 +410,7 @@ class Engine:
         base = rows.data_ptr()
         _ffi.check(self.lib.caelo_extract(self.ctx, vmap.h, _ptr(pc), pc.shape[0], dist_channels, 1 if exact_voxels else 0,
                                           C.c_void_p(base + 240), 64, C.c_void_p(base), 64, C.c_void_p(base + 252), 64,
-                                          _ptr(kpix), _ptr(nkey), _ptr(flags), _ptr(status), _ptr(self._extract_ws),
+                                          _ptr(kpix), _ptr(nkey), _ptr(flags), _ptr(status), _ptr(ws),
                                           self.stream))
         return FrameFeatures(rows, kpix, nkey, status, flags)
 
@@ -343,6 +426,10 @@ class Engine:
 
     def match_pose(self, fa, fb, rand):
         """Relative pose between two FrameFeatures (frame0 = fa, frame1 = fb), Match.py:241-283."""
+        cur = torch.cuda.current_stream(self.device)
+        for f in (fa, fb):          # rows produced on another lane: keep the allocator from recycling them early
+            f.rows.record_stream(cur)
+            f.n_key.record_stream(cur)
         idx = self.match(fa.features, fb.features, fa.n_key, fb.n_key)
         res, mask = self.ransac(fa.key_pts, fb.key_pts, idx, rand, fb.n_key)
         return res, mask, idx

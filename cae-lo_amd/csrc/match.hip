@@ -122,8 +122,10 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const float *__res
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, x = lane & 15;
-    const int k0 = n0p ? *n0p : (int)k0_max;
-    const int k1 = n1p ? *n1p : (int)k1_max;
+    // counts live on the device; clamp so that a caller who forgot to order this launch after the
+    // producer of n0/n1 reads garbage rows, never out of bounds
+    const int k0 = n0p ? min(max(*n0p, 0), (int)k0_max) : (int)k0_max;
+    const int k1 = n1p ? min(max(*n1p, 0), (int)k1_max) : (int)k1_max;
     const int ctile = blockIdx.x, rs = blockIdx.y;
     const int j0 = ctile * 16;
     if (j0 >= k1) return;  // uniform over the column tile's slices: no ticket needed
@@ -624,7 +626,7 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_level(const float *__r
     __shared__ int s_last, s_best, s_success, s_nin;
     __shared__ float Rs[9], Ts[3];
     if (__hip_atomic_load(&ws->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    const int N = n1p ? *n1p : (int)k1_max;
+    const int N = n1p ? min(max(*n1p, 0), (int)k1_max) : (int)k1_max;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float thr = 0.4f * (float)(1 << level);  // 0.4, 0.8, 1.6 (:171,:210)
     // ---- 1. pairs -> LDS (falls back to the global arrays when they do not fit)

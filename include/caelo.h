@@ -176,6 +176,50 @@ int caelo_extract(caelo_ctx *ctx, caelo_voxmap *map, const float *pc, int64_t n,
                   int kp_ld, float *features, int feat_ld, float *valid, int valid_ld, int64_t *key_pixels,
                   int32_t *n_key, uint8_t *flags, int32_t *status, void *ws, void *stream);
 
+/* ---- frame pipeline: whole frames issued round-robin on n_lanes HIP streams, one host thread per lane ----------
+ * Replaces the reference's per-frame driver loops (BatchPreprocess.py:88-140 extract loop, Match.py:296-353 /
+ * PoseEstimation.py pair loop) for throughput: each lane owns a stream, a voxel map and the workspaces of
+ * caelo_extract / caelo_match / caelo_ransac, so the latency-bound kernels of one frame overlap the MFMA-bound
+ * encoder of another and kernel launches are issued from n_lanes threads.  Per-frame results are identical to the
+ * single-call entry points (same kernels, same order within a frame).
+ *   begin(stream)   lanes wait for work already queued on `stream` (the producers of the jobs' inputs)
+ *   submit(job)     copy the job; frame k of the pipeline runs on lane k % n_lanes:
+ *                     caelo_extract(pc -> rows [1024][64] = descriptor 0:60 | xyz 60:63 | valid 63, ...)
+ *                     pair == CAELO_PAIR_CHAIN:    caelo_match + caelo_ransac against the previously submitted frame
+ *                     pair == CAELO_PAIR_EXPLICIT: ... against prev_rows / prev_n_key (e.g. rows gathered from a peer)
+ *   flush(stream)   block until every submitted job is enqueued, then make `stream` wait for all lanes
+ * Buffers named by a job must stay alive until `stream` has passed the flush.  Errors of the worker threads are
+ * returned by the next begin / flush (caelo_last_error() holds the text). */
+typedef struct caelo_pipeline caelo_pipeline;
+#define CAELO_PAIR_NONE 0
+#define CAELO_PAIR_CHAIN 1
+#define CAELO_PAIR_EXPLICIT 2
+typedef struct caelo_frame_job {
+    const float *pc;            /* [n][4] f32 */
+    int64_t n;
+    int32_t dist_channels;      /* 5 | 3, see caelo_extract */
+    int32_t mode;               /* CAELO_EXTRACT_* bits */
+    float *rows;                /* [1024][64] f32 out */
+    int64_t *key_pixels;        /* [1024][2] out */
+    int32_t *n_key;             /* [1] out */
+    uint8_t *flags;             /* [1024][3] out */
+    int32_t *status;            /* int32[4], 16-byte aligned, out */
+    int32_t pair;               /* CAELO_PAIR_* */
+    int32_t reserved;
+    const float *prev_rows;     /* CAELO_PAIR_EXPLICIT: [1024][64] rows of frame 0 of the pair */
+    const int32_t *prev_n_key;  /* CAELO_PAIR_EXPLICIT: its keypoint count (NULL = 1024) */
+    const double *rand;         /* [1500][4] f64 uniform draws (caelo_ransac) */
+    caelo_pose_result *result;  /* out */
+    uint8_t *inlier_mask;       /* [1024] out */
+    int64_t *pair_idx;          /* [1024] out */
+} caelo_frame_job;
+int caelo_pipeline_create(caelo_ctx *ctx, int n_lanes, int64_t max_points, caelo_pipeline **out);
+void caelo_pipeline_destroy(caelo_pipeline *pipe);
+int caelo_pipeline_lanes(const caelo_pipeline *pipe);
+int caelo_pipeline_begin(caelo_pipeline *pipe, void *stream);
+int caelo_pipeline_submit(caelo_pipeline *pipe, const caelo_frame_job *job);
+int caelo_pipeline_flush(caelo_pipeline *pipe, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -337,3 +337,45 @@ def test_fast_voxelization_flags_a_face_point_and_checked_recovers(engine, orc, 
     assert np.array_equal(ff.key_pixels[: len(kpix)].cpu().numpy(), kpix)
     of = np.concatenate([models[1].predict_bits(orc.patches_bits(kp, vox[6 + s], s)[0]) for s in range(3)], axis=1)
     assert np.abs(ff.features[: len(kp)].cpu().numpy() - of).max() <= REL_TOL * np.abs(of).max()
+
+
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_pipeline_equals_single_stream_calls(engine, scans, lanes):
+    """caelo_pipeline (frames round-robin on `lanes` streams, native issue threads) reproduces the
+    one-call-per-stage results bit for bit, including the pair chained across lanes and ring reuse."""
+    import torch
+    from caelo.engine import ransac_draws
+    n = 9
+    pcs = [torch.from_numpy(scans(i % 3)).to(engine.device) for i in range(n)]
+    rnd = [torch.from_numpy(ransac_draws(50 + i)).to(engine.device) for i in range(n)]
+    prev = engine.extract(pcs[2])
+    ref = [engine.extract(pc) for pc in pcs]
+    ref_pose = [engine.match_pose(prev if i == 0 else ref[i - 1], ref[i], rnd[i]) for i in range(n)]
+    pipe = engine.pipeline(lanes)
+    for rep in range(2):   # second pass reuses lanes, maps and event slots
+        batch = pipe.run(pcs, rnd, prev=prev)
+        torch.cuda.synchronize()
+        for i in range(n):
+            f = batch.frame(i)
+            assert torch.equal(f.rows, ref[i].rows) and torch.equal(f.key_pixels, ref[i].key_pixels), i
+            assert int(f.n_key.item()) == int(ref[i].n_key.item()) and torch.equal(f.flags, ref[i].flags)
+            assert torch.equal(f.status, ref[i].status)
+            res, mask, idx = ref_pose[i]
+            assert torch.equal(batch.pair_idx[i], idx) and torch.equal(batch.inlier_mask[i], mask), i
+            assert torch.equal(batch.result[i], res), i
+    # no pair for the first frame when no predecessor is given
+    batch = pipe.run(pcs[:2], rnd[:2])
+    torch.cuda.synchronize()
+    assert int(batch.result[0].sum().item()) == 0 and torch.equal(batch.result[1], ref_pose[1][0])
+
+
+def test_pipeline_reports_worker_errors(engine, scans):
+    import torch
+    from caelo import _ffi
+    from caelo.engine import Pipeline, ransac_draws
+    small = Pipeline(engine, lanes=2, max_points=1024)           # voxel maps too small for a scan
+    pc = torch.from_numpy(scans(0)).to(engine.device)
+    with pytest.raises(_ffi.CaeloError, match="exceed the map capacity"):
+        small.run([pc, pc], [torch.from_numpy(ransac_draws(1)).to(engine.device)] * 2)
+    with pytest.raises(_ffi.CaeloError):
+        engine.pipeline(2).run([pc[:3]], [torch.from_numpy(ransac_draws(1)).to(engine.device)])   # n <= 3
