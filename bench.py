@@ -144,6 +144,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    pipe.stats()
     t0 = time.perf_counter()
     prev, batch = run(K, prev)
     torch.cuda.synchronize()
@@ -155,6 +156,7 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    host = pipe.stats()
     # sanity: every pose solved (not timed)
     ok = sum(int(eng.pose_result(batch.result[i]).success) for i in range(K))
     status = int(prev.status[0].item()) if prev.status is not None else 0
@@ -189,7 +191,8 @@ def main():
             "config": {"workload": "configs[2]: KITTI-seq-00-shaped full odometry (extract + NN match + RANSAC pose) on "
                                    "synthetic 64-beam x 2000-azimuth scans",
                        "points_per_frame": n_points, "keypoints": 1024, "patches_per_frame": 3072,
-                       "frames_per_gpu": K, "hip_streams_per_gpu": pipe.lanes, "parallelism": "frames sharded x%d, one RCCL all-gather of %s [1024,64] f32 frame rows" % (
+                       "frames_per_gpu": K, "hip_streams_per_gpu": pipe.lanes,
+                       "host_issue_us_per_frame": round(host["issue_us_per_frame"], 1), "parallelism": "frames sharded x%d, one RCCL all-gather of %s [1024,64] f32 frame rows" % (
                            world, "the boundary" if args.gather == "boundary" else "all"),
                        "poses_solved": "%d/%d" % (ok, K), "status_bits": status},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -121,7 +121,35 @@ int vox_patches_launch(const caelo_voxmap *m, const float *pts, int pts_ld, int6
 int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride, void *ws,
                 hipStream_t s, hipEvent_t *ev);
 
+// caelo_extract in two halves (frame.hip), for the frame pipeline
+struct caelo_extract_args {
+    caelo_ctx *ctx;
+    caelo_voxmap *map;
+    const float *pc;
+    int64_t n;
+    int dist_channels, mode;
+    float *key_pts;
+    int kp_ld;
+    float *features;
+    int feat_ld;
+    float *valid;
+    int valid_ld;
+    int64_t *key_pixels;
+    int32_t *n_key;
+    uint8_t *flags;
+    int32_t *status;
+    void *ws;
+};
+int extract_check(const caelo_extract_args &a);
+int extract_front_launch(const caelo_extract_args &a, hipStream_t s);   // everything up to the bit-packed patches
+int extract_encode_launch(const caelo_extract_args &a, hipStream_t s);  // the four encoder kernels
+
 #define CAELO_KP_HIST_BINS 2048
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. stalls the
+// whole workgroup on every global load / store / atomic still in flight (microseconds for a contended
+// atomic); kernels that hand data between waves through LDS and keep global traffic asynchronous use this.
+__device__ inline void caelo_lds_barrier() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __host__ __device__ inline unsigned long long caelo_pack3(int x, int y, int z) {
     return ((unsigned long long)(unsigned)(x & 0xFFFFF) << 40) | ((unsigned long long)(unsigned)(y & 0xFFFFF) << 20) |

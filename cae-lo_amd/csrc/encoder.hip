@@ -21,6 +21,7 @@
 #include <math.h>
 
 #include "caelo_internal.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -97,7 +98,11 @@ CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const flo
 
 // phase timestamps (100 MHz) of workgroup 0's first patch in the last k_enc_stage1 launch (debug aid)
 __device__ unsigned long long g_enc_stamp[16];
+#ifdef CAELO_ENC_PROF  // make PROF=1: slots 1..5 accumulate shader-clock cycles per phase over all patches, 6 = patches, 7 = queued cells
+#define ENC_STAMP(i) do { if (threadIdx.x == 0) { const long long t_ = clock64(); enc_acc[i] += t_ - enc_t_prev; enc_t_prev = t_; } } while (0)
+#else
 #define ENC_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && patch == 0) g_enc_stamp[i] = wall_clock64(); } while (0)
+#endif
 int enc_debug_copy(unsigned long long *out_host) {
     CAELO_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_enc_stamp), sizeof(unsigned long long) * 16));
     return CAELO_OK;
@@ -108,9 +113,8 @@ struct Stage1Lds {
     float w1[27 * 8];
     float b1[8];
     float bg[8];
-    unsigned long long list_mask[512];
-    unsigned short list_cell[512];
-    unsigned short rows[256];
+    unsigned long long cell_mask[512];  // per pooled cell: set voxels of its 4^3 receptive field, bit a*16 + b*4 + j
+    unsigned short list_cell[512];      // the cells with a non-zero mask, in arrival order
     unsigned int nzrow[12];  // per padded xp: bit yp set when some cell (xp, yp, *) is non-background
     int list_n;
 };
@@ -139,6 +143,7 @@ struct Stage1Lds {
     if ((NZ2) & 0xCu) { CONV2_ROW(ACC_A, ACC_B, APTR, 2, 2) }
 
 __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long *__restrict__ bits, int64_t n_patches,
+                                                    int group,
                                                     const float *__restrict__ w1g, const float *__restrict__ b1g,
                                                     const float *__restrict__ w2g, const float *__restrict__ c0g,
                                                     float *__restrict__ p2out) {
@@ -179,49 +184,68 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long 
     for (int i = tid; i < 27 * 8; i += 256) L.w1[i] = w1g[i];
     if (tid < 8) { L.b1[tid] = b1g[tid]; L.bg[tid] = c0g[512 * 16 + tid]; }  // bg = tanh(b1), from the host table
     for (int i = tid; i < 2 * P1_PLANE; i += 256) L.p1[i] = 0.0f;  // D == 0: halo, pads, background cells
+    for (int i = tid; i < 512; i += 256) L.cell_mask[i] = 0ull;
     if (tid == 0) L.list_n = 0;
     if (tid < 12) L.nzrow[tid] = 0u;
     __syncthreads();
 
-    for (int64_t patch = blockIdx.x; patch < n_patches; patch += gridDim.x) {
+#ifdef CAELO_ENC_PROF
+    long long enc_t_prev = clock64(), enc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    // Patches cost ~1x / 1.5x / 2.5x at the three scales (set voxels 2 / 54 / 67).  Work item j -> scale
+    // group-1 - j / nk, keypoint j % nk, i.e. coarsest scale first; a persistent workgroup takes the items
+    // j = blockIdx.x + k * gridDim.x and so meets a mix of scales instead of one scale only.
+    const int nk = (int)(n_patches / group);
+    int j = blockIdx.x;
+    // thread = one 16-voxel row of the patch (ix = tid >> 4, iy = tid & 15, bit = iz); fetched one patch ahead
+#define S1_PATCH_OF(J) ((int64_t)((J) % nk) * group + (group - 1 - (J) / nk))
+    unsigned int row = 0u;
+    if (j < (int)n_patches) row = ((const unsigned short *)bits)[S1_PATCH_OF(j) * 256 + tid];
+    while (j < (int)n_patches) {
+        const int64_t patch = S1_PATCH_OF(j);
         ENC_STAMP(0);
-        // ---- load the 512-byte patch as 256 u16 rows (row = ix*16 + iy, bit = iz)
-        if (tid < 64) {
-            const unsigned long long w = bits[patch * 64 + tid];
-            L.rows[tid * 4 + 0] = (unsigned short)(w & 0xFFFF);
-            L.rows[tid * 4 + 1] = (unsigned short)((w >> 16) & 0xFFFF);
-            L.rows[tid * 4 + 2] = (unsigned short)((w >> 32) & 0xFFFF);
-            L.rows[tid * 4 + 3] = (unsigned short)(w >> 48);
-        }
-        __syncthreads();
-        ENC_STAMP(1);
-        // ---- B1: receptive-field mask of each pooled cell; queue the non-background ones
-#pragma unroll 1
-        for (int rep = 0; rep < 2; ++rep) {
-            const int cell = tid + rep * 256;
-            const int px = cell >> 6, py = (cell >> 3) & 7, pz = cell & 7;
-            // 4x4x4 input neighbourhood of the 2x2x2 pooling block, as a 64-bit mask: bit a*16 + b*4 + j
-            unsigned long long mask = 0ull;
+        // ---- B1a: scatter every set voxel into the receptive-field masks of the (up to 8) pooled cells that
+        // see it (fire-and-forget LDS ORs).  Work ~ set voxels, not ~ cells.
+        if (row != 0u) {
+            const int x = tid >> 4, y = tid & 15;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int x = 2 * px - 1 + a;
+            for (int dx = 0; dx < 2; ++dx) {
+                const int px = ((x + 1) >> 1) - dx;
+                if (px < 0 || px > 7) continue;
+                const int a = x + 1 - 2 * px;  // x = 2px - 1 + a
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int y = 2 * py - 1 + b;
-                    unsigned int row = 0;
-                    if (x >= 0 && x < 16 && y >= 0 && y < 16) row = L.rows[x * 16 + y];
-                    const unsigned int nib = ((row << 1) >> (2 * pz)) & 0xFu;  // z = 2pz-1 .. 2pz+2
-                    mask |= (unsigned long long)nib << (a * 16 + b * 4);
+                for (int dy = 0; dy < 2; ++dy) {
+                    const int py = ((y + 1) >> 1) - dy;
+                    if (py < 0 || py > 7) continue;
+                    const int b = y + 1 - 2 * py;
+#pragma unroll
+                    for (int pz = 0; pz < 8; ++pz) {
+                        const unsigned int nib = ((row << 1) >> (2 * pz)) & 0xFu;  // z = 2pz-1 .. 2pz+2
+                        if (nib != 0u)
+                            atomicOr(&L.cell_mask[(px * 8 + py) * 8 + pz], (unsigned long long)nib << (a * 16 + b * 4));
+                    }
                 }
             }
-            if (mask != 0ull) {
-                const int idx = atomicAdd(&L.list_n, 1);
-                L.list_mask[idx] = mask;
-                L.list_cell[idx] = (unsigned short)cell;
-                atomicOr(&L.nzrow[px + 1], 1u << (py + 1));
+        }
+        caelo_lds_barrier();
+        ENC_STAMP(1);
+        // ---- B1b: queue the cells with a non-empty mask (one LDS counter bump per wave)
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int cell = tid + rep * 256;
+            const bool hit = L.cell_mask[cell] != 0ull;
+            const unsigned long long bal = __ballot(hit);
+            if (bal != 0ull) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&L.list_n, __popcll(bal));
+                base = __shfl(base, 0);
+                if (hit) {
+                    L.list_cell[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)cell;
+                    atomicOr(&L.nzrow[(cell >> 6) + 1], 1u << (((cell >> 3) & 7) + 1));
+                }
             }
         }
-        __syncthreads();
+        caelo_lds_barrier();
         ENC_STAMP(2);
         const int nlist = L.list_n;
         // ---- B2: conv1 + pool1 + tanh on the queued cells; 8 lanes = the 8 positions of a pooling block
@@ -231,8 +255,8 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long 
             float acc[8];
             int cell = 0;
             if (item < nlist) {
-                const unsigned long long mask = L.list_mask[item];
                 cell = L.list_cell[item];
+                const unsigned long long mask = L.cell_mask[cell];
                 const int sa = sub >> 2, sb = (sub >> 1) & 1, sc = sub & 1;
                 unsigned int taps = 0;  // bit (ka*3+kb)*3+kc
 #pragma unroll
@@ -269,8 +293,11 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long 
                 L.p1[(sub >> 2) * P1_PLANE + (P1_FRONT + q) * 4 + (sub & 3)] = tanhf(mine) - L.bg[sub];
             }
         }
-        __syncthreads();
+        caelo_lds_barrier();
         ENC_STAMP(3);
+        const int jn = j + (int)gridDim.x;
+        unsigned int row_next = 0u;
+        if (jn < (int)n_patches) row_next = ((const unsigned short *)bits)[S1_PATCH_OF(jn) * 256 + tid];
         // ---- conv2 (8->16) on MFMA: per row pair yi this wave owns the x pair xp = (wave - 2 yi) mod 4
         {
             const int yl = n >> 3, z = n & 7;  // A row m = yl*8 + z
@@ -314,21 +341,32 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long 
                 }
             }
         }
-        __syncthreads();
+        caelo_lds_barrier();
         ENC_STAMP(4);
+#ifdef CAELO_ENC_PROF
+        if (threadIdx.x == 0) { enc_acc[6] += 1; enc_acc[7] += nlist; }
+#else
         if (threadIdx.x == 0 && blockIdx.x == 0 && patch == 0) g_enc_stamp[8] = (unsigned long long)nlist;
+#endif
         // ---- back to D == 0 for the next patch
         for (int i = tid; i < nlist * 2; i += 256) {
             const int cell = L.list_cell[i >> 1];
             const int px = cell >> 6, py = (cell >> 3) & 7, pz = cell & 7;
             const int q = ((px + 1) * 10 + (py + 1)) * 8 + pz;
             *(float4 *)&L.p1[(i & 1) * P1_PLANE + (P1_FRONT + q) * 4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            L.cell_mask[cell] = 0ull;
         }
         if (tid == 0) L.list_n = 0;
         if (tid < 12) L.nzrow[tid] = 0u;
-        __syncthreads();
+        caelo_lds_barrier();
+        j = jn;
+        row = row_next;
         ENC_STAMP(5);
     }
+#ifdef CAELO_ENC_PROF
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_enc_stamp[i], (unsigned long long)enc_acc[i]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -403,21 +441,25 @@ __global__ void __launch_bounds__(256) k_enc_conv3(const float *__restrict__ p2,
             for (int t = 0; t < 27; ++t) {
                 const int ka = t / 9, kb = (t / 3) % 3, kc = t % 3;
                 const int off = ((ka * 6 + kb) * 4 + (kc - 1)) * 4;
+                // tile x reads the padded plane x + ka: planes 0 and 5 are the zero halo, their products are
+                // added zeros -- skipped (2 of the 12 (x, ka) combinations)
+#define C3_LIVE(X) (!(((X) == 0 && ka == 0) || ((X) == 3 && ka == 2)))
                 float4 a[4];
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
+                    if (!C3_LIVE(x)) continue;
                     a[x] = *(const float4 *)(a_ptr + off + x * 24 * 4);
                     if (kc == 0) { if (!zlo) a[x] = make_float4(0.f, 0.f, 0.f, 0.f); }
                     if (kc == 2) { if (!zhi) a[x] = make_float4(0.f, 0.f, 0.f, 0.f); }
                 }
 #pragma unroll
-                for (int x = 0; x < 4; ++x) acc[x] = MFMA16(a[x].x, breg[t][0], acc[x]);
+                for (int x = 0; x < 4; ++x) if (C3_LIVE(x)) acc[x] = MFMA16(a[x].x, breg[t][0], acc[x]);
 #pragma unroll
-                for (int x = 0; x < 4; ++x) acc[x] = MFMA16(a[x].y, breg[t][1], acc[x]);
+                for (int x = 0; x < 4; ++x) if (C3_LIVE(x)) acc[x] = MFMA16(a[x].y, breg[t][1], acc[x]);
 #pragma unroll
-                for (int x = 0; x < 4; ++x) acc[x] = MFMA16(a[x].z, breg[t][2], acc[x]);
+                for (int x = 0; x < 4; ++x) if (C3_LIVE(x)) acc[x] = MFMA16(a[x].z, breg[t][2], acc[x]);
 #pragma unroll
-                for (int x = 0; x < 4; ++x) acc[x] = MFMA16(a[x].w, breg[t][3], acc[x]);
+                for (int x = 0; x < 4; ++x) if (C3_LIVE(x)) acc[x] = MFMA16(a[x].w, breg[t][3], acc[x]);
             }
             if (patch < n_patches) {
                 // C rows 4g + r -> (yl = g, z = r); flatten index (x,y,z,c) = ((x*4 + y)*4 + z)*32 + c
@@ -564,15 +606,18 @@ int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group
         CAELO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_enc_stage1, 256, 0));
         CAELO_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
         slots1 = per_cu * cus > 0 ? per_cu * cus : 1024;
+        if (getenv("CAELO_S1_GRID")) slots1 = atoi(getenv("CAELO_S1_GRID"));
     }
     const unsigned g1 = (unsigned)(n_patches < slots1 ? n_patches : slots1);
     if (ev) CAELO_HIP(hipEventRecord(ev[0], s));
-    k_enc_stage1<<<g1, 256, 0, s>>>((const unsigned long long *)bits, n_patches, c->enc_w1, c->enc_b1, c->enc_w2,
+    const int order_group = (n_patches % group == 0) ? group : 1;
+    k_enc_stage1<<<g1, 256, 0, s>>>((const unsigned long long *)bits, n_patches, order_group, c->enc_w1, c->enc_b1, c->enc_w2,
                                     c->enc_c0, p2);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[1], s));
     const int64_t pairs = (n_patches + 1) / 2;
-    const unsigned g3 = (unsigned)(pairs < 512 ? pairs : 512);
+    static int g3max = getenv("CAELO_C3_GRID") ? atoi(getenv("CAELO_C3_GRID")) : 512;
+    const unsigned g3 = (unsigned)(pairs < g3max ? pairs : g3max);
     k_enc_conv3<<<g3, 256, 0, s>>>(p2, n_patches, c->enc_w3, c->enc_b3, f3);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[2], s));

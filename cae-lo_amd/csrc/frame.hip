@@ -85,23 +85,27 @@ static ExtractLayout extract_layout() {
 
 CAELO_API int64_t caelo_extract_ws_bytes(void) { return (int64_t)extract_layout().total; }
 
-CAELO_API int caelo_extract(caelo_ctx *c, caelo_voxmap *m, const float *pc, int64_t n, int dist_channels, int mode,
-                            float *key_pts, int kp_ld, float *features, int feat_ld, float *valid, int valid_ld,
-                            int64_t *key_pixels, int32_t *n_key, uint8_t *flags, int32_t *status, void *wsv,
-                            void *stream) {
-    CAELO_REQUIRE(c && m && pc && key_pts && features && key_pixels && n_key && flags && status && wsv, "null argument");
-    CAELO_REQUIRE(c->has_resp && c->has_enc, "weights not set");
-    CAELO_REQUIRE(n > 3, "PC.shape[0] > 3 (SphericalRing.py:73)");
-    CAELO_REQUIRE(dist_channels == 5 || dist_channels == 3, "dist_channels must be 5 (demo mode) or 3 (batch mode)");
-    CAELO_REQUIRE(kp_ld >= 3 && feat_ld >= 60, "bad leading dimension");
-    CAELO_REQUIRE(((uintptr_t)status & 15u) == 0, "status must be a 16-byte aligned int32[4]");
-    if (n > m->max_points) {
-        caelo_set_error("caelo_extract: %lld points exceed the map capacity %lld", (long long)n, (long long)m->max_points);
+// The fused path in two halves so that the frame pipeline can put an event edge between them:
+// front = clear + ring image + response + keypoints + voxel map + patch gather (latency-bound kernels),
+// encode = the four MFMA-bound encoder kernels.
+int extract_check(const caelo_extract_args &a) {
+    CAELO_REQUIRE(a.ctx && a.map && a.pc && a.key_pts && a.features && a.key_pixels && a.n_key && a.flags && a.status && a.ws,
+                  "null argument");
+    CAELO_REQUIRE(a.ctx->has_resp && a.ctx->has_enc, "weights not set");
+    CAELO_REQUIRE(a.n > 3, "PC.shape[0] > 3 (SphericalRing.py:73)");
+    CAELO_REQUIRE(a.dist_channels == 5 || a.dist_channels == 3, "dist_channels must be 5 (demo mode) or 3 (batch mode)");
+    CAELO_REQUIRE(a.kp_ld >= 3 && a.feat_ld >= 60, "bad leading dimension");
+    CAELO_REQUIRE(((uintptr_t)a.status & 15u) == 0, "status must be a 16-byte aligned int32[4]");
+    if (a.n > a.map->max_points) {
+        caelo_set_error("caelo_extract: %lld points exceed the map capacity %lld", (long long)a.n, (long long)a.map->max_points);
         return CAELO_ERR_CAPACITY;
     }
-    hipStream_t s = caelo_stream(stream);
+    return CAELO_OK;
+}
+
+int extract_front_launch(const caelo_extract_args &a, hipStream_t s) {
     const ExtractLayout L = extract_layout();
-    char *ws = (char *)wsv;
+    char *ws = (char *)a.ws;
     float *ring = (float *)(ws + L.ring);
     int32_t *counter = (int32_t *)(ws + L.counter);
     int32_t *winner = (int32_t *)(ws + L.winner);
@@ -115,21 +119,41 @@ CAELO_API int caelo_extract(caelo_ctx *c, caelo_voxmap *m, const float *pc, int6
     cl.n = 0;
     cl.item[cl.n++] = {winner, L.counter - L.winner, 0xFFFFFFFFu};
     cl.item[cl.n++] = {counter, L.ring - L.counter, 0u};  // counter | hist | cand_count
-    cl.item[cl.n++] = {status, 16, 0u};  // status is int32[4], 16-byte aligned (word 0 carries the bits)
-    const bool exact_vox = (mode & CAELO_EXTRACT_EXACT_VOXELS) != 0;
-    vox_clear_items(m, exact_vox ? 1 : 0, cl);
+    cl.item[cl.n++] = {a.status, 16, 0u};  // status is int32[4], 16-byte aligned (word 0 carries the bits)
+    const bool exact_vox = (a.mode & CAELO_EXTRACT_EXACT_VOXELS) != 0;
+    vox_clear_items(a.map, exact_vox ? 1 : 0, cl);
     int rc = caelo_clear_many(cl, s);
     if (rc) return rc;
     // ---- ring image, response, keypoints
-    if ((rc = ring_project_launch(pc, n, ring, counter, winner, status, s))) return rc;
-    if ((rc = ring_respond_launch(c, ring, CAELO_RING_W, CAELO_RING_C, resp, s))) return rc;
-    if ((rc = ring_keypoints_launch(ring, CAELO_RING_W, CAELO_RING_C, dist_channels, counter, CAELO_RING_W, resp, cand,
-                                    hist, cand_count, key_pixels, key_pts, kp_ld, valid, valid_ld, n_key, status, s)))
+    if ((rc = ring_project_launch(a.pc, a.n, ring, counter, winner, a.status, s))) return rc;
+    if ((rc = ring_respond_launch(a.ctx, ring, CAELO_RING_W, CAELO_RING_C, resp, s))) return rc;
+    if ((rc = ring_keypoints_launch(ring, CAELO_RING_W, CAELO_RING_C, a.dist_channels, counter, CAELO_RING_W, resp, cand,
+                                    hist, cand_count, a.key_pixels, a.key_pts, a.kp_ld, a.valid, a.valid_ld, a.n_key,
+                                    a.status, s)))
         return rc;
-    // ---- voxel map, patches, descriptors
-    if (exact_vox) rc = vox_build_launch(m, pc, n, 4, false, status, s);
-    else rc = vox_build_fast_launch(m, pc, n, 4, status, s);
+    // ---- voxel map, patches
+    if (exact_vox) rc = vox_build_launch(a.map, a.pc, a.n, 4, false, a.status, s);
+    else rc = vox_build_fast_launch(a.map, a.pc, a.n, 4, a.status, s);
     if (rc) return rc;
-    if ((rc = vox_patches_launch(m, key_pts, kp_ld, CAELO_MAX_KEYPTS, n_key, bits, flags, status, true, s))) return rc;
-    return encode_impl(c, bits, CAELO_MAX_KEYPTS * 3, 3, features, feat_ld, ws + L.enc, s, nullptr);
+    return vox_patches_launch(a.map, a.key_pts, a.kp_ld, CAELO_MAX_KEYPTS, a.n_key, bits, a.flags, a.status, true, s);
+}
+
+int extract_encode_launch(const caelo_extract_args &a, hipStream_t s) {
+    const ExtractLayout L = extract_layout();
+    char *ws = (char *)a.ws;
+    return encode_impl(a.ctx, (const uint64_t *)(ws + L.bits), CAELO_MAX_KEYPTS * 3, 3, a.features, a.feat_ld, ws + L.enc, s,
+                       nullptr);
+}
+
+CAELO_API int caelo_extract(caelo_ctx *c, caelo_voxmap *m, const float *pc, int64_t n, int dist_channels, int mode,
+                            float *key_pts, int kp_ld, float *features, int feat_ld, float *valid, int valid_ld,
+                            int64_t *key_pixels, int32_t *n_key, uint8_t *flags, int32_t *status, void *wsv,
+                            void *stream) {
+    const caelo_extract_args a = {c, m, pc, n, dist_channels, mode, key_pts, kp_ld, features, feat_ld, valid, valid_ld,
+                                  key_pixels, n_key, flags, status, wsv};
+    int rc = extract_check(a);
+    if (rc) return rc;
+    hipStream_t s = caelo_stream(stream);
+    if ((rc = extract_front_launch(a, s))) return rc;
+    return extract_encode_launch(a, s);
 }

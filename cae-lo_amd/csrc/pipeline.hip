@@ -4,12 +4,21 @@
 // hash build, RANSAC replay) and half MFMA-bound (the 3D-CAE encoder).  Back to back on one stream
 // they leave most of the 256 CUs idle most of the time, and a single host thread cannot even issue
 // them as fast as the GPU retires them.  The executor therefore runs whole frames round-robin on
-// `n_lanes` streams, each fed by its own host thread with its own voxel map and workspaces; the only
-// cross-lane edge is "pair (i-1, i) needs the rows of frame i-1", carried by one HIP event.
+// `n_lanes` streams, each fed by its own host thread with its own voxel map and workspaces.  Two
+// cross-lane edges, one HIP event each:
+//   * pair (i-1, i) needs the rows of frame i-1;
+//   * optional (CAELO_ENC_DEPTH=d, off by default): the encoder of frame i starts after the encoder of frame
+//     i - d has finished.  Measured on MI355X: no gain (4.42k vs 4.43k frames/s at 3 lanes) -- the persistent
+//     encoder kernels hold every CU for their whole duration, so the latency-bound kernels of the other lanes
+//     stretch behind them whether or not the encoders themselves are staggered.
 //
 // Host protocol (the submitting thread):   begin(stream) -> submit(job) ... -> flush(stream)
 #include "caelo_internal.h"
 
+#include <stdlib.h>
+
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -23,7 +32,8 @@ constexpr int RING = 128;  // job slots in flight (events are recycled through t
 
 struct Slot {
     hipEvent_t extracted = nullptr;  // recorded on the job's lane after its extract was enqueued
-    bool recorded = false;           // host-side: the record call above has been made
+    hipEvent_t encoded = nullptr;    // the same point (extract ends with the encoder); separate object, separate consumer
+    bool recorded = false;           // host-side: the record calls above have been made
     bool done = false;               // host-side: everything of the job has been enqueued
     caelo_frame_job job;
 };
@@ -51,6 +61,8 @@ struct caelo_pipeline {
     int error = 0;
     std::string error_text;
     hipEvent_t begun = nullptr;
+    int enc_depth = 0;  // > 0: encoders of at most this many frames in flight (0 or >= n_lanes: unconstrained)
+    std::atomic<int64_t> stat_jobs{0}, stat_issue_ns{0}, stat_wait_ns{0};
 };
 
 namespace {
@@ -63,12 +75,35 @@ void fail(caelo_pipeline *p, int rc) {
     }
 }
 
+inline int64_t now_ns() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 void run_job(caelo_pipeline *p, Lane &lane, uint64_t seq) {
+    const int64_t t_start = now_ns();
+    int64_t t_wait = 0;
     Slot &sl = p->slots[seq % RING];
     const caelo_frame_job &j = sl.job;
-    int rc = caelo_extract(p->ctx, lane.map, j.pc, j.n, j.dist_channels, j.mode, j.rows + 60, 64, j.rows, 64, j.rows + 63, 64,
-                           j.key_pixels, j.n_key, j.flags, j.status, lane.ws_extract, lane.stream);
-    if (rc == CAELO_OK && hipEventRecord(sl.extracted, lane.stream) != hipSuccess) {
+    const caelo_extract_args xa = {p->ctx, lane.map, j.pc, j.n, j.dist_channels, j.mode, j.rows + 60, 64, j.rows, 64,
+                                   j.rows + 63, 64, j.key_pixels, j.n_key, j.flags, j.status, lane.ws_extract};
+    int rc = extract_check(xa);
+    if (rc == CAELO_OK) rc = extract_front_launch(xa, lane.stream);
+    if (rc == CAELO_OK && p->enc_depth > 0 && (uint64_t)p->enc_depth < p->lanes.size() && seq >= (uint64_t)p->enc_depth) {
+        Slot &es = p->slots[(seq - p->enc_depth) % RING];  // encoder token: behind frame seq - enc_depth
+        {
+            const int64_t t0 = now_ns();
+            std::unique_lock<std::mutex> g(p->mu);
+            p->cv.wait(g, [&] { return es.recorded; });
+            t_wait += now_ns() - t0;
+        }
+        if (hipStreamWaitEvent(lane.stream, es.encoded, 0) != hipSuccess) {
+            caelo_set_error("caelo_pipeline: hipStreamWaitEvent failed");
+            rc = CAELO_ERR_HIP;
+        }
+    }
+    if (rc == CAELO_OK) rc = extract_encode_launch(xa, lane.stream);
+    if (rc == CAELO_OK && (hipEventRecord(sl.extracted, lane.stream) != hipSuccess ||
+                           hipEventRecord(sl.encoded, lane.stream) != hipSuccess)) {
         caelo_set_error("caelo_pipeline: hipEventRecord failed");
         rc = CAELO_ERR_HIP;
     }
@@ -86,8 +121,10 @@ void run_job(caelo_pipeline *p, Lane &lane, uint64_t seq) {
             prev_n = ps.job.n_key;
             if (p->lanes.size() > 1) {  // the predecessor ran on another lane
                 {
+                    const int64_t t0 = now_ns();
                     std::unique_lock<std::mutex> g(p->mu);
                     p->cv.wait(g, [&] { return ps.recorded; });
+                    t_wait += now_ns() - t0;
                 }
                 if (hipStreamWaitEvent(lane.stream, ps.extracted, 0) != hipSuccess) {
                     caelo_set_error("caelo_pipeline: hipStreamWaitEvent failed");
@@ -103,6 +140,9 @@ void run_job(caelo_pipeline *p, Lane &lane, uint64_t seq) {
                               j.result, j.inlier_mask, lane.ws_ransac, lane.stream);
     }
     if (rc != CAELO_OK) fail(p, rc);
+    p->stat_jobs += 1;
+    p->stat_wait_ns += t_wait;
+    p->stat_issue_ns += now_ns() - t_start - t_wait;
     {
         std::lock_guard<std::mutex> g(p->mu);
         sl.done = true;
@@ -159,8 +199,10 @@ CAELO_API void caelo_pipeline_destroy(caelo_pipeline *p) {
         if (l.joined) (void)hipEventDestroy(l.joined);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
-    for (Slot &s : p->slots)
+    for (Slot &s : p->slots) {
         if (s.extracted) (void)hipEventDestroy(s.extracted);
+        if (s.encoded) (void)hipEventDestroy(s.encoded);
+    }
     if (p->begun) (void)hipEventDestroy(p->begun);
     delete p;
 }
@@ -181,7 +223,11 @@ CAELO_API int caelo_pipeline_create(caelo_ctx *c, int n_lanes, int64_t max_point
         }
     };
     hip_ok(hipEventCreateWithFlags(&p->begun, hipEventDisableTiming), "hipEventCreate");
-    for (Slot &s : p->slots) hip_ok(hipEventCreateWithFlags(&s.extracted, hipEventDisableTiming), "hipEventCreate");
+    for (Slot &s : p->slots) {
+        hip_ok(hipEventCreateWithFlags(&s.extracted, hipEventDisableTiming), "hipEventCreate");
+        hip_ok(hipEventCreateWithFlags(&s.encoded, hipEventDisableTiming), "hipEventCreate");
+    }
+    if (const char *e = getenv("CAELO_ENC_DEPTH")) p->enc_depth = atoi(e) > 0 ? atoi(e) : 0;
     for (Lane &l : p->lanes) {
         hip_ok(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking), "hipStreamCreate");
         hip_ok(hipEventCreateWithFlags(&l.joined, hipEventDisableTiming), "hipEventCreate");
@@ -200,6 +246,15 @@ CAELO_API int caelo_pipeline_create(caelo_ctx *c, int n_lanes, int64_t max_point
 }
 
 CAELO_API int caelo_pipeline_lanes(const caelo_pipeline *p) { return p ? (int)p->lanes.size() : 0; }
+
+CAELO_API int caelo_pipeline_stats(caelo_pipeline *p, int64_t *out_host) {
+    CAELO_REQUIRE(p && out_host, "null argument");
+    out_host[0] = p->stat_jobs.exchange(0);
+    out_host[1] = p->stat_issue_ns.exchange(0);
+    out_host[2] = p->stat_wait_ns.exchange(0);
+    out_host[3] = (int64_t)p->lanes.size();
+    return CAELO_OK;
+}
 
 CAELO_API int caelo_pipeline_begin(caelo_pipeline *p, void *stream) {
     CAELO_REQUIRE(p, "null argument");
@@ -224,8 +279,9 @@ CAELO_API int caelo_pipeline_submit(caelo_pipeline *p, const caelo_frame_job *jo
         caelo_set_error("caelo_pipeline_submit: the first job has no predecessor to chain to");
         return CAELO_ERR_ARG;
     }
-    // slot seq % RING is free once job seq - RING and its chained successor have been enqueued
-    p->cv.wait(g, [&] { return p->submitted + 2 <= p->retired + RING; });
+    // slot seq % RING is free once job seq - RING and the jobs that consume its events (the chained successor,
+    // the encoder-token successor seq - RING + enc_depth) have been enqueued
+    p->cv.wait(g, [&] { return p->submitted + 1 + (uint64_t)(p->enc_depth > 1 ? p->enc_depth : 1) <= p->retired + RING; });
     const uint64_t seq = p->submitted++;
     Slot &sl = p->slots[seq % RING];
     sl.job = *job;

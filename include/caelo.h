@@ -219,6 +219,9 @@ int caelo_pipeline_lanes(const caelo_pipeline *pipe);
 int caelo_pipeline_begin(caelo_pipeline *pipe, void *stream);
 int caelo_pipeline_submit(caelo_pipeline *pipe, const caelo_frame_job *job);
 int caelo_pipeline_flush(caelo_pipeline *pipe, void *stream);
+/* host-side counters since the last call (then reset): out_host[4] = jobs, ns the lane threads spent issuing them,
+ * ns they waited for a predecessor frame to be enqueued on another lane, number of lanes */
+int caelo_pipeline_stats(caelo_pipeline *pipe, int64_t *out_host);
 
 #ifdef __cplusplus
 }
