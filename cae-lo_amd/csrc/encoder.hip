@@ -98,8 +98,10 @@ CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const flo
 
 // phase timestamps (100 MHz) of workgroup 0's first patch in the last k_enc_stage1 launch (debug aid)
 __device__ unsigned long long g_enc_stamp[16];
-#ifdef CAELO_ENC_PROF  // make PROF=1: slots 1..5 accumulate shader-clock cycles per phase over all patches, 6 = patches, 7 = queued cells
-#define ENC_STAMP(i) do { if (threadIdx.x == 0) { const long long t_ = clock64(); enc_acc[i] += t_ - enc_t_prev; enc_t_prev = t_; } } while (0)
+#ifdef CAELO_ENC_PROF  // make PROF=1: slots 0..5 accumulate shader-clock cycles per phase over all patches, 6 = patches, 7 = queued cells.
+// Caveat: s_memtime drains the wave's outstanding stores first, so the phase that ends with the P2 stores ("conv2")
+// is inflated by their latency; use tools/enc_scale_prof.py (unprofiled build) for absolute numbers.
+#define ENC_STAMP(i) do { if (threadIdx.x == 0) { const unsigned t_ = (unsigned)clock64(); L.prof[i] += t_ - enc_t_prev; enc_t_prev = t_; } } while (0)
 #else
 #define ENC_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && patch == 0) g_enc_stamp[i] = wall_clock64(); } while (0)
 #endif
@@ -117,6 +119,9 @@ struct Stage1Lds {
     unsigned short list_cell[512];      // the cells with a non-zero mask, in arrival order
     unsigned int nzrow[12];  // per padded xp: bit yp set when some cell (xp, yp, *) is non-background
     int list_n;
+#ifdef CAELO_ENC_PROF
+    unsigned int prof[8];
+#endif
 };
 
 // 3 taps (one (ka, kb) pair of input rows) of one m-tile: 6 MFMAs on two interleaved accumulators
@@ -190,7 +195,9 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long 
     __syncthreads();
 
 #ifdef CAELO_ENC_PROF
-    long long enc_t_prev = clock64(), enc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned enc_t_prev = (unsigned)clock64();  // phase totals accumulate in LDS (registers would spill at 3 workgroups/CU)
+    if (tid < 8) L.prof[tid] = 0u;
+    __syncthreads();
 #endif
     // Patches cost ~1x / 1.5x / 2.5x at the three scales (set voxels 2 / 54 / 67).  Work item j -> scale
     // group-1 - j / nk, keypoint j % nk, i.e. coarsest scale first; a persistent workgroup takes the items
@@ -344,7 +351,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long 
         caelo_lds_barrier();
         ENC_STAMP(4);
 #ifdef CAELO_ENC_PROF
-        if (threadIdx.x == 0) { enc_acc[6] += 1; enc_acc[7] += nlist; }
+        if (threadIdx.x == 0) { L.prof[6] += 1; L.prof[7] += nlist; }
 #else
         if (threadIdx.x == 0 && blockIdx.x == 0 && patch == 0) g_enc_stamp[8] = (unsigned long long)nlist;
 #endif
@@ -365,7 +372,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long 
     }
 #ifdef CAELO_ENC_PROF
     if (threadIdx.x == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_enc_stamp[i], (unsigned long long)enc_acc[i]);
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_enc_stamp[i], (unsigned long long)L.prof[i]);
 #endif
 }
 
@@ -550,31 +557,54 @@ __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part
                                                   const float *__restrict__ bd1p, const float *__restrict__ wd2,
                                                   const float *__restrict__ bd2, int group, float *__restrict__ out,
                                                   int out_stride) {
-    __shared__ float h[4][DENSE_NP];
-    const int tid = threadIdx.x;
-    const int64_t p0 = (int64_t)blockIdx.x * 4;
-    for (int i = tid; i < 4 * DENSE_NP; i += 256) {
-        const int pl = i / DENSE_NP, j = i % DENSE_NP;
-        const int64_t p = p0 + pl;
-        float v = 0.0f;
-        if (p < n_patches && j < DENSE_N) {
-            float s = bd1p[j];
+    // One wave per patch, no LDS, no barrier.  Lane owns hidden columns j = lane + 64c: the 8 x 4 partial-sum
+    // loads and the 4 x 20 Dense(20) weights of those columns are all in flight at once; the 20 outputs are
+    // 64-lane butterfly sums of per-lane partial dot products.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t p = (int64_t)blockIdx.x * 4 + wave;
+    if (p >= n_patches) return;
+    float s[4];
+    float4 w[4][5];
 #pragma unroll
-            for (int sp = 0; sp < D1_SPLIT; ++sp) s += part[((size_t)sp * n_rows_pad + p) * DENSE_NP + j];
-            v = tanhf(s);
-        }
-        h[pl][j] = v;
+    for (int c = 0; c < 4; ++c) {
+        const int j = lane + 64 * c;
+        const bool ok = j < DENSE_N;
+        s[c] = ok ? bd1p[j] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) w[c][q] = ok ? ((const float4 *)(wd2 + j * 20))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    __syncthreads();
-    if (tid < 80) {
-        const int pl = tid / 20, o = tid % 20;
-        const int64_t p = p0 + pl;
-        if (p < n_patches) {
-            float s = bd2[o];
-            for (int i = 0; i < DENSE_N; ++i) s += h[pl][i] * wd2[i * 20 + o];
-            out[(size_t)(p / group) * out_stride + (size_t)(p % group) * 20 + o] = tanhf(s);
+#pragma unroll
+    for (int sp = 0; sp < D1_SPLIT; ++sp) {
+        const float *row = part + ((size_t)sp * n_rows_pad + p) * DENSE_NP;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = lane + 64 * c;
+            if (j < DENSE_N) s[c] += row[j];
         }
     }
+    float acc[20];
+#pragma unroll
+    for (int o = 0; o < 20; ++o) acc[o] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float hv = (lane + 64 * c < DENSE_N) ? tanhf(s[c]) : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            acc[4 * q + 0] += hv * w[c][q].x;
+            acc[4 * q + 1] += hv * w[c][q].y;
+            acc[4 * q + 2] += hv * w[c][q].z;
+            acc[4 * q + 3] += hv * w[c][q].w;
+        }
+    }
+    float mine = 0.0f;
+#pragma unroll
+    for (int o = 0; o < 20; ++o) {
+        float v = acc[o];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+        mine = (lane == o) ? v : mine;
+    }
+    if (lane < 20) out[(size_t)(p / group) * out_stride + (size_t)(p % group) * 20 + lane] = tanhf(bd2[lane] + mine);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -10,6 +10,9 @@ eng = Engine()
 pc = torch.from_numpy(synth.make_scan(0)).to(eng.device)
 ff = eng.extract(pc)
 bits, _ = eng.patches(eng.voxelize(pc)[0], ff.key_pts.contiguous())
+if len(sys.argv) > 1:      # one scale only (or "empty")
+    bits = (torch.zeros_like(bits) if sys.argv[1] == "empty" else
+            bits.reshape(-1, 3, 64)[:, int(sys.argv[1])].repeat(1, 3).reshape(-1, 3, 64).contiguous())
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * 40)()
 eng.lib.caelo_debug_read(C.cast(buf, C.c_void_p))
