@@ -174,9 +174,23 @@ def main():
         dom = int(np.argmax(ms_avg))
         names = ["k_enc_stage1", "k_enc_conv3", "k_enc_dense1", "k_enc_head"]
         achieved = flops[dom] / (ms_avg[dom] * 1e-3) / 1e12
+        # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the per-launch
+        # FETCH_SIZE / WRITE_SIZE of the same command (two separate rocprofv3 --pmc passes) are committed
+        # under profiles/ and quoted here.  hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024, uncorrected.
+        traffic, traffic_note = None, None
+        try:
+            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
+            k = pmc["kernels"][names[dom]]
+            traffic = int((k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024)
+            traffic_note = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; bytes per launch)"
+        except Exception:
+            pass
         roofline = {"bound": "mfma", "kernel": names[dom], "achieved": round(float(achieved), 3),
                     "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(float(achieved / F32_MFMA_PEAK_TFLOPS), 4),
-                    "traffic": None,
+                    "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_note,
+                    "note": "achieved = ALGORITHMIC (dense Keras) FLOPs / measured launch time; the kernel skips the conv2 "
+                            "products whose input rows equal the all-background response (exact), so frac can exceed 1; "
+                            "executed MFMA share and per-kernel PMC in DESIGN.md section 4",
                     "launch_ms": round(float(ms_avg[dom]), 4), "flops_per_launch": int(flops[dom]),
                     "encoder_kernels_ms": {n: round(float(m), 4) for n, m in zip(names, ms_avg)},
                     "encoder_total_tflops": round(float(flops.sum() / (ms_avg.sum() * 1e-3) / 1e12), 3)}
