@@ -509,11 +509,12 @@ int patch_debug_copy(unsigned long long *out_host) {
 }
 
 // Per wavefront: only the 3x3x3 bricks the 16^3 window can touch are staged in LDS (1.7 KB); the other
-// bricks of the 5x5x5 ball cube stay in the registers of the lanes that fetched them (they only matter
-// for the 496-NN count).  Small LDS footprint = many resident wavefronts: the kernel is latency bound
+// bricks of the 5x5x5 ball cube stay in the registers of the lanes that fetched them, a quarter brick per
+// lane (they only matter for the 496-NN count).  Small LDS footprint = many resident wavefronts: the kernel is latency bound
 // (two dependent random accesses into tables that live at the memory side after the atomic build).
 struct PatchWaveLds {
     unsigned long long win[27 * 8];
+    unsigned int found[128];  // (table slot << 7 | ball-cube brick index) of the bricks that exist
     unsigned int hist[BALL_D2 + 1];
     unsigned long long cls[CLASS_CAP];
     int ncls, cut, room;
@@ -559,22 +560,23 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
     const int nbx = ((kx + BALL_R) >> 3) - bx0 + 1, nby = ((ky + BALL_R) >> 3) - by0 + 1, nbz = ((kz + BALL_R) >> 3) - bz0 + 1;
     // window bricks: first brick of the window per axis, relative to the ball cube (0 or 1)
     const int wx0 = ((kx - 8) >> 3) - bx0, wy0 = ((ky - 8) >> 3) - by0, wz0 = ((kz - 8) >> 3) - bz0;
-    // ---- fetch <= 125 bricks: lane l owns bricks l and l + 64; both first probes, then both payloads, are
-    //      issued together (two dependent round trips per wavefront; the tables are <= 10 % full)
-    unsigned long long key[2];
-    ulonglong2 pay[2][4];
-    int bix[2], biy[2], biz[2];
-    bool have[2];
+    // ---- fetch <= 125 bricks in two dependent round trips.
+    // (1) lane l probes the keys of bricks l and l + 64 (both in flight; the tables are <= 10 % full);
+    // (2) the bricks that exist are compacted, and each 64-byte payload is fetched by FOUR lanes (16 B each):
+    //     a wave-wide load touches 16 cache lines instead of 64, and absent bricks cost nothing -- the kernel
+    //     is bound by the number of line requests the vector L1 can keep in flight, not by bytes.
+    int nfound;
+    for (int i = lane; i < 27 * 8; i += 64) L.win[i] = 0ull;  // absent window bricks read as empty
     {
+        unsigned long long key[2];
         uint32_t h[2];
         bool want[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int l = lane + 64 * u;
-            bix[u] = l / 25; biy[u] = (l / 5) % 5; biz[u] = l % 5;
-            want[u] = l < 125 && bix[u] < nbx && biy[u] < nby && biz[u] < nbz && bx0 + bix[u] >= 0 && by0 + biy[u] >= 0 &&
-                      bz0 + biz[u] >= 0;
-            key[u] = caelo_pack3(bx0 + bix[u], by0 + biy[u], bz0 + biz[u]);
+            const int bix = l / 25, biy = (l / 5) % 5, biz = l % 5;
+            want[u] = l < 125 && bix < nbx && biy < nby && biz < nbz && bx0 + bix >= 0 && by0 + biy >= 0 && bz0 + biz >= 0;
+            key[u] = caelo_pack3(bx0 + bix, by0 + biy, bz0 + biz);
             h[u] = caelo_hash64(key[u]) & tab.mask;
         }
         const unsigned long long k0v = want[0] ? tab.keys[h[0]] : CAELO_EMPTY_KEY;
@@ -585,26 +587,37 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
 #pragma unroll
         for (int u = 0; u < 2; ++u)
             if (slot[u] == -2) slot[u] = table_find(tab.keys, tab.mask, key[u]);  // collided: probe on
+        const unsigned long long b0 = __ballot(slot[0] >= 0), b1 = __ballot(slot[1] >= 0);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int n0 = __popcll(b0);
+        nfound = n0 + __popcll(b1);
+        if (slot[0] >= 0) L.found[__popcll(b0 & below)] = ((unsigned)slot[0] << 7) | (unsigned)lane;
+        if (slot[1] >= 0) L.found[n0 + __popcll(b1 & below)] = ((unsigned)slot[1] << 7) | (unsigned)(lane + 64);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // lane owns quarter `part` (x planes 2 part, 2 part + 1) of found brick it * 16 + (lane >> 2), it = 0..7
+    const int part = lane & 3;
+    ulonglong2 pay[8];
+    int bl[8];  // ball-cube brick index of that brick, -1 = none
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            have[u] = slot[u] >= 0;
-            const ulonglong2 *src = (const ulonglong2 *)(tab.bits + (size_t)(have[u] ? slot[u] : 0) * 8);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) pay[u][q] = have[u] ? src[q] : make_ulonglong2(0ull, 0ull);
-        }
+    for (int it = 0; it < 8; ++it) {
+        const int e = it * 16 + (lane >> 2);
+        const bool ok = e < nfound;
+        const unsigned ent = ok ? L.found[e] : 0u;
+        bl[it] = ok ? (int)(ent & 127u) : -1;
+        pay[it] = make_ulonglong2(0ull, 0ull);
+        if (it * 16 < nfound && ok) pay[it] = ((const ulonglong2 *)(tab.bits + (size_t)(ent >> 7) * 8))[part];
     }
     int pop = 0;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int l = lane + 64 * u;
-        const int wx = bix[u] - wx0, wy = biy[u] - wy0, wz = biz[u] - wz0;
-        const bool inwin = l < 125 && wx >= 0 && wx < 3 && wy >= 0 && wy < 3 && wz >= 0 && wz < 3;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            pop += __popcll(pay[u][q].x) + __popcll(pay[u][q].y);
-            if (inwin) {
-                L.win[((wx * 3 + wy) * 3 + wz) * 8 + 2 * q] = pay[u][q].x;
-                L.win[((wx * 3 + wy) * 3 + wz) * 8 + 2 * q + 1] = pay[u][q].y;
+    for (int it = 0; it < 8; ++it) {
+        pop += __popcll(pay[it].x) + __popcll(pay[it].y);
+        if (bl[it] >= 0) {
+            const int wx = bl[it] / 25 - wx0, wy = (bl[it] / 5) % 5 - wy0, wz = bl[it] % 5 - wz0;
+            if (wx >= 0 && wx < 3 && wy >= 0 && wy < 3 && wz >= 0 && wz < 3) {
+                L.win[((wx * 3 + wy) * 3 + wz) * 8 + 2 * part] = pay[it].x;
+                L.win[((wx * 3 + wy) * 3 + wz) * 8 + 2 * part + 1] = pay[it].y;
             }
         }
     }
@@ -646,13 +659,14 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (!have[u]) continue;
-            const int xb = (bx0 + bix[u]) * 8 - kx, ybase = (by0 + biy[u]) * 8 - ky, zbase = (bz0 + biz[u]) * 8 - kz;
+        for (int it = 0; it < 8; ++it) {
+            if (bl[it] < 0) continue;
+            const int xb = (bx0 + bl[it] / 25) * 8 - kx, ybase = (by0 + (bl[it] / 5) % 5) * 8 - ky,
+                      zbase = (bz0 + bl[it] % 5) * 8 - kz;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                unsigned long long v = (q & 1) ? pay[u][q >> 1].y : pay[u][q >> 1].x;
-                const int dx = xb + q;
+            for (int q = 0; q < 2; ++q) {
+                unsigned long long v = q ? pay[it].y : pay[it].x;
+                const int dx = xb + 2 * part + q;
                 while (v) {
                     const int t = __ffsll((long long)v) - 1;
                     v &= v - 1;
@@ -681,13 +695,13 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
             if (room > 0) {
                 // members of the cut class, for the canonical tie rule (ascending (x,y,z) key)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (!have[u]) continue;
-                    const int xb = (bx0 + bix[u]) * 8, yb = (by0 + biy[u]) * 8, zb = (bz0 + biz[u]) * 8;
+                for (int it = 0; it < 8; ++it) {
+                    if (bl[it] < 0) continue;
+                    const int xb = (bx0 + bl[it] / 25) * 8, yb = (by0 + (bl[it] / 5) % 5) * 8, zb = (bz0 + bl[it] % 5) * 8;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        unsigned long long v = (q & 1) ? pay[u][q >> 1].y : pay[u][q >> 1].x;
-                        const int x = xb + q;
+                    for (int q = 0; q < 2; ++q) {
+                        unsigned long long v = q ? pay[it].y : pay[it].x;
+                        const int x = xb + 2 * part + q;
                         while (v) {
                             const int t = __ffsll((long long)v) - 1;
                             v &= v - 1;
