@@ -678,15 +678,36 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane == 0) {
-            int cum = 0, cut = BALL_D2 + 1, room = 0;
-            for (int d2 = 0; d2 <= BALL_D2; ++d2) {
-                const int hh = (int)L.hist[d2];
-                if (cum + hh > NN_CAP) { cut = d2; room = NN_CAP - cum; break; }
-                cum += hh;
+        {
+            // cut class = first d2 whose cumulative count exceeds 496: lane l owns classes 4l .. 4l+3, a wave
+            // prefix sum replaces the serial walk over 193 LDS words (which alone cost ~6 us on the few
+            // wavefronts that take this path -- the tail of the whole kernel)
+            int hh[4], local = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int d2 = 4 * lane + q;
+                hh[q] = d2 <= BALL_D2 ? (int)L.hist[d2] : 0;
+                local += hh[q];
             }
-            L.cut = cut;
-            L.room = room;
+            int incl = local;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            int cum = incl - local, mycut = -1, myroom = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (mycut < 0 && 4 * lane + q <= BALL_D2 && cum + hh[q] > NN_CAP) { mycut = 4 * lane + q; myroom = NN_CAP - cum; }
+                cum += hh[q];
+            }
+            const unsigned long long hit = __ballot(mycut >= 0);
+            if (hit == 0ull) {
+                if (lane == 0) { L.cut = BALL_D2 + 1; L.room = 0; }
+            } else if (lane == __ffsll((long long)hit) - 1) {
+                L.cut = mycut;
+                L.room = myroom;
+            }
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
