@@ -484,74 +484,98 @@ __global__ void __launch_bounds__(256) k_enc_conv3(const float *__restrict__ p2,
 // ------------------------------------------------------------------------------------------------
 // dense1: split-K GEMM  part[s][row][208] = F3[row][k0:k0+256] x Wd1p[k0:k0+256][208]
 // ------------------------------------------------------------------------------------------------
-#define D1_BM 32
+#define D1_BM 96
 #define D1_BK 32
 #define D1_SPLIT 8
 #define D1_KCHUNK (DENSE_K / D1_SPLIT)
-#define D1_APITCH 34  // conflict-free ds_read_b32 of A[m][k] for 16 rows x 2 k per lane group
-#define D1_BVEC ((D1_BK * DENSE_NP / 4 + 255) / 256)  // float4 of the B tile per thread
+#define D1_THREADS 512
+#define D1_APITCH 34  // conflict-free ds_read_b32 of A[m][k]: 16 rows x 2 k per 32-lane group -> banks 2 row + k
+#define D1_MT (D1_BM / 16)
+#define D1_NT (DENSE_NP / 16)
+#define D1_TILES (D1_MT * D1_NT)               // 78 output tiles per workgroup
+#define D1_WTILES ((D1_TILES + 7) / 8)         // <= 10 per wave
+#define D1_A4 (D1_BM * D1_BK / 4)              // float4 of an A stage
+#define D1_B4 (D1_BK * DENSE_NP / 4)           // float4 of a B stage
 
-// 32 rows x 208 columns per workgroup (768 workgroups = 3 per CU, all co-resident); wave w owns m-tile
-// (w & 1) and n-tiles [0,7) or [7,13).  The next k-stage is fetched into registers while the current
-// one is multiplied, so the L2 latency of the 30 KB stage hides behind the MFMAs.
-__global__ void __launch_bounds__(256) k_enc_dense1(const float *__restrict__ f3, int64_t n_rows_pad,
-                                                    const float *__restrict__ wd1p, float *__restrict__ part) {
-    __shared__ __attribute__((aligned(16))) float As[D1_BM * D1_APITCH];
-    __shared__ __attribute__((aligned(16))) float Bs[D1_BK * DENSE_NP];
+// 96 rows x 208 columns x 256 k per workgroup: 32 x 8 = 256 workgroups of 8 waves, one per CU.  Against the
+// 32-row tile this replaces, every weight stage fetched from L2 is used by three times as many rows (L2 -> LDS
+// traffic 188 -> 80 MB per launch) and a stage carries 80 MFMAs per wave between barriers instead of 56.
+// The 78 output tiles are dealt round-robin to the 8 waves (10,10,10,10,10,10,9,9); a wave reads the A and
+// B fragment of each of its tiles straight from LDS (offsets are wave-uniform), accumulators are static.
+// Stages are double buffered in LDS: the next stage is fetched into registers during the MFMAs and stored to
+// the other buffer, one barrier per stage.
+__global__ void __launch_bounds__(D1_THREADS, 1) k_enc_dense1(const float *__restrict__ f3, int64_t n_rows_pad,
+                                                           const float *__restrict__ wd1p, float *__restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float As[2][D1_BM * D1_APITCH];
+    __shared__ __attribute__((aligned(16))) float Bs[2][D1_BK * DENSE_NP];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, n = lane & 15;
-    const int mt = wave & 1, jbeg = (wave >> 1) ? 7 : 0, jcnt = (wave >> 1) ? 6 : 7;
     const int64_t row0 = (int64_t)blockIdx.x * D1_BM;
     const int split = blockIdx.y;
     const int kbeg = split * D1_KCHUNK;
-    f32x4 acc[7];
+    // wave-uniform LDS offsets of this wave's tiles (named scalars: an indexed array would live in scratch)
+#define D1_TILE_T(I) (wave + 8 * (I) < D1_TILES ? wave + 8 * (I) : 0) /* waves 6, 7: slot 9 recomputes tile 0, never stored */
+#define D1_OFFS(I) const int ao##I = (D1_TILE_T(I) / D1_NT) * 16 * D1_APITCH, bo##I = (D1_TILE_T(I) % D1_NT) * 16;
+    D1_OFFS(0) D1_OFFS(1) D1_OFFS(2) D1_OFFS(3) D1_OFFS(4) D1_OFFS(5) D1_OFFS(6) D1_OFFS(7) D1_OFFS(8) D1_OFFS(9)
+    f32x4 acc[D1_WTILES];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 a_pre, b_pre[D1_BVEC];
-    const int am = tid >> 3, akq = tid & 7;  // A tile: 32 rows x 8 float4
-#define D1_FETCH(K0)                                                                                         \
-    {                                                                                                        \
-        a_pre = *(const float4 *)(f3 + (size_t)(row0 + am) * DENSE_K + (K0) + akq * 4);                      \
-        _Pragma("unroll") for (int r = 0; r < D1_BVEC; ++r) {                                                \
-            const int i = tid + r * 256;                                                                     \
-            b_pre[r] = make_float4(0.f, 0.f, 0.f, 0.f);                                                      \
-            if (i < D1_BK * DENSE_NP / 4) b_pre[r] = *(const float4 *)(wd1p + (size_t)(K0) * DENSE_NP + (size_t)i * 4); \
-        }                                                                                                    \
+    for (int i = 0; i < D1_WTILES; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // a stage = 768 float4 of A + 1664 float4 of B = 4.75 per thread; slot u = tid + 512 r is an A element for
+    // u < 768, else B element u - 768; which of the two (and whether slot 4 exists) is uniform per wave
+    float4 pre[5];
+#define D1_SLOT_OK(R) ((R) < 4 || wave < 6)
+#define D1_SLOT_IS_A(R) ((R) == 0 || ((R) == 1 && wave < 4))
+#define D1_FETCH(K0)                                                                                              \
+    {                                                                                                             \
+        _Pragma("unroll") for (int r = 0; r < 5; ++r) {                                                           \
+            const int u = tid + r * D1_THREADS;                                                                   \
+            if (!D1_SLOT_OK(r)) continue;                                                                         \
+            if (D1_SLOT_IS_A(r)) pre[r] = *(const float4 *)(f3 + (size_t)(row0 + (u >> 3)) * DENSE_K + (K0) + (u & 7) * 4); \
+            else pre[r] = *(const float4 *)(wd1p + (size_t)(K0) * DENSE_NP + (size_t)(u - D1_A4) * 4);           \
+        }                                                                                                         \
+    }
+#define D1_STORE(BUF)                                                                                             \
+    {                                                                                                             \
+        _Pragma("unroll") for (int r = 0; r < 5; ++r) {                                                           \
+            const int u = tid + r * D1_THREADS;                                                                   \
+            if (!D1_SLOT_OK(r)) continue;                                                                         \
+            if (D1_SLOT_IS_A(r)) {                                                                                \
+                float2 *d = (float2 *)&As[BUF][(u >> 3) * D1_APITCH + (u & 7) * 4]; /* 8-byte aligned rows */     \
+                d[0] = make_float2(pre[r].x, pre[r].y);                                                           \
+                d[1] = make_float2(pre[r].z, pre[r].w);                                                           \
+            } else *(float4 *)&Bs[BUF][(u - D1_A4) * 4] = pre[r];                                                 \
+        }                                                                                                         \
     }
     D1_FETCH(kbeg)
-    for (int k0 = kbeg; k0 < kbeg + D1_KCHUNK; k0 += D1_BK) {
-        {
-            float *d = &As[am * D1_APITCH + akq * 4];
-            d[0] = a_pre.x; d[1] = a_pre.y; d[2] = a_pre.z; d[3] = a_pre.w;
-#pragma unroll
-            for (int r = 0; r < D1_BVEC; ++r) {
-                const int i = tid + r * 256;
-                if (i < D1_BK * DENSE_NP / 4) *(float4 *)&Bs[i * 4] = b_pre[r];  // tile rows are contiguous: [32][208]
-            }
-        }
-        __syncthreads();
-        if (k0 + D1_BK < kbeg + D1_KCHUNK) D1_FETCH(k0 + D1_BK)
+    D1_STORE(0)
+    __syncthreads();
+#pragma unroll 1
+    for (int st = 0; st < D1_KCHUNK / D1_BK; ++st) {
+        const int buf = st & 1;
+        const bool more = st + 1 < D1_KCHUNK / D1_BK;
+        if (more) D1_FETCH(kbeg + (st + 1) * D1_BK)
+        const float *A = &As[buf][n * D1_APITCH + g];
+        const float *B = &Bs[buf][g * DENSE_NP + n];
 #pragma unroll
         for (int s = 0; s < D1_BK / 4; ++s) {
-            const float a = As[(mt * 16 + n) * D1_APITCH + 4 * s + g];
-#pragma unroll
-            for (int j = 0; j < 7; ++j)
-                if (j < jcnt) acc[j] = MFMA16(a, Bs[(4 * s + g) * DENSE_NP + 16 * (jbeg + j) + n], acc[j]);
+#define D1_MAC(I) acc[I] = MFMA16(A[ao##I + 4 * s], B[bo##I + 4 * s * DENSE_NP], acc[I]);
+            D1_MAC(0) D1_MAC(1) D1_MAC(2) D1_MAC(3) D1_MAC(4) D1_MAC(5) D1_MAC(6) D1_MAC(7) D1_MAC(8) D1_MAC(9)
         }
+        if (more) D1_STORE(buf ^ 1)
         __syncthreads();
     }
-    // C rows 4g + r of this wave's m-tile
-    float *dst = part + ((size_t)split * n_rows_pad + row0 + mt * 16) * DENSE_NP;
+    // C rows 4g + r of each tile
 #pragma unroll
-    for (int j = 0; j < 7; ++j)
-        if (j < jcnt)
+    for (int i = 0; i < D1_WTILES; ++i) {
+        const int t = wave + 8 * i;
+        if (t >= D1_TILES) continue;
+        float *dst = part + ((size_t)split * n_rows_pad + row0 + (t / D1_NT) * 16 + 4 * g) * DENSE_NP + (t % D1_NT) * 16 + n;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dst[(size_t)(4 * g + r) * DENSE_NP + 16 * (jbeg + j) + n] = acc[j][r];
+        for (int r = 0; r < 4; ++r) dst[(size_t)r * DENSE_NP] = acc[i][r];
+    }
 }
 
-// ------------------------------------------------------------------------------------------------
-// head: reduce split-K partials + bias + tanh -> Dense(20) + tanh -> scatter
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part, int64_t n_patches, int64_t n_rows_pad,
                                                   const float *__restrict__ bd1p, const float *__restrict__ wd2,
@@ -610,7 +634,7 @@ __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part
 // ------------------------------------------------------------------------------------------------
 // host entry
 // ------------------------------------------------------------------------------------------------
-static inline int64_t pad64(int64_t n) { return (n + 63) / 64 * 64; }
+static inline int64_t pad64(int64_t n) { return (n + D1_BM - 1) / D1_BM * D1_BM; }  // rows padded to whole dense-1 tiles
 
 CAELO_API int64_t caelo_encode_ws_bytes(int64_t n_patches) {
     const int64_t np = pad64(n_patches);
@@ -652,7 +676,7 @@ int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[2], s));
     dim3 gd((unsigned)(np / D1_BM), D1_SPLIT);
-    k_enc_dense1<<<gd, 256, 0, s>>>(f3, np, c->enc_wd1, part);
+    k_enc_dense1<<<gd, D1_THREADS, 0, s>>>(f3, np, c->enc_wd1, part);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[3], s));
     k_enc_head<<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(part, n_patches, np, c->enc_bd1, c->enc_wd2, c->enc_bd2,
