@@ -284,12 +284,13 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long 
 #pragma unroll
                 for (int c = 0; c < 8; ++c) acc[c] = -3.0e38f;
             }
-            // max over the pooling block (tanh is monotone: pool the pre-activations)
+            // max over the pooling block = 8 aligned lanes (tanh is monotone: pool the pre-activations); DPP
+            // lane swaps (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror) instead of 24 ds_bpermute round trips
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                acc[c] = fmaxf(acc[c], __shfl_xor(acc[c], 1));
-                acc[c] = fmaxf(acc[c], __shfl_xor(acc[c], 2));
-                acc[c] = fmaxf(acc[c], __shfl_xor(acc[c], 4));
+                acc[c] = fmaxf(acc[c], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[c]), 0xB1, 0xF, 0xF, true)));
+                acc[c] = fmaxf(acc[c], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[c]), 0x4E, 0xF, 0xF, true)));
+                acc[c] = fmaxf(acc[c], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[c]), 0x141, 0xF, 0xF, true)));
             }
             if (item < nlist) {
                 float mine = acc[0];  // lane `sub` finishes channel `sub`
