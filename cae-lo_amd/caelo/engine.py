@@ -241,7 +241,8 @@ class Engine:
         key = (torch.cuda.current_stream(self.device).cuda_stream, kind)
         t = self._wss.get(key)
         if t is None or t.numel() < need:
-            t = self._wss[key] = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            # zero-filled: caelo_match / caelo_ransac keep their tickets in the workspace and leave them zero
+            t = self._wss[key] = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
         return t
 
     def pipeline(self, lanes=3):

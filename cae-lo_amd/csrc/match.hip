@@ -208,7 +208,10 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const float *__res
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have reached L2/memory
     }
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&tickets[ctile], 1) == MM_RS - 1;  // tid 0 is in wave 0: its stores are drained
+    if (tid == 0) {
+        s_last = atomicAdd(&tickets[ctile], 1) == MM_RS - 1;  // tid 0 is in wave 0: its stores are drained
+        if (s_last) tickets[ctile] = 0;  // self-cleaning: the workspace is ready for the next call, no memset launch
+    }
     __syncthreads();
     if (!s_last) return;
     // ---- merge the slices and certify: one thread per column
@@ -277,7 +280,6 @@ CAELO_API int caelo_match(caelo_ctx *c, const float *f0, int ld0, int64_t k0_max
     const size_t tbytes = (size_t)((tiles * 4 + 255) / 256) * 256;
     MmPartial *parts = (MmPartial *)((char *)ws + 256 + tbytes);
     int32_t *stats = (int32_t *)((char *)ws + tbytes);  // [0] columns re-scanned exactly, [1] columns decided between two rows
-    CAELO_HIP(hipMemsetAsync(tickets, 0, tbytes + 256, s));
     const bool vec = (dim % 4 == 0) && (ld0 % 4 == 0) && (ld1 % 4 == 0) && (((uintptr_t)f0 | (uintptr_t)f1) & 15u) == 0;
     dim3 grid((unsigned)tiles, MM_RS);
     if (vec)
@@ -496,8 +498,11 @@ struct RansacWs {
     int32_t iterations;
     int32_t success;
     float threshold;
-    int32_t arrived[CAELO_RANSAC_LEVELS];  // workgroups finished per level (the last one replays the rules)
+    // The three below are zero between calls (the workspace is zero-filled once by its owner, every call leaves
+    // it clean again -- no memset launch in the pair chain):
+    int32_t arrived[CAELO_RANSAC_LEVELS];  // workgroups finished per level (the last one replays the rules, then resets it)
     int32_t finished;                      // the pose record is complete: later launches return at once
+    int32_t exited;                        // last launch: workgroups that saw `finished`; the last of them resets both
 };
 
 CAELO_API int64_t caelo_ransac_ws_bytes(void) { return (int64_t)sizeof(RansacWs); }
@@ -625,7 +630,15 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_level(const float *__r
     __shared__ int s_counts[4];
     __shared__ int s_last, s_best, s_success, s_nin;
     __shared__ float Rs[9], Ts[3];
-    if (__hip_atomic_load(&ws->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (__hip_atomic_load(&ws->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        // an earlier level completed the record.  In the last launch every workgroup passes through here, so the
+        // last one to do so knows nobody will read `finished` again and clears it for the next call.
+        if (level == CAELO_RANSAC_LEVELS - 1 && threadIdx.x == 0 && atomicAdd(&ws->exited, 1) == (int)gridDim.x - 1) {
+            ws->exited = 0;
+            __hip_atomic_store(&ws->finished, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
     const int N = n1p ? min(max(*n1p, 0), (int)k1_max) : (int)k1_max;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float thr = 0.4f * (float)(1 << level);  // 0.4, 0.8, 1.6 (:171,:210)
@@ -666,7 +679,10 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_level(const float *__r
         }
     }
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&ws->arrived[level], 1) == CAELO_RANSAC_MAX_TRIALS / RE_WAVES - 1;
+    if (tid == 0) {
+        s_last = atomicAdd(&ws->arrived[level], 1) == CAELO_RANSAC_MAX_TRIALS / RE_WAVES - 1;
+        if (s_last) ws->arrived[level] = 0;
+    }
     __syncthreads();
     if (!s_last) return;
     // ---- 3. accept rules
@@ -708,7 +724,8 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_level(const float *__r
         res->n_inliers = s_nin;
         res->best_trial = best >= 0 ? level * CAELO_RANSAC_MAX_TRIALS + best : -1;
         res->n_pairs = N;
-        __hip_atomic_store(&ws->finished, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (level < CAELO_RANSAC_LEVELS - 1)  // the last level has no later launch to stop
+            __hip_atomic_store(&ws->finished, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (s_nin > 0) fit_block(P0, l0, pidx, P1, l1, mask, N, res->R, res->T, nullptr);  // :277-282
@@ -721,7 +738,6 @@ CAELO_API int caelo_ransac(caelo_ctx *c, const float *pc0, int ld0, const float 
     CAELO_REQUIRE(k1_max > 0 && ld0 >= 3 && ld1 >= 3, "bad shape");
     hipStream_t s = caelo_stream(stream);
     RansacWs *ws = (RansacWs *)wsv;
-    CAELO_HIP(hipMemsetAsync(&ws->done, 0, sizeof(RansacWs) - offsetof(RansacWs, done), s));
     for (int level = 0; level < CAELO_RANSAC_LEVELS; ++level) {
         k_ransac_level<<<CAELO_RANSAC_MAX_TRIALS / RE_WAVES, 64 * RE_WAVES, 0, s>>>(pc0, ld0, pc1, ld1, pair_idx, k1_max, n1, rnd,
                                                                                     level, ws, result, inlier_mask);

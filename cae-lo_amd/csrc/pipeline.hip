@@ -234,6 +234,9 @@ CAELO_API int caelo_pipeline_create(caelo_ctx *c, int n_lanes, int64_t max_point
         hip_ok(hipMalloc(&l.ws_extract, (size_t)caelo_extract_ws_bytes()), "hipMalloc");
         hip_ok(hipMalloc(&l.ws_match, (size_t)caelo_match_ws_bytes(CAELO_MAX_KEYPTS)), "hipMalloc");
         hip_ok(hipMalloc(&l.ws_ransac, (size_t)caelo_ransac_ws_bytes()), "hipMalloc");
+        // match / ransac workspaces are self-cleaning: zero once, every call leaves them zeroed where it matters
+        if (rc == CAELO_OK) hip_ok(hipMemset(l.ws_match, 0, (size_t)caelo_match_ws_bytes(CAELO_MAX_KEYPTS)), "hipMemset");
+        if (rc == CAELO_OK) hip_ok(hipMemset(l.ws_ransac, 0, (size_t)caelo_ransac_ws_bytes()), "hipMemset");
         if (rc == CAELO_OK) rc = caelo_voxmap_create(c, max_points, &l.map);
     }
     if (rc != CAELO_OK) {
