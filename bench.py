@@ -86,12 +86,13 @@ def cpu_baseline(n_frames=3, max_seconds=40.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lanes", type=int, default=3,
+    ap.add_argument("--lanes", type=int, default=6,
                     help="HIP streams per rank; whole frames are issued round-robin so the latency-bound kernels of "
                          "one frame (keypoint select, voxel hash, RANSAC) overlap the MFMA-bound encoder of another")
+    ap.add_argument("--batch", type=int, default=0, help="frames per encoder launch set (0 = min(lanes, 3))")
     ap.add_argument("--gather", choices=("boundary", "all"), default="boundary",
                     help="rows moved by the single all-gather: each rank's last frame (all that consecutive-pair "
                          "matching needs) or every frame")
@@ -117,7 +118,7 @@ def main():
     rand = [torch.from_numpy(ransac_draws(1000 + rank * 7919 + i)).to(dev) for i in range(POOL)]
     n_points = int(np.mean([p.shape[0] for p in pool]))
 
-    pipe = eng.pipeline(max(1, args.lanes))
+    pipe = eng.pipeline(max(1, args.lanes), args.batch or None)
 
     def run(steps, prev):
         """`steps` frames through the native pipeline (frame i on lane i % lanes: extract, then match + RANSAC
@@ -205,7 +206,7 @@ def main():
             "config": {"workload": "configs[2]: KITTI-seq-00-shaped full odometry (extract + NN match + RANSAC pose) on "
                                    "synthetic 64-beam x 2000-azimuth scans",
                        "points_per_frame": n_points, "keypoints": 1024, "patches_per_frame": 3072,
-                       "frames_per_gpu": K, "hip_streams_per_gpu": pipe.lanes,
+                       "frames_per_gpu": K, "hip_streams_per_gpu": pipe.lanes + 1, "frames_per_encoder_launch": pipe.batch,
                        "host_issue_us_per_frame": round(host["issue_us_per_frame"], 1), "parallelism": "frames sharded x%d, one RCCL all-gather of %s [1024,64] f32 frame rows" % (
                            world, "the boundary" if args.gather == "boundary" else "all"),
                        "poses_solved": "%d/%d" % (ok, K), "status_bits": status},

@@ -126,11 +126,12 @@ class Pipeline:
     """caelo_pipeline (include/caelo.h): whole frames round-robin on `lanes` HIP streams, one native
     host thread per lane.  ``run`` submits K scans and returns without waiting for the GPU."""
 
-    def __init__(self, eng, lanes=3, max_points=None):
+    def __init__(self, eng, lanes=6, batch=None, max_points=None):
         self.eng = eng
+        batch = min(int(lanes), 3) if batch is None else int(batch)
         h = C.c_void_p()
-        _ffi.check(eng.lib.caelo_pipeline_create(eng.ctx, int(lanes), int(max_points or eng.max_points), C.byref(h)))
-        self.h, self.lanes = h, int(lanes)
+        _ffi.check(eng.lib.caelo_pipeline_create(eng.ctx, int(lanes), batch, int(max_points or eng.max_points), C.byref(h)))
+        self.h, self.lanes, self.batch = h, int(lanes), batch
 
     def __del__(self):
         try:
@@ -245,11 +246,12 @@ class Engine:
             t = self._wss[key] = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
         return t
 
-    def pipeline(self, lanes=3):
-        """The native frame executor (caelo_pipeline) with `lanes` streams, created once per lane count."""
-        key = ("pipeline", int(lanes))
+    def pipeline(self, lanes=6, batch=None):
+        """The native frame executor (caelo_pipeline) with `lanes` streams and `batch` frames per encoder launch
+        set, created once per configuration."""
+        key = ("pipeline", int(lanes), batch)
         if key not in self._maps:
-            self._maps[key] = Pipeline(self, lanes)
+            self._maps[key] = Pipeline(self, lanes, batch)
         return self._maps[key]
 
     def voxmap(self, max_points=None, slot=0):

@@ -118,6 +118,15 @@ int vox_build_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, bo
 int vox_build_fast_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, int32_t *status, hipStream_t s);
 int vox_patches_launch(const caelo_voxmap *m, const float *pts, int pts_ld, int64_t k_max, const int32_t *n_key,
                        uint64_t *bits, uint8_t *flags, int32_t *status, bool check_counts, hipStream_t s);
+// patches of up to CAELO_ENC_MAX_FRAMES frames encoded by one launch set (the fixed costs of the four encoder
+// kernels are ~47 us per launch set): frame f = patch / per_frame gets its descriptors in base[f]
+#define CAELO_ENC_MAX_FRAMES 8
+struct caelo_enc_out {
+    float *base[CAELO_ENC_MAX_FRAMES];
+    int64_t per_frame;
+};
+int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, const caelo_enc_out &outs,
+                      int out_stride, void *ws, hipStream_t s, hipEvent_t *ev);
 int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride, void *ws,
                 hipStream_t s, hipEvent_t *ev);
 
@@ -139,6 +148,7 @@ struct caelo_extract_args {
     uint8_t *flags;
     int32_t *status;
     void *ws;
+    uint64_t *bits;  // bit-packed patches [1024][3][64]; null = inside ws (the pipeline points it into a batch buffer)
 };
 int extract_check(const caelo_extract_args &a);
 int extract_front_launch(const caelo_extract_args &a, hipStream_t s);   // everything up to the bit-packed patches

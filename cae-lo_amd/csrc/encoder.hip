@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(D1_THREADS, 1) k_enc_dense1(const float *__res
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part, int64_t n_patches, int64_t n_rows_pad,
                                                   const float *__restrict__ bd1p, const float *__restrict__ wd2,
-                                                  const float *__restrict__ bd2, int group, float *__restrict__ out,
+                                                  const float *__restrict__ bd2, int group, caelo_enc_out outs,
                                                   int out_stride) {
     // One wave per patch, no LDS, no barrier.  Lane owns hidden columns j = lane + 64c: the 8 x 4 partial-sum
     // loads and the 4 x 20 Dense(20) weights of those columns are all in flight at once; the 20 outputs are
@@ -637,7 +637,9 @@ __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part
         for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
         mine = (lane == o) ? v : mine;
     }
-    if (lane < 20) out[(size_t)(p / group) * out_stride + (size_t)(p % group) * 20 + lane] = enc_tanh(bd2[lane] + mine);
+    // patches of several frames in one launch: frame f = p / per_frame writes into its own rows
+    const int64_t f = p / outs.per_frame, q = p - f * outs.per_frame;
+    if (lane < 20) outs.base[f][(size_t)(q / group) * out_stride + (size_t)(q % group) * 20 + lane] = enc_tanh(bd2[lane] + mine);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -652,7 +654,17 @@ CAELO_API int64_t caelo_encode_ws_bytes(int64_t n_patches) {
 
 int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
                        void *ws, hipStream_t s, hipEvent_t *ev /* 5 events or null */) {
-    CAELO_REQUIRE(c && bits && out && ws, "null argument");
+    CAELO_REQUIRE(out, "null argument");
+    caelo_enc_out outs;
+    outs.base[0] = out;
+    outs.per_frame = n_patches > 0 ? n_patches : 1;
+    return encode_batch_impl(c, bits, n_patches, group, outs, out_stride, ws, s, ev);
+}
+
+int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, const caelo_enc_out &outs,
+                      int out_stride, void *ws, hipStream_t s, hipEvent_t *ev /* 5 events or null */) {
+    CAELO_REQUIRE(c && bits && ws, "null argument");
+    CAELO_REQUIRE(outs.per_frame > 0 && (n_patches + outs.per_frame - 1) / outs.per_frame <= CAELO_ENC_MAX_FRAMES, "bad frame table");
     CAELO_REQUIRE(c->has_enc, "encoder weights not set (caelo_set_encoder_weights)");
     CAELO_REQUIRE(n_patches > 0 && group >= 1 && out_stride >= group * 20, "bad shape");
     const int64_t np = pad64(n_patches);
@@ -689,7 +701,7 @@ int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[3], s));
     k_enc_head<<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(part, n_patches, np, c->enc_bd1, c->enc_wd2, c->enc_bd2,
-                                                                group, out, out_stride);
+                                                                group, outs, out_stride);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[4], s));
     return CAELO_OK;

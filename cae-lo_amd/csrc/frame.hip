@@ -113,7 +113,7 @@ int extract_front_launch(const caelo_extract_args &a, hipStream_t s) {
     unsigned long long *cand = (unsigned long long *)(ws + L.cand);
     uint32_t *hist = (uint32_t *)(ws + L.hist);
     int32_t *cand_count = (int32_t *)(ws + L.cand_count);
-    uint64_t *bits = (uint64_t *)(ws + L.bits);
+    uint64_t *bits = a.bits ? a.bits : (uint64_t *)(ws + L.bits);
     // ---- one clear for everything the frame accumulates into
     caelo_clear_list cl;
     cl.n = 0;
@@ -141,8 +141,8 @@ int extract_front_launch(const caelo_extract_args &a, hipStream_t s) {
 int extract_encode_launch(const caelo_extract_args &a, hipStream_t s) {
     const ExtractLayout L = extract_layout();
     char *ws = (char *)a.ws;
-    return encode_impl(a.ctx, (const uint64_t *)(ws + L.bits), CAELO_MAX_KEYPTS * 3, 3, a.features, a.feat_ld, ws + L.enc, s,
-                       nullptr);
+    return encode_impl(a.ctx, a.bits ? a.bits : (const uint64_t *)(ws + L.bits), CAELO_MAX_KEYPTS * 3, 3, a.features,
+                       a.feat_ld, ws + L.enc, s, nullptr);
 }
 
 CAELO_API int caelo_extract(caelo_ctx *c, caelo_voxmap *m, const float *pc, int64_t n, int dist_channels, int mode,
@@ -150,7 +150,7 @@ CAELO_API int caelo_extract(caelo_ctx *c, caelo_voxmap *m, const float *pc, int6
                             int64_t *key_pixels, int32_t *n_key, uint8_t *flags, int32_t *status, void *wsv,
                             void *stream) {
     const caelo_extract_args a = {c, m, pc, n, dist_channels, mode, key_pts, kp_ld, features, feat_ld, valid, valid_ld,
-                                  key_pixels, n_key, flags, status, wsv};
+                                  key_pixels, n_key, flags, status, wsv, nullptr};
     int rc = extract_check(a);
     if (rc) return rc;
     hipStream_t s = caelo_stream(stream);

@@ -216,7 +216,7 @@ typedef struct caelo_frame_job {
     uint8_t *inlier_mask;       /* [1024] out */
     int64_t *pair_idx;          /* [1024] out */
 } caelo_frame_job;
-int caelo_pipeline_create(caelo_ctx *ctx, int n_lanes, int64_t max_points, caelo_pipeline **out);
+int caelo_pipeline_create(caelo_ctx *ctx, int n_lanes, int batch, int64_t max_points, caelo_pipeline **out);
 void caelo_pipeline_destroy(caelo_pipeline *pipe);
 int caelo_pipeline_lanes(const caelo_pipeline *pipe);
 int caelo_pipeline_begin(caelo_pipeline *pipe, void *stream);

@@ -339,13 +339,14 @@ def test_fast_voxelization_flags_a_face_point_and_checked_recovers(engine, orc, 
     assert np.abs(ff.features[: len(kp)].cpu().numpy() - of).max() <= REL_TOL * np.abs(of).max()
 
 
-@pytest.mark.parametrize("lanes", [1, 3])
+@pytest.mark.parametrize("lanes", [1, 3, 6])
 def test_pipeline_equals_single_stream_calls(engine, scans, lanes):
-    """caelo_pipeline (frames round-robin on `lanes` streams, native issue threads) reproduces the
-    one-call-per-stage results bit for bit, including the pair chained across lanes and ring reuse."""
+    """caelo_pipeline (fronts and pairs round-robin on `lanes` streams, encoders batched min(lanes, 3) frames per
+    launch set on their own stream, native issue threads) reproduces the one-call-per-stage results bit for bit,
+    including pairs chained across lanes / batches, a partial last batch and ring reuse."""
     import torch
     from caelo.engine import ransac_draws
-    n = 9
+    n = 10
     pcs = [torch.from_numpy(scans(i % 3)).to(engine.device) for i in range(n)]
     rnd = [torch.from_numpy(ransac_draws(50 + i)).to(engine.device) for i in range(n)]
     prev = engine.extract(pcs[2])
