@@ -179,20 +179,23 @@ int caelo_extract(caelo_ctx *ctx, caelo_voxmap *map, const float *pc, int64_t n,
                   int kp_ld, float *features, int feat_ld, float *valid, int valid_ld, int64_t *key_pixels,
                   int32_t *n_key, uint8_t *flags, int32_t *status, void *ws, void *stream);
 
-/* ---- frame pipeline: whole frames issued round-robin on n_lanes HIP streams, one host thread per lane ----------
+/* ---- frame pipeline: fronts and pairs of consecutive frames on n_lanes HIP streams, encoders batched -----------
  * Replaces the reference's per-frame driver loops (BatchPreprocess.py:88-140 extract loop, Match.py:296-353 /
- * PoseEstimation.py pair loop) for throughput: each lane owns a stream, a voxel map and the workspaces of
- * caelo_extract / caelo_match / caelo_ransac, so the latency-bound kernels of one frame overlap the MFMA-bound
- * encoder of another and kernel launches are issued from n_lanes threads.  Per-frame results are identical to the
- * single-call entry points (same kernels, same order within a frame).
+ * PoseEstimation.py pair loop) for throughput.  Each lane owns a stream, an issue thread, a voxel map and the
+ * workspaces of the front half of caelo_extract / caelo_match / caelo_ransac; the 3D-CAE encoder of `batch`
+ * consecutive frames runs as ONE launch set on a further stream (its fixed costs are ~47 us per launch set) and
+ * writes each frame's descriptors into that frame's rows.  Per-frame results are identical to the single-call
+ * entry points (same kernels, same per-patch arithmetic).
+ *   create(ctx, n_lanes in [1,16], batch in [1, min(8, n_lanes)], max_points)
  *   begin(stream)   lanes wait for work already queued on `stream` (the producers of the jobs' inputs)
- *   submit(job)     copy the job; frame k of the pipeline runs on lane k % n_lanes:
+ *   submit(job)     copy the job; frame k runs its front on lane k % n_lanes:
  *                     caelo_extract(pc -> rows [1024][64] = descriptor 0:60 | xyz 60:63 | valid 63, ...)
  *                     pair == CAELO_PAIR_CHAIN:    caelo_match + caelo_ransac against the previously submitted frame
  *                     pair == CAELO_PAIR_EXPLICIT: ... against prev_rows / prev_n_key (e.g. rows gathered from a peer)
- *   flush(stream)   block until every submitted job is enqueued, then make `stream` wait for all lanes
- * Buffers named by a job must stay alive until `stream` has passed the flush.  Errors of the worker threads are
- * returned by the next begin / flush (caelo_last_error() holds the text). */
+ *                   (pairs are issued n_lanes frames behind the fronts; flush issues the rest)
+ *   flush(stream)   close a partial batch, block until every submitted job is enqueued, make `stream` wait for all
+ * Buffers named by a job must stay alive until `stream` has passed the flush.  Errors of the worker threads stop
+ * further launches and are returned by the next begin / flush (caelo_last_error() holds the text). */
 typedef struct caelo_pipeline caelo_pipeline;
 #define CAELO_PAIR_NONE 0
 #define CAELO_PAIR_CHAIN 1
