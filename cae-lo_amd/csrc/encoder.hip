@@ -493,7 +493,9 @@ __global__ void __launch_bounds__(256) k_enc_conv3(const float *__restrict__ p2,
 // ------------------------------------------------------------------------------------------------
 // dense1: split-K GEMM  part[s][row][208] = F3[row][k0:k0+256] x Wd1p[k0:k0+256][208]
 // ------------------------------------------------------------------------------------------------
-#define D1_BM 96
+#ifndef D1_BM
+#define D1_BM 48  // 96 (one 8-wave workgroup per CU) measured 4 % slower than 48 (two per CU)
+#endif
 #define D1_BK 32
 #define D1_SPLIT 8
 #define D1_KCHUNK (DENSE_K / D1_SPLIT)
@@ -506,14 +508,14 @@ __global__ void __launch_bounds__(256) k_enc_conv3(const float *__restrict__ p2,
 #define D1_A4 (D1_BM * D1_BK / 4)              // float4 of an A stage
 #define D1_B4 (D1_BK * DENSE_NP / 4)           // float4 of a B stage
 
-// 96 rows x 208 columns x 256 k per workgroup: 32 x 8 = 256 workgroups of 8 waves, one per CU.  Against the
-// 32-row tile this replaces, every weight stage fetched from L2 is used by three times as many rows (L2 -> LDS
-// traffic 188 -> 80 MB per launch) and a stage carries 80 MFMAs per wave between barriers instead of 56.
-// The 78 output tiles are dealt round-robin to the 8 waves (10,10,10,10,10,10,9,9); a wave reads the A and
-// B fragment of each of its tiles straight from LDS (offsets are wave-uniform), accumulators are static.
-// Stages are double buffered in LDS: the next stage is fetched into registers during the MFMAs and stored to
-// the other buffer, one barrier per stage.
-__global__ void __launch_bounds__(D1_THREADS, 1) k_enc_dense1(const float *__restrict__ f3, int64_t n_rows_pad,
+// 48 rows x 208 columns x 256 k per workgroup of 8 waves: 64 x 8 = 512 workgroups, two per CU (66 KB of LDS and
+// 77 VGPRs each), so one workgroup's stage barrier is covered by the other's MFMAs and half the register file stays
+// free for the kernels of other streams.  Against the 32-row, 4-wave tile this replaces, a weight stage fetched
+// from L2 serves 1.5x the rows and a stage carries 40 MFMAs per wave between barriers with one barrier per stage.
+// The 39 output tiles are dealt round-robin to the 8 waves (5,5,5,5,5,5,5,4); a wave reads the A and B fragment of
+// each of its tiles straight from LDS (offsets are wave-uniform), accumulators are static.  Stages are double
+// buffered in LDS: the next stage is fetched into registers during the MFMAs and stored to the other buffer.
+__global__ void __launch_bounds__(D1_THREADS, D1_BM == 96 ? 1 : 2) k_enc_dense1(const float *__restrict__ f3, int64_t n_rows_pad,
                                                            const float *__restrict__ wd1p, float *__restrict__ part) {
     __shared__ __attribute__((aligned(16))) float As[2][D1_BM * D1_APITCH];
     __shared__ __attribute__((aligned(16))) float Bs[2][D1_BK * DENSE_NP];
@@ -524,20 +526,30 @@ __global__ void __launch_bounds__(D1_THREADS, 1) k_enc_dense1(const float *__res
     const int split = blockIdx.y;
     const int kbeg = split * D1_KCHUNK;
     // wave-uniform LDS offsets of this wave's tiles (named scalars: an indexed array would live in scratch)
-#define D1_TILE_T(I) (wave + 8 * (I) < D1_TILES ? wave + 8 * (I) : 0) /* waves 6, 7: slot 9 recomputes tile 0, never stored */
+#define D1_TILE_T(I) (wave + 8 * (I) < D1_TILES ? wave + 8 * (I) : 0) /* a slot past the last tile recomputes tile 0, never stored */
 #define D1_OFFS(I) const int ao##I = (D1_TILE_T(I) / D1_NT) * 16 * D1_APITCH, bo##I = (D1_TILE_T(I) % D1_NT) * 16;
-    D1_OFFS(0) D1_OFFS(1) D1_OFFS(2) D1_OFFS(3) D1_OFFS(4) D1_OFFS(5) D1_OFFS(6) D1_OFFS(7) D1_OFFS(8) D1_OFFS(9)
+    D1_OFFS(0) D1_OFFS(1) D1_OFFS(2) D1_OFFS(3) D1_OFFS(4)
+#if D1_WTILES > 5
+    D1_OFFS(5) D1_OFFS(6) D1_OFFS(7) D1_OFFS(8) D1_OFFS(9)
+#endif
     f32x4 acc[D1_WTILES];
 #pragma unroll
     for (int i = 0; i < D1_WTILES; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // a stage = 768 float4 of A + 1664 float4 of B = 4.75 per thread; slot u = tid + 512 r is an A element for
     // u < 768, else B element u - 768; which of the two (and whether slot 4 exists) is uniform per wave
-    float4 pre[5];
+#if D1_BM == 96
+#define D1_SLOTS 5
 #define D1_SLOT_OK(R) ((R) < 4 || wave < 6)
 #define D1_SLOT_IS_A(R) ((R) == 0 || ((R) == 1 && wave < 4))
+#else  // 48 rows: 384 + 1664 = 2048 float4 = 4 per thread, A elements in slot 0 of waves 0..5
+#define D1_SLOTS 4
+#define D1_SLOT_OK(R) true
+#define D1_SLOT_IS_A(R) ((R) == 0 && wave < 6)
+#endif
+    float4 pre[D1_SLOTS];
 #define D1_FETCH(K0)                                                                                              \
     {                                                                                                             \
-        _Pragma("unroll") for (int r = 0; r < 5; ++r) {                                                           \
+        _Pragma("unroll") for (int r = 0; r < D1_SLOTS; ++r) {                                                    \
             const int u = tid + r * D1_THREADS;                                                                   \
             if (!D1_SLOT_OK(r)) continue;                                                                         \
             if (D1_SLOT_IS_A(r)) pre[r] = *(const float4 *)(f3 + (size_t)(row0 + (u >> 3)) * DENSE_K + (K0) + (u & 7) * 4); \
@@ -546,7 +558,7 @@ __global__ void __launch_bounds__(D1_THREADS, 1) k_enc_dense1(const float *__res
     }
 #define D1_STORE(BUF)                                                                                             \
     {                                                                                                             \
-        _Pragma("unroll") for (int r = 0; r < 5; ++r) {                                                           \
+        _Pragma("unroll") for (int r = 0; r < D1_SLOTS; ++r) {                                                    \
             const int u = tid + r * D1_THREADS;                                                                   \
             if (!D1_SLOT_OK(r)) continue;                                                                         \
             if (D1_SLOT_IS_A(r)) {                                                                                \
@@ -569,7 +581,10 @@ __global__ void __launch_bounds__(D1_THREADS, 1) k_enc_dense1(const float *__res
 #pragma unroll
         for (int s = 0; s < D1_BK / 4; ++s) {
 #define D1_MAC(I) acc[I] = MFMA16(A[ao##I + 4 * s], B[bo##I + 4 * s * DENSE_NP], acc[I]);
-            D1_MAC(0) D1_MAC(1) D1_MAC(2) D1_MAC(3) D1_MAC(4) D1_MAC(5) D1_MAC(6) D1_MAC(7) D1_MAC(8) D1_MAC(9)
+            D1_MAC(0) D1_MAC(1) D1_MAC(2) D1_MAC(3) D1_MAC(4)
+#if D1_WTILES > 5
+            D1_MAC(5) D1_MAC(6) D1_MAC(7) D1_MAC(8) D1_MAC(9)
+#endif
         }
         if (more) D1_STORE(buf ^ 1)
         __syncthreads();
