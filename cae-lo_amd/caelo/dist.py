@@ -90,15 +90,16 @@ def local_pairs(n_frames, rank, world):
 
 
 def gather_poses(local_rt, n_frames, group=None):
-    """local_rt [P_local, 12] f32 rows (R row-major | T) of this rank's pairs -> [n_frames-1, 12]
-    on every rank (second collective, 48 B per pair)."""
+    """local_rt [P_local, w] f32 rows of this rank's pairs (w = 12: R row-major | T; more columns ride along) ->
+    [n_frames-1, w] on every rank (second collective, 48 B per pair)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return local_rt
     pmax = -(-n_frames // world)
-    send = local_rt.new_zeros((pmax, 12))
+    w = local_rt.shape[1]
+    send = local_rt.new_zeros((pmax, w))
     send[: local_rt.shape[0]] = local_rt
-    recv = local_rt.new_empty((world * pmax, 12))
+    recv = local_rt.new_empty((world * pmax, w))
     dist.all_gather_into_tensor(recv, send, group=group)
     parts = []
     for r in range(world):
@@ -107,24 +108,7 @@ def gather_poses(local_rt, n_frames, group=None):
 
 
 def chain_poses(rel_rt, Tr=None):
-    """PoseEstimation.py:230-267: prefix product of per-pair LiDAR motions into camera-frame KITTI
-    poses [F,12].  rel_rt [F-1,12] (R row-major | T); Tr [3,4] calibration (identity if None)."""
-    rel = np.asarray(rel_rt, dtype=np.float32).reshape(-1, 12)
-    # float32 end to end, like the reference (Tr, SolveRT's R/T and pose0 are all float32 there)
-    Tr = np.c_[np.eye(3), np.zeros(3)] if Tr is None else np.asarray(Tr)
-    Tr = np.array(Tr.reshape(3, 4), dtype=np.float32)                       # :203
-    R_Tr = Tr[:, 0:3]
-    R_Tr_inv = np.linalg.inv(R_Tr)                                          # :205
-    T_Tr = Tr[:, 3].reshape(3, 1)
-    T_Tr_inv = -np.dot(R_Tr_inv, T_Tr)                                      # :207
-    poses = [np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float32).reshape(12, 1)]  # :232
-    for row in rel:
-        relativeR, relativeT = row[:9].reshape(3, 3), row[9:].reshape(3, 1)
-        pose0 = poses[-1].reshape(3, 4)                                     # Transformations.py:164-168
-        R0, T0 = pose0[:, 0:3], pose0[:, 3].reshape(3, 1)
-        R_poseDiff = np.dot(R_Tr, np.dot(relativeR, R_Tr_inv))             # :259
-        T_poseDiff = np.dot(R_Tr, np.dot(relativeR, T_Tr_inv) + relativeT) + T_Tr  # :260
-        R = np.dot(R0, R_poseDiff)                                          # :261
-        T = np.dot(R0, T_poseDiff) + T0                                     # :262
-        poses.append(np.c_[R, T].reshape((12, 1)))                          # :265-267
-    return np.array(poses, dtype=np.float32).reshape(len(poses), 12)       # :273-274
+    """PoseEstimation.py:230-267 (see caelo.stageio.chain_poses): host-side prefix product over the gathered
+    per-pair (R, T) rows, float32 like the reference."""
+    from .stageio import chain_poses as _chain
+    return _chain(rel_rt, Tr)

@@ -1,0 +1,156 @@
+#!/usr/bin/env python
+"""run_sequence.py -- the counterpart of the reference's PoseEstimation.py loop on libcaelo (SURVEY.md 8c harness row,
+8f-1): consecutive scans -> per-pair relative pose (R, T, nInliers, thr) -> chained KITTI poses [F,12] -> poses file.
+
+    python run_sequence.py --synthetic 20 --out poses_/00.txt
+    python run_sequence.py --scans <seq>/velodyne --calib <calib>/00/calib_.txt --out poses_/00.txt --save-artifacts
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 run_sequence.py --synthetic 800 ...
+
+Frames are sharded contiguously over the ranks (one process per GPU); every rank runs its frames through the
+native pipeline, ONE all-gather moves the boundary frame rows, pose rows are gathered to rank 0, which chains
+them on the host (PoseEstimation.py:253-267) and writes `np.savetxt` rows like PoseEstimation.py:277.
+
+RANSAC draws: the reference uses NumPy's unseeded global generator (Match.py:182); here pair (i, i+1) consumes
+RandomState(seed_base + i).random_sample(...), so results do not depend on sharding or chunking.
+"""
+import argparse
+import glob
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from caelo import _ffi, stageio, synth  # noqa: E402
+from caelo import dist as cdist  # noqa: E402
+from caelo.engine import Engine, FrameBatch, FrameFeatures, ST_VOXEL_INEXACT, raise_status, ransac_draws  # noqa: E402
+
+
+def pose_rows(batch, k):
+    """FrameBatch.result -> numpy: rel_rt [k,12], success, threshold, n_inliers (one host copy)."""
+    raw = batch.result[:k].cpu().numpy()
+    out = np.zeros((k, 12), np.float32)
+    ok = np.zeros(k, bool); thr = np.zeros(k, np.float32); nin = np.zeros(k, np.int32)
+    for i in range(k):
+        r = _ffi.PoseResult.from_buffer_copy(raw[i].tobytes())
+        out[i, :9], out[i, 9:] = np.array(r.R, np.float32), np.array(r.T, np.float32)
+        ok[i], thr[i], nin[i] = bool(r.success), r.threshold, r.n_inliers
+    return out, ok, thr, nin
+
+
+def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, lanes, batch_frames, keep=None):
+    """Frames [lo, hi) of this rank.  Returns per-pair rows for pairs (i-1, i), i in (lo, hi) -- the pair (lo-1, lo)
+    is the caller's (it needs the previous rank's last frame) -- plus the first and last frame's features."""
+    pipe = eng.pipeline(lanes, batch_frames)
+    rel, ok, thr, nin = [], [], [], []
+    prev, first = None, None
+    for c0 in range(lo, hi, chunk):
+        c1 = min(hi, c0 + chunk)
+        scans = [torch.from_numpy(load(i)).to(eng.device) for i in range(c0, c1)]
+        draws = [torch.from_numpy(ransac_draws(seed_base + i - 1)).to(eng.device) for i in range(c0, c1)]
+        batch = pipe.run(scans, draws, prev=prev, dist_channels=dist_channels)
+        status = batch.status[:, 0].cpu().numpy()
+        for j in np.flatnonzero(status & ST_VOXEL_INEXACT):        # a point on a voxel face: redo with the exact kernels
+            ff = eng.extract(scans[j], dist_channels, rows=batch.rows[j], exact_voxels=True)
+            batch.n_key[j:j + 1].copy_(ff.n_key); batch.key_pixels[j].copy_(ff.key_pixels); batch.flags[j].copy_(ff.flags)
+            status[j] = int(ff.status[0].item())
+            for q in (j, j + 1):                                   # the two pairs that touch frame j
+                if q >= c1 - c0 or (q == 0 and prev is None):
+                    continue
+                a = prev if q == 0 else batch.frame(q - 1)
+                batch.result[q].copy_(eng.match_pose(a, batch.frame(q), draws[q])[0])
+        for st in status:
+            raise_status(int(st))
+        r, o, t, n = pose_rows(batch, c1 - c0)
+        s = 0 if prev is not None else 1                           # slot 0 of the first chunk has no predecessor here
+        rel.append(r[s:]); ok.append(o[s:]); thr.append(t[s:]); nin.append(n[s:])
+        if first is None:
+            first = batch.frame(0)
+        prev = batch.frame(c1 - c0 - 1)
+        if keep is not None:
+            keep(c0, batch)
+    cat = (lambda xs, d: np.concatenate(xs) if xs else np.zeros((0,) + d))
+    return cat(rel, (12,)), cat(ok, ()), cat(thr, ()), cat(nin, ()), first, prev
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--synthetic", type=int, default=0, help="number of synthetic 64x2000 scans (caelo.synth)")
+    ap.add_argument("--scans", help="directory of KITTI velodyne .bin files")
+    ap.add_argument("--calib", help="calib_.txt (PoseEstimation.py:199-203) or KITTI calib.txt; identity if omitted")
+    ap.add_argument("--out", default="poses_/00.txt")
+    ap.add_argument("--seed-base", type=int, default=1000)
+    ap.add_argument("--chunk", type=int, default=120, help="frames resident on the GPU at a time")
+    ap.add_argument("--dist-channels", type=int, default=5, choices=(3, 5), help="5 = demo mode, 3 = batch mode (SURVEY 8a-3')")
+    ap.add_argument("--lanes", type=int, default=6)
+    ap.add_argument("--batch", type=int, default=3)
+    ap.add_argument("--save-artifacts", action="store_true", help="write Features/*.mat and InliersIdx/*.mat next to the scans")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.scans:
+        files = sorted(glob.glob(os.path.join(args.scans, "*.bin")))
+        n, load = len(files), (lambda i: stageio.read_scan(files[i]))
+    else:
+        n, load = args.synthetic, synth.make_scan
+        files = [os.path.join(os.path.dirname(os.path.abspath(args.out)), "synthetic", "velodyne", "%06d.bin" % i) for i in range(n)]
+    assert n >= 2, "need at least two scans (--synthetic N or --scans DIR)"
+    Tr = stageio.read_calib_tr(args.calib) if args.calib else None
+
+    eng = Engine(device=local_rank)
+    lo, hi = cdist.shard_frames(n, rank, world)
+    t0 = time.time()
+
+    def keep(c0, batch):
+        if not args.save_artifacts:
+            return
+        rows = batch.rows.cpu().numpy(); nk = batch.n_key.cpu().numpy()
+        idx = batch.pair_idx.cpu().numpy(); mask = batch.inlier_mask.cpu().numpy().astype(bool)
+        for j in range(len(nk)):
+            k = int(nk[j])
+            stageio.save_features(files[c0 + j], rows[j, :k, 60:63], rows[j, :k, 0:60])
+            if c0 + j > lo:
+                m = mask[j, :k]
+                stageio.save_inliers(os.path.dirname(os.path.dirname(files[c0 + j])), c0 + j - 1, c0 + j, idx[j, :k][m], np.arange(k)[m])
+
+    rel, ok, thr, nin, first, last = run_local(eng, load, lo, hi, args.seed_base, args.chunk, args.dist_channels,
+                                               args.lanes, args.batch, keep)
+    if world > 1:   # the pair that straddles the rank boundary: ONE all-gather of the boundary rows
+        gathered = cdist.all_gather_boundary(last.rows)
+        if rank > 0:
+            prev = FrameFeatures.from_rows(gathered[rank - 1])
+            res = eng.match_pose(prev, first, torch.from_numpy(ransac_draws(args.seed_base + lo - 1)).to(eng.device))[0]
+            r = eng.pose_result(res)
+            row = np.r_[np.array(r.R, np.float32), np.array(r.T, np.float32)][None]
+            rel = np.concatenate([row, rel]); ok = np.r_[bool(r.success), ok]; thr = np.r_[np.float32(r.threshold), thr]
+            nin = np.r_[np.int32(r.n_inliers), nin]
+        extra = torch.from_numpy(np.c_[rel, ok, thr, nin].astype(np.float32)).to(eng.device)
+        allrows = cdist.gather_poses(extra, n).cpu().numpy()
+        rel, ok, thr, nin = allrows[:, :12], allrows[:, 12] > 0, allrows[:, 13], allrows[:, 14].astype(np.int32)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    if rank == 0:
+        poses = stageio.chain_poses(rel, Tr)
+        stageio.write_poses(args.out, poses)
+        for i in range(len(rel)):
+            print("%06d-%06d ok=%d thr=%.1f inliers=%4d T=[% .3f % .3f % .3f]" % (i, i + 1, ok[i], thr[i], nin[i], rel[i, 9], rel[i, 10], rel[i, 11]))
+        print("%d frames, %d pairs on %d GPU(s) in %.2f s (%.1f frames/s incl. scan loading) -> %s" % (n, len(rel), world, dt, n / dt, args.out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

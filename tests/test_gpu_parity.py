@@ -380,3 +380,25 @@ def test_pipeline_reports_worker_errors(engine, scans):
         small.run([pc, pc], [torch.from_numpy(ransac_draws(1)).to(engine.device)] * 2)
     with pytest.raises(_ffi.CaeloError):
         engine.pipeline(2).run([pc[:3]], [torch.from_numpy(ransac_draws(1)).to(engine.device)])   # n <= 3
+
+
+def test_run_sequence_vs_reference_sequence_golden(engine, scans):
+    """SURVEY 8c harness row: 20 consecutive synthetic frames through run_sequence.py's loop (native pipeline, three
+    chunks, RANSAC seeded per pair) against per-pair (R, T, nInliers, thr) and chained poses computed by the
+    reference's own functions / statements (tests/golden/sequence_20.npz)."""
+    import importlib.util
+    from conftest import REPO
+    from caelo import stageio
+    spec = importlib.util.spec_from_file_location("run_sequence", os.path.join(REPO, "cae-lo_amd", "run_sequence.py"))
+    rs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rs)
+    g = np.load(os.path.join(GOLDEN, "sequence_20.npz"))
+    n, base = int(g["n_frames"]), int(g["seed_base"])
+    rel, ok, thr, nin, first, last = rs.run_local(engine, scans, 0, n, base, chunk=8, dist_channels=5, lanes=3, batch_frames=2)
+    assert rel.shape == (n - 1, 12) and ok.all() and np.array_equal(thr, g["threshold"])
+    assert np.array_equal(nin, g["n_inliers"]), (nin, g["n_inliers"])
+    assert np.abs(rel[:, :9] - g["rel_rt"][:, :9]).max() <= REL_TOL                      # rotation entries (|.| <= 1)
+    assert np.abs(rel[:, 9:] - g["rel_rt"][:, 9:]).max() <= REL_TOL * np.abs(g["rel_rt"][:, 9:]).max()
+    for name in ("identity", "kitti"):
+        poses = stageio.chain_poses(rel, g["tr_" + name].reshape(3, 4))
+        assert np.abs(poses - g["poses_" + name]).max() <= 20 * REL_TOL * np.abs(g["poses_" + name]).max()

@@ -212,14 +212,96 @@ def trunc_golden():
     np.savez_compressed(os.path.join(GOLD, "patch_truncation.npz"), **g)
 
 
+def blocks_golden():
+    """Voxel.py:161-172 block structures (written to VoxelModel/*.mat, BatchVoxelization.py:61-62) of a small scan: pins
+    caelo.stageio.block_structures, which derives them from AllVoxels0 alone."""
+    pc = synth.make_scan(3, n_beams=16, n_az=600)
+    out = RefVoxel.Voxelization(pc[:, 0:3])
+    g = {"scan_params": np.array([3, 16, 600]), "avlBlocksList": out[3], "cntVoxelsLength": out[4], "AllVoxels": out[5],
+         "AllVoxels0": out[6], "AllVoxels1": out[7], "AllVoxels2": out[8]}
+    assert out[3].dtype == np.int16 and out[4].dtype == np.int32 and out[5].dtype == np.int16
+    np.savez_compressed(os.path.join(GOLD, "voxel_blocks.npz"), **g)
+    print("  blocks golden: %d blocks, %d voxels" % (len(out[3]), len(out[6])))
+
+
+def ref_source_block(path, first, last):
+    """Lines first..last (1-based, inclusive) of a reference script, dedented -- for the statements of
+    PoseEstimation.py's __main__ that are not inside a function and therefore cannot be imported."""
+    import textwrap
+    with open(path) as f:
+        lines = f.read().split("\n")[first - 1:last]
+    return textwrap.dedent("\n".join(lines))
+
+
+def sequence_golden(n_frames=20, seed_base=1000):
+    """SURVEY 8c harness row: per-pair (R, T, nInliers, thr) of consecutive synthetic frames through the reference's
+    own functions (PoseEstimation.py:152-167 = SolveRelativePose on the stored KeyPts / Features), RANSAC seeded
+    per pair with np.random.seed(seed_base + iFrame0), and the pose chaining statements of PoseEstimation.py
+    (:202-207 calibration, :232 first pose, :253-267 update) EXECUTED from the reference source, once with Tr = I and
+    once with a KITTI-like Tr.  The oracle is asserted against every pair."""
+    import Transformations as RefT
+    t0 = time.time()
+    frames = []
+    for f in range(n_frames):
+        pc = synth.make_scan(f)
+        ring, cnt = RefSR.ProjectPC2SphericalRing(pc)
+        resp = np.squeeze(resp_model.predict(ring[0:64, 0:1792, :][:, :, [0, 1, 2]].reshape(1, 64, 1792, 3)))
+        (kp, kpix, _), _ = quiet(RefSR.GetKeyPtsByAE, ring, cnt, resp)
+        vout = RefVoxel.Voxelization(pc[:, 0:3])
+        _, plist = RefVoxel.GetPatchesList(kp, vout[6], vout[7], vout[8])
+        feats = RefMatch.GetFeaturesFromPatches(enc_model, plist)
+        frames.append((kp, feats))
+        print("  seq frame %d: K=%d (%.0fs)" % (f, len(kp), time.time() - t0))
+    g = {"n_frames": n_frames, "seed_base": seed_base}
+    rel = np.zeros((n_frames - 1, 12), np.float32)
+    nin = np.zeros(n_frames - 1, np.int32); thr = np.zeros(n_frames - 1, np.float32); ok = np.zeros(n_frames - 1, bool)
+    for i in range(n_frames - 1):
+        (kp0, F0), (kp1, F1) = frames[i], frames[i + 1]
+        W0 = np.ones((len(kp0), 1), np.float32); W1 = np.ones((len(kp1), 1), np.float32)
+        np.random.seed(seed_base + i)
+        (R, T, isok, i0, i1, th), _ = quiet(RefMatch.SolveRelativePose, kp0, F0, W0, kp1, F1, W1)
+        oR, oT, ook, oi0, oi1, oth = orc.SolveRelativePose(kp0, F0, W0, kp1, F1, W1, rng=np.random.RandomState(seed_base + i))
+        assert ook == isok and oth == th and np.array_equal(oi0, i0) and np.allclose(oR, R, atol=1e-6) and np.allclose(oT, T, atol=1e-5)
+        assert R.dtype == np.float32 and np.asarray(T).dtype == np.float32
+        rel[i, :9] = np.asarray(R).ravel(); rel[i, 9:] = np.asarray(T).ravel()
+        nin[i], thr[i], ok[i] = len(i0), th, isok
+        print("  seq pair %d-%d: ok=%s thr=%.1f inliers=%d T=%s" % (i, i + 1, isok, th, len(i0), np.round(np.asarray(T).ravel(), 3)))
+    g.update(rel_rt=rel, n_inliers=nin, threshold=thr, success=ok, n_key=np.array([len(k) for k, _ in frames], np.int32))
+    calib_block = ref_source_block(os.path.join(REF, "PoseEstimation.py"), 203, 207)   # Tr -> R_Tr, R_Tr_inv, T_Tr, T_Tr_inv
+    chain_block = ref_source_block(os.path.join(REF, "PoseEstimation.py"), 253, 267)   # pose0 -> pose1
+    kitti_tr = np.array([4.276802385584e-04, -9.999672484946e-01, -8.084491683471e-03, -1.198459927713e-02,
+                         -7.210626507497e-03, 8.081198471645e-03, -9.999413164504e-01, -5.403984729748e-02,
+                         9.999738645903e-01, 4.859485810390e-04, -7.206933692422e-03, -2.921968648686e-01])
+    for name, tr in (("identity", np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64)), ("kitti", kitti_tr)):
+        ns = {"np": np, "GetRtFromOnePose": RefT.GetRtFromOnePose, "calib": np.tile(tr, (5, 1))}
+        exec(calib_block, ns)
+        ns["poses"] = [np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float32).reshape(12, 1)]   # :231-233
+        for i in range(n_frames - 1):
+            ns.update(iFrame0=i, relativeR=rel[i, :9].reshape(3, 3), relativeT=rel[i, 9:].reshape(3, 1))
+            exec(chain_block, ns)
+        poses = np.array(ns["poses"], dtype=np.float32)
+        g["poses_" + name] = poses.reshape(poses.shape[0], 12)                                             # :273-274
+        g["tr_" + name] = tr
+        print("  seq poses (%s): last T = %s" % (name, np.round(g["poses_" + name][-1].reshape(3, 4)[:, 3], 3)))
+    np.savez_compressed(os.path.join(GOLD, "sequence_20.npz"), **g)
+
+
 if __name__ == "__main__":
     t0 = time.time()
+    if "--sequence-only" in sys.argv:
+        sequence_golden()
+        sys.exit(0)
+    if "--blocks-only" in sys.argv:
+        blocks_golden()
+        sys.exit(0)
     trunc_golden()
     f0 = frame_golden(0)
     f1 = frame_golden(1)
     pair_golden(f0, f1)
     # dense 128-beam scan: exercises the 496-NN truncation of GetPatchesList (SURVEY 8a-5)
     frame_golden(0, n_beams=128, n_az=4000, n_patch_kp=192, tag="dense128")
+    sequence_golden()
+    blocks_golden()
     print("done in %.1fs" % (time.time() - t0))
     for f in sorted(os.listdir(GOLD)):
         print("  %-24s %8.1f KB" % (f, os.path.getsize(os.path.join(GOLD, f)) / 1024))
