@@ -65,6 +65,8 @@ SIGNATURES = [
     ("caelo_extract_ws_bytes", c_i64, []),
     ("caelo_extract", c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp,
                               c_vp, c_vp]),
+    ("caelo_extend_ws_bytes", c_i64, [c_int, c_int]),
+    ("caelo_extend_keypts", c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("caelo_pipeline_create", c_int, [c_vp, c_int, c_int, c_i64, C.POINTER(c_vp)]),
     ("caelo_pipeline_destroy", None, [c_vp]),
     ("caelo_pipeline_lanes", c_int, [c_vp]),

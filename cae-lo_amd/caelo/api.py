@@ -98,6 +98,25 @@ def GetKeyPtsByAE(SphericalRing, GridCounter, RespondImg):
     return _out(kpts[:k], as_np), _out(kpix[:k], as_np), planar
 
 
+def ExtendKeyPtsInShpericalRing(SphericalRing, GridCounter, KeyPixels):
+    """SphericalRing.py:294-317.  Returns ExtendedKeyPts [M,3] f32 and, like the reference, zeroes the 13 x 13
+    windows of the caller's GridCounter in place (NumPy array or tensor).  Keypixels must come from GetKeyPtsByAE
+    (rows [8,56), cols [8,1784)): windows that leave the image are clipped, not wrapped like NumPy's negative slices."""
+    e = default_engine()
+    as_np = _is_np(SphericalRing)
+    ring = _dev(SphericalRing, torch.float32)
+    cnt = _dev(GridCounter, torch.int32)
+    kpix = _dev(KeyPixels, torch.int64)
+    if kpix.shape[0] == 0:
+        return _out(torch.empty((0, 3), dtype=torch.float32, device=e.device), as_np)
+    ext, n_ext = e.extend_keypts(ring, cnt, kpix)
+    if _is_np(GridCounter):
+        GridCounter[...] = cnt.cpu().numpy().astype(GridCounter.dtype)      # the in-place side effect (:307)
+    elif cnt.data_ptr() != GridCounter.data_ptr():
+        GridCounter.copy_(cnt.to(GridCounter.dtype))
+    return _out(ext[: int(n_ext.item())], as_np)
+
+
 def GetKeyPtsFromRawFileName(rawFileFullPath, RespondLayer):
     """SphericalRing.py:389-416: reads <seq>/SphericalRing/<name>.mat written by BatchPreprocess."""
     from scipy import io

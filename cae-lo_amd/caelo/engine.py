@@ -295,6 +295,21 @@ class Engine:
                                             _ptr(nkey), _ptr(status), self.stream))
         return kpts, kpix, nkey, status
 
+    def extend_keypts(self, ring, counter, key_pixels, n_key=None):
+        """ExtendKeyPtsInShpericalRing on device tensors: ring [H,W,C] f32, counter [Hc,Wc] i32 (MUTATED: the windows
+        are zeroed like SphericalRing.py:307), key_pixels [K,2] i64 -> (ext_pts [K*169,3] f32, n_ext [1] i32)."""
+        assert ring.dtype == torch.float32 and counter.dtype == torch.int32 and key_pixels.dtype == torch.int64
+        assert ring.is_contiguous() and counter.is_contiguous() and key_pixels.is_contiguous()
+        rows, cols = min(ring.shape[0], counter.shape[0]), min(ring.shape[1], counter.shape[1])
+        k = key_pixels.shape[0]
+        ext = self.empty((k * 169, 3), torch.float32)
+        n_ext = self.empty((1,), torch.int32)
+        ws = self._ws("extend", int(self.lib.caelo_extend_ws_bytes(rows, cols)))
+        _ffi.check(self.lib.caelo_extend_keypts(self.ctx, _ptr(ring), ring.shape[1], ring.shape[2], _ptr(counter), counter.shape[1],
+                                                rows, cols, _ptr(key_pixels), k, _ptr(n_key), _ptr(ext), _ptr(n_ext), _ptr(ws),
+                                                self.stream))
+        return ext, n_ext
+
     def voxelize(self, pc, vmap=None, status=None):
         assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] >= 3 and pc.is_contiguous()
         vmap = vmap or self.voxmap(max(self.max_points, pc.shape[0]))

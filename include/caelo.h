@@ -179,6 +179,17 @@ int caelo_extract(caelo_ctx *ctx, caelo_voxmap *map, const float *pc, int64_t n,
                   int kp_ld, float *features, int feat_ld, float *valid, int valid_ld, int64_t *key_pixels,
                   int32_t *n_key, uint8_t *flags, int32_t *status, void *ws, void *stream);
 
+/* ExtendKeyPtsInShpericalRing  (SphericalRing.py:294-317; BatchPreprocess.py:139): the occupied ring pixels of the
+ * 13 x 13 window of every keypixel, keypixels in order, each window row-major, a pixel only for the FIRST keypixel
+ * whose window covers it.  Like the reference it ZEROES those windows in the caller's counter.
+ * ring [>=rows][ring_w][ring_c] f32, counter [>=rows][cnt_w] i32 (in/out); rows x cols = the extent both cover
+ * (69 x 1800 in demo mode, 64 x 1792 in batch mode); key_pixels [k_max][2] i64 (row, col), n_key optional device count.
+ * ext_pts [k_max * 169][3] f32 out, n_ext [1] i32 out.  ws: caelo_extend_ws_bytes(rows, cols) bytes. */
+int64_t caelo_extend_ws_bytes(int rows, int cols);
+int caelo_extend_keypts(caelo_ctx *ctx, const float *ring, int ring_w, int ring_c, int32_t *counter, int cnt_w, int rows,
+                        int cols, const int64_t *key_pixels, int k_max, const int32_t *n_key, float *ext_pts,
+                        int32_t *n_ext, void *ws, void *stream);
+
 /* ---- frame pipeline: fronts and pairs of consecutive frames on n_lanes HIP streams, encoders batched -----------
  * Replaces the reference's per-frame driver loops (BatchPreprocess.py:88-140 extract loop, Match.py:296-353 /
  * PoseEstimation.py pair loop) for throughput.  Each lane owns a stream, an issue thread, a voxel map and the

@@ -110,6 +110,19 @@ def GetKeyPtsByAE(SphericalRing, GridCounter, RespondImg, return_score=False):
     return out + (score,) if return_score else out
 
 
+def ExtendKeyPtsInShpericalRing(SphericalRing, GridCounter, KeyPixels):
+    """SphericalRing.py:294-317, statement by statement (NumPy; K <= 1024 windows).  MUTATES GridCounter like the
+    reference (:307)."""
+    r = 6                                                                # nNeighborRadius (:295)
+    out = [np.zeros((0, 3), np.float32)]
+    for iX, iY in np.asarray(KeyPixels).reshape(-1, 2):                  # :300-302
+        mask = GridCounter[iX - r:iX + r + 1, iY - r:iY + r + 1]         # :304 (a view)
+        nb = SphericalRing[iX - r:iX + r + 1, iY - r:iY + r + 1, 0:3]    # :305
+        out.append(np.asarray(nb[mask > 0], np.float32))                 # :306, row-major over the window
+        mask[:] = 0                                                      # :307
+    return np.concatenate(out, axis=0)                                   # :314-316
+
+
 def Voxelization(PC):
     """Voxel.py:100-173.  Returns the reference's 9-tuple; only AllVoxels0/1/2 (the members the
     hot path consumes) are populated, the block structures are None."""

@@ -402,3 +402,33 @@ def test_run_sequence_vs_reference_sequence_golden(engine, scans):
     for name in ("identity", "kitti"):
         poses = stageio.chain_poses(rel, g["tr_" + name].reshape(3, 4))
         assert np.abs(poses - g["poses_" + name]).max() <= 20 * REL_TOL * np.abs(g["poses_" + name]).max()
+
+
+def test_extend_keypts_bit_exact_both_modes(api, orc, scans):
+    """ExtendKeyPtsInShpericalRing == reference golden (points, order, and the zeroed windows of the
+    caller's GridCounter), NumPy in / NumPy out, plus clipping at the image border instead of NumPy's wrap."""
+    g = np.load(os.path.join(GOLDEN, "extend_0.npz"))
+    ring, cnt = orc.ProjectPC2SphericalRing(scans(0))
+    for mode in ("demo", "batch"):
+        if mode == "demo":
+            r, c = ring.copy(), cnt.copy()
+        else:
+            r, c = np.ascontiguousarray(ring[0:64, 0:1792, 0:3]), np.array(cnt, dtype=np.int8)
+        kpix = g[mode + "_keypixels"].astype(np.int64)
+        ext = api.ExtendKeyPtsInShpericalRing(r, c, kpix)
+        assert ext.dtype == np.float32 and ext.shape == (int(g[mode + "_n_ext"]), 3)
+        assert sha(ext) == str(g[mode + "_ext_sha256"])
+        assert c.dtype == (np.int32 if mode == "demo" else np.int8)
+        assert sha(np.ascontiguousarray(c, np.int32)) == str(g[mode + "_counter_after_sha256"])
+        assert int((c > 0).sum()) == int(g[mode + "_counter_after_nnz"])
+    # few keypixels, overlapping windows, one at the border (clipped)
+    c = cnt.copy()
+    kpix = np.array([[30, 900], [30, 903], [31, 905], [3, 2]], np.int64)
+    ext = api.ExtendKeyPtsInShpericalRing(ring, c, kpix)
+    c2 = cnt.copy()
+    want = orc.ExtendKeyPtsInShpericalRing(ring, c2, kpix[:3])
+    assert np.array_equal(ext[: len(want)], want)
+    rows, cols = np.meshgrid(np.arange(0, 10), np.arange(0, 9), indexing="ij")
+    tail = ring[rows, cols, 0:3][cnt[rows, cols] > 0]
+    assert np.array_equal(ext[len(want):], tail) and not c[0:10, 0:9].any()
+    assert api.ExtendKeyPtsInShpericalRing(ring, cnt.copy(), np.zeros((0, 2), np.int64)).shape == (0, 3)

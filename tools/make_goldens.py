@@ -212,6 +212,32 @@ def trunc_golden():
     np.savez_compressed(os.path.join(GOLD, "patch_truncation.npz"), **g)
 
 
+def extend_golden():
+    """ExtendKeyPtsInShpericalRing (SphericalRing.py:294-317) in both calling modes on frame 0: the reference's output
+    and its in-place edit of GridCounter; the oracle restatement is asserted equal."""
+    pc = synth.make_scan(0)
+    ring, cnt = RefSR.ProjectPC2SphericalRing(pc)
+    resp = np.squeeze(resp_model.predict(ring[0:64, 0:1792, :][:, :, [0, 1, 2]].reshape(1, 64, 1792, 3)))
+    g = {}
+    for mode in ("demo", "batch"):
+        if mode == "demo":
+            r, c = ring.copy(), cnt.copy()
+        else:   # BatchPreprocess.py:97-98,131-139: cropped 3-channel ring, int8 counter of the full image
+            r, c = np.ascontiguousarray(ring[0:64, 0:1792, :][:, :, [0, 1, 2]]), np.array(cnt, dtype=np.int8)
+        (kp, kpix, _), _ = quiet(RefSR.GetKeyPtsByAE, r, c[0:64, 0:1792] if mode == "batch" else c, resp)
+        c_ref, c_orc = c.copy(), c.copy()
+        ext = RefSR.ExtendKeyPtsInShpericalRing(r, c_ref, kpix)
+        o_ext = orc.ExtendKeyPtsInShpericalRing(r, c_orc, kpix)
+        assert np.array_equal(ext, o_ext) and np.array_equal(c_ref, c_orc), "oracle ExtendKeyPts != reference"
+        g[mode + "_keypixels"] = kpix.astype(np.int16)
+        g[mode + "_n_ext"] = len(ext); g[mode + "_ext_sha256"] = sha(np.asarray(ext, np.float32))
+        g[mode + "_ext_head"] = np.asarray(ext[:64], np.float32); g[mode + "_ext_tail"] = np.asarray(ext[-64:], np.float32)
+        g[mode + "_counter_after_sha256"] = sha(np.asarray(c_ref, np.int32)); g[mode + "_counter_after_nnz"] = int((c_ref > 0).sum())
+        print("  extend golden (%s): %d points from %d keypixels, counter nnz %d -> %d" % (
+            mode, len(ext), len(kpix), int((c > 0).sum()), int((c_ref > 0).sum())))
+    np.savez_compressed(os.path.join(GOLD, "extend_0.npz"), **g)
+
+
 def blocks_golden():
     """Voxel.py:161-172 block structures (written to VoxelModel/*.mat, BatchVoxelization.py:61-62) of a small scan: pins
     caelo.stageio.block_structures, which derives them from AllVoxels0 alone."""
@@ -294,6 +320,9 @@ if __name__ == "__main__":
     if "--blocks-only" in sys.argv:
         blocks_golden()
         sys.exit(0)
+    if "--extend-only" in sys.argv:
+        extend_golden()
+        sys.exit(0)
     trunc_golden()
     f0 = frame_golden(0)
     f1 = frame_golden(1)
@@ -302,6 +331,7 @@ if __name__ == "__main__":
     frame_golden(0, n_beams=128, n_az=4000, n_patch_kp=192, tag="dense128")
     sequence_golden()
     blocks_golden()
+    extend_golden()
     print("done in %.1fs" % (time.time() - t0))
     for f in sorted(os.listdir(GOLD)):
         print("  %-24s %8.1f KB" % (f, os.path.getsize(os.path.join(GOLD, f)) / 1024))
