@@ -140,6 +140,11 @@ def main():
         return batch.frame(steps - 1), batch
 
     prev = eng.extract(pool[POOL - 1])
+    # one-time initialisation, not a warm-up step: every lane's stream / hardware queue / issue thread and the encoder
+    # stream are touched once (a HIP stream allocates its queue on first use, ~ms), so that a run with a small
+    # --warmup does not time queue creation
+    prev, _ = run(2 * pipe.lanes, prev)
+    torch.cuda.synchronize()
     prev, _ = run(W, prev) if W > 0 else (prev, None)
     torch.cuda.synchronize()
     if world > 1:
