@@ -605,45 +605,39 @@ __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part
                                                   const float *__restrict__ bd1p, const float *__restrict__ wd2,
                                                   const float *__restrict__ bd2, int group, caelo_enc_out outs,
                                                   int out_stride) {
-    // One wave per patch, no LDS, no barrier.  Lane owns hidden columns j = lane + 64c: the 8 x 4 partial-sum
-    // loads and the 4 x 20 Dense(20) weights of those columns are all in flight at once; the 20 outputs are
-    // 64-lane butterfly sums of per-lane partial dot products.
+    // One wave per patch, no LDS, no barrier.  Lane l < 50 owns the four hidden columns 4l .. 4l+3: one 16-byte load
+    // per split-K partial (8 in flight, 800 contiguous bytes per row) and the 4 x 20 Dense(20) weights of those
+    // columns; the 20 outputs are 64-lane butterfly sums of per-lane partial dot products.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t p = (int64_t)blockIdx.x * 4 + wave;
     if (p >= n_patches) return;
-    float s[4];
+    const bool ok = lane < DENSE_N / 4;
+    float4 s = ok ? *(const float4 *)(bd1p + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 w[4][5];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int j = lane + 64 * c;
-        const bool ok = j < DENSE_N;
-        s[c] = ok ? bd1p[j] : 0.0f;
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int q = 0; q < 5; ++q) w[c][q] = ok ? ((const float4 *)(wd2 + j * 20))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 5; ++q) w[c][q] = ok ? ((const float4 *)(wd2 + (4 * lane + c) * 20))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+        float4 v[D1_SPLIT];
+#pragma unroll
+        for (int sp = 0; sp < D1_SPLIT; ++sp) v[sp] = *(const float4 *)(part + ((size_t)sp * n_rows_pad + p) * DENSE_NP + 4 * lane);
+#pragma unroll
+        for (int sp = 0; sp < D1_SPLIT; ++sp) { s.x += v[sp].x; s.y += v[sp].y; s.z += v[sp].z; s.w += v[sp].w; }
     }
-#pragma unroll
-    for (int sp = 0; sp < D1_SPLIT; ++sp) {
-        const float *row = part + ((size_t)sp * n_rows_pad + p) * DENSE_NP;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int j = lane + 64 * c;
-            if (j < DENSE_N) s[c] += row[j];
-        }
-    }
+    const float hv[4] = {ok ? enc_tanh(s.x) : 0.f, ok ? enc_tanh(s.y) : 0.f, ok ? enc_tanh(s.z) : 0.f, ok ? enc_tanh(s.w) : 0.f};
     float acc[20];
 #pragma unroll
     for (int o = 0; o < 20; ++o) acc[o] = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float hv = (lane + 64 * c < DENSE_N) ? enc_tanh(s[c]) : 0.0f;
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            acc[4 * q + 0] += hv * w[c][q].x;
-            acc[4 * q + 1] += hv * w[c][q].y;
-            acc[4 * q + 2] += hv * w[c][q].z;
-            acc[4 * q + 3] += hv * w[c][q].w;
+            acc[4 * q + 0] += hv[c] * w[c][q].x;
+            acc[4 * q + 1] += hv[c] * w[c][q].y;
+            acc[4 * q + 2] += hv[c] * w[c][q].z;
+            acc[4 * q + 3] += hv[c] * w[c][q].w;
         }
-    }
     float mine = 0.0f;
 #pragma unroll
     for (int o = 0; o < 20; ++o) {
