@@ -432,3 +432,25 @@ def test_extend_keypts_bit_exact_both_modes(api, orc, scans):
     tail = ring[rows, cols, 0:3][cnt[rows, cols] > 0]
     assert np.array_equal(ext[len(want):], tail) and not c[0:10, 0:9].any()
     assert api.ExtendKeyPtsInShpericalRing(ring, cnt.copy(), np.zeros((0, 2), np.int64)).shape == (0, 3)
+
+
+@pytest.mark.parametrize("lanes,batch", [(6, 3), (5, 2), (8, 8)])
+def test_pipeline_long_run_wraps_the_slot_ring(engine, scans, lanes, batch):
+    """280 frames (> the 256-slot job ring, batch sizes that do not divide the lane count, a partial last batch):
+    every frame and every pair equals the single-call results."""
+    import torch
+    from caelo.engine import Pipeline, ransac_draws
+    pcs = [torch.from_numpy(scans(i)).to(engine.device) for i in range(4)]
+    rnd = [torch.from_numpy(ransac_draws(70 + i)).to(engine.device) for i in range(4)]
+    ref = [engine.extract(pc) for pc in pcs]
+    refp = {(a, b): engine.match_pose(ref[a], ref[b], rnd[b]) for a in range(4) for b in range(4)}
+    n = 280
+    pipe = Pipeline(engine, lanes, batch)
+    out = pipe.run([pcs[i % 4] for i in range(n)], [rnd[i % 4] for i in range(n)], prev=ref[3])
+    torch.cuda.synchronize()
+    for i in range(n):
+        assert torch.equal(out.rows[i], ref[i % 4].rows), i
+        res, mask, idx = refp[((i - 1) % 4, i % 4)]
+        assert torch.equal(out.result[i], res) and torch.equal(out.pair_idx[i], idx) and torch.equal(out.inlier_mask[i], mask), i
+    st = pipe.stats()
+    assert st["jobs"] == n and st["lanes"] == lanes
