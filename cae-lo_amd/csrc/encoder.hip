@@ -127,6 +127,7 @@ struct Stage1Lds {
     unsigned short list_cell[512];      // the cells with a non-zero mask, in arrival order
     unsigned int nzrow[12];  // per padded xp: bit yp set when some cell (xp, yp, *) is non-background
     int list_n;
+    int next_j;
 #ifdef CAELO_ENC_PROF
     unsigned int prof[8];
 #endif
@@ -156,7 +157,7 @@ struct Stage1Lds {
     if ((NZ2) & 0xCu) { CONV2_ROW(ACC_A, ACC_B, APTR, 2, 2) }
 
 __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long *__restrict__ bits, int64_t n_patches,
-                                                    int group,
+                                                    int group, int *__restrict__ work_counter,
                                                     const float *__restrict__ w1g, const float *__restrict__ b1g,
                                                     const float *__restrict__ w2g, const float *__restrict__ c0g,
                                                     float *__restrict__ p2out) {
@@ -219,6 +220,10 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long 
     while (j < (int)n_patches) {
         const int64_t patch = S1_PATCH_OF(j);
         ENC_STAMP(0);
+        // work items beyond the first come from a global counter (patch costs vary 10x: a static split leaves the
+        // average workgroup idle for the last ~55 us of the launch); fetched after the mask scatter, published
+        // through LDS at the barrier that ends conv1, i.e. microseconds later
+
         // ---- B1a: scatter every set voxel into the receptive-field masks of the (up to 8) pooled cells that
         // see it (fire-and-forget LDS ORs).  Work ~ set voxels, not ~ cells.
         if (row != 0u) {
@@ -242,6 +247,10 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long 
                 }
             }
         }
+        // issued here, after this patch's prefetched rows were consumed (vmcnt counts in order: an earlier wait for them
+        // would also wait for the atomic); nothing else touches vector memory until the value is published
+        int j_fetch;  // defined in thread 0 only, and only read there (no merge copy that would wait for the atomic)
+        if (tid == 0) j_fetch = atomicAdd(work_counter, 1);
         caelo_lds_barrier();
         ENC_STAMP(1);
         // ---- B1b: queue the cells with a non-empty mask (one LDS counter bump per wave)
@@ -309,9 +318,10 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long 
                 L.p1[(sub >> 2) * P1_PLANE + (P1_FRONT + q) * 4 + (sub & 3)] = enc_tanh(mine) - L.bg[sub];
             }
         }
+        if (tid == 0) L.next_j = (int)gridDim.x + j_fetch;
         caelo_lds_barrier();
         ENC_STAMP(3);
-        const int jn = j + (int)gridDim.x;
+        const int jn = L.next_j;
         unsigned int row_next = 0u;
         if (jn < (int)n_patches) row_next = ((const unsigned short *)bits)[S1_PATCH_OF(jn) * 256 + tid];
         // ---- conv2 (8->16) on MFMA: per row pair yi this wave owns the x pair xp = (wave - 2 yi) mod 4
@@ -658,7 +668,7 @@ static inline int64_t pad64(int64_t n) { return (n + D1_BM - 1) / D1_BM * D1_BM;
 
 CAELO_API int64_t caelo_encode_ws_bytes(int64_t n_patches) {
     const int64_t np = pad64(n_patches);
-    return (np * 1024 + np * 2048 + (int64_t)D1_SPLIT * np * DENSE_NP) * (int64_t)sizeof(float);
+    return 256 + (np * 1024 + np * 2048 + (int64_t)D1_SPLIT * np * DENSE_NP) * (int64_t)sizeof(float);
 }
 
 int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
@@ -677,7 +687,10 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     CAELO_REQUIRE(c->has_enc, "encoder weights not set (caelo_set_encoder_weights)");
     CAELO_REQUIRE(n_patches > 0 && group >= 1 && out_stride >= group * 20, "bad shape");
     const int64_t np = pad64(n_patches);
-    float *p2 = (float *)ws;
+    // ws = [256 bytes: stage-1 work counter] | P2 | F3 | dense-1 partial sums
+    int *work_counter = (int *)ws;
+    CAELO_HIP(hipMemsetAsync(work_counter, 0, 256, s));
+    float *p2 = (float *)((char *)ws + 256);
     float *f3 = p2 + np * 1024;
     float *part = f3 + np * 2048;
     if (np > n_patches)  // rows of the last 64-row tile that no patch writes
@@ -695,7 +708,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     const unsigned g1 = (unsigned)(n_patches < slots1 ? n_patches : slots1);
     if (ev) CAELO_HIP(hipEventRecord(ev[0], s));
     const int order_group = (n_patches % group == 0) ? group : 1;
-    k_enc_stage1<<<g1, 256, 0, s>>>((const unsigned long long *)bits, n_patches, order_group, c->enc_w1, c->enc_b1, c->enc_w2,
+    k_enc_stage1<<<g1, 256, 0, s>>>((const unsigned long long *)bits, n_patches, order_group, work_counter, c->enc_w1, c->enc_b1, c->enc_w2,
                                     c->enc_c0, p2);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[1], s));
