@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=6,
                     help="HIP streams per rank; whole frames are issued round-robin so the latency-bound kernels of "
                          "one frame (keypoint select, voxel hash, RANSAC) overlap the MFMA-bound encoder of another")
-    ap.add_argument("--batch", type=int, default=0, help="frames per encoder launch set (0 = min(lanes, 3))")
+    ap.add_argument("--batch", type=int, default=0, help="frames per encoder launch set (0 = min(lanes, 2))")
     ap.add_argument("--gather", choices=("boundary", "all"), default="boundary",
                     help="rows moved by the single all-gather: each rank's last frame (all that consecutive-pair "
                          "matching needs) or every frame")

@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=120, help="frames resident on the GPU at a time")
     ap.add_argument("--dist-channels", type=int, default=5, choices=(3, 5), help="5 = demo mode, 3 = batch mode (SURVEY 8a-3')")
     ap.add_argument("--lanes", type=int, default=6)
-    ap.add_argument("--batch", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--save-artifacts", action="store_true", help="write Features/*.mat and InliersIdx/*.mat next to the scans")
     args = ap.parse_args()
 

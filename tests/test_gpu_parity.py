@@ -341,7 +341,7 @@ def test_fast_voxelization_flags_a_face_point_and_checked_recovers(engine, orc, 
 
 @pytest.mark.parametrize("lanes", [1, 3, 6])
 def test_pipeline_equals_single_stream_calls(engine, scans, lanes):
-    """caelo_pipeline (fronts and pairs round-robin on `lanes` streams, encoders batched min(lanes, 3) frames per
+    """caelo_pipeline (fronts and pairs round-robin on `lanes` streams, encoders batched min(lanes, 2) frames per
     launch set on their own stream, native issue threads) reproduces the one-call-per-stage results bit for bit,
     including pairs chained across lanes / batches, a partial last batch and ring reuse."""
     import torch
