@@ -212,7 +212,8 @@ def main():
                                    "synthetic 64-beam x 2000-azimuth scans",
                        "points_per_frame": n_points, "keypoints": 1024, "patches_per_frame": 3072,
                        "frames_per_gpu": K, "hip_streams_per_gpu": pipe.lanes + 1, "frames_per_encoder_launch": pipe.batch,
-                       "host_issue_us_per_frame": round(host["issue_us_per_frame"], 1), "parallelism": "frames sharded x%d, one RCCL all-gather of %s [1024,64] f32 frame rows" % (
+                       "host_issue_us_per_frame": round(host["issue_us_per_frame"], 1),
+                       **({"encoder_stream_busy": round(host["encoder_busy_us"] / host["encoder_span_us"], 3)} if host["encoder_span_us"] > 0 else {}), "parallelism": "frames sharded x%d, one RCCL all-gather of %s [1024,64] f32 frame rows" % (
                            world, "the boundary" if args.gather == "boundary" else "all"),
                        "poses_solved": "%d/%d" % (ok, K), "status_bits": status},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -143,11 +143,11 @@ class Pipeline:
 
     def stats(self):
         """Host-side counters since the last call: jobs, us/job spent issuing, us/job waiting for a predecessor."""
-        out = (C.c_int64 * 4)()
+        out = (C.c_int64 * 6)()
         _ffi.check(self.eng.lib.caelo_pipeline_stats(self.h, out))
         n = max(int(out[0]), 1)
         return {"jobs": int(out[0]), "issue_us_per_frame": out[1] / n / 1e3, "wait_us_per_frame": out[2] / n / 1e3,
-                "lanes": int(out[3])}
+                "lanes": int(out[3]), "encoder_busy_us": out[4] / 1e3, "encoder_span_us": out[5] / 1e3}
 
     def run(self, scans, rands, prev=None, dist_channels=5, exact_voxels=False, out=None):
         """scans: K device tensors [n,4] f32; rands: K device tensors of RANSAC draws ([1500,4] f64).

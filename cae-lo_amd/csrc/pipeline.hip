@@ -45,6 +45,7 @@ struct Slot {
 };
 
 struct Batch {
+    hipEvent_t t0 = nullptr, t1 = nullptr;  // CAELO_PIPE_TIMING: encoder launch set begin / end (timed events)
     hipEvent_t encoded = nullptr;  // recorded on the encoder stream after the batch was enqueued
     bool enc_rec = false;
     uint64_t first = 0;            // sequence number of its first job
@@ -91,6 +92,9 @@ struct caelo_pipeline {
     std::string error_text;
     hipEvent_t begun = nullptr;
     std::atomic<int64_t> stat_jobs{0}, stat_issue_ns{0}, stat_wait_ns{0};
+    bool timing = false;             // CAELO_PIPE_TIMING=1: time the encoder launch sets with HIP events
+    std::vector<uint64_t> timed;     // batches enqueued since the last flush
+    double enc_busy_ms = 0, enc_span_ms = 0;
 };
 
 namespace {
@@ -165,12 +169,15 @@ int run_encode(caelo_pipeline *p, uint64_t b, int64_t *waited) {
         rc = hip_rc(hipStreamWaitEvent(enc.stream, sl.fronted, 0), "hipStreamWaitEvent");
         outs.base[i] = sl.job.rows;
     }
+    if (p->timing && rc == CAELO_OK) (void)hipEventRecord(bt.t0, enc.stream);
     if (rc == CAELO_OK && !failed(p))
         rc = encode_batch_impl(p->ctx, p->bits[b % p->n_bits], bt.count * FRAME_PATCHES, 3, outs, 64,
                                p->enc_ws[b % p->encoders.size()], enc.stream, nullptr);
+    if (p->timing && rc == CAELO_OK) (void)hipEventRecord(bt.t1, enc.stream);
     if (rc == CAELO_OK) rc = hip_rc(hipEventRecord(bt.encoded, enc.stream), "hipEventRecord");
     {
         std::lock_guard<std::mutex> g(p->mu);
+        if (p->timing) p->timed.push_back(b);
         bt.enc_rec = true;
     }
     p->cv.notify_all();
@@ -292,8 +299,11 @@ CAELO_API void caelo_pipeline_destroy(caelo_pipeline *p) {
     for (Worker &e : p->encoders) destroy_worker(e);
     for (Slot &s : p->slots)
         if (s.fronted) (void)hipEventDestroy(s.fronted);
-    for (Batch &b : p->batches)
+    for (Batch &b : p->batches) {
         if (b.encoded) (void)hipEventDestroy(b.encoded);
+        if (b.t0) (void)hipEventDestroy(b.t0);
+        if (b.t1) (void)hipEventDestroy(b.t1);
+    }
     for (uint64_t *b : p->bits)
         if (b) (void)hipFree(b);
     for (void *w : p->enc_ws)
@@ -325,6 +335,12 @@ CAELO_API int caelo_pipeline_create(caelo_ctx *c, int n_lanes, int batch, int64_
     hip_ok(hipEventCreateWithFlags(&p->begun, hipEventDisableTiming), "hipEventCreate");
     for (Slot &s : p->slots) hip_ok(hipEventCreateWithFlags(&s.fronted, hipEventDisableTiming), "hipEventCreate");
     for (Batch &b : p->batches) hip_ok(hipEventCreateWithFlags(&b.encoded, hipEventDisableTiming), "hipEventCreate");
+    p->timing = getenv("CAELO_PIPE_TIMING") && atoi(getenv("CAELO_PIPE_TIMING")) > 0;
+    if (p->timing)
+        for (Batch &b : p->batches) {
+            hip_ok(hipEventCreate(&b.t0), "hipEventCreate");
+            hip_ok(hipEventCreate(&b.t1), "hipEventCreate");
+        }
     for (Worker &l : p->lanes) {
         hip_ok(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking), "hipStreamCreate");
         hip_ok(hipEventCreateWithFlags(&l.joined, hipEventDisableTiming), "hipEventCreate");
@@ -366,6 +382,8 @@ CAELO_API int caelo_pipeline_stats(caelo_pipeline *p, int64_t *out_host) {
     out_host[1] = p->stat_issue_ns.exchange(0);
     out_host[2] = p->stat_wait_ns.exchange(0);
     out_host[3] = (int64_t)p->lanes.size();
+    out_host[4] = (int64_t)(p->enc_busy_ms * 1e6);  // CAELO_PIPE_TIMING: ns the encoder stream was inside a launch set ...
+    out_host[5] = (int64_t)(p->enc_span_ms * 1e6);  // ... out of this many ns between the first begin and the last end (last flush)
     return CAELO_OK;
 }
 
@@ -434,6 +452,17 @@ CAELO_API int caelo_pipeline_flush(caelo_pipeline *p, void *stream) {
     }
     p->cv.notify_all();
     int rc = drain(p);
+    if (p->timing && !p->timed.empty()) {   // diagnostic mode: synchronises
+        for (Worker &e : p->encoders) (void)hipStreamSynchronize(e.stream);
+        float ms = 0, busy = 0;
+        for (uint64_t b : p->timed)
+            if (hipEventElapsedTime(&ms, p->batches[b % BATCH_RING].t0, p->batches[b % BATCH_RING].t1) == hipSuccess) busy += ms;
+        float span = 0;
+        (void)hipEventElapsedTime(&span, p->batches[p->timed.front() % BATCH_RING].t0, p->batches[p->timed.back() % BATCH_RING].t1);
+        p->enc_busy_ms = busy;
+        p->enc_span_ms = span;
+        p->timed.clear();
+    }
     for (Worker &l : p->lanes) {
         CAELO_HIP(hipEventRecord(l.joined, l.stream));
         CAELO_HIP(hipStreamWaitEvent(caelo_stream(stream), l.joined, 0));

@@ -236,8 +236,10 @@ int caelo_pipeline_lanes(const caelo_pipeline *pipe);
 int caelo_pipeline_begin(caelo_pipeline *pipe, void *stream);
 int caelo_pipeline_submit(caelo_pipeline *pipe, const caelo_frame_job *job);
 int caelo_pipeline_flush(caelo_pipeline *pipe, void *stream);
-/* host-side counters since the last call (then reset): out_host[4] = jobs, ns the lane threads spent issuing them,
- * ns they waited for a predecessor frame to be enqueued on another lane, number of lanes */
+/* host-side counters since the last call (then reset): out_host[6] = jobs, ns the worker threads spent issuing them,
+ * ns they waited for another worker's record call, number of lanes, and -- only with CAELO_PIPE_TIMING=1 in the
+ * environment at create time (a diagnostic mode whose flush synchronises) -- ns the encoder stream spent inside launch
+ * sets and the ns between the first set's begin and the last set's end of the last flush */
 int caelo_pipeline_stats(caelo_pipeline *pipe, int64_t *out_host);
 
 #ifdef __cplusplus
