@@ -104,10 +104,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # CAELO_DIST_BACKEND=gloo: functional test of the multi-rank path with several ranks on one GPU (RCCL wants one
+    # device per rank); the driver's runs use the default, nccl == RCCL over xGMI
+    backend = os.environ.get("CAELO_DIST_BACKEND", "nccl")
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        dist.init_process_group(backend=backend, **({"device_id": dev} if backend == "nccl" else {}))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     eng = Engine(device=local_rank)
@@ -159,7 +163,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     host = pipe.stats()

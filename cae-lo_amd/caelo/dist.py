@@ -21,6 +21,17 @@ import torch.distributed as dist
 ROW = 64  # floats per key point row: descriptor (60) + xyz (3) + valid (1)
 
 
+def _all_gather_into(recv, send, group=None):
+    """dist.all_gather_into_tensor; device tensors under the gloo backend (functional tests that put several ranks
+    on one GPU) are staged through the host."""
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        r = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(r, send.cpu(), group=group)
+        recv.copy_(r)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
+
+
 def shard_frames(n_frames, rank, world):
     """Contiguous block [lo, hi) of frame indices owned by ``rank`` (sizes differ by at most 1)."""
     base, rem = divmod(n_frames, world)
@@ -63,7 +74,7 @@ def all_gather_frames(local_rows, n_frames, group=None):
     if hi - lo < fmax:
         send = torch.cat([local_rows, local_rows.new_zeros((fmax - (hi - lo), k, ROW))], dim=0)
     recv = local_rows.new_empty((world * fmax, k, ROW))
-    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    _all_gather_into(recv, send.contiguous(), group)
     parts = []
     for r in range(world):
         rlo, rhi = shard_frames(n_frames, r, world)
@@ -79,7 +90,7 @@ def all_gather_boundary(last_rows, group=None):
     if world == 1:
         return last_rows.unsqueeze(0)
     recv = last_rows.new_empty((world * last_rows.shape[0],) + tuple(last_rows.shape[1:]))  # concatenated form
-    dist.all_gather_into_tensor(recv, last_rows.contiguous(), group=group)
+    _all_gather_into(recv, last_rows.contiguous(), group)
     return recv.view((world,) + tuple(last_rows.shape))
 
 
@@ -100,7 +111,7 @@ def gather_poses(local_rt, n_frames, group=None):
     send = local_rt.new_zeros((pmax, w))
     send[: local_rt.shape[0]] = local_rt
     recv = local_rt.new_empty((world * pmax, w))
-    dist.all_gather_into_tensor(recv, send, group=group)
+    _all_gather_into(recv, send, group)
     parts = []
     for r in range(world):
         parts.append(recv[r * pmax: r * pmax + len(local_pairs(n_frames, r, world))])

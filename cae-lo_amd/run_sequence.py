@@ -97,9 +97,11 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = os.environ.get("CAELO_DIST_BACKEND", "nccl")   # gloo: several ranks on one GPU (functional tests)
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend=backend, **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
     if args.scans:
         files = sorted(glob.glob(os.path.join(args.scans, "*.bin")))
         n, load = len(files), (lambda i: stageio.read_scan(files[i]))
