@@ -408,8 +408,11 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long 
 
 __global__ void __launch_bounds__(256) k_enc_conv3(const float *__restrict__ p2, int64_t n_patches,
                                                    const float *__restrict__ w3g, const float *__restrict__ b3g,
-                                                   float *__restrict__ f3) {
+                                                   float *__restrict__ f3, int *__restrict__ stage1_counter) {
     __shared__ __attribute__((aligned(16))) float S[2 * P2_SLOT];
+    // stage 1 (the previous kernel on this stream) is complete: hand its work counter back at zero, so that no
+    // memset launch sits on the encoder stream's critical path
+    if (blockIdx.x == 0 && threadIdx.x == 0) *stage1_counter = 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -687,9 +690,9 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     CAELO_REQUIRE(c->has_enc, "encoder weights not set (caelo_set_encoder_weights)");
     CAELO_REQUIRE(n_patches > 0 && group >= 1 && out_stride >= group * 20, "bad shape");
     const int64_t np = pad64(n_patches);
-    // ws = [256 bytes: stage-1 work counter] | P2 | F3 | dense-1 partial sums
+    // ws = [256 bytes: stage-1 work counter, zero between calls (the owner zero-fills ws once, conv3 resets it)] |
+    // P2 | F3 | dense-1 partial sums
     int *work_counter = (int *)ws;
-    CAELO_HIP(hipMemsetAsync(work_counter, 0, 256, s));
     float *p2 = (float *)((char *)ws + 256);
     float *f3 = p2 + np * 1024;
     float *part = f3 + np * 2048;
@@ -715,7 +718,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     const int64_t pairs = (n_patches + 1) / 2;
     static int g3max = getenv("CAELO_C3_GRID") ? atoi(getenv("CAELO_C3_GRID")) : 512;
     const unsigned g3 = (unsigned)(pairs < g3max ? pairs : g3max);
-    k_enc_conv3<<<g3, 256, 0, s>>>(p2, n_patches, c->enc_w3, c->enc_b3, f3);
+    k_enc_conv3<<<g3, 256, 0, s>>>(p2, n_patches, c->enc_w3, c->enc_b3, f3, work_counter);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[2], s));
     dim3 gd((unsigned)(np / D1_BM), D1_SPLIT);

@@ -345,6 +345,7 @@ CAELO_API int caelo_pipeline_create(caelo_ctx *c, int n_lanes, int batch, int64_
         hip_ok(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking), "hipStreamCreate");
         hip_ok(hipEventCreateWithFlags(&l.joined, hipEventDisableTiming), "hipEventCreate");
         hip_ok(hipMalloc(&l.ws_extract, (size_t)caelo_extract_ws_bytes()), "hipMalloc");
+        if (rc == CAELO_OK) hip_ok(hipMemset(l.ws_extract, 0, (size_t)caelo_extract_ws_bytes()), "hipMemset");
         hip_ok(hipMalloc(&l.ws_match, (size_t)caelo_match_ws_bytes(CAELO_MAX_KEYPTS)), "hipMalloc");
         hip_ok(hipMalloc(&l.ws_ransac, (size_t)caelo_ransac_ws_bytes()), "hipMalloc");
         // match / ransac workspaces are self-cleaning: zero once, every call leaves them zeroed where it matters
@@ -361,6 +362,7 @@ CAELO_API int caelo_pipeline_create(caelo_ctx *c, int n_lanes, int batch, int64_
         hip_ok(hipStreamCreateWithFlags(&p->encoders[i].stream, hipStreamNonBlocking), "hipStreamCreate");
         hip_ok(hipEventCreateWithFlags(&p->encoders[i].joined, hipEventDisableTiming), "hipEventCreate");
         hip_ok(hipMalloc(&p->enc_ws[i], (size_t)caelo_encode_ws_bytes(batch * FRAME_PATCHES)), "hipMalloc");
+        if (rc == CAELO_OK) hip_ok(hipMemset(p->enc_ws[i], 0, 256), "hipMemset");  // stage-1 work counter (self-cleaning)
     }
     for (int i = 0; i < p->n_bits; ++i)
         hip_ok(hipMalloc((void **)&p->bits[i], (size_t)batch * FRAME_PATCHES * 64 * sizeof(uint64_t)), "hipMalloc");

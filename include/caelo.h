@@ -119,7 +119,8 @@ int caelo_pack_patches(caelo_ctx *ctx, const float *dense, int64_t n_patches, ui
 /* PatchEncoder.predict / GetFeaturesFromPatches  (Match.py:130-135; EncoderModel4VoxelPatch.h5)
  * bits [n_patches][64] u64 -> out[(p / group) * out_stride + (p % group) * 20 + j].
  * group = 1, out_stride = 20: plain predict; group = 3, out_stride = 60 on [K][3][64]: Features [K][60].
- * workspace: ws of caelo_encode_ws_bytes(n_patches) bytes. */
+ * workspace: ws of caelo_encode_ws_bytes(n_patches) bytes, zero-filled ONCE by its owner before the first call
+ * (its first 256 bytes hold a work counter that every call returns to zero), one ws per stream. */
 int64_t caelo_encode_ws_bytes(int64_t n_patches);
 int caelo_encode(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
                  void *ws, void *stream);
@@ -173,7 +174,8 @@ int caelo_ransac(caelo_ctx *ctx, const float *pc0, int ld0, const float *pc1, in
  * (BatchPreprocess.py:97-98,131-136).  Outputs (device): key_pts rows [1024][kp_ld], features rows
  * [1024][feat_ld] (60 used), valid (optional) [1024] with stride valid_ld = 1.0 for rows < K,
  * key_pixels [1024][2], n_key [1], flags [1024][3] (caelo_patches), status int32[4] 16-byte aligned
- * (word 0 = CAELO_ST_* bits, cleared by the call).  ws: caelo_extract_ws_bytes() bytes, 256-byte aligned. */
+ * (word 0 = CAELO_ST_* bits, cleared by the call).  ws: caelo_extract_ws_bytes() bytes, 256-byte aligned, zero-filled
+ * once by its owner before the first call (it embeds an encoder workspace), one ws per stream. */
 int64_t caelo_extract_ws_bytes(void);
 int caelo_extract(caelo_ctx *ctx, caelo_voxmap *map, const float *pc, int64_t n, int dist_channels, int mode, float *key_pts,
                   int kp_ld, float *features, int feat_ld, float *valid, int valid_ld, int64_t *key_pixels,
