@@ -67,6 +67,8 @@ SIGNATURES = [
                               c_vp, c_vp]),
     ("caelo_extend_ws_bytes", c_i64, [c_int, c_int]),
     ("caelo_extend_keypts", c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    ("caelo_icp_ws_bytes", c_i64, [c_i64]),
+    ("caelo_icp_step", c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, C.c_double, c_int, c_vp, c_vp, c_vp, c_vp]),
     ("caelo_pipeline_create", c_int, [c_vp, c_int, c_int, c_i64, C.POINTER(c_vp)]),
     ("caelo_pipeline_destroy", None, [c_vp]),
     ("caelo_pipeline_lanes", c_int, [c_vp]),

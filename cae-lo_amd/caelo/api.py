@@ -117,6 +117,39 @@ def ExtendKeyPtsInShpericalRing(SphericalRing, GridCounter, KeyPixels):
     return _out(ext[: int(n_ext.item())], as_np)
 
 
+def RotateMat2EulerAngle_XYZ(R):
+    """Transformations.py:181-186 (degrees)."""
+    import math
+    return np.array([math.atan2(R[2, 1], R[2, 2]), math.atan2(-R[2, 0], math.sqrt(R[2, 1] ** 2 + R[2, 2] ** 2)),
+                     math.atan2(R[1, 0], R[0, 0])]) * (180.0 / math.pi)
+
+
+def ICP(PC0, PC1, maxIterTimes=50, minIterTimes=20 - 1, inlierThreshold=0.5, smallShiftThreshold=0.05, decay_rate=0.9, ep=0.001):
+    """MyICP.py:26-72: point-to-point ICP of PC1 onto PC0 (the re-registration of the extended keypoints after the
+    odometry, RefinePoses.py:273-334).  Nearest neighbours, inlier selection, SolveRT and the update of PC1 run on the
+    GPU (caelo_icp_step); the loop control is the reference's.  -> (R_star [3,3] f64, T_star [3,1] f64, isSuccess)."""
+    e = default_engine()
+    pc0 = _dev(np.ascontiguousarray(PC0)[:, 0:3] if _is_np(PC0) else PC0[:, 0:3], torch.float32).contiguous()
+    pc1 = _dev(np.ascontiguousarray(PC1)[:, 0:3] if _is_np(PC1) else PC1[:, 0:3], torch.float32).contiguous().clone()
+    R_star = np.eye(3, dtype=np.float64)                                              # :27
+    T_star = np.zeros((3, 1), dtype=np.float64)                                       # :28
+    for iIter in range(maxIterTimes):                                                 # :30
+        rt, n_in = e.icp_step(pc0, pc1, inlierThreshold, 100)                         # :31-50
+        if int(n_in.item()) < 100:                                                    # :38-40
+            return R_star, T_star, False
+        rt = rt.cpu().numpy()
+        R, T = rt[:9].reshape(3, 3), rt[9:].reshape(3, 1)
+        R_star = np.dot(R, R_star)                                                    # :51
+        T_star = np.dot(R, T_star) + T                                                # :52
+        normEulers = np.linalg.norm(RotateMat2EulerAngle_XYZ(R))                      # :55-56
+        normT = np.linalg.norm(T)                                                     # :57
+        if iIter >= minIterTimes and normEulers < ep and normT < ep:                  # :58-60
+            break
+        if normEulers < smallShiftThreshold and normT < smallShiftThreshold:          # :64-66
+            inlierThreshold *= decay_rate
+    return R_star, T_star, True
+
+
 def GetKeyPtsFromRawFileName(rawFileFullPath, RespondLayer):
     """SphericalRing.py:389-416: reads <seq>/SphericalRing/<name>.mat written by BatchPreprocess."""
     from scipy import io

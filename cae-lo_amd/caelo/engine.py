@@ -310,6 +310,17 @@ class Engine:
                                                 self.stream))
         return ext, n_ext
 
+    def icp_step(self, pc0, pc1, threshold, min_inliers=100):
+        """One ICP iteration (caelo_icp_step): pc1 [n1,3] f32 is moved IN PLACE.  -> (rt [12] f32, n_inliers [1] i32)."""
+        for t in (pc0, pc1):
+            assert t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == 3 and t.is_contiguous()
+        rt = self.empty((12,), torch.float32)
+        n_in = self.empty((1,), torch.int32)
+        ws = self._ws("icp", int(self.lib.caelo_icp_ws_bytes(pc1.shape[0])))
+        _ffi.check(self.lib.caelo_icp_step(self.ctx, _ptr(pc0), pc0.shape[0], _ptr(pc1), pc1.shape[0], float(threshold),
+                                           int(min_inliers), _ptr(rt), _ptr(n_in), _ptr(ws), self.stream))
+        return rt, n_in
+
     def voxelize(self, pc, vmap=None, status=None):
         assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] >= 3 and pc.is_contiguous()
         vmap = vmap or self.voxmap(max(self.max_points, pc.shape[0]))

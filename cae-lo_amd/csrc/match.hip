@@ -745,3 +745,77 @@ CAELO_API int caelo_ransac(caelo_ctx *c, const float *pc0, int ld0, const float 
     }
     return CAELO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// ICP step: MyICP.py:26-72 / :75-85 -- the refinement that follows the odometry
+// ------------------------------------------------------------------------------------------------
+// One iteration of the reference's point-to-point ICP: for every point of PC1 its nearest neighbour in PC0
+// (sklearn NearestNeighbors(n_neighbors=1): exact Euclidean distance in float64), the pairs closer than the
+// threshold, SolveRT on them, PC1 <- R PC1 + T.  The iteration control (threshold decay, Euler-angle stop rule)
+// stays on the host, like the reference's Python loop.
+#define ICP_TILE 1024
+
+__global__ void __launch_bounds__(256) k_icp_nn(const float *__restrict__ pc0, int n0, const float *__restrict__ pc1, int n1,
+                                                double thr, int64_t *__restrict__ idx0, uint8_t *__restrict__ mask,
+                                                int32_t *__restrict__ n_in) {
+    __shared__ float tile[ICP_TILE * 3];
+    __shared__ int s_cnt;
+    const int tid = threadIdx.x;
+    const int j = blockIdx.x * blockDim.x + tid;
+    if (tid == 0) s_cnt = 0;
+    double qx = 0.0, qy = 0.0, qz = 0.0;
+    if (j < n1) { qx = pc1[3 * (size_t)j]; qy = pc1[3 * (size_t)j + 1]; qz = pc1[3 * (size_t)j + 2]; }
+    double best = 1.0e300;
+    int besti = 0;
+    for (int base = 0; base < n0; base += ICP_TILE) {
+        const int m = min(ICP_TILE, n0 - base);
+        __syncthreads();
+        for (int i = tid; i < 3 * m; i += 256) tile[i] = pc0[3 * (size_t)base + i];
+        __syncthreads();
+        for (int i = 0; i < m; ++i) {  // all lanes read the same address: LDS broadcast
+            const double dx = (double)tile[3 * i] - qx, dy = (double)tile[3 * i + 1] - qy, dz = (double)tile[3 * i + 2] - qz;
+            const double d2 = dx * dx + dy * dy + dz * dz;  // sequential x, y, z like the kd-tree's reduced distance
+            if (d2 < best) { best = d2; besti = base + i; }
+        }
+    }
+    const bool in = j < n1 && sqrt(best) < thr;  // GetPtsInliners: distances < inlierThreshold (:80)
+    if (j < n1) { idx0[j] = besti; mask[j] = in ? 1 : 0; }
+    const unsigned long long bal = __ballot(in);
+    if ((tid & 63) == 0 && bal) atomicAdd(&s_cnt, __popcll(bal));
+    __syncthreads();
+    if (tid == 0 && s_cnt) atomicAdd(n_in, s_cnt);
+}
+
+// SolveRT on the inlier pairs and PC1 <- R PC1 + T (one workgroup; float32 like the reference's arrays)
+__global__ void __launch_bounds__(256) k_icp_fit_apply(const float *__restrict__ pc0, float *__restrict__ pc1, int n1,
+                                                       const int64_t *__restrict__ idx0, const uint8_t *__restrict__ mask,
+                                                       const int32_t *__restrict__ n_in, int min_inliers, float *__restrict__ rt) {
+    if (*n_in < min_inliers) return;  // the host stops the iteration (MyICP.py:38-40)
+    fit_block(pc0, 3, idx0, pc1, 3, mask, n1, rt, rt + 9, nullptr);
+    __syncthreads();
+    const float r0 = rt[0], r1 = rt[1], r2 = rt[2], r3 = rt[3], r4 = rt[4], r5 = rt[5], r6 = rt[6], r7 = rt[7], r8 = rt[8];
+    const float t0 = rt[9], t1 = rt[10], t2 = rt[11];
+    for (int j = threadIdx.x; j < n1; j += 256) {  // PC1 = (np.dot(R, PC1.T) + T).T  (:50)
+        const float x = pc1[3 * (size_t)j], y = pc1[3 * (size_t)j + 1], z = pc1[3 * (size_t)j + 2];
+        pc1[3 * (size_t)j] = r0 * x + r1 * y + r2 * z + t0;
+        pc1[3 * (size_t)j + 1] = r3 * x + r4 * y + r5 * z + t1;
+        pc1[3 * (size_t)j + 2] = r6 * x + r7 * y + r8 * z + t2;
+    }
+}
+
+CAELO_API int64_t caelo_icp_ws_bytes(int64_t n1) { return ((n1 * 9 + 255) / 256) * 256 + 256; }
+
+CAELO_API int caelo_icp_step(caelo_ctx *c, const float *pc0, int64_t n0, float *pc1, int64_t n1, double threshold,
+                             int min_inliers, float *rt, int32_t *n_inliers, void *ws, void *stream) {
+    CAELO_REQUIRE(c && pc0 && pc1 && rt && n_inliers && ws, "null argument");
+    CAELO_REQUIRE(n0 > 0 && n1 > 0 && n0 < (1 << 30) && n1 < (1 << 30), "bad shape");
+    hipStream_t s = caelo_stream(stream);
+    int64_t *idx0 = (int64_t *)ws;
+    uint8_t *mask = (uint8_t *)(idx0 + n1);
+    CAELO_HIP(hipMemsetAsync(n_inliers, 0, sizeof(int32_t), s));
+    k_icp_nn<<<(unsigned)((n1 + 255) / 256), 256, 0, s>>>(pc0, (int)n0, pc1, (int)n1, threshold, idx0, mask, n_inliers);
+    CAELO_LAUNCH_CHECK();
+    k_icp_fit_apply<<<1, 256, 0, s>>>(pc0, pc1, (int)n1, idx0, mask, n_inliers, min_inliers, rt);
+    CAELO_LAUNCH_CHECK();
+    return CAELO_OK;
+}

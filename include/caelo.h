@@ -192,6 +192,15 @@ int caelo_extend_keypts(caelo_ctx *ctx, const float *ring, int ring_w, int ring_
                         int cols, const int64_t *key_pixels, int k_max, const int32_t *n_key, float *ext_pts,
                         int32_t *n_ext, void *ws, void *stream);
 
+/* One iteration of the reference's point-to-point ICP (MyICP.py:26-72; GetPtsInliners :75-85): nearest neighbour in
+ * pc0 [n0][3] of every point of pc1 [n1][3] (exact float64 Euclidean distance, first minimum), the pairs closer than
+ * `threshold`, SolveRT on them -> rt [12] (R row-major | T, device) and pc1 <- R pc1 + T IN PLACE.  n_inliers [1]
+ * (device) = number of pairs; with fewer than min_inliers nothing is fitted or moved (the caller stops: :38-40).
+ * Threshold decay and the Euler-angle stop rule stay with the host loop (caelo.api.ICP).  ws: caelo_icp_ws_bytes(n1). */
+int64_t caelo_icp_ws_bytes(int64_t n1);
+int caelo_icp_step(caelo_ctx *ctx, const float *pc0, int64_t n0, float *pc1, int64_t n1, double threshold, int min_inliers,
+                   float *rt, int32_t *n_inliers, void *ws, void *stream);
+
 /* ---- frame pipeline: fronts and pairs of consecutive frames on n_lanes HIP streams, encoders batched -----------
  * Replaces the reference's per-frame driver loops (BatchPreprocess.py:88-140 extract loop, Match.py:296-353 /
  * PoseEstimation.py pair loop) for throughput.  Each lane owns a stream, an issue thread, a voxel map and the

@@ -123,6 +123,54 @@ def ExtendKeyPtsInShpericalRing(SphericalRing, GridCounter, KeyPixels):
     return np.concatenate(out, axis=0)                                   # :314-316
 
 
+def RotateMat2EulerAngle_XYZ(R):
+    """Transformations.py:181-186 (degrees)."""
+    import math
+    return np.array([math.atan2(R[2, 1], R[2, 2]), math.atan2(-R[2, 0], math.sqrt(R[2, 1] ** 2 + R[2, 2] ** 2)),
+                     math.atan2(R[1, 0], R[0, 0])]) * (180.0 / math.pi)
+
+
+def nearest_neighbours(PC0, PC1, chunk=256):
+    """sklearn NearestNeighbors(n_neighbors=1).fit(PC0).kneighbors(PC1) restated as a brute-force float64 search
+    (exact Euclidean distance, first minimum) -> (distances [n1], indices [n1])."""
+    a = np.asarray(PC0, np.float64)
+    b = np.asarray(PC1, np.float64)
+    dist = np.empty(len(b)); idx = np.empty(len(b), np.int64)
+    for s in range(0, len(b), chunk):
+        d = b[s:s + chunk, None, :] - a[None, :, :]
+        d2 = d[:, :, 0] * d[:, :, 0] + d[:, :, 1] * d[:, :, 1] + d[:, :, 2] * d[:, :, 2]
+        idx[s:s + chunk] = d2.argmin(axis=1)
+        dist[s:s + chunk] = np.sqrt(d2.min(axis=1))
+    return dist, idx
+
+
+def ICP(PC0, PC1, maxIterTimes=50, minIterTimes=20 - 1, inlierThreshold=0.5, smallShiftThreshold=0.05, decay_rate=0.9, ep=0.001,
+        trace=None):
+    """MyICP.py:26-72, statement by statement."""
+    PC0 = np.asarray(PC0); PC1 = np.asarray(PC1)
+    R_star = np.eye(3, dtype=np.float64)
+    T_star = np.zeros((3, 1), dtype=np.float64)
+    for iIter in range(maxIterTimes):
+        distances, indices = nearest_neighbours(PC0, PC1)                # :31-32
+        idx1 = distances < inlierThreshold                               # :35
+        idx0 = indices[idx1]                                             # :36-37
+        if idx0.shape[0] < 100:                                          # :38-40
+            return R_star, T_star, False
+        R, T, _ = SolveRT(PC0[idx0, :], PC1[idx1, :])                    # :42-46
+        PC1 = (np.dot(R, PC1.T) + T).T                                   # :49
+        R_star = np.dot(R, R_star)                                       # :50
+        T_star = np.dot(R, T_star) + T                                   # :51
+        normEulers = np.linalg.norm(RotateMat2EulerAngle_XYZ(R))         # :54-55
+        normT = np.linalg.norm(T)                                        # :56
+        if trace is not None:
+            trace.append((int(idx0.shape[0]), float(inlierThreshold)))
+        if iIter >= minIterTimes and normEulers < ep and normT < ep:     # :57-59
+            break
+        if normEulers < smallShiftThreshold and normT < smallShiftThreshold:   # :63-65
+            inlierThreshold *= decay_rate
+    return R_star, T_star, True
+
+
 def Voxelization(PC):
     """Voxel.py:100-173.  Returns the reference's 9-tuple; only AllVoxels0/1/2 (the members the
     hot path consumes) are populated, the block structures are None."""

@@ -480,3 +480,35 @@ def test_two_ranks_equal_one_rank(tmp_path):
     line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith('{"metric"')][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 8 and d["config"]["poses_solved"] == "8/8" and d["value"] > 0
+
+
+def test_icp_vs_reference_golden(api, orc, models, scans):
+    """caelo.api.ICP (nearest neighbours, inlier selection, SolveRT and the point update on the GPU, the
+    reference's loop control on the host) against MyICP.ICP run by the reference itself: same number of iterations,
+    same inlier counts along the way, pose within tolerance."""
+    g = np.load(os.path.join(GOLDEN, "icp_0_1.npz"))
+    ext = []
+    for f in (0, 1):
+        ring, cnt = orc.ProjectPC2SphericalRing(scans(f))
+        resp = models[0].predict(ring[None, 0:64, 0:1792, 0:3])[0]
+        _, kpix, _ = orc.GetKeyPtsByAE(ring, cnt, resp)
+        ext.append(orc.ExtendKeyPtsInShpericalRing(ring, cnt, kpix))
+    pc1 = np.ascontiguousarray(np.array((np.dot(g["R_odo"], ext[1].T) + g["T_odo"]).T, dtype=np.float32))
+    assert sha(pc1) == str(g["pc1_sha256"])
+    # one step: neighbours and inlier count exactly as the reference's first iteration
+    import torch
+    from caelo.engine import default_engine
+    e = default_engine()
+    d1 = torch.from_numpy(pc1).to(e.device)
+    rt, n_in = e.icp_step(torch.from_numpy(ext[0]).to(e.device), d1, 0.5)
+    assert int(n_in.item()) == int(g["trace_inliers"][0])
+    R, T, ok = api.ICP(ext[0], pc1)
+    assert ok == bool(g["success"]) and R.dtype == np.float64 and T.shape == (3, 1)
+    # ICP stops when a step moves less than ep = 1e-3 (degrees / metres), so two runs whose float32 point updates
+    # round differently (BLAS sgemm in the reference, explicit mul/add here) agree to a fraction of ep, not to 1e-4 of
+    # the ~3 cm correction: the bar is half the stop threshold for T and 1e-4 for the rotation entries
+    assert np.abs(R - g["R_star"]).max() <= REL_TOL and np.abs(T - g["T_star"]).max() <= 5e-4
+    # too few pairs: the reference returns (identity so far, False) (MyICP.py:38-40)
+    far = pc1 + np.float32(1000.0)
+    R, T, ok = api.ICP(ext[0], far)
+    assert ok is False and np.array_equal(R, np.eye(3)) and not T.any()

@@ -238,6 +238,35 @@ def extend_golden():
     np.savez_compressed(os.path.join(GOLD, "extend_0.npz"), **g)
 
 
+def icp_golden():
+    """MyICP.ICP (MyICP.py:26-72) on the extended keypoints of frames 0 and 1, frame 1 pre-aligned with the odometry
+    pose of pair_0_1.npz (seed 0) like RefinePoses.py:283-284; the oracle restatement (brute-force float64 nearest
+    neighbours instead of sklearn's kd-tree) is asserted against it."""
+    import MyICP as RefICP
+    pair = np.load(os.path.join(GOLD, "pair_0_1.npz"))
+    ext = []
+    for f in (0, 1):
+        pc = synth.make_scan(f)
+        ring, cnt = RefSR.ProjectPC2SphericalRing(pc)
+        resp = np.squeeze(resp_model.predict(ring[0:64, 0:1792, :][:, :, [0, 1, 2]].reshape(1, 64, 1792, 3)))
+        (kp, kpix, _), _ = quiet(RefSR.GetKeyPtsByAE, ring, cnt, resp)
+        ext.append(np.asarray(RefSR.ExtendKeyPtsInShpericalRing(ring, cnt, kpix), np.float32))
+    R, T = pair["s0_R"], pair["s0_T"].reshape(3, 1)
+    pc1_ = np.array((np.dot(R, ext[1].T) + T).T, dtype=np.float32)            # RefinePoses.py:284
+    (Rs, Ts, ok), log = quiet(RefICP.ICP, ext[0], pc1_)
+    trace = []
+    oR, oT, ook = orc.ICP(ext[0], pc1_, trace=trace)
+    iters = int(log.split("ICP iters:")[1].split(",")[0]); inl = int(log.split("inliers:")[1].split(",")[0])
+    assert ook == ok and len(trace) == iters and trace[-1][0] == inl, (len(trace), iters, trace[-1], inl)
+    assert np.allclose(oR, Rs, atol=1e-7) and np.allclose(oT, Ts, atol=1e-6), "oracle ICP != reference"
+    g = {"n_ext": np.array([len(ext[0]), len(ext[1])]), "ext0_sha256": sha(ext[0]), "pc1_sha256": sha(pc1_),
+         "R_odo": R, "T_odo": T, "R_star": np.asarray(Rs, np.float64), "T_star": np.asarray(Ts, np.float64), "success": bool(ok),
+         "iters": iters, "inliers_last": inl, "trace_inliers": np.array([t[0] for t in trace], np.int32),
+         "trace_thr": np.array([t[1] for t in trace], np.float64)}
+    np.savez_compressed(os.path.join(GOLD, "icp_0_1.npz"), **g)
+    print("  icp golden: %d iterations, %d inliers, ok=%s, T_star=%s" % (iters, inl, ok, np.round(np.asarray(Ts).ravel(), 4)))
+
+
 def blocks_golden():
     """Voxel.py:161-172 block structures (written to VoxelModel/*.mat, BatchVoxelization.py:61-62) of a small scan: pins
     caelo.stageio.block_structures, which derives them from AllVoxels0 alone."""
@@ -323,6 +352,9 @@ if __name__ == "__main__":
     if "--extend-only" in sys.argv:
         extend_golden()
         sys.exit(0)
+    if "--icp-only" in sys.argv:
+        icp_golden()
+        sys.exit(0)
     trunc_golden()
     f0 = frame_golden(0)
     f1 = frame_golden(1)
@@ -332,6 +364,7 @@ if __name__ == "__main__":
     sequence_golden()
     blocks_golden()
     extend_golden()
+    icp_golden()
     print("done in %.1fs" % (time.time() - t0))
     for f in sorted(os.listdir(GOLD)):
         print("  %-24s %8.1f KB" % (f, os.path.getsize(os.path.join(GOLD, f)) / 1024))
