@@ -109,7 +109,7 @@ int ring_project_launch(const float *pc, int64_t n, float *ring, int32_t *counte
                         hipStream_t s);
 int ring_respond_launch(caelo_ctx *c, const float *in, int in_w, int in_c, float *resp, hipStream_t s);
 int ring_keypoints_launch(const float *ring, int ring_w, int ring_c, int dist_c, const int32_t *counter, int cnt_w,
-                          const float *resp, unsigned long long *cand, uint32_t *hist, int32_t *cand_count,
+                          const float *resp, unsigned long long *cand, int32_t *cand_count,
                           int64_t *key_pixels, float *key_pts, int kp_ld, float *valid, int valid_ld, int32_t *n_key,
                           int32_t *status, hipStream_t s);
 void vox_clear_items(caelo_voxmap *m, int level, caelo_clear_list &list);  // 0 brick keys only, 1 + scale-0 first-touch table, 2 everything

@@ -706,7 +706,6 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
         CAELO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_enc_stage1, 256, 0));
         CAELO_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
         slots1 = per_cu * cus > 0 ? per_cu * cus : 1024;
-        if (getenv("CAELO_S1_GRID")) slots1 = atoi(getenv("CAELO_S1_GRID"));
     }
     const unsigned g1 = (unsigned)(n_patches < slots1 ? n_patches : slots1);
     if (ev) CAELO_HIP(hipEventRecord(ev[0], s));
@@ -716,8 +715,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[1], s));
     const int64_t pairs = (n_patches + 1) / 2;
-    static int g3max = getenv("CAELO_C3_GRID") ? atoi(getenv("CAELO_C3_GRID")) : 512;
-    const unsigned g3 = (unsigned)(pairs < g3max ? pairs : g3max);
+    const unsigned g3 = (unsigned)(pairs < 512 ? pairs : 512);  // persistent: two 4-wave workgroups per CU
     k_enc_conv3<<<g3, 256, 0, s>>>(p2, n_patches, c->enc_w3, c->enc_b3, f3, work_counter);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[2], s));

@@ -60,7 +60,7 @@ int caelo_clear_many(const caelo_clear_list &list, hipStream_t s) {
 // fused extract
 // ------------------------------------------------------------------------------------------------
 struct ExtractLayout {
-    size_t ring, counter, winner, resp, cand, hist, cand_count, bits, enc, total;
+    size_t ring, counter, winner, resp, cand, cand_count, bits, enc, total;
 };
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -69,10 +69,9 @@ static ExtractLayout extract_layout() {
     ExtractLayout L;
     size_t off = 0;
     const size_t npix = (size_t)CAELO_RING_H * CAELO_RING_W;
-    // winner | counter | hist | cand_count are cleared together: keep them adjacent
+    // winner | counter | cand_count are cleared together: keep them adjacent
     L.winner = off; off += align256(npix * 4);
     L.counter = off; off += align256(npix * 4);
-    L.hist = off; off += (size_t)CAELO_KP_HIST_BINS * 4;
     L.cand_count = off; off += 256;
     L.ring = off; off += align256(npix * CAELO_RING_C * 4);
     L.resp = off; off += align256((size_t)CAELO_NET_H * CAELO_NET_W * 8 * 4);
@@ -111,14 +110,13 @@ int extract_front_launch(const caelo_extract_args &a, hipStream_t s) {
     int32_t *winner = (int32_t *)(ws + L.winner);
     float *resp = (float *)(ws + L.resp);
     unsigned long long *cand = (unsigned long long *)(ws + L.cand);
-    uint32_t *hist = (uint32_t *)(ws + L.hist);
     int32_t *cand_count = (int32_t *)(ws + L.cand_count);
     uint64_t *bits = a.bits ? a.bits : (uint64_t *)(ws + L.bits);
     // ---- one clear for everything the frame accumulates into
     caelo_clear_list cl;
     cl.n = 0;
     cl.item[cl.n++] = {winner, L.counter - L.winner, 0xFFFFFFFFu};
-    cl.item[cl.n++] = {counter, L.ring - L.counter, 0u};  // counter | hist | cand_count
+    cl.item[cl.n++] = {counter, L.ring - L.counter, 0u};  // counter | cand_count
     cl.item[cl.n++] = {a.status, 16, 0u};  // status is int32[4], 16-byte aligned (word 0 carries the bits)
     const bool exact_vox = (a.mode & CAELO_EXTRACT_EXACT_VOXELS) != 0;
     vox_clear_items(a.map, exact_vox ? 1 : 0, cl);
@@ -128,7 +126,7 @@ int extract_front_launch(const caelo_extract_args &a, hipStream_t s) {
     if ((rc = ring_project_launch(a.pc, a.n, ring, counter, winner, a.status, s))) return rc;
     if ((rc = ring_respond_launch(a.ctx, ring, CAELO_RING_W, CAELO_RING_C, resp, s))) return rc;
     if ((rc = ring_keypoints_launch(ring, CAELO_RING_W, CAELO_RING_C, a.dist_channels, counter, CAELO_RING_W, resp, cand,
-                                    hist, cand_count, a.key_pixels, a.key_pts, a.kp_ld, a.valid, a.valid_ld, a.n_key,
+                                    cand_count, a.key_pixels, a.key_pts, a.kp_ld, a.valid, a.valid_ld, a.n_key,
                                     a.status, s)))
         return rc;
     // ---- voxel map, patches

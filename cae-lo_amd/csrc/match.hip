@@ -491,7 +491,6 @@ CAELO_API int caelo_solve_rt(caelo_ctx *c, const float *p0, const float *p1, int
 // ------------------------------------------------------------------------------------------------
 struct RansacWs {
     int32_t counts[CAELO_RANSAC_MAX_TRIALS];
-    float Rt[CAELO_RANSAC_MAX_TRIALS][12];
     int32_t done;        // 1 once a level succeeded
     int32_t level_used;
     int32_t best_trial;  // within level_used

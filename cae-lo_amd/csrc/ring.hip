@@ -232,7 +232,7 @@ __device__ __host__ inline unsigned int kp_bin(unsigned int score_bits) {
 __global__ void __launch_bounds__(256) k_kp_score(const float *__restrict__ ring, int ring_w, int ring_c, int dist_c,
                                                   const int32_t *__restrict__ counter, int cnt_w,
                                                   const float *__restrict__ resp, unsigned long long *__restrict__ cand,
-                                                  uint32_t *__restrict__ hist, int32_t *cand_count) {
+                                                  int32_t *cand_count) {
     __shared__ float4 sR[KS_HR * KS_HC * 2];
     __shared__ unsigned char sOcc[KS_HR * KS_HC];
     const int tid = threadIdx.x;
@@ -304,8 +304,8 @@ __global__ void __launch_bounds__(256) k_kp_score(const float *__restrict__ ring
 // ------------------------------------------------------------------------------------------------
 // K4: stable top-(1025) select.  Keys are unique, so "ascending by (score, flat index)" (the stable
 // argsort of :194) is plain ascending key order.  One 1024-thread workgroup:
-//   1. suffix-scan the 65536-bin histogram of the score's top 16 bits (built by k_kp_score) to find
-//      the bin holding the 1025th largest key;
+//   1. histogram the candidates' scores (2048 bins of the top 16 score bits, see kp_bin) in LDS and suffix-scan
+//      it to find the bin holding the 1025th largest key;
 //   2. gather every key from that bin upwards (1025 + a few) into LDS;  bitonic sort;
 //   3. emit sorted[-1025:-1] (:216,:218).
 // If more than 2048 keys share the cut bin and above (pathological ties) an 8-bit MSD radix select
@@ -351,7 +351,7 @@ __device__ unsigned long long radix_select_threshold(const unsigned long long *c
 }
 
 __global__ void __launch_bounds__(SEL_THREADS) k_kp_select(const unsigned long long *__restrict__ cand,
-                                                           const uint32_t *__restrict__ ghist, const int32_t *cand_count,
+                                                           const int32_t *cand_count,
                                                            const float *__restrict__ ring, int ring_w, int ring_c,
                                                            int64_t *__restrict__ key_pixels, float *__restrict__ key_pts,
                                                            int kp_ld, float *__restrict__ valid, int valid_ld,
@@ -470,13 +470,13 @@ __global__ void __launch_bounds__(SEL_THREADS) k_kp_select(const unsigned long l
 }
 
 int ring_keypoints_launch(const float *ring, int ring_w, int ring_c, int dist_c, const int32_t *counter, int cnt_w,
-                          const float *resp, unsigned long long *cand, uint32_t *hist, int32_t *cand_count,
+                          const float *resp, unsigned long long *cand, int32_t *cand_count,
                           int64_t *key_pixels, float *key_pts, int kp_ld, float *valid, int valid_ld, int32_t *n_key,
                           int32_t *status, hipStream_t s) {
     dim3 grid(CAELO_NET_W / KS_COLS, 48 / KS_ROWS);
-    k_kp_score<<<grid, 256, 0, s>>>(ring, ring_w, ring_c, dist_c, counter, cnt_w, resp, cand, hist, cand_count);
+    k_kp_score<<<grid, 256, 0, s>>>(ring, ring_w, ring_c, dist_c, counter, cnt_w, resp, cand, cand_count);
     CAELO_LAUNCH_CHECK();
-    k_kp_select<<<1, SEL_THREADS, 0, s>>>(cand, hist, cand_count, ring, ring_w, ring_c, key_pixels, key_pts, kp_ld, valid,
+    k_kp_select<<<1, SEL_THREADS, 0, s>>>(cand, cand_count, ring, ring_w, ring_c, key_pixels, key_pts, kp_ld, valid,
                                           valid_ld, n_key, status);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
@@ -492,7 +492,7 @@ CAELO_API int caelo_debug_read(unsigned long long *out_host) {  // out_host[40]:
 }
 
 CAELO_API int64_t caelo_keypoints_ws_bytes(void) {
-    return (int64_t)CAELO_NET_H * CAELO_NET_W * 8 + (int64_t)CAELO_KP_HIST_BINS * 4 + 64;
+    return (int64_t)CAELO_NET_H * CAELO_NET_W * 8 + 64;
 }
 
 CAELO_API int caelo_keypoints(caelo_ctx *c, const float *ring, int ring_w, int ring_c, const int32_t *counter,
@@ -502,13 +502,12 @@ CAELO_API int caelo_keypoints(caelo_ctx *c, const float *ring, int ring_w, int r
     CAELO_REQUIRE(ring_w >= CAELO_NET_W && cnt_w >= CAELO_NET_W && ring_c >= 3 && ring_c <= 5, "bad ring shape");
     hipStream_t s = caelo_stream(stream);
     unsigned long long *cand = (unsigned long long *)ws;
-    uint32_t *hist = (uint32_t *)(cand + CAELO_NET_H * CAELO_NET_W);
-    int32_t *cand_count = (int32_t *)(hist + CAELO_KP_HIST_BINS);
+    int32_t *cand_count = (int32_t *)(cand + CAELO_NET_H * CAELO_NET_W);
     caelo_clear_list cl;
     cl.n = 0;
-    cl.item[cl.n++] = {hist, (size_t)CAELO_KP_HIST_BINS * 4 + 64, 0u};
+    cl.item[cl.n++] = {cand_count, 64, 0u};
     int rc = caelo_clear_many(cl, s);
     if (rc) return rc;
-    return ring_keypoints_launch(ring, ring_w, ring_c, ring_c, counter, cnt_w, resp, cand, hist, cand_count, key_pixels,
+    return ring_keypoints_launch(ring, ring_w, ring_c, ring_c, counter, cnt_w, resp, cand, cand_count, key_pixels,
                                  key_pts, 3, nullptr, 0, n_key, status, s);
 }
