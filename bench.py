@@ -50,7 +50,7 @@ FLOP_DENSE2 = 2 * 200 * 20
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 matrix peak
 
 
-def cpu_baseline(n_frames=3, max_seconds=40.0):
+def cpu_baseline(n_frames=16, max_seconds=30.0):
     """CPU oracle end to end (all host cores via OpenMP) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import oracle as orc
