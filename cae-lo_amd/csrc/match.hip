@@ -9,9 +9,11 @@
 //
 // The reference draws from NumPy's global RNG inside the loop; here the caller hands over the
 // uniform doubles in consumption order (3 levels x 500 trials x 4), every hypothesis of a level is
-// scored in parallel (one wavefront each, ballot + popcount for the inlier count) and a single
-// thread replays the sequential accept / early-exit rules over the count array (verified equivalent
-// on the reference: SURVEY 8a-9).
+// scored in parallel (one wavefront each, pairs staged in LDS, ballot + popcount for the inlier count) and
+// the last workgroup of the launch replays the sequential accept / early-exit rules over the count array
+// as a prefix maximum (verified equivalent on the reference: SURVEY 8a-9), writes the inlier mask and refits.
+// Also here: k_icp_nn / k_icp_fit_apply, one iteration of the reference's point-to-point ICP.
+// The workspaces of caelo_match / caelo_ransac are self-cleaning (zero-filled once by their owner).
 #include <stddef.h>
 
 #include "caelo_internal.h"
