@@ -110,19 +110,22 @@ def main():
     local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group(backend=backend, **({"device_id": dev} if backend == "nccl" else {}))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
+    # The engine and the pipeline's HIP streams are created BEFORE the process group: the runtime deals streams onto
+    # its 4 hardware queues in creation order, and throughput depends on that mapping (lanes then encoder as the first
+    # seven streams of the process: 5.7 k frames/s; one stream created ahead of them: 4.3 k) -- RCCL's own streams
+    # must come after.
     eng = Engine(device=local_rank)
+    pipe = eng.pipeline(max(1, args.lanes), args.batch or None)
+    if world > 1:
+        dist.init_process_group(backend=backend, **({"device_id": dev} if backend == "nccl" else {}))
     K, W = args.steps, args.warmup
     # synthetic scans of this rank's stretch of the trajectory, uploaded before the clock starts
     base = rank * K
     pool = [torch.from_numpy(synth.make_scan((base + i) % 997)).to(dev) for i in range(POOL)]
     rand = [torch.from_numpy(ransac_draws(1000 + rank * 7919 + i)).to(dev) for i in range(POOL)]
     n_points = int(np.mean([p.shape[0] for p in pool]))
-
-    pipe = eng.pipeline(max(1, args.lanes), args.batch or None)
 
     def run(steps, prev):
         """`steps` frames through the native pipeline (frame i on lane i % lanes: extract, then match + RANSAC

@@ -100,6 +100,8 @@ def main():
     backend = os.environ.get("CAELO_DIST_BACKEND", "nccl")   # gloo: several ranks on one GPU (functional tests)
     local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    eng = Engine(device=local_rank)
+    eng.pipeline(args.lanes, args.batch)   # its HIP streams first: the stream -> hardware-queue mapping follows creation order
     if world > 1:
         dist.init_process_group(backend=backend, **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
     if args.scans:
@@ -111,7 +113,6 @@ def main():
     assert n >= 2, "need at least two scans (--synthetic N or --scans DIR)"
     Tr = stageio.read_calib_tr(args.calib) if args.calib else None
 
-    eng = Engine(device=local_rank)
     lo, hi = cdist.shard_frames(n, rank, world)
     t0 = time.time()
 
