@@ -93,6 +93,8 @@ def main():
                     help="HIP streams per rank; whole frames are issued round-robin so the latency-bound kernels of "
                          "one frame (keypoint select, voxel hash, RANSAC) overlap the MFMA-bound encoder of another")
     ap.add_argument("--batch", type=int, default=0, help="frames per encoder launch set (0 = min(lanes, 2))")
+    ap.add_argument("--extract-only", action="store_true",
+                    help="BASELINE configs[1]: keypoints + descriptors only (no match / RANSAC); not the headline metric")
     ap.add_argument("--gather", choices=("boundary", "all"), default="boundary",
                     help="rows moved by the single all-gather: each rank's last frame (all that consecutive-pair "
                          "matching needs) or every frame")
@@ -132,7 +134,9 @@ def main():
         against frame i-1), one all-gather of frame rows, then the pair that straddles the rank boundary."""
         scans = [pool[i % POOL] for i in range(steps)]
         draws = [rand[i % POOL] for i in range(steps)]
-        batch = pipe.run(scans, draws, prev=prev if rank == 0 else None)
+        batch = pipe.run(scans, draws, prev=prev if rank == 0 else None, pairs=not args.extract_only)
+        if args.extract_only:
+            return batch.frame(steps - 1), batch
         if world > 1:
             if args.gather == "all":
                 allrows = cdist.all_gather_frames(batch.rows, steps * world)   # ONE collective over xGMI, every frame
@@ -171,7 +175,7 @@ def main():
         dt = float(tmax.item())
     host = pipe.stats()
     # sanity: every pose solved (not timed)
-    ok = sum(int(eng.pose_result(batch.result[i]).success) for i in range(K))
+    ok = 0 if args.extract_only else sum(int(eng.pose_result(batch.result[i]).success) for i in range(K))
     status = int(prev.status[0].item()) if prev.status is not None else 0
 
     out = None
@@ -211,7 +215,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
         out = {
-            "metric": "KITTI frames/sec end-to-end (keypts+desc+match+RANSAC)",
+            "metric": "KITTI frames/sec end-to-end (keypts+desc+match+RANSAC)" if not args.extract_only else
+                      "KITTI frames/sec keypoint+descriptor extraction only (configs[1])",
             "value": round(world * K / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -149,13 +149,14 @@ class Pipeline:
         return {"jobs": int(out[0]), "issue_us_per_frame": out[1] / n / 1e3, "wait_us_per_frame": out[2] / n / 1e3,
                 "lanes": int(out[3]), "encoder_busy_us": out[4] / 1e3, "encoder_span_us": out[5] / 1e3}
 
-    def run(self, scans, rands, prev=None, dist_channels=5, exact_voxels=False, out=None):
+    def run(self, scans, rands=None, prev=None, dist_channels=5, exact_voxels=False, out=None, pairs=True):
         """scans: K device tensors [n,4] f32; rands: K device tensors of RANSAC draws ([1500,4] f64).
         Frame i is matched against frame i-1 (pose in ``result[i]``); frame 0 against ``prev``
-        (FrameFeatures) when given.  Returns a FrameBatch; the current stream has waited for all lanes."""
+        (FrameFeatures) when given; ``pairs=False`` extracts only (BASELINE configs[1]).  Returns a FrameBatch; the
+        current stream has waited for all lanes."""
         eng, lib, k = self.eng, self.eng.lib, len(scans)
         out = out or FrameBatch(eng, k)
-        assert out.k >= k and len(rands) >= k
+        assert out.k >= k and (not pairs or len(rands) >= k)
         stream = eng.stream
         _ffi.check(lib.caelo_pipeline_begin(self.h, stream))
         job = _ffi.FrameJob()
@@ -172,7 +173,9 @@ class Pipeline:
                 job.pc, job.n = pc.data_ptr(), pc.shape[0]
                 job.rows, job.key_pixels, job.n_key = p_rows + i * (MAX_K * 256), p_pix + i * (MAX_K * 16), p_nk + i * 4
                 job.flags, job.status = p_fl + i * (MAX_K * 3), p_st + i * 16
-                if i > 0:
+                if not pairs:
+                    job.pair = _ffi.PAIR_NONE
+                elif i > 0:
                     job.pair, job.prev_rows, job.prev_n_key = _ffi.PAIR_CHAIN, None, None
                 elif prev is not None:
                     assert prev.rows.is_contiguous()
@@ -180,7 +183,7 @@ class Pipeline:
                     job.prev_n_key = prev.n_key.data_ptr() if prev.n_key is not None else None
                 else:
                     job.pair = _ffi.PAIR_NONE
-                job.rand = rands[i].data_ptr()
+                job.rand = rands[i].data_ptr() if pairs else None
                 job.result, job.inlier_mask, job.pair_idx = p_res + i * res_sz, p_mask + i * MAX_K, p_idx + i * (MAX_K * 8)
                 _ffi.check(submit(self.h, ref))
         finally:

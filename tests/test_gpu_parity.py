@@ -364,6 +364,10 @@ def test_pipeline_equals_single_stream_calls(engine, scans, lanes):
             res, mask, idx = ref_pose[i]
             assert torch.equal(batch.pair_idx[i], idx) and torch.equal(batch.inlier_mask[i], mask), i
             assert torch.equal(batch.result[i], res), i
+    # extraction only (BASELINE configs[1]): same rows, no pair work at all
+    batch = pipe.run(pcs[:4], pairs=False)
+    torch.cuda.synchronize()
+    assert all(torch.equal(batch.rows[i], ref[i].rows) for i in range(4)) and int(batch.result.sum().item()) == 0
     # no pair for the first frame when no predecessor is given
     batch = pipe.run(pcs[:2], rnd[:2])
     torch.cuda.synchronize()
