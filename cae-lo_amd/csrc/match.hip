@@ -392,7 +392,9 @@ __device__ inline int rigid_from_H(const double H[9], const double m0[3], const 
             if (!(fabs(det) > 1e-9 * nx * sqrt(nx))) { ok = false; break; }
         }
         const double inv = 1.0 / det;
-        const double g = sqrt(sqrt(nc) * fabs(inv) / sqrt(nx));  // gamma = sqrt(|X^-1|_F / |X|_F)
+        // gamma = sqrt(|X^-1|_F / |X|_F) only steers the convergence speed (any positive scaling has the same fixed
+        // point, the polar factor): single precision is plenty and saves three f64 sqrt + one f64 divide per sweep
+        const double g = (double)sqrtf(sqrtf((float)nc) * fabsf((float)inv) / sqrtf((float)nx));
         const double a = 0.5 * g, b = 0.5 * inv / g;
         double delta = 0.0;
 #pragma unroll
