@@ -382,6 +382,51 @@ class Engine:
         _ffi.check(self.lib.caelo_encode(self.ctx, _ptr(bits), n, group, _ptr(out), 20 * group, _ptr(ws), self.stream))
         return out
 
+    # ---- BASELINE.json configs[4]: 32^3 patches (stress case, not a reference code path; csrc/config5.hip) -----
+    @staticmethod
+    def seeded_dense1_32(seed=5):
+        """The stand-in dense_1 of the 32^3 encoder: N(0, 1/16384) [16384,200] f32 and a zero bias (SURVEY.md
+        section 7 item 7 -- no trained weights exist at this size)."""
+        import numpy as np
+        rs = np.random.RandomState(seed)
+        return (rs.standard_normal((16384, 200)) / 128.0).astype(np.float32), np.zeros(200, np.float32)
+
+    def set_encoder32_dense(self, wd1, bd1):
+        import numpy as np
+        wd1 = np.ascontiguousarray(wd1, np.float32)
+        bd1 = np.ascontiguousarray(bd1, np.float32)
+        assert wd1.shape == (16384, 200) and bd1.shape == (200,)
+        _ffi.check(self.lib.caelo_set_encoder32_dense(self.ctx, _hptr(wd1), _hptr(bd1)))
+
+    def patches32(self, vmap, pts, n_key=None):
+        """-> bits [K,3,512] int64: bit-packed 32^3 patches, window [-16,16)^3, no 496-NN cap."""
+        assert pts.dtype == torch.float32 and pts.dim() == 2 and pts.stride(1) == 1 and pts.shape[1] >= 3
+        k = pts.shape[0]
+        bits = self.empty((k, 3, 512), torch.int64)
+        _ffi.check(self.lib.caelo_patches32(self.ctx, vmap.h, _ptr(pts), int(pts.stride(0)), k, _ptr(n_key), _ptr(bits),
+                                            self.stream))
+        return bits
+
+    def encode32(self, bits, group=1):
+        """bits [..., 512] int64 -> features [n/group, 20*group] f32."""
+        assert bits.dtype == torch.int64 and bits.is_contiguous()
+        n = bits.numel() // 512
+        assert n % group == 0
+        out = self.empty((n // group, 20 * group), torch.float32)
+        ws = self._ws("encode32", int(self.lib.caelo_encode32_ws_bytes(n)))
+        _ffi.check(self.lib.caelo_encode32(self.ctx, _ptr(bits), n, group, _ptr(out), 20 * group, _ptr(ws), self.stream))
+        return out
+
+    def extract32(self, pc, dist_channels=5):
+        """Config-5 frame features: the key points of ``extract`` (project -> response -> top-K rule), described by
+        32^3 patches instead of 16^3 ones.  Staged calls; the 16^3 descriptors ``extract`` also produced are
+        overwritten in the rows."""
+        ff = self.extract(pc, dist_channels, vmap=self.voxmap(max(self.max_points, pc.shape[0])))
+        vmap = self.voxmap(max(self.max_points, pc.shape[0]))
+        bits = self.patches32(vmap, ff.key_pts, ff.n_key)
+        ff.rows[:, 0:60] = self.encode32(bits, group=3)
+        return ff
+
     def encode_profile(self, bits, group=1):
         """encode + per-kernel HIP-event timings (ms): stage1, conv3, dense1, head.  Synchronises."""
         n = bits.numel() // 64

@@ -56,6 +56,7 @@ struct caelo_ctx {
     float *enc_bd1;  // [208]
     float *enc_wd2;  // [200][20]
     float *enc_bd2;  // [20]
+    float *enc32_wd1;  // [16384][208] | bias [208]: dense_1 of the 32^3 stress case (config5.hip), null until set
     bool has_enc;
 };
 
@@ -127,6 +128,9 @@ struct caelo_enc_out {
 };
 int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, const caelo_enc_out &outs,
                       int out_stride, void *ws, hipStream_t s, hipEvent_t *ev);
+int64_t enc_dense32_part_bytes(int64_t np);
+int enc_dense32_head_launch(caelo_ctx *c, const float *f3, int64_t n_patches, int64_t np, float *part, int group, float *out,
+                            int out_stride, hipStream_t s);
 int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride, void *ws,
                 hipStream_t s, hipEvent_t *ev);
 

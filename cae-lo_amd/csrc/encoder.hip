@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(256) k_enc_conv3(const float *__restrict__ p2,
 #endif
 #define D1_BK 32
 #define D1_SPLIT 8
-#define D1_KCHUNK (DENSE_K / D1_SPLIT)
+#define D1_KCHUNK (KTOT / D1_SPLIT)  // KTOT: template parameter of k_enc_dense1 (2048; 16384 for the 32^3 stress case)
 #define D1_THREADS 512
 #define D1_APITCH 34  // conflict-free ds_read_b32 of A[m][k]: 16 rows x 2 k per 32-lane group -> banks 2 row + k
 #define D1_MT (D1_BM / 16)
@@ -533,6 +533,7 @@ __global__ void __launch_bounds__(256) k_enc_conv3(const float *__restrict__ p2,
 // The 39 output tiles are dealt round-robin to the 8 waves (5,5,5,5,5,5,5,4); a wave reads the A and B fragment of
 // each of its tiles straight from LDS (offsets are wave-uniform), accumulators are static.  Stages are double
 // buffered in LDS: the next stage is fetched into registers during the MFMAs and stored to the other buffer.
+template <int KTOT>
 __global__ void __launch_bounds__(D1_THREADS, D1_BM == 96 ? 1 : 2) k_enc_dense1(const float *__restrict__ f3, int64_t n_rows_pad,
                                                            const float *__restrict__ wd1p, float *__restrict__ part) {
     __shared__ __attribute__((aligned(16))) float As[2][D1_BM * D1_APITCH];
@@ -570,7 +571,7 @@ __global__ void __launch_bounds__(D1_THREADS, D1_BM == 96 ? 1 : 2) k_enc_dense1(
         _Pragma("unroll") for (int r = 0; r < D1_SLOTS; ++r) {                                                    \
             const int u = tid + r * D1_THREADS;                                                                   \
             if (!D1_SLOT_OK(r)) continue;                                                                         \
-            if (D1_SLOT_IS_A(r)) pre[r] = *(const float4 *)(f3 + (size_t)(row0 + (u >> 3)) * DENSE_K + (K0) + (u & 7) * 4); \
+            if (D1_SLOT_IS_A(r)) pre[r] = *(const float4 *)(f3 + (size_t)(row0 + (u >> 3)) * KTOT + (K0) + (u & 7) * 4); \
             else pre[r] = *(const float4 *)(wd1p + (size_t)(K0) * DENSE_NP + (size_t)(u - D1_A4) * 4);           \
         }                                                                                                         \
     }
@@ -725,13 +726,29 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[2], s));
     dim3 gd((unsigned)(np / D1_BM), D1_SPLIT);
-    k_enc_dense1<<<gd, D1_THREADS, 0, s>>>(f3, np, c->enc_wd1, part);
+    k_enc_dense1<DENSE_K><<<gd, D1_THREADS, 0, s>>>(f3, np, c->enc_wd1, part);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[3], s));
     k_enc_head<<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(part, n_patches, np, c->enc_bd1, c->enc_wd2, c->enc_bd2,
                                                                 group, outs, out_stride);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[4], s));
+    return CAELO_OK;
+}
+
+// Dense(200) + Dense(20) of the 32^3 stress case (config5.hip): the same two kernels over K = 16384
+int64_t enc_dense32_part_bytes(int64_t np) { return (int64_t)D1_SPLIT * np * DENSE_NP * (int64_t)sizeof(float); }
+int enc_dense32_head_launch(caelo_ctx *c, const float *f3, int64_t n_patches, int64_t np, float *part, int group, float *out,
+                            int out_stride, hipStream_t s) {
+    dim3 gd((unsigned)(np / D1_BM), D1_SPLIT);
+    k_enc_dense1<16384><<<gd, D1_THREADS, 0, s>>>(f3, np, c->enc32_wd1, part);
+    CAELO_LAUNCH_CHECK();
+    caelo_enc_out outs = {};
+    outs.base[0] = out;
+    outs.per_frame = n_patches;
+    k_enc_head<<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(part, n_patches, np, c->enc32_wd1 + (size_t)16384 * DENSE_NP, c->enc_wd2,
+                                                                c->enc_bd2, group, outs, out_stride);
+    CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }
 

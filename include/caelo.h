@@ -125,6 +125,22 @@ int64_t caelo_encode_ws_bytes(int64_t n_patches);
 int caelo_encode(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
                  void *ws, void *stream);
 
+/* ---- BASELINE.json configs[4]: 32^3 patches (a stress case of this repo, NOT a reference code path) ----------
+ * The reference has PatchSize = 16 only (Voxel.py:31-33).  These three entry points keep GetPatchesList's rule
+ * (Voxel.py:177-216: key voxel in f64, wrap-around placement) with the window [-16,16)^3 and the 496-NN cap
+ * disabled, and the encoder's layer stack (Match.py:130-135) on 32^3 inputs: Flatten is 16384 wide, so dense_1
+ * is a caller-supplied [16384][200] matrix (host pointers, like caelo_set_encoder_weights; conv kernels, biases
+ * and dense_2 are the ones already set).
+ * bits [k_max][3][512] u64: voxel (ix,iy,iz) at bit (lin & 63) of word (lin >> 6), lin = (ix*32 + iy)*32 + iz.
+ * caelo_encode32: bits [n_patches][512] -> out[(p / group) * out_stride + (p % group) * 20 + j]; ws of
+ * caelo_encode32_ws_bytes(n_patches) bytes (no initialisation needed). */
+int caelo_patches32(caelo_ctx *ctx, const caelo_voxmap *map, const float *pts, int pts_ld, int64_t k_max,
+                    const int32_t *n_key, uint64_t *bits, void *stream);
+int caelo_set_encoder32_dense(caelo_ctx *ctx, const float *wd1, const float *bd1);
+int64_t caelo_encode32_ws_bytes(int64_t n_patches);
+int caelo_encode32(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
+                   void *ws, void *stream);
+
 /* caelo_encode with a HIP event between its four kernels (stage1 = conv1+pool1+conv2+pool2, conv3,
  * dense1, head) on the launch stream; synchronises, writes the durations in ms to ms_host[4]. */
 int caelo_encode_profile(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches, int group, float *out,

@@ -472,6 +472,85 @@ ORC_EXPORT void orc_encode(const uint64_t *bits, int64_t n, const orc_enc_weight
     }
 }
 
+/* ---- BASELINE.json configs[4]: the "2x voxel-patch resolution" stress case -----
+ * NOT a reference code path: the reference has PatchSize=16 only (Voxel.py:31-33).  Config 5 keeps
+ * GetPatchesList's rule (Voxel.py:177-216) with PatchSize=32: window [-16,16)^3 around the key voxel,
+ * wrap-around placement d mod 32 (:213-214), and the 496-nearest cap DISABLED (a 32^3 window holds up
+ * to 32768 voxels; n_neighbors=496 would truncate nearly every dense patch, and the cap's tie order is
+ * sklearn-defined) -- every occupied voxel inside the window is set.
+ * bits: [K][512] u64 for ONE scale; patch[ix][iy][iz] at bit (lin & 63) of word (lin >> 6),
+ * lin = (ix*32 + iy)*32 + iz. */
+ORC_EXPORT int orc_patches32(const float *pts, int64_t k, const int16_t *vox, int64_t nvox, int scale,
+                             uint64_t *bits) {
+    const double vs = scale == 0 ? VOX_SIZE : (scale == 1 ? VOX_SIZE * 8 : VOX_SIZE * 32);
+    uint64_t *keys = (uint64_t *)malloc(sizeof(uint64_t) * (nvox + 1));
+    for (int64_t i = 0; i < nvox; ++i) keys[i] = pack3(vox[3 * i], vox[3 * i + 1], vox[3 * i + 2]);
+    qsort(keys, nvox, sizeof(uint64_t), cmp_u64);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t p = 0; p < k; ++p) {
+        const int kx = (int)(((double)pts[3 * p] + VIS_L) / vs);
+        const int ky = (int)(((double)pts[3 * p + 1] + VIS_W) / vs);
+        const int kz = (int)(((double)pts[3 * p + 2] + VIS_H) / vs);
+        uint64_t *w = bits + p * 512; memset(w, 0, 512 * sizeof(uint64_t));
+        for (int dx = -16; dx < 16; ++dx) for (int dy = -16; dy < 16; ++dy) {
+            const int x = kx + dx, y = ky + dy;
+            if (x < 0 || y < 0) continue;
+            int zlo = kz - 16; if (zlo < 0) zlo = 0;
+            if (kz + 15 < 0) continue;
+            const uint64_t klo = pack3(x, y, zlo), khi = pack3(x, y, kz + 15);
+            for (int64_t i = lower_bound_u64(keys, nvox, klo); i < nvox && keys[i] <= khi; ++i) {
+                const int dz = (int)(keys[i] & 0xfffff) - kz;
+                const int lin = ((dx & 31) << 10) | ((dy & 31) << 5) | (dz & 31);
+                w[lin >> 6] |= 1ULL << (lin & 63);
+            }
+        }
+    }
+    free(keys);
+    return 0;
+}
+
+/* Config-5 encoder: the same layer stack as orc_encode on a 32^3 patch -- Conv3D(1->8) tanh, MaxPool2
+ * (16^3), Conv3D(8->16) tanh, MaxPool2 (8^3), Conv3D(16->32) tanh, Flatten (8*8*8*32 = 16384),
+ * Dense(200) tanh, Dense(20) tanh.  Conv kernels, dense_2 and all biases come from the .h5; W->wd1 is
+ * the seeded stand-in [16384][200] (no trained dense_1 exists at this size). */
+ORC_EXPORT void orc_encode32(const uint64_t *bits, int64_t n, const orc_enc_weights_t *W, float *out,
+                             int out_stride, int col0) {
+#pragma omp parallel
+    {
+        float *p0 = (float *)malloc(sizeof(float) * 32768);
+        float *a1 = (float *)malloc(sizeof(float) * 32768 * 8);
+        float *q1 = (float *)malloc(sizeof(float) * 4096 * 8);
+        float *a2 = (float *)malloc(sizeof(float) * 4096 * 16);
+        float *q2 = (float *)malloc(sizeof(float) * 512 * 16);
+        float *a3 = (float *)malloc(sizeof(float) * 512 * 32);
+        float h[200];
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t p = 0; p < n; ++p) {
+            const uint64_t *w = bits + p * 512;
+            for (int lin = 0; lin < 32768; ++lin) p0[lin] = (float)((w[lin >> 6] >> (lin & 63)) & 1);
+            conv3d_same(p0, 32, 1, W->w1, W->b1, 8, a1);
+            maxpool2(a1, 32, 8, q1);
+            conv3d_same(q1, 16, 8, W->w2, W->b2, 16, a2);
+            maxpool2(a2, 16, 16, q2);
+            conv3d_same(q2, 8, 16, W->w3, W->b3, 32, a3);
+            for (int j = 0; j < 200; ++j) h[j] = W->bd1[j];
+            for (int i = 0; i < 16384; ++i) {
+                const float v = a3[i];
+                const float *row = W->wd1 + (int64_t)i * 200;
+                for (int j = 0; j < 200; ++j) h[j] += v * row[j];
+            }
+            for (int j = 0; j < 200; ++j) h[j] = tanhf(h[j]);
+            float *o = out + p * out_stride + col0;
+            for (int j = 0; j < 20; ++j) {
+                float acc = W->bd2[j];
+                for (int i = 0; i < 200; ++i) acc += h[i] * W->wd2[i * 20 + j];
+                o[j] = tanhf(acc);
+            }
+        }
+        free(p0); free(a1); free(q1); free(a2); free(q2); free(a3);
+    }
+}
+
 /* ---- NN match: Match.py:257-258  cdist(Codes0,Codes1) f64 + argmin(axis=0), first min wins.
  * SciPy's euclidean kernel: sequential f64 sum of squared differences, sqrt. */
 ORC_EXPORT void orc_match(const float *f0, int64_t k0, const float *f1, int64_t k1, int dim, int64_t *pair_idx,

@@ -248,6 +248,43 @@ class PatchEncoder:
         return self.predict_bits(pack_patches(patches))
 
 
+# ---- BASELINE.json configs[4]: 32^3 patches (not a reference code path; see caelo_oracle.c) ----------
+def patches32_bits(Pts, AllVoxels, scale):
+    """Config 5: GetPatchesList's rule (Voxel.py:177-216) with PatchSize=32 and the 496-NN cap disabled ->
+    bit-packed patches [K,512] u64, lin = (ix*32+iy)*32+iz at bit lin&63 of word lin>>6."""
+    Pts = np.ascontiguousarray(Pts, dtype=np.float32)
+    vox = np.ascontiguousarray(AllVoxels, dtype=np.int16)
+    bits = np.zeros((Pts.shape[0], 512), dtype=np.uint64)
+    lib().orc_patches32(_p(Pts), C.c_int64(Pts.shape[0]), _p(vox), C.c_int64(vox.shape[0]), C.c_int(scale),
+                        _p(bits))
+    return bits
+
+
+def unpack_patches32(bits):
+    """[K,512] u64 -> [K,32,32,32,1] f32."""
+    b = np.ascontiguousarray(bits, dtype="<u8").view(np.uint8).reshape(bits.shape[0], 4096)
+    return np.unpackbits(b, axis=1, bitorder="little").reshape(bits.shape[0], 32, 32, 32, 1).astype(np.float32)
+
+
+class PatchEncoder32:
+    """Config-5 encoder: PatchEncoder's conv kernels, biases and dense_2 with ``dense1`` [16384,200] as the
+    first dense layer (seeded stand-in -- no trained weights exist at this size)."""
+
+    def __init__(self, weights, dense1, bias1):
+        self.w = [np.ascontiguousarray(a, np.float32) for a in weights]
+        self.w[6] = np.ascontiguousarray(dense1, np.float32)
+        self.w[7] = np.ascontiguousarray(bias1, np.float32)
+        assert self.w[6].shape == (16384, 200) and self.w[7].shape == (200,)
+        self._s = _EncW(*[a.ctypes.data for a in self.w])
+
+    def predict_bits(self, bits):
+        bits = np.ascontiguousarray(bits, dtype=np.uint64)
+        assert bits.shape[1] == 512
+        out = np.empty((bits.shape[0], 20), dtype=np.float32)
+        lib().orc_encode32(_p(bits), C.c_int64(bits.shape[0]), C.byref(self._s), _p(out), C.c_int(20), C.c_int(0))
+        return out
+
+
 def GetFeaturesFromPatches(PatchEncoder_, PatchesList):
     """Match.py:130-135."""
     return np.c_[PatchEncoder_.predict(PatchesList[0]), PatchEncoder_.predict(PatchesList[1]),

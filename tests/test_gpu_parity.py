@@ -516,3 +516,65 @@ def test_icp_vs_reference_golden(api, orc, models, scans):
     far = pc1 + np.float32(1000.0)
     R, T, ok = api.ICP(ext[0], far)
     assert ok is False and np.array_equal(R, np.eye(3)) and not T.any()
+
+
+# ---- BASELINE.json configs[4]: 128-beam dense scan, 32^3 patches (stress case; parity vs the oracle only) ------------
+def test_config5_dense_scan_32cube_patches_and_descriptors(engine, api, orc, models, scans):
+    import torch
+    pc = scans(0, 128, 4000)
+    assert pc.shape[0] > 400000
+    ring, cnt = api.ProjectPC2SphericalRing(pc)
+    resp = api.load_model(os.path.join(WEIGHTS, "SphericalRingPCRespondLayer.h5")).predict(
+        np.ascontiguousarray(ring[0:64, 0:1792, 0:3]).reshape(1, 64, 1792, 3))[0]
+    key_pts = np.ascontiguousarray(api.GetKeyPtsByAE(ring, cnt, resp)[0], np.float32)
+    assert key_pts.shape == (1024, 3)
+    A = api.Voxelization(pc[:, 0:3])[6:9]                      # pinned to the reference by the dense-scan golden test
+    vmap, st = engine.voxelize(torch.from_numpy(pc).to(engine.device))
+    bits = engine.patches32(vmap, torch.from_numpy(key_pts).to(engine.device))
+    assert int(st.item()) == 0 and bits.shape == (1024, 3, 512)
+    hb = bits.cpu().numpy().view(np.uint64)
+    pop = []
+    for s in range(3):
+        ob = orc.patches32_bits(key_pts, A[s], s)
+        assert np.array_equal(hb[:, s], ob), "scale %d" % s   # bit-exact
+        pop.append(int(np.unpackbits(ob.view(np.uint8)).sum()))
+    assert min(pop) > 1024                                      # real content at every scale
+    # the 16^3 window is the wrapped centre of the 32^3 one wherever the 496-NN cap does not bite
+    b16, fl = engine.patches(vmap, torch.from_numpy(key_pts).to(engine.device))
+    d32 = orc.unpack_patches32(hb[:64, 2])[..., 0]
+    d16 = orc.unpack_patches(b16[:64, 2].cpu().numpy().view(np.uint64))[..., 0]
+    idx = np.r_[0:8, 24:32]
+    sub = d32[:, idx][:, :, idx][:, :, :, idx]
+    ok = fl[:64, 2].cpu().numpy() == 0
+    assert ok.any() and np.array_equal(sub[ok], d16[ok])
+    # descriptors: every patch on the GPU, a strided subset through the oracle
+    wd1, bd1 = engine.seeded_dense1_32()
+    engine.set_encoder32_dense(wd1, bd1)
+    feats = engine.encode32(bits, group=3)
+    assert feats.shape == (1024, 60)
+    pick = np.arange(0, 1024, 16)
+    enc32 = orc.PatchEncoder32(models[1].w, wd1, bd1)
+    of = np.concatenate([enc32.predict_bits(hb[pick, s]) for s in range(3)], axis=1)
+    gf = feats.cpu().numpy()
+    assert np.isfinite(gf).all() and np.abs(gf).max() < 1.0
+    err = np.abs(gf[pick] - of).max() / np.abs(of).max()
+    assert err <= REL_TOL, err
+    assert np.abs(of).std() > 1e-3                              # not saturated / degenerate
+    f1 = engine.encode32(bits[pick].contiguous(), group=3)      # batch composition never matters, bitwise
+    assert torch.equal(f1, feats[torch.from_numpy(pick).to(engine.device)])
+
+
+def test_config5_pose_from_32cube_descriptors(engine, scans):
+    """End of the config-5 path: two 128-beam frames, 32^3 descriptors, the unchanged match + RANSAC -> the motion the
+    scene generator applied (no reference/oracle pose exists for this configuration)."""
+    import torch
+    from caelo import synth
+    from caelo.engine import ransac_draws
+    engine.set_encoder32_dense(*engine.seeded_dense1_32())
+    ff = [engine.extract32(torch.from_numpy(scans(i, 128, 4000)).to(engine.device)) for i in (0, 1)]
+    assert int(ff[0].status[0].item()) == 0 and int(ff[1].status[0].item()) == 0
+    res, mask, idx = engine.match_pose(ff[0], ff[1], torch.from_numpy(ransac_draws(0)).to(engine.device))
+    r = engine.pose_result(res)
+    R, T = synth.relative_pose_gt(0, 1)
+    assert r.success == 1 and r.n_inliers >= 200
+    assert np.abs(np.array(r.R).reshape(3, 3) - R).max() < 5e-3 and np.abs(np.array(r.T).reshape(3, 1) - T).max() < 0.05
