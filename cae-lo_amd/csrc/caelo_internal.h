@@ -52,6 +52,7 @@ struct caelo_ctx {
     float *enc_c0;   // [512][16] conv2 response of the all-background patch incl. bias, then bg[8]
     float *enc_w3;   // [27][16][32]
     float *enc_b3;   // [32]
+    void *enc_w3x;   // W3 as the conv3 kernel's B operand: [ntile 2][tap pair 14][bf16 split 3][lane 64] x 16 B
     float *enc_wd1;  // [2048][208] (N padded 200 -> 208 with zeros)
     float *enc_bd1;  // [208]
     float *enc_wd2;  // [200][20]

@@ -20,6 +20,7 @@
 // K = 16384 (k_enc_dense1<16384>, encoder.hip).  Dense scans leave little of the sparsity the 16^3 stage-1 kernel
 // lives on, so nothing is skipped here.  See DESIGN.md section 4.5 for measured times.
 #include <math.h>
+#include <stdlib.h>
 
 #include "caelo_internal.h"
 
@@ -244,6 +245,138 @@ __global__ void __launch_bounds__(256, POOL ? 3 : 2) k5_conv_mfma(const float *_
 #undef C5_OFF
 }
 
+// ---- conv3 with f32 products evaluated on the bf16 matrix pipe (3-way operand split) ------------------------------------
+// v_mfma_f32_16x16x32_bf16 retires 16x the FLOPs per cycle of the f32-input MFMA.  An f32 value splits exactly into
+// three bf16 terms, x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (both differences
+// are exact in f32; |x - hi - mid - lo| <= 2^-27 |x|), and a product a b is the sum of the six partial products
+// a_hi b_hi + a_hi b_mid + a_mid b_hi + a_mid b_mid + a_hi b_lo + a_lo b_hi up to 2^-27 |a b| -- below the 2^-24
+// rounding of an f32 multiply.  Each partial product of two bf16 is exact in f32 and the MFMA accumulates in f32, so
+// the result is f32-grade at 6/16 of the f32 MFMA's time.
+// Layout: the activations are split ONCE, when the x slab is staged in LDS: per split and channel half h (8 channels)
+// an array [pos][8] bf16, so a lane's ds_read_b128 is one position's 8 channels and 16 lanes read 256 contiguous
+// bytes; an m-tile is 8 z of two x planes, and the plane pitch (104 positions) puts the two 128-byte runs on
+// complementary bank halves.  K = 32 per instruction = two taps x 16 channels: lanes g < 2 carry tap A of the pair,
+// lanes g >= 2 tap B.  Taps are paired so that B - A is one of three constant position offsets (+1 z, +1 y, +1 x);
+// the upper lanes fold that offset into their base address and every other offset is an instruction immediate.
+typedef __bf16 c5_bf16x8 __attribute__((ext_vector_type(8)));
+#define X3_PLANE 104                 // positions per padded x plane (10 x 10 used)
+#define X3_NPOS (6 * X3_PLANE)       // 4 output planes + 2 halo planes
+#define X3_ARR (X3_NPOS * 16)        // bytes of one (split, half) array
+#define X3_NPAIR 14
+
+__device__ inline uint32_t c5_bf16_rne(float x) {  // bf16(x) as the high half of an f32 bit pattern
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+}
+__device__ inline void c5_split3(float x, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
+    hi = c5_bf16_rne(x);
+    const float r = x - __uint_as_float(hi);
+    mid = c5_bf16_rne(r);
+    lo = c5_bf16_rne(r - __uint_as_float(mid));
+}
+// tap pairs (A, B) with B - A in {+1 z, +1 y, +1 x}; class 3 = no partner (B operand zero)
+__device__ constexpr int c5_pairA(int p) { return p < 9 ? p * 3 : (p < 12 ? (p - 9) * 9 + 2 : (p == 12 ? 8 : 26)); }
+__device__ constexpr int c5_pairClass(int p) { return p < 9 ? 0 : (p < 12 ? 1 : (p == 12 ? 2 : 3)); }
+__device__ constexpr int c5_pairB(int p) { return p < 9 ? p * 3 + 1 : (p < 12 ? (p - 9) * 9 + 5 : (p == 12 ? 17 : -1)); }
+__device__ constexpr int c5_tapPos(int t) { return (t / 9) * X3_PLANE + ((t / 3) % 3) * 10 + (t % 3); }
+
+__global__ void __launch_bounds__(256, 2) k5_conv3_x3(const float *__restrict__ in, const float *__restrict__ w,
+                                                      const float *__restrict__ b, float *__restrict__ out, int n_items) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [split 3][half 2][X3_NPOS][8] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, g = lane >> 4;
+    const int nt = wave >> 1, xpair = wave & 1;
+    // B operand: pair p, split s: 8 bf16 = channels 8 (g & 1) .. + 7 of tap (g < 2 ? A : B), column nt * 16 + m
+    uint4 bq[X3_NPAIR][3];
+#pragma unroll
+    for (int p = 0; p < X3_NPAIR; ++p) {
+        const int tap = g < 2 ? c5_pairA(p) : c5_pairB(p);
+        uint32_t h[8], mi[8], lo[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v = tap >= 0 ? w[(size_t)(tap * 16 + 8 * (g & 1) + i) * 32 + nt * 16 + m] : 0.0f;
+            c5_split3(v, h[i], mi[i], lo[i]);
+        }
+#define C5_PK(A) make_uint4((A[0] >> 16) | A[1], (A[2] >> 16) | A[3], (A[4] >> 16) | A[5], (A[6] >> 16) | A[7])
+        bq[p][0] = C5_PK(h);
+        bq[p][1] = C5_PK(mi);
+        bq[p][2] = C5_PK(lo);
+    }
+    const float bias = b[nt * 16 + m];
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int64_t patch = item >> 1;
+        const int xb = item & 1;
+        const float *src = in + (size_t)patch * 512 * 16;
+        __syncthreads();
+        for (int i = tid; i < X3_NPOS * 2; i += 256) {  // (position, channel half)
+            const int h = i & 1, pos = i >> 1;
+            const int xl = pos / X3_PLANE, rem = pos % X3_PLANE;
+            const int x = xb * 4 - 1 + xl, y = rem / 10 - 1, z = rem % 10 - 1;
+            uint32_t hh[8], mm[8], ll[8];
+            if (rem < 100 && x >= 0 && x < 8 && y >= 0 && y < 8 && z >= 0 && z < 8) {
+                const float4 *q = (const float4 *)(src + (((size_t)x * 8 + y) * 8 + z) * 16 + 8 * h);
+                const float4 v0 = q[0], v1 = q[1];
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c5_split3(v[k], hh[k], mm[k], ll[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) hh[k] = mm[k] = ll[k] = 0u;
+            }
+            *(uint4 *)(lds + (0 * 2 + h) * X3_ARR + pos * 16) = C5_PK(hh);
+            *(uint4 *)(lds + (1 * 2 + h) * X3_ARR + pos * 16) = C5_PK(mm);
+            *(uint4 *)(lds + (2 * 2 + h) * X3_ARR + pos * 16) = C5_PK(ll);
+        }
+        __syncthreads();
+        // m-tile (xpair, y): lane m -> output (x = 2 xpair + (m >> 3), y, z = m & 7); padded corner of its taps
+        const int pos0 = (2 * xpair + (m >> 3)) * X3_PLANE + (m & 7);
+        const unsigned char *base = lds + (g & 1) * X3_ARR + pos0 * 16;
+        const unsigned char *ab[4] = {base + (g >= 2 ? 1 * 16 : 0), base + (g >= 2 ? 10 * 16 : 0),
+                                      base + (g >= 2 ? X3_PLANE * 16 : 0), base};
+        for (int round = 0; round < 4; ++round) {
+            c5_f32x4 acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = (c5_f32x4){bias, bias, bias, bias};
+#pragma unroll
+            for (int p = 0; p < X3_NPAIR; ++p) {
+                const c5_bf16x8 bh = __builtin_bit_cast(c5_bf16x8, bq[p][0]), bm = __builtin_bit_cast(c5_bf16x8, bq[p][1]),
+                                bl = __builtin_bit_cast(c5_bf16x8, bq[p][2]);
+                c5_bf16x8 ah[2], am[2], al[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned char *a = ab[c5_pairClass(p)] + (c5_tapPos(c5_pairA(p)) + (round * 2 + j) * 10) * 16;
+                    ah[j] = __builtin_bit_cast(c5_bf16x8, *(const uint4 *)(a));
+                    am[j] = __builtin_bit_cast(c5_bf16x8, *(const uint4 *)(a + 2 * X3_ARR));
+                    al[j] = __builtin_bit_cast(c5_bf16x8, *(const uint4 *)(a + 4 * X3_ARR));
+                }
+                // smallest terms first; the two accumulators alternate so that no MFMA waits for its predecessor
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[j], bh, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], bl, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[j], bm, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[j], bh, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], bm, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], bh, acc[j], 0, 0, 0);
+            }
+            // C row 4 g + r of tile j: output (x = xb*4 + 2 xpair + (row >> 3), y = round*2 + j, z = row & 7)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * g + r;
+                    const int x = xb * 4 + 2 * xpair + (row >> 3), y = round * 2 + j, z = row & 7;
+                    out[((((size_t)patch * 8 + x) * 8 + y) * 8 + z) * 32 + nt * 16 + m] = c5_tanh(acc[j][r]);
+                }
+        }
+    }
+#undef C5_PK
+}
+
 // ---- C ABI -------------------------------------------------------------------------------------------------------
 CAELO_API int caelo_patches32(caelo_ctx *c, const caelo_voxmap *m, const float *pts, int pts_ld, int64_t k_max,
                               const int32_t *n_key, uint64_t *bits, void *stream) {
@@ -297,7 +430,9 @@ CAELO_API int caelo_encode32(caelo_ctx *c, const uint64_t *bits, int64_t n_patch
     const int items2 = (int)(n_patches * 8), items3 = (int)(n_patches * 2);
     k5_conv_mfma<16, 8, 16, true><<<items2 < 768 ? items2 : 768, 256, 0, s>>>(p1, c->enc_w2, c->enc_b2, p2, items2);
     CAELO_LAUNCH_CHECK();
-    k5_conv_mfma<8, 16, 32, false><<<items3 < 512 ? items3 : 512, 256, 0, s>>>(p2, c->enc_w3, c->enc_b3, f3, items3);
+    static const bool x3 = !(getenv("CAELO_C5_F32") && atoi(getenv("CAELO_C5_F32")));
+    if (x3) k5_conv3_x3<<<items3 < 512 ? items3 : 512, 256, 6 * X3_ARR, s>>>(p2, c->enc_w3, c->enc_b3, f3, items3);
+    else k5_conv_mfma<8, 16, 32, false><<<items3 < 512 ? items3 : 512, 256, 0, s>>>(p2, c->enc_w3, c->enc_b3, f3, items3);
     CAELO_LAUNCH_CHECK();
     return enc_dense32_head_launch(c, f3, n_patches, np, part, group, out, out_stride, s);
 }

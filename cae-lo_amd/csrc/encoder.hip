@@ -46,6 +46,8 @@ __device__ inline float enc_tanh(float x) {
 #define DENSE_N 200
 #define DENSE_NP 208  // padded to 13 MFMA n-tiles
 #define DENSE_K 2048
+#define C3X_NPAIR 14  // tap pairs of the conv3 kernel (see k_enc_conv3)
+static void conv3_split_weights(const float *w3, uint4 *out);
 
 CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const float *b1, const float *w2,
                                         const float *b2, const float *w3, const float *b3, const float *wd1,
@@ -76,6 +78,15 @@ CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const flo
         for (int ch = 0; ch < 8; ++ch) c0[512 * 16 + ch] = bg[ch];
         if (!c->enc_c0) CAELO_HIP(hipMalloc(&c->enc_c0, sizeof(c0)));
         CAELO_HIP(hipMemcpy(c->enc_c0, c0, sizeof(c0), hipMemcpyHostToDevice));
+    }
+    {
+        const size_t n = (size_t)2 * C3X_NPAIR * 3 * 64;
+        uint4 *wx = (uint4 *)malloc(n * sizeof(uint4));
+        if (!wx) { caelo_set_error("out of host memory"); return CAELO_ERR_ARG; }
+        conv3_split_weights(w3, wx);
+        if (!c->enc_w3x) CAELO_HIP(hipMalloc(&c->enc_w3x, n * sizeof(uint4)));
+        CAELO_HIP(hipMemcpy(c->enc_w3x, wx, n * sizeof(uint4), hipMemcpyHostToDevice));
+        free(wx);
     }
     float *pad = (float *)calloc((size_t)DENSE_K * DENSE_NP + DENSE_NP, sizeof(float));
     if (!pad) { caelo_set_error("out of host memory"); return CAELO_ERR_ARG; }
@@ -401,20 +412,76 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long 
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv3 (16->32) implicit GEMM: M = 64 positions/patch, N = 32, K = 27*16
+// conv3 (16->32) implicit GEMM: M = 64 positions/patch, N = 32, K = 27*16 -- f32 products on the bf16 matrix pipe
 // ------------------------------------------------------------------------------------------------
-// P2 in LDS per patch slot: four 4-channel planes; plane p, padded position q, channel c:
-//   S[p*P2_PLANE + (P2_FRONT + q)*4 + c],  q = (xp*6 + yp)*4 + z, xp,yp in 0..5 (halo), z in 0..3.
-// P2_PLANE is a multiple of 64 dwords so the two planes met by one ds_read_b128 lane group fall on
-// complementary bank halves (MI355X_MICROARCH LDS table): conflict free.
-#define P2_FRONT 8
-#define P2_PLANE (160 * 4)
-#define P2_SLOT (4 * P2_PLANE)
+// v_mfma_f32_16x16x32_bf16 retires 16x the FLOPs per cycle of the f32-input MFMA (MI355X_MICROARCH: 2.5 PF vs
+// 157 TF).  An f32 value splits EXACTLY into three bf16 terms, x = hi + mid + lo with hi = bf16(x),
+// mid = bf16(x - hi), lo = bf16(x - hi - mid) (both differences are exact in f32, |x - hi - mid - lo| <= 2^-27 |x|),
+// and a product a*b is a_hi b_hi + a_hi b_mid + a_mid b_hi + a_mid b_mid + a_hi b_lo + a_lo b_hi up to 2^-27 |a b|
+// -- below the 2^-24 rounding of an f32 multiply.  Every partial product of two bf16 is exact in f32 and the MFMA
+// accumulates in f32: the result is f32-grade (measured against the oracle in tests/) at 6/16 of the f32 MFMA's time.
+//
+// The weights are split once on the host (caelo_set_encoder_weights -> enc_w3x, already in register order), the
+// activations once per patch while P2 is staged in LDS.  LDS per patch slot: [split 3][channel half 2][pos][8] bf16
+// (16 B per position), pos = (xp*6 + yp)*8 + zp over the zero-haloed 6x6x6 volume (z pitch 8).  K = 32 per MFMA =
+// two taps x 16 channels: lanes g < 2 carry tap A of a pair, lanes g >= 2 tap B; taps are paired so that B - A is
+// one of three constant position offsets (+1 z, +1 y, +1 x), which the upper lanes fold into their base address --
+// every other offset is an instruction immediate.  An m-tile is one x plane (lane m -> y = m >> 2, z = m & 3); with
+// the z pitch of 8 and the second channel half displaced by 4 positions, each 16-lane group of a ds_read_b128
+// (MI355X_MICROARCH LDS table) touches all 64 banks once.
+#define C3X_PLANE 48                 // positions per padded x plane (6 rows of 8)
+#define C3X_ARR 292                  // positions per (split, half) array: 288 used, = 4 mod 16 (bank rotation of half 1)
+#define C3X_SPLIT (2 * C3X_ARR)
+#define C3X_SLOT (3 * C3X_SPLIT)     // positions (x 16 B) per patch slot
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// tap pairs (A, B): 9 x (kc 0,1) | 3 x (kb 0,1 at kc 2) | (ka 0,1 at kb 2, kc 2) | tap 26 alone
+__host__ __device__ constexpr int c3x_pairA(int p) { return p < 9 ? p * 3 : (p < 12 ? (p - 9) * 9 + 2 : (p == 12 ? 8 : 26)); }
+__host__ __device__ constexpr int c3x_pairB(int p) { return p < 9 ? p * 3 + 1 : (p < 12 ? (p - 9) * 9 + 5 : (p == 12 ? 17 : -1)); }
+__host__ __device__ constexpr int c3x_pairClass(int p) { return p < 9 ? 0 : (p < 12 ? 1 : (p == 12 ? 2 : 3)); }
+__host__ __device__ constexpr int c3x_tapPos(int t) { return (t / 9) * C3X_PLANE + ((t / 3) % 3) * 8 + (t % 3); }
+// x plane X never sees data through the taps of pair P (all of them read the zero halo plane): skipped exactly
+__host__ __device__ constexpr bool c3x_dead(int x, int p) {
+    return (x == 0 && c3x_pairA(p) / 9 == 0 && (c3x_pairB(p) < 0 || c3x_pairB(p) / 9 == 0)) ||
+           (x == 3 && c3x_pairA(p) / 9 == 2 && (c3x_pairB(p) < 0 || c3x_pairB(p) / 9 == 2));
+}
 
-__global__ void __launch_bounds__(256) k_enc_conv3(const float *__restrict__ p2, int64_t n_patches,
-                                                   const float *__restrict__ w3g, const float *__restrict__ b3g,
-                                                   float *__restrict__ f3, int *__restrict__ stage1_counter) {
-    __shared__ __attribute__((aligned(16))) float S[2 * P2_SLOT];
+__host__ __device__ inline uint32_t enc_bf16_rne(float x) {  // bf16(x), round to nearest even, as the high half of an f32 pattern
+    union { float f; uint32_t u; } v = {x};
+    return (v.u + 0x7FFFu + ((v.u >> 16) & 1u)) & 0xFFFF0000u;
+}
+__host__ __device__ inline float enc_bits_f32(uint32_t u) {
+    union { uint32_t u; float f; } v = {u};
+    return v.f;
+}
+__host__ __device__ inline void enc_split3(float x, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
+    hi = enc_bf16_rne(x);
+    const float r = x - enc_bits_f32(hi);
+    mid = enc_bf16_rne(r);
+    lo = enc_bf16_rne(r - enc_bits_f32(mid));
+}
+#define ENC_PK8(A) make_uint4((A[0] >> 16) | A[1], (A[2] >> 16) | A[3], (A[4] >> 16) | A[5], (A[6] >> 16) | A[7])
+
+// host: W3 [27][16][32] -> [ntile 2][pair 14][split 3][lane 64] uint4, the B operand of lane (n = lane & 15, g = lane >> 4)
+static void conv3_split_weights(const float *w3, uint4 *out) {
+    for (int nt = 0; nt < 2; ++nt)
+        for (int p = 0; p < C3X_NPAIR; ++p)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int n = lane & 15, g = lane >> 4;
+                const int tap = g < 2 ? c3x_pairA(p) : c3x_pairB(p);
+                uint32_t h[8], m[8], l[8];
+                for (int i = 0; i < 8; ++i)
+                    enc_split3(tap >= 0 ? w3[(tap * 16 + 8 * (g & 1) + i) * 32 + nt * 16 + n] : 0.0f, h[i], m[i], l[i]);
+                uint4 *o = out + ((size_t)(nt * C3X_NPAIR + p) * 3) * 64 + lane;
+                o[0] = ENC_PK8(h);
+                o[64] = ENC_PK8(m);
+                o[128] = ENC_PK8(l);
+            }
+}
+
+__global__ void __launch_bounds__(256, 2) k_enc_conv3(const float *__restrict__ p2, int64_t n_patches,
+                                                      const uint4 *__restrict__ w3x, const float *__restrict__ b3g,
+                                                      float *__restrict__ f3, int *__restrict__ stage1_counter) {
+    __shared__ uint4 S[2 * C3X_SLOT];
     // stage 1 (the previous kernel on this stream) is complete: hand its work counter back at zero, so that no
     // memset launch sits on the encoder stream's critical path
     if (blockIdx.x == 0 && threadIdx.x == 0) *stage1_counter = 0;
@@ -423,85 +490,85 @@ __global__ void __launch_bounds__(256) k_enc_conv3(const float *__restrict__ p2,
     const int wave = tid >> 6;
     const int g = lane >> 4, n = lane & 15;
     const int ntile = wave & 1, slot = wave >> 1;
-    // B fragment for k-step (tap t, h): W3[t][cin = 4g + h][16*ntile + n]
-    float breg[27][4];
+    uint4 bq[C3X_NPAIR][3];
 #pragma unroll
-    for (int t = 0; t < 27; ++t)
+    for (int p = 0; p < C3X_NPAIR; ++p)
 #pragma unroll
-        for (int h = 0; h < 4; ++h) breg[t][h] = w3g[(t * 16 + 4 * g + h) * 32 + 16 * ntile + n];
+        for (int sp = 0; sp < 3; ++sp) bq[p][sp] = w3x[((size_t)(ntile * C3X_NPAIR + p) * 3 + sp) * 64 + lane];
     const float bias = b3g[16 * ntile + n];
-    for (int i = tid; i < 2 * P2_SLOT; i += 256) S[i] = 0.0f;
+    for (int i = tid; i < 2 * C3X_SLOT; i += 256) S[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     const int64_t n_pairs = (n_patches + 1) / 2;
-    // register staging: the next pair's 2 x 4 KB are fetched while this pair's MFMAs run
+    // register staging: the next pair's 2 x 4 KB are fetched while this pair's MFMAs run; thread -> (slot, position,
+    // channel half): 8 consecutive channels
+    const int f_slot = tid >> 7, f_pos = (tid >> 1) & 63, f_h = tid & 1;
+    const int f_q = (((f_pos >> 4) + 1) * 6 + ((f_pos >> 2) & 3) + 1) * 8 + (f_pos & 3) + 1;
     float4 pre0, pre1;
-#define C3_FETCH(PAIR)                                                                                        \
-    {                                                                                                         \
-        const int64_t pr_ = (PAIR);                                                                           \
-        const int i0_ = tid, i1_ = tid + 256; /* float4 index over [slot][pos][plane], rem = pos*4 + plane */ \
-        const int64_t pa0_ = pr_ * 2 + (i0_ >> 8), pa1_ = pr_ * 2 + (i1_ >> 8);                               \
-        pre0 = make_float4(0.f, 0.f, 0.f, 0.f);                                                               \
-        pre1 = pre0;                                                                                          \
-        if (pr_ < n_pairs && pa0_ < n_patches)                                                                \
-            pre0 = *(const float4 *)(p2 + (size_t)pa0_ * 1024 + ((i0_ & 255) >> 2) * 16 + (i0_ & 3) * 4);    \
-        if (pr_ < n_pairs && pa1_ < n_patches)                                                                \
-            pre1 = *(const float4 *)(p2 + (size_t)pa1_ * 1024 + ((i1_ & 255) >> 2) * 16 + (i1_ & 3) * 4);    \
+#define C3_FETCH(PAIR)                                                                           \
+    {                                                                                            \
+        const int64_t pa_ = (PAIR) * 2 + f_slot;                                                 \
+        pre0 = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
+        pre1 = pre0;                                                                             \
+        if ((PAIR) < n_pairs && pa_ < n_patches) {                                               \
+            const float4 *q_ = (const float4 *)(p2 + (size_t)pa_ * 1024 + f_pos * 16 + 8 * f_h); \
+            pre0 = q_[0];                                                                        \
+            pre1 = q_[1];                                                                        \
+        }                                                                                        \
     }
     C3_FETCH((int64_t)blockIdx.x)
     for (int64_t pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
-        // ---- stage two patches: 2 x 64 positions x 16 channels = 512 float4, 2 per thread
+        {   // split the staged 8 channels into the three bf16 terms: 3 x 16 B into LDS
+            const float v[8] = {pre0.x, pre0.y, pre0.z, pre0.w, pre1.x, pre1.y, pre1.z, pre1.w};
+            uint32_t h[8], m[8], l[8];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int i = tid + r * 256;
-            const int sl = i >> 8, rem = i & 255;
-            const int pos = rem >> 2, pl = rem & 3;
-            const int x = pos >> 4, y = (pos >> 2) & 3, z = pos & 3;
-            const int q = ((x + 1) * 6 + (y + 1)) * 4 + z;
-            *(float4 *)&S[sl * P2_SLOT + pl * P2_PLANE + (P2_FRONT + q) * 4] = r ? pre1 : pre0;
+            for (int k = 0; k < 8; ++k) enc_split3(v[k], h[k], m[k], l[k]);
+            uint4 *d = &S[f_slot * C3X_SLOT + f_h * C3X_ARR + f_q];
+            d[0] = ENC_PK8(h);
+            d[C3X_SPLIT] = ENC_PK8(m);
+            d[2 * C3X_SPLIT] = ENC_PK8(l);
         }
         __syncthreads();
         C3_FETCH(pair + gridDim.x)
         const int64_t patch = pair * 2 + slot;
-        {
-            const int yl = n >> 2, z = n & 3;  // A row m = yl*4 + z ; m-tile index = x
-            const float *plane = S + slot * P2_SLOT + g * P2_PLANE;
-            const bool zlo = z >= 1, zhi = z <= 2;
-            f32x4 acc[4];
+        // lane (m = n, g): output (y = n >> 2, z = n & 3) of x plane X reads padded (X + ka, y + kb, z + kc)
+        const uint4 *base = &S[slot * C3X_SLOT + (g & 1) * C3X_ARR + (n >> 2) * 8 + (n & 3)];
+        const uint4 *ab[4] = {base + (g >= 2 ? 1 : 0), base + (g >= 2 ? 8 : 0), base + (g >= 2 ? C3X_PLANE : 0), base};
 #pragma unroll
-            for (int x = 0; x < 4; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int qbase = (0 * 6 + yl) * 4 + z;
-            const float *a_ptr = plane + (P2_FRONT + qbase) * 4;
+        for (int round = 0; round < 2; ++round) {
+            f32x4 acc[2];
 #pragma unroll
-            for (int t = 0; t < 27; ++t) {
-                const int ka = t / 9, kb = (t / 3) % 3, kc = t % 3;
-                const int off = ((ka * 6 + kb) * 4 + (kc - 1)) * 4;
-                // tile x reads the padded plane x + ka: planes 0 and 5 are the zero halo, their products are
-                // added zeros -- skipped (2 of the 12 (x, ka) combinations)
-#define C3_LIVE(X) (!(((X) == 0 && ka == 0) || ((X) == 3 && ka == 2)))
-                float4 a[4];
+            for (int j = 0; j < 2; ++j) acc[j] = (f32x4){bias, bias, bias, bias};
 #pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    if (!C3_LIVE(x)) continue;
-                    a[x] = *(const float4 *)(a_ptr + off + x * 24 * 4);
-                    if (kc == 0) { if (!zlo) a[x] = make_float4(0.f, 0.f, 0.f, 0.f); }
-                    if (kc == 2) { if (!zhi) a[x] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            for (int p = 0; p < C3X_NPAIR; ++p) {
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[p][0]), bm = __builtin_bit_cast(bf16x8, bq[p][1]),
+                             bl = __builtin_bit_cast(bf16x8, bq[p][2]);
+                bf16x8 ah[2], am[2], al[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (c3x_dead(2 * round + j, p)) continue;
+                    const uint4 *a = ab[c3x_pairClass(p)] + c3x_tapPos(c3x_pairA(p)) + (2 * round + j) * C3X_PLANE;
+                    ah[j] = __builtin_bit_cast(bf16x8, a[0]);
+                    am[j] = __builtin_bit_cast(bf16x8, a[C3X_SPLIT]);
+                    al[j] = __builtin_bit_cast(bf16x8, a[2 * C3X_SPLIT]);
                 }
-#pragma unroll
-                for (int x = 0; x < 4; ++x) if (C3_LIVE(x)) acc[x] = MFMA16(a[x].x, breg[t][0], acc[x]);
-#pragma unroll
-                for (int x = 0; x < 4; ++x) if (C3_LIVE(x)) acc[x] = MFMA16(a[x].y, breg[t][1], acc[x]);
-#pragma unroll
-                for (int x = 0; x < 4; ++x) if (C3_LIVE(x)) acc[x] = MFMA16(a[x].z, breg[t][2], acc[x]);
-#pragma unroll
-                for (int x = 0; x < 4; ++x) if (C3_LIVE(x)) acc[x] = MFMA16(a[x].w, breg[t][3], acc[x]);
+                // smallest terms first; the two accumulators alternate so that no MFMA waits for its predecessor
+#define C3X_MAC(A, B)                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) if (!c3x_dead(2 * round + j, p))                              \
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j], B, acc[j], 0, 0, 0);
+                C3X_MAC(al, bh)
+                C3X_MAC(ah, bl)
+                C3X_MAC(am, bm)
+                C3X_MAC(am, bh)
+                C3X_MAC(ah, bm)
+                C3X_MAC(ah, bh)
             }
             if (patch < n_patches) {
-                // C rows 4g + r -> (yl = g, z = r); flatten index (x,y,z,c) = ((x*4 + y)*4 + z)*32 + c
+                // C rows 4g + r -> (y = g, z = r); flatten index (x,y,z,c) = ((x*4 + y)*4 + z)*32 + c
                 float *dst = f3 + (size_t)patch * 2048 + 16 * ntile + n;
 #pragma unroll
-                for (int x = 0; x < 4; ++x)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dst[((x * 4 + g) * 4 + r) * 32] = enc_tanh(acc[x][r] + bias);
+                    for (int r = 0; r < 4; ++r) dst[(((2 * round + j) * 4 + g) * 4 + r) * 32] = enc_tanh(acc[j][r]);
             }
         }
         __syncthreads();
@@ -722,7 +789,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     if (ev) CAELO_HIP(hipEventRecord(ev[1], s));
     const int64_t pairs = (n_patches + 1) / 2;
     const unsigned g3 = (unsigned)(pairs < 512 ? pairs : 512);  // persistent: two 4-wave workgroups per CU
-    k_enc_conv3<<<g3, 256, 0, s>>>(p2, n_patches, c->enc_w3, c->enc_b3, f3, work_counter);
+    k_enc_conv3<<<g3, 256, 0, s>>>(p2, n_patches, (const uint4 *)c->enc_w3x, c->enc_b3, f3, work_counter);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[2], s));
     dim3 gd((unsigned)(np / D1_BM), D1_SPLIT);

@@ -45,6 +45,7 @@ CAELO_API void caelo_destroy(caelo_ctx *c) {
                      c->enc_b3, c->enc_wd1, c->enc_bd1, c->enc_wd2, c->enc_bd2, c->enc32_wd1};
     for (float *p : ptrs)
         if (p) (void)hipFree(p);
+    if (c->enc_w3x) (void)hipFree(c->enc_w3x);
     delete c;
 }
 
