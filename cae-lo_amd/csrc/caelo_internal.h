@@ -53,11 +53,12 @@ struct caelo_ctx {
     float *enc_w3;   // [27][16][32]
     float *enc_b3;   // [32]
     void *enc_w3x;   // W3 as the conv3 kernel's B operand: [ntile 2][tap pair 14][bf16 split 3][lane 64] x 16 B
-    float *enc_wd1;  // [2048][208] (N padded 200 -> 208 with zeros)
+    void *enc_wd1x;  // dense_1 as the dense-1 kernel's B operand: [k-step 64][bf16 split 3][n-tile 13][lane 64] x 16 B
     float *enc_bd1;  // [208]
     float *enc_wd2;  // [200][20]
     float *enc_bd2;  // [20]
-    float *enc32_wd1;  // [16384][208] | bias [208]: dense_1 of the 32^3 stress case (config5.hip), null until set
+    void *enc32_wd1x;  // dense_1 [16384][200] of the 32^3 stress case (config5.hip) in the same operand layout, null until set
+    float *enc32_bd1;  // [208]
     bool has_enc;
 };
 
@@ -129,6 +130,8 @@ struct caelo_enc_out {
 };
 int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, const caelo_enc_out &outs,
                       int out_stride, void *ws, hipStream_t s, hipEvent_t *ev);
+int64_t enc_dense_pad(int64_t n);  // rows padded to whole dense-1 tiles
+int enc_upload_dense1(const float *wd1, const float *bd1, int K, void **wx_dev, float **bd_dev);
 int64_t enc_dense32_part_bytes(int64_t np);
 int enc_dense32_head_launch(caelo_ctx *c, const float *f3, int64_t n_patches, int64_t np, float *part, int group, float *out,
                             int out_stride, hipStream_t s);

@@ -390,18 +390,10 @@ CAELO_API int caelo_patches32(caelo_ctx *c, const caelo_voxmap *m, const float *
 
 CAELO_API int caelo_set_encoder32_dense(caelo_ctx *c, const float *wd1, const float *bd1) {
     CAELO_REQUIRE(c && wd1 && bd1, "null argument");
-    const size_t K = 16384, N = 200, NP = 208;
-    float *pad = (float *)calloc(K * NP + NP, sizeof(float));
-    if (!pad) { caelo_set_error("out of host memory"); return CAELO_ERR_ARG; }
-    for (size_t k = 0; k < K; ++k) memcpy(pad + k * NP, wd1 + k * N, N * sizeof(float));
-    memcpy(pad + K * NP, bd1, N * sizeof(float));
-    if (!c->enc32_wd1) CAELO_HIP(hipMalloc(&c->enc32_wd1, (K * NP + NP) * sizeof(float)));
-    CAELO_HIP(hipMemcpy(c->enc32_wd1, pad, (K * NP + NP) * sizeof(float), hipMemcpyHostToDevice));
-    free(pad);
-    return CAELO_OK;
+    return enc_upload_dense1(wd1, bd1, 16384, &c->enc32_wd1x, &c->enc32_bd1);
 }
 
-static inline int64_t c5_pad(int64_t n) { return (n + 47) / 48 * 48; }  // whole dense-1 row tiles (D1_BM, encoder.hip)
+static inline int64_t c5_pad(int64_t n) { return enc_dense_pad(n); }  // whole dense-1 row tiles
 
 // ws = P1 [n][16^3][8] | P2 [n][8^3][16] | F3 [np][16384] | dense-1 split-K partial sums (sized by encoder.hip)
 CAELO_API int64_t caelo_encode32_ws_bytes(int64_t n_patches) {
@@ -414,7 +406,7 @@ CAELO_API int caelo_encode32(caelo_ctx *c, const uint64_t *bits, int64_t n_patch
                              void *ws, void *stream) {
     CAELO_REQUIRE(c && bits && out && ws, "null argument");
     CAELO_REQUIRE(c->has_enc, "encoder weights not set (caelo_set_encoder_weights)");
-    CAELO_REQUIRE(c->enc32_wd1, "32^3 dense_1 not set (caelo_set_encoder32_dense)");
+    CAELO_REQUIRE(c->enc32_wd1x, "32^3 dense_1 not set (caelo_set_encoder32_dense)");
     CAELO_REQUIRE(n_patches > 0 && n_patches < (1ll << 27) && group >= 1 && out_stride >= group * 20, "bad shape");
     hipStream_t s = caelo_stream(stream);
     const int64_t np = c5_pad(n_patches);

@@ -48,6 +48,7 @@ __device__ inline float enc_tanh(float x) {
 #define DENSE_K 2048
 #define C3X_NPAIR 14  // tap pairs of the conv3 kernel (see k_enc_conv3)
 static void conv3_split_weights(const float *w3, uint4 *out);
+int enc_upload_dense1(const float *wd1, const float *bd1, int K, void **wx_dev, float **bd_dev);
 
 CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const float *b1, const float *w2,
                                         const float *b2, const float *w3, const float *b3, const float *wd1,
@@ -88,15 +89,10 @@ CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const flo
         CAELO_HIP(hipMemcpy(c->enc_w3x, wx, n * sizeof(uint4), hipMemcpyHostToDevice));
         free(wx);
     }
-    float *pad = (float *)calloc((size_t)DENSE_K * DENSE_NP + DENSE_NP, sizeof(float));
-    if (!pad) { caelo_set_error("out of host memory"); return CAELO_ERR_ARG; }
-    for (int k = 0; k < DENSE_K; ++k) memcpy(pad + (size_t)k * DENSE_NP, wd1 + (size_t)k * DENSE_N, DENSE_N * sizeof(float));
-    memcpy(pad + (size_t)DENSE_K * DENSE_NP, bd1, DENSE_N * sizeof(float));
-    if (!c->enc_wd1) CAELO_HIP(hipMalloc(&c->enc_wd1, (size_t)DENSE_K * DENSE_NP * sizeof(float)));
-    if (!c->enc_bd1) CAELO_HIP(hipMalloc(&c->enc_bd1, DENSE_NP * sizeof(float)));
-    CAELO_HIP(hipMemcpy(c->enc_wd1, pad, (size_t)DENSE_K * DENSE_NP * sizeof(float), hipMemcpyHostToDevice));
-    CAELO_HIP(hipMemcpy(c->enc_bd1, pad + (size_t)DENSE_K * DENSE_NP, DENSE_NP * sizeof(float), hipMemcpyHostToDevice));
-    free(pad);
+    {
+        const int rc = enc_upload_dense1(wd1, bd1, DENSE_K, &c->enc_wd1x, &c->enc_bd1);
+        if (rc) return rc;
+    }
     c->has_enc = true;
     return CAELO_OK;
 }
@@ -576,114 +572,190 @@ __global__ void __launch_bounds__(256, 2) k_enc_conv3(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// dense1: split-K GEMM  part[s][row][208] = F3[row][k0:k0+256] x Wd1p[k0:k0+256][208]
+// dense1: split-K GEMM  part[s][row][208] = F3[row][k0:k0+KTOT/8] x Wd1[k0:k0+KTOT/8][208] -- bf16 x 3 like conv3
 // ------------------------------------------------------------------------------------------------
-#ifndef D1_BM
-#define D1_BM 48  // 96 (one 8-wave workgroup per CU) measured 4 % slower than 48 (two per CU)
-#endif
-#define D1_BK 32
+#define D1_BM 64
+#define D1_BK 32      // one v_mfma_f32_16x16x32_bf16 k-step per stage
 #define D1_SPLIT 8
-#define D1_KCHUNK (KTOT / D1_SPLIT)  // KTOT: template parameter of k_enc_dense1 (2048; 16384 for the 32^3 stress case)
 #define D1_THREADS 512
-#define D1_APITCH 34  // conflict-free ds_read_b32 of A[m][k]: 16 rows x 2 k per 32-lane group -> banks 2 row + k
-#define D1_MT (D1_BM / 16)
-#define D1_NT (DENSE_NP / 16)
-#define D1_TILES (D1_MT * D1_NT)               // 78 output tiles per workgroup
-#define D1_WTILES ((D1_TILES + 7) / 8)         // <= 10 per wave
-#define D1_A4 (D1_BM * D1_BK / 4)              // float4 of an A stage
-#define D1_B4 (D1_BK * DENSE_NP / 4)           // float4 of a B stage
+#define D1_NT (DENSE_NP / 16)          // 13 n-tiles
+#define D1_B16 (3 * D1_NT * 64)        // uint4 of a B stage: [split][n-tile][lane]
+#define D1_BSLOTS ((D1_B16 + D1_THREADS - 1) / D1_THREADS)
 
-// 48 rows x 208 columns x 256 k per workgroup of 8 waves: 64 x 8 = 512 workgroups, two per CU (66 KB of LDS and
-// 77 VGPRs each), so one workgroup's stage barrier is covered by the other's MFMAs and half the register file stays
-// free for the kernels of other streams.  Against the 32-row, 4-wave tile this replaces, a weight stage fetched
-// from L2 serves 1.5x the rows and a stage carries 40 MFMAs per wave between barriers with one barrier per stage.
-// The 39 output tiles are dealt round-robin to the 8 waves (5,5,5,5,5,5,5,4); a wave reads the A and B fragment of
-// each of its tiles straight from LDS (offsets are wave-uniform), accumulators are static.  Stages are double
-// buffered in LDS: the next stage is fetched into registers during the MFMAs and stored to the other buffer.
-template <int KTOT>
-__global__ void __launch_bounds__(D1_THREADS, D1_BM == 96 ? 1 : 2) k_enc_dense1(const float *__restrict__ f3, int64_t n_rows_pad,
-                                                           const float *__restrict__ wd1p, float *__restrict__ part) {
-    __shared__ __attribute__((aligned(16))) float As[2][D1_BM * D1_APITCH];
-    __shared__ __attribute__((aligned(16))) float Bs[2][D1_BK * DENSE_NP];
+// host: Wd1 [K][200] -> per 32-deep k-step the LDS image of the B operand: [kstep][split 3][n-tile 13][lane 64] x 16 B,
+// lane (n = lane & 15, g = lane >> 4) holding k = 32 kstep + 8 g .. + 7 of column 16 ntile + n (zero beyond 200)
+static void dense1_split_weights(const float *wd1, int K, uint4 *out) {
+    for (int ks = 0; ks < K / 32; ++ks)
+        for (int nt = 0; nt < D1_NT; ++nt)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int n = lane & 15, g = lane >> 4, col = nt * 16 + n;
+                uint32_t h[8], m[8], l[8];
+                for (int i = 0; i < 8; ++i)
+                    enc_split3(col < DENSE_N ? wd1[(size_t)(ks * 32 + 8 * g + i) * DENSE_N + col] : 0.0f, h[i], m[i], l[i]);
+                uint4 *o = out + (size_t)ks * D1_B16 + nt * 64 + lane;
+                o[0] = ENC_PK8(h);
+                o[D1_NT * 64] = ENC_PK8(m);
+                o[2 * D1_NT * 64] = ENC_PK8(l);
+            }
+}
+
+int enc_upload_dense1(const float *wd1, const float *bd1, int K, void **wx_dev, float **bd_dev) {
+    const size_t n = (size_t)(K / 32) * D1_B16;
+    uint4 *wx = (uint4 *)malloc(n * sizeof(uint4));
+    if (!wx) { caelo_set_error("out of host memory"); return CAELO_ERR_ARG; }
+    dense1_split_weights(wd1, K, wx);
+    float bd[DENSE_NP] = {0.0f};
+    memcpy(bd, bd1, DENSE_N * sizeof(float));
+    hipError_t e = hipSuccess;
+    if (!*wx_dev) e = hipMalloc(wx_dev, n * sizeof(uint4));
+    if (e == hipSuccess && !*bd_dev) e = hipMalloc((void **)bd_dev, sizeof(bd));
+    if (e == hipSuccess) e = hipMemcpy(*wx_dev, wx, n * sizeof(uint4), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(*bd_dev, bd, sizeof(bd), hipMemcpyHostToDevice);
+    free(wx);
+    if (e != hipSuccess) { caelo_set_error("dense_1 upload failed: %s", hipGetErrorString(e)); return CAELO_ERR_HIP; }
+    return CAELO_OK;
+}
+
+// (64 MTW) rows x 208 columns x KTOT/8 k per workgroup of 8 waves, one workgroup per CU.  A stage is one 32-deep
+// k-step:
+//   * the weight stage is a straight 39 KB copy of the host-built image, moved by LDS-DMA (global_load_lds_dwordx4:
+//     1 KB per wave instruction, no VGPRs, no ds_write pass) into one of two buffers while the MFMAs of the
+//     previous stage run.  Every workgroup streams its whole K chunk of the weights from L2, so the rows per
+//     workgroup set the L2 traffic: 64-row tiles move 245 MB per 6144-row launch and are bound by it (45 us), 192-row
+//     tiles 82 MB;
+//   * the f32 activations are fetched into registers a stage ahead and split into their three bf16 terms on the
+//     way into LDS ([split][g][row] x 16 B: the A operand of lane (m, g) is one ds_read_b128, 16 lanes = 256
+//     contiguous bytes).
+// Wave w owns the MTW m-tiles of row group w >> 1 and n-tiles 0..6 (even waves) / 7..12 (odd): an A fragment is read
+// once per k-step and serves 7 / 6 tiles, a B fragment serves the 6 MFMAs of MTW tiles (see conv3 for the arithmetic).
+#define D1_LDS_BYTES(MTW) ((3 * 4 * 64 * (MTW) + 2 * D1_B16) * 16)
+template <int KTOT, int MTW>
+__global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1(const float *__restrict__ f3, int64_t n_rows_pad,
+                                                              const uint4 *__restrict__ wd1x, float *__restrict__ part) {
+    constexpr int BM = 64 * MTW, A16 = 3 * 4 * BM, NKS = KTOT / D1_SPLIT / D1_BK;
+    extern __shared__ uint4 d1_lds[];
+    uint4 *As = d1_lds;        // [split][g][row]
+    uint4 *Bs = d1_lds + A16;  // two stages of [split][n-tile][lane]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, n = lane & 15;
-    const int64_t row0 = (int64_t)blockIdx.x * D1_BM;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
     const int split = blockIdx.y;
-    const int kbeg = split * D1_KCHUNK;
-    // wave-uniform LDS offsets of this wave's tiles (named scalars: an indexed array would live in scratch)
-#define D1_TILE_T(I) (wave + 8 * (I) < D1_TILES ? wave + 8 * (I) : 0) /* a slot past the last tile recomputes tile 0, never stored */
-#define D1_OFFS(I) const int ao##I = (D1_TILE_T(I) / D1_NT) * 16 * D1_APITCH, bo##I = (D1_TILE_T(I) % D1_NT) * 16;
-    D1_OFFS(0) D1_OFFS(1) D1_OFFS(2) D1_OFFS(3) D1_OFFS(4)
-#if D1_WTILES > 5
-    D1_OFFS(5) D1_OFFS(6) D1_OFFS(7) D1_OFFS(8) D1_OFFS(9)
-#endif
-    f32x4 acc[D1_WTILES];
+    const int ks0 = split * NKS;
+    const int mg = wave >> 1;          // rows mg * 16 MTW ... of the tile
+    const bool odd = (wave & 1) != 0;  // n-tiles 7..12 (6 of them) instead of 0..6
+    const int nt0 = odd ? 7 : 0;
+    f32x4 acc[MTW][7];
 #pragma unroll
-    for (int i = 0; i < D1_WTILES; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // a stage = 768 float4 of A + 1664 float4 of B = 4.75 per thread; slot u = tid + 512 r is an A element for
-    // u < 768, else B element u - 768; which of the two (and whether slot 4 exists) is uniform per wave
-#if D1_BM == 96
-#define D1_SLOTS 5
-#define D1_SLOT_OK(R) ((R) < 4 || wave < 6)
-#define D1_SLOT_IS_A(R) ((R) == 0 || ((R) == 1 && wave < 4))
-#else  // 48 rows: 384 + 1664 = 2048 float4 = 4 per thread, A elements in slot 0 of waves 0..5
-#define D1_SLOTS 4
-#define D1_SLOT_OK(R) true
-#define D1_SLOT_IS_A(R) ((R) == 0 && wave < 6)
-#endif
-    float4 pre[D1_SLOTS];
-#define D1_FETCH(K0)                                                                                              \
-    {                                                                                                             \
-        _Pragma("unroll") for (int r = 0; r < D1_SLOTS; ++r) {                                                    \
-            const int u = tid + r * D1_THREADS;                                                                   \
-            if (!D1_SLOT_OK(r)) continue;                                                                         \
-            if (D1_SLOT_IS_A(r)) pre[r] = *(const float4 *)(f3 + (size_t)(row0 + (u >> 3)) * KTOT + (K0) + (u & 7) * 4); \
-            else pre[r] = *(const float4 *)(wd1p + (size_t)(K0) * DENSE_NP + (size_t)(u - D1_A4) * 4);           \
-        }                                                                                                         \
+    for (int q = 0; q < MTW; ++q)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) acc[q][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int a_row = tid >> 3, a_kq = tid & 7;  // A fetch: rows a_row + 64 r, 4 consecutive k
+    const float *a_src = f3 + (size_t)(row0 + a_row) * KTOT + (size_t)ks0 * D1_BK + a_kq * 4;
+    const uint4 *b_src = wd1x + (size_t)ks0 * D1_B16 + lane;
+    float4 pa[MTW];
+    // B stage KS -> buffer BUF: 39 blocks of 64 x 16 B, block w, w + 8, ... by wave w
+#define D1_FETCH(KS, BUF)                                                                                        \
+    {                                                                                                            \
+        _Pragma("unroll") for (int r = 0; r < 5; ++r) {                                                          \
+            const int blk = wave + 8 * r;                                                                        \
+            if (blk < 3 * D1_NT)                                                                                 \
+                __builtin_amdgcn_global_load_lds(                                                                \
+                    (const void __attribute__((address_space(1))) *)(b_src + (size_t)(KS) * D1_B16 + blk * 64),  \
+                    (void __attribute__((address_space(3))) *)(Bs + (BUF) * D1_B16 + blk * 64), 16, 0, 0);       \
+        }                                                                                                        \
+        _Pragma("unroll") for (int r = 0; r < MTW; ++r)                                                          \
+            pa[r] = *(const float4 *)(a_src + (size_t)(64 * r) * KTOT + (size_t)(KS) * D1_BK);                   \
     }
-#define D1_STORE(BUF)                                                                                             \
-    {                                                                                                             \
-        _Pragma("unroll") for (int r = 0; r < D1_SLOTS; ++r) {                                                    \
-            const int u = tid + r * D1_THREADS;                                                                   \
-            if (!D1_SLOT_OK(r)) continue;                                                                         \
-            if (D1_SLOT_IS_A(r)) {                                                                                \
-                float2 *d = (float2 *)&As[BUF][(u >> 3) * D1_APITCH + (u & 7) * 4]; /* 8-byte aligned rows */     \
-                d[0] = make_float2(pre[r].x, pre[r].y);                                                           \
-                d[1] = make_float2(pre[r].z, pre[r].w);                                                           \
-            } else *(float4 *)&Bs[BUF][(u - D1_A4) * 4] = pre[r];                                                 \
-        }                                                                                                         \
+#define D1_STORE_A()                                                                                       \
+    _Pragma("unroll") for (int r = 0; r < MTW; ++r) {                                                      \
+        uint32_t h0_, m0_, l0_, h1_, m1_, l1_, h2_, m2_, l2_, h3_, m3_, l3_;                               \
+        enc_split3(pa[r].x, h0_, m0_, l0_);                                                                \
+        enc_split3(pa[r].y, h1_, m1_, l1_);                                                                \
+        enc_split3(pa[r].z, h2_, m2_, l2_);                                                                \
+        enc_split3(pa[r].w, h3_, m3_, l3_);                                                                \
+        uint2 *d_ = (uint2 *)&As[(a_kq >> 1) * BM + a_row + 64 * r] + (a_kq & 1);                          \
+        d_[0] = make_uint2((h0_ >> 16) | h1_, (h2_ >> 16) | h3_);                                          \
+        d_[2 * 4 * BM] = make_uint2((m0_ >> 16) | m1_, (m2_ >> 16) | m3_);                                 \
+        d_[2 * 8 * BM] = make_uint2((l0_ >> 16) | l1_, (l2_ >> 16) | l3_);                                 \
     }
-    D1_FETCH(kbeg)
-    D1_STORE(0)
-    __syncthreads();
+    D1_FETCH(0, 0)
 #pragma unroll 1
-    for (int st = 0; st < D1_KCHUNK / D1_BK; ++st) {
-        const int buf = st & 1;
-        const bool more = st + 1 < D1_KCHUNK / D1_BK;
-        if (more) D1_FETCH(kbeg + (st + 1) * D1_BK)
-        const float *A = &As[buf][n * D1_APITCH + g];
-        const float *B = &Bs[buf][g * DENSE_NP + n];
+    for (int st = 0; st < NKS; ++st) {
+        D1_STORE_A()
+        __syncthreads();  // also waits for the LDS-DMA of this stage (vmcnt)
+        if (st + 1 < NKS) D1_FETCH(st + 1, (st + 1) & 1)
+        bf16x8 ah[MTW], am[MTW], al[MTW];
 #pragma unroll
-        for (int s = 0; s < D1_BK / 4; ++s) {
-#define D1_MAC(I) acc[I] = MFMA16(A[ao##I + 4 * s], B[bo##I + 4 * s * DENSE_NP], acc[I]);
-            D1_MAC(0) D1_MAC(1) D1_MAC(2) D1_MAC(3) D1_MAC(4)
-#if D1_WTILES > 5
-            D1_MAC(5) D1_MAC(6) D1_MAC(7) D1_MAC(8) D1_MAC(9)
-#endif
+        for (int q = 0; q < MTW; ++q) {
+            const uint4 *ap = &As[g * BM + (mg * MTW + q) * 16 + n];
+            ah[q] = __builtin_bit_cast(bf16x8, ap[0]);
+            am[q] = __builtin_bit_cast(bf16x8, ap[4 * BM]);
+            al[q] = __builtin_bit_cast(bf16x8, ap[8 * BM]);
         }
-        if (more) D1_STORE(buf ^ 1)
-        __syncthreads();
+        const uint4 *bp = &Bs[(st & 1) * D1_B16 + nt0 * 64 + lane];
+        // n-tiles in groups (the 7th absent on odd waves); within a group the accumulators alternate, so that no
+        // MFMA waits for its predecessor
+#define D1_GROUP(I0, CNT)                                                                                             \
+    {                                                                                                                 \
+        bf16x8 bh[CNT], bm[CNT], bl[CNT];                                                                             \
+        _Pragma("unroll") for (int i = 0; i < CNT; ++i) {                                                             \
+            if ((I0) + i == 6 && odd) continue;                                                                       \
+            bh[i] = __builtin_bit_cast(bf16x8, bp[((I0) + i) * 64]);                                                  \
+            bm[i] = __builtin_bit_cast(bf16x8, bp[(D1_NT + (I0) + i) * 64]);                                          \
+            bl[i] = __builtin_bit_cast(bf16x8, bp[(2 * D1_NT + (I0) + i) * 64]);                                      \
+        }                                                                                                             \
+        D1_TERM(al, bh, I0, CNT) D1_TERM(ah, bl, I0, CNT) D1_TERM(am, bm, I0, CNT)                                     \
+        D1_TERM(am, bh, I0, CNT) D1_TERM(ah, bm, I0, CNT) D1_TERM(ah, bh, I0, CNT)                                     \
+    }
+#define D1_TERM(A, B, I0, CNT)                                                                                        \
+    _Pragma("unroll") for (int q = 0; q < MTW; ++q)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < CNT; ++i) if (!((I0) + i == 6 && odd))                                      \
+        acc[q][(I0) + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[q], B[i], acc[q][(I0) + i], 0, 0, 0);
+        if (MTW == 1) {
+            D1_GROUP(0, 4)
+            D1_GROUP(4, 3)
+        } else {
+            D1_GROUP(0, 2)
+            D1_GROUP(2, 2)
+            D1_GROUP(4, 2)
+            D1_GROUP(6, 1)
+        }
+        caelo_lds_barrier();  // LDS reads done; the DMA of the next stage stays in flight
     }
     // C rows 4g + r of each tile
 #pragma unroll
-    for (int i = 0; i < D1_WTILES; ++i) {
-        const int t = wave + 8 * i;
-        if (t >= D1_TILES) continue;
-        float *dst = part + ((size_t)split * n_rows_pad + row0 + (t / D1_NT) * 16 + 4 * g) * DENSE_NP + (t % D1_NT) * 16 + n;
+    for (int q = 0; q < MTW; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[(size_t)r * DENSE_NP] = acc[i][r];
+        for (int i = 0; i < 7; ++i) {
+            if (i == 6 && odd) continue;
+            float *dst = part + ((size_t)split * n_rows_pad + row0 + (mg * MTW + q) * 16 + 4 * g) * DENSE_NP + (nt0 + i) * 16 + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(size_t)r * DENSE_NP] = acc[q][i][r];
+        }
+}
+
+template <int KTOT>
+static int dense1_launch(const float *f3, int64_t np, const void *wd1x, float *part, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        CAELO_HIP(hipFuncSetAttribute((const void *)k_enc_dense1<KTOT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, D1_LDS_BYTES(1)));
+        CAELO_HIP(hipFuncSetAttribute((const void *)k_enc_dense1<KTOT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, D1_LDS_BYTES(3)));
+        attr = true;
     }
+    // 64-row tiles for K = 2048 (8 stages per workgroup; measured 1 % ahead of 192-row tiles inside the frame
+    // pipeline although 15 % behind in isolation); 192-row tiles for the long-K instance, where the weight stream
+    // from L2 would otherwise bound the kernel
+    const bool big = KTOT > 2048;
+    if (big && np % 192 == 0) {
+        dim3 gd((unsigned)(np / 192), D1_SPLIT);
+        k_enc_dense1<KTOT, 3><<<gd, D1_THREADS, D1_LDS_BYTES(3), s>>>(f3, np, (const uint4 *)wd1x, part);
+    } else {
+        dim3 gd((unsigned)(np / 64), D1_SPLIT);
+        k_enc_dense1<KTOT, 1><<<gd, D1_THREADS, D1_LDS_BYTES(1), s>>>(f3, np, (const uint4 *)wd1x, part);
+    }
+    CAELO_LAUNCH_CHECK();
+    return CAELO_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -792,9 +864,10 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     k_enc_conv3<<<g3, 256, 0, s>>>(p2, n_patches, (const uint4 *)c->enc_w3x, c->enc_b3, f3, work_counter);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[2], s));
-    dim3 gd((unsigned)(np / D1_BM), D1_SPLIT);
-    k_enc_dense1<DENSE_K><<<gd, D1_THREADS, 0, s>>>(f3, np, c->enc_wd1, part);
-    CAELO_LAUNCH_CHECK();
+    {
+        const int rc = dense1_launch<DENSE_K>(f3, np, c->enc_wd1x, part, s);
+        if (rc) return rc;
+    }
     if (ev) CAELO_HIP(hipEventRecord(ev[3], s));
     k_enc_head<<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(part, n_patches, np, c->enc_bd1, c->enc_wd2, c->enc_bd2,
                                                                 group, outs, out_stride);
@@ -804,16 +877,18 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
 }
 
 // Dense(200) + Dense(20) of the 32^3 stress case (config5.hip): the same two kernels over K = 16384
+int64_t enc_dense_pad(int64_t n) { return pad64(n); }
 int64_t enc_dense32_part_bytes(int64_t np) { return (int64_t)D1_SPLIT * np * DENSE_NP * (int64_t)sizeof(float); }
 int enc_dense32_head_launch(caelo_ctx *c, const float *f3, int64_t n_patches, int64_t np, float *part, int group, float *out,
                             int out_stride, hipStream_t s) {
-    dim3 gd((unsigned)(np / D1_BM), D1_SPLIT);
-    k_enc_dense1<16384><<<gd, D1_THREADS, 0, s>>>(f3, np, c->enc32_wd1, part);
-    CAELO_LAUNCH_CHECK();
+    {
+        const int rc = dense1_launch<16384>(f3, np, c->enc32_wd1x, part, s);
+        if (rc) return rc;
+    }
     caelo_enc_out outs = {};
     outs.base[0] = out;
     outs.per_frame = n_patches;
-    k_enc_head<<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(part, n_patches, np, c->enc32_wd1 + (size_t)16384 * DENSE_NP, c->enc_wd2,
+    k_enc_head<<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(part, n_patches, np, c->enc32_bd1, c->enc_wd2,
                                                                 c->enc_bd2, group, outs, out_stride);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;

@@ -42,10 +42,11 @@ CAELO_API int caelo_create(caelo_ctx **out, int device) {
 CAELO_API void caelo_destroy(caelo_ctx *c) {
     if (!c) return;
     float *ptrs[] = {c->resp_w, c->enc_c0, c->enc_w1, c->enc_b1, c->enc_w2, c->enc_b2, c->enc_w3,
-                     c->enc_b3, c->enc_wd1, c->enc_bd1, c->enc_wd2, c->enc_bd2, c->enc32_wd1};
+                     c->enc_b3, c->enc_bd1, c->enc_wd2, c->enc_bd2, c->enc32_bd1};
     for (float *p : ptrs)
         if (p) (void)hipFree(p);
-    if (c->enc_w3x) (void)hipFree(c->enc_w3x);
+    for (void *p : {c->enc_w3x, c->enc_wd1x, c->enc32_wd1x})
+        if (p) (void)hipFree(p);
     delete c;
 }
 
