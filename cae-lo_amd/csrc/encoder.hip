@@ -1,4 +1,4 @@
-// encoder.hip -- 3D-CAE voxel-patch descriptor encoder on f32 MFMA (gfx950).
+// encoder.hip -- 3D-CAE voxel-patch descriptor encoder on the gfx950 matrix cores (f32 in / out / accumulate).
 //
 // Reference behaviour restated here (never its code): PatchEncoder.predict via
 // GetFeaturesFromPatches (Match.py:130-135) with the shipped EncoderModel4VoxelPatch.h5:
@@ -6,7 +6,8 @@
 //   -> Conv3D(16->32) tanh -> Flatten(x,y,z,c) -> Dense(200) tanh -> Dense(20) tanh
 // (Keras channels-last, zero 'same' padding, cross-correlation; the stale relu/linear script
 // AE4VoxelPatch.py:177-197 is NOT what ships).  7.905 MFLOP per patch, 24.28 GFLOP
-// per 3072-patch frame: MFMA-bound (157 TFLOP/s f32 matrix peak).
+// per 3072-patch frame: MFMA-bound (157 TFLOP/s f32 matrix peak; conv3 and Dense(200) go through the 16x faster bf16
+// pipe with exact 3-way operand splits, see k_enc_conv3).
 //
 // Kernels
 //   k_enc_stage1  persistent workgroups, one patch at a time from a global work counter (coarsest scale first):
@@ -16,10 +17,11 @@
 //                 v_mfma_f32_16x16x4_f32, all 54 B-fragments of W2 resident in VGPRs, all-zero input rows skipped
 //                 (23 % of the dense MFMAs run) -> pool2 in registers (tanh(max) == max(tanh)) ->
 //                 P2 [patch][4][4][4][16] to HBM (4 KB).
-//   k_enc_conv3   conv3 implicit GEMM, 2 patches per workgroup, W3 n-tile resident in 108 VGPRs, zero halo planes
-//                 skipped, A fragments by conflict-free ds_read_b128 from four 4-channel LDS planes.
-//   k_enc_dense1  split-K GEMM [patches,2048]x[2048,208]: 48-row tiles, 8 waves, two workgroups per CU,
-//                 double-buffered LDS stages.
+//   k_enc_conv3   conv3 implicit GEMM, 2 patches per workgroup; f32 products as 6 bf16 MFMAs (v_mfma_f32_16x16x32_bf16)
+//                 on 3-way split operands: host-split W3 n-tile resident in 168 VGPRs, P2 split while staged in LDS,
+//                 two taps per MFMA, zero halo planes skipped, A fragments by conflict-free ds_read_b128.
+//   k_enc_dense1  split-K GEMM [patches,2048]x[2048,208], same arithmetic: 64-row tiles, 8 waves, one workgroup per
+//                 CU, host-built weight stages moved by LDS-DMA into two buffers, activations split into LDS.
 //   k_enc_head    split-K reduce + bias + tanh + Dense(20) + tanh, one wave per patch, written into each frame's
 //                 rows (the patches of several frames can share one launch set: encode_batch_impl).
 // All tanh are enc_tanh (v_exp_f32 + v_rcp_f32, |err| < 6e-7).
