@@ -149,7 +149,7 @@ class Pipeline:
         return {"jobs": int(out[0]), "issue_us_per_frame": out[1] / n / 1e3, "wait_us_per_frame": out[2] / n / 1e3,
                 "lanes": int(out[3]), "encoder_busy_us": out[4] / 1e3, "encoder_span_us": out[5] / 1e3}
 
-    def run(self, scans, rands=None, prev=None, dist_channels=5, exact_voxels=False, out=None, pairs=True):
+    def run(self, scans, rands=None, prev=None, dist_channels=5, exact_voxels=False, out=None, pairs=True, dedup=True):
         """scans: K device tensors [n,4] f32; rands: K device tensors of RANSAC draws ([1500,4] f64).
         Frame i is matched against frame i-1 (pose in ``result[i]``); frame 0 against ``prev``
         (FrameFeatures) when given; ``pairs=False`` extracts only (BASELINE configs[1]).  Returns a FrameBatch; the
@@ -160,7 +160,7 @@ class Pipeline:
         stream = eng.stream
         _ffi.check(lib.caelo_pipeline_begin(self.h, stream))
         job = _ffi.FrameJob()
-        job.dist_channels, job.mode = int(dist_channels), 1 if exact_voxels else 0
+        job.dist_channels, job.mode = int(dist_channels), (1 if exact_voxels else 0) | (0 if dedup else 2)
         p_rows, p_pix, p_nk, p_fl, p_st = (out.rows.data_ptr(), out.key_pixels.data_ptr(), out.n_key.data_ptr(),
                                            out.flags.data_ptr(), out.status.data_ptr())
         p_res, p_mask, p_idx = out.result.data_ptr(), out.inlier_mask.data_ptr(), out.pair_idx.data_ptr()
@@ -475,14 +475,15 @@ class Engine:
         return _ffi.PoseResult.from_buffer_copy(res.cpu().numpy().tobytes())
 
     # ---- fused hot path ------------------------------------------------------------------------------
-    def extract(self, pc, dist_channels=5, vmap=None, rows=None, exact_voxels=False):
+    def extract(self, pc, dist_channels=5, vmap=None, rows=None, exact_voxels=False, dedup=True):
         """scan [N,4] f32 (device) -> FrameFeatures, ONE C-ABI call (caelo_extract), no host sync:
         project -> response CNN -> keypoints -> voxelize -> patch gather -> 3x encoder.
         dist_channels: 5 = demo calling mode (SphericalRing.py:414), 3 = batch mode
         (BatchPreprocess.py:97-98,131-136).  ``rows``: optional [1024,64] f32 output slot.
         The default one-pass voxelization flags (status bit ST_VOXEL_INEXACT) the ~1e-10-probability
         frame in which a point lies within an ulp of a voxel face; ``checked()`` re-runs such a frame
-        with ``exact_voxels=True`` (the two-pass first-touch rule of Voxel.py:139-141)."""
+        with ``exact_voxels=True`` (the two-pass first-touch rule of Voxel.py:139-141).  ``dedup=False`` encodes
+        every patch even when it is a bit-identical copy of another one of the frame (same result, more work)."""
         assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] == 4 and pc.is_contiguous()
         ws = self._ws("extract", int(self.lib.caelo_extract_ws_bytes()))
         vmap = vmap or self.voxmap(max(self.max_points, pc.shape[0]))
@@ -493,7 +494,8 @@ class Engine:
         flags = self.empty((MAX_K, 3), torch.uint8)
         status = self.empty((4,), torch.int32)
         base = rows.data_ptr()
-        _ffi.check(self.lib.caelo_extract(self.ctx, vmap.h, _ptr(pc), pc.shape[0], dist_channels, 1 if exact_voxels else 0,
+        _ffi.check(self.lib.caelo_extract(self.ctx, vmap.h, _ptr(pc), pc.shape[0], dist_channels,
+                                          (1 if exact_voxels else 0) | (0 if dedup else 2),
                                           C.c_void_p(base + 240), 64, C.c_void_p(base), 64, C.c_void_p(base + 252), 64,
                                           _ptr(kpix), _ptr(nkey), _ptr(flags), _ptr(status), _ptr(ws),
                                           self.stream))

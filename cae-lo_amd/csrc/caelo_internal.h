@@ -121,6 +121,23 @@ int vox_build_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, bo
 int vox_build_fast_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, int32_t *status, hipStream_t s);
 int vox_patches_launch(const caelo_voxmap *m, const float *pts, int pts_ld, int64_t k_max, const int32_t *n_key,
                        uint64_t *bits, uint8_t *flags, int32_t *status, bool check_counts, hipStream_t s);
+// ---- a frame's patch buffer: bit-packed patches [3072][64] u64, then the de-duplication tables (dedup.hip) ----------
+#define CAELO_FRAME_PATCHES (CAELO_MAX_KEYPTS * 3)
+struct caelo_dedup_tables {
+    int32_t count;  // distinct patches of the frame
+    int32_t pad[63];
+    int32_t list[CAELO_FRAME_PATCHES];     // their patch indices (key point * 3 + scale), coarsest scale first
+    int32_t slot_of[CAELO_FRAME_PATCHES];  // patch -> position of its representative in list
+};
+#define CAELO_FRAME_BITS_BYTES ((size_t)CAELO_FRAME_PATCHES * 64 * 8)
+#define CAELO_FRAME_BUF_BYTES (CAELO_FRAME_BITS_BYTES + sizeof(caelo_dedup_tables))
+__host__ __device__ inline caelo_dedup_tables *caelo_frame_tables(const uint64_t *frame_bits) {
+    return (caelo_dedup_tables *)((char *)frame_bits + CAELO_FRAME_BITS_BYTES);
+}
+int64_t dedup_scratch_bytes();
+void dedup_clear_item(void *scratch, caelo_clear_list &list);
+int dedup_launch(uint64_t *frame_bits, void *scratch, bool enabled, hipStream_t s);
+
 // patches of up to CAELO_ENC_MAX_FRAMES frames encoded by one launch set (the fixed costs of the four encoder
 // kernels are ~47 us per launch set): frame f = patch / per_frame gets its descriptors in base[f]
 #define CAELO_ENC_MAX_FRAMES 8
@@ -128,8 +145,20 @@ struct caelo_enc_out {
     float *base[CAELO_ENC_MAX_FRAMES];
     int64_t per_frame;
 };
+// input side of a launch set.  dedup = 0: n_patches patches, contiguous at bits.  dedup = 1: n_frames frame buffers
+// (bits + f * frame_stride u64 words: [per_frame][64] patches followed by the frame's caelo_dedup_tables); only the
+// distinct patches of each frame are encoded, into rows f * per_frame + (position in the frame's list), and
+// k_enc_head hands patch p of frame f the result of row f * per_frame + slot_of[p].
+struct caelo_enc_in {
+    const unsigned long long *bits;
+    int64_t frame_stride;
+    int32_t per_frame, n_frames, dedup;
+};
+__device__ inline const caelo_dedup_tables *enc_tables(const caelo_enc_in &in, int f) {
+    return (const caelo_dedup_tables *)(in.bits + (size_t)f * in.frame_stride + (size_t)in.per_frame * 64);
+}
 int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, const caelo_enc_out &outs,
-                      int out_stride, void *ws, hipStream_t s, hipEvent_t *ev);
+                      int out_stride, void *ws, hipStream_t s, hipEvent_t *ev, const caelo_enc_in *in = nullptr);
 int64_t enc_dense_pad(int64_t n);  // rows padded to whole dense-1 tiles
 int enc_upload_dense1(const float *wd1, const float *bd1, int K, void **wx_dev, float **bd_dev);
 int64_t enc_dense32_part_bytes(int64_t np);

@@ -170,7 +170,37 @@ struct Stage1Lds {
     if ((NZ2) & 0x6u) { CONV2_ROW(ACC_A, ACC_B, APTR, 2, 1) }                                       \
     if ((NZ2) & 0xCu) { CONV2_ROW(ACC_A, ACC_B, APTR, 2, 2) }
 
-__global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long *__restrict__ bits, int64_t n_patches,
+// Work item J of a launch -> where its bits are and which output row it fills.  J is wave-uniform: everything here
+// stays in scalar registers (the per-frame counts come through the scalar cache).
+__device__ inline int enc_items_total(const caelo_enc_in &in, int64_t n_patches) {
+    if (!in.dedup) return (int)n_patches;
+    int acc = 0;
+    for (int f = 0; f < in.n_frames; ++f) acc += enc_tables(in, f)->count;
+    return acc;
+}
+__device__ inline int enc_item_row(const caelo_enc_in &in, int J, int &f, int &i) {  // de-duplicated launch
+    f = 0;
+    i = J;
+    while (f + 1 < in.n_frames) {
+        const int c = enc_tables(in, f)->count;
+        if (i < c) break;
+        i -= c;
+        ++f;
+    }
+    return f * in.per_frame + i;
+}
+__device__ inline void enc_item(const caelo_enc_in &in, int J, int nk, int group, const unsigned long long *&src, int &row) {
+    if (in.dedup) {
+        int f, i;
+        row = enc_item_row(in, J, f, i);
+        src = in.bits + (size_t)f * in.frame_stride + (size_t)enc_tables(in, f)->list[i] * 64;
+    } else {
+        row = (J % nk) * group + (group - 1 - J / nk);  // coarsest scale first
+        src = in.bits + (size_t)row * 64;
+    }
+}
+
+__global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, int64_t n_patches,
                                                     int group, int *__restrict__ work_counter,
                                                     const float *__restrict__ w1g, const float *__restrict__ b1g,
                                                     const float *__restrict__ w2g, const float *__restrict__ c0g,
@@ -216,6 +246,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long 
     if (tid == 0) L.list_n = 0;
     if (tid < 12) L.nzrow[tid] = 0u;
     __syncthreads();
+    const int n_items = enc_items_total(in, n_patches);  // distinct patches of the launch (all of them without de-duplication)
 
 #ifdef CAELO_ENC_PROF
     unsigned enc_t_prev = (unsigned)clock64();  // phase totals accumulate in LDS (registers would spill at 3 workgroups/CU)
@@ -228,11 +259,15 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long 
     const int nk = (int)(n_patches / group);
     int j = blockIdx.x;
     // thread = one 16-voxel row of the patch (ix = tid >> 4, iy = tid & 15, bit = iz); fetched one patch ahead
-#define S1_PATCH_OF(J) ((int64_t)((J) % nk) * group + (group - 1 - (J) / nk))
     unsigned int row = 0u;
-    if (j < (int)n_patches) row = ((const unsigned short *)bits)[S1_PATCH_OF(j) * 256 + tid];
-    while (j < (int)n_patches) {
-        const int64_t patch = S1_PATCH_OF(j);
+    int patch = 0, patch_next = 0;  // output rows of the current / the prefetched item (wave-uniform)
+    if (j < n_items) {
+        const unsigned long long *src;
+        enc_item(in, j, nk, group, src, patch);
+        patch = __builtin_amdgcn_readfirstlane(patch);
+        row = ((const unsigned short *)src)[tid];
+    }
+    while (j < n_items) {
         ENC_STAMP(0);
         // work items beyond the first come from a global counter (patch costs vary 10x: a static split leaves the
         // average workgroup idle for the last ~55 us of the launch); fetched after the mask scatter, published
@@ -335,9 +370,14 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long 
         if (tid == 0) L.next_j = (int)gridDim.x + j_fetch;
         caelo_lds_barrier();
         ENC_STAMP(3);
-        const int jn = L.next_j;
+        const int jn = __builtin_amdgcn_readfirstlane(L.next_j);
         unsigned int row_next = 0u;
-        if (jn < (int)n_patches) row_next = ((const unsigned short *)bits)[S1_PATCH_OF(jn) * 256 + tid];
+        if (jn < n_items) {
+            const unsigned long long *src;
+            enc_item(in, jn, nk, group, src, patch_next);
+            patch_next = __builtin_amdgcn_readfirstlane(patch_next);
+            row_next = ((const unsigned short *)src)[tid];
+        }
         // ---- conv2 (8->16) on MFMA: per row pair yi this wave owns the x pair xp = (wave - 2 yi) mod 4
         {
             const int yl = n >> 3, z = n & 7;  // A row m = yl*8 + z
@@ -401,6 +441,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const unsigned long long 
         caelo_lds_barrier();
         j = jn;
         row = row_next;
+        patch = patch_next;
         ENC_STAMP(5);
     }
 #ifdef CAELO_ENC_PROF
@@ -476,7 +517,7 @@ static void conv3_split_weights(const float *w3, uint4 *out) {
             }
 }
 
-__global__ void __launch_bounds__(256, 2) k_enc_conv3(const float *__restrict__ p2, int64_t n_patches,
+__global__ void __launch_bounds__(256, 2) k_enc_conv3(const float *__restrict__ p2, int64_t n_patches, const caelo_enc_in in,
                                                       const uint4 *__restrict__ w3x, const float *__restrict__ b3g,
                                                       float *__restrict__ f3, int *__restrict__ stage1_counter) {
     __shared__ uint4 S[2 * C3X_SLOT];
@@ -487,7 +528,7 @@ __global__ void __launch_bounds__(256, 2) k_enc_conv3(const float *__restrict__ 
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int g = lane >> 4, n = lane & 15;
-    const int ntile = wave & 1, slot = wave >> 1;
+    const int ntile = wave & 1, slot = __builtin_amdgcn_readfirstlane(wave >> 1);
     uint4 bq[C3X_NPAIR][3];
 #pragma unroll
     for (int p = 0; p < C3X_NPAIR; ++p)
@@ -496,25 +537,37 @@ __global__ void __launch_bounds__(256, 2) k_enc_conv3(const float *__restrict__ 
     const float bias = b3g[16 * ntile + n];
     for (int i = tid; i < 2 * C3X_SLOT; i += 256) S[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
-    const int64_t n_pairs = (n_patches + 1) / 2;
+    const int n_items = enc_items_total(in, n_patches);
+    const int n_pairs = (n_items + 1) / 2;
+    // item (wave-uniform) -> row of P2 / F3 (the row stage 1 wrote)
+#define C3_ROW(ITEM, ROW)                                     \
+    {                                                         \
+        ROW = (ITEM);                                         \
+        if (in.dedup) {                                       \
+            int f_, i_;                                       \
+            ROW = enc_item_row(in, (ITEM), f_, i_);           \
+        }                                                     \
+    }
     // register staging: the next pair's 2 x 4 KB are fetched while this pair's MFMAs run; thread -> (slot, position,
     // channel half): 8 consecutive channels
-    const int f_slot = tid >> 7, f_pos = (tid >> 1) & 63, f_h = tid & 1;
+    const int f_slot = __builtin_amdgcn_readfirstlane(tid >> 7), f_pos = (tid >> 1) & 63, f_h = tid & 1;
     const int f_q = (((f_pos >> 4) + 1) * 6 + ((f_pos >> 2) & 3) + 1) * 8 + (f_pos & 3) + 1;
     float4 pre0, pre1;
 #define C3_FETCH(PAIR)                                                                           \
     {                                                                                            \
-        const int64_t pa_ = (PAIR) * 2 + f_slot;                                                 \
+        const int pa_ = (PAIR) * 2 + f_slot;                                                     \
         pre0 = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
         pre1 = pre0;                                                                             \
-        if ((PAIR) < n_pairs && pa_ < n_patches) {                                               \
-            const float4 *q_ = (const float4 *)(p2 + (size_t)pa_ * 1024 + f_pos * 16 + 8 * f_h); \
+        if ((PAIR) < n_pairs && pa_ < n_items) {                                                 \
+            int row_;                                                                            \
+            C3_ROW(pa_, row_)                                                                    \
+            const float4 *q_ = (const float4 *)(p2 + (size_t)row_ * 1024 + f_pos * 16 + 8 * f_h); \
             pre0 = q_[0];                                                                        \
             pre1 = q_[1];                                                                        \
         }                                                                                        \
     }
-    C3_FETCH((int64_t)blockIdx.x)
-    for (int64_t pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+    C3_FETCH((int)blockIdx.x)
+    for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
         {   // split the staged 8 channels into the three bf16 terms: 3 x 16 B into LDS
             const float v[8] = {pre0.x, pre0.y, pre0.z, pre0.w, pre1.x, pre1.y, pre1.z, pre1.w};
             uint32_t h[8], m[8], l[8];
@@ -526,8 +579,10 @@ __global__ void __launch_bounds__(256, 2) k_enc_conv3(const float *__restrict__ 
             d[2 * C3X_SPLIT] = ENC_PK8(l);
         }
         __syncthreads();
-        C3_FETCH(pair + gridDim.x)
-        const int64_t patch = pair * 2 + slot;
+        C3_FETCH(pair + (int)gridDim.x)
+        const int item = pair * 2 + slot;
+        int patch;
+        C3_ROW(item, patch)
         // lane (m = n, g): output (y = n >> 2, z = n & 3) of x plane X reads padded (X + ka, y + kb, z + kc)
         const uint4 *base = &S[slot * C3X_SLOT + (g & 1) * C3X_ARR + (n >> 2) * 8 + (n & 3)];
         const uint4 *ab[4] = {base + (g >= 2 ? 1 : 0), base + (g >= 2 ? 8 : 0), base + (g >= 2 ? C3X_PLANE : 0), base};
@@ -560,7 +615,7 @@ __global__ void __launch_bounds__(256, 2) k_enc_conv3(const float *__restrict__ 
                 C3X_MAC(ah, bm)
                 C3X_MAC(ah, bh)
             }
-            if (patch < n_patches) {
+            if (item < n_items) {
                 // C rows 4g + r -> (y = g, z = r); flatten index (x,y,z,c) = ((x*4 + y)*4 + z)*32 + c
                 float *dst = f3 + (size_t)patch * 2048 + 16 * ntile + n;
 #pragma unroll
@@ -633,8 +688,14 @@ int enc_upload_dense1(const float *wd1, const float *bd1, int K, void **wx_dev, 
 #define D1_LDS_BYTES(MTW) ((3 * 4 * 64 * (MTW) + 2 * D1_B16) * 16)
 template <int KTOT, int MTW>
 __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1(const float *__restrict__ f3, int64_t n_rows_pad,
-                                                              const uint4 *__restrict__ wd1x, float *__restrict__ part) {
+                                                              const uint4 *__restrict__ wd1x, float *__restrict__ part,
+                                                              const caelo_enc_in in) {
     constexpr int BM = 64 * MTW, A16 = 3 * 4 * BM, NKS = KTOT / D1_SPLIT / D1_BK;
+    if (in.dedup) {  // a row tile past the frame's distinct patches holds nothing (tiles never straddle frames)
+        const int64_t r0 = (int64_t)blockIdx.x * BM;
+        const int f = (int)(r0 / in.per_frame);
+        if (r0 - (int64_t)f * in.per_frame >= enc_tables(in, f)->count) return;
+    }
     extern __shared__ uint4 d1_lds[];
     uint4 *As = d1_lds;        // [split][g][row]
     uint4 *Bs = d1_lds + A16;  // two stages of [split][n-tile][lane]
@@ -738,7 +799,7 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1(const float *__res
 }
 
 template <int KTOT>
-static int dense1_launch(const float *f3, int64_t np, const void *wd1x, float *part, hipStream_t s) {
+static int dense1_launch(const float *f3, int64_t np, const void *wd1x, float *part, const caelo_enc_in &in, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
         CAELO_HIP(hipFuncSetAttribute((const void *)k_enc_dense1<KTOT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, D1_LDS_BYTES(1)));
@@ -751,10 +812,10 @@ static int dense1_launch(const float *f3, int64_t np, const void *wd1x, float *p
     const bool big = KTOT > 2048;
     if (big && np % 192 == 0) {
         dim3 gd((unsigned)(np / 192), D1_SPLIT);
-        k_enc_dense1<KTOT, 3><<<gd, D1_THREADS, D1_LDS_BYTES(3), s>>>(f3, np, (const uint4 *)wd1x, part);
+        k_enc_dense1<KTOT, 3><<<gd, D1_THREADS, D1_LDS_BYTES(3), s>>>(f3, np, (const uint4 *)wd1x, part, in);
     } else {
         dim3 gd((unsigned)(np / 64), D1_SPLIT);
-        k_enc_dense1<KTOT, 1><<<gd, D1_THREADS, D1_LDS_BYTES(1), s>>>(f3, np, (const uint4 *)wd1x, part);
+        k_enc_dense1<KTOT, 1><<<gd, D1_THREADS, D1_LDS_BYTES(1), s>>>(f3, np, (const uint4 *)wd1x, part, in);
     }
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
@@ -764,13 +825,18 @@ static int dense1_launch(const float *f3, int64_t np, const void *wd1x, float *p
 __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part, int64_t n_patches, int64_t n_rows_pad,
                                                   const float *__restrict__ bd1p, const float *__restrict__ wd2,
                                                   const float *__restrict__ bd2, int group, caelo_enc_out outs,
-                                                  int out_stride) {
+                                                  int out_stride, const caelo_enc_in in) {
     // One wave per patch, no LDS, no barrier.  Lane l < 50 owns the four hidden columns 4l .. 4l+3: one 16-byte load
     // per split-K partial (8 in flight, 800 contiguous bytes per row) and the 4 x 20 Dense(20) weights of those
     // columns; the 20 outputs are 64-lane butterfly sums of per-lane partial dot products.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t p = (int64_t)blockIdx.x * 4 + wave;
     if (p >= n_patches) return;
+    int64_t prow = p;  // the row that holds this patch's result: its representative's with de-duplication
+    if (in.dedup) {
+        const int f = (int)(p / in.per_frame);
+        prow = (int64_t)f * in.per_frame + enc_tables(in, f)->slot_of[p - (int64_t)f * in.per_frame];
+    }
     const bool ok = lane < DENSE_N / 4;
     float4 s = ok ? *(const float4 *)(bd1p + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 w[4][5];
@@ -781,7 +847,7 @@ __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part
     if (ok) {
         float4 v[D1_SPLIT];
 #pragma unroll
-        for (int sp = 0; sp < D1_SPLIT; ++sp) v[sp] = *(const float4 *)(part + ((size_t)sp * n_rows_pad + p) * DENSE_NP + 4 * lane);
+        for (int sp = 0; sp < D1_SPLIT; ++sp) v[sp] = *(const float4 *)(part + ((size_t)sp * n_rows_pad + prow) * DENSE_NP + 4 * lane);
 #pragma unroll
         for (int sp = 0; sp < D1_SPLIT; ++sp) { s.x += v[sp].x; s.y += v[sp].y; s.z += v[sp].z; s.w += v[sp].w; }
     }
@@ -831,8 +897,13 @@ int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group
 }
 
 int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, const caelo_enc_out &outs,
-                      int out_stride, void *ws, hipStream_t s, hipEvent_t *ev /* 5 events or null */) {
+                      int out_stride, void *ws, hipStream_t s, hipEvent_t *ev /* 5 events or null */, const caelo_enc_in *in) {
     CAELO_REQUIRE(c && bits && ws, "null argument");
+    // plain launch: every patch, contiguous
+    const caelo_enc_in ein = in ? *in : caelo_enc_in{(const unsigned long long *)bits, 0, (int32_t)(n_patches < 0x7FFFFFFF ? n_patches : 0), 1, 0};
+    CAELO_REQUIRE(!ein.dedup || (ein.n_frames >= 1 && ein.n_frames <= CAELO_ENC_MAX_FRAMES && ein.per_frame % (3 * D1_BM) == 0 &&
+                                 (int64_t)ein.n_frames * ein.per_frame == n_patches),
+                  "bad de-duplicated launch");
     CAELO_REQUIRE(outs.per_frame > 0 && (n_patches + outs.per_frame - 1) / outs.per_frame <= CAELO_ENC_MAX_FRAMES, "bad frame table");
     CAELO_REQUIRE(c->has_enc, "encoder weights not set (caelo_set_encoder_weights)");
     CAELO_REQUIRE(n_patches > 0 && group >= 1 && out_stride >= group * 20, "bad shape");
@@ -857,22 +928,21 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     const unsigned g1 = (unsigned)(n_patches < slots1 ? n_patches : slots1);
     if (ev) CAELO_HIP(hipEventRecord(ev[0], s));
     const int order_group = (n_patches % group == 0) ? group : 1;
-    k_enc_stage1<<<g1, 256, 0, s>>>((const unsigned long long *)bits, n_patches, order_group, work_counter, c->enc_w1, c->enc_b1, c->enc_w2,
-                                    c->enc_c0, p2);
+    k_enc_stage1<<<g1, 256, 0, s>>>(ein, n_patches, order_group, work_counter, c->enc_w1, c->enc_b1, c->enc_w2, c->enc_c0, p2);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[1], s));
     const int64_t pairs = (n_patches + 1) / 2;
     const unsigned g3 = (unsigned)(pairs < 512 ? pairs : 512);  // persistent: two 4-wave workgroups per CU
-    k_enc_conv3<<<g3, 256, 0, s>>>(p2, n_patches, (const uint4 *)c->enc_w3x, c->enc_b3, f3, work_counter);
+    k_enc_conv3<<<g3, 256, 0, s>>>(p2, n_patches, ein, (const uint4 *)c->enc_w3x, c->enc_b3, f3, work_counter);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[2], s));
     {
-        const int rc = dense1_launch<DENSE_K>(f3, np, c->enc_wd1x, part, s);
+        const int rc = dense1_launch<DENSE_K>(f3, np, c->enc_wd1x, part, ein, s);
         if (rc) return rc;
     }
     if (ev) CAELO_HIP(hipEventRecord(ev[3], s));
     k_enc_head<<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(part, n_patches, np, c->enc_bd1, c->enc_wd2, c->enc_bd2,
-                                                                group, outs, out_stride);
+                                                                group, outs, out_stride, ein);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[4], s));
     return CAELO_OK;
@@ -883,15 +953,16 @@ int64_t enc_dense_pad(int64_t n) { return pad64(n); }
 int64_t enc_dense32_part_bytes(int64_t np) { return (int64_t)D1_SPLIT * np * DENSE_NP * (int64_t)sizeof(float); }
 int enc_dense32_head_launch(caelo_ctx *c, const float *f3, int64_t n_patches, int64_t np, float *part, int group, float *out,
                             int out_stride, hipStream_t s) {
+    const caelo_enc_in plain = {nullptr, 0, (int32_t)n_patches, 1, 0};
     {
-        const int rc = dense1_launch<16384>(f3, np, c->enc32_wd1x, part, s);
+        const int rc = dense1_launch<16384>(f3, np, c->enc32_wd1x, part, plain, s);
         if (rc) return rc;
     }
     caelo_enc_out outs = {};
     outs.base[0] = out;
     outs.per_frame = n_patches;
     k_enc_head<<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(part, n_patches, np, c->enc32_bd1, c->enc_wd2,
-                                                                c->enc_bd2, group, outs, out_stride);
+                                                                c->enc_bd2, group, outs, out_stride, plain);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }

@@ -60,7 +60,7 @@ int caelo_clear_many(const caelo_clear_list &list, hipStream_t s) {
 // fused extract
 // ------------------------------------------------------------------------------------------------
 struct ExtractLayout {
-    size_t ring, counter, winner, resp, cand, cand_count, bits, enc, total;
+    size_t ring, counter, winner, resp, cand, cand_count, bits, dd, enc, total;
 };
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -76,7 +76,8 @@ static ExtractLayout extract_layout() {
     L.ring = off; off += align256(npix * CAELO_RING_C * 4);
     L.resp = off; off += align256((size_t)CAELO_NET_H * CAELO_NET_W * 8 * 4);
     L.cand = off; off += align256((size_t)CAELO_NET_H * CAELO_NET_W * 8);
-    L.bits = off; off += align256((size_t)CAELO_MAX_KEYPTS * 3 * 64 * 8);
+    L.bits = off; off += align256(CAELO_FRAME_BUF_BYTES);  // bit-packed patches + de-duplication tables
+    L.dd = off; off += align256((size_t)dedup_scratch_bytes());
     L.enc = off; off += align256((size_t)caelo_encode_ws_bytes(CAELO_MAX_KEYPTS * 3));
     L.total = off;
     return L;
@@ -120,6 +121,7 @@ int extract_front_launch(const caelo_extract_args &a, hipStream_t s) {
     cl.item[cl.n++] = {a.status, 16, 0u};  // status is int32[4], 16-byte aligned (word 0 carries the bits)
     const bool exact_vox = (a.mode & CAELO_EXTRACT_EXACT_VOXELS) != 0;
     vox_clear_items(a.map, exact_vox ? 1 : 0, cl);
+    dedup_clear_item(ws + L.dd, cl);
     int rc = caelo_clear_many(cl, s);
     if (rc) return rc;
     // ---- ring image, response, keypoints
@@ -133,14 +135,20 @@ int extract_front_launch(const caelo_extract_args &a, hipStream_t s) {
     if (exact_vox) rc = vox_build_launch(a.map, a.pc, a.n, 4, false, a.status, s);
     else rc = vox_build_fast_launch(a.map, a.pc, a.n, 4, a.status, s);
     if (rc) return rc;
-    return vox_patches_launch(a.map, a.key_pts, a.kp_ld, CAELO_MAX_KEYPTS, a.n_key, bits, a.flags, a.status, true, s);
+    if ((rc = vox_patches_launch(a.map, a.key_pts, a.kp_ld, CAELO_MAX_KEYPTS, a.n_key, bits, a.flags, a.status, true, s))) return rc;
+    // equal patches are encoded once (dedup.hip): tables behind the frame's bits
+    return dedup_launch(bits, ws + L.dd, !(a.mode & CAELO_EXTRACT_NO_DEDUP), s);
 }
 
 int extract_encode_launch(const caelo_extract_args &a, hipStream_t s) {
     const ExtractLayout L = extract_layout();
     char *ws = (char *)a.ws;
-    return encode_impl(a.ctx, a.bits ? a.bits : (const uint64_t *)(ws + L.bits), CAELO_MAX_KEYPTS * 3, 3, a.features,
-                       a.feat_ld, ws + L.enc, s, nullptr);
+    const uint64_t *bits = a.bits ? a.bits : (const uint64_t *)(ws + L.bits);
+    caelo_enc_out outs;
+    outs.base[0] = a.features;
+    outs.per_frame = CAELO_FRAME_PATCHES;
+    const caelo_enc_in in = {(const unsigned long long *)bits, 0, CAELO_FRAME_PATCHES, 1, 1};
+    return encode_batch_impl(a.ctx, bits, CAELO_FRAME_PATCHES, 3, outs, a.feat_ld, ws + L.enc, s, nullptr, &in);
 }
 
 CAELO_API int caelo_extract(caelo_ctx *c, caelo_voxmap *m, const float *pc, int64_t n, int dist_channels, int mode,

@@ -145,7 +145,7 @@ int run_front(caelo_pipeline *p, Worker &lane, uint64_t seq, int64_t *waited) {
     }
     const caelo_extract_args xa = {p->ctx, lane.map, j.pc, j.n, j.dist_channels, j.mode, j.rows + 60, 64, j.rows, 64,
                                    j.rows + 63, 64, j.key_pixels, j.n_key, j.flags, j.status, lane.ws_extract,
-                                   p->bits[sl.batch % p->n_bits] + (size_t)sl.index * FRAME_PATCHES * 64};
+                                   p->bits[sl.batch % p->n_bits] + (size_t)sl.index * (CAELO_FRAME_BUF_BYTES / 8)};
     if (!skip && rc == CAELO_OK) rc = extract_check(xa);
     if (!skip && rc == CAELO_OK) rc = extract_front_launch(xa, lane.stream);
     if (rc == CAELO_OK) rc = hip_rc(hipEventRecord(sl.fronted, lane.stream), "hipEventRecord");
@@ -171,8 +171,13 @@ int run_encode(caelo_pipeline *p, uint64_t b, int64_t *waited) {
     }
     if (p->timing && rc == CAELO_OK) (void)hipEventRecord(bt.t0, enc.stream);
     if (rc == CAELO_OK && !failed(p))
+    {
+        // frame buffers of the batch: [3072][64] patches + de-duplication tables each, only distinct patches are encoded
+        const caelo_enc_in in = {(const unsigned long long *)p->bits[b % p->n_bits], (int64_t)(CAELO_FRAME_BUF_BYTES / 8),
+                                 (int32_t)FRAME_PATCHES, bt.count, 1};
         rc = encode_batch_impl(p->ctx, p->bits[b % p->n_bits], bt.count * FRAME_PATCHES, 3, outs, 64,
-                               p->enc_ws[b % p->encoders.size()], enc.stream, nullptr);
+                               p->enc_ws[b % p->encoders.size()], enc.stream, nullptr, &in);
+    }
     if (p->timing && rc == CAELO_OK) (void)hipEventRecord(bt.t1, enc.stream);
     if (rc == CAELO_OK) rc = hip_rc(hipEventRecord(bt.encoded, enc.stream), "hipEventRecord");
     {
@@ -365,7 +370,7 @@ CAELO_API int caelo_pipeline_create(caelo_ctx *c, int n_lanes, int batch, int64_
         if (rc == CAELO_OK) hip_ok(hipMemset(p->enc_ws[i], 0, 256), "hipMemset");  // stage-1 work counter (self-cleaning)
     }
     for (int i = 0; i < p->n_bits; ++i)
-        hip_ok(hipMalloc((void **)&p->bits[i], (size_t)batch * FRAME_PATCHES * 64 * sizeof(uint64_t)), "hipMalloc");
+        hip_ok(hipMalloc((void **)&p->bits[i], (size_t)batch * CAELO_FRAME_BUF_BYTES), "hipMalloc");
     if (rc != CAELO_OK) {
         caelo_pipeline_destroy(p);
         return rc;

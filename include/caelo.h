@@ -54,6 +54,8 @@ typedef enum {
 #define CAELO_ST_VOXEL_INEXACT 32 /* caelo_extract's one-pass voxelization met a point within an ulp of a voxel
                                      face: re-run the frame with CAELO_EXTRACT_EXACT_VOXELS (never data loss) */
 #define CAELO_EXTRACT_EXACT_VOXELS 1 /* caelo_extract mode bit: two-pass first-touch voxelization (Voxel.py:139-141) */
+#define CAELO_EXTRACT_NO_DEDUP 2     /* caelo_extract mode bit: encode every patch, also bit-identical copies of another one
+                                        (by default equal patches of a frame are encoded once: same descriptors, bit for bit) */
 
 typedef struct caelo_ctx caelo_ctx;
 typedef struct caelo_voxmap caelo_voxmap;

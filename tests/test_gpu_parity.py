@@ -578,3 +578,24 @@ def test_config5_pose_from_32cube_descriptors(engine, scans):
     R, T = synth.relative_pose_gt(0, 1)
     assert r.success == 1 and r.n_inliers >= 200
     assert np.abs(np.array(r.R).reshape(3, 3) - R).max() < 5e-3 and np.abs(np.array(r.T).reshape(3, 1) - T).max() < 0.05
+
+
+# ---- exact de-duplication of equal patches (dedup.hip) -------------------------------------------------------------------
+def test_patch_dedup_is_bitwise_invisible(engine, scans, monkeypatch):
+    import torch
+    pcs = [torch.from_numpy(scans(i)).to(engine.device) for i in range(3)]
+    for pc in pcs:
+        a = engine.extract(pc)                       # equal patches encoded once
+        b = engine.extract(pc, dedup=False)          # every patch encoded
+        assert int(a.status[0].item()) == 0 and torch.equal(a.rows, b.rows) and torch.equal(a.key_pixels, b.key_pixels)
+    # the frame really holds duplicates (otherwise this test proves nothing)
+    f = engine.extract(pcs[0])
+    bits, _ = engine.patches(engine.voxelize(pcs[0])[0], f.key_pts.contiguous())
+    distinct = len(np.unique(bits.cpu().numpy().reshape(3072, 64), axis=0))
+    assert distinct < 2600
+    # pipeline: de-duplicated batches == plain single calls
+    pipe = engine.pipeline(lanes=3, batch=2)
+    got = pipe.run(pcs + pcs[:2], pairs=False)
+    torch.cuda.synchronize()
+    for i, pc in enumerate(pcs + pcs[:2]):
+        assert torch.equal(got.rows[i], engine.extract(pc, dedup=False).rows)
