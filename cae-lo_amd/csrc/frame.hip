@@ -147,7 +147,7 @@ int extract_encode_launch(const caelo_extract_args &a, hipStream_t s) {
     caelo_enc_out outs;
     outs.base[0] = a.features;
     outs.per_frame = CAELO_FRAME_PATCHES;
-    const caelo_enc_in in = {(const unsigned long long *)bits, 0, CAELO_FRAME_PATCHES, 1, 1};
+    const caelo_enc_in in = {(const unsigned long long *)bits, 0, CAELO_FRAME_PATCHES, 1, 1, 0};
     return encode_batch_impl(a.ctx, bits, CAELO_FRAME_PATCHES, 3, outs, a.feat_ld, ws + L.enc, s, nullptr, &in);
 }
 

@@ -174,7 +174,7 @@ int run_encode(caelo_pipeline *p, uint64_t b, int64_t *waited) {
     {
         // frame buffers of the batch: [3072][64] patches + de-duplication tables each, only distinct patches are encoded
         const caelo_enc_in in = {(const unsigned long long *)p->bits[b % p->n_bits], (int64_t)(CAELO_FRAME_BUF_BYTES / 8),
-                                 (int32_t)FRAME_PATCHES, bt.count, 1};
+                                 (int32_t)FRAME_PATCHES, bt.count, 1, 1};
         rc = encode_batch_impl(p->ctx, p->bits[b % p->n_bits], bt.count * FRAME_PATCHES, 3, outs, 64,
                                p->enc_ws[b % p->encoders.size()], enc.stream, nullptr, &in);
     }
