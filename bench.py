@@ -225,6 +225,8 @@ def main():
                        "arithmetic": "f32 in / out / accumulate; conv3 and Dense(200) evaluate every f32 product as six exact "
                                      "bf16 x bf16 partial products (3-way operand split) on the bf16 matrix pipe -- f32-grade "
                                      "(descriptor error vs the f32 oracle 1.5e-6, DESIGN.md 4.6); match in f64",
+                       "dedup": "bit-identical patches of a frame are encoded once (exact; DESIGN.md 4.7); the roofline "
+                                "object times the encoder kernels on all 3072 patches",
                        "points_per_frame": n_points, "keypoints": 1024, "patches_per_frame": 3072,
                        "frames_per_gpu": K, "hip_streams_per_gpu": pipe.lanes + 1, "frames_per_encoder_launch": pipe.batch,
                        "host_issue_us_per_frame": round(host["issue_us_per_frame"], 1),
