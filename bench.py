@@ -86,8 +86,8 @@ def cpu_baseline(n_frames=16, max_seconds=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=240)
-    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=960)
+    ap.add_argument("--warmup", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanes", type=int, default=6,
                     help="HIP streams per rank; whole frames are issued round-robin so the latency-bound kernels of "

@@ -61,7 +61,9 @@ __global__ void __launch_bounds__(256) k_dd_insert(const unsigned long long *__r
             if (cur == DD_EMPTY) break;
         }
         if ((cur >> 24) == h) {
-            atomicMin(&S->table[slot], mine);
+            // hundreds of patches share a popular pattern: only a smaller index than the one seen needs the atomic (a
+            // stale larger value only costs an atomic that changes nothing)
+            if (mine < cur) atomicMin(&S->table[slot], mine);
             break;
         }
         slot = (slot + 1) & (DD_SLOTS - 1);
