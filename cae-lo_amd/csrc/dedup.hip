@@ -124,15 +124,15 @@ __global__ void __launch_bounds__(1024) k_dd_scan(const DedupScratch *S, caelo_d
 
 // bits: the frame's [3072][64] u64 patches, followed by its caelo_dedup_tables (caelo_frame_tables)
 int dedup_launch(uint64_t *bits, void *scratch, bool enabled, hipStream_t s) {
-    static unsigned long long mask = 0;
-    static bool off = false;
-    if (!mask) {
+    static const unsigned long long mask = [] {
         const char *e = getenv("CAELO_DEDUP_HASH_BITS");
         const int nb = e ? atoi(e) : 40;
-        mask = nb >= 40 || nb < 1 ? 0xFFFFFFFFFFull : ((1ull << nb) - 1ull) << 1;
+        return nb >= 40 || nb < 1 ? 0xFFFFFFFFFFull : ((1ull << nb) - 1ull) << 1;
+    }();
+    static const bool off = [] {
         const char *d = getenv("CAELO_NO_DEDUP");
-        off = d && atoi(d);
-    }
+        return d && atoi(d);
+    }();
     DedupScratch *S = (DedupScratch *)scratch;
     caelo_dedup_tables *T = caelo_frame_tables(bits);
     const bool on = enabled && !off;

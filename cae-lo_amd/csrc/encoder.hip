@@ -800,12 +800,14 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1(const float *__res
 
 template <int KTOT>
 static int dense1_launch(const float *f3, int64_t np, const void *wd1x, float *part, const caelo_enc_in &in, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        CAELO_HIP(hipFuncSetAttribute((const void *)k_enc_dense1<KTOT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, D1_LDS_BYTES(1)));
-        CAELO_HIP(hipFuncSetAttribute((const void *)k_enc_dense1<KTOT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, D1_LDS_BYTES(3)));
-        attr = true;
-    }
+    // once per process (thread-safe static initialisation: the pipeline's encoder thread and the caller may race here)
+    static const hipError_t attr = [] {
+        hipError_t e = hipFuncSetAttribute((const void *)k_enc_dense1<KTOT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, D1_LDS_BYTES(1));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)k_enc_dense1<KTOT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, D1_LDS_BYTES(3));
+        return e;
+    }();
+    CAELO_HIP(attr);
     // 64-row tiles for K = 2048 (8 stages per workgroup; measured 1 % ahead of 192-row tiles inside the frame
     // pipeline although 15 % behind in isolation); 192-row tiles for the long-K instance, where the weight stream
     // from L2 would otherwise bound the kernel
@@ -918,13 +920,13 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
         CAELO_HIP(hipMemsetAsync(f3 + n_patches * 2048, 0, (size_t)(np - n_patches) * 2048 * sizeof(float), s));
     // persistent grid = exactly the resident workgroup slots (weights stay in registers across patches,
     // no second partially filled round)
-    static int slots1 = 0;
-    if (!slots1) {
+    static const int slots1 = [](int device) {
         int per_cu = 0, cus = 0;
-        CAELO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_enc_stage1, 256, 0));
-        CAELO_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-        slots1 = per_cu * cus > 0 ? per_cu * cus : 1024;
-    }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_enc_stage1, 256, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || per_cu * cus <= 0)
+            return 768;  // 3 workgroups on each of MI355X's 256 CUs
+        return per_cu * cus;
+    }(c->device);
     // Inside the frame pipeline the persistent grids leave a fifth / a quarter of their slots free: stage 1 and conv3
     // otherwise own every register file for their whole run and the other streams' kernels only get CUs between them
     // (measured +3 % frames/s; alone, the full grid is ~8 % faster)

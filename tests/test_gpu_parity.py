@@ -588,6 +588,12 @@ def test_patch_dedup_is_bitwise_invisible(engine, scans, monkeypatch):
         a = engine.extract(pc)                       # equal patches encoded once
         b = engine.extract(pc, dedup=False)          # every patch encoded
         assert int(a.status[0].item()) == 0 and torch.equal(a.rows, b.rows) and torch.equal(a.key_pixels, b.key_pixels)
+    # ragged frame: fewer than 1024 key points (the unused rows hold empty patches, which all collapse into one)
+    part = pcs[0][::7].contiguous()
+    a, b = engine.extract(part), engine.extract(part, dedup=False)
+    k = int(a.n_key.item())
+    assert 50 < k < 1024 and k == int(b.n_key.item())
+    assert torch.equal(a.rows[:, 0:60], b.rows[:, 0:60]) and torch.equal(a.rows[:k], b.rows[:k])  # key point columns past k are not written
     # the frame really holds duplicates (otherwise this test proves nothing)
     f = engine.extract(pcs[0])
     bits, _ = engine.patches(engine.voxelize(pcs[0])[0], f.key_pts.contiguous())
