@@ -377,6 +377,196 @@ __global__ void __launch_bounds__(256, 2) k5_conv3_x3(const float *__restrict__ 
 #undef C5_PK
 }
 
+// ---- conv2 + pool with the same arithmetic: K = 32 = four taps x 8 channels per MFMA ----------------------------------------
+// The 27 taps go into 7 quads in Keras order (taps 4q .. 4q + 3, one empty slot); lane group g carries tap 4q + g, and its
+// position offset is a per-lane value computed once (7 address registers per tile row).  LDS per split: [pos][8] bf16 over
+// the 4 zero-haloed input planes of a pooled x plane (18 x 18 each, 62 KB for the three splits: two workgroups per CU);
+// an m-tile is one 16-voxel z row, a wave owns the 2 x 2 (x, y) rows of a pooled row (MaxPool = register max).
+#define X2_DP 18
+#define X2_NPOS (4 * X2_DP * X2_DP)
+#define X2_ARR (X2_NPOS * 16)
+#define X2_NQ 7
+__device__ constexpr int c5_tapPos2(int t) { return (t / 9) * X2_DP * X2_DP + ((t / 3) % 3) * X2_DP + (t % 3); }
+
+__global__ void __launch_bounds__(256, 2) k5_conv2_x3(const float *__restrict__ in, const float *__restrict__ w,
+                                                      const float *__restrict__ b, float *__restrict__ out, int n_items) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [split 3][X2_NPOS][8] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, g = lane >> 4;
+    // B operand: quad q, split s: the 8 input channels of tap 4 q + g, output column m
+    uint4 bq[X2_NQ][3];
+    int aoff[X2_NQ];  // byte offset of this lane's tap within quad q
+#pragma unroll
+    for (int q = 0; q < X2_NQ; ++q) {
+        const int tap = 4 * q + g;
+        uint32_t h[8], mi[8], lo[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c5_split3(tap < 27 ? w[(size_t)(tap * 8 + i) * 16 + m] : 0.0f, h[i], mi[i], lo[i]);
+#define C5_PK(A) make_uint4((A[0] >> 16) | A[1], (A[2] >> 16) | A[3], (A[4] >> 16) | A[5], (A[6] >> 16) | A[7])
+        bq[q][0] = C5_PK(h);
+        bq[q][1] = C5_PK(mi);
+        bq[q][2] = C5_PK(lo);
+        // tap index is lane dependent: spell the position offset out (t / 9, (t / 3) % 3, t % 3 of a runtime t)
+        const int t = tap < 27 ? tap : 26;  // the empty slot reads a valid address, its weights are zero
+        aoff[q] = ((t / 9) * X2_DP * X2_DP + ((t / 3) % 3) * X2_DP + (t % 3)) * 16;
+    }
+    const float bias = b[m];
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int64_t patch = item >> 3;
+        const int px = item & 7;
+        const float *src = in + (size_t)patch * 4096 * 8;
+        __syncthreads();
+        for (int pos = tid; pos < X2_NPOS; pos += 256) {
+            const int x = 2 * px - 1 + pos / (X2_DP * X2_DP), y = (pos / X2_DP) % X2_DP - 1, z = pos % X2_DP - 1;
+            uint32_t hh[8], mm[8], ll[8];
+            if (x >= 0 && x < 16 && y >= 0 && y < 16 && z >= 0 && z < 16) {
+                const float4 *q4 = (const float4 *)(src + (((size_t)x * 16 + y) * 16 + z) * 8);
+                const float4 v0 = q4[0], v1 = q4[1];
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c5_split3(v[k], hh[k], mm[k], ll[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) hh[k] = mm[k] = ll[k] = 0u;
+            }
+            *(uint4 *)(lds + 0 * X2_ARR + pos * 16) = C5_PK(hh);
+            *(uint4 *)(lds + 1 * X2_ARR + pos * 16) = C5_PK(mm);
+            *(uint4 *)(lds + 2 * X2_ARR + pos * 16) = C5_PK(ll);
+        }
+        __syncthreads();
+        for (int pi = 0; pi < 2; ++pi) {
+            const int py = 2 * wave + pi;
+            // tile (xa, yb): output (xa, y = 2 py + yb, z = m); padded corner = position (xa, y, m)
+            const unsigned char *base = lds + ((2 * py) * X2_DP + m) * 16;
+            c5_f32x4 acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = (c5_f32x4){bias, bias, bias, bias};
+#pragma unroll
+            for (int q = 0; q < X2_NQ; ++q) {
+                const c5_bf16x8 bh = __builtin_bit_cast(c5_bf16x8, bq[q][0]), bm = __builtin_bit_cast(c5_bf16x8, bq[q][1]),
+                                bl = __builtin_bit_cast(c5_bf16x8, bq[q][2]);
+                c5_bf16x8 ah[4], am[4], al[4];
+                const unsigned char *a = base + aoff[q];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {  // j = 2 xa + yb
+                    const int o = ((j >> 1) * X2_DP * X2_DP + (j & 1) * X2_DP) * 16;
+                    ah[j] = __builtin_bit_cast(c5_bf16x8, *(const uint4 *)(a + o));
+                    am[j] = __builtin_bit_cast(c5_bf16x8, *(const uint4 *)(a + o + X2_ARR));
+                    al[j] = __builtin_bit_cast(c5_bf16x8, *(const uint4 *)(a + o + 2 * X2_ARR));
+                }
+#define X2_MAC(A, B) _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j], B, acc[j], 0, 0, 0);
+                X2_MAC(al, bh)
+                X2_MAC(ah, bl)
+                X2_MAC(am, bm)
+                X2_MAC(am, bh)
+                X2_MAC(ah, bm)
+                X2_MAC(ah, bh)
+            }
+            // C rows 4 g + r = z; pooled z = 2 g + zp
+            float *dst = out + ((((size_t)patch * 8 + px) * 8 + py) * 8 + 2 * g) * 16 + m;
+#pragma unroll
+            for (int zp = 0; zp < 2; ++zp) {
+                float v = fmaxf(fmaxf(acc[0][2 * zp], acc[0][2 * zp + 1]), fmaxf(acc[1][2 * zp], acc[1][2 * zp + 1]));
+                v = fmaxf(v, fmaxf(fmaxf(acc[2][2 * zp], acc[2][2 * zp + 1]), fmaxf(acc[3][2 * zp], acc[3][2 * zp + 1])));
+                dst[zp * 16] = c5_tanh(v);
+            }
+        }
+    }
+#undef C5_PK
+#undef X2_MAC
+}
+
+// ---- conv1 + pool on the bf16 pipe: the input is binary, so only the weights need the 3-way split ------------------------
+// Same GEMM view as k5_conv1pool (n = (z parity, channel), m = the 16 even z of a row, k = the 3 x 3 x 4 tap window), with
+// the voxels stored as bf16 0 / 1 (exact): a product is A (B_hi + B_mid + B_lo), three MFMAs per k slab.  The window's
+// 36 k go into two K = 32 slabs: lane group g carries window rows 2g and 2g + 1 (4 consecutive z each = two dwords of
+// the voxel row), the ninth row sits alone in the second slab.  6 x 16 cycles per 32-voxel row instead of 9 x 32.
+#define C1X_PITCH 36                       // bf16 per padded z row (34 used)
+#define C1X_PLANE (34 * C1X_PITCH)
+__global__ void __launch_bounds__(256) k5_conv1pool_x3(const unsigned long long *__restrict__ bits, const float *__restrict__ w1,
+                                                       const float *__restrict__ b1, float *__restrict__ p1, int n_items) {
+    __shared__ __attribute__((aligned(16))) unsigned short vox[4 * C1X_PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, g = lane >> 4;
+    const int dz = m >> 3, ch = m & 7;  // as the n index of B and C
+    // B: slab 0 = window rows 2g, 2g+1; slab 1 = row 8 in lanes g == 0; element i -> (row + i / 4, kc' = i % 4)
+    uint4 bq[2][3];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        uint32_t h[8], mi[8], lo[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = sl == 0 ? 2 * g + (i >> 2) : (g == 0 && i < 4 ? 8 : -1);
+            const int kc = (i & 3) - dz;
+            c5_split3(r >= 0 && kc >= 0 && kc < 3 ? w1[(r * 3 + kc) * 8 + ch] : 0.0f, h[i], mi[i], lo[i]);
+        }
+#define C5_PK(A) make_uint4((A[0] >> 16) | A[1], (A[2] >> 16) | A[3], (A[4] >> 16) | A[5], (A[6] >> 16) | A[7])
+        bq[sl][0] = C5_PK(h);
+        bq[sl][1] = C5_PK(mi);
+        bq[sl][2] = C5_PK(lo);
+#undef C5_PK
+    }
+    // element offsets (bf16 units) of this lane's two window rows in slab 0; slab 1 reads row 8 everywhere
+    const int r0 = 2 * g, r1 = 2 * g + 1;
+    const int off0 = (r0 / 3) * C1X_PLANE + (r0 % 3) * C1X_PITCH, off1 = (r1 / 3) * C1X_PLANE + (r1 % 3) * C1X_PITCH;
+    const int off8 = 2 * C1X_PLANE + 2 * C1X_PITCH;
+    const float bias = b1[ch];
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int64_t patch = item >> 4;
+        const int px = item & 15;
+        const uint32_t *src = (const uint32_t *)(bits + patch * 512);
+        __syncthreads();
+        // 4 planes x 34 rows of 36 bf16 = 18 dwords: thread -> (row, third of the row = 6 dwords)
+        for (int i = tid; i < 4 * 34 * 3; i += 256) {
+            const int row = i / 3, part = i % 3;
+            const int x = 2 * px - 1 + row / 34, y = row % 34 - 1;
+            const uint32_t word = (x >= 0 && x < 32 && y >= 0 && y < 32) ? src[x * 32 + y] : 0u;
+            uint32_t *dst = (uint32_t *)&vox[row * C1X_PITCH + part * 12];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int z0 = part * 12 + 2 * j - 1, z1 = z0 + 1;  // padded indices part*12 + 2j, + 1
+                const uint32_t lo16 = (z0 >= 0 && z0 < 32 && ((word >> z0) & 1u)) ? 0x3F80u : 0u;
+                const uint32_t hi16 = (z1 >= 0 && z1 < 32 && ((word >> z1) & 1u)) ? 0x3F80u : 0u;
+                dst[j] = lo16 | (hi16 << 16);
+            }
+        }
+        __syncthreads();
+        for (int pi = 0; pi < 4; ++pi) {
+            const int py = 4 * wave + pi;
+            // tile (xa, yb): output (xa, y = 2 py + yb, z = 2 m + dz) reads padded (xa + ka, y + kb, 2 m + kc')
+            const unsigned short *base = &vox[(2 * py) * C1X_PITCH + 2 * m];
+            c5_f32x4 acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = (c5_f32x4){bias, bias, bias, bias};
+            c5_bf16x8 a0[4], a1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // j = 2 xa + yb
+                const unsigned short *t = base + (j >> 1) * C1X_PLANE + (j & 1) * C1X_PITCH;
+                // 4-byte aligned pairs of dwords (the row offset 2 m is only even): ds_read2_b32, not ds_read_b64
+                const uint32_t *q0 = (const uint32_t *)(t + off0), *q1 = (const uint32_t *)(t + off1), *q8 = (const uint32_t *)(t + off8);
+                a0[j] = __builtin_bit_cast(c5_bf16x8, make_uint4(q0[0], q0[1], q1[0], q1[1]));
+                a1[j] = __builtin_bit_cast(c5_bf16x8, make_uint4(q8[0], q8[1], 0u, 0u));
+            }
+#pragma unroll
+            for (int sp = 2; sp >= 0; --sp) {  // smallest terms first
+                const c5_bf16x8 b0 = __builtin_bit_cast(c5_bf16x8, bq[0][sp]), b1v = __builtin_bit_cast(c5_bf16x8, bq[1][sp]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[j], b0, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[j], b1v, acc[j], 0, 0, 0);
+            }
+            // C row 4 g + r = pooled z; column = (dz, c)
+            float *dst = p1 + ((((size_t)patch * 16 + px) * 16 + py) * 16 + 4 * g) * 8 + ch;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = fmaxf(fmaxf(acc[0][r], acc[1][r]), fmaxf(acc[2][r], acc[3][r]));
+                v = fmaxf(v, __shfl_xor(v, 8));
+                if (dz == (r >> 1)) dst[r * 8] = c5_tanh(v);
+            }
+        }
+    }
+}
+
 // ---- C ABI -------------------------------------------------------------------------------------------------------
 CAELO_API int caelo_patches32(caelo_ctx *c, const caelo_voxmap *m, const float *pts, int pts_ld, int64_t k_max,
                               const int32_t *n_key, uint64_t *bits, void *stream) {
@@ -416,13 +606,20 @@ CAELO_API int caelo_encode32(caelo_ctx *c, const uint64_t *bits, int64_t n_patch
     float *part = f3 + np * 16384;
     if (np > n_patches) CAELO_HIP(hipMemsetAsync(f3 + n_patches * 16384, 0, (size_t)(np - n_patches) * 16384 * sizeof(float), s));
     const int items1 = (int)(n_patches * 16);
-    k5_conv1pool<<<items1 < 1024 ? items1 : 1024, 256, 0, s>>>((const unsigned long long *)bits, c->enc_w1, c->enc_b1, p1, items1);
+    static const bool x3 = !(getenv("CAELO_C5_F32") && atoi(getenv("CAELO_C5_F32")));
+    if (x3) k5_conv1pool_x3<<<items1 < 1024 ? items1 : 1024, 256, 0, s>>>((const unsigned long long *)bits, c->enc_w1, c->enc_b1, p1, items1);
+    else k5_conv1pool<<<items1 < 1024 ? items1 : 1024, 256, 0, s>>>((const unsigned long long *)bits, c->enc_w1, c->enc_b1, p1, items1);
     CAELO_LAUNCH_CHECK();
     // persistent grids: the B operand (conv weights) is loaded into registers once per workgroup
     const int items2 = (int)(n_patches * 8), items3 = (int)(n_patches * 2);
-    k5_conv_mfma<16, 8, 16, true><<<items2 < 768 ? items2 : 768, 256, 0, s>>>(p1, c->enc_w2, c->enc_b2, p2, items2);
+    if (x3) {
+        static const hipError_t attr = hipFuncSetAttribute((const void *)k5_conv2_x3, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X2_ARR);
+        CAELO_HIP(attr);
+        k5_conv2_x3<<<items2 < 512 ? items2 : 512, 256, 3 * X2_ARR, s>>>(p1, c->enc_w2, c->enc_b2, p2, items2);
+    } else {
+        k5_conv_mfma<16, 8, 16, true><<<items2 < 768 ? items2 : 768, 256, 0, s>>>(p1, c->enc_w2, c->enc_b2, p2, items2);
+    }
     CAELO_LAUNCH_CHECK();
-    static const bool x3 = !(getenv("CAELO_C5_F32") && atoi(getenv("CAELO_C5_F32")));
     if (x3) k5_conv3_x3<<<items3 < 512 ? items3 : 512, 256, 6 * X3_ARR, s>>>(p2, c->enc_w3, c->enc_b3, f3, items3);
     else k5_conv_mfma<8, 16, 32, false><<<items3 < 512 ? items3 : 512, 256, 0, s>>>(p2, c->enc_w3, c->enc_b3, f3, items3);
     CAELO_LAUNCH_CHECK();
