@@ -89,6 +89,9 @@ struct caelo_voxmap {
     // Without first-touch order tracking only the part of the ff region before `||` is cleared.
     char *base;
     size_t ff_bytes_keys, ff_bytes_min, ff_bytes_all, zero_off, zero_bytes, total_bytes;
+    // host-side: the map's only contents are the bricks of the last fused build, all listed in list0 / list1 (+ scale 2):
+    // the next fused build may wipe exactly those entries instead of the whole 25 MB (vox_clear_for_fast_build)
+    bool lists_valid;
     // export scratch
     void *scratch;
     int64_t scratch_bytes;
@@ -116,6 +119,9 @@ int ring_keypoints_launch(const float *ring, int ring_w, int ring_c, int dist_c,
                           int64_t *key_pixels, float *key_pts, int kp_ld, float *valid, int valid_ld, int32_t *n_key,
                           int32_t *status, hipStream_t s);
 void vox_clear_items(caelo_voxmap *m, int level, caelo_clear_list &list);  // 0 brick keys only, 1 + scale-0 first-touch table, 2 everything
+// clear for a fused build: if the map holds nothing but the previous fused build, its listed bricks are wiped by a
+// kernel launched here (before the caller's clear list runs) and only the small scale-2 table + counters join the list
+int vox_clear_for_fast_build(caelo_voxmap *m, caelo_clear_list &list, hipStream_t s);
 int vox_build_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, bool track_order, int32_t *status,
                      hipStream_t s);
 int vox_build_fast_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, int32_t *status, hipStream_t s);

@@ -120,9 +120,11 @@ int extract_front_launch(const caelo_extract_args &a, hipStream_t s) {
     cl.item[cl.n++] = {counter, L.ring - L.counter, 0u};  // counter | cand_count
     cl.item[cl.n++] = {a.status, 16, 0u};  // status is int32[4], 16-byte aligned (word 0 carries the bits)
     const bool exact_vox = (a.mode & CAELO_EXTRACT_EXACT_VOXELS) != 0;
-    vox_clear_items(a.map, exact_vox ? 1 : 0, cl);
+    int rc = CAELO_OK;
+    if (exact_vox) vox_clear_items(a.map, 1, cl);
+    else if ((rc = vox_clear_for_fast_build(a.map, cl, s))) return rc;  // wipes the previous frame's bricks only
     dedup_clear_item(ws + L.dd, cl);
-    int rc = caelo_clear_many(cl, s);
+    rc = caelo_clear_many(cl, s);
     if (rc) return rc;
     // ---- ring image, response, keypoints
     if ((rc = ring_project_launch(a.pc, a.n, ring, counter, winner, a.status, s))) return rc;

@@ -87,7 +87,36 @@ void vox_clear_items(caelo_voxmap *m, int level, caelo_clear_list &list) {
     list.item[list.n++] = {m->base + m->zero_off, m->zero_bytes, 0u};
 }
 
+// wipe the bricks of the previous fused build: key -> empty, 8 payload words -> 0 (entry e, word w per thread)
+__global__ void __launch_bounds__(256) k_vox_clear_lists(caelo_brick_table b0, caelo_brick_table b1, const uint32_t *__restrict__ list0,
+                                                         const uint32_t *__restrict__ list1, const int32_t *__restrict__ counts) {
+    const int n0 = counts[4], n1 = counts[5];
+    const long long total = (long long)(n0 + n1) * 8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i >> 3), w = (int)(i & 7);
+        const caelo_brick_table &t = e < n0 ? b0 : b1;
+        const uint32_t slot = e < n0 ? list0[e] : list1[e - n0];
+        t.bits[(size_t)slot * 8 + w] = 0ull;
+        if (w == 0) t.keys[slot] = CAELO_EMPTY_KEY;
+    }
+}
+
+int vox_clear_for_fast_build(caelo_voxmap *m, caelo_clear_list &list, hipStream_t s) {
+    if (!m->lists_valid) {
+        vox_clear_items(m, 0, list);
+        return CAELO_OK;
+    }
+    k_vox_clear_lists<<<256, 256, 0, s>>>(m->brick[0], m->brick[1], m->list0, m->list1, m->counts);
+    CAELO_LAUNCH_CHECK();
+    // scale 2 has no list: its 16 k-slot table is cleared whole (keys, then payload + the counters right behind it)
+    const size_t slots2 = (size_t)m->brick[2].mask + 1;
+    list.item[list.n++] = {m->brick[2].keys, slots2 * 8, 0xFFFFFFFFu};
+    list.item[list.n++] = {m->brick[2].bits, slots2 * 64 + 64, 0u};
+    return CAELO_OK;
+}
+
 static int voxmap_clear(caelo_voxmap *m, bool track_order, hipStream_t s) {
+    m->lists_valid = false;
     caelo_clear_list list;
     list.n = 0;
     vox_clear_items(m, track_order ? 2 : 1, list);
@@ -413,6 +442,7 @@ __global__ void __launch_bounds__(256) k_vox_count2(caelo_brick_table b2, int32_
 }
 
 int vox_build_fast_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, int32_t *status, hipStream_t s) {
+    m->lists_valid = false;  // until every kernel of the build is enqueued
     k_vox_points<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(pc, n, stride, m->brick[0], m->list0, m->counts, status);
     CAELO_LAUNCH_CHECK();
     k_vox_coarse<<<256, 256, 0, s>>>(m->brick[0], m->brick[1], m->list0, m->list1, m->counts, status);
@@ -421,11 +451,13 @@ int vox_build_fast_launch(caelo_voxmap *m, const float *pc, int64_t n, int strid
     CAELO_LAUNCH_CHECK();
     k_vox_count2<<<(m->brick[2].mask + 256) / 256, 256, 0, s>>>(m->brick[2], m->counts);
     CAELO_LAUNCH_CHECK();
+    m->lists_valid = true;
     return CAELO_OK;
 }
 
 int vox_build_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, bool track_order, int32_t *status,
                      hipStream_t s) {
+    m->lists_valid = false;
     const unsigned grid = (unsigned)((n + 255) / 256);
     k_vox_first<<<grid, 256, 0, s>>>(pc, n, stride, m->vkeys[0], m->vfirst[0], m->vmask[0], status);
     CAELO_LAUNCH_CHECK();
