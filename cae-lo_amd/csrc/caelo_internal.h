@@ -126,7 +126,8 @@ int vox_build_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, bo
                      hipStream_t s);
 int vox_build_fast_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, int32_t *status, hipStream_t s);
 int vox_patches_launch(const caelo_voxmap *m, const float *pts, int pts_ld, int64_t k_max, const int32_t *n_key,
-                       uint64_t *bits, uint8_t *flags, int32_t *status, bool check_counts, hipStream_t s);
+                       uint64_t *bits, uint8_t *flags, int32_t *status, bool check_counts, hipStream_t s,
+                       void *dedup_scratch = nullptr);  // non-null: every patch is entered into the frame's dedup table
 // ---- a frame's patch buffer: bit-packed patches [3072][64] u64, then the de-duplication tables (dedup.hip) ----------
 #define CAELO_FRAME_PATCHES (CAELO_MAX_KEYPTS * 3)
 struct caelo_dedup_tables {
@@ -140,9 +141,18 @@ struct caelo_dedup_tables {
 __host__ __device__ inline caelo_dedup_tables *caelo_frame_tables(const uint64_t *frame_bits) {
     return (caelo_dedup_tables *)((char *)frame_bits + CAELO_FRAME_BITS_BYTES);
 }
+#define DD_SLOTS 8192  // >= 2.6 x the 3072 patches of a frame
+#define DD_EMPTY 0xFFFFFFFFFFFFFFFFull
+struct DedupScratch {
+    unsigned long long table[DD_SLOTS];  // (hash40 << 24) | smallest patch index, DD_EMPTY = free (cleared per frame)
+    int32_t pslot[CAELO_FRAME_PATCHES];
+    int32_t rep[CAELO_FRAME_PATCHES];
+};
 int64_t dedup_scratch_bytes();
 void dedup_clear_item(void *scratch, caelo_clear_list &list);
-int dedup_launch(uint64_t *frame_bits, void *scratch, bool enabled, hipStream_t s);
+unsigned long long dedup_hash_mask();  // 40 bits unless CAELO_DEDUP_HASH_BITS shrinks it (collision tests)
+bool dedup_enabled(int mode);          // mode bit CAELO_EXTRACT_NO_DEDUP / CAELO_NO_DEDUP=1 switch it off
+int dedup_launch(uint64_t *frame_bits, void *scratch, bool enabled, hipStream_t s);  // after k_patches filled the table
 
 // patches of up to CAELO_ENC_MAX_FRAMES frames encoded by one launch set (the fixed costs of the four encoder
 // kernels are ~47 us per launch set): frame f = patch / per_frame gets its descriptors in base[f]
@@ -217,6 +227,41 @@ __device__ inline uint32_t caelo_hash64(unsigned long long k) {
     k *= 0xc4ceb9fe1a85ec53ULL;
     k ^= k >> 33;
     return (uint32_t)k;
+}
+
+// One wavefront holds patch p, lane l its word l: hash the 64 words and claim / join the hash's entry of the frame's
+// de-duplication table (dedup.hip); the entry keeps the smallest patch index of the group.
+__device__ inline unsigned long long caelo_dd_mix(unsigned long long k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return k;
+}
+__device__ inline void caelo_dedup_insert(unsigned long long word, int lane, int p, DedupScratch *S, unsigned long long hash_mask) {
+    unsigned long long h = caelo_dd_mix(word + 0x9E3779B97F4A7C15ull * (unsigned)(lane + 1));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);  // order independent across lanes, position dependent per word
+    if (lane != 0) return;
+    h = caelo_dd_mix(h) & hash_mask & 0xFFFFFFFFFEull;  // 40 bits, never all ones
+    const unsigned long long mine = (h << 24) | (unsigned)p;
+    uint32_t slot = (uint32_t)(caelo_dd_mix(h) & (DD_SLOTS - 1));
+    for (;;) {
+        unsigned long long cur = S->table[slot];
+        if (cur == DD_EMPTY) {
+            cur = atomicCAS(&S->table[slot], DD_EMPTY, mine);
+            if (cur == DD_EMPTY) break;
+        }
+        if ((cur >> 24) == h) {
+            // hundreds of patches share a popular pattern: only a smaller index than the one seen needs the atomic (a
+            // stale larger value only costs an atomic that changes nothing)
+            if (mine < cur) atomicMin(&S->table[slot], mine);
+            break;
+        }
+        slot = (slot + 1) & (DD_SLOTS - 1);
+    }
+    S->pslot[p] = (int32_t)slot;
 }
 
 // read-only lookup: returns slot or -1

@@ -9,7 +9,8 @@
 // not depend on a patch's position in the launch: tests/test_gpu_parity.py), so the encoder runs once per distinct
 // patch and k_enc_head hands the result to every key point that owns a copy.
 //
-// Exactness: patches are grouped by a 40-bit hash, then every patch is compared word by word with the
+// Exactness: patches are grouped by a 40-bit hash (computed and entered into the table by k_patches, which has the
+// words in registers), then every patch is compared word by word with the
 // representative of its group (the smallest patch index with that hash); a patch that differs (hash collision)
 // stays its own representative.  CAELO_DEDUP_HASH_BITS=<n> shrinks the hash to n bits to exercise that path.
 //
@@ -19,57 +20,12 @@
 
 #include "caelo_internal.h"
 
-#define DD_SLOTS 8192  // >= 2.6 x the 3072 patches of a frame
-#define DD_EMPTY 0xFFFFFFFFFFFFFFFFull
-
-struct DedupScratch {
-    unsigned long long table[DD_SLOTS];  // (hash40 << 24) | smallest patch index, DD_EMPTY = free (cleared per frame)
-    int32_t pslot[CAELO_FRAME_PATCHES];
-    int32_t rep[CAELO_FRAME_PATCHES];
-};
-
 int64_t dedup_scratch_bytes() { return (int64_t)sizeof(DedupScratch); }
 void dedup_clear_item(void *scratch, caelo_clear_list &list) {
     list.item[list.n++] = {scratch, sizeof(unsigned long long) * DD_SLOTS, 0xFFFFFFFFu};
 }
 
-__device__ inline unsigned long long dd_mix(unsigned long long k) {
-    k ^= k >> 33;
-    k *= 0xff51afd7ed558ccdULL;
-    k ^= k >> 33;
-    k *= 0xc4ceb9fe1a85ec53ULL;
-    k ^= k >> 33;
-    return k;
-}
-
-// one wavefront per patch: hash the 64 words, claim / join the hash's table entry
-__global__ void __launch_bounds__(256) k_dd_insert(const unsigned long long *__restrict__ bits, DedupScratch *S,
-                                                   unsigned long long hash_mask) {
-    const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-    unsigned long long h = dd_mix(bits[(size_t)p * 64 + lane] + 0x9E3779B97F4A7C15ull * (unsigned)(lane + 1));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);  // order independent across lanes, position dependent per word
-    if (lane != 0) return;
-    h = dd_mix(h) & hash_mask & 0xFFFFFFFFFEull;  // 40 bits, never all ones
-    const unsigned long long mine = (h << 24) | (unsigned)p;
-    uint32_t slot = (uint32_t)(dd_mix(h) & (DD_SLOTS - 1));
-    for (;;) {
-        unsigned long long cur = S->table[slot];
-        if (cur == DD_EMPTY) {
-            cur = atomicCAS(&S->table[slot], DD_EMPTY, mine);
-            if (cur == DD_EMPTY) break;
-        }
-        if ((cur >> 24) == h) {
-            // hundreds of patches share a popular pattern: only a smaller index than the one seen needs the atomic (a
-            // stale larger value only costs an atomic that changes nothing)
-            if (mine < cur) atomicMin(&S->table[slot], mine);
-            break;
-        }
-        slot = (slot + 1) & (DD_SLOTS - 1);
-    }
-    S->pslot[p] = (int32_t)slot;
-}
+// (the per-patch hash + table insert runs at the end of k_patches, voxel.hip: caelo_dedup_insert in caelo_internal.h)
 
 // one wavefront per patch: word-by-word comparison with the group's representative
 __global__ void __launch_bounds__(256) k_dd_verify(const unsigned long long *__restrict__ bits, DedupScratch *S) {
@@ -123,22 +79,27 @@ __global__ void __launch_bounds__(1024) k_dd_scan(const DedupScratch *S, caelo_d
 }
 
 // bits: the frame's [3072][64] u64 patches, followed by its caelo_dedup_tables (caelo_frame_tables)
-int dedup_launch(uint64_t *bits, void *scratch, bool enabled, hipStream_t s) {
+unsigned long long dedup_hash_mask() {
     static const unsigned long long mask = [] {
         const char *e = getenv("CAELO_DEDUP_HASH_BITS");
         const int nb = e ? atoi(e) : 40;
         return nb >= 40 || nb < 1 ? 0xFFFFFFFFFFull : ((1ull << nb) - 1ull) << 1;
     }();
+    return mask;
+}
+bool dedup_enabled(int mode) {
     static const bool off = [] {
         const char *d = getenv("CAELO_NO_DEDUP");
         return d && atoi(d);
     }();
+    return !off && !(mode & CAELO_EXTRACT_NO_DEDUP);
+}
+
+int dedup_launch(uint64_t *bits, void *scratch, bool enabled, hipStream_t s) {
     DedupScratch *S = (DedupScratch *)scratch;
     caelo_dedup_tables *T = caelo_frame_tables(bits);
-    const bool on = enabled && !off;
+    const bool on = enabled;  // the caller asked dedup_enabled() and let k_patches fill the table
     if (on) {
-        k_dd_insert<<<CAELO_FRAME_PATCHES / 4, 256, 0, s>>>((const unsigned long long *)bits, S, mask);
-        CAELO_LAUNCH_CHECK();
         k_dd_verify<<<CAELO_FRAME_PATCHES / 4, 256, 0, s>>>((const unsigned long long *)bits, S);
         CAELO_LAUNCH_CHECK();
     }

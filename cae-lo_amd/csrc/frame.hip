@@ -137,9 +137,13 @@ int extract_front_launch(const caelo_extract_args &a, hipStream_t s) {
     if (exact_vox) rc = vox_build_launch(a.map, a.pc, a.n, 4, false, a.status, s);
     else rc = vox_build_fast_launch(a.map, a.pc, a.n, 4, a.status, s);
     if (rc) return rc;
-    if ((rc = vox_patches_launch(a.map, a.key_pts, a.kp_ld, CAELO_MAX_KEYPTS, a.n_key, bits, a.flags, a.status, true, s))) return rc;
-    // equal patches are encoded once (dedup.hip): tables behind the frame's bits
-    return dedup_launch(bits, ws + L.dd, !(a.mode & CAELO_EXTRACT_NO_DEDUP), s);
+    // equal patches are encoded once (dedup.hip): k_patches enters every patch into the hash table, the tables land
+    // behind the frame's bits
+    const bool dd = dedup_enabled(a.mode);
+    if ((rc = vox_patches_launch(a.map, a.key_pts, a.kp_ld, CAELO_MAX_KEYPTS, a.n_key, bits, a.flags, a.status, true, s,
+                                 dd ? ws + L.dd : nullptr)))
+        return rc;
+    return dedup_launch(bits, ws + L.dd, dd, s);
 }
 
 int extract_encode_launch(const caelo_extract_args &a, hipStream_t s) {

@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
                                                            caelo_brick_table t1, caelo_brick_table t2,
                                                            unsigned long long *__restrict__ bits,
                                                            uint8_t *__restrict__ flags, const int32_t *counts,
-                                                           int32_t *status) {
+                                                           int32_t *status, DedupScratch *dd, unsigned long long dd_mask) {
     if (counts && blockIdx.x == 0 && threadIdx.x == 0 && (counts[0] < 496 || counts[1] < 496 || counts[2] < 496))
         atomicOr(status, CAELO_ST_FEW_VOXELS);  // sklearn ValueError at Voxel.py:195-196
     __shared__ PatchWaveLds lds_all[PW_WAVES];
@@ -580,6 +580,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
     if (kp >= K) {
         out[lane] = 0ull;
         if (lane == 0) flags[pw] = 0;
+        if (dd) caelo_dedup_insert(0ull, lane, (int)pw, dd, dd_mask);
         return;
     }
     const caelo_brick_table tab = scale == 0 ? t0 : (scale == 1 ? t1 : t2);
@@ -802,16 +803,17 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) fl |= __shfl_xor(fl, o);
     out[lane] = word;
+    if (dd) caelo_dedup_insert(word, lane, (int)pw, dd, dd_mask);  // equal patches are encoded once (dedup.hip)
     if (lane == 0) flags[pw] = (uint8_t)fl;
     PATCH_STAMP(3);
 }
 
 int vox_patches_launch(const caelo_voxmap *m, const float *pts, int pts_ld, int64_t k_max, const int32_t *n_key,
-                       uint64_t *bits, uint8_t *flags, int32_t *status, bool check_counts, hipStream_t s) {
+                       uint64_t *bits, uint8_t *flags, int32_t *status, bool check_counts, hipStream_t s, void *dedup_scratch) {
     const int64_t waves = k_max * 3;
     k_patches<<<(unsigned)((waves + PW_WAVES - 1) / PW_WAVES), 64 * PW_WAVES, 0, s>>>(
         pts, pts_ld, k_max, n_key, m->brick[0], m->brick[1], m->brick[2], (unsigned long long *)bits, flags,
-        check_counts ? m->counts : nullptr, status);
+        check_counts ? m->counts : nullptr, status, (DedupScratch *)dedup_scratch, dedup_hash_mask());
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }
