@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(256) k_vox_coarse2(caelo_brick_table b1, caelo
                                                      int32_t *counts, int32_t *status) {
     __shared__ int s_tmp[2];
     const int nb = counts[5];
-    int pop = 0;
+    int pop = 0, pop2 = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
         const uint32_t slot = list1[i];
         const unsigned long long k = b1.keys[slot];
@@ -419,27 +419,20 @@ __global__ void __launch_bounds__(256) k_vox_coarse2(caelo_brick_table b1, caelo
                 for (int hx = 0; hx < 2; ++hx) {
                     if (!orv[hx]) continue;
                     unsigned long long *wd = &b2.bits[(size_t)slot2 * 8 + ((x2 + hx) & 7)];
-                    if ((__hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & orv[hx]) != orv[hx])
-                        (void)__hip_atomic_fetch_or(wd, orv[hx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((__hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & orv[hx]) != orv[hx]) {
+                        // every scale-2 voxel is counted by the one atomic that sets its bit (no separate counting pass)
+                        const unsigned long long old = __hip_atomic_fetch_or(wd, orv[hx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pop2 += __popcll(orv[hx] & ~old);
+                    }
                 }
             }
         }
     }
     caelo_block_add(&counts[1], pop, s_tmp);
+    __syncthreads();  // s_tmp is reused
+    caelo_block_add(&counts[2], pop2, s_tmp);
 }
 
-// one thread per scale-2 brick slot: count
-__global__ void __launch_bounds__(256) k_vox_count2(caelo_brick_table b2, int32_t *counts) {
-    __shared__ int s_tmp[2];
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    int pop = 0;
-    if (i <= b2.mask && b2.keys[i] != CAELO_EMPTY_KEY) {
-        const unsigned long long *w = b2.bits + (size_t)i * 8;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) pop += __popcll(w[q]);
-    }
-    caelo_block_add(&counts[2], pop, s_tmp);
-}
 
 int vox_build_fast_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, int32_t *status, hipStream_t s) {
     m->lists_valid = false;  // until every kernel of the build is enqueued
@@ -448,8 +441,6 @@ int vox_build_fast_launch(caelo_voxmap *m, const float *pc, int64_t n, int strid
     k_vox_coarse<<<256, 256, 0, s>>>(m->brick[0], m->brick[1], m->list0, m->list1, m->counts, status);
     CAELO_LAUNCH_CHECK();
     k_vox_coarse2<<<64, 256, 0, s>>>(m->brick[1], m->brick[2], m->list1, m->counts, status);
-    CAELO_LAUNCH_CHECK();
-    k_vox_count2<<<(m->brick[2].mask + 256) / 256, 256, 0, s>>>(m->brick[2], m->counts);
     CAELO_LAUNCH_CHECK();
     m->lists_valid = true;
     return CAELO_OK;
