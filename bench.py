@@ -196,10 +196,10 @@ def main():
         # under profiles/ and quoted here.  hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024, uncorrected.
         traffic, traffic_note = None, None
         try:
-            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic_v52.json")))
             k = pmc["kernels"][names[dom]]
             traffic = int((k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024)
-            traffic_note = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; bytes per launch)"
+            traffic_note = "profiles/r01_pmc_traffic_v52.json (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; bytes per launch)"
         except Exception:
             pass
         roofline = {"bound": "mfma", "kernel": names[dom], "achieved": round(float(achieved), 3),
