@@ -605,3 +605,20 @@ def test_patch_dedup_is_bitwise_invisible(engine, scans, monkeypatch):
     torch.cuda.synchronize()
     for i, pc in enumerate(pcs + pcs[:2]):
         assert torch.equal(got.rows[i], engine.extract(pc, dedup=False).rows)
+
+
+def test_pipeline_mode_matrix_on_one_pipeline(engine, scans):
+    """dist_channels x exact / fused voxelization x de-duplication on ONE cached pipeline, i.e. the same lanes alternate
+    between the fused build (which wipes the previous frame's bricks from their lists) and the exact build (full clear)."""
+    import torch
+    from caelo.engine import ransac_draws
+    pcs = [torch.from_numpy(scans(i)).to(engine.device) for i in range(3)]
+    rnd = [torch.from_numpy(ransac_draws(5 + i)).to(engine.device) for i in range(3)]
+    pipe = engine.pipeline(6, 2)
+    for dc in (5, 3):
+        for ex in (False, True):
+            for dd in (True, False):
+                out = pipe.run(pcs * 3, rnd * 3, dist_channels=dc, exact_voxels=ex, dedup=dd)
+                torch.cuda.synchronize()
+                for i, pc in enumerate(pcs * 3):
+                    assert torch.equal(out.rows[i], engine.extract(pc, dist_channels=dc, exact_voxels=ex, dedup=False).rows), (dc, ex, dd, i)
