@@ -40,6 +40,9 @@ from caelo import dist as cdist  # noqa: E402
 from caelo.engine import Engine, FrameFeatures, ransac_draws  # noqa: E402
 
 POOL = 6  # distinct consecutive synthetic frames per rank, cycled
+QUANTUM = 1e-3  # coordinates in whole millimetres, like the metrically quantised values of real scans: every frame then
+                # holds points exactly on voxel faces (tests/golden/frame_q0.npz: 14 of 126 k), which the voxelization
+                # resolves like the reference's float64 index arithmetic (Voxel.py:118-152)
 
 # algorithmic FLOPs per patch (SURVEY.md 8d / BASELINE.md section 4): 2 x MACs
 FLOP_CONV1 = 2 * 4096 * 27 * 8
@@ -57,7 +60,7 @@ def cpu_baseline(n_frames=16, max_seconds=30.0):
     resp_m, enc_m = orc.load_models(os.path.join(REPO, "weights", "SphericalRingPCRespondLayer.h5"),
                                     os.path.join(REPO, "weights", "EncoderModel4VoxelPatch.h5"))
     cores = orc.num_threads()
-    clouds = [synth.make_scan(f) for f in range(n_frames + 1)]
+    clouds = [synth.make_scan(f, quantum=QUANTUM) for f in range(n_frames + 1)]
 
     def extract(pc):
         ring, cnt = orc.ProjectPC2SphericalRing(pc)
@@ -125,7 +128,7 @@ def main():
     K, W = args.steps, args.warmup
     # synthetic scans of this rank's stretch of the trajectory, uploaded before the clock starts
     base = rank * K
-    pool = [torch.from_numpy(synth.make_scan((base + i) % 997)).to(dev) for i in range(POOL)]
+    pool = [torch.from_numpy(synth.make_scan((base + i) % 997, quantum=QUANTUM)).to(dev) for i in range(POOL)]
     rand = [torch.from_numpy(ransac_draws(1000 + rank * 7919 + i)).to(dev) for i in range(POOL)]
     n_points = int(np.mean([p.shape[0] for p in pool]))
 
@@ -176,7 +179,9 @@ def main():
     host = pipe.stats()
     # sanity: every pose solved (not timed)
     ok = 0 if args.extract_only else sum(int(eng.pose_result(batch.result[i]).success) for i in range(K))
-    status = int(prev.status[0].item()) if prev.status is not None else 0
+    # every timed frame's status word (OR of the CAELO_ST_* bits; 0 = no frame needed anything but the fast path)
+    st = batch.status[:K, 0].cpu().numpy()
+    status, frames_flagged = int(np.bitwise_or.reduce(st)), int((st != 0).sum())
 
     out = None
     if rank == 0:
@@ -221,7 +226,8 @@ def main():
             "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: KITTI-seq-00-shaped full odometry (extract + NN match + RANSAC pose) on "
-                                   "synthetic 64-beam x 2000-azimuth scans",
+                                   "synthetic 64-beam x 2000-azimuth scans, coordinates quantised to 1 mm (points on voxel "
+                                   "faces in every frame, as in real scans)",
                        "arithmetic": "f32 in / out / accumulate; conv3 and Dense(200) evaluate every f32 product as six exact "
                                      "bf16 x bf16 partial products (3-way operand split) on the bf16 matrix pipe -- f32-grade "
                                      "(descriptor error vs the f32 oracle 1.5e-6, DESIGN.md 4.6); match in f64",
@@ -232,7 +238,7 @@ def main():
                        "host_issue_us_per_frame": round(host["issue_us_per_frame"], 1),
                        **({"encoder_stream_busy": round(host["encoder_busy_us"] / host["encoder_span_us"], 3)} if host["encoder_span_us"] > 0 else {}), "parallelism": "frames sharded x%d, one RCCL all-gather of %s [1024,64] f32 frame rows" % (
                            world, "the boundary" if args.gather == "boundary" else "all"),
-                       "poses_solved": "%d/%d" % (ok, K), "status_bits": status},
+                       "poses_solved": "%d/%d" % (ok, K), "status_bits": status, "frames_flagged": frames_flagged},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -49,6 +49,8 @@ SIGNATURES = [
     ("caelo_voxmap_create", c_int, [c_vp, c_i64, C.POINTER(c_vp)]),
     ("caelo_voxmap_destroy", None, [c_vp]),
     ("caelo_voxelize", c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
+    ("caelo_voxelize_fast", c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
+    ("caelo_voxmap_dump", c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_vp]),
     ("caelo_voxmap_export", c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     ("caelo_voxmap_from_lists", c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     ("caelo_patches", c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),

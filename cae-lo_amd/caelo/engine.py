@@ -20,7 +20,7 @@ RING_H, RING_W, RING_C = 69, 1800, 5
 NET_H, NET_W = 64, 1792
 MAX_K = 1024
 
-ST_COL_OOB, ST_VOXEL_OOB, ST_MAP_FULL, ST_FEW_VOXELS, ST_FEW_KEYPTS, ST_VOXEL_INEXACT = 1, 2, 4, 8, 16, 32
+ST_COL_OOB, ST_VOXEL_OOB, ST_MAP_FULL, ST_FEW_VOXELS, ST_FEW_KEYPTS = 1, 2, 4, 8, 16
 
 _DEFAULT_WEIGHTS = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "weights")
 RESPOND_H5 = os.path.join(_DEFAULT_WEIGHTS, "SphericalRingPCRespondLayer.h5")
@@ -331,6 +331,29 @@ class Engine:
         _ffi.check(self.lib.caelo_voxelize(self.ctx, vmap.h, _ptr(pc), pc.shape[0], pc.shape[1], _ptr(status), self.stream))
         return vmap, status
 
+    def voxelize_fast(self, pc, vmap=None, status=None):
+        """The one-pass build ``extract`` uses (caelo_voxelize_fast): same voxel sets as ``voxelize``, no first-touch order."""
+        assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] >= 3 and pc.is_contiguous()
+        vmap = vmap or self.voxmap(max(self.max_points, pc.shape[0]))
+        status = self.zeros((1,), torch.int32) if status is None else status
+        _ffi.check(self.lib.caelo_voxelize_fast(self.ctx, vmap.h, _ptr(pc), pc.shape[0], pc.shape[1], _ptr(status), self.stream))
+        return vmap, status
+
+    def voxmap_voxels(self, vmap, scale, capacity=1 << 18):
+        """Voxel set of one scale of a device voxel map -> sorted int32 [n,3] (host; caelo_voxmap_dump, synchronises)."""
+        keys = self.empty((capacity,), torch.int64)
+        bits = self.empty((capacity, 8), torch.int64)
+        count = self.empty((1,), torch.int32)
+        _ffi.check(self.lib.caelo_voxmap_dump(self.ctx, vmap.h, int(scale), _ptr(keys), _ptr(bits), capacity, _ptr(count), self.stream))
+        n = int(count.item())
+        assert n <= capacity, "raise capacity"
+        k = keys[:n].cpu().numpy().astype(np.uint64)
+        b = np.unpackbits(bits[:n].cpu().numpy().view(np.uint8).reshape(n, 8, 8), axis=2, bitorder="little")  # [brick, x&7, y&7, z&7]
+        br, x, y, z = np.nonzero(b.reshape(n, 8, 8, 8))
+        base = np.stack([(k >> np.uint64(40)) & np.uint64(0xFFFFF), (k >> np.uint64(20)) & np.uint64(0xFFFFF), k & np.uint64(0xFFFFF)], 1).astype(np.int64) * 8
+        vox = (base[br] + np.stack([x, y, z], 1)).astype(np.int32)
+        return vox[np.lexsort((vox[:, 2], vox[:, 1], vox[:, 0]))]
+
     def voxmap_export(self, vmap, capacity):
         outs = [self.empty((capacity, 3), torch.int16) for _ in range(3)]
         counts = self.empty((3,), torch.int64)
@@ -445,7 +468,7 @@ class Engine:
     def match(self, f0, f1, n0=None, n1=None):
         """f0 [k0,dim], f1 [k1,dim] (row-strided views allowed) -> pair_idx [k1] int64."""
         idx = self.zeros((f1.shape[0],), torch.int64)
-        ws = self._ws("match", int(self.lib.caelo_match_ws_bytes(f1.shape[0])))
+        ws = self._ws("match%d" % f1.shape[0], int(self.lib.caelo_match_ws_bytes(f1.shape[0])))   # one per k1_max (caelo.h)
         _ffi.check(self.lib.caelo_match(self.ctx, _ptr(f0), self._ld(f0), f0.shape[0], _ptr(n0), _ptr(f1), self._ld(f1),
                                         f1.shape[0], _ptr(n1), f0.shape[1], _ptr(idx), _ptr(ws), self.stream))
         return idx
@@ -480,9 +503,9 @@ class Engine:
         project -> response CNN -> keypoints -> voxelize -> patch gather -> 3x encoder.
         dist_channels: 5 = demo calling mode (SphericalRing.py:414), 3 = batch mode
         (BatchPreprocess.py:97-98,131-136).  ``rows``: optional [1024,64] f32 output slot.
-        The default one-pass voxelization flags (status bit ST_VOXEL_INEXACT) the ~1e-10-probability
-        frame in which a point lies within an ulp of a voxel face; ``checked()`` re-runs such a frame
-        with ``exact_voxels=True`` (the two-pass first-touch rule of Voxel.py:139-141).  ``dedup=False`` encodes
+        The default one-pass voxelization and ``exact_voxels=True`` (the two-pass first-touch kernels of
+        ``voxelize``, Voxel.py:139-141) produce the same voxel sets on every cloud, points on voxel faces
+        included (metrically quantised scans have some in every frame).  ``dedup=False`` encodes
         every patch even when it is a bit-identical copy of another one of the frame (same result, more work)."""
         assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] == 4 and pc.is_contiguous()
         ws = self._ws("extract", int(self.lib.caelo_extract_ws_bytes()))
@@ -502,13 +525,8 @@ class Engine:
         return FrameFeatures(rows, kpix, nkey, status, flags)
 
     def checked(self, ff, pc, dist_channels=5):
-        """Synchronising status check of an extract() result: raises what the reference would raise,
-        transparently re-extracts with exact voxelization when the fast path flagged the frame."""
-        st = int(ff.status[0].item())
-        if st & ST_VOXEL_INEXACT:
-            ff = self.extract(pc, dist_channels, rows=ff.rows, exact_voxels=True)
-            st = int(ff.status[0].item())
-        raise_status(st)
+        """Synchronising status check of an extract() result: raises what the reference would raise."""
+        raise_status(int(ff.status[0].item()))
         return ff
 
     def match_pose(self, fa, fb, rand):

@@ -66,9 +66,12 @@ def sensor_pose(frame, step=(0.9, 0.05, 0.0), yaw_step=0.01):
 
 
 def make_scan(frame=0, n_beams=64, n_az=2000, seed=None, scene_seed=SCENE_SEED,
-              pose=None, noise_sigma=0.01):
+              pose=None, noise_sigma=0.01, quantum=None):
     """Return a [N,4] float32 cloud (x,y,z,intensity) in the sensor frame, file order
-    beam-major (all azimuths of beam 0, then beam 1, ...)."""
+    beam-major (all azimuths of beam 0, then beam 1, ...).  ``quantum`` (metres, e.g. 1e-3): coordinates rounded to
+    multiples of it, like the metrically quantised values real scanners deliver -- such clouds put points exactly on
+    voxel faces (x = 4.0), the case the reference's float64 index arithmetic (Voxel.py:118-152) resolves in its own
+    way and a voxelization has to reproduce."""
     if seed is None:
         seed = frame
     (tx, ty, tz), yaw = sensor_pose(frame) if pose is None else pose
@@ -119,9 +122,12 @@ def make_scan(frame=0, n_beams=64, n_az=2000, seed=None, scene_seed=SCENE_SEED,
     keep = t < MAX_RANGE
     r = t + noise
     pc = np.empty((int(keep.sum()), 4), dtype=np.float32)
-    pc[:, 0] = (r * dx)[keep]
-    pc[:, 1] = (r * dy)[keep]
-    pc[:, 2] = (r * dz)[keep]
+    xyz = (r * dx, r * dy, r * dz)
+    if quantum:
+        xyz = tuple(np.rint(v / quantum) * quantum for v in xyz)   # element-wise IEEE ops only (see module docstring)
+    pc[:, 0] = xyz[0][keep]
+    pc[:, 1] = xyz[1][keep]
+    pc[:, 2] = xyz[2][keep]
     pc[:, 3] = inten[keep]
     return pc
 

@@ -81,8 +81,19 @@ struct caelo_voxmap {
     unsigned long long *vkeys[3];
     uint32_t *vfirst[3];
     uint32_t vmask[3];
-    int32_t *counts;  // [16] device ints: [0..2] unique voxels per scale, [4],[5] lengths of list0/list1
+    int32_t *counts;  // [16] device ints: [0..2] unique voxels per scale, [4],[5] lengths of list0/list1, [6] length of
+                      // sp_list, [7] ticket of k_vox_suspects
     uint32_t *list0, *list1;  // slots of the occupied scale-0 / scale-1 bricks, in insertion order (fast path)
+    // "Suspect" voxels of the fused build (voxel.hip, k_vox_points): scale-0 voxels holding a point whose own
+    // int(x_/0.16), int(x_/0.64) differ from its scale-0 index >> 3, >> 5 (x_ within an ulp of a voxel face -- every
+    // metrically quantised cloud has some).  sp_* : voxel key -> smallest point index in it; sb_*: brick key -> number of
+    // suspect voxels in that brick (stored as count - 1 mod 2^32, so that "empty" is the 0xFF fill); sp_list: one entry
+    // per inconsistent point (the slots it touched), which is also how the next build wipes the tables.
+    unsigned long long *sp_keys, *sb_keys;
+    uint32_t *sp_first, *sb_cnt;
+    uint4 *sp_list;     // [max_points]: x = point index, y = sp slot, z = sb slot (0xFFFFFFFF: none), w unused
+    uint32_t sp_mask;   // slots - 1 (>= 2 x max_points slots: never full)
+    size_t sp_off, sp_bytes;  // the four tables, one 0xFF region
     // One allocation, two clear regions (MI355X: two large fills instead of thirteen small ones):
     //   ff region (cleared to 0xFF): brick keys x3 | vkeys0 | vfirst0 || vkeys1 | vkeys2 | vfirst1 | vfirst2
     //   zero region (cleared to 0):  brick bits x3 | counts
@@ -103,7 +114,7 @@ struct caelo_clear_item {
     size_t bytes;  // multiple of 16
     uint32_t pattern;
 };
-#define CAELO_CLEAR_MAX 8
+#define CAELO_CLEAR_MAX 12
 struct caelo_clear_list {
     caelo_clear_item item[CAELO_CLEAR_MAX];
     int n;

@@ -131,6 +131,10 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const float *__res
     const int ctile = blockIdx.x, rs = blockIdx.y;
     const int j0 = ctile * 16;
     if (j0 >= k1) return;  // uniform over the column tile's slices: no ticket needed
+    if (k0 == 0) {         // no frame-0 descriptor at all (the reference's argmin would raise): index 0, the pose fails
+        if (rs == 0 && tid < 16 && j0 + tid < k1) pair_idx[j0 + tid] = 0;
+        return;
+    }
     const double kappa = (4.0 * (double)dim + 64.0) * 1.1102230246251565e-16;  // >= 2x the worst-case bound (dim + 20) 2^-53
     const double BIG = 1.0e300;
     // B fragments (this column tile) and |f1_j|^2.  k-step s of lane group g <-> channel 16 g + s.
@@ -278,10 +282,12 @@ CAELO_API int caelo_match(caelo_ctx *c, const float *f0, int ld0, int64_t k0_max
     CAELO_REQUIRE(dim > 0 && dim <= MT_MAXDIM && ld0 >= dim && ld1 >= dim && k0_max > 0 && k1_max > 0, "bad shape");
     hipStream_t s = caelo_stream(stream);
     const int64_t tiles = (k1_max + 15) / 16;
-    int32_t *tickets = (int32_t *)ws;
+    // layout: stats [256 B] | tickets | partial results.  The ticket region depends on k1_max: a workspace belongs to ONE
+    // (stream, k1_max) -- a call with another k1_max would find the partial results of this one where its tickets live
+    int32_t *stats = (int32_t *)ws;  // [0] columns re-scanned exactly, [1] columns decided between two rows
+    int32_t *tickets = (int32_t *)((char *)ws + 256);
     const size_t tbytes = (size_t)((tiles * 4 + 255) / 256) * 256;
     MmPartial *parts = (MmPartial *)((char *)ws + 256 + tbytes);
-    int32_t *stats = (int32_t *)((char *)ws + tbytes);  // [0] columns re-scanned exactly, [1] columns decided between two rows
     const bool vec = (dim % 4 == 0) && (ld0 % 4 == 0) && (ld1 % 4 == 0) && (((uintptr_t)f0 | (uintptr_t)f1) & 15u) == 0;
     dim3 grid((unsigned)tiles, MM_RS);
     if (vec)
@@ -573,7 +579,7 @@ __device__ void ransac_replay(int N, int level, RansacWs *ws, int *s_counts) {
     ws->threshold = 0.4f * (float)(1 << level);
     ws->success = success;
     ws->level_used = level;
-    ws->best_trial = success ? best : -1;
+    ws->best_trial = (success && target > 0) ? best : -1;  // N < 5: success without any accepted hypothesis -> identity (:177)
     if (success) ws->done = 1;
     (void)s_counts;
 }

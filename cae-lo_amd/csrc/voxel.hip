@@ -58,8 +58,23 @@ CAELO_API int caelo_voxmap_create(caelo_ctx *c, int64_t max_points, caelo_voxmap
     m->zero_bytes = off - m->zero_off;
     const size_t o_list0 = off; off += bslots[0] * 4;
     const size_t o_list1 = off; off += bslots[1] * 4;
+    // suspect-voxel tables of the fused build (one 0xFF region, wiped entry by entry between builds) + their list
+    m->sp_off = off;
+    const size_t o_spk = off; off += vslots * 8;
+    const size_t o_sbk = off; off += vslots * 8;
+    const size_t o_spf = off; off += vslots * 4;
+    const size_t o_sbc = off; off += vslots * 4;
+    m->sp_bytes = off - m->sp_off;
+    const size_t o_splist = off; off += (size_t)max_points * 16;
     m->total_bytes = off;
     CAELO_HIP(hipMalloc(&m->base, m->total_bytes));
+    CAELO_HIP(hipMemset(m->base + m->sp_off, 0xFF, m->sp_bytes));
+    m->sp_keys = (unsigned long long *)(m->base + o_spk);
+    m->sb_keys = (unsigned long long *)(m->base + o_sbk);
+    m->sp_first = (uint32_t *)(m->base + o_spf);
+    m->sb_cnt = (uint32_t *)(m->base + o_sbc);
+    m->sp_list = (uint4 *)(m->base + o_splist);
+    m->sp_mask = (uint32_t)(vslots - 1);
     for (int s = 0; s < 3; ++s) {
         m->brick[s].mask = (uint32_t)(bslots[s] - 1);
         m->brick[s].keys = (unsigned long long *)(m->base + o_bkeys[s]);
@@ -88,9 +103,20 @@ void vox_clear_items(caelo_voxmap *m, int level, caelo_clear_list &list) {
 }
 
 // wipe the bricks of the previous fused build: key -> empty, 8 payload words -> 0 (entry e, word w per thread)
+struct SuspectTables {
+    unsigned long long *sp_keys, *sb_keys;
+    uint32_t *sp_first, *sb_cnt;
+    uint4 *list;
+    uint32_t mask;
+};
+static SuspectTables suspect_tables(const caelo_voxmap *m) {
+    return SuspectTables{m->sp_keys, m->sb_keys, m->sp_first, m->sb_cnt, m->sp_list, m->sp_mask};
+}
+
 __global__ void __launch_bounds__(256) k_vox_clear_lists(caelo_brick_table b0, caelo_brick_table b1, const uint32_t *__restrict__ list0,
-                                                         const uint32_t *__restrict__ list1, const int32_t *__restrict__ counts) {
-    const int n0 = counts[4], n1 = counts[5];
+                                                         const uint32_t *__restrict__ list1, const int32_t *__restrict__ counts,
+                                                         SuspectTables sp) {
+    const int n0 = counts[4], n1 = counts[5], nsp = counts[6];
     const long long total = (long long)(n0 + n1) * 8;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int e = (int)(i >> 3), w = (int)(i & 7);
@@ -99,14 +125,25 @@ __global__ void __launch_bounds__(256) k_vox_clear_lists(caelo_brick_table b0, c
         t.bits[(size_t)slot * 8 + w] = 0ull;
         if (w == 0) t.keys[slot] = CAELO_EMPTY_KEY;
     }
+    // the suspect-voxel tables of the previous build, through its list of inconsistent points
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nsp; e += gridDim.x * blockDim.x) {
+        const uint4 ent = sp.list[e];
+        sp.sp_keys[ent.y] = CAELO_EMPTY_KEY;
+        sp.sp_first[ent.y] = 0xFFFFFFFFu;
+        if (ent.z != 0xFFFFFFFFu) {
+            sp.sb_keys[ent.z] = CAELO_EMPTY_KEY;
+            sp.sb_cnt[ent.z] = 0xFFFFFFFFu;
+        }
+    }
 }
 
 int vox_clear_for_fast_build(caelo_voxmap *m, caelo_clear_list &list, hipStream_t s) {
     if (!m->lists_valid) {
         vox_clear_items(m, 0, list);
+        list.item[list.n++] = {m->base + m->sp_off, m->sp_bytes, 0xFFFFFFFFu};  // the suspect-voxel tables, whole
         return CAELO_OK;
     }
-    k_vox_clear_lists<<<256, 256, 0, s>>>(m->brick[0], m->brick[1], m->list0, m->list1, m->counts);
+    k_vox_clear_lists<<<256, 256, 0, s>>>(m->brick[0], m->brick[1], m->list0, m->list1, m->counts, suspect_tables(m));
     CAELO_LAUNCH_CHECK();
     // scale 2 has no list: its 16 k-slot table is cleared whole (keys, then payload + the counters right behind it)
     const size_t slots2 = (size_t)m->brick[2].mask + 1;
@@ -306,14 +343,22 @@ __global__ void k_vox_check(const int32_t *counts, int32_t *status) {
 // ------------------------------------------------------------------------------------------------
 // K5 fast path (fused extract): one pass over the points + one pass over the scale-0 bricks.
 // A scale-0 brick (8 x 0.02 m) IS a scale-1 voxel (0.16 m) and 4 of those a scale-2 voxel
-// (Voxel.py:15-31), so scales 1/2 follow from the set of scale-0 bricks -- provided every point's
-// own int(x_/0.16), int(x_/0.64) (Voxel.py:147-152) agree with its scale-0 index >> 3, >> 5.  They do
-// unless x_ sits within an ulp of a voxel face; such a point raises CAELO_ST_VOXEL_INEXACT and the
-// caller re-runs the frame through the exact first-touch kernels above.
+// (Voxel.py:15-31), so scales 1/2 follow from the set of scale-0 bricks -- for every scale-0 voxel whose
+// FIRST point (the only one that reaches layers 1/2, Voxel.py:139-158) has its own int(x_/0.16), int(x_/0.64)
+// (Voxel.py:147-152) equal to its scale-0 index >> 3, >> 5.  A point with x_ within an ulp of a voxel face
+// breaks that (x = 4.0 exactly; a few of every metrically quantised scan: 14 of 126 k points at mm resolution).
+// Such points are handled exactly, without leaving the one-pass scheme:
+//   * k_vox_points enters the voxel of every inconsistent point into a small "suspect" table (and counts the
+//     suspect voxels of each brick);
+//   * k_vox_coarse derives a scale-1 voxel from a brick only if the brick holds a NON-suspect voxel (all points of
+//     such a voxel are consistent, so its first one is), k_vox_coarse2 derives scale 2 from those;
+//   * k_vox_suspects (an empty launch when the frame has no inconsistent point) finds the first point of every
+//     suspect voxel (atomicMin over all points) and lets its last workgroup insert that point's own scale-1 / 2
+//     indices -- exactly what the reference's loop does when it meets the voxel for the first time.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_vox_points(const float *__restrict__ pc, int64_t n, int stride,
                                                     caelo_brick_table b0, uint32_t *list0, int32_t *counts,
-                                                    int32_t *status) {
+                                                    int32_t *status, SuspectTables sp) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     VoxIdx v;
@@ -329,8 +374,17 @@ __global__ void __launch_bounds__(256) k_vox_points(const float *__restrict__ pc
         bool consistent = true;
 #pragma unroll
         for (int a = 0; a < 3; ++a) consistent &= (v.v1[a] == (v.g[a] >> 3)) && (v.v2[a] == (v.g[a] >> 5));
-        if (!consistent) st |= CAELO_ST_VOXEL_INEXACT;
         key = caelo_pack3(v.g[0] >> 3, v.g[1] >> 3, v.g[2] >> 3);
+        if (!consistent) {  // rare: its voxel becomes a suspect (tables hold >= 2 slots per point: never full)
+            bool sp_new = false;
+            const int ss = table_insert_new(sp.sp_keys, sp.mask, caelo_pack3(v.g[0], v.g[1], v.g[2]), &sp_new);
+            uint32_t sb = 0xFFFFFFFFu;
+            if (sp_new) {
+                sb = (uint32_t)table_insert(sp.sb_keys, sp.mask, key);
+                atomicAdd(&sp.sb_cnt[sb], 1u);  // 0xFFFFFFFF + 1 = 0: the entry holds (suspect voxels of the brick) - 1
+            }
+            sp.list[atomicAdd(&counts[6], 1)] = make_uint4((uint32_t)i, (uint32_t)ss, sb, 0u);
+        }
     }
     // Neighbouring points of a scan line fall into the same 16 cm brick: only the first lane of each run of
     // equal keys walks the hash table (memory-side atomics cost microseconds), the run reuses its slot.
@@ -358,9 +412,10 @@ __global__ void __launch_bounds__(256) k_vox_points(const float *__restrict__ pc
 
 // the occupied scale-0 bricks (256 per workgroup iteration): a brick is a scale-1 voxel, and counts its voxels
 __global__ void __launch_bounds__(256) k_vox_coarse(caelo_brick_table b0, caelo_brick_table b1, const uint32_t *list0,
-                                                    uint32_t *list1, int32_t *counts, int32_t *status) {
+                                                    uint32_t *list1, int32_t *counts, int32_t *status, SuspectTables sp) {
     __shared__ int s_tmp[2];
     const int nb = counts[4];
+    const bool any_suspect = counts[6] > 0;
     int pop = 0;
     for (int i0 = blockIdx.x * blockDim.x; i0 < nb; i0 += gridDim.x * blockDim.x) {  // uniform trip count per workgroup
         const int i = i0 + threadIdx.x;
@@ -370,10 +425,16 @@ __global__ void __launch_bounds__(256) k_vox_coarse(caelo_brick_table b0, caelo_
             const uint32_t slot = list0[i];
             const unsigned long long k = b0.keys[slot];
             const ulonglong2 *w = (const ulonglong2 *)(b0.bits + (size_t)slot * 8);
+            int mine = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const ulonglong2 u = w[q]; pop += __popcll(u.x) + __popcll(u.y); }
+            for (int q = 0; q < 4; ++q) { const ulonglong2 u = w[q]; mine += __popcll(u.x) + __popcll(u.y); }
+            pop += mine;
+            if (any_suspect) {  // voxels whose first point may disagree with the brick are left to k_vox_suspects
+                const int sb = table_find(sp.sb_keys, sp.mask, k);
+                if (sb >= 0) mine -= (int)(sp.sb_cnt[sb] + 1u);
+            }
             const int x = (int)((k >> 40) & 0xFFFFF), y = (int)((k >> 20) & 0xFFFFF), z = (int)(k & 0xFFFFF);
-            if (!brick_mark_new(b1, x, y, z, &slot1, &is_new)) atomicOr(status, CAELO_ST_MAP_FULL);
+            if (mine > 0 && !brick_mark_new(b1, x, y, z, &slot1, &is_new)) atomicOr(status, CAELO_ST_MAP_FULL);
         }
         const int lpos = caelo_block_reserve(&counts[5], is_new, s_tmp);
         if (is_new) list1[lpos] = (uint32_t)slot1;
@@ -433,14 +494,62 @@ __global__ void __launch_bounds__(256) k_vox_coarse2(caelo_brick_table b1, caelo
     caelo_block_add(&counts[2], pop2, s_tmp);
 }
 
+// The suspect voxels of the frame (see the header of this section).  Grid = one thread per point; nothing to do --
+// one word read per workgroup -- when no point of the frame was inconsistent.
+__global__ void __launch_bounds__(256) k_vox_suspects(const float *__restrict__ pc, int64_t n, int stride, caelo_brick_table b1,
+                                                      caelo_brick_table b2, uint32_t *list1, int32_t *counts, int32_t *status,
+                                                      SuspectTables sp) {
+    const int nsp = counts[6];
+    if (nsp == 0) return;
+    // (1) first point of every suspect voxel: smallest index over ALL points of the voxel, consistent ones included
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float *p = pc + i * stride;
+        const VoxIdx v = voxel_indices(p[0], p[1], p[2]);
+        if (v.ok) {
+            const int ss = table_find(sp.sp_keys, sp.mask, caelo_pack3(v.g[0], v.g[1], v.g[2]));
+            if (ss >= 0) atomicMin(&sp.sp_first[ss], (uint32_t)i);
+        }
+    }
+    // (2) the last workgroup to arrive resolves them (release / acquire around the ticket)
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(&counts[7], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int e = threadIdx.x; e < nsp; e += blockDim.x) {
+        const uint4 ent = sp.list[e];
+        const uint32_t j = __hip_atomic_load(&sp.sp_first[ent.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float *p = pc + (int64_t)j * stride;
+        const VoxIdx v = voxel_indices(p[0], p[1], p[2]);  // the voxel's first point: its own scale-1 / 2 indices count
+        // several inconsistent points of one voxel repeat this: idempotent, the counters only see bits that were new
+        bool is_new = false;
+        const int s1 = table_insert_new(b1.keys, b1.mask, caelo_pack3(v.v1[0] >> 3, v.v1[1] >> 3, v.v1[2] >> 3), &is_new);
+        if (s1 < 0) atomicOr(status, CAELO_ST_MAP_FULL);
+        else {
+            if (is_new) list1[atomicAdd(&counts[5], 1)] = (uint32_t)s1;
+            const unsigned long long bit = 1ull << (((v.v1[1] & 7) << 3) | (v.v1[2] & 7));
+            if (!(atomicOr(&b1.bits[(size_t)s1 * 8 + (v.v1[0] & 7)], bit) & bit)) atomicAdd(&counts[1], 1);
+        }
+        const int r2 = brick_set(b2, v.v2[0], v.v2[1], v.v2[2]);
+        if (r2 < 0) atomicOr(status, CAELO_ST_MAP_FULL);
+        else if (r2) atomicAdd(&counts[2], 1);
+    }
+}
 
 int vox_build_fast_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, int32_t *status, hipStream_t s) {
     m->lists_valid = false;  // until every kernel of the build is enqueued
-    k_vox_points<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(pc, n, stride, m->brick[0], m->list0, m->counts, status);
+    const SuspectTables sp = suspect_tables(m);
+    k_vox_points<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(pc, n, stride, m->brick[0], m->list0, m->counts, status, sp);
     CAELO_LAUNCH_CHECK();
-    k_vox_coarse<<<256, 256, 0, s>>>(m->brick[0], m->brick[1], m->list0, m->list1, m->counts, status);
+    k_vox_coarse<<<256, 256, 0, s>>>(m->brick[0], m->brick[1], m->list0, m->list1, m->counts, status, sp);
     CAELO_LAUNCH_CHECK();
     k_vox_coarse2<<<64, 256, 0, s>>>(m->brick[1], m->brick[2], m->list1, m->counts, status);
+    CAELO_LAUNCH_CHECK();
+    k_vox_suspects<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(pc, n, stride, m->brick[1], m->brick[2], m->list1, m->counts, status, sp);
     CAELO_LAUNCH_CHECK();
     m->lists_valid = true;
     return CAELO_OK;
@@ -473,6 +582,50 @@ CAELO_API int caelo_voxelize(caelo_ctx *c, caelo_voxmap *m, const float *pc, int
     rc = vox_build_launch(m, pc, n, stride, true, status, s);
     if (rc) return rc;
     k_vox_check<<<1, 1, 0, s>>>(m->counts, status);
+    CAELO_LAUNCH_CHECK();
+    return CAELO_OK;
+}
+
+CAELO_API int caelo_voxelize_fast(caelo_ctx *c, caelo_voxmap *m, const float *pc, int64_t n, int stride, int32_t *status,
+                                  void *stream) {
+    CAELO_REQUIRE(c && m && pc && status, "null argument");
+    CAELO_REQUIRE(stride >= 3, "points need >= 3 columns");
+    if (n > m->max_points) {
+        caelo_set_error("caelo_voxelize_fast: %lld points exceed the map capacity %lld", (long long)n, (long long)m->max_points);
+        return CAELO_ERR_CAPACITY;
+    }
+    hipStream_t s = caelo_stream(stream);
+    caelo_clear_list list;
+    list.n = 0;
+    int rc = vox_clear_for_fast_build(m, list, s);
+    if (rc) return rc;
+    if ((rc = caelo_clear_many(list, s))) return rc;
+    if ((rc = vox_build_fast_launch(m, pc, n, stride, status, s))) return rc;
+    k_vox_check<<<1, 1, 0, s>>>(m->counts, status);
+    CAELO_LAUNCH_CHECK();
+    return CAELO_OK;
+}
+
+__global__ void __launch_bounds__(256) k_vox_dump(caelo_brick_table t, unsigned long long *keys, unsigned long long *bits,
+                                                  int64_t capacity, int32_t *count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > t.mask) return;
+    const unsigned long long k = t.keys[i];
+    if (k == CAELO_EMPTY_KEY) return;
+    const int p = atomicAdd(count, 1);
+    if (p >= capacity) return;
+    keys[p] = k;
+    for (int w = 0; w < 8; ++w) bits[(size_t)p * 8 + w] = t.bits[(size_t)i * 8 + w];
+}
+
+CAELO_API int caelo_voxmap_dump(caelo_ctx *c, const caelo_voxmap *m, int scale, uint64_t *keys, uint64_t *bits, int64_t capacity,
+                                int32_t *count, void *stream) {
+    CAELO_REQUIRE(c && m && keys && bits && count && capacity > 0, "bad argument");
+    CAELO_REQUIRE(scale >= 0 && scale < 3, "scale must be 0, 1 or 2");
+    hipStream_t s = caelo_stream(stream);
+    CAELO_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), s));
+    const caelo_brick_table t = m->brick[scale];
+    k_vox_dump<<<(t.mask + 256) / 256, 256, 0, s>>>(t, (unsigned long long *)keys, (unsigned long long *)bits, capacity, count);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }

@@ -28,7 +28,7 @@ import torch.distributed as dist  # noqa: E402
 
 from caelo import _ffi, stageio, synth  # noqa: E402
 from caelo import dist as cdist  # noqa: E402
-from caelo.engine import Engine, FrameBatch, FrameFeatures, ST_VOXEL_INEXACT, raise_status, ransac_draws  # noqa: E402
+from caelo.engine import Engine, FrameBatch, FrameFeatures, raise_status, ransac_draws  # noqa: E402
 
 
 def pose_rows(batch, k):
@@ -55,15 +55,6 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, lanes, batch_f
         draws = [torch.from_numpy(ransac_draws(seed_base + i - 1)).to(eng.device) for i in range(c0, c1)]
         batch = pipe.run(scans, draws, prev=prev, dist_channels=dist_channels)
         status = batch.status[:, 0].cpu().numpy()
-        for j in np.flatnonzero(status & ST_VOXEL_INEXACT):        # a point on a voxel face: redo with the exact kernels
-            ff = eng.extract(scans[j], dist_channels, rows=batch.rows[j], exact_voxels=True)
-            batch.n_key[j:j + 1].copy_(ff.n_key); batch.key_pixels[j].copy_(ff.key_pixels); batch.flags[j].copy_(ff.flags)
-            status[j] = int(ff.status[0].item())
-            for q in (j, j + 1):                                   # the two pairs that touch frame j
-                if q >= c1 - c0 or (q == 0 and prev is None):
-                    continue
-                a = prev if q == 0 else batch.frame(q - 1)
-                batch.result[q].copy_(eng.match_pose(a, batch.frame(q), draws[q])[0])
         for st in status:
             raise_status(int(st))
         r, o, t, n = pose_rows(batch, c1 - c0)

@@ -51,9 +51,9 @@ typedef enum {
 #define CAELO_ST_MAP_FULL 4       /* voxel hash table overflow (capacity bug, never data) */
 #define CAELO_ST_FEW_VOXELS 8     /* a scale holds < 496 voxels: sklearn ValueError at Voxel.py:195-196 */
 #define CAELO_ST_FEW_KEYPTS 16    /* K <= 50: assert at SphericalRing.py:286 */
-#define CAELO_ST_VOXEL_INEXACT 32 /* caelo_extract's one-pass voxelization met a point within an ulp of a voxel
-                                     face: re-run the frame with CAELO_EXTRACT_EXACT_VOXELS (never data loss) */
-#define CAELO_EXTRACT_EXACT_VOXELS 1 /* caelo_extract mode bit: two-pass first-touch voxelization (Voxel.py:139-141) */
+#define CAELO_EXTRACT_EXACT_VOXELS 1 /* caelo_extract mode bit: the two-pass first-touch voxelization of caelo_voxelize
+                                        (Voxel.py:139-141) instead of the one-pass build; both give the reference's voxel
+                                        sets on every input, points on voxel faces included (tests compare them) */
 #define CAELO_EXTRACT_NO_DEDUP 2     /* caelo_extract mode bit: encode every patch, also bit-identical copies of another one
                                         (by default equal patches of a frame are encoded once: same descriptors, bit for bit) */
 
@@ -101,6 +101,16 @@ int caelo_voxmap_create(caelo_ctx *ctx, int64_t max_points, caelo_voxmap **map);
 void caelo_voxmap_destroy(caelo_voxmap *map);
 int caelo_voxelize(caelo_ctx *ctx, caelo_voxmap *map, const float *pc, int64_t n, int stride, int32_t *status,
                    void *stream);
+/* The one-pass build caelo_extract uses (scales 1/2 derived from the scale-0 bricks, points within an ulp of a voxel
+ * face resolved through their voxel's first point): same voxel SETS as caelo_voxelize, no first-touch order, so
+ * caelo_voxmap_export does not apply; caelo_patches and caelo_voxmap_dump do. */
+int caelo_voxelize_fast(caelo_ctx *ctx, caelo_voxmap *map, const float *pc, int64_t n, int stride, int32_t *status,
+                        void *stream);
+/* Occupied 8x8x8-voxel bricks of one scale, unordered: keys [capacity] u64 (brick x << 40 | y << 20 | z),
+ * bits [capacity][8] u64 (word = x & 7, bit = (y & 7) * 8 + (z & 7)), count [1] i32 (device, may exceed capacity:
+ * then only `capacity` bricks were written).  Diagnostic / test access to the device voxel map. */
+int caelo_voxmap_dump(caelo_ctx *ctx, const caelo_voxmap *map, int scale, uint64_t *keys, uint64_t *bits, int64_t capacity,
+                      int32_t *count, void *stream);
 /* AllVoxels0/1/2 in the reference's order (first touch; scale 0 block-grouped, Voxel.py:161-165).
  * out [capacity][3] i16 per scale, counts [3] i64 (device).  Valid after caelo_voxelize. */
 int caelo_voxmap_export(caelo_ctx *ctx, caelo_voxmap *map, int16_t *all0, int16_t *all1, int16_t *all2,
@@ -153,7 +163,8 @@ int caelo_encode_profile(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches
  * n0/n1 device words when non-null.
  * ws: caelo_match_ws_bytes(k1_max) bytes, 256-byte aligned (tickets + partial results of the row slices).
  * The owner zero-fills ws ONCE (hipMemset) before its first use; every call leaves the tickets zero again, so
- * no per-call clear is launched.  One ws per stream: calls sharing a ws must be stream-ordered. */
+ * no per-call clear is launched.  One ws per (stream, k1_max): calls sharing a ws must be stream-ordered and use the
+ * same k1_max (the ticket region's size follows k1_max). */
 int64_t caelo_match_ws_bytes(int64_t k1_max);
 int caelo_match(caelo_ctx *ctx, const float *f0, int ld0, int64_t k0_max, const int32_t *n0, const float *f1, int ld1,
                 int64_t k1_max, const int32_t *n1, int dim, int64_t *pair_idx, void *ws, void *stream);

@@ -43,9 +43,9 @@ def scans():
     from caelo import synth
     cache = {}
 
-    def get(frame, n_beams=64, n_az=2000):
-        key = (frame, n_beams, n_az)
+    def get(frame, n_beams=64, n_az=2000, quantum=None):
+        key = (frame, n_beams, n_az, quantum)
         if key not in cache:
-            cache[key] = synth.make_scan(frame, n_beams=n_beams, n_az=n_az)
+            cache[key] = synth.make_scan(frame, n_beams=n_beams, n_az=n_az, quantum=quantum)
         return cache[key]
     return get

@@ -75,10 +75,32 @@ resp_model, enc_model = orc.load_models(os.path.join(REPO, "weights", "Spherical
                                          os.path.join(REPO, "weights", "EncoderModel4VoxelPatch.h5"))
 
 
-def frame_golden(frame, n_beams=64, n_az=2000, n_patch_kp=None, tag=None):
+def inconsistent_points(pc):
+    """Points whose own scale-1 / scale-2 voxel index (Voxel.py:147-152) differs from their scale-0 index >> 3, >> 5
+    (Voxel.py:122-143) -- computed with the reference's own float64 expressions.  Quantised clouds have some."""
+    n = 0
+    off = (RefVoxel.VisibleLength, RefVoxel.VisibleWidth, RefVoxel.VisibleHeight)
+    for p in pc:
+        if abs(p[0]) > off[0] or abs(p[1]) > off[1] or abs(p[2]) > off[2]:
+            continue
+        bad = False
+        for a in range(3):
+            x_ = p[a] + off[a]
+            ib = int(x_ / RefVoxel.BlockRealSize)
+            g0 = int(np.int32((x_ - ib * RefVoxel.BlockRealSize) / RefVoxel.VoxelSize)) + ib * RefVoxel.BlockSize
+            bad |= int(x_ / RefVoxel.VoxelSizes[1]) != g0 >> 3 or int(x_ / RefVoxel.VoxelSizes[2]) != g0 >> 5
+        n += bad
+    return n
+
+
+def frame_golden(frame, n_beams=64, n_az=2000, n_patch_kp=None, tag=None, quantum=None):
     t0 = time.time()
     g = {}
-    pc = synth.make_scan(frame, n_beams=n_beams, n_az=n_az)
+    pc = synth.make_scan(frame, n_beams=n_beams, n_az=n_az, quantum=quantum)
+    if quantum:
+        g["quantum"] = quantum
+        g["n_inconsistent_points"] = inconsistent_points(pc)
+        print("  frame %s: %d points on voxel faces (scale-1/2 index != scale-0 index >> 3/5)" % (tag, g["n_inconsistent_points"]))
     g["cloud_sha256"] = synth.cloud_sha256(pc)
     g["n_points"] = pc.shape[0]
     g["scan_params"] = np.array([frame, n_beams, n_az])
@@ -117,6 +139,8 @@ def frame_golden(frame, n_beams=64, n_az=2000, n_patch_kp=None, tag=None):
     g["voxel_counts"] = np.array([len(A0), len(A1), len(A2)])
     g["voxels0_sha256"], g["voxels1_sha256"], g["voxels2_sha256"] = sha(A0), sha(A1), sha(A2)
     g["voxels2"] = A2  # small: keep one full list as a fixture
+    if quantum:
+        g["voxels1"] = A1  # the scale the face points perturb most
     print("    voxels %s (%.1fs)" % (g["voxel_counts"], time.time() - tv))
     # -- patches (reference) vs oracle
     kp = kp_d if n_patch_kp is None else kp_d[-n_patch_kp:]
@@ -143,7 +167,7 @@ def frame_golden(frame, n_beams=64, n_az=2000, n_patch_kp=None, tag=None):
     return dict(pc=pc, kp=kp_d, feats=feats, A=(A0, A1, A2))
 
 
-def pair_golden(f0, f1, seeds=(0, 1, 2, 3)):
+def pair_golden(f0, f1, seeds=(0, 1, 2, 3), out="pair_0_1.npz", hard_cases=True):
     g = {}
     kp0, F0, kp1, F1 = f0["kp"], f0["feats"], f1["kp"], f1["feats"]
     W0 = np.ones((kp0.shape[0], 1), np.float32); W1 = np.ones((kp1.shape[0], 1), np.float32)
@@ -169,6 +193,9 @@ def pair_golden(f0, f1, seeds=(0, 1, 2, 3)):
         g["s%d_trace_idx" % s] = np.array([t[0] for t in trace], np.int32)
         g["s%d_trace_cnt" % s] = np.array([t[1] for t in trace], np.int32)
         print("  pair seed %d: ok=%s thr=%.1f iters=%d inliers=%d T=%s" % (s, ok, thr, iters, len(i0), np.round(T.ravel(), 3)))
+    if not hard_cases:
+        np.savez_compressed(os.path.join(GOLD, out), **g)
+        return
     # hard cases: few correspondences -> escalation / failure (Match.py:207-214)
     rs = np.random.RandomState(99)
     P1 = rs.uniform(-30, 30, (300, 3)).astype(np.float32)
@@ -185,7 +212,15 @@ def pair_golden(f0, f1, seeds=(0, 1, 2, 3)):
         g[name + "_P0"] = P0; g[name + "_P1"] = P1; g[name + "_ok"] = bool(ok); g[name + "_thr"] = float(thr)
         g[name + "_mask"] = np.asarray(mask, bool); g[name + "_R"] = np.asarray(R, np.float64); g[name + "_T"] = np.asarray(T, np.float64)
         print("  ransac %s: ok=%s thr=%.1f inliers=%d" % (name, ok, thr, int(np.sum(mask))))
-    np.savez_compressed(os.path.join(GOLD, "pair_0_1.npz"), **g)
+    np.savez_compressed(os.path.join(GOLD, out), **g)
+
+
+def quantised_golden():
+    """mm-quantised scans (KITTI-style values): points exactly on voxel faces, where the reference's float64 index
+    arithmetic decides which scale-1 / scale-2 voxel a scale-0 voxel's first point marks (Voxel.py:139-158)."""
+    q0 = frame_golden(0, quantum=1e-3, tag="q0")
+    q1 = frame_golden(1, quantum=1e-3, tag="q1")
+    pair_golden(q0, q1, seeds=(0, 1), out="pair_q0_q1.npz", hard_cases=False)
 
 
 def trunc_golden():
@@ -346,6 +381,9 @@ if __name__ == "__main__":
     if "--sequence-only" in sys.argv:
         sequence_golden()
         sys.exit(0)
+    if "--quantised-only" in sys.argv:
+        quantised_golden()
+        sys.exit(0)
     if "--blocks-only" in sys.argv:
         blocks_golden()
         sys.exit(0)
@@ -359,6 +397,7 @@ if __name__ == "__main__":
     f0 = frame_golden(0)
     f1 = frame_golden(1)
     pair_golden(f0, f1)
+    quantised_golden()
     # dense 128-beam scan: exercises the 496-NN truncation of GetPatchesList
     frame_golden(0, n_beams=128, n_az=4000, n_patch_kp=192, tag="dense128")
     sequence_golden()
