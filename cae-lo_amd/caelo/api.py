@@ -161,17 +161,70 @@ def GetKeyPtsFromRawFileName(rawFileFullPath, RespondLayer):
     return GetKeyPtsByAE(SphericalRing, GridCounter, RespondImg)
 
 
+class _Blocks:
+    """Member 0 of Voxelization's tuple (Voxel.py:59-72,:126-143): ``Blocks[ix][iy][iz]`` is ``[False]`` for an untouched
+    64^3 block and ``[True, occupancy int8 [64,64,64], [local voxel indices], [global voxel indices]]`` for a touched
+    one.  The reference deep-copies a 156 x 156 x 23 nested list per call; here the same indexing is served on demand
+    from AllVoxels0 and its block structures (identical values, built when asked for)."""
+
+    def __init__(self, avl, cnt, local, a0):
+        self._dims = (156, 156, 23)                                   # nBlocksL, nBlocksW, nBlocksH (Voxel.py:42-44)
+        self._index = {tuple(int(v) for v in b): i for i, b in enumerate(avl)}
+        self._cnt, self._local, self._a0, self._cache = cnt, local, a0, {}
+
+    def __len__(self):
+        return self._dims[0]
+
+    def block(self, ix, iy, iz):
+        key = (ix, iy, iz)
+        if key not in self._index:
+            return [False]
+        if key not in self._cache:
+            i = self._index[key]
+            lo, hi = int(self._cnt[i]), int(self._cnt[i + 1])
+            occ = np.zeros((64, 64, 64), dtype=np.int8)
+            loc = self._local[lo:hi]
+            occ[loc[:, 0], loc[:, 1], loc[:, 2]] = 1
+            self._cache[key] = [True, occ, loc.tolist(), self._a0[lo:hi].tolist()]
+        return self._cache[key]
+
+    class _Level:
+        def __init__(self, owner, prefix):
+            self._o, self._p = owner, prefix
+
+        def __len__(self):
+            return self._o._dims[len(self._p)]
+
+        def __getitem__(self, i):
+            n = self._o._dims[len(self._p)]
+            if not -n <= i < n:
+                raise IndexError("list index out of range")
+            p = self._p + (i % n,)
+            return self._o.block(*p) if len(p) == 3 else _Blocks._Level(self._o, p)
+
+    def __getitem__(self, i):
+        return _Blocks._Level(self, ())[i]
+
+
 def Voxelization(PC):
-    """Voxel.py:100-173.  Returns the reference's 9-tuple; AllVoxels0/1/2 (indices 6,7,8) are exact
-    (values and order), the Python block structures at 0..5 -- consumed only by code outside the hot
-    path -- are None."""
+    """Voxel.py:100-173 -> the reference's 9-tuple (Blocks, VoxelModel1, VoxelModel2, avlBlocksList, cntVoxelsLength,
+    AllVoxels, AllVoxels0, AllVoxels1, AllVoxels2).  AllVoxels0/1/2 come from the device (values and first-touch
+    order); the block structures (:161-172) and the dense int8 models (:106-107,:153-158) are derived from them on the
+    host -- they are consumed only by code outside the hot path (BatchVoxelization.py:61-62, Match.py:28-43)."""
+    from . import stageio
     e = default_engine()
     as_np = _is_np(PC)
     pc = _dev(PC, torch.float32)
     vmap, st = e.voxelize(pc)
     raise_status(int(st.item()) & ~_eng.ST_FEW_VOXELS)  # the reference only complains later, in GetPatchesList
     a0, a1, a2 = e.voxmap_export(vmap, pc.shape[0])
-    return (None, None, None, None, None, None, _out(a0, as_np), _out(a1, as_np), _out(a2, as_np))
+    h0, h1, h2 = (t.cpu().numpy() for t in (a0, a1, a2))
+    avl, cnt, local = stageio.block_structures(h0)
+    vm1 = np.zeros((1248, 1248, 184), dtype=np.int8)                  # nBlocks * 64 / 8 (Voxel.py:106)
+    vm2 = np.zeros((312, 312, 46), dtype=np.int8)                     # nBlocks * 64 / 32 (:107)
+    vm1[h1[:, 0], h1[:, 1], h1[:, 2]] = 1
+    vm2[h2[:, 0], h2[:, 1], h2[:, 2]] = 1
+    return (_Blocks(avl, cnt, local, h0), vm1, vm2, avl, cnt, local, _out(a0, as_np), _out(a1, as_np), _out(a2, as_np))
 
 
 def GetPatchesBits(Pts, AllVoxels0, AllVoxels1, AllVoxels2):
@@ -232,6 +285,8 @@ def RANSAC4RT(Pairs0, Pairs1, Weights0=None, Weights1=None, rng=None):
     r, mask = _ransac(p0, p1, idx, rng)
     R = np.array(r.R_ransac, dtype=np.float32).reshape(3, 3)
     T = np.array(r.T_ransac, dtype=np.float32).reshape(3, 1)
+    if r.best_trial < 0:   # no hypothesis was ever accepted: the reference returns its float64 initial values (:177-178)
+        R, T = np.eye(3, dtype=np.float64), np.zeros((3, 1), dtype=np.float64)
     m = mask.bool()
     thr = {0: 0.4, 1: 0.8, 2: 1.6}[int(round(np.log2(r.threshold / 0.4)))]
     if as_np:

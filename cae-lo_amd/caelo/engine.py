@@ -50,24 +50,21 @@ def raise_status(st):
 
 
 def read_keras_weights(path):
-    """-> ("respond", [w1,b1,w2,b2]) or ("encoder", [10 arrays]) from a Keras 2.2 .h5 file."""
-    import json
+    """-> ("respond", [w1,b1,w2,b2]) or ("encoder", [10 arrays]) from a Keras 2.2 .h5 file.  The layer stack is read
+    from the file's ``model_config`` and compared field by field with what the kernels implement (keras_config.check):
+    any other activation / padding / stride / data format / shape is refused."""
+    from . import keras_config
     h = H5File(path)
-    cfg = json.loads(h.attrs("/")["model_config"].decode("utf8"))
-    classes = [l["class_name"] for l in cfg["config"]["layers"]]
+    kind = keras_config.check(keras_config.layers(h))
     names = [n.decode() for n in h.attrs("/model_weights")["layer_names"]]
     ws = []
     for ln in names:
         for wn in h.attrs("/model_weights/" + ln).get("weight_names", []):
             ws.append(np.ascontiguousarray(h.dataset("/model_weights/%s/%s" % (ln, wn.decode())), np.float32))
-    if "Conv2D" in classes and [w.size for w in ws] == [864, 32, 256, 8]:
-        return "respond", ws
-    if "Conv3D" in classes and [w.size for w in ws] == [216, 8, 3456, 16, 13824, 32, 409600, 200, 4000, 20]:
-        acts = [l["config"].get("activation") for l in cfg["config"]["layers"] if "activation" in l["config"]]
-        if acts != ["tanh"] * 5:
-            raise ValueError("unexpected encoder activations %s (the shipped model is all-tanh)" % acts)
-        return "encoder", ws
-    raise ValueError("%s: not one of the two CAE-LO inference models" % path)
+    want = [864, 32, 256, 8] if kind == "respond" else [216, 8, 3456, 16, 13824, 32, 409600, 200, 4000, 20]
+    if [w.size for w in ws] != want:
+        raise ValueError("%s: weight shapes %s do not match the %s architecture" % (path, [w.shape for w in ws], kind))
+    return kind, ws
 
 
 class VoxelMap:

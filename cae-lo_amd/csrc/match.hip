@@ -45,8 +45,11 @@ struct MmPartial {
     double L1, L2, L3, U;
     int I1, I2;
 };
-// Cross-workgroup hand-off without fences (cdna_hip_programming.md G16, "8-B agent atomics both
-// sides"): relaxed agent-scope stores are write-through (sc1), relaxed agent-scope loads bypass the L1.
+// Cross-workgroup hand-off: the partial results go out as agent-scope atomic stores (write-through, sc1) and come
+// back as agent-scope atomic loads (cdna_hip_programming.md G16, "8-B agent atomics both sides"); on top of that the
+// ticket is a release / acquire pair (__threadfence() before it in the publishing wave, an ACQ_REL read-modify-write,
+// __threadfence() in the last arriver), so the scheme is correct by the HIP memory model, not only by how gfx950's
+// caches happen to behave.  The fences cost nothing measurable at 256 workgroups.
 __device__ inline void mm_publish(MmPartial *dst, const MmPartial &p) {
     unsigned long long *d = (unsigned long long *)dst;
     __hip_atomic_store(d + 0, (unsigned long long)__double_as_longlong(p.L1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -211,15 +214,16 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const float *__res
             pt.L1 = L1; pt.L2 = L2; pt.L3 = L3; pt.U = U; pt.I1 = I1; pt.I2 = I2;
             mm_publish(&mine[x], pt);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have reached L2/memory
+        __threadfence();  // release: the partial results are visible device-wide before the ticket is taken
     }
     __syncthreads();
     if (tid == 0) {
-        s_last = atomicAdd(&tickets[ctile], 1) == MM_RS - 1;  // tid 0 is in wave 0: its stores are drained
+        s_last = __hip_atomic_fetch_add(&tickets[ctile], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == MM_RS - 1;
         if (s_last) tickets[ctile] = 0;  // self-cleaning: the workspace is ready for the next call, no memset launch
     }
     __syncthreads();
     if (!s_last) return;
+    __threadfence();  // acquire: the other slices' partial results
     // ---- merge the slices and certify: one thread per column
     if (tid < 16) {
         const int j = j0 + tid;
@@ -681,19 +685,20 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_level(const float *__r
             cnt += __popcll(__ballot(in));
         }
         if (lane == 0) {
-            // read by the last workgroup of this launch: write-through store, drained before the arrival ticket;
-            // the reader uses agent-scope loads (no release/acquire fences, G16 "atomics both sides")
+            // read by the last workgroup of this launch: agent-scope store, released by the fence before the arrival
+            // ticket (an ACQ_REL read-modify-write); the reader fences after it and uses agent-scope loads
             __hip_atomic_store(&ws->counts[trial], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __threadfence();
         }
     }
     __syncthreads();
     if (tid == 0) {
-        s_last = atomicAdd(&ws->arrived[level], 1) == CAELO_RANSAC_MAX_TRIALS / RE_WAVES - 1;
+        s_last = __hip_atomic_fetch_add(&ws->arrived[level], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == CAELO_RANSAC_MAX_TRIALS / RE_WAVES - 1;
         if (s_last) ws->arrived[level] = 0;
     }
     __syncthreads();
     if (!s_last) return;
+    __threadfence();
     // ---- 3. accept rules
     if (tid < 64) ransac_replay(N, level, ws, s_counts);
     __syncthreads();

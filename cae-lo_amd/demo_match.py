@@ -31,10 +31,8 @@ def frame(PC, RespondLayer, PatchEncoder):
     return KeyPts, Features
 
 
-def main():
-    files = [a for a in sys.argv[1:] if not a.startswith("--")]
-    seed = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 0
-    PC0, PC1 = (stageio.read_scan(files[0]), stageio.read_scan(files[1])) if len(files) >= 2 else (synth.make_scan(0), synth.make_scan(1))
+def run(PC0, PC1, seed=0):
+    """Match.py:312-353 on two scans -> dict of everything the reference's demo computes."""
     PatchEncoder = load_model(ENCODER_H5)                                                       # Match.py:313
     RespondLayer = load_model(RESPOND_H5)                                                       # Match.py:324
     KeyPts0, Features0 = frame(PC0, RespondLayer, PatchEncoder)
@@ -42,9 +40,20 @@ def main():
     Weights0 = np.ones((KeyPts0.shape[0], 1), np.float32); Weights1 = np.ones((KeyPts1.shape[0], 1), np.float32)
     R, T, isSuccess, inliersIdx0, inliersIdx1, residualThreshold = SolveRelativePose(
         KeyPts0, Features0, Weights0, KeyPts1, Features1, Weights1, rng=np.random.RandomState(seed))   # Match.py:349
-    print("nKeyPts =", KeyPts0.shape[0], KeyPts1.shape[0])
+    return dict(KeyPts0=KeyPts0, Features0=Features0, KeyPts1=KeyPts1, Features1=Features1, R=R, T=T, isSuccess=isSuccess,
+                inliersIdx0=inliersIdx0, inliersIdx1=inliersIdx1, residualThreshold=residualThreshold)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    files = [a for a in argv if not a.startswith("--") and not a.lstrip("-").isdigit()]
+    seed = int(argv[argv.index("--seed") + 1]) if "--seed" in argv else 0
+    PC0, PC1 = (stageio.read_scan(files[0]), stageio.read_scan(files[1])) if len(files) >= 2 else (synth.make_scan(0), synth.make_scan(1))
+    o = run(PC0, PC1, seed)
+    R, T = o["R"], o["T"]
+    print("nKeyPts =", o["KeyPts0"].shape[0], o["KeyPts1"].shape[0])
     print("R =\n", np.round(R, 5)); print("T =", np.round(np.asarray(T).ravel(), 4))
-    print("isSuccess =", isSuccess, " nInliers =", len(inliersIdx0), " residualThreshold =", residualThreshold)
+    print("isSuccess =", o["isSuccess"], " nInliers =", len(o["inliersIdx0"]), " residualThreshold =", o["residualThreshold"])
     if len(files) < 2:
         Rg, Tg = synth.relative_pose_gt(0, 1)
         print("synthetic ground truth T =", np.round(Tg.ravel(), 4), " |dT| = %.4f m" % float(np.linalg.norm(np.asarray(T).ravel() - Tg.ravel())))

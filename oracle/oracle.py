@@ -296,6 +296,9 @@ def load_models(respond_h5, encoder_h5):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(_HERE), "cae-lo_amd"))
     from caelo.h5lite import H5File
+    from caelo import keras_config
+    for path, kind in ((respond_h5, "respond"), (encoder_h5, "encoder")):   # the restatement below IS this stack: refuse others
+        keras_config.check(keras_config.layers(path), kind)
     r = H5File(respond_h5)
     g = lambda h, l, n: h.dataset("/model_weights/%s/%s/%s:0" % (l, l, n))
     resp = RespondLayer(g(r, "conv2d_1", "kernel"), g(r, "conv2d_1", "bias"),

@@ -696,3 +696,116 @@ def test_pipeline_mode_matrix_on_one_pipeline(engine, scans):
                 torch.cuda.synchronize()
                 for i, pc in enumerate(pcs * 3):
                     assert torch.equal(out.rows[i], engine.extract(pc, dist_channels=dc, exact_voxels=ex, dedup=False).rows), (dc, ex, dd, i)
+
+
+# ---- SURVEY 8c harness rows and the API's file / tuple surface --------------------------------------------------------
+def test_demo_match_harness_vs_reference_golden(engine, scans, capsys):
+    """cae-lo_amd/demo_match.py = Match.py:294-356 through caelo.api, EXECUTED: key points, descriptors and the pose of
+    frames 0 / 1 against pair_0_1.npz (the reference's SolveRelativePose with np.random.seed(0))."""
+    import importlib.util
+    from conftest import REPO
+    spec = importlib.util.spec_from_file_location("demo_match", os.path.join(REPO, "cae-lo_amd", "demo_match.py"))
+    dm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dm)
+    g = np.load(os.path.join(GOLDEN, "pair_0_1.npz"))
+    f0, f1 = (np.load(os.path.join(GOLDEN, "frame_%d.npz" % f)) for f in (0, 1))
+    out = dm.run(scans(0), scans(1), seed=0)
+    assert np.array_equal(out["KeyPts0"], f0["keypts_demo"]) and np.array_equal(out["KeyPts1"], f1["keypts_demo"])
+    _assert_descriptors(out["Features0"], f0["features"]); _assert_descriptors(out["Features1"], f1["features"])
+    assert out["isSuccess"] == bool(g["s0_ok"]) and out["residualThreshold"] == float(g["s0_thr"])
+    assert np.array_equal(out["inliersIdx0"], g["s0_idx0"]) and np.array_equal(out["inliersIdx1"], g["s0_idx1"])
+    assert np.abs(out["R"] - g["s0_R"]).max() <= REL_TOL and np.abs(out["T"] - g["s0_T"]).max() <= REL_TOL * max(1.0, np.abs(g["s0_T"]).max())
+    dm.main(["--seed", "0"])                                            # the script's own entry point, printing like the reference
+    text = capsys.readouterr().out
+    assert "isSuccess = True" in text and "nInliers = %d" % len(g["s0_idx0"]) in text
+
+
+def test_get_keypts_from_raw_file_name_on_a_reference_written_ring_file(api, tmp_path):
+    """SphericalRing.GetKeyPtsFromRawFileName (:389-416) on a SphericalRing/*.mat WRITTEN BY THE REFERENCE
+    (tests/golden/mat_stage_files.npz) -> the key points the reference's own function returned for that file."""
+    g = np.load(os.path.join(GOLDEN, "mat_stage_files.npz"))
+    names = [str(n) for n in g["file_names"]]
+    path = tmp_path / "00" / "SphericalRing" / "000000.bin.mat"
+    path.parent.mkdir(parents=True)
+    path.write_bytes(g["file_%d" % names.index("SphericalRing/000000.bin.mat")].tobytes())
+    RespondLayer = api.load_model(os.path.join(WEIGHTS, "SphericalRingPCRespondLayer.h5"))
+    KeyPts, KeyPixels, PlanarPts = api.GetKeyPtsFromRawFileName(str(tmp_path / "00" / "velodyne" / "000000.bin"), RespondLayer)
+    assert np.array_equal(KeyPixels, g["f0_keypixels_from_raw"].astype(np.int64)) and KeyPixels.dtype == np.int64
+    assert np.array_equal(KeyPts, g["f0_keypts_from_raw"]) and PlanarPts.size == 0
+    with pytest.raises(FileNotFoundError):
+        api.GetKeyPtsFromRawFileName(str(tmp_path / "00" / "velodyne" / "000009.bin"), RespondLayer)
+
+
+def test_voxelization_returns_the_references_whole_tuple(api, scans):
+    """Voxel.py:161-173: all nine members, against what the reference returned on the same scan (voxel_blocks.npz)."""
+    g = np.load(os.path.join(GOLDEN, "voxel_blocks.npz"))
+    pc = scans(*g["scan_params"].tolist())
+    Blocks, VM1, VM2, avl, cnt, local, A0, A1, A2 = api.Voxelization(pc[:, 0:3])
+    for got, key in ((avl, "avlBlocksList"), (cnt, "cntVoxelsLength"), (local, "AllVoxels"), (A0, "AllVoxels0"), (A1, "AllVoxels1"), (A2, "AllVoxels2")):
+        assert got.dtype == g[key].dtype and np.array_equal(got, g[key]), key
+    assert VM1.shape == tuple(g["vm1_shape"]) and VM2.shape == tuple(g["vm2_shape"]) and str(VM1.dtype) == str(VM2.dtype) == str(g["vm_dtype"])
+    assert np.array_equal(np.argwhere(VM1), g["vm1_nz"]) and np.array_equal(np.argwhere(VM2), g["vm2_nz"])
+    assert [len(Blocks), len(Blocks[0]), len(Blocks[0][0])] == g["blocks_dims"].tolist()
+    for i, (bx, by, bz) in enumerate(g["blocks_probe"].tolist()):
+        b = Blocks[bx][by][bz]
+        assert b[0] is True and len(b) == 4 and b[1].dtype == np.int8 and np.array_equal(np.argwhere(b[1]), g["block%d_occ" % i])
+        assert np.array_equal(np.array(b[2], np.int16), g["block%d_local" % i]) and np.array_equal(np.array(b[3], np.int16), g["block%d_global" % i])
+    ex, ey, ez = g["blocks_empty_probe"].tolist()
+    assert Blocks[ex][ey][ez] == [False]
+    with pytest.raises(IndexError):
+        Blocks[156]
+
+
+# ---- determinism under load (VERDICT r1 item 5) ----------------------------------------------------------------------
+def test_match_ransac_and_pipeline_are_deterministic_under_load(engine, scans):
+    """The cross-workgroup hand-offs (match slices -> certifier, RANSAC hypotheses -> replay, encoder work counter,
+    de-duplication tickets) must give the same bits on every run: 2 000 match + RANSAC calls and 2 000 pipelined frames
+    against one fixed expectation, alone and while two other streams keep the GPU busy with extractions."""
+    import threading
+    import torch
+    from caelo.engine import ransac_draws
+    pcs = [torch.from_numpy(scans(i, quantum=1e-3)).to(engine.device) for i in range(3)]
+    rnd = [torch.from_numpy(ransac_draws(77 + i)).to(engine.device) for i in range(3)]
+    fa, fb = engine.extract(pcs[0]), engine.extract(pcs[1])
+    res0, mask0, idx0 = engine.match_pose(fa, fb, rnd[0])
+    torch.cuda.synchronize()
+    stop = threading.Event()
+
+    def noise(k):   # another host thread on its own stream: extractions back to back
+        st = torch.cuda.Stream(device=engine.device)
+        with torch.cuda.stream(st):
+            while not stop.is_set():
+                engine.extract(pcs[(k + 1) % 3])
+                st.synchronize()
+
+    def match_round(n):
+        bad = 0
+        for i in range(n):
+            res, mask, idx = engine.match_pose(fa, fb, rnd[0])
+            bad += int(not (torch.equal(idx, idx0) and torch.equal(mask, mask0) and torch.equal(res, res0)))
+        return bad
+
+    assert match_round(1000) == 0
+    pipe = engine.pipeline(6)
+    want = pipe.run(pcs * 4, rnd * 4, prev=fa)
+    torch.cuda.synchronize()
+    exp = [t.clone() for t in (want.rows, want.pair_idx, want.inlier_mask, want.result, want.key_pixels)]
+
+    def pipe_round(n):
+        bad = 0
+        for _ in range(n):
+            got = pipe.run(pcs * 4, rnd * 4, prev=fa)
+            torch.cuda.synchronize()
+            bad += int(not all(torch.equal(a, b) for a, b in zip((got.rows, got.pair_idx, got.inlier_mask, got.result, got.key_pixels), exp)))
+        return bad
+
+    assert pipe_round(84) == 0                      # 84 x 12 = 1 008 frames
+    threads = [threading.Thread(target=noise, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    try:
+        assert match_round(1000) == 0 and pipe_round(84) == 0
+    finally:
+        stop.set()
+        for t in threads:
+            t.join()

@@ -104,3 +104,50 @@ def test_sequence_golden_is_self_consistent(seq):
     assert (seq["n_inliers"] > 100).all() and (seq["n_key"] == 1024).all()
     R = seq["rel_rt"][:, :9].reshape(-1, 3, 3)
     assert np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max() < 1e-5          # rotations
+
+
+@pytest.fixture(scope="module")
+def ref_mat_files(tmp_path_factory):
+    """tests/golden/mat_stage_files.npz: .mat files WRITTEN BY THE REFERENCE's own savemat statements
+    (BatchPreprocess.py:54-64,:139-148, BatchVoxelization.py:42-62, PoseEstimation.py:292-295,:297-309 -- executed by
+    tools/make_goldens.py) unpacked into the reference's directory layout."""
+    g = np.load(os.path.join(GOLDEN, "mat_stage_files.npz"))
+    seq = tmp_path_factory.mktemp("refmat") / "00"
+    for i, name in enumerate(g["file_names"]):
+        path = seq / str(name)
+        path.parent.mkdir(parents=True, exist_ok=True)
+        path.write_bytes(g["file_%d" % i].tobytes())
+    (seq / "velodyne").mkdir()
+    return g, str(seq)
+
+
+def test_stageio_reads_files_written_by_the_reference(ref_mat_files):
+    import hashlib
+    from caelo import stageio
+    g, seq = ref_mat_files
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    raw0, raw1 = (os.path.join(seq, "velodyne", "%06d.bin" % f) for f in (0, 1))
+    ring, cnt = stageio.load_spherical_ring(raw0)
+    assert ring.shape == (69, 1800, 5) and ring.dtype == np.float32 and sha(ring) == str(g["f0_ring_sha256"])
+    assert cnt.shape == (69, 1800) and sha(cnt) == str(g["f0_counter_sha256"])
+    kp, a0, a1, a2 = stageio.load_voxel_model_and_keypts(raw0)
+    assert np.array_equal(kp, g["f0_keypts"]) and kp.dtype == np.float32
+    assert [sha(a0), sha(a1), sha(a2)] == [str(v) for v in g["f0_voxel_sha256"]] and a0.dtype == np.int16
+    # the three block structures the reference stored equal what block_structures derives from ITS AllVoxels0
+    from scipy import io
+    m = io.loadmat(stageio.mat_path(raw0, "VoxelModel"))
+    avl, cntl, local = stageio.block_structures(a0)
+    assert np.array_equal(m["avlBlocksList"], avl) and np.array_equal(m["cntVoxelsLength"].ravel(), cntl) and np.array_equal(m["AllVoxels"], local)
+    k2, F, W = stageio.load_keypts_and_features(raw0)
+    assert np.array_equal(k2, g["f0_keypts"]) and np.array_equal(F, g["f0_features"]) and W.shape == (len(k2), 1) and (W == 1).all()
+    i0, i1 = stageio.load_inliers(seq, 0, 1)
+    assert np.array_equal(i0, g["inliers_idx0"]) and np.array_equal(i1, g["inliers_idx1"]) and len(i0) > 100
+    ke = io.loadmat(stageio.mat_path(raw1, "KeyPts"))
+    assert np.array_equal(ke["KeyPts"], g["f1_keypts"]) and sha(np.asarray(ke["ExtendedKeyPts"], np.float32)) == str(g["f1_ext_sha256"])
+    assert ke["PlanarPts"].size == 0                                    # SphericalRing.py:219,285: always empty
+    assert bool(g["reference_loaders_read_stageio_files"])              # the other direction, asserted at generation time
+    # our writers produce files with the same variables, dtypes and shapes as the reference's
+    mine = stageio.save_voxel_model(os.path.join(seq, "mine", "velodyne", "000000.bin"), a0, a1, a2)
+    m2 = io.loadmat(mine)
+    for key in ("avlBlocksList", "cntVoxelsLength", "AllVoxels", "AllVoxels0", "AllVoxels1", "AllVoxels2"):
+        assert m2[key].dtype == m[key].dtype and np.array_equal(m2[key], m[key]), key

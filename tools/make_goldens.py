@@ -310,8 +310,150 @@ def blocks_golden():
     g = {"scan_params": np.array([3, 16, 600]), "avlBlocksList": out[3], "cntVoxelsLength": out[4], "AllVoxels": out[5],
          "AllVoxels0": out[6], "AllVoxels1": out[7], "AllVoxels2": out[8]}
     assert out[3].dtype == np.int16 and out[4].dtype == np.int32 and out[5].dtype == np.int16
+    # tuple members 0-2 (Voxel.py:101-107,:126-158): VoxelModel1/2 as shapes + dtype + occupied cells (argwhere order), Blocks
+    # through three occupied blocks (dense 64^3 int8 occupancy as argwhere, local and global voxel lists) and one empty one
+    Blocks, VM1, VM2 = out[0], out[1], out[2]
+    g["vm1_shape"], g["vm2_shape"] = np.array(VM1.shape), np.array(VM2.shape)
+    g["vm_dtype"] = str(VM1.dtype)
+    assert VM1.dtype == VM2.dtype == np.int8 and set(np.unique(VM1)) <= {0, 1}
+    g["vm1_nz"], g["vm2_nz"] = np.argwhere(VM1).astype(np.int16), np.argwhere(VM2).astype(np.int16)
+    g["blocks_dims"] = np.array([len(Blocks), len(Blocks[0]), len(Blocks[0][0])])
+    probe = [tuple(int(v) for v in out[3][i]) for i in (0, len(out[3]) // 2, len(out[3]) - 1)]
+    g["blocks_probe"] = np.array(probe)
+    for i, (bx, by, bz) in enumerate(probe):
+        b = Blocks[bx][by][bz]
+        assert b[0] is True and b[1].dtype == np.int8 and b[1].shape == (64, 64, 64) and len(b) == 4
+        g["block%d_occ" % i] = np.argwhere(b[1]).astype(np.int16)
+        g["block%d_local" % i] = np.array(b[2], np.int16); g["block%d_global" % i] = np.array(b[3], np.int16)
+    empty = next((x, y, z) for x in range(len(Blocks)) for y in range(len(Blocks[0])) for z in range(len(Blocks[0][0]))
+                 if Blocks[x][y][z][0] is False)
+    assert Blocks[empty[0]][empty[1]][empty[2]] == [False]
+    g["blocks_empty_probe"] = np.array(empty)
     np.savez_compressed(os.path.join(GOLD, "voxel_blocks.npz"), **g)
     print("  blocks golden: %d blocks, %d voxels" % (len(out[3]), len(out[6])))
+
+
+def mat_golden():
+    """the .mat stage files.  (1) WRITTEN BY THE REFERENCE -- its own functions / statements
+    (BatchPreprocess.py:54-64 and :139-148, BatchVoxelization.BatchVoxelization :42-62, PoseEstimation.py:293-295 and
+    :297-309) run on a small synthetic sequence -- and read back here with caelo.stageio (asserted equal); the files
+    themselves are committed as the fixture tests/golden/mat_stage_files.npz so the CPU tests re-read them without the
+    reference.  (2) WRITTEN BY caelo.stageio and read by the reference's own loaders (Match.LoadVoxelModelAndKeyPts,
+    Match.LoadKeyPtsAndFeatures, Match.LoadVoxelModel, SphericalRing.GetKeyPtsFromRawFileName), asserted equal."""
+    import shutil
+    import tempfile
+    from scipy import io
+    import BatchVoxelization as RefBV
+    from caelo import stageio
+    tmp = tempfile.mkdtemp(prefix="caelo_mat_")
+    g = {}
+    try:
+        seq = os.path.join(tmp, "ref", "00")
+        os.makedirs(os.path.join(seq, "velodyne"))
+        params = (0, 64, 1000)          # 64 beams x 1000 azimuths: ~63 k points, a few hundred key points, small files
+        raws, clouds = [], []
+        for f in (0, 1):
+            pc = synth.make_scan(f, n_beams=params[1], n_az=params[2])
+            raw = os.path.join(seq, "velodyne", "%06d.bin" % f)
+            pc.tofile(raw)
+            raws.append(raw); clouds.append(pc)
+        g["scan_params"] = np.array(params); g["cloud_sha256"] = np.array([synth.cloud_sha256(c) for c in clouds])
+        # ---- (1) the reference writes
+        ring_block = ref_source_block(os.path.join(REF, "BatchPreprocess.py"), 54, 64)        # Projection + savemat
+        keypt_block = ref_source_block(os.path.join(REF, "BatchPreprocess.py"), 136, 148)     # GetKeyPtsByAE .. savemat
+        feat_block = ref_source_block(os.path.join(REF, "PoseEstimation.py"), 292, 295)       # for iFrame ...: savemat
+        inl_block = ref_source_block(os.path.join(REF, "PoseEstimation.py"), 297, 309)
+        frames = []
+        for f, (raw, pc) in enumerate(zip(raws, clouds)):
+            ns = {"np": np, "os": os, "io": io, "ProjectPC2SphericalRing": RefSR.ProjectPC2SphericalRing, "PC": pc,
+                  "rawFileFullPath": raw, "TargetFolderName": "SphericalRing"}
+            exec(ring_block, ns)
+            ring, cnt = ns["SphericalRing"], ns["GridCounter"]
+            resp = np.squeeze(resp_model.predict(ring[0:64, 0:1792, :][:, :, [0, 1, 2]].reshape(1, 64, 1792, 3)))
+            ring_b = np.ascontiguousarray(ring[0:64, 0:1792, :][:, :, [0, 1, 2]]); cnt_b = np.array(cnt, dtype=np.int8)   # batch mode
+            ns = {"np": np, "os": os, "io": io, "print": lambda *a, **k: None, "GetKeyPtsByAE": lambda *a: quiet(RefSR.GetKeyPtsByAE, *a)[0],
+                  "ExtendKeyPtsInShpericalRing": RefSR.ExtendKeyPtsInShpericalRing, "SphericalRing": ring_b,
+                  # the full int8 counter, as BatchPreprocess.py:98,132 hands it over
+                  "GridCounter": cnt_b.copy(), "RespondImg": resp, "strDataBaseDir": os.path.dirname(seq),
+                  "strSequence": "00", "KeyPtFolderName": "KeyPts", "iFrame": f, "nFramesInSequence": 2}
+            exec(keypt_block, ns)
+            kp, ext = ns["KeyPts"], ns["ExtendedKeyPts"]
+            vout = RefVoxel.Voxelization(pc[:, 0:3])
+            _, plist = RefVoxel.GetPatchesList(kp, vout[6], vout[7], vout[8])
+            feats = RefMatch.GetFeaturesFromPatches(enc_model, plist)
+            frames.append(dict(ring=ring, cnt=cnt, kp=kp, ext=ext, vout=vout, feats=feats, W=np.ones((len(kp), 1), np.float32)))
+        quiet(RefBV.BatchVoxelization, raws, 0, [0])
+        np.random.seed(5)
+        (R, T, ok, i0, i1, thr), _ = quiet(RefMatch.SolveRelativePose, frames[0]["kp"], frames[0]["feats"], frames[0]["W"],
+                                           frames[1]["kp"], frames[1]["feats"], frames[1]["W"])
+        ns = {"os": os, "io": io, "str": str, "range": range, "len": len, "nFrames": 2, "FeatruesDataDir": os.path.join(seq, "Features"),
+              "listKeyPtsData": [(fr["kp"], fr["feats"], fr["W"]) for fr in frames]}
+        os.makedirs(ns["FeatruesDataDir"])
+        exec(feat_block, ns)
+        ns = {"os": os, "io": io, "strDataBaseDir": os.path.dirname(seq), "strSequence": "00", "iKeyPtSource": 0,
+              "inliersData": [[0, 1, i0, i1]]}
+        exec(inl_block, ns)
+        # ... and caelo.stageio reads them back
+        files = {}
+        for f, (raw, fr) in enumerate(zip(raws, frames)):
+            ring, cnt = stageio.load_spherical_ring(raw)
+            assert ring.dtype == np.float32 and np.array_equal(ring, fr["ring"]) and np.array_equal(cnt, fr["cnt"])
+            kp, a0, a1, a2 = stageio.load_voxel_model_and_keypts(raw)
+            assert np.array_equal(kp, fr["kp"]) and np.array_equal(a0, fr["vout"][6]) and np.array_equal(a1, fr["vout"][7]) and np.array_equal(a2, fr["vout"][8])
+            m = io.loadmat(stageio.mat_path(raw, "VoxelModel"))
+            avl, cntl, local = stageio.block_structures(a0)
+            assert np.array_equal(m["avlBlocksList"], avl) and np.array_equal(m["cntVoxelsLength"].ravel(), cntl) and np.array_equal(m["AllVoxels"], local)
+            k2, F, W = stageio.load_keypts_and_features(raw)
+            assert np.array_equal(k2, fr["kp"]) and np.array_equal(F, fr["feats"]) and np.array_equal(W, fr["W"])
+            ke = io.loadmat(stageio.mat_path(raw, "KeyPts"))
+            assert np.array_equal(ke["ExtendedKeyPts"], fr["ext"])
+            g["f%d_ring_sha256" % f] = sha(fr["ring"]); g["f%d_counter_sha256" % f] = sha(fr["cnt"])
+            g["f%d_keypts" % f] = fr["kp"]; g["f%d_ext_sha256" % f] = sha(np.asarray(fr["ext"], np.float32)); g["f%d_n_ext" % f] = len(fr["ext"])
+            g["f%d_features" % f] = fr["feats"].astype(np.float32)
+            g["f%d_voxel_sha256" % f] = np.array([sha(fr["vout"][6]), sha(fr["vout"][7]), sha(fr["vout"][8])])
+            for folder in ("SphericalRing", "KeyPts", "VoxelModel", "Features"):
+                if f == 1 and folder != "KeyPts":
+                    continue            # the fixture keeps frame 0's five files, frame 1's KeyPts and the pair's InliersIdx
+                with open(stageio.mat_path(raw, folder), "rb") as fh:
+                    files["%s/%06d.bin.mat" % (folder, f)] = np.frombuffer(fh.read(), np.uint8)
+        j0, j1 = stageio.load_inliers(seq, 0, 1)
+        assert np.array_equal(j0, i0) and np.array_equal(j1, i1)
+        with open(os.path.join(seq, "InliersIdx", "000000-000001.bin.mat"), "rb") as fh:
+            files["InliersIdx/000000-000001.bin.mat"] = np.frombuffer(fh.read(), np.uint8)
+        g["inliers_idx0"], g["inliers_idx1"] = i0.astype(np.int32), i1.astype(np.int32)
+        g["file_names"] = np.array(sorted(files))
+        for i, name in enumerate(sorted(files)):
+            g["file_%d" % i] = files[name]
+        # ---- (2) caelo.stageio writes, the reference's loaders read
+        seq2 = os.path.join(tmp, "ours", "00")
+        os.makedirs(os.path.join(seq2, "velodyne"))
+        for f, fr in enumerate(frames):
+            raw = os.path.join(seq2, "velodyne", "%06d.bin" % f)
+            stageio.save_spherical_ring(raw, fr["ring"], fr["cnt"])
+            stageio.save_keypts(raw, fr["kp"], fr["ext"])
+            stageio.save_voxel_model(raw, fr["vout"][6], fr["vout"][7], fr["vout"][8])
+            stageio.save_features(raw, fr["kp"], fr["feats"])
+            kp, a0, a1, a2 = RefMatch.LoadVoxelModelAndKeyPts(raw)
+            assert np.array_equal(kp, fr["kp"]) and np.array_equal(a0, fr["vout"][6]) and np.array_equal(a1, fr["vout"][7]) and np.array_equal(a2, fr["vout"][8])
+            k2, F, W = RefMatch.LoadKeyPtsAndFeatures(raw)
+            assert np.array_equal(k2, fr["kp"]) and np.array_equal(F, fr["feats"]) and np.array_equal(W, fr["W"])
+            Blocks, VM1, VM2 = RefMatch.LoadVoxelModel(raw)          # rebuilds the voxel models from OUR block structures
+            assert np.array_equal(VM1, fr["vout"][1]) and np.array_equal(VM2, fr["vout"][2])
+            for bx, by, bz in fr["vout"][3][:: max(1, len(fr["vout"][3]) // 7)]:
+                assert np.array_equal(Blocks[bx][by][bz][1], fr["vout"][0][bx][by][bz][1])
+            (kp3, kpix3, _), _ = quiet(RefSR.GetKeyPtsFromRawFileName, raw, resp_model)      # demo mode on OUR ring file
+            (kp4, kpix4, _), _ = quiet(RefSR.GetKeyPtsFromRawFileName, raws[f], resp_model)   # ... and on the reference's
+            assert np.array_equal(kp3, kp4) and np.array_equal(kpix3, kpix4)
+            g["f%d_keypixels_from_raw" % f] = kpix4.astype(np.int16); g["f%d_keypts_from_raw" % f] = kp4.astype(np.float32)
+        stageio.save_inliers(seq2, 0, 1, i0, i1)
+        m = io.loadmat(os.path.join(seq2, "InliersIdx", "000000-000001.bin.mat"))
+        assert np.array_equal(m["inliersIdx0"].ravel(), i0) and int(m["iFrame1"]) == 1
+        g["reference_loaders_read_stageio_files"] = True
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    np.savez_compressed(os.path.join(GOLD, "mat_stage_files.npz"), **g)
+    print("  mat golden: %d reference-written files (%.0f KB raw), K = %d / %d, %d inliers" % (
+        len(files), sum(v.size for v in files.values()) / 1024, len(frames[0]["kp"]), len(frames[1]["kp"]), len(i0)))
 
 
 def ref_source_block(path, first, last):
@@ -384,6 +526,9 @@ if __name__ == "__main__":
     if "--quantised-only" in sys.argv:
         quantised_golden()
         sys.exit(0)
+    if "--mat-only" in sys.argv:
+        mat_golden()
+        sys.exit(0)
     if "--blocks-only" in sys.argv:
         blocks_golden()
         sys.exit(0)
@@ -402,6 +547,7 @@ if __name__ == "__main__":
     frame_golden(0, n_beams=128, n_az=4000, n_patch_kp=192, tag="dense128")
     sequence_golden()
     blocks_golden()
+    mat_golden()
     extend_golden()
     icp_golden()
     print("done in %.1fs" % (time.time() - t0))
