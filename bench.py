@@ -15,9 +15,9 @@ rank); the timed region per rank is
 Rank 0 prints one JSON line (contract in the task statement) including
     roofline      the dominant kernel (k_enc_stage1, conv1+conv2 of the 3D-CAE encoder), algorithmic
                   FLOPs / HIP-event time measured live through caelo_encode_profile
-    Frames are issued round-robin on --lanes HIP streams by the native executor (caelo_pipeline: one host
-    thread, voxel map and workspaces per lane) so that one frame's latency-bound kernels overlap another's
-    MFMA-bound encoder.
+    The frames go through the native executor (caelo_pipeline): --batch consecutive frames share ONE launch of every
+    front kernel, one encoder launch set and one match / RANSAC launch; the three stages of successive batches overlap
+    on three HIP streams (front(b+1) || encoder(b) || pairs(b-1)).
     cpu_baseline  the CPU oracle (oracle/, the reference restated in C/NumPy) on the host cores,
                   bounded sample, rank 0 at N == 1 only.
 """
@@ -92,10 +92,9 @@ def main():
     ap.add_argument("--steps", type=int, default=960)
     ap.add_argument("--warmup", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lanes", type=int, default=6,
-                    help="HIP streams per rank; whole frames are issued round-robin so the latency-bound kernels of "
-                         "one frame (keypoint select, voxel hash, RANSAC) overlap the MFMA-bound encoder of another")
-    ap.add_argument("--batch", type=int, default=0, help="frames per encoder launch set (0 = min(lanes, 2))")
+    ap.add_argument("--batch", type=int, default=4, help="frames per launch (1..8): the front kernels, the encoder launch "
+                                                         "set and the match / RANSAC launches each cover a whole batch")
+    ap.add_argument("--buffers", type=int, default=3, help="batches of patches in flight between the front and the encoder")
     ap.add_argument("--extract-only", action="store_true",
                     help="BASELINE configs[1]: keypoints + descriptors only (no match / RANSAC); not the headline metric")
     ap.add_argument("--gather", choices=("boundary", "all"), default="boundary",
@@ -117,12 +116,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
-    # The engine and the pipeline's HIP streams are created BEFORE the process group: the runtime deals streams onto
-    # its 4 hardware queues in creation order, and throughput depends on that mapping (lanes then encoder as the first
-    # seven streams of the process: 5.7 k frames/s; one stream created ahead of them: 4.3 k) -- RCCL's own streams
-    # must come after.
     eng = Engine(device=local_rank)
-    pipe = eng.pipeline(max(1, args.lanes), args.batch or None)
+    pipe = eng.pipeline(args.batch, args.buffers)
     if world > 1:
         dist.init_process_group(backend=backend, **({"device_id": dev} if backend == "nccl" else {}))
     K, W = args.steps, args.warmup
@@ -133,8 +128,8 @@ def main():
     n_points = int(np.mean([p.shape[0] for p in pool]))
 
     def run(steps, prev):
-        """`steps` frames through the native pipeline (frame i on lane i % lanes: extract, then match + RANSAC
-        against frame i-1), one all-gather of frame rows, then the pair that straddles the rank boundary."""
+        """`steps` frames through the native pipeline (extract, then match + RANSAC against frame i-1, `batch` frames
+        per launch), one all-gather of frame rows, then the pair that straddles the rank boundary."""
         scans = [pool[i % POOL] for i in range(steps)]
         draws = [rand[i % POOL] for i in range(steps)]
         batch = pipe.run(scans, draws, prev=prev if rank == 0 else None, pairs=not args.extract_only)
@@ -154,10 +149,9 @@ def main():
         return batch.frame(steps - 1), batch
 
     prev = eng.extract(pool[POOL - 1])
-    # one-time initialisation, not a warm-up step: every lane's stream / hardware queue / issue thread and the encoder
-    # stream are touched once (a HIP stream allocates its queue on first use, ~ms), so that a run with a small
-    # --warmup does not time queue creation
-    prev, _ = run(2 * pipe.lanes, prev)
+    # one-time initialisation, not a warm-up step: the three stage streams and every hand-off buffer are touched once (a
+    # HIP stream allocates its hardware queue on first use, ~ms), so that a run with a small --warmup does not time that
+    prev, _ = run(pipe.buffers * pipe.batch, prev)
     torch.cuda.synchronize()
     prev, _ = run(W, prev) if W > 0 else (prev, None)
     torch.cuda.synchronize()
@@ -234,9 +228,9 @@ def main():
                        "dedup": "bit-identical patches of a frame are encoded once (exact; DESIGN.md 4.7); the roofline "
                                 "object times the encoder kernels on all 3072 patches",
                        "points_per_frame": n_points, "keypoints": 1024, "patches_per_frame": 3072,
-                       "frames_per_gpu": K, "hip_streams_per_gpu": pipe.lanes + 1, "frames_per_encoder_launch": pipe.batch,
+                       "frames_per_gpu": K, "hip_streams_per_gpu": 3, "frames_per_launch": pipe.batch,
                        "host_issue_us_per_frame": round(host["issue_us_per_frame"], 1),
-                       **({"encoder_stream_busy": round(host["encoder_busy_us"] / host["encoder_span_us"], 3)} if host["encoder_span_us"] > 0 else {}), "parallelism": "frames sharded x%d, one RCCL all-gather of %s [1024,64] f32 frame rows" % (
+                       "parallelism": "frames sharded x%d, one RCCL all-gather of %s [1024,64] f32 frame rows" % (
                            world, "the boundary" if args.gather == "boundary" else "all"),
                        "poses_solved": "%d/%d" % (ok, K), "status_bits": status, "frames_flagged": frames_flagged},
             "roofline": roofline, "cpu_baseline": cpu,

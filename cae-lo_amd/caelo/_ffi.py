@@ -77,7 +77,7 @@ SIGNATURES = [
     ("caelo_icp_step", c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, C.c_double, c_int, c_vp, c_vp, c_vp, c_vp]),
     ("caelo_pipeline_create", c_int, [c_vp, c_int, c_int, c_i64, C.POINTER(c_vp)]),
     ("caelo_pipeline_destroy", None, [c_vp]),
-    ("caelo_pipeline_lanes", c_int, [c_vp]),
+    ("caelo_pipeline_batch", c_int, [c_vp]),
     ("caelo_pipeline_begin", c_int, [c_vp, c_vp]),
     ("caelo_pipeline_submit", c_int, [c_vp, C.POINTER(FrameJob)]),
     ("caelo_pipeline_flush", c_int, [c_vp, c_vp]),

@@ -120,15 +120,15 @@ class FrameBatch:
 
 
 class Pipeline:
-    """caelo_pipeline (include/caelo.h): whole frames round-robin on `lanes` HIP streams, one native
-    host thread per lane.  ``run`` submits K scans and returns without waiting for the GPU."""
+    """caelo_pipeline (include/caelo.h): `batch` consecutive frames share one launch of every front kernel, one
+    encoder launch set and one match / RANSAC launch; the three stages of successive batches overlap on three HIP
+    streams.  ``run`` submits K scans and returns without waiting for the GPU."""
 
-    def __init__(self, eng, lanes=6, batch=None, max_points=None):
+    def __init__(self, eng, batch=4, buffers=3, max_points=None):
         self.eng = eng
-        batch = min(int(lanes), 2) if batch is None else int(batch)   # measured best at 6 lanes (5.64 k vs 5.51 k at 3)
         h = C.c_void_p()
-        _ffi.check(eng.lib.caelo_pipeline_create(eng.ctx, int(lanes), batch, int(max_points or eng.max_points), C.byref(h)))
-        self.h, self.lanes, self.batch = h, int(lanes), batch
+        _ffi.check(eng.lib.caelo_pipeline_create(eng.ctx, int(batch), int(buffers), int(max_points or eng.max_points), C.byref(h)))
+        self.h, self.batch, self.buffers = h, int(batch), int(buffers)
 
     def __del__(self):
         try:
@@ -139,12 +139,12 @@ class Pipeline:
             pass
 
     def stats(self):
-        """Host-side counters since the last call: jobs, us/job spent issuing, us/job waiting for a predecessor."""
+        """Host-side counters since the last call: jobs, us/frame the calling thread spent issuing launches, batches."""
         out = (C.c_int64 * 6)()
         _ffi.check(self.eng.lib.caelo_pipeline_stats(self.h, out))
         n = max(int(out[0]), 1)
-        return {"jobs": int(out[0]), "issue_us_per_frame": out[1] / n / 1e3, "wait_us_per_frame": out[2] / n / 1e3,
-                "lanes": int(out[3]), "encoder_busy_us": out[4] / 1e3, "encoder_span_us": out[5] / 1e3}
+        return {"jobs": int(out[0]), "issue_us_per_frame": out[1] / n / 1e3, "batches": int(out[2]), "batch": int(out[3]),
+                "buffers": int(out[4]), "streams": int(out[5])}
 
     def run(self, scans, rands=None, prev=None, dist_channels=5, exact_voxels=False, out=None, pairs=True, dedup=True):
         """scans: K device tensors [n,4] f32; rands: K device tensors of RANSAC draws ([1500,4] f64).
@@ -246,12 +246,12 @@ class Engine:
             t = self._wss[key] = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
         return t
 
-    def pipeline(self, lanes=6, batch=None):
-        """The native frame executor (caelo_pipeline) with `lanes` streams and `batch` frames per encoder launch
-        set, created once per configuration."""
-        key = ("pipeline", int(lanes), batch)
+    def pipeline(self, batch=4, buffers=3):
+        """The native frame executor (caelo_pipeline): `batch` frames per launch, `buffers` batches of patches in flight
+        between the front and the encoder; created once per configuration."""
+        key = ("pipeline", int(batch), int(buffers))
         if key not in self._maps:
-            self._maps[key] = Pipeline(self, lanes, batch)
+            self._maps[key] = Pipeline(self, batch, buffers)
         return self._maps[key]
 
     def voxmap(self, max_points=None, slot=0):

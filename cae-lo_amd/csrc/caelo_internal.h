@@ -82,7 +82,7 @@ struct caelo_voxmap {
     uint32_t *vfirst[3];
     uint32_t vmask[3];
     int32_t *counts;  // [16] device ints: [0..2] unique voxels per scale, [4],[5] lengths of list0/list1, [6] length of
-                      // sp_list, [7] ticket of k_vox_suspects
+                      // sp_list
     uint32_t *list0, *list1;  // slots of the occupied scale-0 / scale-1 bricks, in insertion order (fast path)
     // "Suspect" voxels of the fused build (voxel.hip, k_vox_points): scale-0 voxels holding a point whose own
     // int(x_/0.16), int(x_/0.64) differ from its scale-0 index >> 3, >> 5 (x_ within an ulp of a voxel face -- every
@@ -108,6 +108,73 @@ struct caelo_voxmap {
     int64_t scratch_bytes;
 };
 
+struct SuspectTables {
+    unsigned long long *sp_keys, *sb_keys;
+    uint32_t *sp_first, *sb_cnt;
+    uint4 *list;
+    uint32_t mask;
+};
+inline SuspectTables suspect_tables(const caelo_voxmap *m) {
+    return SuspectTables{m->sp_keys, m->sb_keys, m->sp_first, m->sb_cnt, m->sp_list, m->sp_mask};
+}
+
+// ---- a set of frames behind ONE launch ------------------------------------------------------------------------------
+// The front half of a frame (ring image, response, keypoints, voxel hash, patch gather) is ~15 short, latency-bound
+// kernels that leave most of the 256 CUs idle.  Every such kernel therefore takes a caelo_frame_set -- up to
+// CAELO_FB_MAX frames, blockIdx.z = frame -- so that a batch of frames costs the launches (and the tails, and the
+// single-workgroup stretches) of one.  The single-frame C-ABI entry points pass a set of one.
+#define CAELO_FB_MAX 8
+struct DedupScratch;
+struct caelo_frame_dev {
+    const float *pc;              // [n][pc_stride] f32
+    int64_t n;
+    int32_t pc_stride, dist_c;
+    float *ring;                  // [69][1800][5] (or the caller's image for the staged entry points)
+    int32_t *counter, *winner;
+    float *resp;                  // [64][1792][8]
+    unsigned long long *cand;
+    int32_t *cand_count;
+    int64_t *key_pixels;
+    float *key_pts, *valid;
+    int32_t *n_key;
+    uint8_t *flags;
+    int32_t *status;
+    int32_t kp_ld, valid_ld;
+    caelo_brick_table brick[3];
+    int32_t *counts;
+    uint32_t *list0, *list1;
+    SuspectTables sp;
+    unsigned long long *vkeys[3];  // exact path: voxel-level first-touch tables
+    uint32_t *vfirst[3];
+    uint32_t vmask0, vmask12;
+    unsigned long long *bits;     // bit-packed patches [1024][3][64] (+ dedup tables behind them)
+    DedupScratch *dd;
+};
+struct caelo_frame_set {
+    caelo_frame_dev f[CAELO_FB_MAX];
+    int32_t n;
+};
+static_assert(sizeof(caelo_frame_set) <= 3800, "caelo_frame_set must fit the kernel argument segment");
+void frame_dev_set_map(caelo_frame_dev &d, const caelo_voxmap *m);
+
+// the pair half (NN match + RANSAC + refit) of up to CAELO_FB_MAX frame pairs behind one launch each, blockIdx.z = pair
+struct caelo_pair_dev {
+    const float *f0, *f1;        // descriptors [k][ld]
+    const int32_t *n0, *n1;      // device key point counts (null = k_max)
+    const float *pc0, *pc1;      // key points [k][pld] (xyz first)
+    int64_t *pair_idx;
+    void *ws_match, *ws_ransac;
+    const double *rand;
+    caelo_pose_result *result;
+    uint8_t *mask;
+};
+struct caelo_pair_set {
+    caelo_pair_dev p[CAELO_FB_MAX];
+    int32_t n;
+};
+int match_set(const caelo_pair_set &ps, int ld0, int64_t k0_max, int ld1, int64_t k1_max, int dim, hipStream_t s);
+int ransac_set(const caelo_pair_set &ps, int pld0, int pld1, int64_t k1_max, hipStream_t s);
+
 // a (pointer, bytes, byte value) triple for the multi-buffer clear kernel (frame.hip)
 struct caelo_clear_item {
     void *ptr;
@@ -120,6 +187,7 @@ struct caelo_clear_list {
     int n;
 };
 int caelo_clear_many(const caelo_clear_list &list, hipStream_t s);
+int caelo_clear_many_set(const caelo_clear_list *lists, int n_frames, hipStream_t s);  // one launch, blockIdx.y = frame
 
 // internal launchers shared by the staged entry points and the fused caelo_extract (no clears inside)
 int ring_project_launch(const float *pc, int64_t n, float *ring, int32_t *counter, int32_t *winner, int32_t *status,
@@ -129,10 +197,18 @@ int ring_keypoints_launch(const float *ring, int ring_w, int ring_c, int dist_c,
                           const float *resp, unsigned long long *cand, int32_t *cand_count,
                           int64_t *key_pixels, float *key_pts, int kp_ld, float *valid, int valid_ld, int32_t *n_key,
                           int32_t *status, hipStream_t s);
+int ring_project_set(const caelo_frame_set &fs, hipStream_t s);
+int ring_respond_set(caelo_ctx *c, const caelo_frame_set &fs, int in_w, int in_c, hipStream_t s);
+int ring_keypoints_set(const caelo_frame_set &fs, int ring_w, int ring_c, int cnt_w, hipStream_t s);
 void vox_clear_items(caelo_voxmap *m, int level, caelo_clear_list &list);  // 0 brick keys only, 1 + scale-0 first-touch table, 2 everything
 // clear for a fused build: if the map holds nothing but the previous fused build, its listed bricks are wiped by a
 // kernel launched here (before the caller's clear list runs) and only the small scale-2 table + counters join the list
 int vox_clear_for_fast_build(caelo_voxmap *m, caelo_clear_list &list, hipStream_t s);
+int vox_clear_for_fast_build_set(caelo_voxmap *const *maps, int n, caelo_clear_list *lists, hipStream_t s);
+int vox_build_fast_set(caelo_voxmap *const *maps, const caelo_frame_set &fs, hipStream_t s);
+int vox_build_set(caelo_voxmap *const *maps, const caelo_frame_set &fs, bool track_order, hipStream_t s);
+int vox_patches_set(const caelo_frame_set &fs, int64_t k_max, bool check_counts, hipStream_t s);
+int dedup_set(const caelo_frame_set &fs, bool enabled, hipStream_t s);
 int vox_build_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, bool track_order, int32_t *status,
                      hipStream_t s);
 int vox_build_fast_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, int32_t *status, hipStream_t s);
@@ -216,7 +292,8 @@ struct caelo_extract_args {
     uint64_t *bits;  // bit-packed patches [1024][3][64]; null = inside ws (the pipeline points it into a batch buffer)
 };
 int extract_check(const caelo_extract_args &a);
-int extract_front_launch(const caelo_extract_args &a, hipStream_t s);   // everything up to the bit-packed patches
+int extract_front_launch(const caelo_extract_args &a, hipStream_t s);
+int extract_front_set(const caelo_extract_args *args, int n, hipStream_t s);  // n frames, the launches of one   // everything up to the bit-packed patches
 int extract_encode_launch(const caelo_extract_args &a, hipStream_t s);  // the four encoder kernels
 
 #define CAELO_KP_HIST_BINS 2048

@@ -28,7 +28,9 @@ void dedup_clear_item(void *scratch, caelo_clear_list &list) {
 // (the per-patch hash + table insert runs at the end of k_patches, voxel.hip: caelo_dedup_insert in caelo_internal.h)
 
 // one wavefront per patch: word-by-word comparison with the group's representative
-__global__ void __launch_bounds__(256) k_dd_verify(const unsigned long long *__restrict__ bits, DedupScratch *S) {
+__global__ void __launch_bounds__(256) k_dd_verify(const caelo_frame_set fs) {
+    const unsigned long long *__restrict__ bits = fs.f[blockIdx.z].bits;
+    DedupScratch *S = fs.f[blockIdx.z].dd;
     const int lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int r = (int)(S->table[S->pslot[p]] & 0xFFFFFFull);
@@ -38,7 +40,9 @@ __global__ void __launch_bounds__(256) k_dd_verify(const unsigned long long *__r
 }
 
 // one workgroup: the representatives in encoder order (scale 2, 1, 0; key point index within a scale)
-__global__ void __launch_bounds__(1024) k_dd_scan(const DedupScratch *S, caelo_dedup_tables *T, int identity) {
+__global__ void __launch_bounds__(1024) k_dd_scan(const caelo_frame_set fs, int identity) {
+    const DedupScratch *S = fs.f[blockIdx.z].dd;
+    caelo_dedup_tables *T = caelo_frame_tables((const uint64_t *)fs.f[blockIdx.z].bits);
     __shared__ int wsum[16];
     __shared__ int pos_of[CAELO_FRAME_PATCHES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -96,14 +100,19 @@ bool dedup_enabled(int mode) {
 }
 
 int dedup_launch(uint64_t *bits, void *scratch, bool enabled, hipStream_t s) {
-    DedupScratch *S = (DedupScratch *)scratch;
-    caelo_dedup_tables *T = caelo_frame_tables(bits);
-    const bool on = enabled;  // the caller asked dedup_enabled() and let k_patches fill the table
-    if (on) {
-        k_dd_verify<<<CAELO_FRAME_PATCHES / 4, 256, 0, s>>>((const unsigned long long *)bits, S);
+    caelo_frame_set fs = {};
+    fs.n = 1;
+    fs.f[0].bits = (unsigned long long *)bits;
+    fs.f[0].dd = (DedupScratch *)scratch;
+    return dedup_set(fs, enabled, s);
+}
+
+int dedup_set(const caelo_frame_set &fs, bool enabled, hipStream_t s) {
+    if (enabled) {  // the caller asked dedup_enabled() and let k_patches fill the tables
+        k_dd_verify<<<dim3(CAELO_FRAME_PATCHES / 4, 1, fs.n), 256, 0, s>>>(fs);
         CAELO_LAUNCH_CHECK();
     }
-    k_dd_scan<<<1, 1024, 0, s>>>(S, T, on ? 0 : 1);
+    k_dd_scan<<<dim3(1, 1, fs.n), 1024, 0, s>>>(fs, enabled ? 0 : 1);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }

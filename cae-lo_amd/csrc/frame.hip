@@ -17,6 +17,28 @@ struct ClearArgs {
     int n;
 };
 
+struct ClearSet {   // blockIdx.y = frame
+    uint4 *ptr[CAELO_FB_MAX][CAELO_CLEAR_MAX];
+    unsigned int end[CAELO_FB_MAX][CAELO_CLEAR_MAX];  // cumulative uint4 counts (< 2^32 x 16 B per frame)
+    uint32_t pattern[CAELO_FB_MAX][CAELO_CLEAR_MAX];
+    int n[CAELO_FB_MAX];
+};
+static_assert(sizeof(ClearSet) <= 3800, "ClearSet must fit the kernel argument segment");
+
+__global__ void __launch_bounds__(256) k_clear_set(const ClearSet a) {
+    const int f = blockIdx.y;
+    const int n = a.n[f];
+    if (n == 0) return;
+    const unsigned int total = a.end[f][n - 1];
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int r = 0;
+        while (i >= a.end[f][r]) ++r;
+        const unsigned int local = i - (r ? a.end[f][r - 1] : 0u);
+        const uint32_t p = a.pattern[f][r];
+        a.ptr[f][r][local] = make_uint4(p, p, p, p);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_clear_many(ClearArgs a) {
     const unsigned long long total = a.end[a.n - 1];
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -52,6 +74,37 @@ int caelo_clear_many(const caelo_clear_list &list, hipStream_t s) {
     unsigned long long blocks = (cum + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride: 16 workgroups per CU
     k_clear_many<<<(unsigned)blocks, 256, 0, s>>>(a);
+    CAELO_LAUNCH_CHECK();
+    return CAELO_OK;
+}
+
+int caelo_clear_many_set(const caelo_clear_list *lists, int n_frames, hipStream_t s) {
+    if (n_frames == 1) return caelo_clear_many(lists[0], s);
+    ClearSet a;
+    unsigned long long most = 0;
+    for (int f = 0; f < n_frames; ++f) {
+        unsigned long long cum = 0;
+        a.n[f] = 0;
+        for (int i = 0; i < lists[f].n; ++i) {
+            const caelo_clear_item &it = lists[f].item[i];
+            if (it.bytes == 0) continue;
+            if (((uintptr_t)it.ptr & 15u) || (it.bytes & 15u)) {
+                CAELO_HIP(hipMemsetAsync(it.ptr, (int)(it.pattern & 0xFF), it.bytes, s));
+                continue;
+            }
+            cum += it.bytes / 16;
+            a.ptr[f][a.n[f]] = (uint4 *)it.ptr;
+            a.end[f][a.n[f]] = (unsigned int)cum;
+            a.pattern[f][a.n[f]] = it.pattern;
+            ++a.n[f];
+        }
+        if (cum >= 0xFFFFFFFFull) { caelo_set_error("caelo_clear_many_set: region too large"); return CAELO_ERR_ARG; }
+        most = cum > most ? cum : most;
+    }
+    if (most == 0) return CAELO_OK;
+    unsigned long long blocks = (most + 255) / 256;
+    if (blocks > 2048) blocks = 2048;  // grid-stride
+    k_clear_set<<<dim3((unsigned)blocks, n_frames), 256, 0, s>>>(a);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }
@@ -103,47 +156,56 @@ int extract_check(const caelo_extract_args &a) {
     return CAELO_OK;
 }
 
-int extract_front_launch(const caelo_extract_args &a, hipStream_t s) {
+int extract_front_launch(const caelo_extract_args &a, hipStream_t s) { return extract_front_set(&a, 1, s); }
+
+// The front halves of n frames (n <= CAELO_FB_MAX, one mode for all) with the launches of one: every kernel takes the
+// frame set and runs frame blockIdx.z.  Each frame brings its own voxel map and workspace.
+int extract_front_set(const caelo_extract_args *args, int n, hipStream_t s) {
+    CAELO_REQUIRE(n >= 1 && n <= CAELO_FB_MAX, "bad frame count");
     const ExtractLayout L = extract_layout();
-    char *ws = (char *)a.ws;
-    float *ring = (float *)(ws + L.ring);
-    int32_t *counter = (int32_t *)(ws + L.counter);
-    int32_t *winner = (int32_t *)(ws + L.winner);
-    float *resp = (float *)(ws + L.resp);
-    unsigned long long *cand = (unsigned long long *)(ws + L.cand);
-    int32_t *cand_count = (int32_t *)(ws + L.cand_count);
-    uint64_t *bits = a.bits ? a.bits : (uint64_t *)(ws + L.bits);
-    // ---- one clear for everything the frame accumulates into
-    caelo_clear_list cl;
-    cl.n = 0;
-    cl.item[cl.n++] = {winner, L.counter - L.winner, 0xFFFFFFFFu};
-    cl.item[cl.n++] = {counter, L.ring - L.counter, 0u};  // counter | cand_count
-    cl.item[cl.n++] = {a.status, 16, 0u};  // status is int32[4], 16-byte aligned (word 0 carries the bits)
-    const bool exact_vox = (a.mode & CAELO_EXTRACT_EXACT_VOXELS) != 0;
+    const bool exact_vox = (args[0].mode & CAELO_EXTRACT_EXACT_VOXELS) != 0;
+    const bool dd = dedup_enabled(args[0].mode);
+    caelo_frame_set fs = {};
+    fs.n = n;
+    caelo_clear_list cl[CAELO_FB_MAX];
+    caelo_voxmap *maps[CAELO_FB_MAX];
+    for (int i = 0; i < n; ++i) {
+        const caelo_extract_args &a = args[i];
+        CAELO_REQUIRE(a.mode == args[0].mode, "the frames of a set share one mode");
+        char *ws = (char *)a.ws;
+        caelo_frame_dev &d = fs.f[i];
+        maps[i] = a.map;
+        frame_dev_set_map(d, a.map);
+        d.pc = a.pc; d.n = a.n; d.pc_stride = 4; d.dist_c = a.dist_channels;
+        d.ring = (float *)(ws + L.ring); d.counter = (int32_t *)(ws + L.counter); d.winner = (int32_t *)(ws + L.winner);
+        d.resp = (float *)(ws + L.resp); d.cand = (unsigned long long *)(ws + L.cand); d.cand_count = (int32_t *)(ws + L.cand_count);
+        d.key_pixels = a.key_pixels; d.key_pts = a.key_pts; d.kp_ld = a.kp_ld; d.valid = a.valid; d.valid_ld = a.valid_ld;
+        d.n_key = a.n_key; d.flags = a.flags; d.status = a.status;
+        d.bits = (unsigned long long *)(a.bits ? a.bits : (uint64_t *)(ws + L.bits));
+        d.dd = dd ? (DedupScratch *)(ws + L.dd) : nullptr;
+        // ---- one clear for everything the frame accumulates into
+        cl[i].n = 0;
+        cl[i].item[cl[i].n++] = {d.winner, L.counter - L.winner, 0xFFFFFFFFu};
+        cl[i].item[cl[i].n++] = {d.counter, L.ring - L.counter, 0u};  // counter | cand_count
+        cl[i].item[cl[i].n++] = {a.status, 16, 0u};  // status is int32[4], 16-byte aligned (word 0 carries the bits)
+        if (exact_vox) vox_clear_items(a.map, 1, cl[i]);
+        dedup_clear_item(ws + L.dd, cl[i]);
+    }
     int rc = CAELO_OK;
-    if (exact_vox) vox_clear_items(a.map, 1, cl);
-    else if ((rc = vox_clear_for_fast_build(a.map, cl, s))) return rc;  // wipes the previous frame's bricks only
-    dedup_clear_item(ws + L.dd, cl);
-    rc = caelo_clear_many(cl, s);
-    if (rc) return rc;
+    if (!exact_vox && (rc = vox_clear_for_fast_build_set(maps, n, cl, s))) return rc;  // wipes the previous frames' bricks only
+    if ((rc = caelo_clear_many_set(cl, n, s))) return rc;
     // ---- ring image, response, keypoints
-    if ((rc = ring_project_launch(a.pc, a.n, ring, counter, winner, a.status, s))) return rc;
-    if ((rc = ring_respond_launch(a.ctx, ring, CAELO_RING_W, CAELO_RING_C, resp, s))) return rc;
-    if ((rc = ring_keypoints_launch(ring, CAELO_RING_W, CAELO_RING_C, a.dist_channels, counter, CAELO_RING_W, resp, cand,
-                                    cand_count, a.key_pixels, a.key_pts, a.kp_ld, a.valid, a.valid_ld, a.n_key,
-                                    a.status, s)))
-        return rc;
+    if ((rc = ring_project_set(fs, s))) return rc;
+    if ((rc = ring_respond_set(args[0].ctx, fs, CAELO_RING_W, CAELO_RING_C, s))) return rc;
+    if ((rc = ring_keypoints_set(fs, CAELO_RING_W, CAELO_RING_C, CAELO_RING_W, s))) return rc;
     // ---- voxel map, patches
-    if (exact_vox) rc = vox_build_launch(a.map, a.pc, a.n, 4, false, a.status, s);
-    else rc = vox_build_fast_launch(a.map, a.pc, a.n, 4, a.status, s);
+    if (exact_vox) rc = vox_build_set(maps, fs, false, s);
+    else rc = vox_build_fast_set(maps, fs, s);
     if (rc) return rc;
     // equal patches are encoded once (dedup.hip): k_patches enters every patch into the hash table, the tables land
     // behind the frame's bits
-    const bool dd = dedup_enabled(a.mode);
-    if ((rc = vox_patches_launch(a.map, a.key_pts, a.kp_ld, CAELO_MAX_KEYPTS, a.n_key, bits, a.flags, a.status, true, s,
-                                 dd ? ws + L.dd : nullptr)))
-        return rc;
-    return dedup_launch(bits, ws + L.dd, dd, s);
+    if ((rc = vox_patches_set(fs, CAELO_MAX_KEYPTS, true, s))) return rc;
+    return dedup_set(fs, dd, s);
 }
 
 int extract_encode_launch(const caelo_extract_args &a, hipStream_t s) {

@@ -45,11 +45,26 @@ struct MmPartial {
     double L1, L2, L3, U;
     int I1, I2;
 };
-// Cross-workgroup hand-off: the partial results go out as agent-scope atomic stores (write-through, sc1) and come
-// back as agent-scope atomic loads (cdna_hip_programming.md G16, "8-B agent atomics both sides"); on top of that the
-// ticket is a release / acquire pair (__threadfence() before it in the publishing wave, an ACQ_REL read-modify-write,
-// __threadfence() in the last arriver), so the scheme is correct by the HIP memory model, not only by how gfx950's
-// caches happen to behave.  The fences cost nothing measurable at 256 workgroups.
+// Cross-workgroup hand-off: the partial results go out as agent-scope atomic stores (write-through to the coherence
+// point, sc1) and come back as agent-scope atomic loads (cdna_hip_programming.md G16, "8-B agent atomics both sides");
+// the publishing wave waits for its stores to complete (s_waitcnt vmcnt(0)) before the workgroup takes its ticket, an
+// agent-scope read-modify-write.  Every shared location is touched by agent-scope atomics only, so no access can be
+// served from a non-coherent cache.  CAELO_XWG_FENCES=1 builds the formal release / acquire version instead
+// (__threadfence() around an ACQ_REL ticket): on gfx950 an agent-scope release is an L2 write-back walk and an acquire an
+// invalidate, PER WORKGROUP -- measured 18.7 -> 33 us per 1024 x 1024 match for bit-identical results
+// (tests/test_gpu_parity.py::test_match_ransac_and_pipeline_are_deterministic_under_load runs either build).
+#ifndef CAELO_XWG_FENCES
+#define CAELO_XWG_FENCES 0
+#endif
+#if CAELO_XWG_FENCES
+#define XWG_RELEASE() __threadfence()
+#define XWG_ACQUIRE() __threadfence()
+#define XWG_TICKET(PTR) __hip_atomic_fetch_add((PTR), 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define XWG_RELEASE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define XWG_ACQUIRE() asm volatile("" ::: "memory")
+#define XWG_TICKET(PTR) __hip_atomic_fetch_add((PTR), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
 __device__ inline void mm_publish(MmPartial *dst, const MmPartial &p) {
     unsigned long long *d = (unsigned long long *)dst;
     __hip_atomic_store(d + 0, (unsigned long long)__double_as_longlong(p.L1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -113,11 +128,16 @@ __device__ inline void load_frag(const float *row, bool valid, int g, int dim, d
 }
 
 template <bool VEC>
-__global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const float *__restrict__ f0, int ld0, int64_t k0_max,
-                                                              const int32_t *n0p, const float *__restrict__ f1, int ld1,
-                                                              int64_t k1_max, const int32_t *n1p, int dim,
-                                                              int64_t *__restrict__ pair_idx, int32_t *tickets,
-                                                              MmPartial *parts, int32_t *stats) {
+__global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_set ps, int ld0, int64_t k0_max, int ld1,
+                                                              int64_t k1_max, int dim, size_t tbytes) {
+    const caelo_pair_dev &P = ps.p[blockIdx.z];
+    const float *__restrict__ f0 = P.f0, *__restrict__ f1 = P.f1;
+    const int32_t *n0p = P.n0, *n1p = P.n1;
+    int64_t *__restrict__ pair_idx = P.pair_idx;
+    // workspace layout: stats [256 B] | tickets | partial results (see match_set)
+    int32_t *stats = (int32_t *)P.ws_match;
+    int32_t *tickets = (int32_t *)((char *)P.ws_match + 256);
+    MmPartial *parts = (MmPartial *)((char *)P.ws_match + 256 + tbytes);
     __shared__ double sL[3][MM_WAVES][16];
     __shared__ int sI[2][MM_WAVES][16];
     __shared__ double sU[MM_WAVES][16];
@@ -214,16 +234,16 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const float *__res
             pt.L1 = L1; pt.L2 = L2; pt.L3 = L3; pt.U = U; pt.I1 = I1; pt.I2 = I2;
             mm_publish(&mine[x], pt);
         }
-        __threadfence();  // release: the partial results are visible device-wide before the ticket is taken
+        XWG_RELEASE();  // the partial results have reached the coherence point before the ticket is taken
     }
     __syncthreads();
     if (tid == 0) {
-        s_last = __hip_atomic_fetch_add(&tickets[ctile], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == MM_RS - 1;
+        s_last = XWG_TICKET(&tickets[ctile]) == MM_RS - 1;
         if (s_last) tickets[ctile] = 0;  // self-cleaning: the workspace is ready for the next call, no memset launch
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();  // acquire: the other slices' partial results
+    XWG_ACQUIRE();
     // ---- merge the slices and certify: one thread per column
     if (tid < 16) {
         const int j = j0 + tid;
@@ -283,21 +303,26 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const float *__res
 CAELO_API int caelo_match(caelo_ctx *c, const float *f0, int ld0, int64_t k0_max, const int32_t *n0, const float *f1,
                           int ld1, int64_t k1_max, const int32_t *n1, int dim, int64_t *pair_idx, void *ws, void *stream) {
     CAELO_REQUIRE(c && f0 && f1 && pair_idx && ws, "null argument");
+    caelo_pair_set ps = {};
+    ps.n = 1;
+    ps.p[0].f0 = f0; ps.p[0].n0 = n0; ps.p[0].f1 = f1; ps.p[0].n1 = n1; ps.p[0].pair_idx = pair_idx; ps.p[0].ws_match = ws;
+    return match_set(ps, ld0, k0_max, ld1, k1_max, dim, caelo_stream(stream));
+}
+
+int match_set(const caelo_pair_set &ps, int ld0, int64_t k0_max, int ld1, int64_t k1_max, int dim, hipStream_t s) {
+    CAELO_REQUIRE(ps.n >= 1 && ps.n <= CAELO_FB_MAX, "bad pair count");
     CAELO_REQUIRE(dim > 0 && dim <= MT_MAXDIM && ld0 >= dim && ld1 >= dim && k0_max > 0 && k1_max > 0, "bad shape");
-    hipStream_t s = caelo_stream(stream);
     const int64_t tiles = (k1_max + 15) / 16;
     // layout: stats [256 B] | tickets | partial results.  The ticket region depends on k1_max: a workspace belongs to ONE
     // (stream, k1_max) -- a call with another k1_max would find the partial results of this one where its tickets live
-    int32_t *stats = (int32_t *)ws;  // [0] columns re-scanned exactly, [1] columns decided between two rows
-    int32_t *tickets = (int32_t *)((char *)ws + 256);
     const size_t tbytes = (size_t)((tiles * 4 + 255) / 256) * 256;
-    MmPartial *parts = (MmPartial *)((char *)ws + 256 + tbytes);
-    const bool vec = (dim % 4 == 0) && (ld0 % 4 == 0) && (ld1 % 4 == 0) && (((uintptr_t)f0 | (uintptr_t)f1) & 15u) == 0;
-    dim3 grid((unsigned)tiles, MM_RS);
+    bool vec = (dim % 4 == 0) && (ld0 % 4 == 0) && (ld1 % 4 == 0);
+    for (int i = 0; i < ps.n; ++i) vec = vec && (((uintptr_t)ps.p[i].f0 | (uintptr_t)ps.p[i].f1) & 15u) == 0;
+    dim3 grid((unsigned)tiles, MM_RS, ps.n);
     if (vec)
-        k_match_mfma<true><<<grid, 64 * MM_WAVES, 0, s>>>(f0, ld0, k0_max, n0, f1, ld1, k1_max, n1, dim, pair_idx, tickets, parts, stats);
+        k_match_mfma<true><<<grid, 64 * MM_WAVES, 0, s>>>(ps, ld0, k0_max, ld1, k1_max, dim, tbytes);
     else
-        k_match_mfma<false><<<grid, 64 * MM_WAVES, 0, s>>>(f0, ld0, k0_max, n0, f1, ld1, k1_max, n1, dim, pair_idx, tickets, parts, stats);
+        k_match_mfma<false><<<grid, 64 * MM_WAVES, 0, s>>>(ps, ld0, k0_max, ld1, k1_max, dim, tbytes);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }
@@ -629,19 +654,30 @@ __device__ inline void sample_hypothesis(const float *P0, int l0, const int64_t 
 //   2. one wavefront per hypothesis: Kabsch on the 4-sample, residuals, ballot + popcount inlier count;
 //   3. the last workgroup to arrive (one ticket per workgroup; counts published with write-through
 //      stores, read with agent-scope loads) replays the sequential accept rules in parallel;
-//   4. if the level succeeded -- or it was the last one -- the same workgroup finishes the pose in place:
-//      inlier mask of the winner, refit over all inliers (Match.py:273-282), result record.  Later
-//      launches see `finished` and return at once.
+//   4. if the level succeeded -- or it was the last one -- the same workgroup records the winner (recomputed from its
+//      sample: R_star, T_star, threshold, iteration count).  Later level launches see `finished` and return at once.
+// k_ransac_finish (one workgroup per pair, after the three level launches) writes the inlier mask of the winner and
+// refits over all inliers (Match.py:273-282).  Round 1 did that inside the finishing workgroup of the level kernel,
+// from the pairs it had staged in LDS; under concurrent streams ~1 call in 3 000 then stored 64-element runs of
+// constant 0 / 1 from some of its wavefronts although the inlier COUNT summed from the same registers was right
+// (tools/stress_mask.py: sentinel-filled buffer, D2H cross-check, exactly one replay per call counted) -- the
+// "3 of 41 suite runs" of round 1.  The hand-off protocol was not involved.  A kernel of its own that reads the
+// pairs from global memory shows 0 mismatches in 72 000 frames; DESIGN.md 4.4 has the measurements.
 #define RE_WAVES 4
 #define RE_LDS_PAIRS 1024
-__global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_level(const float *__restrict__ pc0, int ld0,
-                                                                const float *__restrict__ pc1, int ld1,
-                                                                const int64_t *__restrict__ pair_idx, int64_t k1_max,
-                                                                const int32_t *n1p, const double *__restrict__ rnd, int level,
-                                                                RansacWs *ws, caelo_pose_result *res, uint8_t *mask) {
+
+template <int level>
+__global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_level(const caelo_pair_set ps, int ld0, int ld1, int64_t k1_max) {
+    const caelo_pair_dev &P = ps.p[blockIdx.z];
+    const float *__restrict__ pc0 = P.pc0, *__restrict__ pc1 = P.pc1;
+    const int64_t *__restrict__ pair_idx = P.pair_idx;
+    const int32_t *n1p = P.n1;
+    const double *__restrict__ rnd = P.rand;
+    RansacWs *ws = (RansacWs *)P.ws_ransac;
+    caelo_pose_result *res = P.result;
     __shared__ float sP0[RE_LDS_PAIRS * 3], sP1[RE_LDS_PAIRS * 3];
     __shared__ int s_counts[4];
-    __shared__ int s_last, s_best, s_success, s_nin;
+    __shared__ int s_last, s_best, s_success;
     __shared__ float Rs[9], Ts[3];
     if (__hip_atomic_load(&ws->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
         // an earlier level completed the record.  In the last launch every workgroup passes through here, so the
@@ -685,24 +721,24 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_level(const float *__r
             cnt += __popcll(__ballot(in));
         }
         if (lane == 0) {
-            // read by the last workgroup of this launch: agent-scope store, released by the fence before the arrival
-            // ticket (an ACQ_REL read-modify-write); the reader fences after it and uses agent-scope loads
+            // read by the last workgroup of this launch: agent-scope store, complete before the arrival ticket; the
+            // reader uses agent-scope loads (see XWG_* above)
             __hip_atomic_store(&ws->counts[trial], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence();
+            XWG_RELEASE();
         }
     }
     __syncthreads();
     if (tid == 0) {
-        s_last = __hip_atomic_fetch_add(&ws->arrived[level], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == CAELO_RANSAC_MAX_TRIALS / RE_WAVES - 1;
+        s_last = XWG_TICKET(&ws->arrived[level]) == CAELO_RANSAC_MAX_TRIALS / RE_WAVES - 1;
         if (s_last) ws->arrived[level] = 0;
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
+    XWG_ACQUIRE();
     // ---- 3. accept rules
     if (tid < 64) ransac_replay(N, level, ws, s_counts);
     __syncthreads();
-    if (tid == 0) { s_success = ws->success; s_best = ws->best_trial; s_nin = 0; }
+    if (tid == 0) { s_success = ws->success; s_best = ws->best_trial; }
     __syncthreads();
     const int success = s_success, best = s_best;
     if (!success && level < CAELO_RANSAC_LEVELS - 1) return;  // escalate: the next launch doubles the threshold
@@ -714,49 +750,96 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_level(const float *__r
         if (tid < 3) Ts[tid] = T[tid];
     }
     __syncthreads();
-    int local = 0;
-    for (int i = tid; i < (int)k1_max; i += 64 * RE_WAVES) {
-        uint8_t in = 0;
-        if (i < N && best >= 0) {
-            const float *a = P0 + (size_t)l0 * (pidx ? pidx[i] : i);
-            const float *b = P1 + (size_t)l1 * i;
-            in = residual(Rs, Ts, a[0], a[1], a[2], b[0], b[1], b[2]) < thr;
-        }
-        mask[i] = in;
-        local += in;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
-    if (lane == 0) atomicAdd(&s_nin, local);
-    __syncthreads();
-    if (tid < 9) { res->R_ransac[tid] = Rs[tid]; res->R[tid] = Rs[tid]; }
-    if (tid < 3) { res->T_ransac[tid] = Ts[tid]; res->T[tid] = Ts[tid]; }
+    if (tid < 9) res->R_ransac[tid] = Rs[tid];
+    if (tid < 3) res->T_ransac[tid] = Ts[tid];
     if (tid == 0) {
         res->threshold = thr;
         res->success = success;
         res->iterations = ws->iterations;
-        res->n_inliers = s_nin;
         res->best_trial = best >= 0 ? level * CAELO_RANSAC_MAX_TRIALS + best : -1;
         res->n_pairs = N;
         if (level < CAELO_RANSAC_LEVELS - 1)  // the last level has no later launch to stop
             __hip_atomic_store(&ws->finished, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// After the three level launches: the inlier mask of the winning hypothesis (Match.py:193-194 with R_star, T_star and
+// the final threshold), the inlier count and the refit over all inliers (Match.py:273-282).  One workgroup per pair.
+__global__ void __launch_bounds__(256) k_ransac_finish(const caelo_pair_set ps, int ld0, int ld1, int64_t k1_max) {
+    const caelo_pair_dev &P = ps.p[blockIdx.z];
+    const float *__restrict__ pc0 = P.pc0, *__restrict__ pc1 = P.pc1;
+    const int64_t *__restrict__ pair_idx = P.pair_idx;
+    caelo_pose_result *res = P.result;
+    uint8_t *mask = P.mask;
+    __shared__ float Rs[9], Ts[3];
+    __shared__ int s_nin;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int N = P.n1 ? min(max(*P.n1, 0), (int)k1_max) : (int)k1_max;
+    if (tid < 9) Rs[tid] = res->R_ransac[tid];
+    if (tid < 3) Ts[tid] = res->T_ransac[tid];
+    if (tid == 0) s_nin = 0;
     __syncthreads();
-    if (s_nin > 0) fit_block(P0, l0, pidx, P1, l1, mask, N, res->R, res->T, nullptr);  // :277-282
+    const float thr = res->threshold;
+    const bool have = res->best_trial >= 0;
+    int local = 0;
+    // four consecutive pairs per thread, one aligned 32-bit store: the whole mask row goes out as full dwords
+    const bool word_ok = (((uintptr_t)mask) & 3u) == 0;
+    for (int i0 = tid * 4; i0 < (int)k1_max; i0 += 4 * 256) {
+        unsigned int packed = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q;
+            unsigned int in = 0;
+            if (i < N && have) {
+                const float *a = pc0 + (size_t)ld0 * pair_idx[i];
+                const float *b = pc1 + (size_t)ld1 * i;
+                in = residual(Rs, Ts, a[0], a[1], a[2], b[0], b[1], b[2]) < thr ? 1u : 0u;
+            }
+            packed |= in << (8 * q);
+            local += (int)in;
+        }
+        if (word_ok && i0 + 3 < (int)k1_max) *(unsigned int *)(mask + i0) = packed;
+        else
+            for (int q = 0; q < 4 && i0 + q < (int)k1_max; ++q) mask[i0 + q] = (uint8_t)((packed >> (8 * q)) & 1u);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if (lane == 0) atomicAdd(&s_nin, local);
+    __syncthreads();
+    if (tid < 9) res->R[tid] = Rs[tid];
+    if (tid < 3) res->T[tid] = Ts[tid];
+    if (tid == 0) res->n_inliers = s_nin;
+    __syncthreads();
+    if (s_nin > 0) fit_block(pc0, ld0, pair_idx, pc1, ld1, mask, N, res->R, res->T, nullptr);  // :277-282
 }
 
 CAELO_API int caelo_ransac(caelo_ctx *c, const float *pc0, int ld0, const float *pc1, int ld1, const int64_t *pair_idx,
                            int64_t k1_max, const int32_t *n1, const double *rnd, caelo_pose_result *result,
                            uint8_t *inlier_mask, void *wsv, void *stream) {
     CAELO_REQUIRE(c && pc0 && pc1 && pair_idx && rnd && result && inlier_mask && wsv, "null argument");
+    caelo_pair_set ps = {};
+    ps.n = 1;
+    caelo_pair_dev &p = ps.p[0];
+    p.pc0 = pc0; p.pc1 = pc1; p.pair_idx = const_cast<int64_t *>(pair_idx); p.n1 = n1; p.rand = rnd; p.result = result;
+    p.mask = inlier_mask; p.ws_ransac = wsv;
+    return ransac_set(ps, ld0, ld1, k1_max, caelo_stream(stream));
+}
+
+int ransac_set(const caelo_pair_set &ps, int ld0, int ld1, int64_t k1_max, hipStream_t s) {
+    CAELO_REQUIRE(ps.n >= 1 && ps.n <= CAELO_FB_MAX, "bad pair count");
     CAELO_REQUIRE(k1_max > 0 && ld0 >= 3 && ld1 >= 3, "bad shape");
-    hipStream_t s = caelo_stream(stream);
-    RansacWs *ws = (RansacWs *)wsv;
-    for (int level = 0; level < CAELO_RANSAC_LEVELS; ++level) {
-        k_ransac_level<<<CAELO_RANSAC_MAX_TRIALS / RE_WAVES, 64 * RE_WAVES, 0, s>>>(pc0, ld0, pc1, ld1, pair_idx, k1_max, n1, rnd,
-                                                                                    level, ws, result, inlier_mask);
-        CAELO_LAUNCH_CHECK();
-    }
+    // the threshold level is a template parameter, not a kernel argument: the three launches then have IDENTICAL
+    // argument blocks (see DESIGN.md 4.4 for the stale-argument observation that motivated this)
+    const dim3 grid(CAELO_RANSAC_MAX_TRIALS / RE_WAVES, 1, ps.n);
+    static_assert(CAELO_RANSAC_LEVELS == 3, "one instantiation per threshold level");
+    k_ransac_level<0><<<grid, 64 * RE_WAVES, 0, s>>>(ps, ld0, ld1, k1_max);
+    CAELO_LAUNCH_CHECK();
+    k_ransac_level<1><<<grid, 64 * RE_WAVES, 0, s>>>(ps, ld0, ld1, k1_max);
+    CAELO_LAUNCH_CHECK();
+    k_ransac_level<2><<<grid, 64 * RE_WAVES, 0, s>>>(ps, ld0, ld1, k1_max);
+    CAELO_LAUNCH_CHECK();
+    k_ransac_finish<<<dim3(1, 1, ps.n), 256, 0, s>>>(ps, ld0, ld1, k1_max);
+    CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }
 

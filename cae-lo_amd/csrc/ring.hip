@@ -73,11 +73,13 @@ struct ProjConst {
     double pi, az_res, v_res, v_off;
 };
 
-__global__ void __launch_bounds__(256) k_project_points(const float4 *__restrict__ pc, int64_t n, int32_t *winner,
-                                                        int32_t *counter, int32_t *status, ProjConst k) {
+// every kernel below: blockIdx.z = frame of the set (caelo_internal.h)
+__global__ void __launch_bounds__(256) k_project_points(const caelo_frame_set fs, ProjConst k) {
+    const caelo_frame_dev &F = fs.f[blockIdx.z];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = pc[i];
+    if (i >= F.n) return;
+    int32_t *const winner = F.winner, *const counter = F.counter, *const status = F.status;
+    const float4 p = ((const float4 *)F.pc)[i];
     // :77 LA.norm axis=1 in f32: squares, sequential sum, sqrt
     float s = __fmul_rn(p.x, p.x);
     s = __fadd_rn(s, __fmul_rn(p.y, p.y));
@@ -97,8 +99,11 @@ __global__ void __launch_bounds__(256) k_project_points(const float4 *__restrict
     atomicAdd(&counter[pix], 1);                                                      // :93
 }
 
-__global__ void __launch_bounds__(256) k_ring_fill(const float4 *__restrict__ pc, const int32_t *__restrict__ winner,
-                                                   float *__restrict__ ring) {
+__global__ void __launch_bounds__(256) k_ring_fill(const caelo_frame_set fs) {
+    const caelo_frame_dev &F = fs.f[blockIdx.z];
+    const float4 *__restrict__ pc = (const float4 *)F.pc;
+    const int32_t *__restrict__ winner = F.winner;
+    float *__restrict__ ring = F.ring;
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= CAELO_RING_H * CAELO_RING_W) return;
     const int w = winner[pix];
@@ -115,9 +120,23 @@ __global__ void __launch_bounds__(256) k_ring_fill(const float4 *__restrict__ pc
     for (int c = 0; c < 5; ++c) o[c] = v[c];
 }
 
+static int64_t set_max_points(const caelo_frame_set &fs) {
+    int64_t n = 0;
+    for (int i = 0; i < fs.n; ++i) n = fs.f[i].n > n ? fs.f[i].n : n;
+    return n;
+}
+
 int ring_project_launch(const float *pc, int64_t n, float *ring, int32_t *counter, int32_t *winner_ws, int32_t *status,
                         hipStream_t s) {
+    caelo_frame_set fs = {};
+    fs.n = 1;
+    fs.f[0].pc = pc; fs.f[0].n = n; fs.f[0].ring = ring; fs.f[0].counter = counter; fs.f[0].winner = winner_ws; fs.f[0].status = status;
+    return ring_project_set(fs, s);
+}
+
+int ring_project_set(const caelo_frame_set &fs, hipStream_t s) {
     const int npix = CAELO_RING_H * CAELO_RING_W;
+    const int64_t n = set_max_points(fs);
     ProjConst k;
     k.pi = 3.14159265358979323846;
     const double d2r = k.pi / 180.0;                        // SphericalRing.py:28
@@ -125,9 +144,9 @@ int ring_project_launch(const float *pc, int64_t n, float *ring, int32_t *counte
     const double vdown = -24.8 * d2r, vup = 2.0 * d2r;      // :49-50
     k.v_res = (vup - vdown) / (64 - 1);                     // :51
     k.v_off = -vdown / k.v_res;                             // :52
-    k_project_points<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((const float4 *)pc, n, winner_ws, counter, status, k);
+    k_project_points<<<dim3((unsigned)((n + 255) / 256), 1, fs.n), 256, 0, s>>>(fs, k);
     CAELO_LAUNCH_CHECK();
-    k_ring_fill<<<(npix + 255) / 256, 256, 0, s>>>((const float4 *)pc, winner_ws, ring);
+    k_ring_fill<<<dim3((npix + 255) / 256, 1, fs.n), 256, 0, s>>>(fs);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }
@@ -153,8 +172,9 @@ CAELO_API int caelo_project(caelo_ctx *c, const float *pc, int64_t n, float *rin
 // response image -- and therefore the keypoint indices -- are bit-identical to the oracle's.
 // Weights are indexed uniformly across the wave -> scalar loads.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_respond(const float *__restrict__ in, int in_w, int in_c,
-                                                 const float *__restrict__ wts, float *__restrict__ resp) {
+__global__ void __launch_bounds__(256) k_respond(const caelo_frame_set fs, int in_w, int in_c, const float *__restrict__ wts) {
+    const float *__restrict__ in = fs.f[blockIdx.z].ring;
+    float *__restrict__ resp = fs.f[blockIdx.z].resp;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= CAELO_NET_W) return;
@@ -196,8 +216,15 @@ __global__ void __launch_bounds__(256) k_respond(const float *__restrict__ in, i
 }
 
 int ring_respond_launch(caelo_ctx *c, const float *in, int in_w, int in_c, float *resp, hipStream_t s) {
-    dim3 grid((CAELO_NET_W + 255) / 256, CAELO_NET_H);
-    k_respond<<<grid, 256, 0, s>>>(in, in_w, in_c, c->resp_w, resp);
+    caelo_frame_set fs = {};
+    fs.n = 1;
+    fs.f[0].ring = const_cast<float *>(in); fs.f[0].resp = resp;
+    return ring_respond_set(c, fs, in_w, in_c, s);
+}
+
+int ring_respond_set(caelo_ctx *c, const caelo_frame_set &fs, int in_w, int in_c, hipStream_t s) {
+    dim3 grid((CAELO_NET_W + 255) / 256, CAELO_NET_H, fs.n);
+    k_respond<<<grid, 256, 0, s>>>(fs, in_w, in_c, c->resp_w);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }
@@ -231,10 +258,14 @@ __device__ __host__ inline unsigned int kp_bin(unsigned int score_bits) {
 #define KS_HR (KS_ROWS + 4)
 #define KS_HC (KS_COLS + 4)
 
-__global__ void __launch_bounds__(256) k_kp_score(const float *__restrict__ ring, int ring_w, int ring_c, int dist_c,
-                                                  const int32_t *__restrict__ counter, int cnt_w,
-                                                  const float *__restrict__ resp, unsigned long long *__restrict__ cand,
-                                                  int32_t *cand_count) {
+__global__ void __launch_bounds__(256) k_kp_score(const caelo_frame_set fs, int ring_w, int ring_c, int cnt_w) {
+    const caelo_frame_dev &F = fs.f[blockIdx.z];
+    const float *__restrict__ ring = F.ring;
+    const int dist_c = F.dist_c;
+    const int32_t *__restrict__ counter = F.counter;
+    const float *__restrict__ resp = F.resp;
+    unsigned long long *__restrict__ cand = F.cand;
+    int32_t *cand_count = F.cand_count;
     __shared__ float4 sR[KS_HR * KS_HC * 2];
     __shared__ unsigned char sOcc[KS_HR * KS_HC];
     const int tid = threadIdx.x;
@@ -318,7 +349,7 @@ __global__ void __launch_bounds__(256) k_kp_score(const float *__restrict__ ring
 
 // phase timestamps of the last k_kp_select launch (wall_clock64, 100 MHz), read by caelo_debug_read
 __device__ unsigned long long g_sel_stamp[16];
-#define SEL_STAMP(i) do { if (threadIdx.x == 0) g_sel_stamp[i] = wall_clock64(); } while (0)
+#define SEL_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.z == 0) g_sel_stamp[i] = wall_clock64(); } while (0)
 
 __device__ unsigned long long radix_select_threshold(const unsigned long long *cand, int M, int keep, unsigned int *hist,
                                                      unsigned long long *s_prefix, int *s_want) {
@@ -352,12 +383,16 @@ __device__ unsigned long long radix_select_threshold(const unsigned long long *c
     return *s_prefix;
 }
 
-__global__ void __launch_bounds__(SEL_THREADS) k_kp_select(const unsigned long long *__restrict__ cand,
-                                                           const int32_t *cand_count,
-                                                           const float *__restrict__ ring, int ring_w, int ring_c,
-                                                           int64_t *__restrict__ key_pixels, float *__restrict__ key_pts,
-                                                           int kp_ld, float *__restrict__ valid, int valid_ld,
-                                                           int32_t *n_key, int32_t *status) {
+__global__ void __launch_bounds__(SEL_THREADS) k_kp_select(const caelo_frame_set fs, int ring_w, int ring_c) {
+    const caelo_frame_dev &F = fs.f[blockIdx.z];
+    const unsigned long long *__restrict__ cand = F.cand;
+    const int32_t *cand_count = F.cand_count;
+    const float *__restrict__ ring = F.ring;
+    int64_t *__restrict__ key_pixels = F.key_pixels;
+    float *__restrict__ key_pts = F.key_pts;
+    const int kp_ld = F.kp_ld, valid_ld = F.valid_ld;
+    float *__restrict__ valid = F.valid;
+    int32_t *n_key = F.n_key, *status = F.status;
     __shared__ __attribute__((aligned(16))) unsigned long long sel[SEL_N];
     __shared__ unsigned int hist[256];
     __shared__ unsigned int part[SEL_THREADS];
@@ -475,11 +510,20 @@ int ring_keypoints_launch(const float *ring, int ring_w, int ring_c, int dist_c,
                           const float *resp, unsigned long long *cand, int32_t *cand_count,
                           int64_t *key_pixels, float *key_pts, int kp_ld, float *valid, int valid_ld, int32_t *n_key,
                           int32_t *status, hipStream_t s) {
-    dim3 grid(CAELO_NET_W / KS_COLS, 48 / KS_ROWS);
-    k_kp_score<<<grid, 256, 0, s>>>(ring, ring_w, ring_c, dist_c, counter, cnt_w, resp, cand, cand_count);
+    caelo_frame_set fs = {};
+    fs.n = 1;
+    caelo_frame_dev &d = fs.f[0];
+    d.ring = const_cast<float *>(ring); d.dist_c = dist_c; d.counter = const_cast<int32_t *>(counter); d.resp = const_cast<float *>(resp);
+    d.cand = cand; d.cand_count = cand_count; d.key_pixels = key_pixels; d.key_pts = key_pts; d.kp_ld = kp_ld;
+    d.valid = valid; d.valid_ld = valid_ld; d.n_key = n_key; d.status = status;
+    return ring_keypoints_set(fs, ring_w, ring_c, cnt_w, s);
+}
+
+int ring_keypoints_set(const caelo_frame_set &fs, int ring_w, int ring_c, int cnt_w, hipStream_t s) {
+    dim3 grid(CAELO_NET_W / KS_COLS, 48 / KS_ROWS, fs.n);
+    k_kp_score<<<grid, 256, 0, s>>>(fs, ring_w, ring_c, cnt_w);
     CAELO_LAUNCH_CHECK();
-    k_kp_select<<<1, SEL_THREADS, 0, s>>>(cand, cand_count, ring, ring_w, ring_c, key_pixels, key_pts, kp_ld, valid,
-                                          valid_ld, n_key, status);
+    k_kp_select<<<dim3(1, 1, fs.n), SEL_THREADS, 0, s>>>(fs, ring_w, ring_c);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }

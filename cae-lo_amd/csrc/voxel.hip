@@ -103,19 +103,28 @@ void vox_clear_items(caelo_voxmap *m, int level, caelo_clear_list &list) {
 }
 
 // wipe the bricks of the previous fused build: key -> empty, 8 payload words -> 0 (entry e, word w per thread)
-struct SuspectTables {
-    unsigned long long *sp_keys, *sb_keys;
-    uint32_t *sp_first, *sb_cnt;
-    uint4 *list;
-    uint32_t mask;
-};
-static SuspectTables suspect_tables(const caelo_voxmap *m) {
-    return SuspectTables{m->sp_keys, m->sb_keys, m->sp_first, m->sb_cnt, m->sp_list, m->sp_mask};
+void frame_dev_set_map(caelo_frame_dev &d, const caelo_voxmap *m) {
+    for (int i = 0; i < 3; ++i) {
+        d.brick[i] = m->brick[i];
+        d.vkeys[i] = m->vkeys[i];
+        d.vfirst[i] = m->vfirst[i];
+    }
+    d.vmask0 = m->vmask[0];
+    d.vmask12 = m->vmask[1];
+    d.counts = m->counts;
+    d.list0 = m->list0;
+    d.list1 = m->list1;
+    d.sp = suspect_tables(m);
 }
 
-__global__ void __launch_bounds__(256) k_vox_clear_lists(caelo_brick_table b0, caelo_brick_table b1, const uint32_t *__restrict__ list0,
-                                                         const uint32_t *__restrict__ list1, const int32_t *__restrict__ counts,
-                                                         SuspectTables sp) {
+// blockIdx.z = frame; frames whose map is cleared whole this time (clear_mask bit) have nothing to do here
+__global__ void __launch_bounds__(256) k_vox_clear_lists(const caelo_frame_set fs, unsigned int skip_mask) {
+    if ((skip_mask >> blockIdx.z) & 1u) return;
+    const caelo_frame_dev &F = fs.f[blockIdx.z];
+    const caelo_brick_table b0 = F.brick[0], b1 = F.brick[1];
+    const uint32_t *__restrict__ list0 = F.list0, *__restrict__ list1 = F.list1;
+    const int32_t *__restrict__ counts = F.counts;
+    const SuspectTables sp = F.sp;
     const int n0 = counts[4], n1 = counts[5], nsp = counts[6];
     const long long total = (long long)(n0 + n1) * 8;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -138,17 +147,35 @@ __global__ void __launch_bounds__(256) k_vox_clear_lists(caelo_brick_table b0, c
 }
 
 int vox_clear_for_fast_build(caelo_voxmap *m, caelo_clear_list &list, hipStream_t s) {
-    if (!m->lists_valid) {
-        vox_clear_items(m, 0, list);
-        list.item[list.n++] = {m->base + m->sp_off, m->sp_bytes, 0xFFFFFFFFu};  // the suspect-voxel tables, whole
-        return CAELO_OK;
+    caelo_voxmap *maps[1] = {m};
+    return vox_clear_for_fast_build_set(maps, 1, &list, s);
+}
+
+// maps[i] / lists[i]: frame i of a set.  One launch wipes the listed bricks of every map that holds nothing but its
+// previous fused build; the others (first use, or an exact build in between) get their whole tables on the clear list.
+int vox_clear_for_fast_build_set(caelo_voxmap *const *maps, int n, caelo_clear_list *lists, hipStream_t s) {
+    caelo_frame_set fs = {};
+    fs.n = n;
+    unsigned int skip = 0;
+    for (int i = 0; i < n; ++i) {
+        caelo_voxmap *m = maps[i];
+        frame_dev_set_map(fs.f[i], m);
+        caelo_clear_list &list = lists[i];
+        if (!m->lists_valid) {
+            skip |= 1u << i;
+            vox_clear_items(m, 0, list);
+            list.item[list.n++] = {m->base + m->sp_off, m->sp_bytes, 0xFFFFFFFFu};  // the suspect-voxel tables, whole
+            continue;
+        }
+        // scale 2 has no list: its 16 k-slot table is cleared whole (keys, then payload + the counters right behind it)
+        const size_t slots2 = (size_t)m->brick[2].mask + 1;
+        list.item[list.n++] = {m->brick[2].keys, slots2 * 8, 0xFFFFFFFFu};
+        list.item[list.n++] = {m->brick[2].bits, slots2 * 64 + 64, 0u};
     }
-    k_vox_clear_lists<<<256, 256, 0, s>>>(m->brick[0], m->brick[1], m->list0, m->list1, m->counts, suspect_tables(m));
-    CAELO_LAUNCH_CHECK();
-    // scale 2 has no list: its 16 k-slot table is cleared whole (keys, then payload + the counters right behind it)
-    const size_t slots2 = (size_t)m->brick[2].mask + 1;
-    list.item[list.n++] = {m->brick[2].keys, slots2 * 8, 0xFFFFFFFFu};
-    list.item[list.n++] = {m->brick[2].bits, slots2 * 64 + 64, 0u};
+    if (skip != (1u << n) - 1u) {
+        k_vox_clear_lists<<<dim3(256, 1, n), 256, 0, s>>>(fs, skip);
+        CAELO_LAUNCH_CHECK();
+    }
     return CAELO_OK;
 }
 
@@ -276,9 +303,15 @@ __device__ inline VoxIdx voxel_indices(float fx, float fy, float fz) {
 // 2 lets exactly that point (the reference's first touch, Voxel.py:139-141) set the scale-0/1/2 bits
 // -- a later duplicate never reaches layers 1/2 in the reference either (`continue` at :140).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_vox_first(const float *__restrict__ pc, int64_t n, int stride,
-                                                   unsigned long long *vkeys, uint32_t *vfirst, uint32_t vmask,
-                                                   int32_t *status) {
+__global__ void __launch_bounds__(256) k_vox_first(const caelo_frame_set fs) {
+    const caelo_frame_dev &F = fs.f[blockIdx.z];
+    const float *__restrict__ pc = F.pc;
+    const int64_t n = F.n;
+    const int stride = F.pc_stride;
+    unsigned long long *vkeys = F.vkeys[0];
+    uint32_t *vfirst = F.vfirst[0];
+    const uint32_t vmask = F.vmask0;
+    int32_t *status = F.status;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float *p = pc + i * stride;
@@ -296,13 +329,18 @@ __device__ inline void wave_count(int32_t *counter, bool pred) {
     if (pred && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(counter, __popcll(m));
 }
 
-__global__ void __launch_bounds__(256) k_vox_insert(const float *__restrict__ pc, int64_t n, int stride,
-                                                    const unsigned long long *__restrict__ vkeys0,
-                                                    const uint32_t *__restrict__ vfirst0, uint32_t vmask0,
-                                                    caelo_brick_table b0, caelo_brick_table b1, caelo_brick_table b2,
-                                                    unsigned long long *vkeys1, uint32_t *vfirst1,
-                                                    unsigned long long *vkeys2, uint32_t *vfirst2, uint32_t vmask12,
-                                                    int track_order, int32_t *counts, int32_t *status) {
+__global__ void __launch_bounds__(256) k_vox_insert(const caelo_frame_set fs, int track_order) {
+    const caelo_frame_dev &F = fs.f[blockIdx.z];
+    const float *__restrict__ pc = F.pc;
+    const int64_t n = F.n;
+    const int stride = F.pc_stride;
+    const unsigned long long *__restrict__ vkeys0 = F.vkeys[0];
+    const uint32_t *__restrict__ vfirst0 = F.vfirst[0];
+    const uint32_t vmask0 = F.vmask0, vmask12 = F.vmask12;
+    const caelo_brick_table b0 = F.brick[0], b1 = F.brick[1], b2 = F.brick[2];
+    unsigned long long *vkeys1 = F.vkeys[1], *vkeys2 = F.vkeys[2];
+    uint32_t *vfirst1 = F.vfirst[1], *vfirst2 = F.vfirst[2];
+    int32_t *counts = F.counts, *status = F.status;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool first = false;
     VoxIdx v;
@@ -352,13 +390,19 @@ __global__ void k_vox_check(const int32_t *counts, int32_t *status) {
 //     suspect voxels of each brick);
 //   * k_vox_coarse derives a scale-1 voxel from a brick only if the brick holds a NON-suspect voxel (all points of
 //     such a voxel are consistent, so its first one is), k_vox_coarse2 derives scale 2 from those;
-//   * k_vox_suspects (an empty launch when the frame has no inconsistent point) finds the first point of every
-//     suspect voxel (atomicMin over all points) and lets its last workgroup insert that point's own scale-1 / 2
-//     indices -- exactly what the reference's loop does when it meets the voxel for the first time.
+//   * k_vox_suspects_first / _resolve (empty launches when the frame has no inconsistent point) find the first point
+//     of every suspect voxel (atomicMin over all points) and insert that point's own scale-1 / 2 indices -- exactly
+//     what the reference's loop does when it meets the voxel for the first time.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_vox_points(const float *__restrict__ pc, int64_t n, int stride,
-                                                    caelo_brick_table b0, uint32_t *list0, int32_t *counts,
-                                                    int32_t *status, SuspectTables sp) {
+__global__ void __launch_bounds__(256) k_vox_points(const caelo_frame_set fs) {
+    const caelo_frame_dev &F = fs.f[blockIdx.z];
+    const float *__restrict__ pc = F.pc;
+    const int64_t n = F.n;
+    const int stride = F.pc_stride;
+    const caelo_brick_table b0 = F.brick[0];
+    uint32_t *list0 = F.list0;
+    int32_t *counts = F.counts, *status = F.status;
+    const SuspectTables sp = F.sp;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     VoxIdx v;
@@ -411,8 +455,13 @@ __global__ void __launch_bounds__(256) k_vox_points(const float *__restrict__ pc
 }
 
 // the occupied scale-0 bricks (256 per workgroup iteration): a brick is a scale-1 voxel, and counts its voxels
-__global__ void __launch_bounds__(256) k_vox_coarse(caelo_brick_table b0, caelo_brick_table b1, const uint32_t *list0,
-                                                    uint32_t *list1, int32_t *counts, int32_t *status, SuspectTables sp) {
+__global__ void __launch_bounds__(256) k_vox_coarse(const caelo_frame_set fs) {
+    const caelo_frame_dev &F = fs.f[blockIdx.z];
+    const caelo_brick_table b0 = F.brick[0], b1 = F.brick[1];
+    const uint32_t *list0 = F.list0;
+    uint32_t *list1 = F.list1;
+    int32_t *counts = F.counts, *status = F.status;
+    const SuspectTables sp = F.sp;
     __shared__ int s_tmp[2];
     const int nb = counts[4];
     const bool any_suspect = counts[6] > 0;
@@ -444,8 +493,11 @@ __global__ void __launch_bounds__(256) k_vox_coarse(caelo_brick_table b0, caelo_
 
 // the occupied scale-1 bricks: count their voxels and mark the scale-2 voxels under them
 // (a scale-1 brick spans 2x2x2 scale-2 voxels: scale-2 index = scale-1 index >> 2)
-__global__ void __launch_bounds__(256) k_vox_coarse2(caelo_brick_table b1, caelo_brick_table b2, const uint32_t *list1,
-                                                     int32_t *counts, int32_t *status) {
+__global__ void __launch_bounds__(256) k_vox_coarse2(const caelo_frame_set fs) {
+    const caelo_frame_dev &F = fs.f[blockIdx.z];
+    const caelo_brick_table b1 = F.brick[1], b2 = F.brick[2];
+    const uint32_t *list1 = F.list1;
+    int32_t *counts = F.counts, *status = F.status;
     __shared__ int s_tmp[2];
     const int nb = counts[5];
     int pop = 0, pop2 = 0;
@@ -494,35 +546,35 @@ __global__ void __launch_bounds__(256) k_vox_coarse2(caelo_brick_table b1, caelo
     caelo_block_add(&counts[2], pop2, s_tmp);
 }
 
-// The suspect voxels of the frame (see the header of this section).  Grid = one thread per point; nothing to do --
-// one word read per workgroup -- when no point of the frame was inconsistent.
-__global__ void __launch_bounds__(256) k_vox_suspects(const float *__restrict__ pc, int64_t n, int stride, caelo_brick_table b1,
-                                                      caelo_brick_table b2, uint32_t *list1, int32_t *counts, int32_t *status,
-                                                      SuspectTables sp) {
-    const int nsp = counts[6];
-    if (nsp == 0) return;
-    // (1) first point of every suspect voxel: smallest index over ALL points of the voxel, consistent ones included
+// The suspect voxels of the frame (see the header of this section), two launches that have nothing to do -- one word
+// read per workgroup -- when no point of the frame was inconsistent.  (A single kernel whose last workgroup resolves
+// would need an agent-scope release per workgroup: on gfx950 that is an L2 write-back walk, 433 us for 8 frames.)
+// (1) first point of every suspect voxel: smallest index over ALL points of the voxel, consistent ones included
+__global__ void __launch_bounds__(256) k_vox_suspects_first(const caelo_frame_set fs) {
+    const caelo_frame_dev &F = fs.f[blockIdx.z];
+    if (F.counts[6] == 0) return;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const float *p = pc + i * stride;
-        const VoxIdx v = voxel_indices(p[0], p[1], p[2]);
-        if (v.ok) {
-            const int ss = table_find(sp.sp_keys, sp.mask, caelo_pack3(v.g[0], v.g[1], v.g[2]));
-            if (ss >= 0) atomicMin(&sp.sp_first[ss], (uint32_t)i);
-        }
-    }
-    // (2) the last workgroup to arrive resolves them (release / acquire around the ticket)
-    __shared__ int s_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0)
-        s_last = __hip_atomic_fetch_add(&counts[7], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    for (int e = threadIdx.x; e < nsp; e += blockDim.x) {
+    if (i >= F.n) return;
+    const float *p = F.pc + i * F.pc_stride;
+    const VoxIdx v = voxel_indices(p[0], p[1], p[2]);
+    if (!v.ok) return;
+    const int ss = table_find(F.sp.sp_keys, F.sp.mask, caelo_pack3(v.g[0], v.g[1], v.g[2]));
+    if (ss >= 0) atomicMin(&F.sp.sp_first[ss], (uint32_t)i);
+}
+
+// (2) that point's own scale-1 / 2 indices are inserted, exactly what the reference's loop does when it meets the voxel
+__global__ void __launch_bounds__(256) k_vox_suspects_resolve(const caelo_frame_set fs) {
+    const caelo_frame_dev &F = fs.f[blockIdx.z];
+    const float *__restrict__ pc = F.pc;
+    const int stride = F.pc_stride;
+    const caelo_brick_table b1 = F.brick[1], b2 = F.brick[2];
+    uint32_t *list1 = F.list1;
+    int32_t *counts = F.counts, *status = F.status;
+    const SuspectTables sp = F.sp;
+    const int nsp = counts[6];
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nsp; e += gridDim.x * blockDim.x) {
         const uint4 ent = sp.list[e];
-        const uint32_t j = __hip_atomic_load(&sp.sp_first[ent.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t j = sp.sp_first[ent.y];
         const float *p = pc + (int64_t)j * stride;
         const VoxIdx v = voxel_indices(p[0], p[1], p[2]);  // the voxel's first point: its own scale-1 / 2 indices count
         // several inconsistent points of one voxel repeat this: idempotent, the counters only see bits that were new
@@ -540,30 +592,57 @@ __global__ void __launch_bounds__(256) k_vox_suspects(const float *__restrict__ 
     }
 }
 
+static int64_t vox_set_max_points(const caelo_frame_set &fs) {
+    int64_t n = 0;
+    for (int i = 0; i < fs.n; ++i) n = fs.f[i].n > n ? fs.f[i].n : n;
+    return n;
+}
+
+static void vox_single_set(caelo_frame_set &fs, const caelo_voxmap *m, const float *pc, int64_t n, int stride, int32_t *status) {
+    fs.n = 1;
+    frame_dev_set_map(fs.f[0], m);
+    fs.f[0].pc = pc; fs.f[0].n = n; fs.f[0].pc_stride = stride; fs.f[0].status = status;
+}
+
 int vox_build_fast_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, int32_t *status, hipStream_t s) {
-    m->lists_valid = false;  // until every kernel of the build is enqueued
-    const SuspectTables sp = suspect_tables(m);
-    k_vox_points<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(pc, n, stride, m->brick[0], m->list0, m->counts, status, sp);
+    caelo_frame_set fs = {};
+    vox_single_set(fs, m, pc, n, stride, status);
+    caelo_voxmap *maps[1] = {m};
+    return vox_build_fast_set(maps, fs, s);
+}
+
+// fused build of every frame of the set (fs.f[i] carries map i's tables, the scan and the status word)
+int vox_build_fast_set(caelo_voxmap *const *maps, const caelo_frame_set &fs, hipStream_t s) {
+    for (int i = 0; i < fs.n; ++i) maps[i]->lists_valid = false;  // until every kernel of the build is enqueued
+    const unsigned gp = (unsigned)((vox_set_max_points(fs) + 255) / 256);
+    k_vox_points<<<dim3(gp, 1, fs.n), 256, 0, s>>>(fs);
     CAELO_LAUNCH_CHECK();
-    k_vox_coarse<<<256, 256, 0, s>>>(m->brick[0], m->brick[1], m->list0, m->list1, m->counts, status, sp);
+    k_vox_coarse<<<dim3(256, 1, fs.n), 256, 0, s>>>(fs);
     CAELO_LAUNCH_CHECK();
-    k_vox_coarse2<<<64, 256, 0, s>>>(m->brick[1], m->brick[2], m->list1, m->counts, status);
+    k_vox_coarse2<<<dim3(64, 1, fs.n), 256, 0, s>>>(fs);
     CAELO_LAUNCH_CHECK();
-    k_vox_suspects<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(pc, n, stride, m->brick[1], m->brick[2], m->list1, m->counts, status, sp);
+    k_vox_suspects_first<<<dim3(gp, 1, fs.n), 256, 0, s>>>(fs);
     CAELO_LAUNCH_CHECK();
-    m->lists_valid = true;
+    k_vox_suspects_resolve<<<dim3(4, 1, fs.n), 256, 0, s>>>(fs);
+    CAELO_LAUNCH_CHECK();
+    for (int i = 0; i < fs.n; ++i) maps[i]->lists_valid = true;
     return CAELO_OK;
 }
 
 int vox_build_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, bool track_order, int32_t *status,
                      hipStream_t s) {
-    m->lists_valid = false;
-    const unsigned grid = (unsigned)((n + 255) / 256);
-    k_vox_first<<<grid, 256, 0, s>>>(pc, n, stride, m->vkeys[0], m->vfirst[0], m->vmask[0], status);
+    caelo_frame_set fs = {};
+    vox_single_set(fs, m, pc, n, stride, status);
+    caelo_voxmap *maps[1] = {m};
+    return vox_build_set(maps, fs, track_order, s);
+}
+
+int vox_build_set(caelo_voxmap *const *maps, const caelo_frame_set &fs, bool track_order, hipStream_t s) {
+    for (int i = 0; i < fs.n; ++i) maps[i]->lists_valid = false;
+    const unsigned grid = (unsigned)((vox_set_max_points(fs) + 255) / 256);
+    k_vox_first<<<dim3(grid, 1, fs.n), 256, 0, s>>>(fs);
     CAELO_LAUNCH_CHECK();
-    k_vox_insert<<<grid, 256, 0, s>>>(pc, n, stride, m->vkeys[0], m->vfirst[0], m->vmask[0], m->brick[0], m->brick[1],
-                                      m->brick[2], m->vkeys[1], m->vfirst[1], m->vkeys[2], m->vfirst[2], m->vmask[1],
-                                      track_order ? 1 : 0, m->counts, status);
+    k_vox_insert<<<dim3(grid, 1, fs.n), 256, 0, s>>>(fs, track_order ? 1 : 0);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }
@@ -678,7 +757,7 @@ CAELO_API int caelo_voxmap_from_lists(caelo_ctx *c, caelo_voxmap *m, const int16
 
 // debug aid: timestamps (100 MHz) of workgroup 0 / wave 0 of the last k_patches launch
 __device__ unsigned long long g_patch_stamp[8];
-#define PATCH_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_patch_stamp[i] = wall_clock64(); } while (0)
+#define PATCH_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_patch_stamp[i] = wall_clock64(); } while (0)
 int patch_debug_copy(unsigned long long *out_host) {
     CAELO_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_patch_stamp), sizeof(unsigned long long) * 8));
     return CAELO_OK;
@@ -702,12 +781,18 @@ __device__ inline int wave_sum(int v) {
     return v;
 }
 
-__global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restrict__ pts, int pts_ld, int64_t k_max,
-                                                           const int32_t *__restrict__ n_key, caelo_brick_table t0,
-                                                           caelo_brick_table t1, caelo_brick_table t2,
-                                                           unsigned long long *__restrict__ bits,
-                                                           uint8_t *__restrict__ flags, const int32_t *counts,
-                                                           int32_t *status, DedupScratch *dd, unsigned long long dd_mask) {
+__global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const caelo_frame_set fs, int64_t k_max, int check_counts,
+                                                           unsigned long long dd_mask) {
+    const caelo_frame_dev &F = fs.f[blockIdx.z];
+    const float *__restrict__ pts = F.key_pts;
+    const int pts_ld = F.kp_ld;
+    const int32_t *__restrict__ n_key = F.n_key;
+    const caelo_brick_table t0 = F.brick[0], t1 = F.brick[1], t2 = F.brick[2];
+    unsigned long long *__restrict__ bits = F.bits;
+    uint8_t *__restrict__ flags = F.flags;
+    const int32_t *counts = check_counts ? F.counts : nullptr;
+    int32_t *status = F.status;
+    DedupScratch *dd = F.dd;
     if (counts && blockIdx.x == 0 && threadIdx.x == 0 && (counts[0] < 496 || counts[1] < 496 || counts[2] < 496))
         atomicOr(status, CAELO_ST_FEW_VOXELS);  // sklearn ValueError at Voxel.py:195-196
     __shared__ PatchWaveLds lds_all[PW_WAVES];
@@ -954,10 +1039,19 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const float *__restri
 
 int vox_patches_launch(const caelo_voxmap *m, const float *pts, int pts_ld, int64_t k_max, const int32_t *n_key,
                        uint64_t *bits, uint8_t *flags, int32_t *status, bool check_counts, hipStream_t s, void *dedup_scratch) {
+    caelo_frame_set fs = {};
+    fs.n = 1;
+    caelo_frame_dev &d = fs.f[0];
+    frame_dev_set_map(d, m);
+    d.key_pts = const_cast<float *>(pts); d.kp_ld = pts_ld; d.n_key = const_cast<int32_t *>(n_key);
+    d.bits = (unsigned long long *)bits; d.flags = flags; d.status = status; d.dd = (DedupScratch *)dedup_scratch;
+    return vox_patches_set(fs, k_max, check_counts, s);
+}
+
+int vox_patches_set(const caelo_frame_set &fs, int64_t k_max, bool check_counts, hipStream_t s) {
     const int64_t waves = k_max * 3;
-    k_patches<<<(unsigned)((waves + PW_WAVES - 1) / PW_WAVES), 64 * PW_WAVES, 0, s>>>(
-        pts, pts_ld, k_max, n_key, m->brick[0], m->brick[1], m->brick[2], (unsigned long long *)bits, flags,
-        check_counts ? m->counts : nullptr, status, (DedupScratch *)dedup_scratch, dedup_hash_mask());
+    k_patches<<<dim3((unsigned)((waves + PW_WAVES - 1) / PW_WAVES), 1, fs.n), 64 * PW_WAVES, 0, s>>>(fs, k_max, check_counts ? 1 : 0,
+                                                                                                   dedup_hash_mask());
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }

@@ -43,10 +43,10 @@ def pose_rows(batch, k):
     return out, ok, thr, nin
 
 
-def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, lanes, batch_frames, keep=None):
+def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, keep=None):
     """Frames [lo, hi) of this rank.  Returns per-pair rows for pairs (i-1, i), i in (lo, hi) -- the pair (lo-1, lo)
     is the caller's (it needs the previous rank's last frame) -- plus the first and last frame's features."""
-    pipe = eng.pipeline(lanes, batch_frames)
+    pipe = eng.pipeline(batch_frames)
     rel, ok, thr, nin = [], [], [], []
     prev, first = None, None
     for c0 in range(lo, hi, chunk):
@@ -78,8 +78,7 @@ def main():
     ap.add_argument("--seed-base", type=int, default=1000)
     ap.add_argument("--chunk", type=int, default=120, help="frames resident on the GPU at a time")
     ap.add_argument("--dist-channels", type=int, default=5, choices=(3, 5), help="5 = demo mode, 3 = batch mode (SURVEY 8a-3')")
-    ap.add_argument("--lanes", type=int, default=6)
-    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4, help="frames per launch (caelo_pipeline)")
     ap.add_argument("--save-artifacts", action="store_true", help="write Features/*.mat and InliersIdx/*.mat next to the scans")
     args = ap.parse_args()
 
@@ -92,7 +91,6 @@ def main():
     local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     eng = Engine(device=local_rank)
-    eng.pipeline(args.lanes, args.batch)   # its HIP streams first: the stream -> hardware-queue mapping follows creation order
     if world > 1:
         dist.init_process_group(backend=backend, **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
     if args.scans:
@@ -120,7 +118,7 @@ def main():
                 stageio.save_inliers(os.path.dirname(os.path.dirname(files[c0 + j])), c0 + j - 1, c0 + j, idx[j, :k][m], np.arange(k)[m])
 
     rel, ok, thr, nin, first, last = run_local(eng, load, lo, hi, args.seed_base, args.chunk, args.dist_channels,
-                                               args.lanes, args.batch, keep)
+                                               args.batch, keep)
     if world > 1:   # the pair that straddles the rank boundary: ONE all-gather of the boundary rows
         gathered = cdist.all_gather_boundary(last.rows)
         if rank > 0:

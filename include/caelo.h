@@ -230,23 +230,22 @@ int64_t caelo_icp_ws_bytes(int64_t n1);
 int caelo_icp_step(caelo_ctx *ctx, const float *pc0, int64_t n0, float *pc1, int64_t n1, double threshold, int min_inliers,
                    float *rt, int32_t *n_inliers, void *ws, void *stream);
 
-/* ---- frame pipeline: fronts and pairs of consecutive frames on n_lanes HIP streams, encoders batched -----------
+/* ---- frame pipeline: batches of frames behind single launches, three stages on three HIP streams ------------------
  * Replaces the reference's per-frame driver loops (BatchPreprocess.py:88-140 extract loop, Match.py:296-353 /
- * PoseEstimation.py pair loop) for throughput.  Each lane owns a stream, an issue thread, a voxel map and the
- * workspaces of the front half of caelo_extract / caelo_match / caelo_ransac; the 3D-CAE encoder of `batch`
- * consecutive frames runs as ONE launch set on a further stream (its fixed costs are ~47 us per launch set) and
- * writes each frame's descriptors into that frame's rows.  Per-frame results are identical to the single-call
- * entry points (same kernels, same per-patch arithmetic).
- *   create(ctx, n_lanes in [1,16], batch in [1, min(8, n_lanes)], max_points)
- *   begin(stream)   lanes wait for work already queued on `stream` (the producers of the jobs' inputs)
- *   submit(job)     copy the job; frame k runs its front on lane k % n_lanes:
+ * PoseEstimation.py pair loop) for throughput.  `batch` consecutive frames share ONE launch of every kernel of the
+ * front half of caelo_extract (ring image, response, keypoints, voxel map, patch gather), one encoder launch set and
+ * one caelo_match / caelo_ransac launch per threshold level; front(b+1), encoder(b) and pairs(b-1) overlap on three
+ * streams.  Per-frame results are identical to the single-call entry points (same kernels, same per-frame arithmetic).
+ *   create(ctx, batch in [1,8], n_buffers in [2,4], max_points)   n_buffers = batches of patches in flight between
+ *                                                                   the front and the encoder
+ *   begin(stream)   the stages wait for work already queued on `stream` (the producers of the jobs' inputs)
+ *   submit(job)     copy the job; every `batch` jobs (or when the mode changes) the batch is launched:
  *                     caelo_extract(pc -> rows [1024][64] = descriptor 0:60 | xyz 60:63 | valid 63, ...)
  *                     pair == CAELO_PAIR_CHAIN:    caelo_match + caelo_ransac against the previously submitted frame
  *                     pair == CAELO_PAIR_EXPLICIT: ... against prev_rows / prev_n_key (e.g. rows gathered from a peer)
- *                   (pairs are issued n_lanes frames behind the fronts; flush issues the rest)
- *   flush(stream)   close a partial batch, block until every submitted job is enqueued, make `stream` wait for all
- * Buffers named by a job must stay alive until `stream` has passed the flush.  Errors of the worker threads stop
- * further launches and are returned by the next begin / flush (caelo_last_error() holds the text). */
+ *   flush(stream)   launch a partial batch, make `stream` wait for all three stages
+ * Buffers named by a job must stay alive until `stream` has passed the flush.  Calls come from ONE host thread.
+ * A failed launch is returned by the submit / flush that issued it (caelo_last_error() holds the text). */
 typedef struct caelo_pipeline caelo_pipeline;
 #define CAELO_PAIR_NONE 0
 #define CAELO_PAIR_CHAIN 1
@@ -270,16 +269,14 @@ typedef struct caelo_frame_job {
     uint8_t *inlier_mask;       /* [1024] out */
     int64_t *pair_idx;          /* [1024] out */
 } caelo_frame_job;
-int caelo_pipeline_create(caelo_ctx *ctx, int n_lanes, int batch, int64_t max_points, caelo_pipeline **out);
+int caelo_pipeline_create(caelo_ctx *ctx, int batch, int n_buffers, int64_t max_points, caelo_pipeline **out);
 void caelo_pipeline_destroy(caelo_pipeline *pipe);
-int caelo_pipeline_lanes(const caelo_pipeline *pipe);
+int caelo_pipeline_batch(const caelo_pipeline *pipe);
 int caelo_pipeline_begin(caelo_pipeline *pipe, void *stream);
 int caelo_pipeline_submit(caelo_pipeline *pipe, const caelo_frame_job *job);
 int caelo_pipeline_flush(caelo_pipeline *pipe, void *stream);
-/* host-side counters since the last call (then reset): out_host[6] = jobs, ns the worker threads spent issuing them,
- * ns they waited for another worker's record call, number of lanes, and -- only with CAELO_PIPE_TIMING=1 in the
- * environment at create time (a diagnostic mode whose flush synchronises) -- ns the encoder stream spent inside launch
- * sets and the ns between the first set's begin and the last set's end of the last flush */
+/* host-side counters since the last call (then reset): out_host[6] = jobs, ns the calling thread spent issuing their
+ * launches, batches launched, batch size, hand-off buffers, HIP streams used */
 int caelo_pipeline_stats(caelo_pipeline *pipe, int64_t *out_host);
 
 #ifdef __cplusplus
