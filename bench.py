@@ -39,7 +39,9 @@ from caelo import synth  # noqa: E402
 from caelo import dist as cdist  # noqa: E402
 from caelo.engine import Engine, FrameFeatures, ransac_draws  # noqa: E402
 
-POOL = 6  # distinct consecutive synthetic frames per rank, cycled
+POOL = 6  # distinct consecutive synthetic frames per rank, walked back and forth (0 1 .. 5 4 .. 1 0 1 ..) so that every
+          # timed pair is a pair of NEIGHBOURING scans, like a real sequence (cycling 5 -> 0 would make every sixth pair
+          # a 4.5 m jump whose match fails and escalates RANSAC to 1.6 m)
 QUANTUM = 1e-3  # coordinates in whole millimetres, like the metrically quantised values of real scans: every frame then
                 # holds points exactly on voxel faces (tests/golden/frame_q0.npz: 14 of 126 k), which the voxelization
                 # resolves like the reference's float64 index arithmetic (Voxel.py:118-152)
@@ -127,11 +129,19 @@ def main():
     rand = [torch.from_numpy(ransac_draws(1000 + rank * 7919 + i)).to(dev) for i in range(POOL)]
     n_points = int(np.mean([p.shape[0] for p in pool]))
 
+    def walk(i):          # 0 1 2 3 4 5 4 3 2 1 0 1 ...
+        i %= 2 * (POOL - 1)
+        return i if i < POOL else 2 * (POOL - 1) - i
+
+    start = [0]           # position of the last frame handed out: `prev` below is frame walk(0) = 0
+
     def run(steps, prev):
         """`steps` frames through the native pipeline (extract, then match + RANSAC against frame i-1, `batch` frames
         per launch), one all-gather of frame rows, then the pair that straddles the rank boundary."""
-        scans = [pool[i % POOL] for i in range(steps)]
-        draws = [rand[i % POOL] for i in range(steps)]
+        order = [walk(start[0] + 1 + i) for i in range(steps)]
+        start[0] += steps
+        scans = [pool[j] for j in order]
+        draws = [rand[j] for j in order]
         batch = pipe.run(scans, draws, prev=prev if rank == 0 else None, pairs=not args.extract_only)
         if args.extract_only:
             return batch.frame(steps - 1), batch
@@ -148,7 +158,7 @@ def main():
                 batch.result[0].copy_(eng.match_pose(prev, batch.frame(0), rand[0])[0])
         return batch.frame(steps - 1), batch
 
-    prev = eng.extract(pool[POOL - 1])
+    prev = eng.extract(pool[0])
     # one-time initialisation, not a warm-up step: the three stage streams and every hand-off buffer are touched once (a
     # HIP stream allocates its hardware queue on first use, ~ms), so that a run with a small --warmup does not time that
     prev, _ = run(pipe.buffers * pipe.batch, prev)

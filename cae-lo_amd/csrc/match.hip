@@ -30,65 +30,20 @@
 //   is ~1e-13 wide: one row per column survives unless descriptors are duplicated.
 //   (An f32 MFMA version of the same filter keeps ~100 rows per column on these descriptors -- the
 //   |a|^2+|b|^2-2ab form cancels ~4 digits -- and was slower than the plain f64 scan.)
-// Grid = (column tiles of 16 frame-1 descriptors) x MM_RS row slices; a workgroup's 16 waves take one
-// 16-row tile of frame 0 each (more slices of 256 rows when k0 > 1024).  Every workgroup reduces its
-// rows to the three smallest lower bounds per column and publishes them; the last slice to arrive (agent
-// -scope release / ticket / acquire) merges the slices and certifies.  If a third bound still passes the
-// test the column is re-scanned exactly by that workgroup.
+// Grid = (column tiles of 16 frame-1 descriptors) x pairs of the set.  A workgroup is 4 wavefronts; its column
+// tile's B fragments stay in registers and each wavefront walks every fourth 16-row tile of frame 0, keeping the
+// three smallest lower bounds per column; the four partial results meet in LDS and one thread per column
+// certifies.  Nothing crosses workgroups (round 1 split the rows over four 1024-thread workgroups per column tile
+// that met through global tickets: 18.7 us per pair alone, and starved behind the encoder's persistent grids inside
+// the pipeline), and a 256-thread workgroup fits next to them on any CU.
 // ------------------------------------------------------------------------------------------------
 typedef double mm_f64x4 __attribute__((ext_vector_type(4)));
-#define MM_WAVES 16
+#define MM_WAVES 4
 #define MM_KSTEPS 16  // dim <= 64
-#define MM_RS 4       // row slices per column tile
-
-struct MmPartial {
-    double L1, L2, L3, U;
-    int I1, I2;
-};
-// Cross-workgroup hand-off: the partial results go out as agent-scope atomic stores (write-through to the coherence
-// point, sc1) and come back as agent-scope atomic loads (cdna_hip_programming.md G16, "8-B agent atomics both sides");
-// the publishing wave waits for its stores to complete (s_waitcnt vmcnt(0)) before the workgroup takes its ticket, an
-// agent-scope read-modify-write.  Every shared location is touched by agent-scope atomics only, so no access can be
-// served from a non-coherent cache.  CAELO_XWG_FENCES=1 builds the formal release / acquire version instead
-// (__threadfence() around an ACQ_REL ticket): on gfx950 an agent-scope release is an L2 write-back walk and an acquire an
-// invalidate, PER WORKGROUP -- measured 18.7 -> 33 us per 1024 x 1024 match for bit-identical results
-// (tests/test_gpu_parity.py::test_match_ransac_and_pipeline_are_deterministic_under_load runs either build).
-#ifndef CAELO_XWG_FENCES
-#define CAELO_XWG_FENCES 0
-#endif
-#if CAELO_XWG_FENCES
-#define XWG_RELEASE() __threadfence()
-#define XWG_ACQUIRE() __threadfence()
-#define XWG_TICKET(PTR) __hip_atomic_fetch_add((PTR), 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
-#else
-#define XWG_RELEASE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#define XWG_ACQUIRE() asm volatile("" ::: "memory")
-#define XWG_TICKET(PTR) __hip_atomic_fetch_add((PTR), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#endif
-__device__ inline void mm_publish(MmPartial *dst, const MmPartial &p) {
-    unsigned long long *d = (unsigned long long *)dst;
-    __hip_atomic_store(d + 0, (unsigned long long)__double_as_longlong(p.L1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(d + 1, (unsigned long long)__double_as_longlong(p.L2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(d + 2, (unsigned long long)__double_as_longlong(p.L3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(d + 3, (unsigned long long)__double_as_longlong(p.U), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(d + 4, ((unsigned long long)(unsigned)p.I2 << 32) | (unsigned)p.I1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ inline MmPartial mm_consume(const MmPartial *src) {
-    unsigned long long *s = (unsigned long long *)src;
-    MmPartial p;
-    p.L1 = __longlong_as_double((long long)__hip_atomic_load(s + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    p.L2 = __longlong_as_double((long long)__hip_atomic_load(s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    p.L3 = __longlong_as_double((long long)__hip_atomic_load(s + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    p.U = __longlong_as_double((long long)__hip_atomic_load(s + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const unsigned long long ii = __hip_atomic_load(s + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    p.I1 = (int)(unsigned)(ii & 0xFFFFFFFFull);
-    p.I2 = (int)(unsigned)(ii >> 32);
-    return p;
-}
 
 CAELO_API int64_t caelo_match_ws_bytes(int64_t k1_max) {
-    const int64_t tiles = (k1_max + 15) / 16;
-    return 256 + ((tiles * 4 + 255) / 256) * 256 + tiles * MM_RS * 16 * (int64_t)sizeof(MmPartial);
+    (void)k1_max;
+    return 256;  // [0] columns re-scanned exactly, [1] columns decided between two rows (statistics only)
 }
 
 __device__ inline double exact_dist(const float *a, const float *b, int dim) {
@@ -129,33 +84,29 @@ __device__ inline void load_frag(const float *row, bool valid, int g, int dim, d
 
 template <bool VEC>
 __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_set ps, int ld0, int64_t k0_max, int ld1,
-                                                              int64_t k1_max, int dim, size_t tbytes) {
+                                                              int64_t k1_max, int dim) {
     const caelo_pair_dev &P = ps.p[blockIdx.z];
     const float *__restrict__ f0 = P.f0, *__restrict__ f1 = P.f1;
     const int32_t *n0p = P.n0, *n1p = P.n1;
     int64_t *__restrict__ pair_idx = P.pair_idx;
-    // workspace layout: stats [256 B] | tickets | partial results (see match_set)
     int32_t *stats = (int32_t *)P.ws_match;
-    int32_t *tickets = (int32_t *)((char *)P.ws_match + 256);
-    MmPartial *parts = (MmPartial *)((char *)P.ws_match + 256 + tbytes);
     __shared__ double sL[3][MM_WAVES][16];
     __shared__ int sI[2][MM_WAVES][16];
     __shared__ double sU[MM_WAVES][16];
     __shared__ int s_rescan[16];
     __shared__ double s_rd[MM_WAVES];
     __shared__ int s_ri[MM_WAVES];
-    __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, x = lane & 15;
     // counts live on the device; clamp so that a caller who forgot to order this launch after the
     // producer of n0/n1 reads garbage rows, never out of bounds
     const int k0 = n0p ? min(max(*n0p, 0), (int)k0_max) : (int)k0_max;
     const int k1 = n1p ? min(max(*n1p, 0), (int)k1_max) : (int)k1_max;
-    const int ctile = blockIdx.x, rs = blockIdx.y;
+    const int ctile = blockIdx.x;
     const int j0 = ctile * 16;
-    if (j0 >= k1) return;  // uniform over the column tile's slices: no ticket needed
+    if (j0 >= k1) return;
     if (k0 == 0) {         // no frame-0 descriptor at all (the reference's argmin would raise): index 0, the pose fails
-        if (rs == 0 && tid < 16 && j0 + tid < k1) pair_idx[j0 + tid] = 0;
+        if (tid < 16 && j0 + tid < k1) pair_idx[j0 + tid] = 0;
         return;
     }
     const double kappa = (4.0 * (double)dim + 64.0) * 1.1102230246251565e-16;  // >= 2x the worst-case bound (dim + 20) 2^-53
@@ -171,18 +122,26 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
     double L1 = BIG, L2 = BIG, L3 = BIG, U = BIG;
     int I1 = 0x7FFFFFFF, I2 = 0x7FFFFFFF;
     const int ntiles = (k0 + 15) >> 4;
-    for (int t = rs * MM_WAVES + wave; t < ntiles; t += MM_RS * MM_WAVES) {
+    // the next row tile's fragment is fetched while this one's MFMAs run
+    double a[MM_KSTEPS], an[MM_KSTEPS];
+    if (wave < ntiles) load_frag<VEC>(f0 + (size_t)((wave << 4) + x) * ld0, (wave << 4) + x < k0, g, dim, a);
+    for (int t = wave; t < ntiles; t += MM_WAVES) {
         const int i0 = t << 4;
-        double a[MM_KSTEPS];
-        load_frag<VEC>(f0 + (size_t)(i0 + x) * ld0, i0 + x < k0, g, dim, a);
+        const int tn = t + MM_WAVES;
+        if (tn < ntiles) load_frag<VEC>(f0 + (size_t)((tn << 4) + x) * ld0, (tn << 4) + x < k0, g, dim, an);
         double p = 0.0;
 #pragma unroll
         for (int s = 0; s < MM_KSTEPS; ++s) p += a[s] * a[s];
         p += __shfl_xor(p, 16);
         p += __shfl_xor(p, 32);  // |f0_{i0+x}|^2 on every lane with this x
-        mm_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        // two accumulators: no MFMA waits for its predecessor (the rounding bound kappa holds for any summation order)
+        mm_f64x4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < MM_KSTEPS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
+        for (int s = 0; s < MM_KSTEPS; s += 2) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s + 1], b[s + 1], acc2, 0, 0, 0);
+        }
+        acc += acc2;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = g + 4 * r;          // f64 C/D layout: row = (lane >> 4) + 4 * reg, col = lane & 15
@@ -195,8 +154,10 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
                 top3_insert(v - e, i, L1, L2, L3, I1, I2);
             }
         }
+#pragma unroll
+        for (int s = 0; s < MM_KSTEPS; ++s) a[s] = an[s];
     }
-    // ---- workgroup top-3 per column: merge the 4 lane groups by shuffles, the 16 waves through LDS
+    // ---- workgroup top-3 per column: merge the 4 lane groups by shuffles, the 4 waves through LDS
 #define MM_SHFL_MERGE(OFF)                                                                           \
     {                                                                                                \
         const double pL1 = __shfl_xor(L1, OFF), pL2 = __shfl_xor(L2, OFF), pL3 = __shfl_xor(L3, OFF); \
@@ -215,54 +176,25 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
         sU[wave][x] = U;
     }
     __syncthreads();
-    MmPartial *mine = parts + ((size_t)ctile * MM_RS + rs) * 16;
-    if (wave == 0) {
-        // lane (g, x): merge waves 4g .. 4g+3 of column x, then the 4 lane groups again
-        L1 = BIG; L2 = BIG; L3 = BIG; U = BIG; I1 = 0x7FFFFFFF; I2 = 0x7FFFFFFF;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int w = 4 * g + q;
-            U = sU[w][x] < U ? sU[w][x] : U;
-            top3_insert(sL[0][w][x], sI[0][w][x], L1, L2, L3, I1, I2);
-            top3_insert(sL[1][w][x], sI[1][w][x], L1, L2, L3, I1, I2);
-            top3_insert(sL[2][w][x], 0x7FFFFFFF, L1, L2, L3, I1, I2);
-        }
-        MM_SHFL_MERGE(16)
-        MM_SHFL_MERGE(32)
-        if (g == 0) {
-            MmPartial pt;
-            pt.L1 = L1; pt.L2 = L2; pt.L3 = L3; pt.U = U; pt.I1 = I1; pt.I2 = I2;
-            mm_publish(&mine[x], pt);
-        }
-        XWG_RELEASE();  // the partial results have reached the coherence point before the ticket is taken
-    }
-    __syncthreads();
-    if (tid == 0) {
-        s_last = XWG_TICKET(&tickets[ctile]) == MM_RS - 1;
-        if (s_last) tickets[ctile] = 0;  // self-cleaning: the workspace is ready for the next call, no memset launch
-    }
-    __syncthreads();
-    if (!s_last) return;
-    XWG_ACQUIRE();
-    // ---- merge the slices and certify: one thread per column
+    // ---- merge the waves and certify: one thread per column
     if (tid < 16) {
         const int j = j0 + tid;
         int rescan = 0;
         if (j < k1) {
             double a1 = BIG, a2 = BIG, a3 = BIG, Umin = BIG;
             int i1 = 0x7FFFFFFF, i2 = 0x7FFFFFFF;
-            for (int q = 0; q < MM_RS; ++q) {
-                const MmPartial pt = mm_consume(&parts[((size_t)ctile * MM_RS + q) * 16 + tid]);
-                Umin = pt.U < Umin ? pt.U : Umin;
-                top3_insert(pt.L1, pt.I1, a1, a2, a3, i1, i2);
-                top3_insert(pt.L2, pt.I2, a1, a2, a3, i1, i2);
-                top3_insert(pt.L3, 0x7FFFFFFF, a1, a2, a3, i1, i2);
+#pragma unroll
+            for (int w = 0; w < MM_WAVES; ++w) {
+                Umin = sU[w][tid] < Umin ? sU[w][tid] : Umin;
+                top3_insert(sL[0][w][tid], sI[0][w][tid], a1, a2, a3, i1, i2);
+                top3_insert(sL[1][w][tid], sI[1][w][tid], a1, a2, a3, i1, i2);
+                top3_insert(sL[2][w][tid], 0x7FFFFFFF, a1, a2, a3, i1, i2);
             }
             if (a3 <= Umin) {
                 rescan = 1;  // three or more rows inside the window
-                atomicAdd(&stats[0], 1);
+                if (stats) atomicAdd(&stats[0], 1);
             } else if (a2 <= Umin) {
-                atomicAdd(&stats[1], 1);
+                if (stats) atomicAdd(&stats[1], 1);
                 const float *bj = f1 + (size_t)j * ld1;
                 const double d1 = exact_dist(f0 + (size_t)i1 * ld0, bj, dim), d2 = exact_dist(f0 + (size_t)i2 * ld0, bj, dim);
                 pair_idx[j] = (d2 < d1 || (d2 == d1 && i2 < i1)) ? i2 : i1;
@@ -313,16 +245,13 @@ int match_set(const caelo_pair_set &ps, int ld0, int64_t k0_max, int ld1, int64_
     CAELO_REQUIRE(ps.n >= 1 && ps.n <= CAELO_FB_MAX, "bad pair count");
     CAELO_REQUIRE(dim > 0 && dim <= MT_MAXDIM && ld0 >= dim && ld1 >= dim && k0_max > 0 && k1_max > 0, "bad shape");
     const int64_t tiles = (k1_max + 15) / 16;
-    // layout: stats [256 B] | tickets | partial results.  The ticket region depends on k1_max: a workspace belongs to ONE
-    // (stream, k1_max) -- a call with another k1_max would find the partial results of this one where its tickets live
-    const size_t tbytes = (size_t)((tiles * 4 + 255) / 256) * 256;
     bool vec = (dim % 4 == 0) && (ld0 % 4 == 0) && (ld1 % 4 == 0);
     for (int i = 0; i < ps.n; ++i) vec = vec && (((uintptr_t)ps.p[i].f0 | (uintptr_t)ps.p[i].f1) & 15u) == 0;
-    dim3 grid((unsigned)tiles, MM_RS, ps.n);
+    dim3 grid((unsigned)tiles, 1, ps.n);
     if (vec)
-        k_match_mfma<true><<<grid, 64 * MM_WAVES, 0, s>>>(ps, ld0, k0_max, ld1, k1_max, dim, tbytes);
+        k_match_mfma<true><<<grid, 64 * MM_WAVES, 0, s>>>(ps, ld0, k0_max, ld1, k1_max, dim);
     else
-        k_match_mfma<false><<<grid, 64 * MM_WAVES, 0, s>>>(ps, ld0, k0_max, ld1, k1_max, dim, tbytes);
+        k_match_mfma<false><<<grid, 64 * MM_WAVES, 0, s>>>(ps, ld0, k0_max, ld1, k1_max, dim);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }
@@ -332,72 +261,81 @@ int match_set(const caelo_pair_set &ps, int ld0, int64_t k0_max, int ld1, int64_
 // one-sided Jacobi SVD in f64: H V = U S ; R = V U^T (the reference's V.T @ U.T with V = Vh);
 // det(R) < 0 -> the reference negates column 2 of Vh, i.e. R <- diag(1,1,-1) R  (:151-155).
 // ------------------------------------------------------------------------------------------------
-__device__ __noinline__ int rigid_from_H_jacobi(const double Hin[9], const double m0[3], const double m1[3], float R[9], float T[3]) {
-    double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    for (int i = 0; i < 9; ++i) A[i] = Hin[i];
+// Written on scalars only (every index a compile-time constant after unrolling): no private arrays that would live
+// in scratch memory -- none of the pair kernels uses any.
+#define JAC_ROT(AP, AQ, VP, VQ)                                       \
+    {                                                                 \
+        const double ap_ = AP, aq_ = AQ;                              \
+        AP = cs * ap_ - sn * aq_;                                     \
+        AQ = sn * ap_ + cs * aq_;                                     \
+        const double vp_ = VP, vq_ = VQ;                              \
+        VP = cs * vp_ - sn * vq_;                                     \
+        VQ = sn * vp_ + cs * vq_;                                     \
+    }
+// one Jacobi rotation of columns p, q (given as their three entries of A and V); returns |gamma| or 0 when skipped
+#define JAC_PAIR(A0P, A1P, A2P, A0Q, A1Q, A2Q, V0P, V1P, V2P, V0Q, V1Q, V2Q)                                 \
+    {                                                                                                        \
+        double alpha = 0, beta = 0, gamma = 0;                                                               \
+        alpha += A0P * A0P; beta += A0Q * A0Q; gamma += A0P * A0Q;                                           \
+        alpha += A1P * A1P; beta += A1Q * A1Q; gamma += A1P * A1Q;                                           \
+        alpha += A2P * A2P; beta += A2Q * A2Q; gamma += A2P * A2Q;                                           \
+        const double lim = 1e-30 + 1e-16 * sqrt(alpha * beta);                                               \
+        if (!(fabs(gamma) <= lim)) {                                                                         \
+            offmax = fmax(offmax, fabs(gamma));                                                              \
+            const double zeta = (beta - alpha) / (2.0 * gamma);                                              \
+            const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));              \
+            const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;                                          \
+            JAC_ROT(A0P, A0Q, V0P, V0Q) JAC_ROT(A1P, A1Q, V1P, V1Q) JAC_ROT(A2P, A2Q, V2P, V2Q)              \
+        }                                                                                                    \
+    }
+#define JAC_SWAP(X, Y) { const double t_ = X; X = Y; Y = t_; }
+__device__ inline int rigid_from_H_jacobi(const double Hin[9], const double m0[3], const double m1[3], float R[9], float T[3]) {
+    // A = H (columns 0, 1, 2 as a*0, a*1, a*2), V = I
+    double a00 = Hin[0], a01 = Hin[1], a02 = Hin[2], a10 = Hin[3], a11 = Hin[4], a12 = Hin[5], a20 = Hin[6], a21 = Hin[7], a22 = Hin[8];
+    double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
+#pragma unroll 1
     for (int sweep = 0; sweep < 12; ++sweep) {
         double offmax = 0.0;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                double alpha = 0, beta = 0, gamma = 0;
-                for (int r = 0; r < 3; ++r) {
-                    alpha += A[3 * r + p] * A[3 * r + p];
-                    beta += A[3 * r + q] * A[3 * r + q];
-                    gamma += A[3 * r + p] * A[3 * r + q];
-                }
-                const double lim = 1e-30 + 1e-16 * sqrt(alpha * beta);
-                if (fabs(gamma) <= lim) continue;
-                offmax = fmax(offmax, fabs(gamma));
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
-                for (int r = 0; r < 3; ++r) {
-                    const double ap = A[3 * r + p], aq = A[3 * r + q];
-                    A[3 * r + p] = cs * ap - sn * aq;
-                    A[3 * r + q] = sn * ap + cs * aq;
-                    const double vp = V[3 * r + p], vq = V[3 * r + q];
-                    V[3 * r + p] = cs * vp - sn * vq;
-                    V[3 * r + q] = sn * vp + cs * vq;
-                }
-            }
+        JAC_PAIR(a00, a10, a20, a01, a11, a21, v00, v10, v20, v01, v11, v21)  // (p, q) = (0, 1)
+        JAC_PAIR(a00, a10, a20, a02, a12, a22, v00, v10, v20, v02, v12, v22)  // (0, 2)
+        JAC_PAIR(a01, a11, a21, a02, a12, a22, v01, v11, v21, v02, v12, v22)  // (1, 2)
         if (offmax == 0.0) break;
     }
-    // columns of A are u_i * s_i; order by descending s so a (near-)null direction ends up last
-    double s[3];
-    int ord[3] = {0, 1, 2};
-    for (int i = 0; i < 3; ++i) s[i] = sqrt(A[i] * A[i] + A[3 + i] * A[3 + i] + A[6 + i] * A[6 + i]);
-    for (int a = 0; a < 2; ++a)
-        for (int b = a + 1; b < 3; ++b)
-            if (s[ord[b]] > s[ord[a]]) { const int tmp = ord[a]; ord[a] = ord[b]; ord[b] = tmp; }
-    double U[9], W[9];
-    for (int i = 0; i < 3; ++i) {
-        const int cI = ord[i];
-        const double inv = s[cI] > 0 ? 1.0 / s[cI] : 0.0;
-        for (int r = 0; r < 3; ++r) { U[3 * r + i] = A[3 * r + cI] * inv; W[3 * r + i] = V[3 * r + cI]; }
+    // columns of A are u_i * s_i; order by descending s so a (near-)null direction ends up last (the same three
+    // compare-exchanges as a bubble sort of the column order)
+    double s0 = sqrt(a00 * a00 + a10 * a10 + a20 * a20), s1 = sqrt(a01 * a01 + a11 * a11 + a21 * a21), s2 = sqrt(a02 * a02 + a12 * a12 + a22 * a22);
+    if (s1 > s0) { JAC_SWAP(s0, s1) JAC_SWAP(a00, a01) JAC_SWAP(a10, a11) JAC_SWAP(a20, a21) JAC_SWAP(v00, v01) JAC_SWAP(v10, v11) JAC_SWAP(v20, v21) }
+    if (s2 > s0) { JAC_SWAP(s0, s2) JAC_SWAP(a00, a02) JAC_SWAP(a10, a12) JAC_SWAP(a20, a22) JAC_SWAP(v00, v02) JAC_SWAP(v10, v12) JAC_SWAP(v20, v22) }
+    if (s2 > s1) { JAC_SWAP(s1, s2) JAC_SWAP(a01, a02) JAC_SWAP(a11, a12) JAC_SWAP(a21, a22) JAC_SWAP(v01, v02) JAC_SWAP(v11, v12) JAC_SWAP(v21, v22) }
+    const double i0 = s0 > 0 ? 1.0 / s0 : 0.0, i1 = s1 > 0 ? 1.0 / s1 : 0.0, i2 = s2 > 0 ? 1.0 / s2 : 0.0;
+    // U = [u0 u1 u2] (column j = entries u0j, u1j, u2j), W = the matching columns of V
+    double u00 = a00 * i0, u10 = a10 * i0, u20 = a20 * i0, u01 = a01 * i1, u11 = a11 * i1, u21 = a21 * i1, u02 = a02 * i2, u12 = a12 * i2, u22 = a22 * i2;
+    const double tiny = 1e-12 * (s0 > 0 ? s0 : 1.0);
+    if (s1 <= tiny) {  // rank <= 1: any orthonormal completion (the pose is meaningless anyway)
+        double e0 = 1, e1 = 0;
+        const double e2 = 0;
+        if (fabs(u00) > 0.9) { e0 = 0; e1 = 1; }
+        const double d = e0 * u00 + e1 * u10 + e2 * u20;
+        const double w0 = e0 - d * u00, w1 = e1 - d * u10, w2 = e2 - d * u20;
+        const double nv = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+        u01 = w0 / nv; u11 = w1 / nv; u21 = w2 / nv;
     }
-    const double tiny = 1e-12 * (s[ord[0]] > 0 ? s[ord[0]] : 1.0);
-    if (s[ord[1]] <= tiny) {  // rank <= 1: any orthonormal completion (the pose is meaningless anyway)
-        double e[3] = {1, 0, 0};
-        if (fabs(U[0]) > 0.9) { e[0] = 0; e[1] = 1; }
-        double d = e[0] * U[0] + e[1] * U[3] + e[2] * U[6];
-        double v[3] = {e[0] - d * U[0], e[1] - d * U[3], e[2] - d * U[6]};
-        const double nv = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-        for (int r = 0; r < 3; ++r) U[3 * r + 1] = v[r] / nv;
+    if (s2 <= tiny) {  // rank 2: u3 = u1 x u2 (sign is LAPACK-specific in the reference)
+        u02 = u10 * u21 - u20 * u11;
+        u12 = u20 * u01 - u00 * u21;
+        u22 = u00 * u11 - u10 * u01;
     }
-    if (s[ord[2]] <= tiny) {  // rank 2: u3 = u1 x u2 (sign is LAPACK-specific in the reference)
-        U[2] = U[3] * U[7] - U[6] * U[4];
-        U[5] = U[6] * U[1] - U[0] * U[7];
-        U[8] = U[0] * U[4] - U[3] * U[1];
-    }
-    double Rd[9];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) Rd[3 * i + j] = W[3 * i] * U[3 * j] + W[3 * i + 1] * U[3 * j + 1] + W[3 * i + 2] * U[3 * j + 2];
-    const double det = Rd[0] * (Rd[4] * Rd[8] - Rd[5] * Rd[7]) - Rd[1] * (Rd[3] * Rd[8] - Rd[5] * Rd[6]) +
-                       Rd[2] * (Rd[3] * Rd[7] - Rd[4] * Rd[6]);
-    if (det < 0) { Rd[6] = -Rd[6]; Rd[7] = -Rd[7]; Rd[8] = -Rd[8]; }  // :151-155
-    for (int i = 0; i < 9; ++i) R[i] = (float)Rd[i];
-    for (int i = 0; i < 3; ++i)
-        T[i] = (float)(m0[i] - (Rd[3 * i] * m1[0] + Rd[3 * i + 1] * m1[1] + Rd[3 * i + 2] * m1[2]));  // :157
+    // R = W U^T
+    double r0 = v00 * u00 + v01 * u01 + v02 * u02, r1 = v00 * u10 + v01 * u11 + v02 * u12, r2 = v00 * u20 + v01 * u21 + v02 * u22;
+    double r3 = v10 * u00 + v11 * u01 + v12 * u02, r4 = v10 * u10 + v11 * u11 + v12 * u12, r5 = v10 * u20 + v11 * u21 + v12 * u22;
+    double r6 = v20 * u00 + v21 * u01 + v22 * u02, r7 = v20 * u10 + v21 * u11 + v22 * u12, r8 = v20 * u20 + v21 * u21 + v22 * u22;
+    const double det = r0 * (r4 * r8 - r5 * r7) - r1 * (r3 * r8 - r5 * r6) + r2 * (r3 * r7 - r4 * r6);
+    if (det < 0) { r6 = -r6; r7 = -r7; r8 = -r8; }  // :151-155
+    R[0] = (float)r0; R[1] = (float)r1; R[2] = (float)r2; R[3] = (float)r3; R[4] = (float)r4; R[5] = (float)r5;
+    R[6] = (float)r6; R[7] = (float)r7; R[8] = (float)r8;
+    T[0] = (float)(m0[0] - (r0 * m1[0] + r1 * m1[1] + r2 * m1[2]));  // :157
+    T[1] = (float)(m0[1] - (r3 * m1[0] + r4 * m1[1] + r5 * m1[2]));
+    T[2] = (float)(m0[2] - (r6 * m1[0] + r7 * m1[1] + r8 * m1[2]));
     return det < 0 ? -1 : 1;  // isCredible (:139,:152)
 }
 
@@ -528,26 +466,21 @@ CAELO_API int caelo_solve_rt(caelo_ctx *c, const float *p0, const float *p1, int
 // ------------------------------------------------------------------------------------------------
 // RANSAC
 // ------------------------------------------------------------------------------------------------
+// workspace of one pair: the inlier counts of the 500 hypotheses of the level being replayed.  Written by one kernel,
+// read by the next (k_ransac_hyp -> k_ransac_finish) or inside one workgroup: nothing to initialise, nothing to clean.
 struct RansacWs {
     int32_t counts[CAELO_RANSAC_MAX_TRIALS];
-    int32_t done;        // 1 once a level succeeded
-    int32_t level_used;
-    int32_t best_trial;  // within level_used
-    int32_t iterations;
-    int32_t success;
-    float threshold;
-    // The three below are zero between calls (the workspace is zero-filled once by its owner, every call leaves
-    // it clean again -- no memset launch in the pair chain):
-    int32_t arrived[CAELO_RANSAC_LEVELS];  // workgroups finished per level (the last one replays the rules, then resets it)
-    int32_t finished;                      // the pose record is complete: later launches return at once
-    int32_t exited;                        // last launch: workgroups that saw `finished`; the last of them resets both
 };
 
 CAELO_API int64_t caelo_ransac_ws_bytes(void) { return (int64_t)sizeof(RansacWs); }
 
+struct RansacVerdict {
+    int iterations, success, best_trial;  // best_trial within the level, -1 = none accepted
+};
+
 // sequential accept / exit rules of Match.py:166-169,:181,:195-214 replayed over the counts (one wave:
 // the counts are staged in LDS, lane 0 walks them)
-__device__ void ransac_replay(int N, int level, RansacWs *ws, int *s_counts) {
+__device__ void ransac_replay(int N, const int32_t *counts, RansacVerdict *out) {
     // The loop of :181-206 keeps the running maximum of the admissible counts (strict >: the FIRST
     // occurrence wins) and stops at the first iteration it >= 100 whose running maximum reached
     // 0.25 N, or at 500.  Restated as a prefix-max scan so one wavefront does it in parallel:
@@ -563,7 +496,7 @@ __device__ void ransac_replay(int N, int level, RansacWs *ws, int *s_counts) {
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const int i = lane * PER + q;
-        int v = i < CAELO_RANSAC_MAX_TRIALS ? __hip_atomic_load(&ws->counts[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        int v = i < CAELO_RANSAC_MAX_TRIALS ? counts[i] : 0;
         v = v >= least ? v : 0;
         c[q] = v;
         run = run > v ? run : v;
@@ -604,13 +537,9 @@ __device__ void ransac_replay(int N, int level, RansacWs *ws, int *s_counts) {
     for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(best, o); best = best < t ? best : t; }
     if (lane != 0) return;
     const int success = (target > 0) || (least <= 0);  // leastInliers == 0 admits every hypothesis
-    ws->iterations = stop;
-    ws->threshold = 0.4f * (float)(1 << level);
-    ws->success = success;
-    ws->level_used = level;
-    ws->best_trial = (success && target > 0) ? best : -1;  // N < 5: success without any accepted hypothesis -> identity (:177)
-    if (success) ws->done = 1;
-    (void)s_counts;
+    out->iterations = stop;
+    out->success = success;
+    out->best_trial = (success && target > 0) ? best : -1;  // N < 5: success without any accepted hypothesis -> identity (:177)
 }
 
 // hypothesis from 4 sampled pairs (SolveRT on the sample, Match.py:141-157; means / centring in f32 like
@@ -648,50 +577,52 @@ __device__ inline void sample_hypothesis(const float *P0, int l0, const int64_t 
     rigid_from_H(H, m0, m1, R, T);
 }
 
-// One launch per threshold level (0.4 / 0.8 / 1.6 m).  Workgroup = 4 wavefronts = 4 hypotheses.
-//   1. the matched pairs (P0[pair_idx[i]], P1[i]) are gathered once per workgroup into LDS (coalesced; the
-//      per-hypothesis residual loops then never touch global memory);
-//   2. one wavefront per hypothesis: Kabsch on the 4-sample, residuals, ballot + popcount inlier count;
-//   3. the last workgroup to arrive (one ticket per workgroup; counts published with write-through
-//      stores, read with agent-scope loads) replays the sequential accept rules in parallel;
-//   4. if the level succeeded -- or it was the last one -- the same workgroup records the winner (recomputed from its
-//      sample: R_star, T_star, threshold, iteration count).  Later level launches see `finished` and return at once.
-// k_ransac_finish (one workgroup per pair, after the three level launches) writes the inlier mask of the winner and
-// refits over all inliers (Match.py:273-282).  Round 1 did that inside the finishing workgroup of the level kernel,
-// from the pairs it had staged in LDS; under concurrent streams ~1 call in 3 000 then stored 64-element runs of
-// constant 0 / 1 from some of its wavefronts although the inlier COUNT summed from the same registers was right
-// (tools/stress_mask.py: sentinel-filled buffer, D2H cross-check, exactly one replay per call counted) -- the
-// "3 of 41 suite runs" of round 1.  The hand-off protocol was not involved.  A kernel of its own that reads the
-// pairs from global memory shows 0 mismatches in 72 000 frames; DESIGN.md 4.4 has the measurements.
+// Two launches per set of pairs.
+//   k_ransac_hyp     the 500 hypotheses of the first threshold level (0.4 m), one wavefront each, 4 per workgroup:
+//                    the matched pairs (P0[pair_idx[i]], P1[i]) are gathered once per workgroup into LDS (coalesced;
+//                    the residual loops then never touch global memory), Kabsch on the 4-sample, residuals, ballot +
+//                    popcount inlier count -> counts[trial].
+//   k_ransac_finish  one workgroup per pair: replays the sequential accept / early-exit rules over the counts
+//                    (Match.py:181-206) as a prefix maximum; if the level failed (no hypothesis reached leastInliers,
+//                    :207-214) it evaluates the next level's 500 hypotheses itself -- rare, so its four wavefronts
+//                    are enough -- up to 1.6 m; then the winner's pose, the inlier mask (:193-194), the inlier count
+//                    and the refit over all inliers (:273-282).
+// Everything that crosses workgroups crosses a kernel boundary.  Round 1 finished inside the last workgroup of a
+// per-level launch (tickets, a `finished` flag, a self-cleaning workspace) and evaluated the mask from the pairs that
+// workgroup had staged in LDS; under concurrent streams ~1 call in 3 000 then stored 64-element runs of constant 0 / 1
+// from some of its wavefronts although the inlier COUNT summed from the same registers was right (tools/stress_mask.py:
+// sentinel-filled buffer, D2H cross-check, exactly one replay per call counted) -- the "3 of 41 suite runs" of round 1.
+// The hand-off protocol was not involved.  This structure shows 0 mismatches in 72 000 frames.
 #define RE_WAVES 4
 #define RE_LDS_PAIRS 1024
 
-template <int level>
-__global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_level(const caelo_pair_set ps, int ld0, int ld1, int64_t k1_max) {
+// inlier count of one hypothesis by one wavefront (every lane returns it)
+__device__ inline int hypothesis_count(const float *P0, int l0, const int64_t *pidx, const float *P1, int l1, int N, const double *r4,
+                                       float thr, int lane) {
+    float R[9], T[3];
+    sample_hypothesis(P0, l0, pidx, P1, l1, N, r4, R, T);
+    int cnt = 0;  // residuals + inlier count (:191-194): ballot + popcount per 64 pairs
+    for (int i = lane; i < ((N + 63) & ~63); i += 64) {
+        bool in = false;
+        if (i < N) {
+            const float *a = P0 + (size_t)l0 * (pidx ? pidx[i] : i);
+            const float *b = P1 + (size_t)l1 * i;
+            in = residual(R, T, a[0], a[1], a[2], b[0], b[1], b[2]) < thr;
+        }
+        cnt += __popcll(__ballot(in));
+    }
+    return cnt;
+}
+
+__global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp(const caelo_pair_set ps, int ld0, int ld1, int64_t k1_max) {
     const caelo_pair_dev &P = ps.p[blockIdx.z];
     const float *__restrict__ pc0 = P.pc0, *__restrict__ pc1 = P.pc1;
     const int64_t *__restrict__ pair_idx = P.pair_idx;
-    const int32_t *n1p = P.n1;
-    const double *__restrict__ rnd = P.rand;
     RansacWs *ws = (RansacWs *)P.ws_ransac;
-    caelo_pose_result *res = P.result;
     __shared__ float sP0[RE_LDS_PAIRS * 3], sP1[RE_LDS_PAIRS * 3];
-    __shared__ int s_counts[4];
-    __shared__ int s_last, s_best, s_success;
-    __shared__ float Rs[9], Ts[3];
-    if (__hip_atomic_load(&ws->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-        // an earlier level completed the record.  In the last launch every workgroup passes through here, so the
-        // last one to do so knows nobody will read `finished` again and clears it for the next call.
-        if (level == CAELO_RANSAC_LEVELS - 1 && threadIdx.x == 0 && atomicAdd(&ws->exited, 1) == (int)gridDim.x - 1) {
-            ws->exited = 0;
-            __hip_atomic_store(&ws->finished, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
-    }
-    const int N = n1p ? min(max(*n1p, 0), (int)k1_max) : (int)k1_max;
+    const int N = P.n1 ? min(max(*P.n1, 0), (int)k1_max) : (int)k1_max;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float thr = 0.4f * (float)(1 << level);  // 0.4, 0.8, 1.6 (:171,:210)
-    // ---- 1. pairs -> LDS (falls back to the global arrays when they do not fit)
+    // pairs -> LDS (falls back to the global arrays when they do not fit)
     const bool in_lds = N <= RE_LDS_PAIRS;
     if (in_lds) {
         for (int i = tid; i < N; i += 64 * RE_WAVES) {
@@ -702,85 +633,55 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_level(const caelo_pair
         }
     }
     __syncthreads();
-    const float *P0 = in_lds ? sP0 : pc0, *P1 = in_lds ? sP1 : pc1;
-    const int l0 = in_lds ? 3 : ld0, l1 = in_lds ? 3 : ld1;
-    const int64_t *pidx = in_lds ? nullptr : pair_idx;
-    // ---- 2. this wavefront's hypothesis
     const int trial = blockIdx.x * RE_WAVES + wave;
-    {
-        float R[9], T[3];
-        sample_hypothesis(P0, l0, pidx, P1, l1, N, rnd + ((size_t)level * CAELO_RANSAC_MAX_TRIALS + trial) * 4, R, T);
-        int cnt = 0;  // residuals + inlier count (:191-194): ballot + popcount per 64 pairs
-        for (int i = lane; i < ((N + 63) & ~63); i += 64) {
-            bool in = false;
-            if (i < N) {
-                const float *a = P0 + (size_t)l0 * (pidx ? pidx[i] : i);
-                const float *b = P1 + (size_t)l1 * i;
-                in = residual(R, T, a[0], a[1], a[2], b[0], b[1], b[2]) < thr;
-            }
-            cnt += __popcll(__ballot(in));
-        }
-        if (lane == 0) {
-            // read by the last workgroup of this launch: agent-scope store, complete before the arrival ticket; the
-            // reader uses agent-scope loads (see XWG_* above)
-            __hip_atomic_store(&ws->counts[trial], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            XWG_RELEASE();
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        s_last = XWG_TICKET(&ws->arrived[level]) == CAELO_RANSAC_MAX_TRIALS / RE_WAVES - 1;
-        if (s_last) ws->arrived[level] = 0;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    XWG_ACQUIRE();
-    // ---- 3. accept rules
-    if (tid < 64) ransac_replay(N, level, ws, s_counts);
-    __syncthreads();
-    if (tid == 0) { s_success = ws->success; s_best = ws->best_trial; }
-    __syncthreads();
-    const int success = s_success, best = s_best;
-    if (!success && level < CAELO_RANSAC_LEVELS - 1) return;  // escalate: the next launch doubles the threshold
-    // ---- 4. finish: the winner is recomputed here (deterministic), identity if every level failed (:177)
-    if (tid < 64) {
-        float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, T[3] = {0.f, 0.f, 0.f};
-        if (best >= 0) sample_hypothesis(P0, l0, pidx, P1, l1, N, rnd + ((size_t)level * CAELO_RANSAC_MAX_TRIALS + best) * 4, R, T);
-        if (tid < 9) Rs[tid] = R[tid];
-        if (tid < 3) Ts[tid] = T[tid];
-    }
-    __syncthreads();
-    if (tid < 9) res->R_ransac[tid] = Rs[tid];
-    if (tid < 3) res->T_ransac[tid] = Ts[tid];
-    if (tid == 0) {
-        res->threshold = thr;
-        res->success = success;
-        res->iterations = ws->iterations;
-        res->best_trial = best >= 0 ? level * CAELO_RANSAC_MAX_TRIALS + best : -1;
-        res->n_pairs = N;
-        if (level < CAELO_RANSAC_LEVELS - 1)  // the last level has no later launch to stop
-            __hip_atomic_store(&ws->finished, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    int cnt;
+    if (in_lds) cnt = hypothesis_count(sP0, 3, nullptr, sP1, 3, N, P.rand + (size_t)trial * 4, 0.4f, lane);
+    else cnt = hypothesis_count(pc0, ld0, pair_idx, pc1, ld1, N, P.rand + (size_t)trial * 4, 0.4f, lane);
+    if (lane == 0) ws->counts[trial] = cnt;
 }
 
-// After the three level launches: the inlier mask of the winning hypothesis (Match.py:193-194 with R_star, T_star and
-// the final threshold), the inlier count and the refit over all inliers (Match.py:273-282).  One workgroup per pair.
 __global__ void __launch_bounds__(256) k_ransac_finish(const caelo_pair_set ps, int ld0, int ld1, int64_t k1_max) {
     const caelo_pair_dev &P = ps.p[blockIdx.z];
     const float *__restrict__ pc0 = P.pc0, *__restrict__ pc1 = P.pc1;
     const int64_t *__restrict__ pair_idx = P.pair_idx;
+    const double *__restrict__ rnd = P.rand;
+    RansacWs *ws = (RansacWs *)P.ws_ransac;
     caelo_pose_result *res = P.result;
     uint8_t *mask = P.mask;
     __shared__ float Rs[9], Ts[3];
     __shared__ int s_nin;
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ RansacVerdict s_v;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = P.n1 ? min(max(*P.n1, 0), (int)k1_max) : (int)k1_max;
-    if (tid < 9) Rs[tid] = res->R_ransac[tid];
-    if (tid < 3) Ts[tid] = res->T_ransac[tid];
+    // ---- accept rules, level by level (:207-214: thr doubles while no hypothesis reaches leastInliers, up to 1.6)
+    int level = 0;
+    for (;; ++level) {
+        if (level > 0) {  // rare: this level's 500 hypotheses, one wavefront each, four at a time
+            const float thr_l = 0.4f * (float)(1 << level);
+            for (int trial = wave; trial < CAELO_RANSAC_MAX_TRIALS; trial += 4) {
+                const int cnt = hypothesis_count(pc0, ld0, pair_idx, pc1, ld1, N, rnd + ((size_t)level * CAELO_RANSAC_MAX_TRIALS + trial) * 4,
+                                                 thr_l, lane);
+                if (lane == 0) ws->counts[trial] = cnt;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        if (tid < 64) ransac_replay(N, ws->counts, &s_v);
+        __syncthreads();
+        if (s_v.success || level == CAELO_RANSAC_LEVELS - 1) break;
+        __syncthreads();  // everyone has read s_v before the next level overwrites it
+    }
+    const int success = s_v.success, best = s_v.best_trial;
+    const float thr = 0.4f * (float)(1 << level);  // 0.4, 0.8, 1.6 (:171,:210)
+    // ---- the winner is recomputed from its sample (deterministic), identity if every level failed (:177)
+    if (tid < 64) {
+        float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, T[3] = {0.f, 0.f, 0.f};
+        if (best >= 0) sample_hypothesis(pc0, ld0, pair_idx, pc1, ld1, N, rnd + ((size_t)level * CAELO_RANSAC_MAX_TRIALS + best) * 4, R, T);
+        if (tid < 9) Rs[tid] = R[tid];
+        if (tid < 3) Ts[tid] = T[tid];
+    }
     if (tid == 0) s_nin = 0;
     __syncthreads();
-    const float thr = res->threshold;
-    const bool have = res->best_trial >= 0;
     int local = 0;
     // four consecutive pairs per thread, one aligned 32-bit store: the whole mask row goes out as full dwords
     const bool word_ok = (((uintptr_t)mask) & 3u) == 0;
@@ -790,7 +691,7 @@ __global__ void __launch_bounds__(256) k_ransac_finish(const caelo_pair_set ps, 
         for (int q = 0; q < 4; ++q) {
             const int i = i0 + q;
             unsigned int in = 0;
-            if (i < N && have) {
+            if (i < N && best >= 0) {
                 const float *a = pc0 + (size_t)ld0 * pair_idx[i];
                 const float *b = pc1 + (size_t)ld1 * i;
                 in = residual(Rs, Ts, a[0], a[1], a[2], b[0], b[1], b[2]) < thr ? 1u : 0u;
@@ -806,9 +707,16 @@ __global__ void __launch_bounds__(256) k_ransac_finish(const caelo_pair_set ps, 
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
     if (lane == 0) atomicAdd(&s_nin, local);
     __syncthreads();
-    if (tid < 9) res->R[tid] = Rs[tid];
-    if (tid < 3) res->T[tid] = Ts[tid];
-    if (tid == 0) res->n_inliers = s_nin;
+    if (tid < 9) { res->R_ransac[tid] = Rs[tid]; res->R[tid] = Rs[tid]; }
+    if (tid < 3) { res->T_ransac[tid] = Ts[tid]; res->T[tid] = Ts[tid]; }
+    if (tid == 0) {
+        res->threshold = thr;
+        res->success = success;
+        res->iterations = s_v.iterations;
+        res->n_inliers = s_nin;
+        res->best_trial = best >= 0 ? level * CAELO_RANSAC_MAX_TRIALS + best : -1;
+        res->n_pairs = N;
+    }
     __syncthreads();
     if (s_nin > 0) fit_block(pc0, ld0, pair_idx, pc1, ld1, mask, N, res->R, res->T, nullptr);  // :277-282
 }
@@ -828,15 +736,7 @@ CAELO_API int caelo_ransac(caelo_ctx *c, const float *pc0, int ld0, const float 
 int ransac_set(const caelo_pair_set &ps, int ld0, int ld1, int64_t k1_max, hipStream_t s) {
     CAELO_REQUIRE(ps.n >= 1 && ps.n <= CAELO_FB_MAX, "bad pair count");
     CAELO_REQUIRE(k1_max > 0 && ld0 >= 3 && ld1 >= 3, "bad shape");
-    // the threshold level is a template parameter, not a kernel argument: the three launches then have IDENTICAL
-    // argument blocks (see DESIGN.md 4.4 for the stale-argument observation that motivated this)
-    const dim3 grid(CAELO_RANSAC_MAX_TRIALS / RE_WAVES, 1, ps.n);
-    static_assert(CAELO_RANSAC_LEVELS == 3, "one instantiation per threshold level");
-    k_ransac_level<0><<<grid, 64 * RE_WAVES, 0, s>>>(ps, ld0, ld1, k1_max);
-    CAELO_LAUNCH_CHECK();
-    k_ransac_level<1><<<grid, 64 * RE_WAVES, 0, s>>>(ps, ld0, ld1, k1_max);
-    CAELO_LAUNCH_CHECK();
-    k_ransac_level<2><<<grid, 64 * RE_WAVES, 0, s>>>(ps, ld0, ld1, k1_max);
+    k_ransac_hyp<<<dim3(CAELO_RANSAC_MAX_TRIALS / RE_WAVES, 1, ps.n), 64 * RE_WAVES, 0, s>>>(ps, ld0, ld1, k1_max);
     CAELO_LAUNCH_CHECK();
     k_ransac_finish<<<dim3(1, 1, ps.n), 256, 0, s>>>(ps, ld0, ld1, k1_max);
     CAELO_LAUNCH_CHECK();

@@ -161,10 +161,8 @@ int caelo_encode_profile(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches
 /* NN match  (Match.py:257-258): pair_idx[j] = argmin_i ||f0[i]-f1[j]|| (f64, first minimum).
  * f0 [k0][ld0], f1 [k1][ld1] (leading dimensions in floats, >= dim, dim <= 64); k0/k1 read from the
  * n0/n1 device words when non-null.
- * ws: caelo_match_ws_bytes(k1_max) bytes, 256-byte aligned (tickets + partial results of the row slices).
- * The owner zero-fills ws ONCE (hipMemset) before its first use; every call leaves the tickets zero again, so
- * no per-call clear is launched.  One ws per (stream, k1_max): calls sharing a ws must be stream-ordered and use the
- * same k1_max (the ticket region's size follows k1_max). */
+ * ws: caelo_match_ws_bytes(k1_max) bytes (two statistics counters the calls only add to: columns re-scanned exactly,
+ * columns decided between two rows); zero-fill it once if you read them.  Nothing crosses workgroups. */
 int64_t caelo_match_ws_bytes(int64_t k1_max);
 int caelo_match(caelo_ctx *ctx, const float *f0, int ld0, int64_t k0_max, const int32_t *n0, const float *f1, int ld1,
                 int64_t k1_max, const int32_t *n1, int dim, int64_t *pair_idx, void *ws, void *stream);
@@ -177,9 +175,9 @@ int caelo_solve_rt(caelo_ctx *ctx, const float *p0, const float *p1, int64_t n, 
 /* RANSAC4RT + SolveRelativePose tail  (Match.py:162-218, :260-283).
  * pc0 [k0][ld0], pc1 [k1][ld1] (xyz in the first 3 columns), pair_idx [k1]; rand [3*500][4] f64 = the uniform doubles the
  * reference's np.random.random((4,)) would return, in consumption order.
- * result (device, caelo_pose_result) + inlier mask [k1_max] u8.  workspace ws:
- * caelo_ransac_ws_bytes() bytes; like the match workspace it is zero-filled once by its owner (hipMemset) and
- * left clean by every call. */
+ * result (device, caelo_pose_result) + inlier mask [k1_max] u8 (4-byte aligned for dword stores).  workspace ws:
+ * caelo_ransac_ws_bytes() bytes (the hypotheses' inlier counts between the two kernels of a call; no
+ * initialisation), one ws per call in flight. */
 typedef struct {
     float R[9];           /* final refit rotation, row-major */
     float T[3];
