@@ -52,7 +52,12 @@ FLOP_CONV2 = 2 * 512 * 216 * 16
 FLOP_CONV3 = 2 * 64 * 432 * 32
 FLOP_DENSE1 = 2 * 2048 * 200
 FLOP_DENSE2 = 2 * 200 * 20
-F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 matrix peak
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input matrix peak (v_mfma_f32_16x16x4_f32)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak (v_mfma_f32_16x16x32_bf16)
+# conv3 / Dense(200) evaluate every f32 product as SIX bf16 x bf16 partial products on the bf16 pipe:
+# the ceiling for their f32-equivalent (algorithmic) rate is the bf16 peak / 6
+X3_F32_EQUIV_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+FLOP_PER_MFMA_F32 = 2 * 16 * 16 * 4
 
 
 def cpu_baseline(n_frames=16, max_seconds=30.0):
@@ -88,6 +93,107 @@ def cpu_baseline(n_frames=16, max_seconds=30.0):
                       "match+RANSAC, oracle C/NumPy restatement with OpenMP on %d threads, %.1f s" % (done, cores, dt)}
 
 
+def bench_dense128(args, eng, world, rank, backend, dev):
+    """BASELINE configs[4]: synthetic 128-beam x 4000-azimuth scan (~507 k points), 32^3 voxel patches (the 3D-conv MFMA
+    stress; DESIGN.md 4.5 states the definition).  A step = one scan: key points by the 16^3 path, 3 x 1024 patches of
+    32^3 voxels, the encoder stack on them.  One stream; every rank runs its own frames (weak scaling)."""
+    K, W = args.steps, args.warmup
+    pool = [torch.from_numpy(synth.make_scan((rank * 7 + i) % 997, n_beams=128, n_az=4000, quantum=QUANTUM)).to(dev) for i in range(2)]
+    wd1, bd1 = eng.seeded_dense1_32()
+    eng.set_encoder32_dense(wd1, bd1)
+    big = max(p.shape[0] for p in pool)
+    for p in pool:
+        eng.extract32(p)
+    torch.cuda.synchronize()
+    for i in range(W):
+        eng.extract32(pool[i % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        ff = eng.extract32(pool[i % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        vmap = eng.voxmap(max(eng.max_points, big))
+        eng.voxelize(pool[0], vmap)
+        bits = eng.patches32(vmap, ff.key_pts.contiguous(), ff.n_key)
+        for _ in range(2):
+            eng.encode32_profile(bits, group=3)
+        ms = np.array([eng.encode32_profile(bits, group=3)[1] for _ in range(8)]).mean(axis=0)
+        npat = bits.numel() // 512
+        # dense FLOPs per 32^3 patch (2 x MACs): conv1 32^3 x 27 x 8, conv2 16^3 x 216 x 16, conv3 8^3 x 432 x 32, dense 16384 x 200 (+ 200 x 20)
+        flops = npat * np.array([2 * 32768 * 27 * 8, 2 * 4096 * 216 * 16, 2 * 512 * 432 * 32, 2 * 16384 * 200 + 2 * 200 * 20], dtype=np.float64)
+        names = ["k5_conv1pool_x3", "k5_conv2_x3", "k5_conv3_x3", "k_enc_dense1<16384> + k_enc_head"]
+        # conv1's input is binary (exact in bf16): 3 bf16 MFMAs per product block; the other layers 6
+        peaks = [BF16_MFMA_PEAK_TFLOPS / 3.0, X3_F32_EQUIV_PEAK_TFLOPS, X3_F32_EQUIV_PEAK_TFLOPS, X3_F32_EQUIV_PEAK_TFLOPS]
+        tf = flops / (ms * 1e-3) / 1e12
+        dom = int(np.argmax(ms))
+        table = {n: {"ms": round(float(m), 4), "f32_equiv_tflops": round(float(t), 2), "pipe_peak": round(pk, 1), "pipe_frac": round(float(t / pk), 4)}
+                 for n, m, t, pk in zip(names, ms, tf, peaks)}
+        roofline = {"bound": "mfma", "kernel": names[dom], "achieved": round(float(tf[dom]), 2), "peak": round(peaks[dom], 1),
+                    "unit": "TFLOP/s", "frac": round(float(tf[dom] / peaks[dom]), 4), "traffic": None,
+                    "launch_ms": round(float(ms[dom]), 4),
+                    "achieved_is": "dense (= executed: these kernels skip nothing) f32-equivalent FLOPs of the layer / launch time, "
+                                   "against the bf16 matrix peak / 6 (six bf16 MFMAs per f32 product block, DESIGN.md 4.6)",
+                    "encoder_kernels": table, "encoder_total_ms": round(float(ms.sum()), 4),
+                    "encoder_total_f32_equiv_tflops": round(float(flops.sum() / (ms.sum() * 1e-3) / 1e12), 2)}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline_dense128()
+        print(json.dumps({
+            "metric": "frames/sec keypoint + 32^3-patch descriptor extraction, 128-beam dense scan (configs[4])",
+            "value": round(world * K / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[4]: synthetic 128-beam x 4000-azimuth scan, 2x voxel-patch resolution (32^3), 1 mm "
+                                   "coordinates; not a reference code path (PatchSize = 16 there): definition in DESIGN.md 4.5",
+                       "arithmetic": "f32 in / out / accumulate; every conv / dense product as exact bf16 partial products on the bf16 "
+                                     "matrix pipe (f32-grade, DESIGN.md 4.6)",
+                       "points_per_frame": int(pool[0].shape[0]), "keypoints": int(ff.n_key.item()), "patches_per_frame": int(npat),
+                       "patch_voxels": 32768, "frames_per_gpu": K, "parallelism": "frames sharded x%d, no collective" % world},
+            "roofline": roofline, "cpu_baseline": cpu}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline_dense128(n_patches=96):
+    """CPU oracle of the 32^3 encoder on a bounded sample, scaled to a frame (3072 patches); the front stages (ring image,
+    response, key points, voxelization) are timed on one whole frame."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle as orc
+    resp_m, enc_m = orc.load_models(os.path.join(REPO, "weights", "SphericalRingPCRespondLayer.h5"),
+                                    os.path.join(REPO, "weights", "EncoderModel4VoxelPatch.h5"))
+    from caelo.engine import Engine as _E
+    wd1, bd1 = _E.seeded_dense1_32()
+    enc32 = orc.PatchEncoder32(enc_m.w, wd1, bd1)
+    pc = synth.make_scan(0, n_beams=128, n_az=4000, quantum=QUANTUM)
+    t0 = time.time()
+    ring, cnt = orc.ProjectPC2SphericalRing(pc)
+    resp = resp_m.predict(ring[None, 0:64, 0:1792, 0:3])[0]
+    kp, _, _ = orc.GetKeyPtsByAE(ring, cnt, resp)
+    v = orc.Voxelization(pc[:, 0:3])
+    t_front = time.time() - t0
+    t0 = time.time()
+    per = n_patches // 3
+    for s_ in range(3):
+        enc32.predict_bits(orc.patches32_bits(kp[:per], v[6 + s_], s_))
+    t_enc = (time.time() - t0) * (3 * len(kp)) / (3 * per)
+    return {"value": round(1.0 / (t_front + t_enc), 4), "unit": "frames/s", "cores": int(orc.num_threads()), "kind": "port",
+            "sample": "front stages of one 128-beam frame (%.1f s) + the 32^3 oracle encoder on %d of its %d patches scaled to the "
+                      "frame (%.1f s), oracle C/NumPy restatement with OpenMP on %d threads" % (t_front, 3 * per, 3 * len(kp), t_enc, orc.num_threads())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,12 +203,18 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="frames per launch (1..8): the front kernels, the encoder launch "
                                                          "set and the match / RANSAC launches each cover a whole batch")
     ap.add_argument("--buffers", type=int, default=3, help="batches of patches in flight between the front and the encoder")
-    ap.add_argument("--extract-only", action="store_true",
-                    help="BASELINE configs[1]: keypoints + descriptors only (no match / RANSAC); not the headline metric")
+    ap.add_argument("--config", choices=("odometry", "extract", "dense128"), default="odometry",
+                    help="odometry = BASELINE configs[2] (the headline metric); extract = configs[1] (keypoints + descriptors "
+                         "only); dense128 = configs[4] (128-beam x 4000-azimuth scan, 32^3 patches: 3D-conv MFMA stress)")
+    ap.add_argument("--extract-only", action="store_true", help="same as --config extract")
     ap.add_argument("--gather", choices=("boundary", "all"), default="boundary",
                     help="rows moved by the single all-gather: each rank's last frame (all that consecutive-pair "
                          "matching needs) or every frame")
     args = ap.parse_args()
+    if args.config == "extract":
+        args.extract_only = True
+    elif args.extract_only:
+        args.config = "extract"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -119,6 +231,10 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     eng = Engine(device=local_rank)
+    if args.config == "dense128":
+        if world > 1:
+            dist.init_process_group(backend=backend, **({"device_id": dev} if backend == "nccl" else {}))
+        return bench_dense128(args, eng, world, rank, backend, dev)
     pipe = eng.pipeline(args.batch, args.buffers)
     if world > 1:
         dist.init_process_group(backend=backend, **({"device_id": dev} if backend == "nccl" else {}))
@@ -189,37 +305,56 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel, HIP events on the launch stream ----------------------
+        # ---- roofline of the encoder kernels, HIP events on the launch stream, ONE frame (all 3072 patches) per launch
         bits, _ = eng.patches(eng.voxelize(pool[0])[0], eng.extract(pool[0]).key_pts.contiguous())
         n_patches = bits.numel() // 64
         for _ in range(3):
             eng.encode_profile(bits, group=3)
-        ms = np.array([eng.encode_profile(bits, group=3)[1] for _ in range(20)])
-        ms_avg = ms.mean(axis=0)
+        prof = np.array([eng.encode_profile(bits, group=3)[1] for _ in range(20)])
+        ms_avg = prof[:, 0:4].mean(axis=0)
+        mfma_exec = float(prof[:, 4].mean()) * 1e6                    # conv2 MFMAs stage 1 executed (counted by the kernel)
+        mfma_dense = n_patches * 32 * 27 * 2                           # ... of a dense conv2: 32 m-tiles x 27 taps x 2 k-steps
         flops = n_patches * np.array([FLOP_CONV1 + FLOP_CONV2, FLOP_CONV3, FLOP_DENSE1, FLOP_DENSE2])
-        dom = int(np.argmax(ms_avg))
         names = ["k_enc_stage1", "k_enc_conv3", "k_enc_dense1", "k_enc_head"]
-        achieved = flops[dom] / (ms_avg[dom] * 1e-3) / 1e12
-        # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the per-launch
-        # FETCH_SIZE / WRITE_SIZE of the same command (two separate rocprofv3 --pmc passes) are committed
-        # under profiles/ and quoted here.  hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024, uncorrected.
+        dom = int(np.argmax(ms_avg))
+        alg_tf = flops / (ms_avg * 1e-3) / 1e12
+        # what each kernel's matrix pipe actually did, against the peak of THAT pipe (always <= 1):
+        #   stage 1: executed f32 MFMAs (it skips all-background rows exactly; conv1 runs on the VALU and is not counted)
+        #   conv3 / Dense(200): f32-equivalent rate against bf16 peak / 6 (six bf16 MFMAs per f32 product block)
+        exec_tf = [mfma_exec * FLOP_PER_MFMA_F32 / (ms_avg[0] * 1e-3) / 1e12, alg_tf[1], alg_tf[2], None]
+        peaks = [F32_MFMA_PEAK_TFLOPS, X3_F32_EQUIV_PEAK_TFLOPS, X3_F32_EQUIV_PEAK_TFLOPS, None]
+        table = {}
+        for i, nme in enumerate(names):
+            table[nme] = {"ms": round(float(ms_avg[i]), 4), "algorithmic_tflops": round(float(alg_tf[i]), 2)}
+            if peaks[i]:
+                table[nme].update({"pipe_tflops": round(float(exec_tf[i]), 2), "pipe_peak": round(peaks[i], 1),
+                                   "pipe_frac": round(float(exec_tf[i] / peaks[i]), 4)})
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; the per-launch
+        # FETCH_SIZE / WRITE_SIZE of the same launch (separate rocprofv3 --pmc passes) are committed under profiles/.
         traffic, traffic_note = None, None
-        try:
-            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic_v52.json")))
-            k = pmc["kernels"][names[dom]]
-            traffic = int((k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024)
-            traffic_note = "profiles/r01_pmc_traffic_v52.json (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; bytes per launch)"
-        except Exception:
-            pass
-        roofline = {"bound": "mfma", "kernel": names[dom], "achieved": round(float(achieved), 3),
-                    "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(float(achieved / F32_MFMA_PEAK_TFLOPS), 4),
+        for pmc_file in ("r02_pmc_traffic.json", "r01_pmc_traffic_v52.json"):
+            try:
+                pmc = json.load(open(os.path.join(REPO, "profiles", pmc_file)))
+                k = pmc["kernels"][names[dom]]
+                traffic = int((k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024)
+                traffic_note = "profiles/%s (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; bytes per launch)" % pmc_file
+                break
+            except Exception:
+                pass
+        roofline = {"bound": "mfma", "kernel": names[dom], "achieved": table[names[dom]]["pipe_tflops"],
+                    "peak": table[names[dom]]["pipe_peak"], "unit": "TFLOP/s", "frac": table[names[dom]]["pipe_frac"],
                     "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_note,
-                    "note": "achieved = ALGORITHMIC (dense Keras) FLOPs / measured launch time; the kernel skips the conv2 "
-                            "products whose input rows equal the all-background response (exact), so frac can exceed 1; "
-                            "executed MFMA share and per-kernel PMC in DESIGN.md section 4",
-                    "launch_ms": round(float(ms_avg[dom]), 4), "flops_per_launch": int(flops[dom]),
-                    "encoder_kernels_ms": {n: round(float(m), 4) for n, m in zip(names, ms_avg)},
-                    "encoder_total_tflops": round(float(flops.sum() / (ms_avg.sum() * 1e-3) / 1e12), 3)}
+                    "launch_ms": round(float(ms_avg[dom]), 4),
+                    "achieved_is": "FLOPs of the MFMA instructions the kernel EXECUTED (counted by the kernel) / launch time, against "
+                                   "the peak of the pipe they run on; always <= 1",
+                    "algorithmic_tflops": round(float(alg_tf[dom]), 2),
+                    "algorithmic_note": "dense Keras FLOPs of the layers the kernel replaces / launch time; stage 1 executes %.1f %% of "
+                                        "the dense conv2 MFMAs (all-background rows add exact zeros and are skipped) and conv1 on the "
+                                        "VALU, so this figure can exceed the f32 pipe's %.1f TFLOP/s and is NOT a roofline fraction" % (
+                                            100.0 * mfma_exec / mfma_dense, F32_MFMA_PEAK_TFLOPS),
+                    "executed_mfma_share": round(mfma_exec / mfma_dense, 4),
+                    "encoder_kernels": table,
+                    "encoder_total_ms_all_patches": round(float(ms_avg.sum()), 4)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()

@@ -63,6 +63,7 @@ SIGNATURES = [
     ("caelo_set_encoder32_dense", c_int, [c_vp, c_vp, c_vp]),
     ("caelo_encode32_ws_bytes", c_i64, [c_i64]),
     ("caelo_encode32", c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp]),
+    ("caelo_encode32_profile", c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     ("caelo_match_ws_bytes", c_i64, [c_i64]),
     ("caelo_match", c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_vp, c_vp]),
     ("caelo_solve_rt", c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),

@@ -437,6 +437,16 @@ class Engine:
         _ffi.check(self.lib.caelo_encode32(self.ctx, _ptr(bits), n, group, _ptr(out), 20 * group, _ptr(ws), self.stream))
         return out
 
+    def encode32_profile(self, bits, group=1):
+        """encode32 + per-launch HIP-event timings (ms): conv1+pool, conv2+pool, conv3, Dense(200)+head.  Synchronises."""
+        n = bits.numel() // 512
+        out = self.empty((n // group, 20 * group), torch.float32)
+        ws = self._ws("encode32", int(self.lib.caelo_encode32_ws_bytes(n)))
+        ms = (C.c_float * 4)()
+        _ffi.check(self.lib.caelo_encode32_profile(self.ctx, _ptr(bits), n, group, _ptr(out), 20 * group, _ptr(ws), self.stream,
+                                                   C.cast(ms, C.c_void_p)))
+        return out, list(ms)
+
     def extract32(self, pc, dist_channels=5):
         """Config-5 frame features: the key points of ``extract`` (project -> response -> top-K rule), described by
         32^3 patches instead of 16^3 ones.  Staged calls; the 16^3 descriptors ``extract`` also produced are
@@ -448,11 +458,12 @@ class Engine:
         return ff
 
     def encode_profile(self, bits, group=1):
-        """encode + per-kernel HIP-event timings (ms): stage1, conv3, dense1, head.  Synchronises."""
+        """encode + per-kernel HIP-event timings (ms): stage1, conv3, dense1, head, then the conv2 MFMA instructions
+        stage 1 executed (millions).  Synchronises."""
         n = bits.numel() // 64
         out = self.empty((n // group, 20 * group), torch.float32)
         ws = self._encode_ws(n)
-        ms = (C.c_float * 4)()
+        ms = (C.c_float * 5)()
         _ffi.check(self.lib.caelo_encode_profile(self.ctx, _ptr(bits), n, group, _ptr(out), 20 * group, _ptr(ws),
                                                  self.stream, C.cast(ms, C.c_void_p)))
         return out, list(ms)

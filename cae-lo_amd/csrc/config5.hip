@@ -592,8 +592,8 @@ CAELO_API int64_t caelo_encode32_ws_bytes(int64_t n_patches) {
     return (n_patches * (32768 + 8192) + np * 16384) * (int64_t)sizeof(float) + enc_dense32_part_bytes(np);
 }
 
-CAELO_API int caelo_encode32(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
-                             void *ws, void *stream) {
+static int encode32_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
+                         void *ws, void *stream, hipEvent_t *ev /* 5 events or null */) {
     CAELO_REQUIRE(c && bits && out && ws, "null argument");
     CAELO_REQUIRE(c->has_enc, "encoder weights not set (caelo_set_encoder_weights)");
     CAELO_REQUIRE(c->enc32_wd1x, "32^3 dense_1 not set (caelo_set_encoder32_dense)");
@@ -607,9 +607,11 @@ CAELO_API int caelo_encode32(caelo_ctx *c, const uint64_t *bits, int64_t n_patch
     if (np > n_patches) CAELO_HIP(hipMemsetAsync(f3 + n_patches * 16384, 0, (size_t)(np - n_patches) * 16384 * sizeof(float), s));
     const int items1 = (int)(n_patches * 16);
     static const bool x3 = !(getenv("CAELO_C5_F32") && atoi(getenv("CAELO_C5_F32")));
+    if (ev) CAELO_HIP(hipEventRecord(ev[0], s));
     if (x3) k5_conv1pool_x3<<<items1 < 1024 ? items1 : 1024, 256, 0, s>>>((const unsigned long long *)bits, c->enc_w1, c->enc_b1, p1, items1);
     else k5_conv1pool<<<items1 < 1024 ? items1 : 1024, 256, 0, s>>>((const unsigned long long *)bits, c->enc_w1, c->enc_b1, p1, items1);
     CAELO_LAUNCH_CHECK();
+    if (ev) CAELO_HIP(hipEventRecord(ev[1], s));
     // persistent grids: the B operand (conv weights) is loaded into registers once per workgroup
     const int items2 = (int)(n_patches * 8), items3 = (int)(n_patches * 2);
     if (x3) {
@@ -620,8 +622,32 @@ CAELO_API int caelo_encode32(caelo_ctx *c, const uint64_t *bits, int64_t n_patch
         k5_conv_mfma<16, 8, 16, true><<<items2 < 768 ? items2 : 768, 256, 0, s>>>(p1, c->enc_w2, c->enc_b2, p2, items2);
     }
     CAELO_LAUNCH_CHECK();
+    if (ev) CAELO_HIP(hipEventRecord(ev[2], s));
     if (x3) k5_conv3_x3<<<items3 < 512 ? items3 : 512, 256, 6 * X3_ARR, s>>>(p2, c->enc_w3, c->enc_b3, f3, items3);
     else k5_conv_mfma<8, 16, 32, false><<<items3 < 512 ? items3 : 512, 256, 0, s>>>(p2, c->enc_w3, c->enc_b3, f3, items3);
     CAELO_LAUNCH_CHECK();
-    return enc_dense32_head_launch(c, f3, n_patches, np, part, group, out, out_stride, s);
+    if (ev) CAELO_HIP(hipEventRecord(ev[3], s));
+    const int rc = enc_dense32_head_launch(c, f3, n_patches, np, part, group, out, out_stride, s);
+    if (ev && rc == CAELO_OK) CAELO_HIP(hipEventRecord(ev[4], s));
+    return rc;
+}
+
+CAELO_API int caelo_encode32(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
+                             void *ws, void *stream) {
+    return encode32_impl(c, bits, n_patches, group, out, out_stride, ws, stream, nullptr);
+}
+
+// caelo_encode32 with a HIP event between its launches; synchronises; ms_host[4] = conv1+pool, conv2+pool, conv3, Dense(200)+head
+CAELO_API int caelo_encode32_profile(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
+                                     void *ws, void *stream, float *ms_host) {
+    CAELO_REQUIRE(ms_host != nullptr, "null argument");
+    hipEvent_t ev[5];
+    for (int i = 0; i < 5; ++i) CAELO_HIP(hipEventCreate(&ev[i]));
+    int rc = encode32_impl(c, bits, n_patches, group, out, out_stride, ws, stream, ev);
+    if (rc == CAELO_OK) {
+        CAELO_HIP(hipEventSynchronize(ev[4]));
+        for (int i = 0; i < 4; ++i) CAELO_HIP(hipEventElapsedTime(&ms_host[i], ev[i], ev[i + 1]));
+    }
+    for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
 }

@@ -451,6 +451,341 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// stage 1 in two kernels (round 2): k_enc_conv1 (sparse conv1 + pool1, one WAVEFRONT per patch) -> k_enc_conv2
+// ------------------------------------------------------------------------------------------------
+// k_enc_stage1 above interleaves, per patch and per 4-wave workgroup, three short VALU / LDS phases (mask scatter,
+// cell queue, conv1) with the conv2 MFMA phase: five workgroup barriers per patch, the matrix pipe busy 26 % of the
+// time.  The split gives each part the shape it wants:
+//   * k_enc_conv1: the conv1 work is proportional to the set voxels (2 / 54 / 67 of 4096) and independent per patch:
+//     one wavefront per patch, 5 KB of LDS each, wave barriers only, many wavefronts per SIMD.  Output = the patch's
+//     non-background cells as a list (cell index ascending, D = tanh(pool(conv1)) - tanh(b1), 8 channels).
+//   * k_enc_conv2: persistent workgroups; per patch ONE workgroup barrier: the list is scattered into one of two D
+//     planes in LDS while the MFMAs of the previous patch read the other (each wavefront owns a quarter of the plane,
+//     so un-scattering the patch before last and scattering the next one need no barrier in between).
+// Arithmetic is unchanged (same sums in the same order as k_enc_stage1), so the two paths are bit-identical.
+#define DL_MAX 512  // a patch has 512 pooled cells: 4 quarters (cell >> 7 = x plane pair) of 128
+#define DL_Q 128
+struct EncLists {
+    int32_t *count;        // [rows][4]: entries per quarter
+    unsigned short *cell;  // [rows][4][DL_Q], ascending inside a quarter
+    float *val;            // [rows][4][DL_Q][8]
+};
+
+__global__ void __launch_bounds__(256) k_enc_conv1(const caelo_enc_in in, int64_t n_patches, int group, const float *__restrict__ w1g,
+                                                   const float *__restrict__ b1g, const float *__restrict__ c0g, EncLists dl,
+                                                   unsigned long long *mfma_count) {
+    __shared__ float s_w1[27 * 8];
+    __shared__ float s_b1[8], s_bg[8];
+    __shared__ unsigned long long s_mask[4][512];
+    __shared__ unsigned short s_list[4][512];
+    __shared__ unsigned char s_qpos[4][512];  // position of the entry inside its quarter (< 128)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (mfma_count && blockIdx.x == 0 && tid == 0) *mfma_count = 0ull;  // k_enc_conv2 (next on the stream) adds to it
+    for (int i = tid; i < 27 * 8; i += 256) s_w1[i] = w1g[i];
+    if (tid < 8) { s_b1[tid] = b1g[tid]; s_bg[tid] = c0g[512 * 16 + tid]; }
+    unsigned long long *cm = s_mask[wave];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) cm[lane + 64 * q] = 0ull;
+    __syncthreads();
+    const int n_items = enc_items_total(in, n_patches);
+    const int nk = (int)(n_patches / group);
+    const int J = blockIdx.x * 4 + wave;  // wave-uniform
+    if (J >= n_items) return;
+    const unsigned long long *src;
+    int row;
+    enc_item(in, J, nk, group, src, row);
+    row = __builtin_amdgcn_readfirstlane(row);
+    // ---- scatter every set voxel into the receptive-field masks of the (up to 8) pooled cells that see it; lane l
+    // holds the 16-voxel rows l, l + 64, l + 128, l + 192 of the patch (row r: ix = r >> 4, iy = r & 15, bit = iz)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = lane + 64 * q;
+        const unsigned int bits16 = ((const unsigned short *)src)[r];
+        if (bits16 == 0u) continue;
+        const int x = r >> 4, y = r & 15;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int px = ((x + 1) >> 1) - dx;
+            if (px < 0 || px > 7) continue;
+            const int a = x + 1 - 2 * px;  // x = 2px - 1 + a
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const int py = ((y + 1) >> 1) - dy;
+                if (py < 0 || py > 7) continue;
+                const int b = y + 1 - 2 * py;
+#pragma unroll
+                for (int pz = 0; pz < 8; ++pz) {
+                    const unsigned int nib = ((bits16 << 1) >> (2 * pz)) & 0xFu;  // z = 2pz-1 .. 2pz+2
+                    if (nib != 0u) atomicOr(&cm[(px * 8 + py) * 8 + pz], (unsigned long long)nib << (a * 16 + b * 4));
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- the cells with a non-empty mask, in ascending cell order; s_list holds (quarter-local position << 9 | cell)
+    // in global list order, qcnt[k] = entries of quarter k (quarter = cell >> 7 = two 64-cell chunks)
+    int nlist = 0, qcnt[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int cell = lane + 64 * q;
+        const bool hit = cm[cell] != 0ull;
+        const unsigned long long bal = __ballot(hit);
+        const int below = __popcll(bal & ((1ull << lane) - 1ull));
+        if (hit) s_list[wave][nlist + below] = (unsigned short)cell;
+        if (hit) s_qpos[wave][nlist + below] = (unsigned char)(qcnt[q >> 1] + below);
+        nlist += __popcll(bal);
+        qcnt[q >> 1] += __popcll(bal);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- conv1 + pool1 + tanh on the queued cells; 8 lanes = the 8 positions of a pooling block (as in k_enc_stage1)
+    unsigned short *ocell = dl.cell + (size_t)row * DL_MAX;
+    float *oval = dl.val + (size_t)row * DL_MAX * 8;
+    for (int base = 0; base < nlist; base += 8) {
+        const int item = base + (lane >> 3);
+        const int sub = lane & 7;
+        float acc[8];
+        int cell = 0;
+        if (item < nlist) {
+            cell = s_list[wave][item];
+            const unsigned long long mask = cm[cell];
+            const int sa = sub >> 2, sb = (sub >> 1) & 1, sc = sub & 1;
+            unsigned int taps = 0;  // bit (ka*3+kb)*3+kc
+#pragma unroll
+            for (int ka = 0; ka < 3; ++ka)
+#pragma unroll
+                for (int kb = 0; kb < 3; ++kb)
+                    taps |= ((unsigned int)(mask >> ((sa + ka) * 16 + (sb + kb) * 4 + sc)) & 7u) << ((ka * 3 + kb) * 3);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = s_b1[c];
+            while (taps) {  // ascending tap order == the oracle's (kx,ky,kz) order
+                const int t = __ffs((int)taps) - 1;
+                taps &= taps - 1;
+                const float4 wa = *(const float4 *)&s_w1[t * 8], wb = *(const float4 *)&s_w1[t * 8 + 4];
+                acc[0] += wa.x; acc[1] += wa.y; acc[2] += wa.z; acc[3] += wa.w;
+                acc[4] += wb.x; acc[5] += wb.y; acc[6] += wb.z; acc[7] += wb.w;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = -3.0e38f;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            acc[c] = fmaxf(acc[c], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[c]), 0xB1, 0xF, 0xF, true)));
+            acc[c] = fmaxf(acc[c], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[c]), 0x4E, 0xF, 0xF, true)));
+            acc[c] = fmaxf(acc[c], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[c]), 0x141, 0xF, 0xF, true)));
+        }
+        if (item < nlist) {
+            float mine = acc[0];  // lane `sub` finishes channel `sub`
+#pragma unroll
+            for (int c = 1; c < 8; ++c) mine = (sub == c) ? acc[c] : mine;
+            const int slot = (cell >> 7) * DL_Q + s_qpos[wave][item];
+            oval[(size_t)slot * 8 + sub] = enc_tanh(mine) - s_bg[sub];
+            if (sub == 0) ocell[slot] = (unsigned short)cell;
+        }
+    }
+    if (lane < 4) dl.count[(size_t)row * 4 + lane] = lane == 0 ? qcnt[0] : (lane == 1 ? qcnt[1] : (lane == 2 ? qcnt[2] : qcnt[3]));
+}
+
+struct Conv2Lds {
+    float p1[2][2 * P1_PLANE];   // two D buffers (each: two 4-channel planes, halo)
+    unsigned int nzrow[2][12];
+    int next_j[2];
+};
+
+__global__ void __launch_bounds__(256, 3) k_enc_conv2(const caelo_enc_in in, int64_t n_patches, int group, int *__restrict__ work_counter,
+                                                      const float *__restrict__ w2g, const float *__restrict__ c0g, const EncLists dl,
+                                                      float *__restrict__ p2out, unsigned long long *__restrict__ mfma_count) {
+    __shared__ __attribute__((aligned(16))) Conv2Lds L;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int g = lane >> 4;   // MFMA k-group
+    const int n = lane & 15;   // MFMA column (output channel) for B/C, row for A
+    float breg[27][2];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        breg[t][0] = w2g[(t * 8 + 2 * g) * 16 + n];
+        breg[t][1] = w2g[(t * 8 + 2 * g + 1) * 16 + n];
+    }
+    f32x4 c0r[4][2];
+#pragma unroll
+    for (int yi = 0; yi < 4; ++yi) {
+        const int xp = (wave - 2 * yi) & 3;
+#pragma unroll
+        for (int xt = 0; xt < 2; ++xt) {
+            const float *c0a = c0g + (size_t)((((2 * xp + xt) * 8 + 2 * yi + (g >> 1)) * 8 + 4 * (g & 1)) * 16 + n);
+            c0r[yi][xt] = (f32x4){c0a[0], c0a[16], c0a[32], c0a[48]};
+        }
+    }
+    for (int i = tid; i < 2 * 2 * P1_PLANE; i += 256) (&L.p1[0][0])[i] = 0.0f;  // D == 0: halo, pads, background cells
+    if (tid < 24) (&L.nzrow[0][0])[tid] = 0u;
+    __syncthreads();
+    const int n_items = enc_items_total(in, n_patches);
+    const int nk = (int)(n_patches / group);
+    unsigned int executed = 0;  // MFMA tap rows this wave executed (x 6 MFMAs): measured roofline numerator
+
+    // Wave w owns quarter w of the D planes (cells with cell >> 7 == w: padded planes 2w + 1, 2w + 2) and quarter w of
+    // every patch's cell list.  An entry is fetched into registers two patches ahead (lane = entry; the rare quarter
+    // with more than 64 entries takes a slower path), scattered into LDS one patch ahead and wiped after its patch was
+    // convolved -- from the cell index kept in a register, so the only global loads are the prefetches.
+#define C2_ROW_OF(ITEM, ROW)                                    \
+    {                                                           \
+        const unsigned long long *src_;                         \
+        enc_item(in, (ITEM), nk, group, src_, ROW);             \
+        ROW = __builtin_amdgcn_readfirstlane(ROW);              \
+    }
+#define C2_Q(CELL) (((((CELL) >> 6) + 1) * 10 + ((((CELL) >> 3) & 7) + 1)) * 8 + ((CELL) & 7))
+#define C2_PUT(BUF, CELL, VA, VB)                                                     \
+    {                                                                                 \
+        const int q_ = C2_Q(CELL);                                                    \
+        *(float4 *)&L.p1[BUF][(P1_FRONT + q_) * 4] = VA;                              \
+        *(float4 *)&L.p1[BUF][P1_PLANE + (P1_FRONT + q_) * 4] = VB;                   \
+    }
+    // prefetch registers of the item two ahead, and what each buffer currently holds from this lane
+    int pf_cnt = 0, pf_cell = 0, pf_row = 0;
+    float4 pf_a = make_float4(0.f, 0.f, 0.f, 0.f), pf_b = pf_a;
+    int held_cnt[2] = {0, 0}, held_cell[2] = {0, 0}, held_row[2] = {0, 0};
+#define C2_PREFETCH(ROW)                                                                               \
+    {                                                                                                  \
+        pf_row = (ROW);                                                                                \
+        pf_cnt = __builtin_amdgcn_readfirstlane(dl.count[(size_t)(ROW) * 4 + wave]);                   \
+        const size_t o_ = ((size_t)(ROW) * 4 + wave) * DL_Q + lane;                                    \
+        pf_cell = dl.cell[o_];                                                                         \
+        pf_a = ((const float4 *)dl.val)[2 * o_];                                                       \
+        pf_b = ((const float4 *)dl.val)[2 * o_ + 1];                                                   \
+    }
+    // registers -> buffer BUF (this wave's quarter), occupancy bits of its two padded planes
+#define C2_SCATTER(BUF)                                                                                \
+    {                                                                                                  \
+        unsigned int nz0_ = 0u, nz1_ = 0u;                                                             \
+        if (lane < pf_cnt) {                                                                           \
+            C2_PUT(BUF, pf_cell, pf_a, pf_b)                                                           \
+            const unsigned int bit_ = 1u << (((pf_cell >> 3) & 7) + 1);                                \
+            if ((pf_cell >> 6) & 1) nz1_ = bit_; else nz0_ = bit_;                                     \
+        }                                                                                              \
+        for (int e_ = 64 + lane; e_ < pf_cnt; e_ += 64) { /* rare: more than 64 entries in the quarter */ \
+            const size_t o_ = ((size_t)pf_row * 4 + wave) * DL_Q + e_;                                 \
+            const int cell_ = dl.cell[o_];                                                             \
+            const float4 va_ = ((const float4 *)dl.val)[2 * o_], vb_ = ((const float4 *)dl.val)[2 * o_ + 1]; \
+            C2_PUT(BUF, cell_, va_, vb_)                                                               \
+            const unsigned int bit_ = 1u << (((cell_ >> 3) & 7) + 1);                                  \
+            if ((cell_ >> 6) & 1) nz1_ |= bit_; else nz0_ |= bit_;                                     \
+        }                                                                                              \
+        _Pragma("unroll") for (int o_ = 32; o_ > 0; o_ >>= 1) { nz0_ |= __shfl_xor(nz0_, o_); nz1_ |= __shfl_xor(nz1_, o_); } \
+        if (lane == 0) { L.nzrow[BUF][2 * wave + 1] = nz0_; L.nzrow[BUF][2 * wave + 2] = nz1_; }      \
+        held_cnt[BUF] = pf_cnt; held_cell[BUF] = pf_cell; held_row[BUF] = pf_row;                      \
+    }
+#define C2_WIPE(BUF)                                                                                   \
+    {                                                                                                  \
+        const float4 z4_ = make_float4(0.f, 0.f, 0.f, 0.f);                                            \
+        if (lane < held_cnt[BUF]) C2_PUT(BUF, held_cell[BUF], z4_, z4_)                                \
+        for (int e_ = 64 + lane; e_ < held_cnt[BUF]; e_ += 64) {                                       \
+            const int cell_ = dl.cell[((size_t)held_row[BUF] * 4 + wave) * DL_Q + e_];                 \
+            C2_PUT(BUF, cell_, z4_, z4_)                                                               \
+        }                                                                                              \
+    }
+    // software pipeline over this workgroup's items: cur (being convolved, in buffer `buf`), nxt (scattered in the
+    // other buffer), nn (prefetched in registers), and the work counter is one fetch ahead of that
+    int j_cur = blockIdx.x, j_nxt = n_items, j_nn = n_items, row_cur = 0, row_nxt = 0;
+    if (tid == 0) {
+        L.next_j[0] = (int)gridDim.x + atomicAdd(work_counter, 1);
+        L.next_j[1] = (int)gridDim.x + atomicAdd(work_counter, 1);
+    }
+    if (j_cur < n_items) {
+        C2_ROW_OF(j_cur, row_cur)
+        C2_PREFETCH(row_cur)
+        C2_SCATTER(0)
+    }
+    __syncthreads();
+    j_nxt = __builtin_amdgcn_readfirstlane(L.next_j[0]);
+    j_nn = __builtin_amdgcn_readfirstlane(L.next_j[1]);
+    if (j_nxt < n_items) {
+        C2_ROW_OF(j_nxt, row_nxt)
+        C2_PREFETCH(row_nxt)
+        C2_SCATTER(1)
+    }
+    __syncthreads();
+    int buf = 0;
+    while (j_cur < n_items) {
+        // the item three ahead: fetched now, published at this iteration's barrier; the item two ahead: into registers
+        int j_fetch = 0;
+        if (tid == 0) j_fetch = atomicAdd(work_counter, 1);
+        pf_cnt = 0;
+        if (j_nn < n_items) {
+            int row_nn;
+            C2_ROW_OF(j_nn, row_nn)
+            C2_PREFETCH(row_nn)
+        }
+        // ---- conv2 (8->16) on MFMA from buffer `buf`: per row pair yi this wave owns the x pair xp = (wave - 2 yi) mod 4
+        {
+            const int patch = row_cur;
+            const int yl = n >> 3, z = n & 7;  // A row m = yl*8 + z
+            const float *plane = &L.p1[buf][0] + (g >> 1) * P1_PLANE + 2 * (g & 1);
+            const unsigned int *nzr = L.nzrow[buf];
+            const bool zlo = z >= 1, zhi = z <= 6;
+#pragma unroll
+            for (int yi = 0; yi < 4; ++yi) {
+                const int y0 = 2 * yi;
+                const int xp = (wave - 2 * yi) & 3;
+                const unsigned int r0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((nzr[2 * xp] >> y0) & 0xFu));
+                const unsigned int r1 = (unsigned)__builtin_amdgcn_readfirstlane((int)((nzr[2 * xp + 1] >> y0) & 0xFu));
+                const unsigned int r2 = (unsigned)__builtin_amdgcn_readfirstlane((int)((nzr[2 * xp + 2] >> y0) & 0xFu));
+                const unsigned int r3 = (unsigned)__builtin_amdgcn_readfirstlane((int)((nzr[2 * xp + 3] >> y0) & 0xFu));
+                float *dst = p2out + (size_t)patch * 1024 + (size_t)(((xp * 4 + yi) * 4 + 2 * (g & 1)) * 16 + n);
+                // accumulators start from C0 = b2 + conv2(BG); a pair that nothing but background feeds keeps them as they
+                // are (the pooled constants are recomputed rather than held in 8 more registers)
+                f32x4 acc0 = c0r[yi][0];
+                f32x4 acc1 = c0r[yi][1];
+                if ((r0 | r1 | r2 | r3) != 0u) {
+                f32x4 acc0b = {0.f, 0.f, 0.f, 0.f}, acc1b = {0.f, 0.f, 0.f, 0.f};
+                const int qbase = ((2 * xp) * 10 + (y0 + yl)) * 8 + z;
+                const float *a0 = plane + (P1_FRONT + qbase) * 4;
+                const float *a1 = a0 + 80 * 4;
+                CONV2_TILE(acc0, acc0b, a0, r0, r1, r2)
+                CONV2_TILE(acc1, acc1b, a1, r1, r2, r3)
+#define C2_HITS(R) (unsigned)((((R) & 0x3u) != 0u) + (((R) & 0x6u) != 0u) + (((R) & 0xCu) != 0u))
+                executed += C2_HITS(r0) + 2u * C2_HITS(r1) + 2u * C2_HITS(r2) + C2_HITS(r3);
+                acc0 += acc0b;
+                acc1 += acc1b;
+                }
+                float v0 = fmaxf(fmaxf(acc0[0], acc0[1]), fmaxf(acc1[0], acc1[1]));  // pz = 2*(g&1)
+                float v1 = fmaxf(fmaxf(acc0[2], acc0[3]), fmaxf(acc1[2], acc1[3]));  // pz = 2*(g&1)+1
+                v0 = fmaxf(v0, __shfl_xor(v0, 32));
+                v1 = fmaxf(v1, __shfl_xor(v1, 32));
+                if (g < 2) {
+                    dst[0] = enc_tanh(v0);
+                    dst[16] = enc_tanh(v1);
+                }
+            }
+        }
+        if (tid == 0) L.next_j[buf] = (int)gridDim.x + j_fetch;  // slot by parity: a slow reader of the previous one is never overtaken
+        __builtin_amdgcn_s_waitcnt(0);  // the prefetched registers have arrived (vmcnt) -- the stores too, which costs little here
+        caelo_lds_barrier();  // every wave is done reading `buf`; next_j is published
+        const int j_n3 = __builtin_amdgcn_readfirstlane(L.next_j[buf]);
+        // ---- this wave's quarter of `buf`: wipe the patch just convolved, bring in the prefetched one (no barrier in
+        // between: nobody else touches this quarter) while the other waves may already be in the next patch's MFMAs
+        C2_WIPE(buf)
+        int row_nn2 = 0;
+        if (j_nn < n_items) {
+            row_nn2 = pf_row;
+            C2_SCATTER(buf)
+        } else {
+            if (lane == 0) { L.nzrow[buf][2 * wave + 1] = 0u; L.nzrow[buf][2 * wave + 2] = 0u; }
+            held_cnt[buf] = 0;
+        }
+        j_cur = j_nxt; row_cur = row_nxt;
+        j_nxt = j_nn; row_nxt = row_nn2;
+        j_nn = j_n3;
+        buf ^= 1;
+    }
+    if (mfma_count && lane == 0 && executed) atomicAdd(mfma_count, (unsigned long long)executed);
+}
+
+// ------------------------------------------------------------------------------------------------
 // conv3 (16->32) implicit GEMM: M = 64 positions/patch, N = 32, K = 27*16 -- f32 products on the bf16 matrix pipe
 // ------------------------------------------------------------------------------------------------
 // v_mfma_f32_16x16x32_bf16 retires 16x the FLOPs per cycle of the f32-input MFMA (MI355X_MICROARCH: 2.5 PF vs
@@ -884,9 +1219,12 @@ __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part
 // ------------------------------------------------------------------------------------------------
 static inline int64_t pad64(int64_t n) { return (n + D1_BM - 1) / D1_BM * D1_BM; }  // rows padded to whole dense-1 tiles
 
+// per row: counts (4 quarters x 4 B) + cells (512 x 2 B) + values (512 x 8 x 4 B) of the non-background cells after conv1 + pool1
+static inline int64_t dl_bytes(int64_t np) { return np * (4 * 4 + DL_MAX * 2 + (int64_t)DL_MAX * 8 * 4); }
+
 CAELO_API int64_t caelo_encode_ws_bytes(int64_t n_patches) {
     const int64_t np = pad64(n_patches);
-    return 256 + (np * 1024 + np * 2048 + (int64_t)D1_SPLIT * np * DENSE_NP) * (int64_t)sizeof(float);
+    return 256 + (np * 1024 + np * 2048 + (int64_t)D1_SPLIT * np * DENSE_NP) * (int64_t)sizeof(float) + dl_bytes(np);
 }
 
 int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
@@ -910,19 +1248,27 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     CAELO_REQUIRE(c->has_enc, "encoder weights not set (caelo_set_encoder_weights)");
     CAELO_REQUIRE(n_patches > 0 && group >= 1 && out_stride >= group * 20, "bad shape");
     const int64_t np = pad64(n_patches);
-    // ws = [256 bytes: stage-1 work counter, zero between calls (the owner zero-fills ws once, conv3 resets it)] |
-    // P2 | F3 | dense-1 partial sums
+    // ws = [256 bytes: conv-2 work counter, zero between calls (the owner zero-fills ws once, conv3 resets it); bytes 8..15
+    // = MFMA tap rows the last conv-2 launch executed] | P2 | F3 | dense-1 partial sums | conv-1 cell lists
     int *work_counter = (int *)ws;
+    unsigned long long *mfma_count = (unsigned long long *)((char *)ws + 8);
     float *p2 = (float *)((char *)ws + 256);
     float *f3 = p2 + np * 1024;
     float *part = f3 + np * 2048;
+    EncLists dl;
+    dl.val = part + (size_t)D1_SPLIT * np * DENSE_NP;
+    dl.count = (int32_t *)(dl.val + (size_t)np * DL_MAX * 8);
+    dl.cell = (unsigned short *)(dl.count + np * 4);
     if (np > n_patches)  // rows of the last 64-row tile that no patch writes
         CAELO_HIP(hipMemsetAsync(f3 + n_patches * 2048, 0, (size_t)(np - n_patches) * 2048 * sizeof(float), s));
     // persistent grid = exactly the resident workgroup slots (weights stay in registers across patches,
     // no second partially filled round)
+    // k_enc_stage1 (conv1 + conv2 in one persistent kernel) is the default; CAELO_ENC_SPLIT=1 selects the two-kernel
+    // variant (k_enc_conv1 + k_enc_conv2, bit-identical results), measured 25 % slower
+    static const bool fused_stage1 = !(getenv("CAELO_ENC_SPLIT") && atoi(getenv("CAELO_ENC_SPLIT")) > 0);
     static const int slots1 = [](int device) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_enc_stage1, 256, 0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_stage1 ? (const void *)k_enc_stage1 : (const void *)k_enc_conv2, 256, 0) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || per_cu * cus <= 0)
             return 768;  // 3 workgroups on each of MI355X's 256 CUs
         return per_cu * cus;
@@ -934,8 +1280,15 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     const unsigned g1 = (unsigned)(n_patches < cap1 ? n_patches : cap1);
     if (ev) CAELO_HIP(hipEventRecord(ev[0], s));
     const int order_group = (n_patches % group == 0) ? group : 1;
-    k_enc_stage1<<<g1, 256, 0, s>>>(ein, n_patches, order_group, work_counter, c->enc_w1, c->enc_b1, c->enc_w2, c->enc_c0, p2);
-    CAELO_LAUNCH_CHECK();
+    if (fused_stage1) {
+        k_enc_stage1<<<g1, 256, 0, s>>>(ein, n_patches, order_group, work_counter, c->enc_w1, c->enc_b1, c->enc_w2, c->enc_c0, p2);
+        CAELO_LAUNCH_CHECK();
+    } else {
+        k_enc_conv1<<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(ein, n_patches, order_group, c->enc_w1, c->enc_b1, c->enc_c0, dl, mfma_count);
+        CAELO_LAUNCH_CHECK();
+        k_enc_conv2<<<g1, 256, 0, s>>>(ein, n_patches, order_group, work_counter, c->enc_w2, c->enc_c0, dl, p2, mfma_count);
+        CAELO_LAUNCH_CHECK();
+    }
     if (ev) CAELO_HIP(hipEventRecord(ev[1], s));
     const int64_t pairs = (n_patches + 1) / 2;
     const int64_t cap3 = ein.yield ? 256 : 512;
@@ -952,6 +1305,16 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
                                                                 group, outs, out_stride, ein);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[4], s));
+    if (ev && fused_stage1) {
+        // Profiling calls only, outside the timed events: how many conv2 MFMAs did stage 1 execute?  k_enc_stage1 has no
+        // register left for a counter (168 VGPRs / 106 SGPRs at three workgroups per CU: counting cost 50 % of its time), so
+        // the two-kernel variant -- the same rows, the same skipping rule, bit-identical P2 -- is run once more to count.
+        k_enc_conv1<<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(ein, n_patches, order_group, c->enc_w1, c->enc_b1, c->enc_c0, dl, mfma_count);
+        CAELO_LAUNCH_CHECK();
+        k_enc_conv2<<<g1, 256, 0, s>>>(ein, n_patches, order_group, work_counter, c->enc_w2, c->enc_c0, dl, p2, mfma_count);
+        CAELO_LAUNCH_CHECK();
+        CAELO_HIP(hipMemsetAsync(work_counter, 0, sizeof(int), s));  // conv3 is not there to hand it back at zero
+    }
     return CAELO_OK;
 }
 
@@ -991,6 +1354,9 @@ CAELO_API int caelo_encode_profile(caelo_ctx *c, const uint64_t *bits, int64_t n
     if (rc == CAELO_OK) {
         CAELO_HIP(hipEventSynchronize(ev[4]));
         for (int i = 0; i < 4; ++i) CAELO_HIP(hipEventElapsedTime(&ms_host[i], ev[i], ev[i + 1]));
+        unsigned long long rows = 0;  // conv2 tap rows executed (6 v_mfma_f32_16x16x4_f32 each), counted by the kernel itself
+        CAELO_HIP(hipMemcpy(&rows, (char *)ws + 8, sizeof(rows), hipMemcpyDeviceToHost));
+        ms_host[4] = (float)((double)rows * 6.0 / 1e6);
     }
     for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ev[i]);
     return rc;

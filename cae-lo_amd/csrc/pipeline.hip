@@ -84,7 +84,8 @@ int issue_batch(caelo_pipeline *p) {
         caelo_enc_out outs;
         outs.per_frame = FRAME_PATCHES;
         for (int i = 0; i < n; ++i) outs.base[i] = jobs[i].rows;
-        const caelo_enc_in in = {(const unsigned long long *)p->bits[nb], (int64_t)(CAELO_FRAME_BUF_BYTES / 8), (int32_t)FRAME_PATCHES, n, 1, 1};
+        static const int yield = getenv("CAELO_ENC_YIELD") ? atoi(getenv("CAELO_ENC_YIELD")) : 1;
+        const caelo_enc_in in = {(const unsigned long long *)p->bits[nb], (int64_t)(CAELO_FRAME_BUF_BYTES / 8), (int32_t)FRAME_PATCHES, n, 1, yield};
         rc = encode_batch_impl(p->ctx, p->bits[nb], n * FRAME_PATCHES, 3, outs, 64, p->enc_ws, p->sE, nullptr, &in);
         if (rc) return rc;
     }

@@ -153,8 +153,15 @@ int64_t caelo_encode32_ws_bytes(int64_t n_patches);
 int caelo_encode32(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
                    void *ws, void *stream);
 
+/* caelo_encode32 with a HIP event between its launches; synchronises; ms_host[4] = conv1+pool, conv2+pool, conv3,
+ * Dense(200)+head in ms (measurement aid for bench.py --config 5) */
+int caelo_encode32_profile(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
+                           void *ws, void *stream, float *ms_host);
+
 /* caelo_encode with a HIP event between its four kernels (stage1 = conv1+pool1+conv2+pool2, conv3,
- * dense1, head) on the launch stream; synchronises, writes the durations in ms to ms_host[4]. */
+ * dense1, head) on the launch stream; synchronises, writes the durations in ms to ms_host[0..3] and the number of
+ * conv2 MFMA instructions stage 1 actually executed, in millions, to ms_host[4] (it skips all-background rows; the
+ * dense count is n_patches x 1728).  ms_host holds 5 floats. */
 int caelo_encode_profile(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches, int group, float *out,
                          int out_stride, void *ws, void *stream, float *ms_host);
 

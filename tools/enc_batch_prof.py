@@ -9,7 +9,7 @@ eng = Engine()
 pc = torch.from_numpy(synth.make_scan(0)).to(eng.device)
 ff = eng.extract(pc)
 bits, _ = eng.patches(eng.voxelize(pc)[0], ff.key_pts.contiguous())
-for k in (1, 2, 3, 4):
+for k in (1, 2, 4, 8):
     b = bits.repeat(k, 1, 1).contiguous()
     for _ in range(3): eng.encode_profile(b, group=3)
     ms = np.mean([eng.encode_profile(b, group=3)[1] for _ in range(10)], axis=0) * 1e3
