@@ -200,7 +200,7 @@ def main():
     ap.add_argument("--steps", type=int, default=960)
     ap.add_argument("--warmup", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=4, help="frames per launch (1..8): the front kernels, the encoder launch "
+    ap.add_argument("--batch", type=int, default=8, help="frames per launch (1..8): the front kernels, the encoder launch "
                                                          "set and the match / RANSAC launches each cover a whole batch")
     ap.add_argument("--buffers", type=int, default=3, help="batches of patches in flight between the front and the encoder")
     ap.add_argument("--config", choices=("odometry", "extract", "dense128"), default="odometry",

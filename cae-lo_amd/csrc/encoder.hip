@@ -298,6 +298,8 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
         }
         // issued here, after this patch's prefetched rows were consumed (vmcnt counts in order: an earlier wait for them
         // would also wait for the atomic); nothing else touches vector memory until the value is published
+        // (handing the items out four at a time -- one same-address device atomic per chunk -- was tried: 364 -> 348 us for an
+        // 8-frame launch, 64 -> 84 us for one frame, where four items per workgroup is all there is: not kept)
         int j_fetch;  // defined in thread 0 only, and only read there (no merge copy that would wait for the atomic)
         if (tid == 0) j_fetch = atomicAdd(work_counter, 1);
         caelo_lds_barrier();
@@ -691,9 +693,12 @@ __global__ void __launch_bounds__(256, 3) k_enc_conv2(const caelo_enc_in in, int
     // software pipeline over this workgroup's items: cur (being convolved, in buffer `buf`), nxt (scattered in the
     // other buffer), nn (prefetched in registers), and the work counter is one fetch ahead of that
     int j_cur = blockIdx.x, j_nxt = n_items, j_nn = n_items, row_cur = 0, row_nxt = 0;
+#ifndef C2_STATIC
+#define C2_STATIC 1
+#endif
     if (tid == 0) {
-        L.next_j[0] = (int)gridDim.x + atomicAdd(work_counter, 1);
-        L.next_j[1] = (int)gridDim.x + atomicAdd(work_counter, 1);
+        L.next_j[0] = C2_STATIC ? (int)(blockIdx.x + gridDim.x) : (int)gridDim.x + atomicAdd(work_counter, 1);
+        L.next_j[1] = C2_STATIC ? (int)(blockIdx.x + 2 * gridDim.x) : (int)gridDim.x + atomicAdd(work_counter, 1);
     }
     if (j_cur < n_items) {
         C2_ROW_OF(j_cur, row_cur)
@@ -713,7 +718,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_conv2(const caelo_enc_in in, int
     while (j_cur < n_items) {
         // the item three ahead: fetched now, published at this iteration's barrier; the item two ahead: into registers
         int j_fetch = 0;
-        if (tid == 0) j_fetch = atomicAdd(work_counter, 1);
+        if (tid == 0) j_fetch = C2_STATIC ? j_nn : atomicAdd(work_counter, 1);
         pf_cnt = 0;
         if (j_nn < n_items) {
             int row_nn;
@@ -762,8 +767,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_conv2(const caelo_enc_in in, int
                 }
             }
         }
-        if (tid == 0) L.next_j[buf] = (int)gridDim.x + j_fetch;  // slot by parity: a slow reader of the previous one is never overtaken
-        __builtin_amdgcn_s_waitcnt(0);  // the prefetched registers have arrived (vmcnt) -- the stores too, which costs little here
+        if (tid == 0) L.next_j[buf] = (int)gridDim.x + j_fetch;  // (static: j_nn + gridDim.x) slot by parity: a slow reader of the previous one is never overtaken
         caelo_lds_barrier();  // every wave is done reading `buf`; next_j is published
         const int j_n3 = __builtin_amdgcn_readfirstlane(L.next_j[buf]);
         // ---- this wave's quarter of `buf`: wipe the patch just convolved, bring in the prefetched one (no barrier in
