@@ -23,6 +23,17 @@ class PoseResult(C.Structure):
                 ("iterations", c_i32), ("n_inliers", c_i32), ("best_trial", c_i32), ("n_pairs", c_i32)]
 
 
+class IcpParams(C.Structure):
+    _fields_ = [("threshold0", C.c_double), ("threshold1", C.c_double), ("decay0", C.c_double), ("decay1", C.c_double),
+                ("small_shift", C.c_double), ("ep", C.c_double), ("max_iter", c_i32), ("min_iter", c_i32), ("min_pairs", c_i32),
+                ("fail_only_first", c_i32), ("use_planar", c_i32), ("reserved", c_i32)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("R_star", C.c_double * 9), ("T_star", C.c_double * 3), ("threshold0", C.c_double), ("threshold1", C.c_double),
+                ("iterations", c_i32), ("success", c_i32), ("n_inliers_pts", c_i32), ("n_inliers_planar", c_i32)]
+
+
 class FrameJob(C.Structure):
     """caelo_frame_job (include/caelo.h): one frame of the pipeline, device pointers as integers."""
     _fields_ = [("pc", c_vp), ("n", c_i64), ("dist_channels", c_i32), ("mode", c_i32), ("rows", c_vp),
@@ -76,6 +87,8 @@ SIGNATURES = [
     ("caelo_extend_keypts", c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("caelo_icp_ws_bytes", c_i64, [c_i64]),
     ("caelo_icp_step", c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, C.c_double, c_int, c_vp, c_vp, c_vp, c_vp]),
+    ("caelo_icp_loop_ws_bytes", c_i64, [c_i64, c_i64]),
+    ("caelo_icp", c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, C.POINTER(IcpParams), c_vp, c_vp, c_vp]),
     ("caelo_pipeline_create", c_int, [c_vp, c_int, c_int, c_i64, C.POINTER(c_vp)]),
     ("caelo_pipeline_destroy", None, [c_vp]),
     ("caelo_pipeline_batch", c_int, [c_vp]),

@@ -124,30 +124,55 @@ def RotateMat2EulerAngle_XYZ(R):
                      math.atan2(R[1, 0], R[0, 0])]) * (180.0 / math.pi)
 
 
+def _icp_points(P, cols=3):
+    P = np.ascontiguousarray(P)[:, 0:cols] if _is_np(P) else P[:, 0:cols]
+    return _dev(P, torch.float32).contiguous()
+
+
 def ICP(PC0, PC1, maxIterTimes=50, minIterTimes=20 - 1, inlierThreshold=0.5, smallShiftThreshold=0.05, decay_rate=0.9, ep=0.001):
-    """MyICP.py:26-72: point-to-point ICP of PC1 onto PC0 (the re-registration of the extended keypoints after the
-    odometry, RefinePoses.py:273-334).  Nearest neighbours, inlier selection, SolveRT and the update of PC1 run on the
-    GPU (caelo_icp_step); the loop control is the reference's.  -> (R_star [3,3] f64, T_star [3,1] f64, isSuccess)."""
+    """MyICP.py:26-72: point-to-point ICP of PC1 onto PC0 (the commented-out alternative at RefinePoses.py:295).  The whole
+    loop -- nearest neighbours, inlier gate, SolveRT, the update of PC1, the Euler-angle stop rule, the threshold decay --
+    runs on the device (caelo_icp); one synchronisation at the end.  -> (R_star [3,3] f64, T_star [3,1] f64, isSuccess)."""
     e = default_engine()
-    pc0 = _dev(np.ascontiguousarray(PC0)[:, 0:3] if _is_np(PC0) else PC0[:, 0:3], torch.float32).contiguous()
-    pc1 = _dev(np.ascontiguousarray(PC1)[:, 0:3] if _is_np(PC1) else PC1[:, 0:3], torch.float32).contiguous().clone()
-    R_star = np.eye(3, dtype=np.float64)                                              # :27
-    T_star = np.zeros((3, 1), dtype=np.float64)                                       # :28
-    for iIter in range(maxIterTimes):                                                 # :30
-        rt, n_in = e.icp_step(pc0, pc1, inlierThreshold, 100)                         # :31-50
-        if int(n_in.item()) < 100:                                                    # :38-40
-            return R_star, T_star, False
-        rt = rt.cpu().numpy()
-        R, T = rt[:9].reshape(3, 3), rt[9:].reshape(3, 1)
-        R_star = np.dot(R, R_star)                                                    # :51
-        T_star = np.dot(R, T_star) + T                                                # :52
-        normEulers = np.linalg.norm(RotateMat2EulerAngle_XYZ(R))                      # :55-56
-        normT = np.linalg.norm(T)                                                     # :57
-        if iIter >= minIterTimes and normEulers < ep and normT < ep:                  # :58-60
-            break
-        if normEulers < smallShiftThreshold and normT < smallShiftThreshold:          # :64-66
-            inlierThreshold *= decay_rate
-    return R_star, T_star, True
+    res = e.icp(_icp_points(PC0), _icp_points(PC1).clone(), threshold0=inlierThreshold, decay0=decay_rate,
+                small_shift=smallShiftThreshold, ep=ep, max_iter=maxIterTimes, min_iter=minIterTimes, min_pairs=100, fail_only_first=0)
+    r = e.icp_result(res)
+    return np.array(r.R_star, np.float64).reshape(3, 3), np.array(r.T_star, np.float64).reshape(3, 1), bool(r.success)
+
+
+def ICP_Pt2PtAndPt2Plane(PC0, PC1, PtsWithNorm0, PtsWithNorm1, maxIterTimes=50, minIterTimes=20 - 1, inlierThreshold0=0.5,
+                         decay_rate0=0.9, inlierThreshold1=2.0, decay_rate1=0.5, smallShiftThreshold=0.1, ep=0.01, rng=None,
+                         return_info=False):
+    """MyICP.py:127-201 (caller RefinePoses.py:291-293): every iteration fits ONE rigid motion to the point pairs and the
+    planar pairs (foot of the perpendicular, MyICP.py:88-114).  Device-resident loop (caelo_icp).  ``rng``: RandomState for
+    the subsampling of more than 2000 planar points (:135-140; NumPy's global generator when None, like the reference).
+    Empty planar sets raise ValueError like sklearn's fit at :94 -- which is what the reference's own artefacts lead to
+    (GetKeyPtsByAE always returns an empty PlanarPts, SphericalRing.py:219,285)."""
+    e = default_engine()
+    PN0, PN1 = np.asarray(PtsWithNorm0), np.asarray(PtsWithNorm1)
+    for a in (PN0, PN1):
+        if a.ndim != 2 or a.shape[0] == 0 or a.shape[1] == 0:
+            raise ValueError("Found array with 0 sample(s) (shape=%s) while a minimum of 1 is required." % (a.shape,))
+    nMaxPts = 2000                                                                        # :135
+    if PN1.shape[0] > nMaxPts:
+        rs = np.random.mtrand._rand if rng is None else rng
+        RandIdxes = np.array(rs.random_sample((nMaxPts,)) * PN1.shape[0], dtype=np.int32)   # :137-139
+        PN1 = PN1[RandIdxes, :]
+    res = e.icp(_icp_points(PC0), _icp_points(PC1).clone(), _icp_points(PN0, 6), _icp_points(PN1, 6).clone(),
+                threshold0=inlierThreshold0, threshold1=inlierThreshold1, decay0=decay_rate0, decay1=decay_rate1,
+                small_shift=smallShiftThreshold, ep=ep, max_iter=maxIterTimes, min_iter=minIterTimes, min_pairs=200, fail_only_first=1)
+    r = e.icp_result(res)
+    out = (np.array(r.R_star, np.float64).reshape(3, 3), np.array(r.T_star, np.float64).reshape(3, 1), bool(r.success))
+    return out + (r,) if return_info else out
+
+
+def RefinementCore(poses, ExtKeyPts0, PlanarPts0, ExtKeyPts1, PlanarPts1, iFrame0, iFrame1, relRs, relTs, inlierThreshold0, Tr, rng=None):
+    """RefinePoses.py:273-334 (the two file reads at :276-277 replaced by their arrays, the module globals R_Tr ... by
+    ``Tr``): re-register frame iFrame1 on iFrame0 with ICP_Pt2PtAndPt2Plane on the device, reject implausible changes,
+    update the pose of iFrame1 and forward-update the following poses.  -> (flag, poses_, relRs, relTs)."""
+    from . import refine
+    return refine.RefinementCore(poses, ExtKeyPts0, PlanarPts0, ExtKeyPts1, PlanarPts1, iFrame0, iFrame1, relRs, relTs, inlierThreshold0, Tr,
+                                 icp=ICP_Pt2PtAndPt2Plane, rng=rng)
 
 
 def GetKeyPtsFromRawFileName(rawFileFullPath, RespondLayer):

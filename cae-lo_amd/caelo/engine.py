@@ -321,6 +321,33 @@ class Engine:
                                            int(min_inliers), _ptr(rt), _ptr(n_in), _ptr(ws), self.stream))
         return rt, n_in
 
+    def icp(self, pc0, pc1, planar0=None, planar1=None, **kw):
+        """The reference's ICP loops entirely on the device (caelo_icp): pc1 [n1,3] (and planar1 [m1,6]) are MOVED in place.
+        kw: threshold0/1, decay0/1, small_shift, ep, max_iter, min_iter, min_pairs, fail_only_first.  -> IcpResult bytes tensor
+        (read it with ``icp_result``: the only synchronisation)."""
+        for t in (pc0, pc1):
+            assert t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == 3 and t.is_contiguous()
+        use_planar = planar0 is not None
+        if use_planar:
+            for t in (planar0, planar1):
+                assert t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous() and (t.shape[0] == 0 or t.shape[1] == 6)
+        prm = _ffi.IcpParams(threshold0=kw.get("threshold0", 0.5), threshold1=kw.get("threshold1", 2.0), decay0=kw.get("decay0", 0.9),
+                             decay1=kw.get("decay1", 0.5), small_shift=kw.get("small_shift", 0.05), ep=kw.get("ep", 0.001),
+                             max_iter=kw.get("max_iter", 50), min_iter=kw.get("min_iter", 19), min_pairs=kw.get("min_pairs", 100),
+                             fail_only_first=kw.get("fail_only_first", 0), use_planar=1 if use_planar else 0, reserved=0)
+        m0 = planar0.shape[0] if use_planar else 0
+        m1 = planar1.shape[0] if use_planar else 0
+        res = self.empty((C.sizeof(_ffi.IcpResult),), torch.uint8)
+        ws = self._ws("icp_loop", int(self.lib.caelo_icp_loop_ws_bytes(pc1.shape[0], m1)))
+        _ffi.check(self.lib.caelo_icp(self.ctx, _ptr(pc0), pc0.shape[0], _ptr(pc1), pc1.shape[0], _ptr(planar0) if m0 else None, m0,
+                                      _ptr(planar1) if m1 else None, m1, C.byref(prm), _ptr(res), _ptr(ws), self.stream))
+        return res
+
+    @staticmethod
+    def icp_result(res):
+        """Synchronising read of a caelo_icp_result."""
+        return _ffi.IcpResult.from_buffer_copy(res.cpu().numpy().tobytes())
+
     def voxelize(self, pc, vmap=None, status=None):
         assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] >= 3 and pc.is_contiguous()
         vmap = vmap or self.voxmap(max(self.max_points, pc.shape[0]))

@@ -1,0 +1,137 @@
+// caelo_rigid.h -- 3x3 rigid fit (SolveRT, Match.py:138-158) shared by match.hip and icp.hip.  Device code only.
+#pragma once
+#include "caelo_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 rigid fit from a cross-covariance H = sum (p1 - m1)(p0 - m0)^T   (Match.py:141-157)
+// one-sided Jacobi SVD in f64: H V = U S ; R = V U^T (the reference's V.T @ U.T with V = Vh);
+// det(R) < 0 -> the reference negates column 2 of Vh, i.e. R <- diag(1,1,-1) R  (:151-155).
+// ------------------------------------------------------------------------------------------------
+// Written on scalars only (every index a compile-time constant after unrolling): no private arrays that would live
+// in scratch memory -- none of the pair kernels uses any.
+#define JAC_ROT(AP, AQ, VP, VQ)                                       \
+    {                                                                 \
+        const double ap_ = AP, aq_ = AQ;                              \
+        AP = cs * ap_ - sn * aq_;                                     \
+        AQ = sn * ap_ + cs * aq_;                                     \
+        const double vp_ = VP, vq_ = VQ;                              \
+        VP = cs * vp_ - sn * vq_;                                     \
+        VQ = sn * vp_ + cs * vq_;                                     \
+    }
+// one Jacobi rotation of columns p, q (given as their three entries of A and V); returns |gamma| or 0 when skipped
+#define JAC_PAIR(A0P, A1P, A2P, A0Q, A1Q, A2Q, V0P, V1P, V2P, V0Q, V1Q, V2Q)                                 \
+    {                                                                                                        \
+        double alpha = 0, beta = 0, gamma = 0;                                                               \
+        alpha += A0P * A0P; beta += A0Q * A0Q; gamma += A0P * A0Q;                                           \
+        alpha += A1P * A1P; beta += A1Q * A1Q; gamma += A1P * A1Q;                                           \
+        alpha += A2P * A2P; beta += A2Q * A2Q; gamma += A2P * A2Q;                                           \
+        const double lim = 1e-30 + 1e-16 * sqrt(alpha * beta);                                               \
+        if (!(fabs(gamma) <= lim)) {                                                                         \
+            offmax = fmax(offmax, fabs(gamma));                                                              \
+            const double zeta = (beta - alpha) / (2.0 * gamma);                                              \
+            const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));              \
+            const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;                                          \
+            JAC_ROT(A0P, A0Q, V0P, V0Q) JAC_ROT(A1P, A1Q, V1P, V1Q) JAC_ROT(A2P, A2Q, V2P, V2Q)              \
+        }                                                                                                    \
+    }
+#define JAC_SWAP(X, Y) { const double t_ = X; X = Y; Y = t_; }
+__device__ inline int rigid_from_H_jacobi(const double Hin[9], const double m0[3], const double m1[3], float R[9], float T[3]) {
+    // A = H (columns 0, 1, 2 as a*0, a*1, a*2), V = I
+    double a00 = Hin[0], a01 = Hin[1], a02 = Hin[2], a10 = Hin[3], a11 = Hin[4], a12 = Hin[5], a20 = Hin[6], a21 = Hin[7], a22 = Hin[8];
+    double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
+#pragma unroll 1
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        double offmax = 0.0;
+        JAC_PAIR(a00, a10, a20, a01, a11, a21, v00, v10, v20, v01, v11, v21)  // (p, q) = (0, 1)
+        JAC_PAIR(a00, a10, a20, a02, a12, a22, v00, v10, v20, v02, v12, v22)  // (0, 2)
+        JAC_PAIR(a01, a11, a21, a02, a12, a22, v01, v11, v21, v02, v12, v22)  // (1, 2)
+        if (offmax == 0.0) break;
+    }
+    // columns of A are u_i * s_i; order by descending s so a (near-)null direction ends up last (the same three
+    // compare-exchanges as a bubble sort of the column order)
+    double s0 = sqrt(a00 * a00 + a10 * a10 + a20 * a20), s1 = sqrt(a01 * a01 + a11 * a11 + a21 * a21), s2 = sqrt(a02 * a02 + a12 * a12 + a22 * a22);
+    if (s1 > s0) { JAC_SWAP(s0, s1) JAC_SWAP(a00, a01) JAC_SWAP(a10, a11) JAC_SWAP(a20, a21) JAC_SWAP(v00, v01) JAC_SWAP(v10, v11) JAC_SWAP(v20, v21) }
+    if (s2 > s0) { JAC_SWAP(s0, s2) JAC_SWAP(a00, a02) JAC_SWAP(a10, a12) JAC_SWAP(a20, a22) JAC_SWAP(v00, v02) JAC_SWAP(v10, v12) JAC_SWAP(v20, v22) }
+    if (s2 > s1) { JAC_SWAP(s1, s2) JAC_SWAP(a01, a02) JAC_SWAP(a11, a12) JAC_SWAP(a21, a22) JAC_SWAP(v01, v02) JAC_SWAP(v11, v12) JAC_SWAP(v21, v22) }
+    const double i0 = s0 > 0 ? 1.0 / s0 : 0.0, i1 = s1 > 0 ? 1.0 / s1 : 0.0, i2 = s2 > 0 ? 1.0 / s2 : 0.0;
+    // U = [u0 u1 u2] (column j = entries u0j, u1j, u2j), W = the matching columns of V
+    double u00 = a00 * i0, u10 = a10 * i0, u20 = a20 * i0, u01 = a01 * i1, u11 = a11 * i1, u21 = a21 * i1, u02 = a02 * i2, u12 = a12 * i2, u22 = a22 * i2;
+    const double tiny = 1e-12 * (s0 > 0 ? s0 : 1.0);
+    if (s1 <= tiny) {  // rank <= 1: any orthonormal completion (the pose is meaningless anyway)
+        double e0 = 1, e1 = 0;
+        const double e2 = 0;
+        if (fabs(u00) > 0.9) { e0 = 0; e1 = 1; }
+        const double d = e0 * u00 + e1 * u10 + e2 * u20;
+        const double w0 = e0 - d * u00, w1 = e1 - d * u10, w2 = e2 - d * u20;
+        const double nv = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+        u01 = w0 / nv; u11 = w1 / nv; u21 = w2 / nv;
+    }
+    if (s2 <= tiny) {  // rank 2: u3 = u1 x u2 (sign is LAPACK-specific in the reference)
+        u02 = u10 * u21 - u20 * u11;
+        u12 = u20 * u01 - u00 * u21;
+        u22 = u00 * u11 - u10 * u01;
+    }
+    // R = W U^T
+    double r0 = v00 * u00 + v01 * u01 + v02 * u02, r1 = v00 * u10 + v01 * u11 + v02 * u12, r2 = v00 * u20 + v01 * u21 + v02 * u22;
+    double r3 = v10 * u00 + v11 * u01 + v12 * u02, r4 = v10 * u10 + v11 * u11 + v12 * u12, r5 = v10 * u20 + v11 * u21 + v12 * u22;
+    double r6 = v20 * u00 + v21 * u01 + v22 * u02, r7 = v20 * u10 + v21 * u11 + v22 * u12, r8 = v20 * u20 + v21 * u21 + v22 * u22;
+    const double det = r0 * (r4 * r8 - r5 * r7) - r1 * (r3 * r8 - r5 * r6) + r2 * (r3 * r7 - r4 * r6);
+    if (det < 0) { r6 = -r6; r7 = -r7; r8 = -r8; }  // :151-155
+    R[0] = (float)r0; R[1] = (float)r1; R[2] = (float)r2; R[3] = (float)r3; R[4] = (float)r4; R[5] = (float)r5;
+    R[6] = (float)r6; R[7] = (float)r7; R[8] = (float)r8;
+    T[0] = (float)(m0[0] - (r0 * m1[0] + r1 * m1[1] + r2 * m1[2]));  // :157
+    T[1] = (float)(m0[1] - (r3 * m1[0] + r4 * m1[1] + r5 * m1[2]));
+    T[2] = (float)(m0[2] - (r6 * m1[0] + r7 * m1[1] + r8 * m1[2]));
+    return det < 0 ? -1 : 1;  // isCredible (:139,:152)
+}
+
+// Fast path: R = V U^T is the orthogonal polar factor of H^T.  Scaled Newton iteration
+// X <- (g X + X^-T / g) / 2 (Higham) converges quadratically in f64 (5-7 steps, no sqrt/div chains of a
+// Jacobi SVD: ~10x shorter dependency chain, and every hypothesis wavefront runs this serially).
+// Rank-deficient or badly conditioned H (repeated sample indices) falls back to the Jacobi SVD above.
+__device__ inline int rigid_from_H(const double H[9], const double m0[3], const double m1[3], float R[9], float T[3]) {
+    double X[9] = {H[0], H[3], H[6], H[1], H[4], H[7], H[2], H[5], H[8]};  // X0 = H^T
+    double fro = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fro += X[i] * X[i];
+    bool ok = fro > 0.0;
+    double det0 = 0.0;
+    for (int it = 0; it < 16 && ok; ++it) {
+        double C[9];  // cofactors: X^-T = C / det
+        C[0] = X[4] * X[8] - X[5] * X[7]; C[1] = X[5] * X[6] - X[3] * X[8]; C[2] = X[3] * X[7] - X[4] * X[6];
+        C[3] = X[2] * X[7] - X[1] * X[8]; C[4] = X[0] * X[8] - X[2] * X[6]; C[5] = X[1] * X[6] - X[0] * X[7];
+        C[6] = X[1] * X[5] - X[2] * X[4]; C[7] = X[2] * X[3] - X[0] * X[5]; C[8] = X[0] * X[4] - X[1] * X[3];
+        const double det = X[0] * C[0] + X[1] * C[1] + X[2] * C[2];
+        double nx = 0.0, nc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { nx += X[i] * X[i]; nc += C[i] * C[i]; }
+        if (it == 0) {
+            det0 = det;
+            // sigma_min / sigma_max >= |det| / |X|_F^3 : refuse anything near rank deficiency
+            if (!(fabs(det) > 1e-9 * nx * sqrt(nx))) { ok = false; break; }
+        }
+        const double inv = 1.0 / det;
+        // gamma = sqrt(|X^-1|_F / |X|_F) only steers the convergence speed (any positive scaling has the same fixed
+        // point, the polar factor): single precision is plenty and saves three f64 sqrt + one f64 divide per sweep
+        const double g = (double)sqrtf(sqrtf((float)nc) * fabsf((float)inv) / sqrtf((float)nx));
+        const double a = 0.5 * g, b = 0.5 * inv / g;
+        double delta = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const double nxt = a * X[i] + b * C[i];
+            delta += (nxt - X[i]) * (nxt - X[i]);
+            X[i] = nxt;
+        }
+        if (delta < 1e-30 * 3.0) break;  // |X_{k+1} - X_k|_F < 1e-15 |Q|_F
+        if (it == 15) ok = false;
+    }
+    if (!ok) return rigid_from_H_jacobi(H, m0, m1, R, T);
+    if (det0 < 0) { X[6] = -X[6]; X[7] = -X[7]; X[8] = -X[8]; }  // Match.py:151-155: Vh[:,2] *= -1  <=>  negate row 2 of R
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = (float)X[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        T[i] = (float)(m0[i] - (X[3 * i] * m1[0] + X[3 * i + 1] * m1[1] + X[3 * i + 2] * m1[2]));  // :157
+    return det0 < 0 ? -1 : 1;
+}
+

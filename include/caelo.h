@@ -235,6 +235,32 @@ int64_t caelo_icp_ws_bytes(int64_t n1);
 int caelo_icp_step(caelo_ctx *ctx, const float *pc0, int64_t n0, float *pc1, int64_t n1, double threshold, int min_inliers,
                    float *rt, int32_t *n_inliers, void *ws, void *stream);
 
+/* The whole loop of the reference's re-registration on the device:
+ *   ICP                    MyICP.py:26-72    use_planar = 0, min_pairs = 100, fail_only_first = 0, threshold0 = 0.5, decay0 = 0.9,
+ *                                            small_shift = 0.05, ep = 0.001, max_iter = 50, min_iter = 19
+ *   ICP_Pt2PtAndPt2Plane   MyICP.py:127-201  use_planar = 1, min_pairs = 200, fail_only_first = 1 (too few pairs is a failure only in
+ *                                            the first iteration), threshold1 / decay1 for the planar gate (caller RefinePoses.py:291-295)
+ * pc0 [n0][3], pc1 [n1][3] f32 (pc1 is MOVED in place by every iteration); planar0 [m0][6], planar1 [m1][6] f32 = xyz | normal
+ * (planar1's xyz moves, its normals do not: MyICP.py:177).  With use_planar an empty planar set is an error, like sklearn's
+ * ValueError at MyICP.py:94 -- GetKeyPtsByAE always returns an empty PlanarPts (SphericalRing.py:219,285).
+ * Per iteration: nearest neighbours (exact float64 distance, first minimum) of both sets, the gates, ONE SolveRT over all pairs,
+ * R_star / T_star accumulated in float64, the Euler-angle stop rule and the threshold decay -- no host synchronisation; `result`
+ * (device) is complete when the stream has passed the call.  ws: caelo_icp_loop_ws_bytes(n1, m1) bytes. */
+typedef struct {
+    double threshold0, threshold1, decay0, decay1, small_shift, ep;
+    int32_t max_iter, min_iter, min_pairs, fail_only_first, use_planar, reserved;
+} caelo_icp_params;
+typedef struct {
+    double R_star[9], T_star[3];
+    double threshold0, threshold1;   /* after the last decay */
+    int32_t iterations;              /* iterations that moved pc1 */
+    int32_t success;                 /* isSuccess */
+    int32_t n_inliers_pts, n_inliers_planar; /* pairs of the last evaluated iteration */
+} caelo_icp_result;
+int64_t caelo_icp_loop_ws_bytes(int64_t n1, int64_t m1);
+int caelo_icp(caelo_ctx *ctx, const float *pc0, int64_t n0, float *pc1, int64_t n1, const float *planar0, int64_t m0, float *planar1,
+              int64_t m1, const caelo_icp_params *params, caelo_icp_result *result, void *ws, void *stream);
+
 /* ---- frame pipeline: batches of frames behind single launches, three stages on three HIP streams ------------------
  * Replaces the reference's per-frame driver loops (BatchPreprocess.py:88-140 extract loop, Match.py:296-353 /
  * PoseEstimation.py pair loop) for throughput.  `batch` consecutive frames share ONE launch of every kernel of the

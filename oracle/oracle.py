@@ -171,6 +171,145 @@ def ICP(PC0, PC1, maxIterTimes=50, minIterTimes=20 - 1, inlierThreshold=0.5, sma
     return R_star, T_star, True
 
 
+def GetPtsInliners(PC0, PC1, inlierThreshold):
+    """MyICP.py:75-85."""
+    distances, indices = nearest_neighbours(PC0, PC1)
+    idx1 = distances < inlierThreshold
+    return PC0[indices[idx1], :], PC1[idx1, :]
+
+
+def GetPlanarPtsInliners(PtsWithNorm0, PtsWithNorm1, inlierThreshold0, inlierThreshold1):
+    """MyICP.py:88-114: planar pairs = (foot of the perpendicular from the frame-0 neighbour onto the plane through the
+    frame-1 point, that point).  An empty set raises like sklearn's fit (:94)."""
+    PC0, PC1, Norms1 = PtsWithNorm0[:, 0:3], PtsWithNorm1[:, 0:3], PtsWithNorm1[:, 3:6]
+    if PC0.shape[0] == 0 or PC0.ndim != 2 or PC0.shape[1] == 0:
+        raise ValueError("Found array with 0 sample(s) (shape=%s) while a minimum of 1 is required." % (PC0.shape,))
+    distances, indices = nearest_neighbours(PC0, PC1)                    # :94-95
+    idx1 = distances < inlierThreshold1                                  # :98
+    inliers0, inliers1, norms1 = PC0[indices[idx1], :], PC1[idx1, :], Norms1[idx1, :]
+    vetors = inliers0 - inliers1                                         # :104
+    dist2Planes = np.sum(norms1 * vetors, axis=1)                        # :105
+    pedals = inliers1 + norms1 * np.tile(dist2Planes.reshape(dist2Planes.shape[0], 1), [1, 3])   # :106
+    d = np.linalg.norm(pedals - inliers1, axis=1)                        # :108
+    idx = (d < inlierThreshold0).flatten()                               # :109
+    return pedals[idx, :], inliers1[idx, :]
+
+
+def ICP_Pt2PtAndPt2Plane(PC0, PC1, PtsWithNorm0, PtsWithNorm1, maxIterTimes=50, minIterTimes=20 - 1, inlierThreshold0=0.5,
+                         decay_rate0=0.9, inlierThreshold1=2.0, decay_rate1=0.5, smallShiftThreshold=0.1, ep=0.01, rng=None, trace=None):
+    """MyICP.py:127-201, statement by statement (rng: RandomState standing in for NumPy's global generator at :137)."""
+    PC0 = np.asarray(PC0); PC1 = np.asarray(PC1)
+    PtsWithNorm0 = np.asarray(PtsWithNorm0); PtsWithNorm1 = np.array(PtsWithNorm1)
+    R_star = np.eye(3, dtype=np.float64)
+    T_star = np.zeros((3, 1), dtype=np.float64)
+    nMaxPts = 2000                                                       # :135
+    if PtsWithNorm1.shape[0] > nMaxPts:
+        RandIdxes = (rng or np.random).random_sample((nMaxPts,)) * PtsWithNorm1.shape[0]
+        PtsWithNorm1 = PtsWithNorm1[np.array(RandIdxes, dtype=np.int32), :]
+    isSuccess = True
+    for iIter in range(maxIterTimes):
+        in0p, in1p = GetPtsInliners(PC0, PC1, inlierThreshold0)          # :145
+        in0q, in1q = GetPlanarPtsInliners(PtsWithNorm0, PtsWithNorm1, inlierThreshold0, inlierThreshold1)   # :148 (iIter < 100)
+        inliers0, inliers1 = np.r_[in0p, in0q], np.r_[in1p, in1q]
+        if inliers0.shape[0] < 200:                                      # :166-169
+            if iIter < 1:
+                isSuccess = False
+            break
+        R, T, _ = SolveRT(inliers0, inliers1)                            # :172
+        PC1 = (np.dot(R, PC1.T) + T).T                                   # :175
+        PtsWithNorm1[:, 0:3] = (np.dot(R, PtsWithNorm1[:, 0:3].T) + T).T   # :176 (the normals stay)
+        R_star = np.dot(R, R_star)
+        T_star = np.dot(R, T_star) + T
+        normEulers = np.linalg.norm(RotateMat2EulerAngle_XYZ(R))
+        normT = np.linalg.norm(T)
+        if trace is not None:
+            trace.append((int(in0p.shape[0]), int(in0q.shape[0]), float(inlierThreshold0), float(inlierThreshold1)))
+        if iIter >= minIterTimes:                                        # :185-187
+            if normEulers < ep and normT < ep:
+                break
+        if normEulers < smallShiftThreshold and normT < smallShiftThreshold:   # :190-192
+            inlierThreshold0 *= decay_rate0
+            inlierThreshold1 *= decay_rate1
+    return R_star, T_star, isSuccess
+
+
+def GetRtFromOnePose(pose):
+    """Transformations.py:164-168."""
+    pose = np.asarray(pose).reshape(3, 4)
+    return pose[:, 0:3], pose[:, 3].reshape(3, 1)
+
+
+def GetRelRtBetween2Poses(pose0, pose1):
+    """Transformations.py:106-113."""
+    R0, T0 = GetRtFromOnePose(pose0)
+    R0_inv = np.linalg.inv(R0)
+    T0_inv = -np.dot(R0_inv, T0)
+    R1, T1 = GetRtFromOnePose(pose1)
+    return np.dot(R0_inv, R1), np.dot(R0_inv, T1) + T0_inv
+
+
+def GetLidarRelRtBetween2Poses(pose0, pose1, R_Tr, T_Tr, R_Tr_inv, T_Tr_inv):
+    """Transformations.py:118-125."""
+    R0, T0 = GetRtFromOnePose(pose0)
+    R0_inv = np.linalg.inv(R0)
+    T0_inv = -np.dot(R0_inv, T0)
+    R1, T1 = GetRtFromOnePose(pose1)
+    R = np.dot(R_Tr_inv, np.dot(R0_inv, np.dot(R1, R_Tr)))
+    T = np.dot(R_Tr_inv, np.dot(R0_inv, np.dot(R1, T_Tr) + T1) + T0_inv) + T_Tr_inv
+    return R, T
+
+
+def ForwardUpdatePoses(poses, frameNum, newPose, relRs, relTs):
+    """RefinePoses.py:120-145."""
+    poses_, relRs_, relTs_ = np.array(poses), np.array(relRs), np.array(relTs)
+    poses_[frameNum, :] = newPose
+    relR, relT = GetRelRtBetween2Poses(poses_[frameNum - 1, :], newPose)
+    relRs_[frameNum - 1, :, :] = relR
+    relTs_[frameNum - 1, :] = relT.reshape(3,)
+    for iFrame in range(frameNum + 1, poses_.shape[0], 1):
+        R0, T0 = GetRtFromOnePose(poses_[iFrame - 1])
+        R = np.dot(R0, relRs_[iFrame - 1, :, :])
+        T = np.dot(R0, relTs_[iFrame - 1, :].reshape(3, 1)) + T0
+        poses_[iFrame, :] = np.c_[R, T].reshape((1, 12))
+    return poses_, relRs_, relTs_
+
+
+def RefinementCore(poses, ExtKeyPts0, PlanarPts0, ExtKeyPts1, PlanarPts1, iFrame0, iFrame1, relRs, relTs, inlierThreshold0, Tr,
+                   icp=None, rng=None):
+    """RefinePoses.py:273-334 with the two file reads (:276-277) replaced by their results (arrays) and the module
+    globals R_Tr / T_Tr / ... (:549-556) derived from ``Tr``; ``icp`` = the ICP_Pt2PtAndPt2Plane to call (default: the
+    restatement above)."""
+    icp = icp or ICP_Pt2PtAndPt2Plane
+    poses_ = np.array(poses)
+    R_Tr, T_Tr = GetRtFromOnePose(np.asarray(Tr))
+    R_Tr_inv = np.linalg.inv(R_Tr)
+    T_Tr_inv = -np.dot(R_Tr_inv, T_Tr)
+    pose0, pose1 = poses[iFrame0, :], poses[iFrame1, :]
+    oriRelR, oriRelT = GetLidarRelRtBetween2Poses(pose0, pose1, R_Tr, T_Tr, R_Tr_inv, T_Tr_inv)        # :283
+    KeyPts1_ = np.array(((np.dot(oriRelR, ExtKeyPts1.T) + oriRelT).T), dtype=np.float32)               # :284
+    PlanarPts1_ = np.array(PlanarPts1)                                                                 # :286
+    PlanarPts1_[:, 0:3] = np.array(((np.dot(oriRelR, PlanarPts1[:, 0:3].T) + oriRelT).T), dtype=np.float32)   # :287
+    R_ICP, T_ICP, isSuccess = icp(ExtKeyPts0, KeyPts1_, PlanarPts0, PlanarPts1_, maxIterTimes=50, minIterTimes=20 - 1,
+                                  inlierThreshold0=inlierThreshold0, decay_rate0=0.9, inlierThreshold1=5.0, decay_rate1=0.9,
+                                  smallShiftThreshold=0.1, ep=0.001, **({"rng": rng} if rng is not None else {}))   # :290-293
+    if isSuccess == False:                                                                             # :297-298
+        return -1, poses_, relRs, relTs
+    relativeR = np.dot(R_ICP, oriRelR)                                                                 # :300-301
+    relativeT = np.dot(R_ICP, oriRelT) + T_ICP
+    diffRelEulers = np.linalg.norm(RotateMat2EulerAngle_XYZ(oriRelR) - RotateMat2EulerAngle_XYZ(relativeR))   # :304-307
+    diffRelT = np.linalg.norm(oriRelT - relativeT)
+    if diffRelEulers > 10 or diffRelT > 5:                                                             # :308-309
+        return 0, poses_, relRs, relTs
+    R0, T0 = GetRtFromOnePose(pose0)                                                                   # :313
+    R_poseDiff = np.dot(R_Tr, np.dot(relativeR, R_Tr_inv))                                             # :315-316
+    T_poseDiff = np.dot(R_Tr, np.dot(relativeR, T_Tr_inv) + relativeT) + T_Tr
+    R = np.dot(R0, R_poseDiff)
+    T = np.dot(R0, T_poseDiff) + T0
+    pose1 = np.c_[R, T].reshape((12,))                                                                 # :320-321
+    poses_, relRs, relTs = ForwardUpdatePoses(poses, iFrame1, pose1, relRs, relTs)                     # :326
+    return 1, poses_, relRs, relTs
+
+
 def Voxelization(PC):
     """Voxel.py:100-173.  Returns the reference's 9-tuple; only AllVoxels0/1/2 (the members the
     hot path consumes) are populated, the block structures are None."""

@@ -816,3 +816,34 @@ def test_match_ransac_and_pipeline_are_deterministic_under_load(engine, scans):
         stop.set()
         for t in threads:
             t.join()
+
+
+# ---- SURVEY 8f-4, the rest: Pt2Pt + Pt2Plane ICP and RefinementCore on the device ----------------------------------------
+def test_refinement_vs_reference_golden(api, orc, models, scans):
+    """caelo.api.ICP_Pt2PtAndPt2Plane (the whole loop on the device, one synchronisation) and caelo.api.RefinementCore against
+    MyICP.ICP_Pt2PtAndPt2Plane / RefinePoses.RefinementCore run by the reference itself (refine_0_1.npz): iteration count,
+    pair counts of the last iteration, poses within tolerance; and the ValueError the reference's own (always empty)
+    PlanarPts lead to."""
+    from test_oracle_golden import _refine_inputs
+    g = np.load(os.path.join(GOLDEN, "refine_0_1.npz"))
+    ext, planar = _refine_inputs(orc, models, scans)
+    e0 = np.zeros((0, 0), np.float32)
+    with pytest.raises(ValueError, match="0 sample"):          # SphericalRing.py:219,285 -> MyICP.py:94
+        api.ICP_Pt2PtAndPt2Plane(ext[0], ext[1], e0, e0)
+    R, T = g["R_odo"], g["T_odo"]
+    pc1 = np.array((np.dot(R, ext[1].T) + T).T, dtype=np.float32)
+    pn1 = planar[1].copy(); pn1[:, 0:3] = np.array((np.dot(R, planar[1][:, 0:3].T) + T).T, dtype=np.float32)
+    Rs, Ts, ok, info = api.ICP_Pt2PtAndPt2Plane(ext[0], pc1, planar[0], pn1, maxIterTimes=50, minIterTimes=19, inlierThreshold0=0.5,
+                                                decay_rate0=0.9, inlierThreshold1=5.0, decay_rate1=0.9, smallShiftThreshold=0.1, ep=0.001,
+                                                rng=np.random.RandomState(int(g["p2p_seed"])), return_info=True)
+    assert ok == bool(g["p2p_success"]) and info.iterations == int(g["p2p_iters"])
+    # pair counts of the last iteration: after 29 float32 rigid moves a point within 1e-6 of the gate may fall either side
+    assert np.abs(np.array([info.n_inliers_pts, info.n_inliers_planar]) - g["p2p_trace"][-1, 0:2]).max() <= 2
+    assert abs(info.threshold0 - g["p2p_trace"][-1, 2]) <= 1e-9 or abs(info.threshold0 - 0.9 * g["p2p_trace"][-1, 2]) <= 1e-9   # the trace holds the threshold BEFORE the last decay
+    assert np.abs(Rs - g["p2p_R_star"]).max() <= REL_TOL and np.abs(Ts - g["p2p_T_star"]).max() <= 5e-4
+    flag, poses_, relRs_, relTs_ = api.RefinementCore(g["rc_poses_in"], ext[0], planar[0], ext[1], planar[1], 0, 1, g["rc_relRs_in"],
+                                                      g["rc_relTs_in"], 0.5, g["rc_tr"], rng=np.random.RandomState(int(g["rc_seed"])))
+    assert flag == int(g["rc_flag"]) == 1
+    assert np.abs(poses_ - g["rc_poses_out"]).max() <= 20 * REL_TOL * np.abs(g["rc_poses_out"]).max()
+    assert np.abs(relRs_ - g["rc_relRs_out"]).max() <= REL_TOL and np.abs(relTs_ - g["rc_relTs_out"]).max() <= 1e-3
+    assert not np.allclose(poses_[1], g["rc_poses_in"][1], atol=1e-3)     # the refinement really moved pose 1

@@ -302,6 +302,84 @@ def icp_golden():
     print("  icp golden: %d iterations, %d inliers, ok=%s, T_star=%s" % (iters, inl, ok, np.round(np.asarray(Ts).ravel(), 4)))
 
 
+def refine_golden():
+    """SURVEY 8f-4, the rest: MyICP.ICP_Pt2PtAndPt2Plane (MyICP.py:127-201) and RefinePoses.RefinementCore
+    (RefinePoses.py:273-334, with ForwardUpdatePoses :120-145) run by the reference itself.
+    * With what the reference's own pipeline stores -- GetKeyPtsByAE returns an EMPTY PlanarPts (SphericalRing.py:219,285) --
+      ICP_Pt2PtAndPt2Plane raises (sklearn refuses to fit an empty set, MyICP.py:94): recorded.
+    * With planar points given (ground returns of the synthetic scans with their normal), both run; the oracle restatements are
+      asserted against them.  RefinePoses.py cannot be imported (it executes a script at module level): the two function
+      definitions are executed from its source into a namespace that provides what they use."""
+    import copy
+    import MyICP as RefICP
+    import Transformations as RefT
+    pair = np.load(os.path.join(GOLD, "pair_0_1.npz"))
+    seq = np.load(os.path.join(GOLD, "sequence_20.npz"))
+    ext, planar = [], []
+    for f in (0, 1):
+        pc = synth.make_scan(f)
+        ring, cnt = RefSR.ProjectPC2SphericalRing(pc)
+        resp = np.squeeze(resp_model.predict(ring[0:64, 0:1792, :][:, :, [0, 1, 2]].reshape(1, 64, 1792, 3)))
+        (kp, kpix, _), _ = quiet(RefSR.GetKeyPtsByAE, ring, cnt, resp)
+        ext.append(np.asarray(RefSR.ExtendKeyPtsInShpericalRing(ring, cnt, kpix), np.float32))
+        g_ = pc[(pc[:, 2] < -1.6) & (np.abs(pc[:, 0]) < 30) & (np.abs(pc[:, 1]) < 30)][::9, 0:3]       # ground returns near the sensor
+        planar.append(np.ascontiguousarray(np.c_[g_, np.tile(np.array([[0, 0, 1]], np.float32), (len(g_), 1))], np.float32))
+    assert planar[1].shape[0] > 2000, planar[1].shape       # exercises the random subsampling at MyICP.py:135-140
+    g = {"planar_stride": 9, "n_planar": np.array([len(planar[0]), len(planar[1])]), "n_ext": np.array([len(ext[0]), len(ext[1])])}
+    # ---- (1) empty planar points: what the reference's own artefacts lead to
+    e0 = np.zeros((0, 0), np.float32)
+    try:
+        quiet(RefICP.ICP_Pt2PtAndPt2Plane, ext[0], ext[1], e0, e0)
+        raise AssertionError("the reference was expected to raise on empty planar points")
+    except ValueError as ex:
+        g["empty_planar_exception"] = "ValueError: " + str(ex)
+    try:
+        orc.ICP_Pt2PtAndPt2Plane(ext[0], ext[1], e0, e0)
+        raise AssertionError("oracle did not raise")
+    except ValueError:
+        pass
+    # ---- (2) ICP_Pt2PtAndPt2Plane with RefinementCore's parameters (:290-293), frame 1 pre-aligned by the odometry pose
+    R, T = pair["s0_R"], pair["s0_T"].reshape(3, 1)
+    pc1_ = np.array((np.dot(R, ext[1].T) + T).T, dtype=np.float32)
+    pn1_ = planar[1].copy(); pn1_[:, 0:3] = np.array((np.dot(R, planar[1][:, 0:3].T) + T).T, dtype=np.float32)
+    kw = dict(maxIterTimes=50, minIterTimes=20 - 1, inlierThreshold0=0.5, decay_rate0=0.9, inlierThreshold1=5.0, decay_rate1=0.9,
+              smallShiftThreshold=0.1, ep=0.001)
+    np.random.seed(3)
+    (Rs, Ts, ok), log = quiet(RefICP.ICP_Pt2PtAndPt2Plane, ext[0], pc1_.copy(), planar[0], pn1_.copy(), **kw)
+    trace = []
+    oR, oT, ook = orc.ICP_Pt2PtAndPt2Plane(ext[0], pc1_.copy(), planar[0], pn1_.copy(), rng=np.random.RandomState(3), trace=trace, **kw)
+    iters = int(log.split("ICP iters:")[1].split(",")[0]); in0 = int(log.split("inliers0:")[1].split(",")[0]); in1 = int(log.split("inliers1:")[1].split(",")[0])
+    assert ook == ok and len(trace) == iters and trace[-1][0] == in0 and trace[-1][1] == in1, (len(trace), iters, trace[-1], in0, in1)
+    assert np.allclose(oR, Rs, atol=1e-7) and np.allclose(oT, Ts, atol=1e-6), "oracle ICP_Pt2PtAndPt2Plane != reference"
+    g.update(R_odo=R, T_odo=T, p2p_R_star=np.asarray(Rs, np.float64), p2p_T_star=np.asarray(Ts, np.float64), p2p_success=bool(ok),
+             p2p_iters=iters, p2p_trace=np.array(trace, np.float64), p2p_seed=3)
+    print("  refine golden: Pt2Pt+Pt2Plane %d iterations, inliers %d + %d, ok=%s, T_star=%s" % (iters, in0, in1, ok, np.round(np.asarray(Ts).ravel(), 4)))
+    # ---- (3) RefinementCore: the reference's function executed from its source
+    src = ref_source_block(os.path.join(REF, "RefinePoses.py"), 120, 145) + "\n\n" + ref_source_block(os.path.join(REF, "RefinePoses.py"), 273, 334)
+    tr = seq["tr_kitti"].astype(np.float64)
+    R_Tr, T_Tr = RefT.GetRtFromOnePose(tr)
+    R_Tr_inv = np.linalg.inv(R_Tr); T_Tr_inv = -np.dot(R_Tr_inv, T_Tr)
+    ns = {k: getattr(RefT, k) for k in dir(RefT) if not k.startswith("_")}
+    ns.update(np=np, LA=np.linalg, copy=copy, dot=np.dot, ICP_Pt2PtAndPt2Plane=lambda *a, **k: quiet(RefICP.ICP_Pt2PtAndPt2Plane, *a, **k)[0],
+              LoadExtendedKeyPts=lambda strSequence, iFrame: (ext[iFrame], planar[iFrame]), R_Tr=R_Tr, T_Tr=T_Tr, R_Tr_inv=R_Tr_inv,
+              T_Tr_inv=T_Tr_inv, iShowMatchingResult=0, print=lambda *a, **k: None)
+    exec(src, ns)
+    poses = seq["poses_kitti"].astype(np.float64)
+    relRs = np.zeros((len(poses) - 1, 3, 3)); relTs = np.zeros((len(poses) - 1, 3))
+    for i in range(len(poses) - 1):
+        r_, t_ = RefT.GetRelRtBetween2Poses(poses[i], poses[i + 1])
+        relRs[i], relTs[i] = r_, t_.reshape(3,)
+    np.random.seed(4)
+    flag, poses_, relRs_, relTs_ = ns["RefinementCore"](poses, "00", 0, 1, relRs, relTs, 0.5)
+    oflag, oposes, orelRs, orelTs = orc.RefinementCore(poses, ext[0], planar[0], ext[1], planar[1], 0, 1, relRs, relTs, 0.5, tr, rng=np.random.RandomState(4))
+    assert oflag == flag == 1, (oflag, flag)
+    assert np.allclose(oposes, poses_, atol=1e-6) and np.allclose(orelRs, relRs_, atol=1e-7) and np.allclose(orelTs, relTs_, atol=1e-6), "oracle RefinementCore != reference"
+    g.update(rc_flag=int(flag), rc_poses_in=poses, rc_poses_out=np.asarray(poses_), rc_relRs_in=relRs, rc_relTs_in=relTs, rc_relRs_out=np.asarray(relRs_),
+             rc_relTs_out=np.asarray(relTs_), rc_tr=tr, rc_seed=4)
+    print("  refine golden: RefinementCore flag %d, pose1 T %s -> %s" % (flag, np.round(poses[1].reshape(3, 4)[:, 3], 4), np.round(np.asarray(poses_)[1].reshape(3, 4)[:, 3], 4)))
+    np.savez_compressed(os.path.join(GOLD, "refine_0_1.npz"), **g)
+
+
 def blocks_golden():
     """Voxel.py:161-172 block structures (written to VoxelModel/*.mat, BatchVoxelization.py:61-62) of a small scan: pins
     caelo.stageio.block_structures, which derives them from AllVoxels0 alone."""
@@ -526,6 +604,9 @@ if __name__ == "__main__":
     if "--quantised-only" in sys.argv:
         quantised_golden()
         sys.exit(0)
+    if "--refine-only" in sys.argv:
+        refine_golden()
+        sys.exit(0)
     if "--mat-only" in sys.argv:
         mat_golden()
         sys.exit(0)
@@ -550,6 +631,7 @@ if __name__ == "__main__":
     mat_golden()
     extend_golden()
     icp_golden()
+    refine_golden()
     print("done in %.1fs" % (time.time() - t0))
     for f in sorted(os.listdir(GOLD)):
         print("  %-24s %8.1f KB" % (f, os.path.getsize(os.path.join(GOLD, f)) / 1024))
