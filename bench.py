@@ -292,10 +292,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_rank_fps = [round(K / dt, 1)]
     if world > 1:
-        tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        mine = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_fps = [round(K / float(t.item()), 1) for t in every]     # each rank's own rate (its barrier-to-barrier time)
+        dt = max(float(t.item()) for t in every)                          # the job's time = the slowest rank's
     host = pipe.stats()
     # sanity: every pose solved (not timed)
     ok = 0 if args.extract_only else sum(int(eng.pose_result(batch.result[i]).success) for i in range(K))
@@ -377,6 +380,7 @@ def main():
                        "host_issue_us_per_frame": round(host["issue_us_per_frame"], 1),
                        "parallelism": "frames sharded x%d, one RCCL all-gather of %s [1024,64] f32 frame rows" % (
                            world, "the boundary" if args.gather == "boundary" else "all"),
+                       "per_rank_frames_per_s": per_rank_fps,
                        "poses_solved": "%d/%d" % (ok, K), "status_bits": status, "frames_flagged": frames_flagged},
             "roofline": roofline, "cpu_baseline": cpu,
         }
