@@ -72,6 +72,7 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--synthetic", type=int, default=0, help="number of synthetic 64x2000 scans (caelo.synth)")
+    ap.add_argument("--quantum", type=float, default=0.0, help="round the synthetic coordinates to multiples of this (m), e.g. 0.001")
     ap.add_argument("--scans", help="directory of KITTI velodyne .bin files")
     ap.add_argument("--calib", help="calib_.txt (PoseEstimation.py:199-203) or KITTI calib.txt; identity if omitted")
     ap.add_argument("--out", default="poses_/00.txt")
@@ -97,7 +98,7 @@ def main():
         files = sorted(glob.glob(os.path.join(args.scans, "*.bin")))
         n, load = len(files), (lambda i: stageio.read_scan(files[i]))
     else:
-        n, load = args.synthetic, synth.make_scan
+        n, load = args.synthetic, (lambda i: synth.make_scan(i, quantum=args.quantum or None))
         files = [os.path.join(os.path.dirname(os.path.abspath(args.out)), "synthetic", "velodyne", "%06d.bin" % i) for i in range(n)]
     assert n >= 2, "need at least two scans (--synthetic N or --scans DIR)"
     Tr = stageio.read_calib_tr(args.calib) if args.calib else None

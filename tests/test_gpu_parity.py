@@ -871,3 +871,26 @@ def test_two_ranks_over_rccl_when_two_gpus_are_visible(tmp_path):
     subprocess.run([sys.executable, script, "--synthetic", "11", "--out", one], check=True, env=env, capture_output=True, timeout=300)
     subprocess.run(launch + ["--master-port", "29552", script, "--synthetic", "11", "--out", two], check=True, env=env, capture_output=True, timeout=600)
     assert open(one).read() == open(two).read()
+
+
+def test_run_sequence_saves_consistent_artifacts_on_quantised_scans(tmp_path):
+    """run_sequence.py --save-artifacts on mm-quantised scans (the input class that used to take a Python fallback): the
+    Features / InliersIdx files it writes are readable with the reference's keys and agree with the printed pose lines."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    from caelo import stageio
+    out = tmp_path / "seq" / "poses_" / "00.txt"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "cae-lo_amd", "run_sequence.py"), "--synthetic", "6", "--quantum", "0.001",
+                        "--save-artifacts", "--chunk", "4", "--out", str(out)], check=True, capture_output=True, timeout=300)
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln[:6].isdigit()]
+    assert len(lines) == 5 and all("ok=1" in ln for ln in lines)
+    seq = tmp_path / "seq" / "poses_" / "synthetic"
+    for i in range(6):
+        kp, F, W = stageio.load_keypts_and_features(str(seq / "velodyne" / ("%06d.bin" % i)))
+        assert kp.shape == (1024, 3) and F.shape == (1024, 60) and W.shape == (1024, 1) and np.abs(F).max() < 1.0
+    for i in range(5):
+        i0, i1 = stageio.load_inliers(str(seq), i, i + 1)
+        n_printed = int(lines[i].split("inliers=")[1].split()[0])
+        assert len(i0) == len(i1) == n_printed > 50 and i0.max() < 1024 and np.all(np.diff(i1) > 0)
+    assert len(open(out).read().splitlines()) == 6
