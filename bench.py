@@ -305,6 +305,7 @@ def main():
     # every timed frame's status word (OR of the CAELO_ST_* bits; 0 = no frame needed anything but the fast path)
     st = batch.status[:K, 0].cpu().numpy()
     status, frames_flagged = int(np.bitwise_or.reduce(st)), int((st != 0).sum())
+    lane_faults = eng.lane_faults()   # pose kernels' lane-agreement self-check: 0 on healthy hardware
 
     out = None
     if rank == 0:
@@ -381,7 +382,8 @@ def main():
                        "parallelism": "frames sharded x%d, one RCCL all-gather of %s [1024,64] f32 frame rows" % (
                            world, "the boundary" if args.gather == "boundary" else "all"),
                        "per_rank_frames_per_s": per_rank_fps,
-                       "poses_solved": "%d/%d" % (ok, K), "status_bits": status, "frames_flagged": frames_flagged},
+                       "poses_solved": "%d/%d" % (ok, K), "status_bits": status, "frames_flagged": frames_flagged,
+                       "lane_faults": lane_faults},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -246,6 +246,13 @@ class Engine:
             t = self._wss[key] = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
         return t
 
+    def lane_faults(self):
+        """caelo_lane_faults: wavefronts of the pose kernels whose lanes disagreed on a hypothesis they all derive from the
+        same inputs (a hardware self-check; synchronises).  0 on healthy hardware."""
+        out = C.c_int64(0)
+        _ffi.check(self.lib.caelo_lane_faults(self.ctx, C.byref(out)))
+        return int(out.value)
+
     def pipeline(self, batch=4, buffers=3):
         """The native frame executor (caelo_pipeline): `batch` frames per launch, `buffers` batches of patches in flight
         between the front and the encoder; created once per configuration."""

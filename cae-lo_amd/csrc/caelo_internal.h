@@ -60,6 +60,7 @@ struct caelo_ctx {
     void *enc32_wd1x;  // dense_1 [16384][200] of the 32^3 stress case (config5.hip) in the same operand layout, null until set
     float *enc32_bd1;  // [208]
     bool has_enc;
+    int32_t *faults;  // device counter of the pair kernels' lane-agreement checks (match.hip); 0 on healthy hardware
 };
 
 // ---- voxel map ---------------------------------------------------------------------------------
@@ -171,6 +172,7 @@ struct caelo_pair_dev {
 struct caelo_pair_set {
     caelo_pair_dev p[CAELO_FB_MAX];
     int32_t n;
+    int32_t *faults;  // caelo_ctx::faults (may be null)
 };
 int match_set(const caelo_pair_set &ps, int ld0, int64_t k0_max, int ld1, int64_t k1_max, int dim, hipStream_t s);
 int ransac_set(const caelo_pair_set &ps, int pld0, int pld1, int64_t k1_max, hipStream_t s);

@@ -31,16 +31,20 @@
 //   is ~1e-13 wide: one row per column survives unless descriptors are duplicated.
 //   (An f32 MFMA version of the same filter keeps ~100 rows per column on these descriptors -- the
 //   |a|^2+|b|^2-2ab form cancels ~4 digits -- and was slower than the plain f64 scan.)
-// Grid = (column tiles of 16 frame-1 descriptors) x pairs of the set.  A workgroup is 4 wavefronts; its column
-// tile's B fragments stay in registers and each wavefront walks every fourth 16-row tile of frame 0, keeping the
-// three smallest lower bounds per column; the four partial results meet in LDS and one thread per column
-// certifies.  Nothing crosses workgroups (round 1 split the rows over four 1024-thread workgroups per column tile
-// that met through global tickets: 18.7 us per pair alone, and starved behind the encoder's persistent grids inside
-// the pipeline), and a 256-thread workgroup fits next to them on any CU.
+// Grid = (blocks of 4 column tiles = 64 frame-1 descriptors) x pairs of the set.  A workgroup is 8 wavefronts: wavefront
+// w owns column tile w & 3 (its B fragments stay in registers) and the 16-row tiles of frame 0 with parity w >> 2.  The
+// workgroup walks frame 0 ONCE: each step stages two row tiles (16 x 64 f32 each) in LDS with one coalesced 16-byte load
+// per thread, double buffered, and every wavefront reads its A fragment from there -- frame 0 is read from L2 once per
+// 64 columns (4.2 MB per pair) instead of once per 16 (16.7 MB: the 4-wave version of this kernel was bound by exactly
+// that, 134 MB per 8 pairs at 2.3 TB/s = 59 us, its top-3 bookkeeping and MFMAs hidden underneath).  Partial top-3
+// lists meet in LDS, one thread per column certifies.  Nothing crosses workgroups (round 1 split the rows over four
+// 1024-thread workgroups per column tile that met through global tickets and starved behind the encoder's persistent grids).
 // ------------------------------------------------------------------------------------------------
 typedef double mm_f64x4 __attribute__((ext_vector_type(4)));
-#define MM_WAVES 4
-#define MM_KSTEPS 16  // dim <= 64
+#define MM_WAVES 8
+#define MM_CT 4        // column tiles per workgroup
+#define MM_KSTEPS 16   // dim <= 64
+#define MM_LDA 68      // floats per staged row (64 + 4: rows start 4 banks apart)
 
 CAELO_API int64_t caelo_match_ws_bytes(int64_t k1_max) {
     (void)k1_max;
@@ -83,6 +87,24 @@ __device__ inline void load_frag(const float *row, bool valid, int g, int dim, d
     }
 }
 
+// this thread's 16 bytes of a staged row tile: row (tid >> 4) & 15 of tile `t`, channels 4 (tid & 15) .. + 3
+template <bool VEC>
+__device__ inline float4 mm_stage_load(const float *f0, int ld0, int k0, int dim, int t, int tid) {
+    const int row = (t << 4) + ((tid >> 4) & 15), c = (tid & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < k0) {
+        const float *src = f0 + (size_t)row * ld0 + c;
+        if (VEC) { if (c < dim) v = *(const float4 *)src; }  // dim % 4 == 0 on this path
+        else {
+            if (c < dim) v.x = src[0];
+            if (c + 1 < dim) v.y = src[1];
+            if (c + 2 < dim) v.z = src[2];
+            if (c + 3 < dim) v.w = src[3];
+        }
+    }
+    return v;
+}
+
 template <bool VEC>
 __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_set ps, int ld0, int64_t k0_max, int ld1,
                                                               int64_t k1_max, int dim) {
@@ -91,30 +113,33 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
     const int32_t *n0p = P.n0, *n1p = P.n1;
     int64_t *__restrict__ pair_idx = P.pair_idx;
     int32_t *stats = (int32_t *)P.ws_match;
+    __shared__ __attribute__((aligned(16))) float sA[2][2][16 * MM_LDA];  // [buffer][row-tile parity][row][channel]
     __shared__ double sL[3][MM_WAVES][16];
     __shared__ int sI[2][MM_WAVES][16];
     __shared__ double sU[MM_WAVES][16];
-    __shared__ int s_rescan[16];
+    __shared__ int s_rescan[16 * MM_CT];
     __shared__ double s_rd[MM_WAVES];
     __shared__ int s_ri[MM_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, x = lane & 15;
+    const int cw = wave & (MM_CT - 1), rh = wave >> 2;
     // counts live on the device; clamp so that a caller who forgot to order this launch after the
     // producer of n0/n1 reads garbage rows, never out of bounds
     const int k0 = n0p ? min(max(*n0p, 0), (int)k0_max) : (int)k0_max;
     const int k1 = n1p ? min(max(*n1p, 0), (int)k1_max) : (int)k1_max;
-    const int ctile = blockIdx.x;
-    const int j0 = ctile * 16;
-    if (j0 >= k1) return;
+    const int jb = blockIdx.x * 16 * MM_CT;  // first column of the workgroup
+    if (jb >= k1) return;
     if (k0 == 0) {         // no frame-0 descriptor at all (the reference's argmin would raise): index 0, the pose fails
-        if (tid < 16 && j0 + tid < k1) pair_idx[j0 + tid] = 0;
+        if (tid < 16 * MM_CT && jb + tid < k1) pair_idx[jb + tid] = 0;
         return;
     }
+    const int j0 = jb + cw * 16;
+    const bool live = j0 < k1;  // a wavefront whose column tile lies beyond k1 still stages rows and keeps the barriers
     const double kappa = (4.0 * (double)dim + 64.0) * 1.1102230246251565e-16;  // >= 2x the worst-case bound (dim + 20) 2^-53
     const double BIG = 1.0e300;
     // B fragments (this column tile) and |f1_j|^2.  k-step s of lane group g <-> channel 16 g + s.
     double b[MM_KSTEPS];
-    load_frag<VEC>(f1 + (size_t)(j0 + x) * ld1, j0 + x < k1, g, dim, b);
+    load_frag<VEC>(f1 + (size_t)(j0 + x) * ld1, live && j0 + x < k1, g, dim, b);
     double n1 = 0.0;
 #pragma unroll
     for (int s = 0; s < MM_KSTEPS; ++s) n1 += b[s] * b[s];
@@ -123,42 +148,56 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
     double L1 = BIG, L2 = BIG, L3 = BIG, U = BIG;
     int I1 = 0x7FFFFFFF, I2 = 0x7FFFFFFF;
     const int ntiles = (k0 + 15) >> 4;
-    // the next row tile's fragment is fetched while this one's MFMAs run
-    double a[MM_KSTEPS], an[MM_KSTEPS];
-    if (wave < ntiles) load_frag<VEC>(f0 + (size_t)((wave << 4) + x) * ld0, (wave << 4) + x < k0, g, dim, a);
-    for (int t = wave; t < ntiles; t += MM_WAVES) {
-        const int i0 = t << 4;
-        const int tn = t + MM_WAVES;
-        if (tn < ntiles) load_frag<VEC>(f0 + (size_t)((tn << 4) + x) * ld0, (tn << 4) + x < k0, g, dim, an);
-        double p = 0.0;
+    const int nsteps = (ntiles + 1) >> 1;
+    // thread -> (parity of the tile it stages, position inside the tile)
+    const int st_par = tid >> 8;
+    float *st_dst0 = &sA[0][st_par][((tid >> 4) & 15) * MM_LDA + (tid & 15) * 4];
+    float4 stage = mm_stage_load<VEC>(f0, ld0, k0, dim, st_par, tid);
+    *(float4 *)st_dst0 = stage;
+    __syncthreads();
+    for (int it = 0; it < nsteps; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nsteps) stage = mm_stage_load<VEC>(f0, ld0, k0, dim, 2 * (it + 1) + st_par, tid);  // in flight during the MFMAs
+        const int t = 2 * it + rh;
+        if (live && t < ntiles) {
+            const int i0 = t << 4;
+            const float *ar = &sA[buf][rh][x * MM_LDA + 16 * g];
+            double a[MM_KSTEPS];
 #pragma unroll
-        for (int s = 0; s < MM_KSTEPS; ++s) p += a[s] * a[s];
-        p += __shfl_xor(p, 16);
-        p += __shfl_xor(p, 32);  // |f0_{i0+x}|^2 on every lane with this x
-        // two accumulators: no MFMA waits for its predecessor (the rounding bound kappa holds for any summation order)
-        mm_f64x4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *(const float4 *)(ar + 4 * q);
+                a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+            }
+            double p = 0.0;
 #pragma unroll
-        for (int s = 0; s < MM_KSTEPS; s += 2) {
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s + 1], b[s + 1], acc2, 0, 0, 0);
-        }
-        acc += acc2;
+            for (int s = 0; s < MM_KSTEPS; ++s) p += a[s] * a[s];
+            p += __shfl_xor(p, 16);
+            p += __shfl_xor(p, 32);  // |f0_{i0+x}|^2 on every lane with this x
+            // two accumulators: no MFMA waits for its predecessor (the rounding bound kappa holds for any summation order)
+            mm_f64x4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = g + 4 * r;          // f64 C/D layout: row = (lane >> 4) + 4 * reg, col = lane & 15
-            const double n0 = __shfl(p, row);   // lane `row` (g = 0) holds that row's norm
-            const int i = i0 + row;
-            if (i < k0) {
-                const double v = n0 - 2.0 * acc[r];
-                const double e = kappa * (n0 + n1);
-                U = (v + e) < U ? (v + e) : U;
-                top3_insert(v - e, i, L1, L2, L3, I1, I2);
+            for (int s = 0; s < MM_KSTEPS; s += 2) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s + 1], b[s + 1], acc2, 0, 0, 0);
+            }
+            acc += acc2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = g + 4 * r;          // f64 C/D layout: row = (lane >> 4) + 4 * reg, col = lane & 15
+                const double n0 = __shfl(p, row);   // lane `row` (g = 0) holds that row's norm
+                const int i = i0 + row;
+                if (i < k0) {
+                    const double v = n0 - 2.0 * acc[r];
+                    const double e = kappa * (n0 + n1);
+                    U = (v + e) < U ? (v + e) : U;
+                    top3_insert(v - e, i, L1, L2, L3, I1, I2);
+                }
             }
         }
-#pragma unroll
-        for (int s = 0; s < MM_KSTEPS; ++s) a[s] = an[s];
+        if (it + 1 < nsteps) *(float4 *)(st_dst0 + (buf ^ 1) * (2 * 16 * MM_LDA)) = stage;  // the other buffer: nobody reads it in this step
+        __syncthreads();
     }
-    // ---- workgroup top-3 per column: merge the 4 lane groups by shuffles, the 4 waves through LDS
+    // ---- workgroup top-3 per column: merge the 4 lane groups by shuffles, the two row halves through LDS
 #define MM_SHFL_MERGE(OFF)                                                                           \
     {                                                                                                \
         const double pL1 = __shfl_xor(L1, OFF), pL2 = __shfl_xor(L2, OFF), pL3 = __shfl_xor(L3, OFF); \
@@ -177,19 +216,21 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
         sU[wave][x] = U;
     }
     __syncthreads();
-    // ---- merge the waves and certify: one thread per column
-    if (tid < 16) {
-        const int j = j0 + tid;
+    // ---- merge the row halves and certify: one thread per column of the workgroup's 64
+    if (tid < 16 * MM_CT) {
+        const int ct = tid >> 4, col = tid & 15;
+        const int j = jb + tid;
         int rescan = 0;
         if (j < k1) {
             double a1 = BIG, a2 = BIG, a3 = BIG, Umin = BIG;
             int i1 = 0x7FFFFFFF, i2 = 0x7FFFFFFF;
 #pragma unroll
-            for (int w = 0; w < MM_WAVES; ++w) {
-                Umin = sU[w][tid] < Umin ? sU[w][tid] : Umin;
-                top3_insert(sL[0][w][tid], sI[0][w][tid], a1, a2, a3, i1, i2);
-                top3_insert(sL[1][w][tid], sI[1][w][tid], a1, a2, a3, i1, i2);
-                top3_insert(sL[2][w][tid], 0x7FFFFFFF, a1, a2, a3, i1, i2);
+            for (int h = 0; h < MM_WAVES / MM_CT; ++h) {
+                const int w = ct + MM_CT * h;
+                Umin = sU[w][col] < Umin ? sU[w][col] : Umin;
+                top3_insert(sL[0][w][col], sI[0][w][col], a1, a2, a3, i1, i2);
+                top3_insert(sL[1][w][col], sI[1][w][col], a1, a2, a3, i1, i2);
+                top3_insert(sL[2][w][col], 0x7FFFFFFF, a1, a2, a3, i1, i2);
             }
             if (a3 <= Umin) {
                 rescan = 1;  // three or more rows inside the window
@@ -207,9 +248,9 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
     }
     __syncthreads();
     // ---- exact re-scan of a column whose window holds three or more rows (whole workgroup)
-    for (int cidx = 0; cidx < 16; ++cidx) {
+    for (int cidx = 0; cidx < 16 * MM_CT; ++cidx) {
         if (!s_rescan[cidx]) continue;  // uniform
-        const float *bj = f1 + (size_t)(j0 + cidx) * ld1;
+        const float *bj = f1 + (size_t)(jb + cidx) * ld1;
         double best = BIG;
         int besti = 0x7FFFFFFF;
         for (int i = tid; i < k0; i += 64 * MM_WAVES) {
@@ -228,7 +269,7 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
         if (tid == 0) {
             for (int w = 1; w < MM_WAVES; ++w)
                 if (s_rd[w] < best || (s_rd[w] == best && s_ri[w] < besti)) { best = s_rd[w]; besti = s_ri[w]; }
-            pair_idx[j0 + cidx] = besti;
+            pair_idx[jb + cidx] = besti;
         }
     }
 }
@@ -245,7 +286,7 @@ CAELO_API int caelo_match(caelo_ctx *c, const float *f0, int ld0, int64_t k0_max
 int match_set(const caelo_pair_set &ps, int ld0, int64_t k0_max, int ld1, int64_t k1_max, int dim, hipStream_t s) {
     CAELO_REQUIRE(ps.n >= 1 && ps.n <= CAELO_FB_MAX, "bad pair count");
     CAELO_REQUIRE(dim > 0 && dim <= MT_MAXDIM && ld0 >= dim && ld1 >= dim && k0_max > 0 && k1_max > 0, "bad shape");
-    const int64_t tiles = (k1_max + 15) / 16;
+    const int64_t tiles = (k1_max + 16 * MM_CT - 1) / (16 * MM_CT);  // workgroups of MM_CT column tiles
     bool vec = (dim % 4 == 0) && (ld0 % 4 == 0) && (ld1 % 4 == 0);
     for (int i = 0; i < ps.n; ++i) vec = vec && (((uintptr_t)ps.p[i].f0 | (uintptr_t)ps.p[i].f1) & 15u) == 0;
     dim3 grid((unsigned)tiles, 1, ps.n);
@@ -464,11 +505,27 @@ __device__ inline void sample_hypothesis(const float *P0, int l0, const int64_t 
 #define RE_WAVES 4
 #define RE_LDS_PAIRS 1024
 
+// Every lane of a wavefront derives the same hypothesis from the same four pairs; lanes that disagree mean the hardware
+// mis-executed something (with packed-f32 instructions enabled, gfx950 sporadically drops the subtrahend of
+// one `v_pk_add_f32 ... op_sel:[0,1]` in lanes 48-63 when three queues are busy -- the library is built without them).
+// The check costs a dozen v_readfirstlane per hypothesis and turns a silent wrong inlier count into a counter that
+// caelo_lane_faults() reports and the tests and bench.py assert to be zero.
+__device__ inline void lane_agreement(const float R[9], const float T[3], int lane, int32_t *faults) {
+    if (!faults) return;
+    unsigned int diff = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) diff |= __float_as_uint(R[q]) ^ (unsigned int)__builtin_amdgcn_readfirstlane((int)__float_as_uint(R[q]));
+#pragma unroll
+    for (int q = 0; q < 3; ++q) diff |= __float_as_uint(T[q]) ^ (unsigned int)__builtin_amdgcn_readfirstlane((int)__float_as_uint(T[q]));
+    if (__ballot(diff != 0) != 0ull && lane == 0) atomicAdd(faults, 1);
+}
+
 // inlier count of one hypothesis by one wavefront (every lane returns it)
 __device__ inline int hypothesis_count(const float *P0, int l0, const int64_t *pidx, const float *P1, int l1, int N, const double *r4,
-                                       float thr, int lane) {
+                                       float thr, int lane, int32_t *faults) {
     float R[9], T[3];
     sample_hypothesis(P0, l0, pidx, P1, l1, N, r4, R, T);
+    lane_agreement(R, T, lane, faults);
     int cnt = 0;  // residuals + inlier count (:191-194): ballot + popcount per 64 pairs
     for (int i = lane; i < ((N + 63) & ~63); i += 64) {
         bool in = false;
@@ -503,8 +560,8 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp(const caelo_pair_s
     __syncthreads();
     const int trial = blockIdx.x * RE_WAVES + wave;
     int cnt;
-    if (in_lds) cnt = hypothesis_count(sP0, 3, nullptr, sP1, 3, N, P.rand + (size_t)trial * 4, 0.4f, lane);
-    else cnt = hypothesis_count(pc0, ld0, pair_idx, pc1, ld1, N, P.rand + (size_t)trial * 4, 0.4f, lane);
+    if (in_lds) cnt = hypothesis_count(sP0, 3, nullptr, sP1, 3, N, P.rand + (size_t)trial * 4, 0.4f, lane, ps.faults);
+    else cnt = hypothesis_count(pc0, ld0, pair_idx, pc1, ld1, N, P.rand + (size_t)trial * 4, 0.4f, lane, ps.faults);
     if (lane == 0) ws->counts[trial] = cnt;
 }
 
@@ -528,7 +585,7 @@ __global__ void __launch_bounds__(256) k_ransac_finish(const caelo_pair_set ps, 
             const float thr_l = 0.4f * (float)(1 << level);
             for (int trial = wave; trial < CAELO_RANSAC_MAX_TRIALS; trial += 4) {
                 const int cnt = hypothesis_count(pc0, ld0, pair_idx, pc1, ld1, N, rnd + ((size_t)level * CAELO_RANSAC_MAX_TRIALS + trial) * 4,
-                                                 thr_l, lane);
+                                                 thr_l, lane, ps.faults);
                 if (lane == 0) ws->counts[trial] = cnt;
             }
             __threadfence_block();
@@ -545,6 +602,7 @@ __global__ void __launch_bounds__(256) k_ransac_finish(const caelo_pair_set ps, 
     if (tid < 64) {
         float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, T[3] = {0.f, 0.f, 0.f};
         if (best >= 0) sample_hypothesis(pc0, ld0, pair_idx, pc1, ld1, N, rnd + ((size_t)level * CAELO_RANSAC_MAX_TRIALS + best) * 4, R, T);
+        lane_agreement(R, T, lane, ps.faults);
         if (tid < 9) Rs[tid] = R[tid];
         if (tid < 3) Ts[tid] = T[tid];
     }
@@ -595,6 +653,7 @@ CAELO_API int caelo_ransac(caelo_ctx *c, const float *pc0, int ld0, const float 
     CAELO_REQUIRE(c && pc0 && pc1 && pair_idx && rnd && result && inlier_mask && wsv, "null argument");
     caelo_pair_set ps = {};
     ps.n = 1;
+    ps.faults = c->faults;
     caelo_pair_dev &p = ps.p[0];
     p.pc0 = pc0; p.pc1 = pc1; p.pair_idx = const_cast<int64_t *>(pair_idx); p.n1 = n1; p.rand = rnd; p.result = result;
     p.mask = inlier_mask; p.ws_ransac = wsv;

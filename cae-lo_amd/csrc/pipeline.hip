@@ -93,6 +93,7 @@ int issue_batch(caelo_pipeline *p) {
     const int64_t t2 = now_ns();
     // ---- pairs: frame i against its predecessor (the previous batch's last frame for i = 0) or an explicit one
     caelo_pair_set ps = {};
+    ps.faults = p->ctx->faults;
     for (int i = 0; i < n; ++i) {
         const caelo_frame_job &j = jobs[i];
         if (j.pair == CAELO_PAIR_NONE) continue;

@@ -35,6 +35,8 @@ CAELO_API int caelo_create(caelo_ctx **out, int device) {
     caelo_ctx *c = new caelo_ctx();
     memset(c, 0, sizeof(*c));
     c->device = device;
+    CAELO_HIP(hipMalloc((void **)&c->faults, sizeof(int32_t)));
+    CAELO_HIP(hipMemset(c->faults, 0, sizeof(int32_t)));
     *out = c;
     return CAELO_OK;
 }
@@ -45,9 +47,18 @@ CAELO_API void caelo_destroy(caelo_ctx *c) {
                      c->enc_b3, c->enc_bd1, c->enc_wd2, c->enc_bd2, c->enc32_bd1};
     for (float *p : ptrs)
         if (p) (void)hipFree(p);
-    for (void *p : {c->enc_w3x, c->enc_wd1x, c->enc32_wd1x})
+    for (void *p : {c->enc_w3x, c->enc_wd1x, c->enc32_wd1x, (void *)c->faults})
         if (p) (void)hipFree(p);
     delete c;
+}
+
+CAELO_API int caelo_lane_faults(caelo_ctx *c, int64_t *count_host) {
+    CAELO_REQUIRE(c && count_host, "null argument");
+    int32_t v = 0;
+    CAELO_HIP(hipDeviceSynchronize());
+    CAELO_HIP(hipMemcpy(&v, c->faults, sizeof(v), hipMemcpyDeviceToHost));
+    *count_host = v;
+    return CAELO_OK;
 }
 
 CAELO_API int caelo_set_respond_weights(caelo_ctx *c, const float *w1, const float *b1, const float *w2,

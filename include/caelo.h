@@ -64,6 +64,10 @@ int caelo_abi_version(void);
 const char *caelo_last_error(void);
 int caelo_create(caelo_ctx **ctx, int device);
 void caelo_destroy(caelo_ctx *ctx);
+/* Hardware self-check of the pose kernels (no reference counterpart): every lane of a wavefront derives the same RANSAC
+ * hypothesis, so lanes that disagree mean a mis-executed instruction.  Synchronises the device and returns how many
+ * wavefronts saw that since caelo_create.  0 on healthy hardware; tests and bench.py assert it. */
+int caelo_lane_faults(caelo_ctx *ctx, int64_t *count_host);
 
 /* Weights (HOST pointers, Keras layouts as stored in the .h5).  Replaces
  * keras.models.load_model(...) at Match.py:313,324 / Dirs.py:29-30. */

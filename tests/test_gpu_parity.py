@@ -534,6 +534,7 @@ def test_pipeline_long_run_wraps_the_slot_ring(engine, scans, batch, buffers):
         assert torch.equal(out.result[i], res) and torch.equal(out.pair_idx[i], idx) and torch.equal(out.inlier_mask[i], mask), i
     st = pipe.stats()
     assert st["jobs"] == n and st["batch"] == batch and st["buffers"] == buffers and st["streams"] == 3
+    assert engine.lane_faults() == 0   # the pose kernels' hardware self-check
 
 
 def test_two_ranks_equal_one_rank(tmp_path):
@@ -816,6 +817,7 @@ def test_match_ransac_and_pipeline_are_deterministic_under_load(engine, scans):
         stop.set()
         for t in threads:
             t.join()
+    assert engine.lane_faults() == 0   # no wavefront's lanes disagreed on a hypothesis
 
 
 # ---- SURVEY 8f-4, the rest: Pt2Pt + Pt2Plane ICP and RefinementCore on the device ----------------------------------------

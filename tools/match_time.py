@@ -1,0 +1,23 @@
+"""Time caelo_match on a set of 8 pairs (the pipeline's launch shape) with HIP events."""
+import os, sys, ctypes as C
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "cae-lo_amd"))
+import numpy as np, torch
+from caelo import synth
+from caelo.engine import Engine, ransac_draws
+eng = Engine()
+pcs = [torch.from_numpy(synth.make_scan(i, quantum=1e-3)).to(eng.device) for i in range(6)]
+rnd = [torch.from_numpy(ransac_draws(i)).to(eng.device) for i in range(6)]
+pipe = eng.pipeline(8)
+order = [0, 1, 2, 3, 4, 5, 4, 3, 2, 1] * 8
+scans = [pcs[i] for i in order[:64]]; draws = [rnd[i] for i in order[:64]]
+prev = eng.extract(pcs[1])
+for _ in range(3):
+    pipe.run(scans, draws, prev=prev)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    pipe.run(scans, draws, prev=prev)
+e1.record(); torch.cuda.synchronize()
+print("pipeline: %.1f us/frame" % (e0.elapsed_time(e1) / 5 / 64 * 1e3))

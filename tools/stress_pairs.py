@@ -1,0 +1,34 @@
+"""Stress the pair stage under the three-stream executor: every frame's pose, inlier mask and NN indices against the
+single-call results, plus the library's lane-agreement counter (caelo_lane_faults).
+
+    python tools/stress_pairs.py [reps]            # expected: 0 mismatching frames, 0 lane faults
+    CAELO_LIB=/path/to/variant.so python tools/stress_pairs.py
+
+With a library built with packed-f32 instructions (`make -C cae-lo_amd/csrc PACKED_F32=1 BUILD=/tmp/pk OUT=/tmp/pk.so`)
+an MI355X shows ~1 faulty hypothesis wavefront per 1 000 and a wrong pose in ~1 frame of 600."""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "cae-lo_amd"))
+import torch
+from caelo import synth, _ffi
+if os.environ.get("CAELO_LIB"):
+    _ffi.LIB_PATH = os.environ["CAELO_LIB"]
+from caelo.engine import Engine, Pipeline, ransac_draws
+
+eng = Engine()
+pcs = [torch.from_numpy(synth.make_scan(i)).to(eng.device) for i in range(4)]
+rnd = [torch.from_numpy(ransac_draws(70 + i)).to(eng.device) for i in range(4)]
+ref = [eng.extract(pc) for pc in pcs]
+refp = {(a, b): eng.match_pose(ref[a], ref[b], rnd[b]) for a in range(4) for b in range(4)}
+n, reps, bad, frames = 280, int(sys.argv[1]) if len(sys.argv) > 1 else 8, 0, 0
+for batch, buffers in [(3, 2), (8, 3)] * reps:
+    pipe = Pipeline(eng, batch, buffers)
+    out = pipe.run([pcs[i % 4] for i in range(n)], [rnd[i % 4] for i in range(n)], prev=ref[3])
+    torch.cuda.synchronize()
+    for i in range(n):
+        res, mask, idx = refp[((i - 1) % 4, i % 4)]
+        ok = (torch.equal(out.rows[i], ref[i % 4].rows) and torch.equal(out.result[i], res)
+              and torch.equal(out.pair_idx[i], idx) and torch.equal(out.inlier_mask[i], mask))
+        bad += 0 if ok else 1
+    frames += n
+print("frames %d  mismatching %d  hypothesis wavefronts %d  lane faults %d" % (frames, bad, frames * 500, eng.lane_faults()))
