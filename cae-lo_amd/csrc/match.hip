@@ -15,6 +15,7 @@
 // Also here: k_icp_nn / k_icp_fit_apply, one iteration of the reference's point-to-point ICP.
 // The workspaces of caelo_match / caelo_ransac are self-cleaning (zero-filled once by their owner).
 #include <stddef.h>
+#include <type_traits>
 
 #include "caelo_internal.h"
 #include "caelo_rigid.h"
@@ -31,20 +32,31 @@
 //   is ~1e-13 wide: one row per column survives unless descriptors are duplicated.
 //   (An f32 MFMA version of the same filter keeps ~100 rows per column on these descriptors -- the
 //   |a|^2+|b|^2-2ab form cancels ~4 digits -- and was slower than the plain f64 scan.)
-// Grid = (blocks of 4 column tiles = 64 frame-1 descriptors) x pairs of the set.  A workgroup is 8 wavefronts: wavefront
-// w owns column tile w & 3 (its B fragments stay in registers) and the 16-row tiles of frame 0 with parity w >> 2.  The
-// workgroup walks frame 0 ONCE: each step stages two row tiles (16 x 64 f32 each) in LDS with one coalesced 16-byte load
-// per thread, double buffered, and every wavefront reads its A fragment from there -- frame 0 is read from L2 once per
-// 64 columns (4.2 MB per pair) instead of once per 16 (16.7 MB: the 4-wave version of this kernel was bound by exactly
-// that, 134 MB per 8 pairs at 2.3 TB/s = 59 us, its top-3 bookkeeping and MFMAs hidden underneath).  Partial top-3
-// lists meet in LDS, one thread per column certifies.  Nothing crosses workgroups (round 1 split the rows over four
-// 1024-thread workgroups per column tile that met through global tickets and starved behind the encoder's persistent grids).
+// Grid = (blocks of 2 column tiles = 32 frame-1 descriptors) x pairs of the set: 256 workgroups for 8 pairs, one per CU.
+// A workgroup is 8 wavefronts: wavefront w owns column tile w & 1 (its B fragments stay in registers) and the 16-row
+// tiles t of frame 0 with t % 4 == w >> 1.  The workgroup walks frame 0 ONCE: each step stages 8 row tiles (16 x 64 f32
+// each) in LDS with four coalesced 16-byte loads per thread, in flight during the previous step's MFMAs, double buffered,
+// and every wavefront reads its A fragments from there -- frame 0 is read from L2 once per 32 columns (8.4 MB per pair)
+// instead of once per 16 (16.7 MB).
+// The f64 MFMA is the slow one on this chip (16x16x4: 64 cycles of the pipe, SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_MFMA;
+// peak 78.6 TFLOP/s) and a tile needs 16 of them and ~200 VALU instructions (f32 -> f64, norms, the top-3 bookkeeping):
+// the two wavefronts of a SIMD run the loop in opposite phase (one in its MFMAs while the other does the bookkeeping of
+// its previous tile).  Measured: 49 us per 8 pairs; 30 us with the MFMAs replaced by plain FMAs, 14.5 us is the MFMA time
+// alone -- the f64 matrix instruction and the f64 VALU share their ALUs on this chip (matrix f64 peak = vector f64 peak
+// = 78.6 TFLOP/s), so f64 bookkeeping next to f64 MFMAs adds up instead of overlapping; the remaining lever is fewer
+// f64 VALU instructions per tile.
+// Partial top-3 lists meet in LDS, one thread per column certifies.  Nothing crosses workgroups (round 1 split the rows
+// over four 1024-thread workgroups per column tile that met through global tickets and starved behind the encoder's
+// persistent grids).
 // ------------------------------------------------------------------------------------------------
 typedef double mm_f64x4 __attribute__((ext_vector_type(4)));
 #define MM_WAVES 8
-#define MM_CT 4        // column tiles per workgroup
+#define MM_CT 2        // column tiles per workgroup
+#define MM_RQ 4        // row quarters: wavefront w owns column tile w & 1 and the row tiles t with t % 4 == w >> 1
 #define MM_KSTEPS 16   // dim <= 64
 #define MM_LDA 68      // floats per staged row (64 + 4: rows start 4 banks apart)
+#define MM_TPS 2       // row tiles per wavefront and step: a step stages MM_RQ * MM_TPS tiles (128 rows), one barrier each
+#define MM_STEP_TILES (MM_RQ * MM_TPS)
 
 CAELO_API int64_t caelo_match_ws_bytes(int64_t k1_max) {
     (void)k1_max;
@@ -58,6 +70,17 @@ __device__ inline double exact_dist(const float *a, const float *b, int dim) {
         acc = __dadd_rn(acc, __dmul_rn(d, d));
     }
     return sqrt(acc);
+}
+
+// the same on selects only (no control flow: the match kernel's epilogue must stay in one basic block with the next
+// tile's MFMAs so that the two interleave)
+__device__ inline void top3_insert_sel(double lo, int i, double &L1, double &L2, double &L3, int &I1, int &I2) {
+    const bool c1 = lo < L1, c2 = lo < L2, c3 = lo < L3;
+    L3 = c2 ? L2 : (c3 ? lo : L3);
+    I2 = c1 ? I1 : (c2 ? i : I2);
+    L2 = c1 ? L1 : (c2 ? lo : L2);
+    I1 = c1 ? i : I1;
+    L1 = c1 ? lo : L1;
 }
 
 // insert (lo, i) into an ascending top-3 (indices kept for the first two)
@@ -113,7 +136,7 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
     const int32_t *n0p = P.n0, *n1p = P.n1;
     int64_t *__restrict__ pair_idx = P.pair_idx;
     int32_t *stats = (int32_t *)P.ws_match;
-    __shared__ __attribute__((aligned(16))) float sA[2][2][16 * MM_LDA];  // [buffer][row-tile parity][row][channel]
+    __shared__ __attribute__((aligned(16))) float sA[2][MM_STEP_TILES][16 * MM_LDA];  // [buffer][row tile of the step][row][channel]
     __shared__ double sL[3][MM_WAVES][16];
     __shared__ int sI[2][MM_WAVES][16];
     __shared__ double sU[MM_WAVES][16];
@@ -122,7 +145,7 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
     __shared__ int s_ri[MM_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, x = lane & 15;
-    const int cw = wave & (MM_CT - 1), rh = wave >> 2;
+    const int cw = wave & (MM_CT - 1), rh = wave / MM_CT;
     // counts live on the device; clamp so that a caller who forgot to order this launch after the
     // producer of n0/n1 reads garbage rows, never out of bounds
     const int k0 = n0p ? min(max(*n0p, 0), (int)k0_max) : (int)k0_max;
@@ -134,12 +157,12 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
         return;
     }
     const int j0 = jb + cw * 16;
-    const bool live = j0 < k1;  // a wavefront whose column tile lies beyond k1 still stages rows and keeps the barriers
+    // (a wavefront whose column tile lies beyond k1 computes on zeros: same instruction stream, its results are never read)
     const double kappa = (4.0 * (double)dim + 64.0) * 1.1102230246251565e-16;  // >= 2x the worst-case bound (dim + 20) 2^-53
     const double BIG = 1.0e300;
     // B fragments (this column tile) and |f1_j|^2.  k-step s of lane group g <-> channel 16 g + s.
     double b[MM_KSTEPS];
-    load_frag<VEC>(f1 + (size_t)(j0 + x) * ld1, live && j0 + x < k1, g, dim, b);
+    load_frag<VEC>(f1 + (size_t)(j0 + x) * ld1, j0 + x < k1, g, dim, b);
     double n1 = 0.0;
 #pragma unroll
     for (int s = 0; s < MM_KSTEPS; ++s) n1 += b[s] * b[s];
@@ -148,56 +171,91 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
     double L1 = BIG, L2 = BIG, L3 = BIG, U = BIG;
     int I1 = 0x7FFFFFFF, I2 = 0x7FFFFFFF;
     const int ntiles = (k0 + 15) >> 4;
-    const int nsteps = (ntiles + 1) >> 1;
-    // thread -> (parity of the tile it stages, position inside the tile)
+    const int nsteps = (ntiles + MM_STEP_TILES - 1) / MM_STEP_TILES;
+    // thread -> (tiles st_par, st_par + 2, ... of a step, position inside the tile): 4 loads of 16 B in flight per thread
     const int st_par = tid >> 8;
     float *st_dst0 = &sA[0][st_par][((tid >> 4) & 15) * MM_LDA + (tid & 15) * 4];
-    float4 stage = mm_stage_load<VEC>(f0, ld0, k0, dim, st_par, tid);
-    *(float4 *)st_dst0 = stage;
-    __syncthreads();
-    for (int it = 0; it < nsteps; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < nsteps) stage = mm_stage_load<VEC>(f0, ld0, k0, dim, 2 * (it + 1) + st_par, tid);  // in flight during the MFMAs
-        const int t = 2 * it + rh;
-        if (live && t < ntiles) {
-            const int i0 = t << 4;
-            const float *ar = &sA[buf][rh][x * MM_LDA + 16 * g];
-            double a[MM_KSTEPS];
+    float4 stage[MM_STEP_TILES / 2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = *(const float4 *)(ar + 4 * q);
-                a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
-            }
-            double p = 0.0;
-#pragma unroll
-            for (int s = 0; s < MM_KSTEPS; ++s) p += a[s] * a[s];
-            p += __shfl_xor(p, 16);
-            p += __shfl_xor(p, 32);  // |f0_{i0+x}|^2 on every lane with this x
-            // two accumulators: no MFMA waits for its predecessor (the rounding bound kappa holds for any summation order)
-            mm_f64x4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s = 0; s < MM_KSTEPS; s += 2) {
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s + 1], b[s + 1], acc2, 0, 0, 0);
-            }
-            acc += acc2;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = g + 4 * r;          // f64 C/D layout: row = (lane >> 4) + 4 * reg, col = lane & 15
-                const double n0 = __shfl(p, row);   // lane `row` (g = 0) holds that row's norm
-                const int i = i0 + row;
-                if (i < k0) {
-                    const double v = n0 - 2.0 * acc[r];
-                    const double e = kappa * (n0 + n1);
-                    U = (v + e) < U ? (v + e) : U;
-                    top3_insert(v - e, i, L1, L2, L3, I1, I2);
-                }
-            }
-        }
-        if (it + 1 < nsteps) *(float4 *)(st_dst0 + (buf ^ 1) * (2 * 16 * MM_LDA)) = stage;  // the other buffer: nobody reads it in this step
-        __syncthreads();
+    for (int k = 0; k < MM_STEP_TILES / 2; ++k) {
+        stage[k] = mm_stage_load<VEC>(f0, ld0, k0, dim, 2 * k + st_par, tid);
+        *(float4 *)(st_dst0 + 2 * k * 16 * MM_LDA) = stage[k];
     }
-    // ---- workgroup top-3 per column: merge the 4 lane groups by shuffles, the two row halves through LDS
+    __syncthreads();
+    // bookkeeping of one finished tile: rows i0 + g + 4 r of the accumulator against this lane's column.  Select-only.
+#define MM_BOOKKEEP(ACC, ACC2, PN, I0)                                                              \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                 \
+        const int row = g + 4 * r; /* f64 C/D layout: row = (lane >> 4) + 4 * reg, col = lane & 15 */ \
+        const double n0 = __shfl(PN, row); /* lane `row` (g = 0) holds that row's norm */           \
+        const int i = (I0) + row;                                                                   \
+        const bool in = i < k0; /* rows past k0 were staged as zeros */                             \
+        const double v = n0 - 2.0 * ((ACC)[r] + (ACC2)[r]);                                         \
+        const double e = kappa * (n0 + n1);                                                         \
+        const double hi = in ? v + e : BIG, lo = in ? v - e : BIG;                                  \
+        U = hi < U ? hi : U;                                                                        \
+        top3_insert_sel(lo, i, L1, L2, L3, I1, I2);                                                 \
+    }
+    mm_f64x4 accP = {0.0, 0.0, 0.0, 0.0}, acc2P = {0.0, 0.0, 0.0, 0.0};
+    double pP = 0.0;
+    int i0P = 0x40000000;  // "no tile yet": every row fails i < k0
+    // The two wavefronts of a SIMD (w and w + 4) run the loop in opposite phase: one issues a tile's MFMAs and then the
+    // bookkeeping of the tile before, the other the bookkeeping first -- while one occupies the matrix pipe the other
+    // has VALU work, and the barrier at the end of a step re-aligns them to exactly that.
+    auto main_loop = [&](auto vfirst_t) {
+        constexpr bool VFIRST = decltype(vfirst_t)::value;
+#pragma unroll 1
+        for (int it = 0; it < nsteps; ++it) {
+            const int buf = it & 1;
+            if (it + 1 < nsteps) {  // the next step's rows: in flight during this step's MFMAs
+#pragma unroll
+                for (int k = 0; k < MM_STEP_TILES / 2; ++k)
+                    stage[k] = mm_stage_load<VEC>(f0, ld0, k0, dim, MM_STEP_TILES * (it + 1) + 2 * k + st_par, tid);
+            }
+#pragma unroll
+            for (int k = 0; k < MM_TPS; ++k) {
+                if (VFIRST) {
+                    MM_BOOKKEEP(accP, acc2P, pP, i0P)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const int t = MM_STEP_TILES * it + k * MM_RQ + rh;  // tiles past the last hold zeros and fail i < k0
+                const float *ar = &sA[buf][k * MM_RQ + rh][x * MM_LDA + 16 * g];
+                double a[MM_KSTEPS];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *(const float4 *)(ar + 4 * q);
+                    a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+                }
+                double p = 0.0;
+#pragma unroll
+                for (int s = 0; s < MM_KSTEPS; ++s) p += a[s] * a[s];
+                p += __shfl_xor(p, 16);
+                p += __shfl_xor(p, 32);  // |f0_{i0+x}|^2 on every lane with this x
+                // two accumulators: no MFMA waits for its predecessor (the rounding bound kappa holds for any summation order)
+                mm_f64x4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < MM_KSTEPS; s += 2) {
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s + 1], b[s + 1], acc2, 0, 0, 0);
+                }
+                if (!VFIRST) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    MM_BOOKKEEP(accP, acc2P, pP, i0P)  // the previous tile: its MFMAs finished long ago
+                }
+                accP = acc; acc2P = acc2; pP = p; i0P = t << 4;
+            }
+            if (it + 1 < nsteps) {  // the other buffer: nobody reads it in this step
+#pragma unroll
+                for (int k = 0; k < MM_STEP_TILES / 2; ++k)
+                    *(float4 *)(st_dst0 + ((buf ^ 1) * MM_STEP_TILES + 2 * k) * 16 * MM_LDA) = stage[k];
+            }
+            __syncthreads();
+        }
+    };
+    if (__builtin_amdgcn_readfirstlane(wave) < 4) main_loop(std::false_type{});
+    else main_loop(std::true_type{});
+    MM_BOOKKEEP(accP, acc2P, pP, i0P)
+#undef MM_BOOKKEEP
+    // ---- workgroup top-3 per column: merge the 4 lane groups by shuffles, the four row quarters through LDS
 #define MM_SHFL_MERGE(OFF)                                                                           \
     {                                                                                                \
         const double pL1 = __shfl_xor(L1, OFF), pL2 = __shfl_xor(L2, OFF), pL3 = __shfl_xor(L3, OFF); \
@@ -216,7 +274,7 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
         sU[wave][x] = U;
     }
     __syncthreads();
-    // ---- merge the row halves and certify: one thread per column of the workgroup's 64
+    // ---- merge the row quarters and certify: one thread per column of the workgroup's 32
     if (tid < 16 * MM_CT) {
         const int ct = tid >> 4, col = tid & 15;
         const int j = jb + tid;
