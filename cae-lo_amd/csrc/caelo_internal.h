@@ -254,6 +254,9 @@ struct caelo_enc_out {
 // (bits + f * frame_stride u64 words: [per_frame][64] patches followed by the frame's caelo_dedup_tables); only the
 // distinct patches of each frame are encoded, into rows f * per_frame + (position in the frame's list), and
 // k_enc_head hands patch p of frame f the result of row f * per_frame + slot_of[p].
+// encoder workspace header: [0] work counter of the per-workgroup stage-1 / conv-2 kernels, [8..15] executed-MFMA count of the
+// last counting launch, [1024..2047] eight per-XCD queue counters of k_enc_stage1w (a 128-byte line each).  Zero between calls.
+#define CAELO_ENC_WS_HEADER 2048
 struct caelo_enc_in {
     const unsigned long long *bits;
     int64_t frame_stride;

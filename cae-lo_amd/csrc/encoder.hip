@@ -453,6 +453,361 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// stage 1, one WAVEFRONT per patch (round 2, CAELO_ENC_WAVE=1; not the default): no workgroup barrier after start-up
+// ------------------------------------------------------------------------------------------------
+// k_enc_stage1 above shares a patch among the 4 wavefronts of a workgroup: five workgroup barriers per patch, the non-
+// background cells of a patch cluster so that one or two wavefronts carry most of its MFMAs while the others wait, and
+// the matrix pipe is busy 26 % of the time.  Here a wavefront owns a patch from its bits to its P2 rows, so wavefronts
+// never wait for each other and the SIMD interleaves the conv1 VALU work of one with the conv2 MFMAs of another.
+// What made this impossible before was LDS: the dense D grid of a patch is 26 KB (one wavefront per SIMD).  conv2's
+// output x pair xp only needs the four input x planes 2xp-1 .. 2xp+2, and the cell list is sorted by x: D lives in a
+// RING of four x planes (10 KB), conv1 fills it plane by plane and conv2 follows two planes behind:
+//     planes 0,1,2 -> conv2(x pair 0) -> planes 3,4 -> conv2(1) -> 5,6 -> conv2(2) -> 7 -> conv2(3)
+// A plane's cells are wiped from their list segment before the slot is reused.  Same sums in the same order as
+// k_enc_stage1 (same CONV2 tile code, same skipping rule): P2 is bit-identical.  The C0 accumulator fragments of all 16
+// tile pairs stay in registers as 9 border classes (see below); nothing in the patch loop reads global memory except
+// the next patch's bits.
+// Work items: per-XCD queues (item j belongs to XCD j % 8; a wavefront's first item is static, further ones come from
+// its XCD's counter): one same-address device atomic costs ~12 ns, 3 072 per frame on ONE counter would be a 37 us floor.
+#define S1W_WAVES 4
+#define S1W_RING_CELLS (4 * 80)                          // 4 x-plane slots of 10 (y, halo) x 8 (z) cells
+#define S1W_PLANE ((S1W_RING_CELLS + 2 * P1_FRONT) * 4)  // floats of one 4-channel half
+#define S1W_CSTRIDE 32                                   // ints between two XCD counters (one 128-byte line each)
+struct Stage1wWave {
+    float ring[2 * S1W_PLANE];
+    unsigned long long mask[512];
+    unsigned short list[512];
+    unsigned int nz[12];         // padded x plane 0..9: bit yp set when some cell (x, yp, *) is non-background
+    unsigned short pstart[12];   // list segment of x plane px = [pstart[px], pstart[px + 1])
+};
+struct Stage1wLds {
+    float w1[27 * 8];
+    float b1[8];
+    float bg[8];
+    Stage1wWave w[S1W_WAVES];
+};
+
+// 3 taps of one m-tile from the x plane AP points into (tap plane KA, tap row KB): 6 MFMAs on two interleaved accumulators
+#define CONV2W_ROW(ACC_A, ACC_B, AP, KA, KB)                                                       \
+    _Pragma("unroll") for (int kc = 0; kc < 3; ++kc) {                                             \
+        const int t = (KA) * 9 + (KB) * 3 + kc;                                                     \
+        float2 av = *(const float2 *)((AP) + ((KB) * 8 + (kc - 1)) * 4);                            \
+        if (kc == 0) { if (!zlo) av = make_float2(0.f, 0.f); }                                      \
+        if (kc == 2) { if (!zhi) av = make_float2(0.f, 0.f); }                                      \
+        ACC_A = MFMA16(av.x, breg[t][0], ACC_A);                                                    \
+        ACC_B = MFMA16(av.y, breg[t][1], ACC_B);                                                    \
+    }
+#define CONV2W_TILE(ACC_A, ACC_B, AP0, AP1, AP2, NZ0, NZ1, NZ2)                                     \
+    if ((NZ0) & 0x3u) { CONV2W_ROW(ACC_A, ACC_B, AP0, 0, 0) }                                       \
+    if ((NZ0) & 0x6u) { CONV2W_ROW(ACC_A, ACC_B, AP0, 0, 1) }                                       \
+    if ((NZ0) & 0xCu) { CONV2W_ROW(ACC_A, ACC_B, AP0, 0, 2) }                                       \
+    if ((NZ1) & 0x3u) { CONV2W_ROW(ACC_A, ACC_B, AP1, 1, 0) }                                       \
+    if ((NZ1) & 0x6u) { CONV2W_ROW(ACC_A, ACC_B, AP1, 1, 1) }                                       \
+    if ((NZ1) & 0xCu) { CONV2W_ROW(ACC_A, ACC_B, AP1, 1, 2) }                                       \
+    if ((NZ2) & 0x3u) { CONV2W_ROW(ACC_A, ACC_B, AP2, 2, 0) }                                       \
+    if ((NZ2) & 0x6u) { CONV2W_ROW(ACC_A, ACC_B, AP2, 2, 1) }                                       \
+    if ((NZ2) & 0xCu) { CONV2W_ROW(ACC_A, ACC_B, AP2, 2, 2) }
+
+#define S1W_WAVE_SYNC()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+__global__ void __launch_bounds__(64 * S1W_WAVES, 2) k_enc_stage1w(const caelo_enc_in in, int64_t n_patches, int group,
+                                                                 int *__restrict__ counters, const float *__restrict__ w1g,
+                                                                 const float *__restrict__ b1g, const float *__restrict__ w2g,
+                                                                 const float *__restrict__ c0g, float *__restrict__ p2out) {
+    __shared__ __attribute__((aligned(16))) Stage1wLds L;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4;   // MFMA k-group
+    const int n = lane & 15;   // MFMA column (output channel) for B/C, row for A
+    // ---- one-time: weights.  B fragment for k-step (tap t, h): W2[t][cin = 2g + h][n]
+    float breg[27][2];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        breg[t][0] = w2g[(t * 8 + 2 * g) * 16 + n];
+        breg[t][1] = w2g[(t * 8 + 2 * g + 1) * 16 + n];
+    }
+    // C0 = b2 + conv2(BG) accumulator fragments.  A wavefront owns all 16 tile pairs of a patch (128 registers of C0), but C0
+    // only depends on which borders a position touches: x in {0, interior, 7}, y likewise (z is fixed per lane), and the
+    // host builds the table with one loop order, so equal border patterns hold equal floats.  9 fragments cover every tile:
+    // c0cls[xc][yc], xc = 0 / 1 / 2 for x = 0 / 1..6 / 7, yc = 0 / 1 / 2 for the row pairs yi = 0 / 1,2 / 3; bgcls = the
+    // outputs tanh(pool2(C0)) of a pair that sees nothing but background, by (x pair 0 / 1,2 / 3, yc).
+    f32x4 c0cls[3][3];
+    float bgcls[3][3][2];
+#pragma unroll
+    for (int xc = 0; xc < 3; ++xc)
+#pragma unroll
+        for (int yc = 0; yc < 3; ++yc) {
+            const int x = xc == 0 ? 0 : (xc == 1 ? 2 : 7), y = (yc == 0 ? 0 : (yc == 1 ? 2 : 6)) + (g >> 1);
+            const float *c0a = c0g + (size_t)(((x * 8 + y) * 8 + 4 * (g & 1)) * 16 + n);
+            c0cls[xc][yc] = (f32x4){c0a[0], c0a[16], c0a[32], c0a[48]};
+        }
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+        for (int yc = 0; yc < 3; ++yc) {
+            const f32x4 f0 = c0cls[pc == 0 ? 0 : 1][yc], f1 = c0cls[pc == 2 ? 2 : 1][yc];
+            float v0 = fmaxf(fmaxf(f0[0], f0[1]), fmaxf(f1[0], f1[1]));
+            float v1 = fmaxf(fmaxf(f0[2], f0[3]), fmaxf(f1[2], f1[3]));
+            v0 = fmaxf(v0, __shfl_xor(v0, 32));
+            v1 = fmaxf(v1, __shfl_xor(v1, 32));
+            bgcls[pc][yc][0] = enc_tanh(v0);
+            bgcls[pc][yc][1] = enc_tanh(v1);
+        }
+    for (int i = tid; i < 27 * 8; i += 64 * S1W_WAVES) L.w1[i] = w1g[i];
+    if (tid < 8) { L.b1[tid] = b1g[tid]; L.bg[tid] = c0g[512 * 16 + tid]; }  // bg = tanh(b1), from the host table
+    Stage1wWave &W = L.w[wave];
+    for (int i = lane; i < 2 * S1W_PLANE; i += 64) W.ring[i] = 0.0f;  // D == 0: halo, pads, background cells
+#pragma unroll
+    for (int q = 0; q < 8; ++q) W.mask[lane + 64 * q] = 0ull;
+    if (lane < 12) { W.nz[lane] = 0u; W.pstart[lane] = 0; }
+    __syncthreads();  // the only workgroup barrier: from here on every wavefront is on its own
+    const int n_items = enc_items_total(in, n_patches);
+    const int nk = (int)(n_patches / group);
+    // ---- this XCD's queue: items xcd, xcd + 8, ...; the first one per wavefront is static
+    const int xcd = blockIdx.x & 7;
+    const int wg_of_xcd = ((int)gridDim.x - xcd + 7) >> 3;
+    const int first_dyn = wg_of_xcd * S1W_WAVES;  // queue position the counter starts handing out
+    int *ctr = counters + xcd * S1W_CSTRIDE;
+    int J = xcd + 8 * ((int)(blockIdx.x >> 3) * S1W_WAVES + wave);
+    // lane l holds the 16-voxel rows l, l + 64, l + 128, l + 192 of the patch (row r: ix = r >> 4, iy = r & 15, bit = iz)
+    unsigned int rows[4] = {0u, 0u, 0u, 0u};
+    int patch = 0;
+    if (J < n_items) {
+        const unsigned long long *src;
+        enc_item(in, J, nk, group, src, patch);
+        patch = __builtin_amdgcn_readfirstlane(patch);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rows[q] = ((const unsigned short *)src)[lane + 64 * q];
+    }
+    const int yl = n >> 3, z = n & 7;  // A row m = yl*8 + z
+    const bool zlo = z >= 1, zhi = z <= 6;
+    int Jn = n_items;  // the item after J
+    if (J < n_items) {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(ctr, 1);
+        Jn = xcd + 8 * (first_dyn + __builtin_amdgcn_readfirstlane(v));
+    }
+#ifdef CAELO_ENC_PROF
+    unsigned int pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned int pt = (unsigned)wall_clock64();
+#define S1W_STAMP(i) do { const unsigned t_ = (unsigned)wall_clock64(); pf[i] += t_ - pt; pt = t_; } while (0)
+#else
+#define S1W_STAMP(i) do { } while (0)
+#endif
+    while (J < n_items) {
+        S1W_STAMP(7);
+        // ---- scatter every set voxel into the receptive-field masks of the (up to 8) pooled cells that see it
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned int bits16 = rows[q];
+            if (bits16 == 0u) continue;
+            const int r = lane + 64 * q;
+            const int x = r >> 4, y = r & 15;
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int px = ((x + 1) >> 1) - dx;
+                if (px < 0 || px > 7) continue;
+                const int a = x + 1 - 2 * px;  // x = 2px - 1 + a
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    const int py = ((y + 1) >> 1) - dy;
+                    if (py < 0 || py > 7) continue;
+                    const int b = y + 1 - 2 * py;
+#pragma unroll
+                    for (int pz = 0; pz < 8; ++pz) {
+                        const unsigned int nib = ((bits16 << 1) >> (2 * pz)) & 0xFu;  // z = 2pz-1 .. 2pz+2
+                        if (nib != 0u) atomicOr(&W.mask[(px * 8 + py) * 8 + pz], (unsigned long long)nib << (a * 16 + b * 4));
+                    }
+                }
+            }
+        }
+        // ---- prefetch, two deep: the rows of the NEXT item (its index arrived during the previous patch) and the index of the
+        // one after (one returning atomic on this XCD's counter).  Both are consumed before the last conv2 block below, a
+        // whole patch later: nothing here waits for memory.
+        unsigned int rows_next[4] = {0u, 0u, 0u, 0u};
+        int patch_next = 0;
+        if (Jn < n_items) {
+            const unsigned long long *src;
+            enc_item(in, Jn, nk, group, src, patch_next);
+            patch_next = __builtin_amdgcn_readfirstlane(patch_next);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rows_next[q] = ((const unsigned short *)src)[lane + 64 * q];
+        }
+        int fetched = 0;
+        if (lane == 0) fetched = atomicAdd(ctr, 1);
+        S1W_WAVE_SYNC();
+        S1W_STAMP(0);
+        // ---- the cells with a non-empty mask in ascending cell order = x plane by x plane (64 cells each)
+        int nlist = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int cell = lane + 64 * q;
+            const bool hit = W.mask[cell] != 0ull;
+            const unsigned long long bal = __ballot(hit);
+            if (hit) W.list[nlist + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)cell;
+            // byte py of the ballot = the 8 z cells of row (q, py): non-empty rows -> bit py + 1 of the padded plane q + 1
+            unsigned long long m = bal;
+            m |= m >> 4; m |= m >> 2; m |= m >> 1;
+            m &= 0x0101010101010101ull;
+            const unsigned int nzb = (unsigned int)((m * 0x0102040810204080ull) >> 56) << 1;
+            if (lane == 0) { W.pstart[q] = (unsigned short)nlist; W.nz[q + 1] = nzb; }
+            nlist += __popcll(bal);
+        }
+        if (lane == 0) W.pstart[8] = (unsigned short)nlist;
+        S1W_WAVE_SYNC();
+        S1W_STAMP(1);
+        // ---- x plane by x plane: conv1 + pool1 + tanh into the ring, conv2 two planes behind
+#pragma unroll 1
+        for (int px = 0; px < 8; ++px) {
+            if (px >= 4) {  // the slot's previous tenant (plane px - 4): wipe its cells
+                const int s0 = W.pstart[px - 4], s1 = W.pstart[px - 3];
+                const int slot = (px + 1) & 3;
+                for (int i = lane; i < 2 * (s1 - s0); i += 64) {
+                    const int cell = W.list[s0 + (i >> 1)];
+                    const int q = (slot * 10 + ((cell >> 3) & 7) + 1) * 8 + (cell & 7);
+                    *(float4 *)&W.ring[(i & 1) * S1W_PLANE + (P1_FRONT + q) * 4] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                S1W_WAVE_SYNC();
+            }
+            S1W_STAMP(4);
+            {
+                const int s0 = __builtin_amdgcn_readfirstlane((int)W.pstart[px]), s1 = __builtin_amdgcn_readfirstlane((int)W.pstart[px + 1]);
+                const int slot = (px + 1) & 3;
+                for (int base = s0; base < s1; base += 8) {  // 8 lanes = the 8 positions of a pooling block
+                    const int item = base + (lane >> 3);
+                    const int sub = lane & 7;
+                    float acc[8];
+                    int cell = 0;
+                    if (item < s1) {
+                        cell = W.list[item];
+                        const unsigned long long mask = W.mask[cell];
+                        const int sa = sub >> 2, sb = (sub >> 1) & 1, sc = sub & 1;
+                        unsigned int taps = 0;  // bit (ka*3+kb)*3+kc
+#pragma unroll
+                        for (int ka = 0; ka < 3; ++ka)
+#pragma unroll
+                            for (int kb = 0; kb < 3; ++kb)
+                                taps |= ((unsigned int)(mask >> ((sa + ka) * 16 + (sb + kb) * 4 + sc)) & 7u) << ((ka * 3 + kb) * 3);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) acc[c] = L.b1[c];
+                        while (taps) {  // ascending tap order == the oracle's (kx,ky,kz) order
+                            const int t = __ffs((int)taps) - 1;
+                            taps &= taps - 1;
+                            const float4 wa = *(const float4 *)&L.w1[t * 8], wb = *(const float4 *)&L.w1[t * 8 + 4];
+                            acc[0] += wa.x; acc[1] += wa.y; acc[2] += wa.z; acc[3] += wa.w;
+                            acc[4] += wb.x; acc[5] += wb.y; acc[6] += wb.z; acc[7] += wb.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) acc[c] = -3.0e38f;
+                    }
+                    // max over the pooling block = 8 aligned lanes (tanh is monotone: pool the pre-activations)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        acc[c] = fmaxf(acc[c], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[c]), 0xB1, 0xF, 0xF, true)));
+                        acc[c] = fmaxf(acc[c], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[c]), 0x4E, 0xF, 0xF, true)));
+                        acc[c] = fmaxf(acc[c], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[c]), 0x141, 0xF, 0xF, true)));
+                    }
+                    if (item < s1) {
+                        float mine = acc[0];  // lane `sub` finishes channel `sub`
+#pragma unroll
+                        for (int c = 1; c < 8; ++c) mine = (sub == c) ? acc[c] : mine;
+                        const int q = (slot * 10 + ((cell >> 3) & 7) + 1) * 8 + (cell & 7);
+                        W.ring[(sub >> 2) * S1W_PLANE + (P1_FRONT + q) * 4 + (sub & 3)] = enc_tanh(mine) - L.bg[sub];
+                    }
+                }
+            }
+            S1W_STAMP(2);
+            if (!(px == 2 || px == 4 || px == 6 || px == 7)) continue;
+            if (px == 7) {  // the prefetches of this patch: waited for HERE, before the last P2 stores are in flight
+                asm volatile("" :: "v"(rows_next[0]), "v"(rows_next[1]), "v"(rows_next[2]), "v"(rows_next[3]), "v"(fetched));
+            }
+            S1W_WAVE_SYNC();
+            // ---- conv2 (8->16) on MFMA for the output x pair xp: input planes (padded) 2xp .. 2xp+3
+            const int xp = px == 7 ? 3 : (px >> 1) - 1;
+            const unsigned int nz0 = (unsigned)__builtin_amdgcn_readfirstlane((int)W.nz[2 * xp]);
+            const unsigned int nz1 = (unsigned)__builtin_amdgcn_readfirstlane((int)W.nz[2 * xp + 1]);
+            const unsigned int nz2 = (unsigned)__builtin_amdgcn_readfirstlane((int)W.nz[2 * xp + 2]);
+            const unsigned int nz3 = (unsigned)__builtin_amdgcn_readfirstlane((int)W.nz[2 * xp + 3]);
+            const float *plane = W.ring + (g >> 1) * S1W_PLANE + 2 * (g & 1) + (P1_FRONT + yl * 8 + z) * 4;
+            const float *pl0 = plane + (((2 * xp) & 3) * 80) * 4, *pl1 = plane + (((2 * xp + 1) & 3) * 80) * 4;
+            const float *pl2 = plane + (((2 * xp + 2) & 3) * 80) * 4, *pl3 = plane + (((2 * xp + 3) & 3) * 80) * 4;
+            const bool x_lo = xp == 0, x_hi = xp == 3;  // wave-uniform
+#pragma unroll
+            for (int yi = 0; yi < 4; ++yi) {
+                const int y0 = 2 * yi;
+                const int yc = yi == 0 ? 0 : (yi == 3 ? 2 : 1);
+                const unsigned int r0 = (nz0 >> y0) & 0xFu, r1 = (nz1 >> y0) & 0xFu, r2 = (nz2 >> y0) & 0xFu, r3 = (nz3 >> y0) & 0xFu;
+                const int pair = xp * 4 + yi;
+                // C column = n (channel), rows 4g..4g+3 -> z = 4*(g&1)+r ; pooled cell (xp, yi, 2*(g&1)+{0,1})
+                float *dst = p2out + (size_t)patch * 1024 + (size_t)((pair * 4 + 2 * (g & 1)) * 16 + n);
+                if ((r0 | r1 | r2 | r3) == 0u) {  // nothing but background feeds this pair: per-model constants
+                    if (g < 2) {
+                        dst[0] = x_lo ? bgcls[0][yc][0] : (x_hi ? bgcls[2][yc][0] : bgcls[1][yc][0]);
+                        dst[16] = x_lo ? bgcls[0][yc][1] : (x_hi ? bgcls[2][yc][1] : bgcls[1][yc][1]);
+                    }
+                    continue;
+                }
+                // accumulators start from C0 = b2 + conv2(BG); two per tile to keep the MFMA chains independent
+                f32x4 acc0, acc1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc0[r] = x_lo ? c0cls[0][yc][r] : c0cls[1][yc][r];
+                    acc1[r] = x_hi ? c0cls[2][yc][r] : c0cls[1][yc][r];
+                }
+                f32x4 acc0b = {0.f, 0.f, 0.f, 0.f}, acc1b = {0.f, 0.f, 0.f, 0.f};
+                const float *a0 = pl0 + y0 * 32, *a1 = pl1 + y0 * 32, *a2 = pl2 + y0 * 32, *a3 = pl3 + y0 * 32;
+                CONV2W_TILE(acc0, acc0b, a0, a1, a2, r0, r1, r2)
+                CONV2W_TILE(acc1, acc1b, a1, a2, a3, r1, r2, r3)
+                acc0 += acc0b;
+                acc1 += acc1b;
+                // ---- pool2: x pair in registers, z pairs in registers, y pair across lanes g <-> g^2
+                float v0 = fmaxf(fmaxf(acc0[0], acc0[1]), fmaxf(acc1[0], acc1[1]));  // pz = 2*(g&1)
+                float v1 = fmaxf(fmaxf(acc0[2], acc0[3]), fmaxf(acc1[2], acc1[3]));  // pz = 2*(g&1)+1
+                v0 = fmaxf(v0, __shfl_xor(v0, 32));
+                v1 = fmaxf(v1, __shfl_xor(v1, 32));
+                if (g < 2) {
+                    dst[0] = enc_tanh(v0);
+                    dst[16] = enc_tanh(v1);
+                }
+            }
+            S1W_STAMP(3);
+        }
+        S1W_STAMP(3);
+        S1W_WAVE_SYNC();
+        // ---- back to D == 0 and empty masks for the next patch (planes 0..3 were wiped when their slots were reused;
+        // wiping their positions again is harmless)
+        for (int i = lane; i < nlist; i += 64) {
+            const int cell = W.list[i];
+            const int q = ((((cell >> 6) + 1) & 3) * 10 + ((cell >> 3) & 7) + 1) * 8 + (cell & 7);
+            *(float4 *)&W.ring[(P1_FRONT + q) * 4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            *(float4 *)&W.ring[S1W_PLANE + (P1_FRONT + q) * 4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            W.mask[cell] = 0ull;
+        }
+        S1W_WAVE_SYNC();
+        S1W_STAMP(4);
+#ifdef CAELO_ENC_PROF
+        pf[5] += 1; pf[6] += (unsigned)nlist;
+#endif
+        J = Jn;
+        Jn = xcd + 8 * (first_dyn + __builtin_amdgcn_readfirstlane(fetched));
+        patch = patch_next;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rows[q] = rows_next[q];
+    }
+#ifdef CAELO_ENC_PROF
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_enc_stamp[i], (unsigned long long)pf[i]);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // stage 1 in two kernels (round 2): k_enc_conv1 (sparse conv1 + pool1, one WAVEFRONT per patch) -> k_enc_conv2
 // ------------------------------------------------------------------------------------------------
 // k_enc_stage1 above interleaves, per patch and per 4-wave workgroup, three short VALU / LDS phases (mask scatter,
@@ -858,11 +1213,13 @@ static void conv3_split_weights(const float *w3, uint4 *out) {
 
 __global__ void __launch_bounds__(256, 2) k_enc_conv3(const float *__restrict__ p2, int64_t n_patches, const caelo_enc_in in,
                                                       const uint4 *__restrict__ w3x, const float *__restrict__ b3g,
-                                                      float *__restrict__ f3, int *__restrict__ stage1_counter) {
+                                                      float *__restrict__ f3, int *__restrict__ stage1_counter,
+                                                      int *__restrict__ xcd_counters) {
     __shared__ uint4 S[2 * C3X_SLOT];
     // stage 1 (the previous kernel on this stream) is complete: hand its work counter back at zero, so that no
     // memset launch sits on the encoder stream's critical path
     if (blockIdx.x == 0 && threadIdx.x == 0) *stage1_counter = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 8) xcd_counters[threadIdx.x * S1W_CSTRIDE] = 0;  // k_enc_stage1w's queues
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -1150,7 +1507,8 @@ static int dense1_launch(const float *f3, int64_t np, const void *wd1x, float *p
     // 64-row tiles for K = 2048 (8 stages per workgroup; measured 1 % ahead of 192-row tiles inside the frame
     // pipeline although 15 % behind in isolation); 192-row tiles for the long-K instance, where the weight stream
     // from L2 would otherwise bound the kernel
-    const bool big = KTOT > 2048;
+    static const int force = getenv("CAELO_D1_MTW") ? atoi(getenv("CAELO_D1_MTW")) : 0;
+    const bool big = force ? force == 3 : KTOT > 2048;
     if (big && np % 192 == 0) {
         dim3 gd((unsigned)(np / 192), D1_SPLIT);
         k_enc_dense1<KTOT, 3><<<gd, D1_THREADS, D1_LDS_BYTES(3), s>>>(f3, np, (const uint4 *)wd1x, part, in);
@@ -1228,7 +1586,7 @@ static inline int64_t dl_bytes(int64_t np) { return np * (4 * 4 + DL_MAX * 2 + (
 
 CAELO_API int64_t caelo_encode_ws_bytes(int64_t n_patches) {
     const int64_t np = pad64(n_patches);
-    return 256 + (np * 1024 + np * 2048 + (int64_t)D1_SPLIT * np * DENSE_NP) * (int64_t)sizeof(float) + dl_bytes(np);
+    return CAELO_ENC_WS_HEADER + (np * 1024 + np * 2048 + (int64_t)D1_SPLIT * np * DENSE_NP) * (int64_t)sizeof(float) + dl_bytes(np);
 }
 
 int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
@@ -1252,11 +1610,11 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     CAELO_REQUIRE(c->has_enc, "encoder weights not set (caelo_set_encoder_weights)");
     CAELO_REQUIRE(n_patches > 0 && group >= 1 && out_stride >= group * 20, "bad shape");
     const int64_t np = pad64(n_patches);
-    // ws = [256 bytes: conv-2 work counter, zero between calls (the owner zero-fills ws once, conv3 resets it); bytes 8..15
+    // ws = [header (CAELO_ENC_WS_HEADER bytes): work counter, zero between calls (the owner zero-fills ws once, conv3 resets it); bytes 8..15
     // = MFMA tap rows the last conv-2 launch executed] | P2 | F3 | dense-1 partial sums | conv-1 cell lists
     int *work_counter = (int *)ws;
     unsigned long long *mfma_count = (unsigned long long *)((char *)ws + 8);
-    float *p2 = (float *)((char *)ws + 256);
+    float *p2 = (float *)((char *)ws + CAELO_ENC_WS_HEADER);
     float *f3 = p2 + np * 1024;
     float *part = f3 + np * 2048;
     EncLists dl;
@@ -1270,6 +1628,18 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     // k_enc_stage1 (conv1 + conv2 in one persistent kernel) is the default; CAELO_ENC_SPLIT=1 selects the two-kernel
     // variant (k_enc_conv1 + k_enc_conv2, bit-identical results), measured 25 % slower
     static const bool fused_stage1 = !(getenv("CAELO_ENC_SPLIT") && atoi(getenv("CAELO_ENC_SPLIT")) > 0);
+    // CAELO_ENC_WAVE=1 selects k_enc_stage1w (a patch per wavefront, no workgroup barriers; bit-identical P2) instead of
+    // k_enc_stage1 (a patch per 4-wave workgroup).  Measured slower: 93 vs 62 us for one frame, 375 vs 292 us for an 8-frame
+    // launch -- two wavefronts per SIMD (LDS) do not cover its LDS / dependency waits either.
+    static const bool wave_stage1 = fused_stage1 && getenv("CAELO_ENC_WAVE") && atoi(getenv("CAELO_ENC_WAVE")) > 0;
+    static const int slots1w = [](int device) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_enc_stage1w, 64 * S1W_WAVES, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || per_cu * cus <= 0)
+            return 512;
+        return per_cu * cus;
+    }(c->device);
+    int *xcd_counters = (int *)((char *)ws + 1024);  // 8 x one 128-byte line
     static const int slots1 = [](int device) {
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_stage1 ? (const void *)k_enc_stage1 : (const void *)k_enc_conv2, 256, 0) != hipSuccess ||
@@ -1284,7 +1654,13 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     const unsigned g1 = (unsigned)(n_patches < cap1 ? n_patches : cap1);
     if (ev) CAELO_HIP(hipEventRecord(ev[0], s));
     const int order_group = (n_patches % group == 0) ? group : 1;
-    if (fused_stage1) {
+    if (wave_stage1) {
+        const int64_t capw = ein.yield ? (int64_t)slots1w * 4 / 5 : slots1w;
+        const int64_t wgs = (n_patches + S1W_WAVES - 1) / S1W_WAVES;
+        k_enc_stage1w<<<(unsigned)(wgs < capw ? wgs : capw), 64 * S1W_WAVES, 0, s>>>(ein, n_patches, order_group, xcd_counters, c->enc_w1, c->enc_b1,
+                                                                                   c->enc_w2, c->enc_c0, p2);
+        CAELO_LAUNCH_CHECK();
+    } else if (fused_stage1) {
         k_enc_stage1<<<g1, 256, 0, s>>>(ein, n_patches, order_group, work_counter, c->enc_w1, c->enc_b1, c->enc_w2, c->enc_c0, p2);
         CAELO_LAUNCH_CHECK();
     } else {
@@ -1297,7 +1673,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     const int64_t pairs = (n_patches + 1) / 2;
     const int64_t cap3 = ein.yield ? 256 : 512;
     const unsigned g3 = (unsigned)(pairs < cap3 ? pairs : cap3);  // persistent: two 4-wave workgroups per CU
-    k_enc_conv3<<<g3, 256, 0, s>>>(p2, n_patches, ein, (const uint4 *)c->enc_w3x, c->enc_b3, f3, work_counter);
+    k_enc_conv3<<<g3, 256, 0, s>>>(p2, n_patches, ein, (const uint4 *)c->enc_w3x, c->enc_b3, f3, work_counter, xcd_counters);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[2], s));
     {

@@ -200,7 +200,7 @@ CAELO_API int caelo_pipeline_create(caelo_ctx *c, int batch, int n_buffers, int6
         if (rc == CAELO_OK) rc = caelo_voxmap_create(c, max_points, &p->maps[i]);
     }
     hip_ok(hipMalloc(&p->enc_ws, (size_t)caelo_encode_ws_bytes(batch * FRAME_PATCHES)), "hipMalloc");
-    if (rc == CAELO_OK) hip_ok(hipMemset(p->enc_ws, 0, 256), "hipMemset");  // stage-1 work counter (self-cleaning)
+    if (rc == CAELO_OK) hip_ok(hipMemset(p->enc_ws, 0, CAELO_ENC_WS_HEADER), "hipMemset");  // stage-1 work counters (self-cleaning)
     if (rc != CAELO_OK) {
         caelo_pipeline_destroy(p);
         return rc;

@@ -136,7 +136,7 @@ int caelo_pack_patches(caelo_ctx *ctx, const float *dense, int64_t n_patches, ui
  * bits [n_patches][64] u64 -> out[(p / group) * out_stride + (p % group) * 20 + j].
  * group = 1, out_stride = 20: plain predict; group = 3, out_stride = 60 on [K][3][64]: Features [K][60].
  * workspace: ws of caelo_encode_ws_bytes(n_patches) bytes, zero-filled ONCE by its owner before the first call
- * (its first 256 bytes hold a work counter that every call returns to zero), one ws per stream. */
+ * (its first 2 048 bytes hold work counters that every call returns to zero), one ws per stream. */
 int64_t caelo_encode_ws_bytes(int64_t n_patches);
 int caelo_encode(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
                  void *ws, void *stream);
