@@ -545,10 +545,10 @@ __device__ inline void sample_hypothesis(const float *P0, int l0, const int64_t 
 }
 
 // Two launches per set of pairs.
-//   k_ransac_hyp     the 500 hypotheses of the first threshold level (0.4 m), one wavefront each, 4 per workgroup:
+//   k_ransac_hyp     the 500 hypotheses of the first threshold level (0.4 m), four per wavefront, 16 per workgroup:
 //                    the matched pairs (P0[pair_idx[i]], P1[i]) are gathered once per workgroup into LDS (coalesced;
-//                    the residual loops then never touch global memory), Kabsch on the 4-sample, residuals, ballot +
-//                    popcount inlier count -> counts[trial].
+//                    the residual loop then never touches global memory), Kabsch on the 4-samples (one hypothesis
+//                    per lane group), residuals of the four poses in one pass, ballot + popcount -> counts[trial].
 //   k_ransac_finish  one workgroup per pair: replays the sequential accept / early-exit rules over the counts
 //                    (Match.py:181-206) as a prefix maximum; if the level failed (no hypothesis reached leastInliers,
 //                    :207-214) it evaluates the next level's 500 hypotheses itself -- rare, so its four wavefronts
@@ -597,6 +597,11 @@ __device__ inline int hypothesis_count(const float *P0, int l0, const int64_t *p
     return cnt;
 }
 
+// One wavefront = RH_PER_WAVE hypotheses: lane l derives hypothesis l & 3 (the Kabsch step is a long serial f64 chain
+// that costs the same for 1 or 64 lanes; the 16 lanes that share a hypothesis must agree -- the hardware self-check),
+// then the four poses are broadcast through scalar registers and ONE pass over the staged pairs counts the inliers of
+// all four (a pair is read from LDS once).  Round 2 before: one hypothesis per wavefront, 35 us per 8 pairs.
+#define RH_PER_WAVE 4
 __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp(const caelo_pair_set ps, int ld0, int ld1, int64_t k1_max) {
     const caelo_pair_dev &P = ps.p[blockIdx.z];
     const float *__restrict__ pc0 = P.pc0, *__restrict__ pc1 = P.pc1;
@@ -616,11 +621,52 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp(const caelo_pair_s
         }
     }
     __syncthreads();
-    const int trial = blockIdx.x * RE_WAVES + wave;
-    int cnt;
-    if (in_lds) cnt = hypothesis_count(sP0, 3, nullptr, sP1, 3, N, P.rand + (size_t)trial * 4, 0.4f, lane, ps.faults);
-    else cnt = hypothesis_count(pc0, ld0, pair_idx, pc1, ld1, N, P.rand + (size_t)trial * 4, 0.4f, lane, ps.faults);
-    if (lane == 0) ws->counts[trial] = cnt;
+    const int trial0 = (blockIdx.x * RE_WAVES + wave) * RH_PER_WAVE;  // wave-uniform
+    if (trial0 >= CAELO_RANSAC_MAX_TRIALS) return;
+    if (!in_lds) {  // more pairs than the LDS stage holds: one hypothesis at a time from global memory
+        for (int h = 0; h < RH_PER_WAVE && trial0 + h < CAELO_RANSAC_MAX_TRIALS; ++h) {
+            const int cnt = hypothesis_count(pc0, ld0, pair_idx, pc1, ld1, N, P.rand + (size_t)(trial0 + h) * 4, 0.4f, lane, ps.faults);
+            if (lane == 0) ws->counts[trial0 + h] = cnt;
+        }
+        return;
+    }
+    // ---- lane l: hypothesis trial0 + (l & 3) (a trial past the last repeats the last one; its count is not stored)
+    const int mine = min(trial0 + (lane & (RH_PER_WAVE - 1)), CAELO_RANSAC_MAX_TRIALS - 1);
+    float R[9], T[3];
+    sample_hypothesis(sP0, 3, nullptr, sP1, 3, N, P.rand + (size_t)mine * 4, R, T);
+    if (ps.faults) {  // the 16 lanes of a hypothesis hold the same pose, bit for bit
+        unsigned int hsh = 0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) hsh = hsh * 0x9E3779B1u + __float_as_uint(R[q]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) hsh = hsh * 0x9E3779B1u + __float_as_uint(T[q]);
+        const bool bad = hsh != (unsigned int)__shfl_xor((int)hsh, 4) || hsh != (unsigned int)__shfl_xor((int)hsh, 16) ||
+                         hsh != (unsigned int)__shfl_xor((int)hsh, 32);
+        if (__ballot(bad) != 0ull && lane == 0) atomicAdd(ps.faults, 1);
+    }
+    // ---- the four poses in scalar registers, one pass over the pairs
+    float Rs[RH_PER_WAVE][9], Ts[RH_PER_WAVE][3];
+#pragma unroll
+    for (int h = 0; h < RH_PER_WAVE; ++h) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) Rs[h][q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(R[q]), h));
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Ts[h][q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(T[q]), h));
+    }
+    int cnt[RH_PER_WAVE] = {0, 0, 0, 0};
+    for (int i = lane; i < ((N + 63) & ~63); i += 64) {
+        const bool live = i < N;
+        const int ii = live ? i : 0;
+        const float ax = sP0[3 * ii], ay = sP0[3 * ii + 1], az = sP0[3 * ii + 2];
+        const float bx = sP1[3 * ii], by = sP1[3 * ii + 1], bz = sP1[3 * ii + 2];
+#pragma unroll
+        for (int h = 0; h < RH_PER_WAVE; ++h) {
+            const bool in = live && residual(Rs[h], Ts[h], ax, ay, az, bx, by, bz) < 0.4f;
+            cnt[h] += __popcll(__ballot(in));
+        }
+    }
+    if (lane < RH_PER_WAVE && trial0 + lane < CAELO_RANSAC_MAX_TRIALS)
+        ws->counts[trial0 + lane] = lane == 0 ? cnt[0] : (lane == 1 ? cnt[1] : (lane == 2 ? cnt[2] : cnt[3]));
 }
 
 __global__ void __launch_bounds__(256) k_ransac_finish(const caelo_pair_set ps, int ld0, int ld1, int64_t k1_max) {
@@ -721,7 +767,7 @@ CAELO_API int caelo_ransac(caelo_ctx *c, const float *pc0, int ld0, const float 
 int ransac_set(const caelo_pair_set &ps, int ld0, int ld1, int64_t k1_max, hipStream_t s) {
     CAELO_REQUIRE(ps.n >= 1 && ps.n <= CAELO_FB_MAX, "bad pair count");
     CAELO_REQUIRE(k1_max > 0 && ld0 >= 3 && ld1 >= 3, "bad shape");
-    k_ransac_hyp<<<dim3(CAELO_RANSAC_MAX_TRIALS / RE_WAVES, 1, ps.n), 64 * RE_WAVES, 0, s>>>(ps, ld0, ld1, k1_max);
+    k_ransac_hyp<<<dim3((CAELO_RANSAC_MAX_TRIALS + RE_WAVES * RH_PER_WAVE - 1) / (RE_WAVES * RH_PER_WAVE), 1, ps.n), 64 * RE_WAVES, 0, s>>>(ps, ld0, ld1, k1_max);
     CAELO_LAUNCH_CHECK();
     k_ransac_finish<<<dim3(1, 1, ps.n), 256, 0, s>>>(ps, ld0, ld1, k1_max);
     CAELO_LAUNCH_CHECK();
