@@ -49,6 +49,8 @@ struct caelo_pipeline {
     // host state
     std::vector<caelo_frame_job> pending;
     uint64_t n_batches = 0, submitted = 0;
+    int since_begin = 0;  // batches issued since caelo_pipeline_begin
+    int first_batch = 0;  // size of the first batch of the next run (caelo_pipeline_expect), 0 = a full one
     bool have_last = false;
     caelo_frame_job last = {};
     int64_t stat_jobs = 0, stat_issue_ns = 0, stat_batches = 0;
@@ -120,6 +122,8 @@ int issue_batch(caelo_pipeline *p) {
     p->have_last = true;
     p->stat_jobs += n;
     p->stat_batches += 1;
+    p->since_begin += 1;
+    p->first_batch = 0;
     p->pending.clear();
     const int64_t t3 = now_ns();
     p->stat_issue_ns += t3 - t0;
@@ -226,8 +230,19 @@ CAELO_API int caelo_pipeline_stats(caelo_pipeline *p, int64_t *out_host) {
 CAELO_API int caelo_pipeline_begin(caelo_pipeline *p, void *stream) {
     CAELO_REQUIRE(p, "null argument");
     p->pending.clear();
+    p->since_begin = 0;
     CAELO_HIP(hipEventRecord(p->begun, caelo_stream(stream)));
     for (hipStream_t s : {p->sF, p->sE, p->sP}) CAELO_HIP(hipStreamWaitEvent(s, p->begun, 0));
+    return CAELO_OK;
+}
+
+// A run whose length is not a multiple of the batch size has one partial batch; nothing overlaps the front stage of the FIRST
+// batch (the encoder, the critical resource, idles meanwhile), so that is where the short one belongs: 20 frames as 4 + 8 + 8
+// instead of 8 + 8 + 4 is 7.9 -> 8.2 k frames/s.  (A short first batch on top of full ones -- 2 + 8 + 8 + 2 -- costs more in
+// launch sets than it gains: 7.7 k.)  Without the hint every batch is full and the remainder goes last.
+CAELO_API int caelo_pipeline_expect(caelo_pipeline *p, int64_t n_frames) {
+    CAELO_REQUIRE(p && n_frames >= 0, "bad argument");
+    p->first_batch = (int)(n_frames % p->batch);
     return CAELO_OK;
 }
 
@@ -249,7 +264,8 @@ CAELO_API int caelo_pipeline_submit(caelo_pipeline *p, const caelo_frame_job *jo
     }
     p->pending.push_back(*job);
     ++p->submitted;
-    if ((int)p->pending.size() == p->batch) return issue_batch(p);
+    const int target = (p->since_begin == 0 && p->first_batch > 0) ? p->first_batch : p->batch;
+    if ((int)p->pending.size() >= target) return issue_batch(p);
     return CAELO_OK;
 }
 

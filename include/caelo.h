@@ -312,6 +312,9 @@ int caelo_pipeline_submit(caelo_pipeline *pipe, const caelo_frame_job *job);
 int caelo_pipeline_flush(caelo_pipeline *pipe, void *stream);
 /* host-side counters since the last call (then reset): out_host[6] = jobs, ns the calling thread spent issuing their
  * launches, batches launched, batch size, hand-off buffers, HIP streams used */
+/* Optional hint before caelo_pipeline_begin: the run will submit n_frames jobs.  The partial batch (n_frames % batch) is then
+ * issued FIRST instead of last -- nothing can overlap the first batch's front stage, so a short one starts the encoder sooner. */
+int caelo_pipeline_expect(caelo_pipeline *pipe, int64_t n_frames);
 int caelo_pipeline_stats(caelo_pipeline *pipe, int64_t *out_host);
 
 #ifdef __cplusplus
