@@ -3,6 +3,7 @@ ctypes -> C ABI), against the CPU oracle on the same seeded inputs and against t
 generated from the reference.  Bar: bit-exact for indices / bytes / integer work, <= 1e-4 relative
 for descriptors and poses (BASELINE.json north_star)."""
 import hashlib
+import sys
 import os
 
 import numpy as np
@@ -896,3 +897,68 @@ def test_run_sequence_saves_consistent_artifacts_on_quantised_scans(tmp_path):
         n_printed = int(lines[i].split("inliers=")[1].split()[0])
         assert len(i0) == len(i1) == n_printed > 50 and i0.max() < 1024 and np.all(np.diff(i1) > 0)
     assert len(open(out).read().splitlines()) == 6
+
+
+# ---- round 2: the variants that claim bit-identical results, and the pipeline's batch plan -------------------------------------
+_VARIANT_SCRIPT = r"""
+import os, sys, hashlib
+sys.path.insert(0, os.path.join(%(repo)r, "cae-lo_amd"))
+import torch
+from caelo import synth
+from caelo.engine import Engine
+eng = Engine()
+for i in range(2):
+    pc = torch.from_numpy(synth.make_scan(i, quantum=1e-3)).to(eng.device)
+    f = eng.extract(pc)
+    torch.cuda.synchronize()
+    print(hashlib.sha256(f.rows.cpu().numpy().tobytes()).hexdigest())
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"CAELO_ENC_WAVE": "1"}, {"CAELO_ENC_SPLIT": "1"}])
+def test_stage1_variants_are_bit_identical(engine, env):
+    """k_enc_stage1w (a patch per wavefront) and the two-kernel variant (k_enc_conv1 + k_enc_conv2) promise the default kernel's
+    P2 bit for bit (same sums in the same order): the frame rows (descriptors + key points) of two scans, hashed in a process
+    that runs the variant, equal this process's."""
+    import hashlib
+    import subprocess
+    import torch
+    from caelo import synth
+    want = []
+    for i in range(2):
+        f = engine.extract(torch.from_numpy(synth.make_scan(i, quantum=1e-3)).to(engine.device))
+        torch.cuda.synchronize()
+        want.append(hashlib.sha256(f.rows.cpu().numpy().tobytes()).hexdigest())
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _VARIANT_SCRIPT % {"repo": repo}], env=dict(os.environ, **env),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = [l for l in out.stdout.split() if len(l) == 64]
+    assert got == want
+
+
+@pytest.mark.gpu
+def test_pipeline_batch_plan_does_not_change_results(engine, scans):
+    """caelo_pipeline_expect moves the partial batch of a run to the front (20 frames on batch 8: 4 + 8 + 8); every frame and
+    every pair must come out as from full batches with the remainder last, and the hardware self-check stays at 0."""
+    import ctypes as C
+    import torch
+    from caelo.engine import Pipeline, ransac_draws
+    pcs = [torch.from_numpy(scans(i, quantum=1e-3)).to(engine.device) for i in range(3)]
+    rnd = [torch.from_numpy(ransac_draws(90 + i)).to(engine.device) for i in range(3)]
+    prev = engine.extract(pcs[2])
+    n = 20
+    pipe = Pipeline(engine, 8, 3)
+    a = pipe.run([pcs[i % 3] for i in range(n)], [rnd[i % 3] for i in range(n)], prev=prev)
+    torch.cuda.synchronize()
+    st = pipe.stats()
+    assert st["jobs"] == n and st["batches"] == 3
+    got = [t.clone() for t in (a.rows, a.pair_idx, a.inlier_mask, a.result, a.key_pixels)]
+    # the same run fed in two calls of 16 + 4: full batches first, the remainder last
+    b = pipe.run([pcs[i % 3] for i in range(16)], [rnd[i % 3] for i in range(16)], prev=prev)
+    c = pipe.run([pcs[i % 3] for i in range(16, n)], [rnd[i % 3] for i in range(16, n)], prev=b.frame(15))
+    torch.cuda.synchronize()
+    for g, x, y in zip(got, (b.rows, b.pair_idx, b.inlier_mask, b.result, b.key_pixels), (c.rows, c.pair_idx, c.inlier_mask, c.result, c.key_pixels)):
+        assert torch.equal(g[:16], x[:16]) and torch.equal(g[16:n], y[:4])
+    assert engine.lane_faults() == 0
