@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcaelo.so")
+LIB_PATH = os.environ.get("CAELO_LIB") or os.path.join(_HERE, "libcaelo.so")   # CAELO_LIB: A/B runs of a variant build (tools/)
 
 c_vp, c_i64, c_i32, c_int = C.c_void_p, C.c_int64, C.c_int32, C.c_int
 

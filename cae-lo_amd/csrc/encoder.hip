@@ -1329,7 +1329,12 @@ __global__ void __launch_bounds__(256, 2) k_enc_conv3(const float *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 #define D1_BM 64
 #define D1_BK 32      // one v_mfma_f32_16x16x32_bf16 k-step per stage
-#define D1_SPLIT 8
+#define D1_SPLIT 8  // the most k slices any instance uses: sizes the partial-sum buffer
+// k slices per row tile: 8 for the long-K instance (K = 16384: 16 row tiles x 8 = 128 workgroups per frame); 4 for K = 2048 --
+// one frame still fills the chip (48 x 4 workgroups, 29 us either way), a batch of 8 frames writes and re-reads half the partial
+// sums (10.3 -> 10.6 k frames/s; 2 slices: 10.7 k but 48 us for a single frame).  One value for every launch size: the head adds
+// the slices in order, so the descriptors' low bits depend on it and single calls must equal batched ones bit for bit.
+#define D1_SPLIT_OF(KTOT) ((KTOT) > 2048 ? 8 : 4)
 #define D1_THREADS 512
 #define D1_NT (DENSE_NP / 16)          // 13 n-tiles
 #define D1_B16 (3 * D1_NT * 64)        // uint4 of a B stage: [split][n-tile][lane]
@@ -1386,7 +1391,7 @@ template <int KTOT, int MTW>
 __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1(const float *__restrict__ f3, int64_t n_rows_pad,
                                                               const uint4 *__restrict__ wd1x, float *__restrict__ part,
                                                               const caelo_enc_in in) {
-    constexpr int BM = 64 * MTW, A16 = 3 * 4 * BM, NKS = KTOT / D1_SPLIT / D1_BK;
+    constexpr int BM = 64 * MTW, A16 = 3 * 4 * BM, NKS = KTOT / D1_SPLIT_OF(KTOT) / D1_BK;
     if (in.dedup) {  // a row tile past the frame's distinct patches holds nothing (tiles never straddle frames)
         const int64_t r0 = (int64_t)blockIdx.x * BM;
         const int f = (int)(r0 / in.per_frame);
@@ -1510,10 +1515,10 @@ static int dense1_launch(const float *f3, int64_t np, const void *wd1x, float *p
     static const int force = getenv("CAELO_D1_MTW") ? atoi(getenv("CAELO_D1_MTW")) : 0;
     const bool big = force ? force == 3 : KTOT > 2048;
     if (big && np % 192 == 0) {
-        dim3 gd((unsigned)(np / 192), D1_SPLIT);
+        dim3 gd((unsigned)(np / 192), D1_SPLIT_OF(KTOT));
         k_enc_dense1<KTOT, 3><<<gd, D1_THREADS, D1_LDS_BYTES(3), s>>>(f3, np, (const uint4 *)wd1x, part, in);
     } else {
-        dim3 gd((unsigned)(np / 64), D1_SPLIT);
+        dim3 gd((unsigned)(np / 64), D1_SPLIT_OF(KTOT));
         k_enc_dense1<KTOT, 1><<<gd, D1_THREADS, D1_LDS_BYTES(1), s>>>(f3, np, (const uint4 *)wd1x, part, in);
     }
     CAELO_LAUNCH_CHECK();
@@ -1521,6 +1526,7 @@ static int dense1_launch(const float *f3, int64_t np, const void *wd1x, float *p
 }
 
 // ------------------------------------------------------------------------------------------------
+template <int SPLIT>
 __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part, int64_t n_patches, int64_t n_rows_pad,
                                                   const float *__restrict__ bd1p, const float *__restrict__ wd2,
                                                   const float *__restrict__ bd2, int group, caelo_enc_out outs,
@@ -1544,11 +1550,11 @@ __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part
 #pragma unroll
         for (int q = 0; q < 5; ++q) w[c][q] = ok ? ((const float4 *)(wd2 + (4 * lane + c) * 20))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (ok) {
-        float4 v[D1_SPLIT];
+        float4 v[SPLIT];
 #pragma unroll
-        for (int sp = 0; sp < D1_SPLIT; ++sp) v[sp] = *(const float4 *)(part + ((size_t)sp * n_rows_pad + prow) * DENSE_NP + 4 * lane);
+        for (int sp = 0; sp < SPLIT; ++sp) v[sp] = *(const float4 *)(part + ((size_t)sp * n_rows_pad + prow) * DENSE_NP + 4 * lane);
 #pragma unroll
-        for (int sp = 0; sp < D1_SPLIT; ++sp) { s.x += v[sp].x; s.y += v[sp].y; s.z += v[sp].z; s.w += v[sp].w; }
+        for (int sp = 0; sp < SPLIT; ++sp) { s.x += v[sp].x; s.y += v[sp].y; s.z += v[sp].z; s.w += v[sp].w; }
     }
     const float hv[4] = {ok ? enc_tanh(s.x) : 0.f, ok ? enc_tanh(s.y) : 0.f, ok ? enc_tanh(s.z) : 0.f, ok ? enc_tanh(s.w) : 0.f};
     float acc[20];
@@ -1681,7 +1687,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
         if (rc) return rc;
     }
     if (ev) CAELO_HIP(hipEventRecord(ev[3], s));
-    k_enc_head<<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(part, n_patches, np, c->enc_bd1, c->enc_wd2, c->enc_bd2,
+    k_enc_head<D1_SPLIT_OF(DENSE_K)><<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(part, n_patches, np, c->enc_bd1, c->enc_wd2, c->enc_bd2,
                                                                 group, outs, out_stride, ein);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[4], s));
@@ -1711,7 +1717,7 @@ int enc_dense32_head_launch(caelo_ctx *c, const float *f3, int64_t n_patches, in
     caelo_enc_out outs = {};
     outs.base[0] = out;
     outs.per_frame = n_patches;
-    k_enc_head<<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(part, n_patches, np, c->enc32_bd1, c->enc_wd2,
+    k_enc_head<D1_SPLIT_OF(16384)><<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(part, n_patches, np, c->enc32_bd1, c->enc_wd2,
                                                                 c->enc_bd2, group, outs, out_stride, plain);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;

@@ -11,8 +11,6 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "cae-lo_amd"))
 import torch
 from caelo import synth, _ffi
-if os.environ.get("CAELO_LIB"):
-    _ffi.LIB_PATH = os.environ["CAELO_LIB"]
 from caelo.engine import Engine, Pipeline, ransac_draws
 
 eng = Engine()
