@@ -183,6 +183,8 @@ CAELO_API int caelo_pipeline_create(caelo_ctx *c, int batch, int n_buffers, int6
     hip_ok(hipStreamCreateWithFlags(&p->sF, hipStreamNonBlocking), "hipStreamCreate");
     if (n_streams >= 2) hip_ok(hipStreamCreateWithFlags(&p->sE, hipStreamNonBlocking), "hipStreamCreate");
     else p->sE = p->sF;
+    // (the pair stream at the highest or lowest priority was tried: 10.59 / 10.60 k frames/s against 10.57 k, and k_match_mfma
+    // waits for CUs just as long -- the encoder's persistent workgroups do not give theirs up)
     if (n_streams >= 3) hip_ok(hipStreamCreateWithFlags(&p->sP, hipStreamNonBlocking), "hipStreamCreate");
     else p->sP = p->sF;
     hip_ok(hipEventCreateWithFlags(&p->begun, hipEventDisableTiming), "hipEventCreate");

@@ -962,3 +962,46 @@ def test_pipeline_batch_plan_does_not_change_results(engine, scans):
     for g, x, y in zip(got, (b.rows, b.pair_idx, b.inlier_mask, b.result, b.key_pixels), (c.rows, c.pair_idx, c.inlier_mask, c.result, c.key_pixels)):
         assert torch.equal(g[:16], x[:16]) and torch.equal(g[16:n], y[:4])
     assert engine.lane_faults() == 0
+
+
+@pytest.mark.gpu
+def test_match_shape_sweep_vs_oracle(engine, orc):
+    """The round-2 match kernel tiles frame 1 in blocks of 32 columns and frame 0 in steps of 128 rows, two column tiles
+    x four row quarters per workgroup: every remainder class of both, descriptor widths that are / are not multiples of 4
+    (vector / scalar loads), one-row and one-column problems -- bit-exact against the oracle's f64 cdist + argmin
+    (Match.py:257-258), ties included (duplicated rows: the first minimum wins)."""
+    import torch
+    rs = np.random.RandomState(21)
+    for k0, k1, dim in [(1, 1, 60), (1, 40, 60), (15, 31, 60), (16, 32, 60), (17, 33, 60), (127, 65, 20), (129, 1, 60),
+                        (1024, 1000, 60), (1000, 1024, 64), (257, 95, 3), (640, 333, 7), (1024, 1024, 60)]:
+        a = rs.uniform(-1, 1, (k0, dim)).astype(np.float32)
+        b = rs.uniform(-1, 1, (k1, dim)).astype(np.float32)
+        if k0 > 40 and k1 > 8:
+            a[k0 // 2] = a[3]              # exact tie between two frame-0 rows
+            b[5] = a[3]                    # ... met exactly by a frame-1 row (distance 0 twice)
+            b[6] = (a[7] + a[9]) * 0.5     # and a near tie
+        idx = engine.match(torch.from_numpy(a).to(engine.device), torch.from_numpy(b).to(engine.device)).cpu().numpy()
+        want = orc.match(a, b)[0]
+        assert np.array_equal(idx, want), (k0, k1, dim, np.nonzero(idx != want)[0][:8])
+    assert engine.lane_faults() == 0
+
+
+@pytest.mark.gpu
+def test_ransac_pair_count_sweep_vs_oracle(api, orc):
+    """RANSAC4RT over pair counts around every boundary of the kernels: fewer than 5 pairs (leastInliers = 0: Match.py:166),
+    counts that are not a multiple of 64, exactly the 1024 the LDS stage holds, and more (the hypotheses then read global
+    memory): success flag, threshold level and inlier set bit-exact against the oracle with the same NumPy draws."""
+    from caelo import synth
+    Rg, Tg = synth.relative_pose_gt(0, 2)
+    for n, seed in [(3, 1), (4, 2), (5, 3), (63, 4), (64, 5), (65, 6), (500, 7), (1023, 8), (1024, 9), (1025, 10), (1500, 11)]:
+        rs = np.random.RandomState(100 + seed)
+        P1 = rs.uniform(-40, 40, (n, 3)).astype(np.float32)
+        P0 = (P1 @ Rg.T + Tg.T).astype(np.float32)
+        bad = rs.uniform(size=n) < 0.3
+        P0[bad] = rs.uniform(-40, 40, (int(bad.sum()), 3)).astype(np.float32)
+        R, T, ok, mask, thr = api.RANSAC4RT(P0, P1, None, None, rng=np.random.RandomState(seed))
+        oR, oT, ook, omask, othr = orc.RANSAC4RT(P0, P1, None, None, rng=np.random.RandomState(seed))[:5]
+        assert ok == bool(ook) and thr == float(othr), (n, ok, ook, thr, othr)
+        assert np.array_equal(mask, np.asarray(omask, bool)), (n, int(mask.sum()), int(np.asarray(omask).sum()))
+        if ok and mask.sum() >= 4:
+            assert np.abs(np.asarray(R, np.float64) - oR).max() <= 1e-4 and np.abs(np.asarray(T, np.float64) - oT).max() <= 1e-3, n
