@@ -132,6 +132,8 @@ int enc_debug_copy(unsigned long long *out_host) {
     return CAELO_OK;
 }
 
+#define S1_RPITCH 20
+#define S1_ROWS (18 * S1_RPITCH)
 struct Stage1Lds {
     float p1[2 * P1_PLANE];
     float w1[27 * 8];
@@ -140,6 +142,7 @@ struct Stage1Lds {
     unsigned long long cell_mask[512];  // per pooled cell: set voxels of its 4^3 receptive field, bit a*16 + b*4 + j
     unsigned short list_cell[512];      // the cells with a non-zero mask, in arrival order
     unsigned int nzrow[12];  // per padded xp: bit yp set when some cell (xp, yp, *) is non-background
+    unsigned short rows[2][S1_ROWS];  // the patch's 256 voxel rows (16 z bits each) with a zero border: [x + 1][y + 1], pitch S1_RPITCH
     int list_n;
     int next_j;
 #ifdef CAELO_ENC_PROF
@@ -243,6 +246,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
     if (tid < 8) { L.b1[tid] = b1g[tid]; L.bg[tid] = c0g[512 * 16 + tid]; }  // bg = tanh(b1), from the host table
     for (int i = tid; i < 2 * P1_PLANE; i += 256) L.p1[i] = 0.0f;  // D == 0: halo, pads, background cells
     for (int i = tid; i < 512; i += 256) L.cell_mask[i] = 0ull;
+    for (int i = tid; i < 2 * S1_ROWS; i += 256) (&L.rows[0][0])[i] = 0;  // the border stays zero
     if (tid == 0) L.list_n = 0;
     if (tid < 12) L.nzrow[tid] = 0u;
     __syncthreads();
@@ -267,33 +271,36 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
         patch = __builtin_amdgcn_readfirstlane(patch);
         row = ((const unsigned short *)src)[tid];
     }
+    const int row_slot = ((tid >> 4) + 1) * S1_RPITCH + (tid & 15) + 1;  // where this thread's row lives in L.rows[*]
+    L.rows[0][row_slot] = (unsigned short)row;
+    int rbuf = 0;
+    __syncthreads();
     while (j < n_items) {
         ENC_STAMP(0);
         // work items beyond the first come from a global counter (patch costs vary 10x: a static split leaves the
         // average workgroup idle for the last ~55 us of the launch); fetched after the mask scatter, published
         // through LDS at the barrier that ends conv1, i.e. microseconds later
 
-        // ---- B1a: scatter every set voxel into the receptive-field masks of the (up to 8) pooled cells that
-        // see it (fire-and-forget LDS ORs).  Work ~ set voxels, not ~ cells.
-        if (row != 0u) {
-            const int x = tid >> 4, y = tid & 15;
+        // ---- B1: the receptive-field masks of this thread's two pooled cells (c and c + 256), GATHERED from the 4 x 4 voxel
+        // rows that feed them: bit a*16 + b*4 + j <-> voxel (2px-1+a, 2py-1+b, 2pz-1+j).  Two aligned 32-bit LDS reads per
+        // (cell, a) = rows y' = 2py .. 2py+3 of the bordered copy; no atomics, no barrier between mask building and queueing
+        // (round 1 scattered every set voxel into up to 8 masks with LDS ORs: 1 500 wave instructions per patch, 5 barriers).
+        unsigned long long cmask[2];
+        {
+            const int py = (tid >> 3) & 7, sh = 2 * (tid & 7);
 #pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                const int px = ((x + 1) >> 1) - dx;
-                if (px < 0 || px > 7) continue;
-                const int a = x + 1 - 2 * px;  // x = 2px - 1 + a
+            for (int rep = 0; rep < 2; ++rep) {
+                const int px = (tid >> 6) + 4 * rep;
+                const unsigned int *rp = (const unsigned int *)&L.rows[rbuf][(2 * px) * S1_RPITCH + 2 * py];  // x' = 2px + a, y' = 2py
+                unsigned int m32[2] = {0u, 0u};
 #pragma unroll
-                for (int dy = 0; dy < 2; ++dy) {
-                    const int py = ((y + 1) >> 1) - dy;
-                    if (py < 0 || py > 7) continue;
-                    const int b = y + 1 - 2 * py;
-#pragma unroll
-                    for (int pz = 0; pz < 8; ++pz) {
-                        const unsigned int nib = ((row << 1) >> (2 * pz)) & 0xFu;  // z = 2pz-1 .. 2pz+2
-                        if (nib != 0u)
-                            atomicOr(&L.cell_mask[(px * 8 + py) * 8 + pz], (unsigned long long)nib << (a * 16 + b * 4));
-                    }
+                for (int a = 0; a < 4; ++a) {
+                    const unsigned int w0 = rp[a * (S1_RPITCH / 2)], w1 = rp[a * (S1_RPITCH / 2) + 1];
+                    const unsigned int n0 = (((w0 & 0xFFFFu) << 1) >> sh) & 0xFu, n1 = (((w0 >> 16) << 1) >> sh) & 0xFu;
+                    const unsigned int n2 = (((w1 & 0xFFFFu) << 1) >> sh) & 0xFu, n3 = (((w1 >> 16) << 1) >> sh) & 0xFu;
+                    m32[a >> 1] |= (n0 | (n1 << 4) | (n2 << 8) | (n3 << 12)) << ((a & 1) * 16);
                 }
+                cmask[rep] = (unsigned long long)m32[0] | ((unsigned long long)m32[1] << 32);
             }
         }
         // issued here, after this patch's prefetched rows were consumed (vmcnt counts in order: an earlier wait for them
@@ -302,13 +309,12 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
         // 8-frame launch, 64 -> 84 us for one frame, where four items per workgroup is all there is: not kept)
         int j_fetch;  // defined in thread 0 only, and only read there (no merge copy that would wait for the atomic)
         if (tid == 0) j_fetch = atomicAdd(work_counter, 1);
-        caelo_lds_barrier();
         ENC_STAMP(1);
-        // ---- B1b: queue the cells with a non-empty mask (one LDS counter bump per wave)
+        // ---- queue the cells with a non-empty mask (one LDS counter bump per wave)
 #pragma unroll
         for (int rep = 0; rep < 2; ++rep) {
             const int cell = tid + rep * 256;
-            const bool hit = L.cell_mask[cell] != 0ull;
+            const bool hit = cmask[rep] != 0ull;
             const unsigned long long bal = __ballot(hit);
             if (bal != 0ull) {
                 int base = 0;
@@ -316,6 +322,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
                 base = __shfl(base, 0);
                 if (hit) {
                     L.list_cell[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)cell;
+                    L.cell_mask[cell] = cmask[rep];
                     atomicOr(&L.nzrow[(cell >> 6) + 1], 1u << (((cell >> 3) & 7) + 1));
                 }
             }
@@ -436,10 +443,11 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
             const int px = cell >> 6, py = (cell >> 3) & 7, pz = cell & 7;
             const int q = ((px + 1) * 10 + (py + 1)) * 8 + pz;
             *(float4 *)&L.p1[(i & 1) * P1_PLANE + (P1_FRONT + q) * 4] = make_float4(0.f, 0.f, 0.f, 0.f);
-            L.cell_mask[cell] = 0ull;
         }
         if (tid == 0) L.list_n = 0;
         if (tid < 12) L.nzrow[tid] = 0u;
+        L.rows[rbuf ^ 1][row_slot] = (unsigned short)row_next;  // the next patch's rows (fetched during conv2)
+        rbuf ^= 1;
         caelo_lds_barrier();
         j = jn;
         row = row_next;
