@@ -1541,7 +1541,7 @@ __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part
                                                   int out_stride, const caelo_enc_in in) {
     // One wave per patch, no LDS, no barrier.  Lane l < 50 owns the four hidden columns 4l .. 4l+3: one 16-byte load
     // per split-K partial (8 in flight, 800 contiguous bytes per row) and the 4 x 20 Dense(20) weights of those
-    // columns; the 20 outputs are 64-lane butterfly sums of per-lane partial dot products.
+    // columns; the 20 outputs are 64-lane sums of per-lane partial dot products (reduce-scatter butterfly below).
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t p = (int64_t)blockIdx.x * 4 + wave;
     if (p >= n_patches) return;
@@ -1577,17 +1577,29 @@ __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part
             acc[4 * q + 2] += hv[c] * w[c][q].z;
             acc[4 * q + 3] += hv[c] * w[c][q].w;
         }
-    float mine = 0.0f;
+    // The 20 outputs = sums of acc[o] over the 64 lanes.  Reduce-scatter butterfly: at every step a lane keeps one half of its
+    // values and hands the other half to its partner (20 -> 10 -> 5 -> 3 -> 2 -> 1 values, 22 shuffles instead of the 120 of
+    // twenty full butterflies).  Every partial sum is the sum of the same two operands as in the full butterfly, so the result
+    // is bit-identical to it.  Lane l ends with output o = 10 b5 + 5 b4 + 3 b3 + 2 b2 + b1 (bits of l; some lanes hold padding).
+    const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0, h2 = (lane & 4) != 0, h1 = (lane & 2) != 0;
+    float a10[10], a5[6], a3[4], a2[2];
 #pragma unroll
-    for (int o = 0; o < 20; ++o) {
-        float v = acc[o];
+    for (int i = 0; i < 10; ++i) a10[i] = (h5 ? acc[10 + i] : acc[i]) + __shfl_xor(h5 ? acc[i] : acc[10 + i], 32);
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-        mine = (lane == o) ? v : mine;
-    }
+    for (int i = 0; i < 5; ++i) a5[i] = (h4 ? a10[5 + i] : a10[i]) + __shfl_xor(h4 ? a10[i] : a10[5 + i], 16);
+    a5[5] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a3[i] = (h3 ? a5[3 + i] : a5[i]) + __shfl_xor(h3 ? a5[i] : a5[3 + i], 8);
+    a3[3] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a2[i] = (h2 ? a3[2 + i] : a3[i]) + __shfl_xor(h2 ? a3[i] : a3[2 + i], 4);
+    float mine = (h1 ? a2[1] : a2[0]) + __shfl_xor(h1 ? a2[0] : a2[1], 2);
+    mine += __shfl_xor(mine, 1);
+    const int o = (h5 ? 10 : 0) + (h4 ? 5 : 0) + (h3 ? 3 : 0) + (h2 ? 2 : 0) + (h1 ? 1 : 0);
+    const bool holds = (lane & 1) == 0 && (h3 ? !h2 : !(h2 && h1));
     // patches of several frames in one launch: frame f = p / per_frame writes into its own rows
     const int64_t f = p / outs.per_frame, q = p - f * outs.per_frame;
-    if (lane < 20) outs.base[f][(size_t)(q / group) * out_stride + (size_t)(q % group) * 20 + lane] = enc_tanh(bd2[lane] + mine);
+    if (holds) outs.base[f][(size_t)(q / group) * out_stride + (size_t)(q % group) * 20 + o] = enc_tanh(bd2[o] + mine);
 }
 
 // ------------------------------------------------------------------------------------------------
