@@ -261,7 +261,8 @@ struct caelo_enc_in {
     const unsigned long long *bits;
     int64_t frame_stride;
     int32_t per_frame, n_frames, dedup;
-    int32_t yield;  // 1: the launch shares the GPU with other streams (frame pipeline): persistent grids leave CU slots free
+    int32_t yield;  // the launch shares the GPU with other streams (frame pipeline): persistent grids leave CU slots free --
+                    // bit 0: stage 1 a fifth of its slots, bit 1: conv3 half of its, bit 2: conv3 a quarter
 };
 __device__ inline const caelo_dedup_tables *enc_tables(const caelo_enc_in &in, int f) {
     return (const caelo_dedup_tables *)(in.bits + (size_t)f * in.frame_stride + (size_t)in.per_frame * 64);

@@ -1673,10 +1673,10 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
             return 768;  // 3 workgroups on each of MI355X's 256 CUs
         return per_cu * cus;
     }(c->device);
-    // Inside the frame pipeline the persistent grids leave a fifth (stage 1) / half (conv3) of their slots free: stage 1 and conv3
-    // otherwise own every register file for their whole run and the other streams' kernels only get CUs between them
-    // (measured +3 % frames/s; alone, the full grid is ~8 % faster)
-    const int64_t cap1 = ein.yield ? (int64_t)slots1 * 4 / 5 : slots1;
+    // Inside the frame pipeline the persistent grids leave a fifth (stage 1) / a quarter (conv3) of their slots free: stage 1 and
+    // conv3 otherwise own every register file for their whole run and the other streams' kernels only get CUs between them
+    // (round 1: +3 % frames/s; with the round-2 executor the setting is worth about 1 %, caelo_enc_in::yield bits)
+    const int64_t cap1 = (ein.yield & 1) ? (int64_t)slots1 * 4 / 5 : slots1;
     const unsigned g1 = (unsigned)(n_patches < cap1 ? n_patches : cap1);
     if (ev) CAELO_HIP(hipEventRecord(ev[0], s));
     const int order_group = (n_patches % group == 0) ? group : 1;
@@ -1697,7 +1697,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     }
     if (ev) CAELO_HIP(hipEventRecord(ev[1], s));
     const int64_t pairs = (n_patches + 1) / 2;
-    const int64_t cap3 = ein.yield ? 256 : 512;
+    const int64_t cap3 = (ein.yield & 2) ? 256 : ((ein.yield & 4) ? 384 : 512);
     const unsigned g3 = (unsigned)(pairs < cap3 ? pairs : cap3);  // persistent: two 4-wave workgroups per CU
     k_enc_conv3<<<g3, 256, 0, s>>>(p2, n_patches, ein, (const uint4 *)c->enc_w3x, c->enc_b3, f3, work_counter, xcd_counters);
     CAELO_LAUNCH_CHECK();
