@@ -447,7 +447,7 @@ struct RansacVerdict {
 
 // sequential accept / exit rules of Match.py:166-169,:181,:195-214 replayed over the counts (one wave:
 // the counts are staged in LDS, lane 0 walks them)
-__device__ void ransac_replay(int N, const int32_t *counts, RansacVerdict *out) {
+__device__ __forceinline__ void ransac_replay(int N, const int32_t *counts, RansacVerdict *out, const int *preloaded = nullptr) {
     // The loop of :181-206 keeps the running maximum of the admissible counts (strict >: the FIRST
     // occurrence wins) and stops at the first iteration it >= 100 whose running maximum reached
     // 0.25 N, or at 500.  Restated as a prefix-max scan so one wavefront does it in parallel:
@@ -463,7 +463,7 @@ __device__ void ransac_replay(int N, const int32_t *counts, RansacVerdict *out) 
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const int i = lane * PER + q;
-        int v = i < CAELO_RANSAC_MAX_TRIALS ? counts[i] : 0;
+        int v = preloaded ? preloaded[q] : (i < CAELO_RANSAC_MAX_TRIALS ? counts[i] : 0);
         v = v >= least ? v : 0;
         c[q] = v;
         run = run > v ? run : v;
@@ -677,78 +677,137 @@ __global__ void __launch_bounds__(256) k_ransac_finish(const caelo_pair_set ps, 
     RansacWs *ws = (RansacWs *)P.ws_ransac;
     caelo_pose_result *res = P.result;
     uint8_t *mask = P.mask;
+    __shared__ float sP0[RE_LDS_PAIRS * 3], sP1[RE_LDS_PAIRS * 3];
     __shared__ float Rs[9], Ts[3];
-    __shared__ int s_nin;
     __shared__ RansacVerdict s_v;
+    __shared__ double red[4][FIT_TERMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = P.n1 ? min(max(*P.n1, 0), (int)k1_max) : (int)k1_max;
-    // ---- accept rules, level by level (:207-214: thr doubles while no hypothesis reaches leastInliers, up to 1.6)
-    int level = 0;
-    for (;; ++level) {
-        if (level > 0) {  // rare: this level's 500 hypotheses, one wavefront each, four at a time
-            const float thr_l = 0.4f * (float)(1 << level);
-            for (int trial = wave; trial < CAELO_RANSAC_MAX_TRIALS; trial += 4) {
-                const int cnt = hypothesis_count(pc0, ld0, pair_idx, pc1, ld1, N, rnd + ((size_t)level * CAELO_RANSAC_MAX_TRIALS + trial) * 4,
-                                                 thr_l, lane, ps.faults);
-                if (lane == 0) ws->counts[trial] = cnt;
-            }
-            __threadfence_block();
-            __syncthreads();
+    // ---- the first level's counts (wavefront 0, eight per lane) are fetched while all four wavefronts gather the matched
+    // pairs into LDS once: the winner's sample, the inlier mask and the refit below then never touch global memory again
+    // (round 2 before: three passes of dependent global gathers in this one-workgroup kernel, 27 us)
+    int c0[(CAELO_RANSAC_MAX_TRIALS + 63) / 64];
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < (CAELO_RANSAC_MAX_TRIALS + 63) / 64; ++q) {
+            const int i = lane * ((CAELO_RANSAC_MAX_TRIALS + 63) / 64) + q;
+            c0[q] = i < CAELO_RANSAC_MAX_TRIALS ? ws->counts[i] : 0;
         }
+    }
+    const bool in_lds = N <= RE_LDS_PAIRS;
+    if (in_lds) {
+        for (int i = tid; i < N; i += 256) {
+            const float *a = pc0 + (size_t)ld0 * pair_idx[i];
+            const float *b = pc1 + (size_t)ld1 * i;
+            sP0[3 * i] = a[0]; sP0[3 * i + 1] = a[1]; sP0[3 * i + 2] = a[2];
+            sP1[3 * i] = b[0]; sP1[3 * i + 1] = b[1]; sP1[3 * i + 2] = b[2];
+        }
+    }
+    // ---- accept rules, level by level (:207-214: thr doubles while no hypothesis reaches leastInliers, up to 1.6)
+    if (tid < 64) ransac_replay(N, ws->counts, &s_v, c0);
+    __syncthreads();  // also the end of the staging above
+    int level = 0;
+    while (!s_v.success && level < CAELO_RANSAC_LEVELS - 1) {  // rare: the next level's 500 hypotheses, one wavefront each, four at a time
+        __syncthreads();  // everyone has read s_v before it is overwritten
+        ++level;
+        const float thr_l = 0.4f * (float)(1 << level);
+        for (int trial = wave; trial < CAELO_RANSAC_MAX_TRIALS; trial += 4) {
+            const int cnt = hypothesis_count(pc0, ld0, pair_idx, pc1, ld1, N, rnd + ((size_t)level * CAELO_RANSAC_MAX_TRIALS + trial) * 4,
+                                             thr_l, lane, ps.faults);
+            if (lane == 0) ws->counts[trial] = cnt;
+        }
+        __threadfence_block();
+        __syncthreads();
         if (tid < 64) ransac_replay(N, ws->counts, &s_v);
         __syncthreads();
-        if (s_v.success || level == CAELO_RANSAC_LEVELS - 1) break;
-        __syncthreads();  // everyone has read s_v before the next level overwrites it
     }
     const int success = s_v.success, best = s_v.best_trial;
     const float thr = 0.4f * (float)(1 << level);  // 0.4, 0.8, 1.6 (:171,:210)
     // ---- the winner is recomputed from its sample (deterministic), identity if every level failed (:177)
     if (tid < 64) {
         float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, T[3] = {0.f, 0.f, 0.f};
-        if (best >= 0) sample_hypothesis(pc0, ld0, pair_idx, pc1, ld1, N, rnd + ((size_t)level * CAELO_RANSAC_MAX_TRIALS + best) * 4, R, T);
+        if (best >= 0) {
+            const double *r4 = rnd + ((size_t)level * CAELO_RANSAC_MAX_TRIALS + best) * 4;
+            if (in_lds) sample_hypothesis(sP0, 3, nullptr, sP1, 3, N, r4, R, T);
+            else sample_hypothesis(pc0, ld0, pair_idx, pc1, ld1, N, r4, R, T);
+        }
         lane_agreement(R, T, lane, ps.faults);
         if (tid < 9) Rs[tid] = R[tid];
         if (tid < 3) Ts[tid] = T[tid];
     }
-    if (tid == 0) s_nin = 0;
     __syncthreads();
-    int local = 0;
-    // four consecutive pairs per thread, one aligned 32-bit store: the whole mask row goes out as full dwords
+    // ---- one pass: inlier mask (four consecutive pairs per thread, one aligned 32-bit store: the whole mask row goes out as full
+    // dwords) and the sums of the refit over the inliers (:193-194, :273-282)
+    double acc[FIT_TERMS];
+#pragma unroll
+    for (int t = 0; t < FIT_TERMS; ++t) acc[t] = 0.0;
     const bool word_ok = (((uintptr_t)mask) & 3u) == 0;
     for (int i0 = tid * 4; i0 < (int)k1_max; i0 += 4 * 256) {
         unsigned int packed = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = i0 + q;
-            unsigned int in = 0;
             if (i < N && best >= 0) {
-                const float *a = pc0 + (size_t)ld0 * pair_idx[i];
-                const float *b = pc1 + (size_t)ld1 * i;
-                in = residual(Rs, Ts, a[0], a[1], a[2], b[0], b[1], b[2]) < thr ? 1u : 0u;
+                const float *a = in_lds ? sP0 + 3 * i : pc0 + (size_t)ld0 * pair_idx[i];
+                const float *b = in_lds ? sP1 + 3 * i : pc1 + (size_t)ld1 * i;
+                const float ax = a[0], ay = a[1], az = a[2], bx = b[0], by = b[1], bz = b[2];
+                if (residual(Rs, Ts, ax, ay, az, bx, by, bz) < thr) {
+                    packed |= 1u << (8 * q);
+                    const double x0 = ax, y0 = ay, z0 = az, x1 = bx, y1 = by, z1 = bz;
+                    acc[0] += 1.0;
+                    acc[1] += x0; acc[2] += y0; acc[3] += z0;
+                    acc[4] += x1; acc[5] += y1; acc[6] += z1;
+                    acc[7] += x1 * x0; acc[8] += x1 * y0; acc[9] += x1 * z0;   // P1^T P0  (:146)
+                    acc[10] += y1 * x0; acc[11] += y1 * y0; acc[12] += y1 * z0;
+                    acc[13] += z1 * x0; acc[14] += z1 * y0; acc[15] += z1 * z0;
+                }
             }
-            packed |= in << (8 * q);
-            local += (int)in;
         }
         if (word_ok && i0 + 3 < (int)k1_max) *(unsigned int *)(mask + i0) = packed;
         else
             for (int q = 0; q < 4 && i0 + q < (int)k1_max; ++q) mask[i0 + q] = (uint8_t)((packed >> (8 * q)) & 1u);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
-    if (lane == 0) atomicAdd(&s_nin, local);
+    for (int t = 0; t < FIT_TERMS; ++t)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[t] += __shfl_xor(acc[t], o);
+    if (lane == 0)
+#pragma unroll
+        for (int t = 0; t < FIT_TERMS; ++t) red[wave][t] = acc[t];
     __syncthreads();
-    if (tid < 9) { res->R_ransac[tid] = Rs[tid]; res->R[tid] = Rs[tid]; }
-    if (tid < 3) { res->T_ransac[tid] = Ts[tid]; res->T[tid] = Ts[tid]; }
+    if (tid < 9) { res->R_ransac[tid] = Rs[tid]; }
+    if (tid < 3) { res->T_ransac[tid] = Ts[tid]; }
     if (tid == 0) {
+        double sm[FIT_TERMS];
+#pragma unroll
+        for (int t = 0; t < FIT_TERMS; ++t) sm[t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+        const int n_in = (int)sm[0];
         res->threshold = thr;
         res->success = success;
         res->iterations = s_v.iterations;
-        res->n_inliers = s_nin;
+        res->n_inliers = n_in;
         res->best_trial = best >= 0 ? level * CAELO_RANSAC_MAX_TRIALS + best : -1;
         res->n_pairs = N;
+        float R[9], T[3];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) R[q] = Rs[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) T[q] = Ts[q];
+        if (n_in > 0) {  // :277-282: the pose over all inliers
+            const double cnt = sm[0];
+            const double m0[3] = {sm[1] / cnt, sm[2] / cnt, sm[3] / cnt}, m1[3] = {sm[4] / cnt, sm[5] / cnt, sm[6] / cnt};
+            double H[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) H[3 * i + j] = sm[7 + 3 * i + j] - cnt * m1[i] * m0[j];
+            rigid_from_H(H, m0, m1, R, T);
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) res->R[q] = R[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) res->T[q] = T[q];
     }
-    __syncthreads();
-    if (s_nin > 0) fit_block(pc0, ld0, pair_idx, pc1, ld1, mask, N, res->R, res->T, nullptr);  // :277-282
 }
 
 CAELO_API int caelo_ransac(caelo_ctx *c, const float *pc0, int ld0, const float *pc1, int ld1, const int64_t *pair_idx,
