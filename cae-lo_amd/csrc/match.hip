@@ -72,22 +72,22 @@ __device__ inline double exact_dist(const float *a, const float *b, int dim) {
     return sqrt(acc);
 }
 
-// the same on selects only (no control flow: the match kernel's epilogue must stay in one basic block with the next
-// tile's MFMAs so that the two interleave)
-__device__ inline void top3_insert_sel(double lo, int i, double &L1, double &L2, double &L3, int &I1, int &I2) {
-    const bool c1 = lo < L1, c2 = lo < L2, c3 = lo < L3;
-    L3 = c2 ? L2 : (c3 ? lo : L3);
-    I2 = c1 ? I1 : (c2 ? i : I2);
-    L2 = c1 ? L1 : (c2 ? lo : L2);
-    I1 = c1 ? i : I1;
-    L1 = c1 ? lo : L1;
+// ---- top-3 with the row index INSIDE the key.  The lower bound lo of a row is widened by 2^-30 (|v| + e) and its low
+// MM_IDX_BITS mantissa bits are replaced by the row index (a change of < 2^-31 |lo|: the key is still a lower bound).  An
+// ascending top-3 of such keys is a five-instruction min / max network -- no compares, no selects, no separate index registers
+// (the compiler turned the select form into branches and register shuffles: 225 VALU instructions per tile, now ~100).
+#define MM_IDX_BITS 21
+#define MM_IDX_MASK ((1 << MM_IDX_BITS) - 1)
+__device__ inline double mm_key(double lo, int i) {
+    return __longlong_as_double((__double_as_longlong(lo) & ~(long long)MM_IDX_MASK) | (long long)i);
 }
-
-// insert (lo, i) into an ascending top-3 (indices kept for the first two)
-__device__ inline void top3_insert(double lo, int i, double &L1, double &L2, double &L3, int &I1, int &I2) {
-    if (lo < L1) { L3 = L2; L2 = L1; I2 = I1; L1 = lo; I1 = i; }
-    else if (lo < L2) { L3 = L2; L2 = lo; I2 = i; }
-    else if (lo < L3) { L3 = lo; }
+__device__ inline int mm_key_index(double key) { return (int)(__double_as_longlong(key) & (long long)MM_IDX_MASK); }
+__device__ inline void mm_key_insert(double key, double &L1, double &L2, double &L3) {
+    const double u1 = __builtin_fmax(L1, key);
+    L1 = __builtin_fmin(L1, key);
+    const double u2 = __builtin_fmax(L2, u1);
+    L2 = __builtin_fmin(L2, u1);
+    L3 = __builtin_fmin(L3, u2);
 }
 
 // 16 channels [16g, 16g+16) of one descriptor row as doubles (zero beyond dim / for an invalid row)
@@ -114,8 +114,11 @@ __device__ inline void load_frag(const float *row, bool valid, int g, int dim, d
 template <bool VEC>
 __device__ inline float4 mm_stage_load(const float *f0, int ld0, int k0, int dim, int t, int tid) {
     const int row = (t << 4) + ((tid >> 4) & 15), c = (tid & 15) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    // rows past k0 (the tail of the last tile, whole tiles of the last step) are staged as a point 1e18 away on channel 0: their
+    // distance to anything is ~1e36, so they never win a column and the bookkeeping needs no validity test
+    float4 v = make_float4(c == 0 ? 1.0e18f : 0.f, 0.f, 0.f, 0.f);
     if (row < k0) {
+        v.x = 0.f;
         const float *src = f0 + (size_t)row * ld0 + c;
         if (VEC) { if (c < dim) v = *(const float4 *)src; }  // dim % 4 == 0 on this path
         else {
@@ -138,7 +141,6 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
     int32_t *stats = (int32_t *)P.ws_match;
     __shared__ __attribute__((aligned(16))) float sA[2][MM_STEP_TILES][16 * MM_LDA];  // [buffer][row tile of the step][row][channel]
     __shared__ double sL[3][MM_WAVES][16];
-    __shared__ int sI[2][MM_WAVES][16];
     __shared__ double sU[MM_WAVES][16];
     __shared__ int s_rescan[16 * MM_CT];
     __shared__ double s_rd[MM_WAVES];
@@ -168,8 +170,7 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
     for (int s = 0; s < MM_KSTEPS; ++s) n1 += b[s] * b[s];
     n1 += __shfl_xor(n1, 16);
     n1 += __shfl_xor(n1, 32);
-    double L1 = BIG, L2 = BIG, L3 = BIG, U = BIG;
-    int I1 = 0x7FFFFFFF, I2 = 0x7FFFFFFF;
+    double L1 = BIG, L2 = BIG, L3 = BIG, U = BIG;  // keys (mm_key): BIG carries no index
     const int ntiles = (k0 + 15) >> 4;
     const int nsteps = (ntiles + MM_STEP_TILES - 1) / MM_STEP_TILES;
     // thread -> (tiles st_par, st_par + 2, ... of a step, position inside the tile): 4 loads of 16 B in flight per thread
@@ -182,22 +183,20 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
         *(float4 *)(st_dst0 + 2 * k * 16 * MM_LDA) = stage[k];
     }
     __syncthreads();
-    // bookkeeping of one finished tile: rows i0 + g + 4 r of the accumulator against this lane's column.  Select-only.
+    // bookkeeping of one finished tile: rows i0 + g + 4 r of the accumulator against this lane's column
 #define MM_BOOKKEEP(ACC, ACC2, PN, I0)                                                              \
     _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                 \
         const int row = g + 4 * r; /* f64 C/D layout: row = (lane >> 4) + 4 * reg, col = lane & 15 */ \
         const double n0 = __shfl(PN, row); /* lane `row` (g = 0) holds that row's norm */           \
-        const int i = (I0) + row;                                                                   \
-        const bool in = i < k0; /* rows past k0 were staged as zeros */                             \
-        const double v = n0 - 2.0 * ((ACC)[r] + (ACC2)[r]);                                         \
+        const double v = __builtin_fma(-2.0, (ACC)[r] + (ACC2)[r], n0); /* = n0 - 2 dot, one rounding */ \
         const double e = kappa * (n0 + n1);                                                         \
-        const double hi = in ? v + e : BIG, lo = in ? v - e : BIG;                                  \
-        U = hi < U ? hi : U;                                                                        \
-        top3_insert_sel(lo, i, L1, L2, L3, I1, I2);                                                 \
+        U = __builtin_fmin(U, v + e);                                                               \
+        const double ew = __builtin_fma(__builtin_fabs(v) + e, 9.313225746154785e-10 /* 2^-30 */, e); \
+        mm_key_insert(mm_key(v - ew, (I0) + row), L1, L2, L3);                                      \
     }
     mm_f64x4 accP = {0.0, 0.0, 0.0, 0.0}, acc2P = {0.0, 0.0, 0.0, 0.0};
     double pP = 0.0;
-    int i0P = 0x40000000;  // "no tile yet": every row fails i < k0
+    int i0P = -1;  // no tile yet
     // The two wavefronts of a SIMD (w and w + 4) run the loop in opposite phase: one issues a tile's MFMAs and then the
     // bookkeeping of the tile before, the other the bookkeeping first -- while one occupies the matrix pipe the other
     // has VALU work, and the barrier at the end of a step re-aligns them to exactly that.
@@ -214,7 +213,7 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
 #pragma unroll
             for (int k = 0; k < MM_TPS; ++k) {
                 if (VFIRST) {
-                    MM_BOOKKEEP(accP, acc2P, pP, i0P)
+                    if (i0P >= 0) { MM_BOOKKEEP(accP, acc2P, pP, i0P) }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const int t = MM_STEP_TILES * it + k * MM_RQ + rh;  // tiles past the last hold zeros and fail i < k0
@@ -227,7 +226,7 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
                 }
                 double p = 0.0;
 #pragma unroll
-                for (int s = 0; s < MM_KSTEPS; ++s) p += a[s] * a[s];
+                for (int s = 0; s < MM_KSTEPS; ++s) p = __builtin_fma(a[s], a[s], p);
                 p += __shfl_xor(p, 16);
                 p += __shfl_xor(p, 32);  // |f0_{i0+x}|^2 on every lane with this x
                 // two accumulators: no MFMA waits for its predecessor (the rounding bound kappa holds for any summation order)
@@ -239,7 +238,7 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
                 }
                 if (!VFIRST) {
                     __builtin_amdgcn_sched_barrier(0);
-                    MM_BOOKKEEP(accP, acc2P, pP, i0P)  // the previous tile: its MFMAs finished long ago
+                    if (i0P >= 0) { MM_BOOKKEEP(accP, acc2P, pP, i0P) }  // the previous tile: its MFMAs finished long ago
                 }
                 accP = acc; acc2P = acc2; pP = p; i0P = t << 4;
             }
@@ -253,24 +252,21 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
     };
     if (__builtin_amdgcn_readfirstlane(wave) < 4) main_loop(std::false_type{});
     else main_loop(std::true_type{});
-    MM_BOOKKEEP(accP, acc2P, pP, i0P)
+    if (i0P >= 0) { MM_BOOKKEEP(accP, acc2P, pP, i0P) }
 #undef MM_BOOKKEEP
     // ---- workgroup top-3 per column: merge the 4 lane groups by shuffles, the four row quarters through LDS
 #define MM_SHFL_MERGE(OFF)                                                                           \
     {                                                                                                \
         const double pL1 = __shfl_xor(L1, OFF), pL2 = __shfl_xor(L2, OFF), pL3 = __shfl_xor(L3, OFF); \
-        const double pU = __shfl_xor(U, OFF);                                                        \
-        const int pI1 = __shfl_xor(I1, OFF), pI2 = __shfl_xor(I2, OFF);                              \
-        U = pU < U ? pU : U;                                                                         \
-        top3_insert(pL1, pI1, L1, L2, L3, I1, I2);                                                   \
-        top3_insert(pL2, pI2, L1, L2, L3, I1, I2);                                                   \
-        top3_insert(pL3, 0x7FFFFFFF, L1, L2, L3, I1, I2);                                            \
+        U = __builtin_fmin(U, __shfl_xor(U, OFF));                                                   \
+        mm_key_insert(pL1, L1, L2, L3);                                                              \
+        mm_key_insert(pL2, L1, L2, L3);                                                              \
+        mm_key_insert(pL3, L1, L2, L3);                                                              \
     }
     MM_SHFL_MERGE(16)
     MM_SHFL_MERGE(32)
     if (g == 0) {
         sL[0][wave][x] = L1; sL[1][wave][x] = L2; sL[2][wave][x] = L3;
-        sI[0][wave][x] = I1; sI[1][wave][x] = I2;
         sU[wave][x] = U;
     }
     __syncthreads();
@@ -281,15 +277,15 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
         int rescan = 0;
         if (j < k1) {
             double a1 = BIG, a2 = BIG, a3 = BIG, Umin = BIG;
-            int i1 = 0x7FFFFFFF, i2 = 0x7FFFFFFF;
 #pragma unroll
             for (int h = 0; h < MM_WAVES / MM_CT; ++h) {
                 const int w = ct + MM_CT * h;
-                Umin = sU[w][col] < Umin ? sU[w][col] : Umin;
-                top3_insert(sL[0][w][col], sI[0][w][col], a1, a2, a3, i1, i2);
-                top3_insert(sL[1][w][col], sI[1][w][col], a1, a2, a3, i1, i2);
-                top3_insert(sL[2][w][col], 0x7FFFFFFF, a1, a2, a3, i1, i2);
+                Umin = __builtin_fmin(Umin, sU[w][col]);
+                mm_key_insert(sL[0][w][col], a1, a2, a3);
+                mm_key_insert(sL[1][w][col], a1, a2, a3);
+                mm_key_insert(sL[2][w][col], a1, a2, a3);
             }
+            const int i1 = mm_key_index(a1), i2 = mm_key_index(a2);
             if (a3 <= Umin) {
                 rescan = 1;  // three or more rows inside the window
                 if (stats) atomicAdd(&stats[0], 1);
@@ -344,6 +340,7 @@ CAELO_API int caelo_match(caelo_ctx *c, const float *f0, int ld0, int64_t k0_max
 int match_set(const caelo_pair_set &ps, int ld0, int64_t k0_max, int ld1, int64_t k1_max, int dim, hipStream_t s) {
     CAELO_REQUIRE(ps.n >= 1 && ps.n <= CAELO_FB_MAX, "bad pair count");
     CAELO_REQUIRE(dim > 0 && dim <= MT_MAXDIM && ld0 >= dim && ld1 >= dim && k0_max > 0 && k1_max > 0, "bad shape");
+    CAELO_REQUIRE(k0_max + 16 * MM_STEP_TILES < MM_IDX_MASK, "too many frame-0 rows (the row index travels in 21 key bits)");
     const int64_t tiles = (k1_max + 16 * MM_CT - 1) / (16 * MM_CT);  // workgroups of MM_CT column tiles
     bool vec = (dim % 4 == 0) && (ld0 % 4 == 0) && (ld1 % 4 == 0);
     for (int i = 0; i < ps.n; ++i) vec = vec && (((uintptr_t)ps.p[i].f0 | (uintptr_t)ps.p[i].f1) & 15u) == 0;
