@@ -24,7 +24,7 @@ before = np.array(buf[16:32], dtype=np.int64)
 _, ms = eng.encode_profile(bits, group=3)
 eng.lib.caelo_debug_read(C.cast(buf, C.c_void_p))
 d = np.array(buf[16:32], dtype=np.int64) - before
-names = ["loop", "B1a scatter", "B1b queue", "B2 conv1+pool", "conv2 mfma", "cleanup"]
+names = ["loop", "B1 masks (gather)", "B1 queue", "B2 conv1+pool", "conv2 mfma", "cleanup"]
 tot = d[0:6].sum()
 print("stage1 %.1f us; patches %d, queued cells/patch %.1f" % (ms[0] * 1e3, d[6], d[7] / max(d[6], 1)))
 for i in range(0, 6):
