@@ -142,6 +142,7 @@ struct Stage1Lds {
     unsigned long long cell_mask[512];  // per pooled cell: set voxels of its 4^3 receptive field, bit a*16 + b*4 + j
     unsigned short list_cell[512];      // the cells with a non-zero mask, in arrival order
     unsigned int nzrow[12];  // per padded xp: bit yp set when some cell (xp, yp, *) is non-background
+    float2 bgout[4][4][32];  // [wave][yi][lane < 32]: outputs of a tile pair that sees nothing but background (see the kernel)
     unsigned short rows[2][S1_ROWS];  // the patch's 256 voxel rows (16 z bits each) with a zero border: [x + 1][y + 1], pitch S1_RPITCH
     int list_n;
     int next_j;
@@ -226,8 +227,9 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
     // waves: wave w owns, for every row pair yi, the x pair xp = (w - 2 yi) mod 4.
     // C0 = b2 + conv2(BG) accumulator fragments of this lane's 8 m-tiles are patch independent: loaded once,
     // together with the outputs tanh(pool2(C0)) of a pair that sees nothing but background.
+    // (the all-background outputs live in LDS, not in registers: with them the kernel spilled 5 registers, and every reload
+    // on the background path -- a scratch load followed by s_waitcnt vmcnt(0) -- also waited for the P2 stores before it)
     f32x4 c0r[4][2];
-    float bgout[4][2];
 #pragma unroll
     for (int yi = 0; yi < 4; ++yi) {
         const int xp = (wave - 2 * yi) & 3;
@@ -240,8 +242,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
         float v1 = fmaxf(fmaxf(c0r[yi][0][2], c0r[yi][0][3]), fmaxf(c0r[yi][1][2], c0r[yi][1][3]));
         v0 = fmaxf(v0, __shfl_xor(v0, 32));
         v1 = fmaxf(v1, __shfl_xor(v1, 32));
-        bgout[yi][0] = enc_tanh(v0);
-        bgout[yi][1] = enc_tanh(v1);
+        if (lane < 32) L.bgout[wave][yi][lane] = make_float2(enc_tanh(v0), enc_tanh(v1));
     }
     for (int i = tid; i < 27 * 8; i += 256) L.w1[i] = w1g[i];
     if (tid < 8) { L.b1[tid] = b1g[tid]; L.bg[tid] = c0g[512 * 16 + tid]; }  // bg = tanh(b1), from the host table
@@ -415,7 +416,10 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
                 // C column = n (channel), rows 4g..4g+3 -> z = 4*(g&1)+r ; pooled cell (xp, yi, 2*(g&1)+{0,1})
                 float *dst = p2out + (size_t)patch * 1024 + (size_t)(((xp * 4 + yi) * 4 + 2 * (g & 1)) * 16 + n);
                 if ((r0 | r1 | r2 | r3) == 0u) {  // nothing but background feeds this pair: per-model constants
-                    if (g < 2) { dst[0] = bgout[yi][0]; dst[16] = bgout[yi][1]; }
+                    if (g < 2) {
+                        const float2 o = L.bgout[wave][yi][lane];
+                        dst[0] = o.x; dst[16] = o.y;
+                    }
                     continue;
                 }
                 // accumulators start from C0 = b2 + conv2(BG); two per tile to keep the MFMA chains independent
