@@ -17,14 +17,16 @@ python $R/tools/timeline.py /tmp/kb/kb_results.db 1700 400 > $O/timeline_bench.t
 # one batch of 8 frames per launch set, one stream: every kernel alone on the GPU
 rm -rf /tmp/k1; CAELO_PIPE_STREAMS=1 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/k1 -o k1 -- python $R/tools/match_time.py > /dev/null 2>&1
 python $R/tools/prof_summary.py /tmp/k1/k1_results.db "CAELO_PIPE_STREAMS=1 rocprofv3 --kernel-trace --stats -- python tools/match_time.py (8 frames per launch, one stream)" > $O/kernel_stats_one_stream.txt 2>&1
-# the launch bench.py's roofline object times
-rm -rf /tmp/rl; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rl -o rl -- python $R/tools/roofline_launch.py 40 > /dev/null 2>&1
-python $R/tools/prof_summary.py /tmp/rl/rl_results.db "rocprofv3 --kernel-trace --stats -- python tools/roofline_launch.py 40" > $O/kernel_stats_roofline_launch.txt 2>&1
-for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
-  rm -rf /tmp/pm_$c; timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/pm_$c -o pm -- python $R/tools/roofline_launch.py 12 > /dev/null 2>&1
+# the launches bench.py's roofline object times: 8 frames per launch (headline: the pipeline's launch shape) and one frame
+rm -rf /tmp/rl; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rl -o rl -- python $R/tools/roofline_launch.py 30 8 > /dev/null 2>&1
+python $R/tools/prof_summary.py /tmp/rl/rl_results.db "rocprofv3 --kernel-trace --stats -- python tools/roofline_launch.py 30 8   (8 frames = 24576 patches per launch)" > $O/kernel_stats_roofline_launch.txt 2>&1
+rm -rf /tmp/rl1; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rl1 -o rl -- python $R/tools/roofline_launch.py 40 1 > /dev/null 2>&1
+python $R/tools/prof_summary.py /tmp/rl1/rl_results.db "rocprofv3 --kernel-trace --stats -- python tools/roofline_launch.py 40 1   (one frame = 3072 patches per launch)" > $O/kernel_stats_roofline_launch_1frame.txt 2>&1
+for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES; do
+  rm -rf /tmp/pm_$c; timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/pm_$c -o pm -- python $R/tools/roofline_launch.py 10 8 > /dev/null 2>&1
 done
-python $R/tools/pmc_traffic_json.py /tmp/pm_FETCH_SIZE/pm_results.db /tmp/pm_WRITE_SIZE/pm_results.db "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/roofline_launch.py 12; KB per launch, uncorrected" > $O/pmc_traffic.json 2>&1
-python $R/tools/pmc_summary.py /tmp/pm_SQ_VALU_MFMA_BUSY_CYCLES/pm_results.db k_enc > $O/pmc_mfma_busy.txt 2>&1
+python $R/tools/pmc_traffic_json.py /tmp/pm_FETCH_SIZE/pm_results.db /tmp/pm_WRITE_SIZE/pm_results.db "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/roofline_launch.py 10 8; KB per launch of 8 frames (24576 patches), uncorrected" > $O/pmc_traffic.json 2>&1
+( python $R/tools/pmc_summary.py /tmp/pm_SQ_VALU_MFMA_BUSY_CYCLES/pm_results.db k_enc; python $R/tools/pmc_summary.py /tmp/pm_SQ_BUSY_CYCLES/pm_results.db k_enc ) > $O/pmc_mfma_busy.txt 2>&1
 # match kernel counters (one stream, 8 pairs per launch)
 : > $O/pmc_match.txt
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY"; do

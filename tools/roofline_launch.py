@@ -1,5 +1,6 @@
-"""The launch bench.py's `roofline` object times -- caelo_encode_profile on the 3072 patches of one frame -- repeated, for
-rocprofv3 --kernel-trace / --pmc passes (profiles/r02_*): same input, same kernels, one frame per launch."""
+"""The launches bench.py's `roofline` object times -- caelo_encode_profile on the patches of `frames` frames (1: round 1's figure,
+8: the pipeline's launch shape and bench.py's headline) -- repeated, for rocprofv3 --kernel-trace / --pmc passes (profiles/r02_*).
+    python tools/roofline_launch.py [repeats=12] [frames=1]"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "cae-lo_amd"))
@@ -7,9 +8,13 @@ import torch
 from caelo import synth
 from caelo.engine import Engine
 eng = Engine()
-pc = torch.from_numpy(synth.make_scan(0, quantum=1e-3)).to(eng.device)
-bits, _ = eng.patches(eng.voxelize(pc)[0], eng.extract(pc).key_pts.contiguous())
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 1      # frames per launch: 8 = the pipeline's launch shape (bench.py's headline roofline)
+parts = []
+for i in range(min(frames, 6)):
+    pc = torch.from_numpy(synth.make_scan(i, quantum=1e-3)).to(eng.device)
+    parts.append(eng.patches(eng.voxelize(pc)[0], eng.extract(pc).key_pts.contiguous())[0].reshape(-1, 64))
+bits = torch.cat([parts[i % len(parts)] for i in range(frames)], dim=0).contiguous()
 for _ in range(n):
     eng.encode_profile(bits, group=3)
 torch.cuda.synchronize()
