@@ -204,7 +204,6 @@ __device__ inline void enc_item(const caelo_enc_in &in, int J, int nk, int group
     }
 }
 
-template <bool AHEAD>
 __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, int64_t n_patches,
                                                     int group, int *__restrict__ work_counter,
                                                     const float *__restrict__ w1g, const float *__restrict__ b1g,
@@ -273,12 +272,6 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
         patch = __builtin_amdgcn_readfirstlane(patch);
         row = ((const unsigned short *)src)[tid];
     }
-    // thread 0: the work-counter value.  Launches with many items per workgroup (the pipeline's 8-frame batches) fetch it one
-    // patch AHEAD (see below); a single frame is four items per workgroup, where pinning two of them up front costs more in
-    // balance (62 -> 66 us) than the hidden latency gains, so it fetches and consumes within the patch as round 1 did.
-    constexpr bool ahead = AHEAD;  // chosen by the host: launches of four or more frames
-    int j_fetch = 0;
-    if (tid == 0 && ahead && j < n_items) j_fetch = atomicAdd(work_counter, 1);
     const int row_slot = ((tid >> 4) + 1) * S1_RPITCH + (tid & 15) + 1;  // where this thread's row lives in L.rows[*]
     L.rows[0][row_slot] = (unsigned short)row;
     int rbuf = 0;
@@ -311,7 +304,13 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
                 cmask[rep] = (unsigned long long)m32[0] | ((unsigned long long)m32[1] << 32);
             }
         }
-        if (tid == 0 && !ahead) j_fetch = atomicAdd(work_counter, 1);  // (after this patch's prefetched rows were consumed: vmcnt is in order)
+        // issued here, after this patch's prefetched rows were consumed (vmcnt counts in order: an earlier wait for them
+        // would also wait for the atomic); consumed at the end of conv1, microseconds later.  Tried and dropped: handing the items
+        // out four per atomic (364 -> 348 us for an 8-frame launch, 64 -> 84 us for one frame), and fetching one patch AHEAD (the
+        // round trip then never shows in the phase profile, but pinning a second item per workgroup costs balance: 359 -> 365 us
+        // per 8-frame launch, 62 -> 66 us for one frame, 11.09 -> 11.03 k frames/s).
+        int j_fetch;  // defined in thread 0 only, and only read there (no merge copy that would wait for the atomic)
+        if (tid == 0) j_fetch = atomicAdd(work_counter, 1);
         ENC_STAMP(1);
         // ---- queue the cells with a non-empty mask (one LDS counter bump per wave)
 #pragma unroll
@@ -379,16 +378,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
                 L.p1[(sub >> 2) * P1_PLANE + (P1_FRONT + q) * 4 + (sub & 3)] = enc_tanh(mine) - L.bg[sub];
             }
         }
-        // `ahead`: the next item's index was fetched ONE PATCH AGO (a returning device-scope atomic takes ~2.5 us -- as long as a light
-        // patch's conv1: consumed in the patch that issued it, it sat on the critical path of every patch; phase profile of
-        // all-empty patches: 5.7 k cycles in this phase).  Published here, and the fetch for the patch after next goes out right
-        // behind it: vmcnt is in order, and at this point nothing else of this thread is in flight.
-        // (Handing the items out four at a time -- one same-address atomic per chunk -- was tried: 364 -> 348 us for an 8-frame
-        // launch, 64 -> 84 us for one frame, where four items per workgroup is all there is: not kept.)
-        if (tid == 0) {
-            L.next_j = (int)gridDim.x + j_fetch;
-            if (ahead) j_fetch = atomicAdd(work_counter, 1);
-        }
+        if (tid == 0) L.next_j = (int)gridDim.x + j_fetch;
         caelo_lds_barrier();
         ENC_STAMP(3);
         const int jn = __builtin_amdgcn_readfirstlane(L.next_j);
@@ -1683,7 +1673,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     int *xcd_counters = (int *)((char *)ws + 1024);  // 8 x one 128-byte line
     static const int slots1 = [](int device) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_stage1 ? (const void *)k_enc_stage1<false> : (const void *)k_enc_conv2, 256, 0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_stage1 ? (const void *)k_enc_stage1 : (const void *)k_enc_conv2, 256, 0) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || per_cu * cus <= 0)
             return 768;  // 3 workgroups on each of MI355X's 256 CUs
         return per_cu * cus;
@@ -1702,10 +1692,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
                                                                                    c->enc_w2, c->enc_c0, p2);
         CAELO_LAUNCH_CHECK();
     } else if (fused_stage1) {
-        if (n_patches >= 4 * 3072)
-            k_enc_stage1<true><<<g1, 256, 0, s>>>(ein, n_patches, order_group, work_counter, c->enc_w1, c->enc_b1, c->enc_w2, c->enc_c0, p2);
-        else
-            k_enc_stage1<false><<<g1, 256, 0, s>>>(ein, n_patches, order_group, work_counter, c->enc_w1, c->enc_b1, c->enc_w2, c->enc_c0, p2);
+        k_enc_stage1<<<g1, 256, 0, s>>>(ein, n_patches, order_group, work_counter, c->enc_w1, c->enc_b1, c->enc_w2, c->enc_c0, p2);
         CAELO_LAUNCH_CHECK();
     } else {
         k_enc_conv1<<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(ein, n_patches, order_group, c->enc_w1, c->enc_b1, c->enc_c0, dl, mfma_count);
