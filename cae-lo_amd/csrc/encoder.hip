@@ -151,6 +151,7 @@ struct Stage1Lds {
 #endif
 };
 
+#define S1_XDEAL(YI) ((YI) == 0 ? 0 : ((YI) == 1 ? 3 : ((YI) == 2 ? 1 : 2)))  // k_enc_stage1's deal of tile pairs to wavefronts
 // 3 taps (one (ka, kb) pair of input rows) of one m-tile: 6 MFMAs on two interleaved accumulators
 #define CONV2_ROW(ACC_A, ACC_B, APTR, KA, KB)                                                      \
     _Pragma("unroll") for (int kc = 0; kc < 3; ++kc) {                                             \
@@ -222,8 +223,10 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
         breg[t][0] = w2g[(t * 8 + 2 * g) * 16 + n];
         breg[t][1] = w2g[(t * 8 + 2 * g + 1) * 16 + n];
     }
-    // Tile pairs are dealt to the 4 waves so that a 2x2 cluster of occupied pairs lands on 4 different
-    // waves: wave w owns, for every row pair yi, the x pair xp = (w - 2 yi) mod 4.
+    // Tile pairs are dealt to the 4 waves as a XOR Latin square: wave w owns, for every row pair yi, the x pair xp = w ^ d(yi),
+    // d = 0, 3, 1, 2 -- every 2x2 cluster of occupied pairs lands on 4 different waves, and of all 24^3 ways to give each wave one
+    // pair per yi this one balances the MFMA rows best on the golden frames (tools/conv2_balance.py: average / busiest wavefront
+    // 0.83; round 1's xp = (w - 2 yi) mod 4: 0.78; the worst deal: 0.58).
     // C0 = b2 + conv2(BG) accumulator fragments of this lane's 8 m-tiles are patch independent: loaded once,
     // together with the outputs tanh(pool2(C0)) of a pair that sees nothing but background.
     // (the all-background outputs live in LDS, not in registers: with them the kernel spilled 5 registers, and every reload
@@ -231,7 +234,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
     f32x4 c0r[4][2];
 #pragma unroll
     for (int yi = 0; yi < 4; ++yi) {
-        const int xp = (wave - 2 * yi) & 3;
+        const int xp = wave ^ S1_XDEAL(yi);
 #pragma unroll
         for (int xt = 0; xt < 2; ++xt) {
             const float *c0a = c0g + (size_t)((((2 * xp + xt) * 8 + 2 * yi + (g >> 1)) * 8 + 4 * (g & 1)) * 16 + n);
@@ -389,7 +392,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
             patch_next = __builtin_amdgcn_readfirstlane(patch_next);
             row_next = ((const unsigned short *)src)[tid];
         }
-        // ---- conv2 (8->16) on MFMA: per row pair yi this wave owns the x pair xp = (wave - 2 yi) mod 4
+        // ---- conv2 (8->16) on MFMA: per row pair yi this wave owns the x pair xp = wave ^ d(yi)
         {
             const int yl = n >> 3, z = n & 7;  // A row m = yl*8 + z
             const float *plane = L.p1 + (g >> 1) * P1_PLANE + 2 * (g & 1);
@@ -397,7 +400,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
 #pragma unroll
             for (int yi = 0; yi < 4; ++yi) {
                 const int y0 = 2 * yi;
-                const int xp = (wave - 2 * yi) & 3;
+                const int xp = wave ^ S1_XDEAL(yi);
                 // wave-uniform occupancy of the input rows yp = y0 .. y0+3 in the padded planes 2xp .. 2xp+3
                 const unsigned int r0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((L.nzrow[2 * xp] >> y0) & 0xFu));
                 const unsigned int r1 = (unsigned)__builtin_amdgcn_readfirstlane((int)((L.nzrow[2 * xp + 1] >> y0) & 0xFu));

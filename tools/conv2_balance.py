@@ -4,7 +4,8 @@ executed (m-tile, tap-row) blocks per pair from the same occupancy rule the kern
 
     python tools/conv2_balance.py
 
-Printed for DESIGN.md 4.1: the static deal reaches 78 % (58 / 74 / 86 % at scales 0 / 1 / 2), greedy longest-first taking 92 %,
+Printed for DESIGN.md 4.1: round 1's static deal reaches 78 % (58 / 74 / 86 % at scales 0 / 1 / 2), the XOR Latin square the kernel
+uses now 83 % (the best of all 24^3 one-pair-per-row-pair deals on the two golden frames), greedy longest-first taking 92 %,
 in-order taking 86 % -- and the measured kernel with in-patch taking (LDS claim per pair, runtime-addressed pair body) was SLOWER
 (358 -> 405 us per 8-frame launch): the claim round trip and the lost compile-time addressing cost more than the balance gains."""
 import os
@@ -33,12 +34,14 @@ for xp in range(4):
 tot = rows.sum(axis=(1, 2))
 print("cells / patch by scale:", [round(float(cell[s::3].sum(axis=(1, 2, 3)).mean()), 1) for s in range(3)])
 print("executed share of the dense conv2: %.3f (%.0f MFMAs per patch)" % (tot.mean() / (16 * 18), tot.mean() * 6))
-per_wave = np.zeros((n, 4), int)
-for w in range(4):
-    for yi in range(4):
-        per_wave[:, w] += rows[:, (w - 2 * yi) & 3, yi]
-print("static deal: average / busiest wavefront = %.3f" % (per_wave.sum() / 4 / per_wave.max(axis=1).sum()),
-      [round(float(per_wave[s::3].sum() / 4 / per_wave[s::3].max(axis=1).sum()), 3) for s in range(3)])
+for name, deal in (("round 1's deal xp = (w - 2 yi) mod 4", lambda w, yi: (w - 2 * yi) & 3),
+                   ("XOR Latin square xp = w ^ (0, 3, 1, 2)[yi] (the kernel's)", lambda w, yi: w ^ (0, 3, 1, 2)[yi])):
+    per_wave = np.zeros((n, 4), int)
+    for w in range(4):
+        for yi in range(4):
+            per_wave[:, w] += rows[:, deal(w, yi), yi]
+    print("%s: average / busiest wavefront = %.3f" % (name, per_wave.sum() / 4 / per_wave.max(axis=1).sum()),
+          [round(float(per_wave[s::3].sum() / 4 / per_wave[s::3].max(axis=1).sum()), 3) for s in range(3)])
 
 
 def taking(r, order):
