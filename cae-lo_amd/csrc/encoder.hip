@@ -132,10 +132,13 @@ int enc_debug_copy(unsigned long long *out_host) {
     return CAELO_OK;
 }
 
+// k_enc_stage1's D planes carry a z halo as well (z pitch 10): the two out-of-range z taps read stored zeros instead of being
+// predicated -- 4 v_cndmask and the s_nops behind them per 6 MFMAs less.  q = (xp*10 + yp)*10 + zp, zp = z + 1.
+#define S1P_PLANE ((1000 + 4) * 4)   // floats per 4-channel half, +4 cells: the two halves start 16 banks apart
 #define S1_RPITCH 20
 #define S1_ROWS (18 * S1_RPITCH)
 struct Stage1Lds {
-    float p1[2 * P1_PLANE];
+    float p1[2 * S1P_PLANE];
     float w1[27 * 8];
     float b1[8];
     float bg[8];
@@ -151,6 +154,24 @@ struct Stage1Lds {
 #endif
 };
 
+// the same with a z halo in the planes (k_enc_stage1): no predication
+#define CONV2Z_ROW(ACC_A, ACC_B, APTR, KA, KB)                                                     \
+    _Pragma("unroll") for (int kc = 0; kc < 3; ++kc) {                                             \
+        const int t = (KA) * 9 + (KB) * 3 + kc;                                                     \
+        const float2 av = *(const float2 *)((APTR) + (((KA) * 10 + (KB)) * 10 + (kc - 1)) * 4);     \
+        ACC_A = MFMA16(av.x, breg[t][0], ACC_A);                                                    \
+        ACC_B = MFMA16(av.y, breg[t][1], ACC_B);                                                    \
+    }
+#define CONV2Z_TILE(ACC_A, ACC_B, APTR, NZ0, NZ1, NZ2)                                              \
+    if ((NZ0) & 0x3u) { CONV2Z_ROW(ACC_A, ACC_B, APTR, 0, 0) }                                      \
+    if ((NZ0) & 0x6u) { CONV2Z_ROW(ACC_A, ACC_B, APTR, 0, 1) }                                      \
+    if ((NZ0) & 0xCu) { CONV2Z_ROW(ACC_A, ACC_B, APTR, 0, 2) }                                      \
+    if ((NZ1) & 0x3u) { CONV2Z_ROW(ACC_A, ACC_B, APTR, 1, 0) }                                      \
+    if ((NZ1) & 0x6u) { CONV2Z_ROW(ACC_A, ACC_B, APTR, 1, 1) }                                      \
+    if ((NZ1) & 0xCu) { CONV2Z_ROW(ACC_A, ACC_B, APTR, 1, 2) }                                      \
+    if ((NZ2) & 0x3u) { CONV2Z_ROW(ACC_A, ACC_B, APTR, 2, 0) }                                      \
+    if ((NZ2) & 0x6u) { CONV2Z_ROW(ACC_A, ACC_B, APTR, 2, 1) }                                      \
+    if ((NZ2) & 0xCu) { CONV2Z_ROW(ACC_A, ACC_B, APTR, 2, 2) }
 #define S1_XDEAL(YI) ((YI) == 0 ? 0 : ((YI) == 1 ? 3 : ((YI) == 2 ? 1 : 2)))  // k_enc_stage1's deal of tile pairs to wavefronts
 // 3 taps (one (ka, kb) pair of input rows) of one m-tile: 6 MFMAs on two interleaved accumulators
 #define CONV2_ROW(ACC_A, ACC_B, APTR, KA, KB)                                                      \
@@ -248,7 +269,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
     }
     for (int i = tid; i < 27 * 8; i += 256) L.w1[i] = w1g[i];
     if (tid < 8) { L.b1[tid] = b1g[tid]; L.bg[tid] = c0g[512 * 16 + tid]; }  // bg = tanh(b1), from the host table
-    for (int i = tid; i < 2 * P1_PLANE; i += 256) L.p1[i] = 0.0f;  // D == 0: halo, pads, background cells
+    for (int i = tid; i < 2 * S1P_PLANE; i += 256) L.p1[i] = 0.0f;  // D == 0: halo, pads, background cells
     for (int i = tid; i < 512; i += 256) L.cell_mask[i] = 0ull;
     for (int i = tid; i < 2 * S1_ROWS; i += 256) (&L.rows[0][0])[i] = 0;  // the border stays zero
     if (tid == 0) L.list_n = 0;
@@ -377,8 +398,8 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
 #pragma unroll
                 for (int c = 1; c < 8; ++c) mine = (sub == c) ? acc[c] : mine;
                 const int px = cell >> 6, py = (cell >> 3) & 7, pz = cell & 7;
-                const int q = ((px + 1) * 10 + (py + 1)) * 8 + pz;
-                L.p1[(sub >> 2) * P1_PLANE + (P1_FRONT + q) * 4 + (sub & 3)] = enc_tanh(mine) - L.bg[sub];
+                const int q = ((px + 1) * 10 + (py + 1)) * 10 + pz + 1;
+                L.p1[(sub >> 2) * S1P_PLANE + q * 4 + (sub & 3)] = enc_tanh(mine) - L.bg[sub];
             }
         }
         if (tid == 0) L.next_j = (int)gridDim.x + j_fetch;
@@ -395,8 +416,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
         // ---- conv2 (8->16) on MFMA: per row pair yi this wave owns the x pair xp = wave ^ d(yi)
         {
             const int yl = n >> 3, z = n & 7;  // A row m = yl*8 + z
-            const float *plane = L.p1 + (g >> 1) * P1_PLANE + 2 * (g & 1);
-            const bool zlo = z >= 1, zhi = z <= 6;
+            const float *plane = L.p1 + (g >> 1) * S1P_PLANE + 2 * (g & 1);
 #pragma unroll
             for (int yi = 0; yi < 4; ++yi) {
                 const int y0 = 2 * yi;
@@ -420,11 +440,11 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
                 f32x4 acc1 = c0r[yi][1];
                 f32x4 acc0b = {0.f, 0.f, 0.f, 0.f}, acc1b = {0.f, 0.f, 0.f, 0.f};
                 // padded position of (x = 2xp, y = y0 + yl, z) for tap (0,0,1): xp' = x + ka, yp = y + kb
-                const int qbase = ((2 * xp) * 10 + (y0 + yl)) * 8 + z;
-                const float *a0 = plane + (P1_FRONT + qbase) * 4;
-                const float *a1 = a0 + 80 * 4;
-                CONV2_TILE(acc0, acc0b, a0, r0, r1, r2)
-                CONV2_TILE(acc1, acc1b, a1, r1, r2, r3)
+                const int qbase = ((2 * xp) * 10 + (y0 + yl)) * 10 + z + 1;
+                const float *a0 = plane + qbase * 4;
+                const float *a1 = a0 + 100 * 4;
+                CONV2Z_TILE(acc0, acc0b, a0, r0, r1, r2)
+                CONV2Z_TILE(acc1, acc1b, a1, r1, r2, r3)
                 acc0 += acc0b;
                 acc1 += acc1b;
                 // ---- pool2: x pair in registers, z pairs in registers, y pair across lanes g <-> g^2
@@ -449,8 +469,8 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
         for (int i = tid; i < nlist * 2; i += 256) {
             const int cell = L.list_cell[i >> 1];
             const int px = cell >> 6, py = (cell >> 3) & 7, pz = cell & 7;
-            const int q = ((px + 1) * 10 + (py + 1)) * 8 + pz;
-            *(float4 *)&L.p1[(i & 1) * P1_PLANE + (P1_FRONT + q) * 4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int q = ((px + 1) * 10 + (py + 1)) * 10 + pz + 1;
+            *(float4 *)&L.p1[(i & 1) * S1P_PLANE + q * 4] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (tid == 0) L.list_n = 0;
         if (tid < 12) L.nzrow[tid] = 0u;
