@@ -390,7 +390,7 @@ def main():
                        "dedup": "bit-identical patches of a frame are encoded once (exact; DESIGN.md 4.7); the roofline "
                                 "object times the encoder kernels on all 3072 patches",
                        "points_per_frame": n_points, "keypoints": 1024, "patches_per_frame": 3072,
-                       "frames_per_gpu": K, "hip_streams_per_gpu": 3, "frames_per_launch": pipe.batch,
+                       "frames_per_gpu": K, "hip_streams_per_gpu": host["streams"], "frames_per_launch": pipe.batch,
                        "host_issue_us_per_frame": round(host["issue_us_per_frame"], 1),
                        "parallelism": "frames sharded x%d, one RCCL all-gather of %s [1024,64] f32 frame rows" % (
                            world, "the boundary" if args.gather == "boundary" else "all"),

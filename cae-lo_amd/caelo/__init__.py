@@ -10,6 +10,15 @@
 Sub-modules are imported lazily so that the light ones (h5lite, synth) work without torch.
 """
 import importlib
+import os
+import sys
+
+# The frame pipeline overlaps four HIP streams when the runtime has hardware queues for them: ROCclr deals streams onto
+# GPU_MAX_HW_QUEUES queues (default 4, one of which the default stream holds) and reads the variable when HIP initialises, which
+# happens at the first device call -- after this import in every entry point of the repository.  Respecting a value the user set.
+_torch = sys.modules.get("torch")
+if "GPU_MAX_HW_QUEUES" not in os.environ and not (_torch is not None and _torch.cuda.is_initialized()):
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"   # (left alone when HIP is already up: the pipeline then stays on three streams)
 
 __all__ = ["api", "engine", "dist", "h5lite", "synth", "_ffi"]
 

@@ -299,7 +299,8 @@ struct caelo_extract_args {
 };
 int extract_check(const caelo_extract_args &a);
 int extract_front_launch(const caelo_extract_args &a, hipStream_t s);
-int extract_front_set(const caelo_extract_args *args, int n, hipStream_t s);  // n frames, the launches of one   // everything up to the bit-packed patches
+int extract_front_set(const caelo_extract_args *args, int n, hipStream_t s, hipStream_t s_vox = nullptr, hipEvent_t ev_fork = nullptr,
+                      hipEvent_t ev_join = nullptr);  // s_vox: build the voxel maps beside the key-point chain  // n frames, the launches of one   // everything up to the bit-packed patches
 int extract_encode_launch(const caelo_extract_args &a, hipStream_t s);  // the four encoder kernels
 
 #define CAELO_KP_HIST_BINS 2048

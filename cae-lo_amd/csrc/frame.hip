@@ -160,7 +160,7 @@ int extract_front_launch(const caelo_extract_args &a, hipStream_t s) { return ex
 
 // The front halves of n frames (n <= CAELO_FB_MAX, one mode for all) with the launches of one: every kernel takes the
 // frame set and runs frame blockIdx.z.  Each frame brings its own voxel map and workspace.
-int extract_front_set(const caelo_extract_args *args, int n, hipStream_t s) {
+int extract_front_set(const caelo_extract_args *args, int n, hipStream_t s, hipStream_t s_vox, hipEvent_t ev_fork, hipEvent_t ev_join) {
     CAELO_REQUIRE(n >= 1 && n <= CAELO_FB_MAX, "bad frame count");
     const ExtractLayout L = extract_layout();
     const bool exact_vox = (args[0].mode & CAELO_EXTRACT_EXACT_VOXELS) != 0;
@@ -194,14 +194,24 @@ int extract_front_set(const caelo_extract_args *args, int n, hipStream_t s) {
     int rc = CAELO_OK;
     if (!exact_vox && (rc = vox_clear_for_fast_build_set(maps, n, cl, s))) return rc;  // wipes the previous frames' bricks only
     if ((rc = caelo_clear_many_set(cl, n, s))) return rc;
+    // The voxel map only needs the points: with a second stream (the frame pipeline passes one when the runtime has hardware
+    // queues to spare) it is built beside the ring image -> response -> key points chain; both meet before the patch gather.
+    hipStream_t sv = s_vox ? s_vox : s;
+    if (s_vox) {
+        CAELO_HIP(hipEventRecord(ev_fork, s));
+        CAELO_HIP(hipStreamWaitEvent(s_vox, ev_fork, 0));
+    }
+    // ---- voxel map
+    if (exact_vox) rc = vox_build_set(maps, fs, false, sv);
+    else rc = vox_build_fast_set(maps, fs, sv);
+    if (rc) return rc;
+    if (s_vox) CAELO_HIP(hipEventRecord(ev_join, s_vox));
     // ---- ring image, response, keypoints
     if ((rc = ring_project_set(fs, s))) return rc;
     if ((rc = ring_respond_set(args[0].ctx, fs, CAELO_RING_W, CAELO_RING_C, s))) return rc;
     if ((rc = ring_keypoints_set(fs, CAELO_RING_W, CAELO_RING_C, CAELO_RING_W, s))) return rc;
-    // ---- voxel map, patches
-    if (exact_vox) rc = vox_build_set(maps, fs, false, s);
-    else rc = vox_build_fast_set(maps, fs, s);
-    if (rc) return rc;
+    if (s_vox) CAELO_HIP(hipStreamWaitEvent(s, ev_join, 0));
+    // ---- patches
     // equal patches are encoded once (dedup.hip): k_patches enters every patch into the hash table, the tables land
     // behind the frame's bits
     if ((rc = vox_patches_set(fs, CAELO_MAX_KEYPTS, true, s))) return rc;
