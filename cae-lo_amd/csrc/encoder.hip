@@ -1576,31 +1576,50 @@ __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part
                                                   const float *__restrict__ bd1p, const float *__restrict__ wd2,
                                                   const float *__restrict__ bd2, int group, caelo_enc_out outs,
                                                   int out_stride, const caelo_enc_in in) {
-    // One wave per patch, no LDS, no barrier.  Lane l < 50 owns the four hidden columns 4l .. 4l+3: one 16-byte load
-    // per split-K partial (8 in flight, 800 contiguous bytes per row) and the 4 x 20 Dense(20) weights of those
-    // columns; the 20 outputs are 64-lane sums of per-lane partial dot products (reduce-scatter butterfly below).
+    // A wave walks patches p, p + (waves of the grid), ...; no LDS, no barrier.  Lane l < 50 owns the four hidden columns 4l .. 4l+3:
+    // one 16-byte load per split-K partial (800 contiguous bytes per row) and the 4 x 20 Dense(20) weights of those columns, which
+    // stay in registers across the wave's patches (a wave per patch re-read the 16 KB of weights from L2 per patch: five times
+    // the bytes of the partial sums).  The next patch's partial sums are fetched under this patch's arithmetic.  The 20 outputs
+    // are 64-lane sums of per-lane partial dot products (reduce-scatter butterfly below).
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t p = (int64_t)blockIdx.x * 4 + wave;
-    if (p >= n_patches) return;
-    int64_t prow = p;  // the row that holds this patch's result: its representative's with de-duplication
-    if (in.dedup) {
-        const int f = (int)(p / in.per_frame);
-        prow = (int64_t)f * in.per_frame + enc_tables(in, f)->slot_of[p - (int64_t)f * in.per_frame];
+    // 32-bit patch arithmetic (the host entry refuses launches of 2^31 patches): 64-bit divisions are long software loops here
+    const unsigned n_all = (unsigned)n_patches, stride = gridDim.x * 4u, per_in = (unsigned)in.per_frame, per_out = (unsigned)outs.per_frame;
+    unsigned p = blockIdx.x * 4u + (unsigned)wave;
+    if (p >= n_all) return;
+    // the row that holds a patch's result: its representative's with de-duplication
+#define HEAD_ROW(P, ROW)                                                          \
+    {                                                                             \
+        ROW = (P);                                                                \
+        if (in.dedup) {                                                           \
+            const unsigned f_ = (P) / per_in;                                     \
+            ROW = f_ * per_in + (unsigned)enc_tables(in, (int)f_)->slot_of[(P) - f_ * per_in]; \
+        }                                                                         \
     }
     const bool ok = lane < DENSE_N / 4;
-    float4 s = ok ? *(const float4 *)(bd1p + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // (lanes 50..63 read lane 49's addresses and are masked out of the sums by hv = 0 below: no pointer selects, no branches)
+    const int cl = ok ? lane : DENSE_N / 4 - 1;
+    const float4 bias4 = *(const float4 *)(bd1p + 4 * cl);
     float4 w[4][5];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int q = 0; q < 5; ++q) w[c][q] = ok ? ((const float4 *)(wd2 + (4 * lane + c) * 20))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok) {
-        float4 v[SPLIT];
+        for (int q = 0; q < 5; ++q) w[c][q] = ((const float4 *)(wd2 + (4 * cl + c) * 20))[q];
+    float4 v[SPLIT], vn[SPLIT];
+#define HEAD_FETCH(V, ROW)                                               \
+    _Pragma("unroll") for (int sp = 0; sp < SPLIT; ++sp)                 \
+        V[sp] = *(const float4 *)(part + ((size_t)sp * n_rows_pad + (ROW)) * DENSE_NP + 4 * cl);
+    unsigned prow, prow_next = 0u;
+    HEAD_ROW(p, prow)
+    HEAD_FETCH(v, prow)
+    if (p + stride < n_all) HEAD_ROW(p + stride, prow_next)
+    const int o_mine = (lane & 32 ? 10 : 0) + (lane & 16 ? 5 : 0) + (lane & 8 ? 3 : 0) + (lane & 4 ? 2 : 0) + (lane & 2 ? 1 : 0);
+    const float bo = o_mine < 20 ? bd2[o_mine] : 0.0f;  // (padding lanes of the butterfly count past 19)
+    for (; p < n_all; p += stride) {
+    if (p + stride < n_all) HEAD_FETCH(vn, prow_next)
+    if (p + 2 * stride < n_all) HEAD_ROW(p + 2 * stride, prow_next)
+    float4 s = bias4;
 #pragma unroll
-        for (int sp = 0; sp < SPLIT; ++sp) v[sp] = *(const float4 *)(part + ((size_t)sp * n_rows_pad + prow) * DENSE_NP + 4 * lane);
-#pragma unroll
-        for (int sp = 0; sp < SPLIT; ++sp) { s.x += v[sp].x; s.y += v[sp].y; s.z += v[sp].z; s.w += v[sp].w; }
-    }
+    for (int sp = 0; sp < SPLIT; ++sp) { s.x += v[sp].x; s.y += v[sp].y; s.z += v[sp].z; s.w += v[sp].w; }
     const float hv[4] = {ok ? enc_tanh(s.x) : 0.f, ok ? enc_tanh(s.y) : 0.f, ok ? enc_tanh(s.z) : 0.f, ok ? enc_tanh(s.w) : 0.f};
     float acc[20];
 #pragma unroll
@@ -1635,13 +1654,23 @@ __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part
     const int o = (h5 ? 10 : 0) + (h4 ? 5 : 0) + (h3 ? 3 : 0) + (h2 ? 2 : 0) + (h1 ? 1 : 0);
     const bool holds = (lane & 1) == 0 && (h3 ? !h2 : !(h2 && h1));
     // patches of several frames in one launch: frame f = p / per_frame writes into its own rows
-    const int64_t f = p / outs.per_frame, q = p - f * outs.per_frame;
-    if (holds) outs.base[f][(size_t)(q / group) * out_stride + (size_t)(q % group) * 20 + o] = enc_tanh(bd2[o] + mine);
+    const unsigned f = p / per_out, q = p - f * per_out, kp = q / (unsigned)group;
+    if (holds) outs.base[f][(size_t)kp * out_stride + (size_t)(q - kp * (unsigned)group) * 20 + o] = enc_tanh(bo + mine);
+#pragma unroll
+    for (int sp = 0; sp < SPLIT; ++sp) v[sp] = vn[sp];
+    }
+#undef HEAD_ROW
+#undef HEAD_FETCH
 }
 
 // ------------------------------------------------------------------------------------------------
 // host entry
 // ------------------------------------------------------------------------------------------------
+// k_enc_head: a wave per patch up to three workgroups per CU (two for the 8-slice instance: 176 registers), then the waves loop
+static inline unsigned enc_head_grid(int64_t n_patches, int64_t cap = 768) {
+    const int64_t wgs = (n_patches + 3) / 4;
+    return (unsigned)(wgs < cap ? wgs : cap);
+}
 static inline int64_t pad64(int64_t n) { return (n + D1_BM - 1) / D1_BM * D1_BM; }  // rows padded to whole dense-1 tiles
 
 // per row: counts (4 quarters x 4 B) + cells (512 x 2 B) + values (512 x 8 x 4 B) of the non-background cells after conv1 + pool1
@@ -1671,7 +1700,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
                   "bad de-duplicated launch");
     CAELO_REQUIRE(outs.per_frame > 0 && (n_patches + outs.per_frame - 1) / outs.per_frame <= CAELO_ENC_MAX_FRAMES, "bad frame table");
     CAELO_REQUIRE(c->has_enc, "encoder weights not set (caelo_set_encoder_weights)");
-    CAELO_REQUIRE(n_patches > 0 && group >= 1 && out_stride >= group * 20, "bad shape");
+    CAELO_REQUIRE(n_patches > 0 && n_patches < 0x7FFFFFFF && group >= 1 && out_stride >= group * 20, "bad shape");
     const int64_t np = pad64(n_patches);
     // ws = [header (CAELO_ENC_WS_HEADER bytes): work counter, zero between calls (the owner zero-fills ws once, conv3 resets it); bytes 8..15
     // = MFMA tap rows the last conv-2 launch executed] | P2 | F3 | dense-1 partial sums | conv-1 cell lists
@@ -1744,7 +1773,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
         if (rc) return rc;
     }
     if (ev) CAELO_HIP(hipEventRecord(ev[3], s));
-    k_enc_head<D1_SPLIT_OF(DENSE_K)><<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(part, n_patches, np, c->enc_bd1, c->enc_wd2, c->enc_bd2,
+    k_enc_head<D1_SPLIT_OF(DENSE_K)><<<enc_head_grid(n_patches), 256, 0, s>>>(part, n_patches, np, c->enc_bd1, c->enc_wd2, c->enc_bd2,
                                                                 group, outs, out_stride, ein);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[4], s));
@@ -1774,7 +1803,7 @@ int enc_dense32_head_launch(caelo_ctx *c, const float *f3, int64_t n_patches, in
     caelo_enc_out outs = {};
     outs.base[0] = out;
     outs.per_frame = n_patches;
-    k_enc_head<D1_SPLIT_OF(16384)><<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(part, n_patches, np, c->enc32_bd1, c->enc_wd2,
+    k_enc_head<D1_SPLIT_OF(16384)><<<enc_head_grid(n_patches, 512), 256, 0, s>>>(part, n_patches, np, c->enc32_bd1, c->enc_wd2,
                                                                 c->enc_bd2, group, outs, out_stride, plain);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
