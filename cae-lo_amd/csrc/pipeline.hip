@@ -187,7 +187,16 @@ CAELO_API int caelo_pipeline_create(caelo_ctx *c, int batch, int n_buffers, int6
     // a stream, the encoder has its own; 3 (default): one stream per stage
     const int n_streams = getenv("CAELO_PIPE_STREAMS") ? atoi(getenv("CAELO_PIPE_STREAMS")) : 3;
     hip_ok(hipStreamCreateWithFlags(&p->sF, hipStreamNonBlocking), "hipStreamCreate");
-    if (n_streams >= 2) hip_ok(hipStreamCreateWithFlags(&p->sE, hipStreamNonBlocking), "hipStreamCreate");
+    if (n_streams >= 2) {
+        // the encoder stream is the critical path of a batch (99 % busy, its kernels stretched by the other streams'): it gets the
+        // highest priority, so that conv3 / Dense(200) / the head are handed CUs first (12.3 -> 12.5 k frames/s; CAELO_PIPE_ENC_PRIO=0
+        // turns it off)
+        int lo = 0, hi = 0;
+        if (!(getenv("CAELO_PIPE_ENC_PRIO") && atoi(getenv("CAELO_PIPE_ENC_PRIO")) == 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
+            hip_ok(hipStreamCreateWithPriority(&p->sE, hipStreamNonBlocking, hi), "hipStreamCreate");
+        else
+            hip_ok(hipStreamCreateWithFlags(&p->sE, hipStreamNonBlocking), "hipStreamCreate");
+    }
     else p->sE = p->sF;
     // (the pair stream at the highest or lowest priority was tried: 10.59 / 10.60 k frames/s against 10.57 k, and k_match_mfma
     // waits for CUs just as long -- the encoder's persistent workgroups do not give theirs up)
