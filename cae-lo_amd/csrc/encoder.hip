@@ -1544,6 +1544,185 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1(const float *__res
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// dense1, software-pipelined.  k_enc_dense1 above needs 90 KB of LDS, so ONE workgroup runs per CU, and its stage is a chain --
+// write A, barrier, fetch fragments from LDS, 42 MFMAs per wave, barrier -- in which the matrix pipe idles through every LDS
+// round trip (SQ counters, 8-frame launch: MFMA busy 35 %, waves parked at waitcnt / barrier 51 % of their cycles).  This kernel
+// keeps the one workgroup per CU and gives it the whole LDS: A double-buffered, THREE weight stages (144 KB), so that
+//   - the fragments of the next group of column tiles (and of the next stage, across the barrier) are in flight while the
+//     current group's MFMAs run: the pipe has work on both sides of the single barrier of a stage;
+//   - the weight DMA runs two stages ahead and the rows of F3 (HBM) two stages ahead in alternating registers; the barrier
+//     waits with vmcnt(6): only the older stage must have landed.
+// The weight DMA, the F3 loads and the A stores are inline asm with hand-counted waits: with a compiler-visible LDS-DMA in the
+// loop hipcc waits vmcnt(0) before every use of a loaded register and before every LDS store, and lgkmcnt(0) before every use
+// of an LDS fragment (measured on a three-line kernel); without one its lgkmcnt arithmetic is exact.  Same products in the same order per accumulator as k_enc_dense1: bit-identical partial sums.
+#ifndef D1P_EXP
+#define D1P_EXP 0
+#endif
+#define D1P_A16 (3 * 4 * D1_BM)
+#define D1P_LDS_BYTES ((2 * D1P_A16 + 3 * D1_B16) * 16)
+template <int KTOT>
+__global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1p(const float *__restrict__ f3, int64_t n_rows_pad,
+                                                               const uint4 *__restrict__ wd1x, float *__restrict__ part,
+                                                               const caelo_enc_in in) {
+    constexpr int BM = D1_BM, NKS = KTOT / D1_SPLIT_OF(KTOT) / D1_BK;
+    static_assert(NKS % 2 == 0 && NKS >= 6, "stages are unrolled in pairs, the last four peeled");
+    if (in.dedup) {  // a row tile past the frame's distinct patches holds nothing (tiles never straddle frames)
+        const int64_t r0 = (int64_t)blockIdx.x * BM;
+        const int f = (int)(r0 / in.per_frame);
+        if (r0 - (int64_t)f * in.per_frame >= enc_tables(in, f)->count) return;
+    }
+    extern __shared__ uint4 d1_lds[];
+    uint4 *As = d1_lds;                // [2][split][g][row]
+    uint4 *Bs = d1_lds + 2 * D1P_A16;  // [3][split][n-tile][lane]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, n = lane & 15;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int split = blockIdx.y;
+    const int ks0 = split * NKS;
+    const int mg = wave >> 1;          // rows mg * 16 ... of the tile
+    const bool odd = (wave & 1) != 0;  // n-tiles 7..12 (6 of them) instead of 0..6
+    const int nt0 = odd ? 7 : 0;
+    f32x4 acc[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // A fetch: row a_row, 4 consecutive k (16 bytes) from 4 a_kq.  Lane -> (row, a_kq) so that the 16 lanes one LDS store cycle
+    // serves (8 rows x the two halves of a 16-byte unit) fall into 16 different bank pairs; (tid >> 3, tid & 7) put four
+    // lanes on every bank: 288 conflict cycles per stage, 20 us of the 8-frame launch.  A wave still reads 8 rows x 128 bytes.
+    const int a_row = wave * 8 + ((lane >> 1) & 7), a_kq = ((lane >> 4) << 1) | (lane & 1);
+    const float *a_src = f3 + (size_t)(row0 + a_row) * KTOT + (size_t)ks0 * D1_BK + a_kq * 4;
+    const uint4 *b_src = wd1x + (size_t)ks0 * D1_B16 + lane;
+    const uint32_t b_lds = (uint32_t)(uintptr_t)(void __attribute__((address_space(3))) *)Bs;  // (the DMA adds 16 x lane itself)
+    // LDS byte address of this thread's 8 bytes of A buffer 0, high term ([split][g = a_kq >> 1][row] x 16 B, half a_kq & 1)
+    const uint32_t a_lds = (uint32_t)(uintptr_t)(void __attribute__((address_space(3))) *)&As[(a_kq >> 1) * BM + a_row] + (a_kq & 1) * 8;
+    f32x4 paA, paB;
+    bf16x8 af0[3], af1[3], bf0[4][3], bf1[3][3];
+    // five 1 KB pieces per wave and stage (39 pieces: the eighth wave sends piece 38 twice -- every wave has the same count of
+    // loads in flight, which the vmcnt arithmetic below relies on)
+#define D1P_FETCH_B(KS, BUF)                                                                                     \
+    {                                                                                                            \
+        _Pragma("unroll") for (int r = 0; r < 5; ++r) {                                                          \
+            const int blk = wave + 8 * r < 3 * D1_NT ? wave + 8 * r : 3 * D1_NT - 1;                             \
+            const uint4 *gp_ = b_src + (size_t)(KS) * D1_B16 + blk * 64;                                         \
+            const uint32_t la_ = b_lds + (uint32_t)((BUF) * D1_B16 + blk * 64) * 16u;                            \
+            if (D1P_EXP != 1) __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(la_), "v"(gp_) : "memory"); \
+        }                                                                                                        \
+    }
+#define D1P_LOAD_A(P, KS)                                                                                        \
+    {                                                                                                            \
+        const float *p_ = a_src + (size_t)(KS) * D1_BK;                                                          \
+        if (D1P_EXP != 2) __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=v"(P) : "v"(p_) : "memory");    \
+        else P = (f32x4){1.f, 2.f, 3.f, (float)(KS)};                                                            \
+    }
+    // (the three stores are inline asm as well: a compiler-visible LDS store is ordered behind every LDS-DMA in flight -- vmcnt(0))
+#define D1P_STORE_A(P, ABUF)                                                                               \
+    {                                                                                                      \
+        uint32_t h01_, m01_, l01_, h23_, m23_, l23_;                                                       \
+        enc_split3_pk(P[0], P[1], h01_, m01_, l01_);                                                       \
+        enc_split3_pk(P[2], P[3], h23_, m23_, l23_);                                                       \
+        const unsigned long long dh_ = ((unsigned long long)h23_ << 32) | h01_, dm_ = ((unsigned long long)m23_ << 32) | m01_, \
+                                 dl_ = ((unsigned long long)l23_ << 32) | l01_;                            \
+        if (D1P_EXP != 3) __asm__ volatile("ds_write_b64 %0, %1 offset:%4\n\tds_write_b64 %0, %2 offset:%5\n\tds_write_b64 %0, %3 offset:%6" \
+                         : : "v"(a_lds), "v"(dh_), "v"(dm_), "v"(dl_), "n"((ABUF) * D1P_A16 * 16),           \
+                             "n"((ABUF) * D1P_A16 * 16 + 4 * BM * 16), "n"((ABUF) * D1P_A16 * 16 + 8 * BM * 16) : "memory"); \
+    }
+#define D1P_READ_A(AF, ABUF)                                                                               \
+    {                                                                                                      \
+        const uint4 *ap_ = &As[(ABUF) * D1P_A16 + g * BM + mg * 16 + n];                                   \
+        AF[0] = __builtin_bit_cast(bf16x8, ap_[0]);                                                        \
+        AF[1] = __builtin_bit_cast(bf16x8, ap_[4 * BM]);                                                   \
+        AF[2] = __builtin_bit_cast(bf16x8, ap_[8 * BM]);                                                   \
+    }
+    // column tiles nt0 .. nt0+3 (group 0) and nt0+4 .. nt0+6 (group 1; the last one absent on odd waves)
+#define D1P_READ_B0(BUF)                                                                                   \
+    {                                                                                                      \
+        const uint4 *bp_ = &Bs[(BUF) * D1_B16 + nt0 * 64 + lane];                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+        _Pragma("unroll") for (int sp = 0; sp < 3; ++sp) bf0[i][sp] = __builtin_bit_cast(bf16x8, bp_[(sp * D1_NT + i) * 64]); \
+    }
+    // (odd waves own six tiles: their seventh accumulator repeats tile 12 and is dropped at the end -- no branches in the stage;
+    // the SIMDs that run the odd waves have the idle slots: 36 instead of 42 MFMAs per wave and stage)
+#define D1P_READ_B1(BUF)                                                                                   \
+    {                                                                                                      \
+        const uint4 *bp_ = &Bs[(BUF) * D1_B16 + lane];                                                     \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                    \
+            const int t_ = (i == 2 && odd) ? D1_NT - 1 : nt0 + 4 + i;                                      \
+            _Pragma("unroll") for (int sp = 0; sp < 3; ++sp) bf1[i][sp] = __builtin_bit_cast(bf16x8, bp_[(sp * D1_NT + t_) * 64]); \
+        }                                                                                                  \
+    }
+    // smallest terms first (AF / B index: 0 high, 1 middle, 2 low); the accumulators alternate
+#define D1P_TERM0(AF, SA, SB) \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[SA], bf0[i][SB], acc[i], 0, 0, 0);
+#define D1P_MFMA_G0(AF) D1P_TERM0(AF, 2, 0) D1P_TERM0(AF, 0, 2) D1P_TERM0(AF, 1, 1) D1P_TERM0(AF, 1, 0) D1P_TERM0(AF, 0, 1) D1P_TERM0(AF, 0, 0)
+#define D1P_TERM1(AF, SA, SB) \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) acc[4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[SA], bf1[i][SB], acc[4 + i], 0, 0, 0);
+#define D1P_MFMA_G1(AF) D1P_TERM1(AF, 2, 0) D1P_TERM1(AF, 0, 2) D1P_TERM1(AF, 1, 1) D1P_TERM1(AF, 1, 0) D1P_TERM1(AF, 0, 1) D1P_TERM1(AF, 0, 0)
+    // One stage ST whose successor exists.  On entry: bf0 / AFC hold (or are receiving) stage ST's first group and A fragments;
+    // in flight, oldest first: weight DMA ST+1 (5), rows ST+1 (register PN), and -- if YOUNGER -- DMA ST+2 (5), rows ST+2.
+    // ISSUE: start DMA ST+3 (into the buffer stage ST leaves) and rows ST+3.  BC / BN: weight buffers of ST / ST+1.
+#define D1P_STAGE(ST, AFC, AFN, PN, ABN, BC, BN, YOUNGER, ISSUE)                                                    \
+    {                                                                                                               \
+        D1P_READ_B1(BC)                                                                                             \
+        __builtin_amdgcn_sched_barrier(0); /* the reads stay ahead of the MFMAs that cover them */                  \
+        D1P_MFMA_G0(AFC)                                                                                            \
+        if (YOUNGER) __asm__ volatile("s_waitcnt vmcnt(6)" : "+v"(PN) : : "memory");                                \
+        else __asm__ volatile("s_waitcnt vmcnt(0)" : "+v"(PN) : : "memory");                                        \
+        D1P_STORE_A(PN, ABN)                                                                                        \
+        /* rows ST+1 are written, weights ST+1 have landed (older than the rows just waited for), every wave is */  \
+        /* done reading stage ST's buffers */                                                                       \
+        __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        if (ISSUE) {                                                                                                \
+            D1P_FETCH_B((ST) + 3, BC)                                                                               \
+            D1P_LOAD_A(PN, (ST) + 3)                                                                                \
+        }                                                                                                           \
+        D1P_READ_A(AFN, ABN)                                                                                        \
+        D1P_READ_B0(BN)                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        D1P_MFMA_G1(AFC)                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+    }
+    D1P_FETCH_B(0, 0)
+    D1P_LOAD_A(paA, 0)
+    D1P_FETCH_B(1, 1)
+    D1P_LOAD_A(paB, 1)
+    D1P_FETCH_B(2, 2)
+    __asm__ volatile("s_waitcnt vmcnt(11)" : "+v"(paA) : : "memory");  // stage 0: its weights (older) and its rows
+    D1P_STORE_A(paA, 0)
+    D1P_LOAD_A(paA, 2)
+    __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    D1P_READ_A(af0, 0)
+    D1P_READ_B0(0)
+    int b0 = 0;  // weight buffer of stage st (st % 3)
+#pragma unroll 1
+    for (int st = 0; st < NKS - 4; st += 2) {
+        const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+        D1P_STAGE(st, af0, af1, paB, 1, b0, b1, true, true)
+        D1P_STAGE(st + 1, af1, af0, paA, 0, b1, b2, true, true)
+        b0 = b2;
+    }
+    {
+        constexpr int c0 = (NKS - 4) % 3, c1 = (NKS - 3) % 3, c2 = (NKS - 2) % 3, c3 = (NKS - 1) % 3;
+        D1P_STAGE(NKS - 4, af0, af1, paB, 1, c0, c1, true, true)
+        D1P_STAGE(NKS - 3, af1, af0, paA, 0, c1, c2, true, false)
+        D1P_STAGE(NKS - 2, af0, af1, paB, 1, c2, c3, false, false)
+        // the last stage: its first group and A fragments are on their way, nothing to prepare
+        D1P_READ_B1(c3)
+        __builtin_amdgcn_sched_barrier(0);
+        D1P_MFMA_G0(af1)
+        D1P_MFMA_G1(af1)
+    }
+    // C rows 4g + r of each tile
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        if (i == 6 && odd) continue;
+        float *dst = part + ((size_t)split * n_rows_pad + row0 + mg * 16 + 4 * g) * DENSE_NP + (nt0 + i) * 16 + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(size_t)r * DENSE_NP] = acc[i][r];
+    }
+}
+
 template <int KTOT>
 static int dense1_launch(const float *f3, int64_t np, const void *wd1x, float *part, const caelo_enc_in &in, hipStream_t s) {
     // once per process (thread-safe static initialisation: the pipeline's encoder thread and the caller may race here)
@@ -1551,6 +1730,8 @@ static int dense1_launch(const float *f3, int64_t np, const void *wd1x, float *p
         hipError_t e = hipFuncSetAttribute((const void *)k_enc_dense1<KTOT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, D1_LDS_BYTES(1));
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)k_enc_dense1<KTOT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, D1_LDS_BYTES(3));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)k_enc_dense1p<KTOT>, hipFuncAttributeMaxDynamicSharedMemorySize, D1P_LDS_BYTES);
         return e;
     }();
     CAELO_HIP(attr);
@@ -1564,7 +1745,11 @@ static int dense1_launch(const float *f3, int64_t np, const void *wd1x, float *p
         k_enc_dense1<KTOT, 3><<<gd, D1_THREADS, D1_LDS_BYTES(3), s>>>(f3, np, (const uint4 *)wd1x, part, in);
     } else {
         dim3 gd((unsigned)(np / 64), D1_SPLIT_OF(KTOT));
-        k_enc_dense1<KTOT, 1><<<gd, D1_THREADS, D1_LDS_BYTES(1), s>>>(f3, np, (const uint4 *)wd1x, part, in);
+        static const bool plain = getenv("CAELO_D1_PLAIN") && atoi(getenv("CAELO_D1_PLAIN")) > 0;  // the older kernel (bit-identical)
+        if (plain)
+            k_enc_dense1<KTOT, 1><<<gd, D1_THREADS, D1_LDS_BYTES(1), s>>>(f3, np, (const uint4 *)wd1x, part, in);
+        else
+            k_enc_dense1p<KTOT><<<gd, D1_THREADS, D1P_LDS_BYTES, s>>>(f3, np, (const uint4 *)wd1x, part, in);
     }
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
