@@ -1412,7 +1412,7 @@ int enc_upload_dense1(const float *wd1, const float *bd1, int K, void **wx_dev, 
     float bd[DENSE_NP] = {0.0f};
     memcpy(bd, bd1, DENSE_N * sizeof(float));
     hipError_t e = hipSuccess;
-    if (!*wx_dev) e = hipMalloc(wx_dev, n * sizeof(uint4));
+    if (!*wx_dev) e = hipMalloc(wx_dev, (n + 64) * sizeof(uint4));  // + one 1 KB piece: k_enc_dense1p's eighth wave copies a 40th piece per stage
     if (e == hipSuccess && !*bd_dev) e = hipMalloc((void **)bd_dev, sizeof(bd));
     if (e == hipSuccess) e = hipMemcpy(*wx_dev, wx, n * sizeof(uint4), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(*bd_dev, bd, sizeof(bd), hipMemcpyHostToDevice);
@@ -1556,126 +1556,149 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1(const float *__res
 // The weight DMA, the F3 loads and the A stores are inline asm with hand-counted waits: with a compiler-visible LDS-DMA in the
 // loop hipcc waits vmcnt(0) before every use of a loaded register and before every LDS store, and lgkmcnt(0) before every use
 // of an LDS fragment (measured on a three-line kernel); without one its lgkmcnt arithmetic is exact.  Same products in the same order per accumulator as k_enc_dense1: bit-identical partial sums.
-#ifndef D1P_EXP
-#define D1P_EXP 0
-#endif
-#define D1P_A16 (3 * 4 * D1_BM)
-#define D1P_LDS_BYTES ((2 * D1P_A16 + 3 * D1_B16) * 16)
-template <int KTOT>
+#define D1P_BSTRIDE (40 * 64)  // uint4 per weight buffer: 39 pieces of 1 KB + the 40th the eighth wave brings along
+#define D1P_NBUF(MTW) ((MTW) == 1 ? 3 : 2)
+#define D1P_LDS_BYTES(MTW) ((2 * 3 * 4 * D1_BM * (MTW) + D1P_NBUF(MTW) * D1P_BSTRIDE) * 16)
+// MTW = 1: 64 rows per workgroup, three weight stages (DMA two stages ahead), 144 KB.  MTW = 2: 128 rows -- every wave owns two
+// row tiles, each weight fragment feeds two MFMAs, and the weight stream from L2 (39 KB per stage and workgroup: 983 MB per
+// 8-frame launch at 64 rows, 7.9 TB/s at 125 us -- the LDS-DMA ceiling of the chip) halves; its stages are twice as long, so
+// two weight buffers (DMA one stage ahead) do: 128 KB.
+template <int KTOT, int MTW>
 __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1p(const float *__restrict__ f3, int64_t n_rows_pad,
                                                                const uint4 *__restrict__ wd1x, float *__restrict__ part,
                                                                const caelo_enc_in in) {
-    constexpr int BM = D1_BM, NKS = KTOT / D1_SPLIT_OF(KTOT) / D1_BK;
-    static_assert(NKS % 2 == 0 && NKS >= 6, "stages are unrolled in pairs, the last four peeled");
+    constexpr int BM = D1_BM * MTW, A16 = 3 * 4 * BM, NBUF = D1P_NBUF(MTW), NKS = KTOT / D1_SPLIT_OF(KTOT) / D1_BK;
+    constexpr int PER_STAGE = 5 + MTW;  // loads a thread has in flight per stage: five DMA pieces + its rows
+    static_assert(MTW == 1 || MTW == 2, "two instances");
+    static_assert(NKS % 2 == 0 && NKS >= 6, "stages are unrolled in pairs, the last ones peeled");
     if (in.dedup) {  // a row tile past the frame's distinct patches holds nothing (tiles never straddle frames)
         const int64_t r0 = (int64_t)blockIdx.x * BM;
         const int f = (int)(r0 / in.per_frame);
         if (r0 - (int64_t)f * in.per_frame >= enc_tables(in, f)->count) return;
     }
     extern __shared__ uint4 d1_lds[];
-    uint4 *As = d1_lds;                // [2][split][g][row]
-    uint4 *Bs = d1_lds + 2 * D1P_A16;  // [3][split][n-tile][lane]
+    uint4 *As = d1_lds;            // [2][split][g][row]
+    uint4 *Bs = d1_lds + 2 * A16;  // [NBUF][split][n-tile][lane] (+ 1 KB)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, n = lane & 15;
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     const int split = blockIdx.y;
     const int ks0 = split * NKS;
-    const int mg = wave >> 1;          // rows mg * 16 ... of the tile
+    const int mg = wave >> 1;          // rows mg * 16 MTW ... of the tile
     const bool odd = (wave & 1) != 0;  // n-tiles 7..12 (6 of them) instead of 0..6
     const int nt0 = odd ? 7 : 0;
-    f32x4 acc[7];
+    f32x4 acc[MTW][7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // A fetch: row a_row, 4 consecutive k (16 bytes) from 4 a_kq.  Lane -> (row, a_kq) so that the 16 lanes one LDS store cycle
-    // serves (8 rows x the two halves of a 16-byte unit) fall into 16 different bank pairs; (tid >> 3, tid & 7) put four
+    for (int q = 0; q < MTW; ++q)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) acc[q][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // A fetch: rows a_row (+ 64), 4 consecutive k (16 bytes) from 4 a_kq.  Lane -> (row, a_kq) so that the 16 lanes one LDS store
+    // cycle serves (8 rows x the two halves of a 16-byte unit) fall into 16 different bank pairs; (tid >> 3, tid & 7) put four
     // lanes on every bank: 288 conflict cycles per stage, 20 us of the 8-frame launch.  A wave still reads 8 rows x 128 bytes.
     const int a_row = wave * 8 + ((lane >> 1) & 7), a_kq = ((lane >> 4) << 1) | (lane & 1);
     const float *a_src = f3 + (size_t)(row0 + a_row) * KTOT + (size_t)ks0 * D1_BK + a_kq * 4;
-    const uint4 *b_src = wd1x + (size_t)ks0 * D1_B16 + lane;
-    const uint32_t b_lds = (uint32_t)(uintptr_t)(void __attribute__((address_space(3))) *)Bs;  // (the DMA adds 16 x lane itself)
+    // this wave's middle piece (5 wave + 2) of weight buffer 0 in LDS (the DMA adds 16 x lane itself) and of stage ks0 in memory
+    const uint32_t b_lds = (uint32_t)(uintptr_t)(void __attribute__((address_space(3))) *)(Bs + (5 * wave + 2) * 64);
+    const uint4 *b_mid = wd1x + (size_t)ks0 * D1_B16 + (5 * wave + 2) * 64 + lane;
     // LDS byte address of this thread's 8 bytes of A buffer 0, high term ([split][g = a_kq >> 1][row] x 16 B, half a_kq & 1)
     const uint32_t a_lds = (uint32_t)(uintptr_t)(void __attribute__((address_space(3))) *)&As[(a_kq >> 1) * BM + a_row] + (a_kq & 1) * 8;
-    f32x4 paA, paB;
-    bf16x8 af0[3], af1[3], bf0[4][3], bf1[3][3];
-    // five 1 KB pieces per wave and stage (39 pieces: the eighth wave sends piece 38 twice -- every wave has the same count of
-    // loads in flight, which the vmcnt arithmetic below relies on)
+    f32x4 paA[MTW], paB[MTW];
+    bf16x8 af0[MTW][3], af1[MTW][3], bf0[4][3], bf1[3][3];
+    // five CONSECUTIVE 1 KB pieces per wave and stage, addressed from the middle one by the instruction's immediate offset (it
+    // moves the global and the LDS address alike): one M0 write and one address register per stage instead of five of each.
+    // The eighth wave's fifth piece is piece 39 -- the first KB of the next stage (the weight image is padded by one piece),
+    // landing in the buffer's 40th KB, which nobody reads.  Every wave has the same count of loads in flight, which the vmcnt
+    // arithmetic below relies on.
 #define D1P_FETCH_B(KS, BUF)                                                                                     \
     {                                                                                                            \
-        _Pragma("unroll") for (int r = 0; r < 5; ++r) {                                                          \
-            const int blk = wave + 8 * r < 3 * D1_NT ? wave + 8 * r : 3 * D1_NT - 1;                             \
-            const uint4 *gp_ = b_src + (size_t)(KS) * D1_B16 + blk * 64;                                         \
-            const uint32_t la_ = b_lds + (uint32_t)((BUF) * D1_B16 + blk * 64) * 16u;                            \
-            if (D1P_EXP != 1) __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(la_), "v"(gp_) : "memory"); \
-        }                                                                                                        \
+        const uint4 *gp_ = b_mid + (size_t)(KS) * D1_B16;                                                        \
+        const uint32_t la_ = b_lds + (uint32_t)(BUF) * (D1P_BSTRIDE * 16u);                                      \
+        __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"                                                       \
+                         "global_load_lds_dwordx4 %1, off offset:-2048\n\tglobal_load_lds_dwordx4 %1, off offset:-1024\n\t" \
+                         "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"    \
+                         "global_load_lds_dwordx4 %1, off offset:2048" : : "s"(la_), "v"(gp_) : "memory");       \
     }
 #define D1P_LOAD_A(P, KS)                                                                                        \
-    {                                                                                                            \
-        const float *p_ = a_src + (size_t)(KS) * D1_BK;                                                          \
-        if (D1P_EXP != 2) __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=v"(P) : "v"(p_) : "memory");    \
-        else P = (f32x4){1.f, 2.f, 3.f, (float)(KS)};                                                            \
+    _Pragma("unroll") for (int r = 0; r < MTW; ++r) {                                                            \
+        const float *p_ = a_src + (size_t)(64 * r) * KTOT + (size_t)(KS) * D1_BK;                                \
+        __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=v"(P[r]) : "v"(p_) : "memory");                   \
     }
-    // (the three stores are inline asm as well: a compiler-visible LDS store is ordered behind every LDS-DMA in flight -- vmcnt(0))
+    // wait until at most N loads are in flight; the registers are operands so that no use moves above the wait
+#define D1P_WAIT_A(P, N)                                                                                         \
+    {                                                                                                            \
+        if (MTW == 1) __asm__ volatile("s_waitcnt vmcnt(%1)" : "+v"(P[0]) : "n"(N) : "memory");                  \
+        else __asm__ volatile("s_waitcnt vmcnt(%2)" : "+v"(P[0]), "+v"(P[MTW - 1]) : "n"(N) : "memory");         \
+    }
+    // (the stores are inline asm as well: a compiler-visible LDS store is ordered behind every LDS-DMA in flight -- vmcnt(0))
 #define D1P_STORE_A(P, ABUF)                                                                               \
-    {                                                                                                      \
+    _Pragma("unroll") for (int r = 0; r < MTW; ++r) {                                                      \
         uint32_t h01_, m01_, l01_, h23_, m23_, l23_;                                                       \
-        enc_split3_pk(P[0], P[1], h01_, m01_, l01_);                                                       \
-        enc_split3_pk(P[2], P[3], h23_, m23_, l23_);                                                       \
+        enc_split3_pk(P[r][0], P[r][1], h01_, m01_, l01_);                                                 \
+        enc_split3_pk(P[r][2], P[r][3], h23_, m23_, l23_);                                                 \
         const unsigned long long dh_ = ((unsigned long long)h23_ << 32) | h01_, dm_ = ((unsigned long long)m23_ << 32) | m01_, \
                                  dl_ = ((unsigned long long)l23_ << 32) | l01_;                            \
-        if (D1P_EXP != 3) __asm__ volatile("ds_write_b64 %0, %1 offset:%4\n\tds_write_b64 %0, %2 offset:%5\n\tds_write_b64 %0, %3 offset:%6" \
-                         : : "v"(a_lds), "v"(dh_), "v"(dm_), "v"(dl_), "n"((ABUF) * D1P_A16 * 16),           \
-                             "n"((ABUF) * D1P_A16 * 16 + 4 * BM * 16), "n"((ABUF) * D1P_A16 * 16 + 8 * BM * 16) : "memory"); \
+        if (r == 0)                                                                                        \
+            __asm__ volatile("ds_write_b64 %0, %1 offset:%4\n\tds_write_b64 %0, %2 offset:%5\n\tds_write_b64 %0, %3 offset:%6" \
+                             : : "v"(a_lds), "v"(dh_), "v"(dm_), "v"(dl_), "n"((ABUF) * A16 * 16),           \
+                                 "n"((ABUF) * A16 * 16 + 4 * BM * 16), "n"((ABUF) * A16 * 16 + 8 * BM * 16) : "memory"); \
+        else                                                                                               \
+            __asm__ volatile("ds_write_b64 %0, %1 offset:%4\n\tds_write_b64 %0, %2 offset:%5\n\tds_write_b64 %0, %3 offset:%6" \
+                             : : "v"(a_lds), "v"(dh_), "v"(dm_), "v"(dl_), "n"((ABUF) * A16 * 16 + 1024),    \
+                                 "n"((ABUF) * A16 * 16 + 4 * BM * 16 + 1024), "n"((ABUF) * A16 * 16 + 8 * BM * 16 + 1024) : "memory"); \
     }
 #define D1P_READ_A(AF, ABUF)                                                                               \
-    {                                                                                                      \
-        const uint4 *ap_ = &As[(ABUF) * D1P_A16 + g * BM + mg * 16 + n];                                   \
-        AF[0] = __builtin_bit_cast(bf16x8, ap_[0]);                                                        \
-        AF[1] = __builtin_bit_cast(bf16x8, ap_[4 * BM]);                                                   \
-        AF[2] = __builtin_bit_cast(bf16x8, ap_[8 * BM]);                                                   \
+    _Pragma("unroll") for (int q = 0; q < MTW; ++q) {                                                      \
+        const uint4 *ap_ = &As[(ABUF) * A16 + g * BM + (mg * MTW + q) * 16 + n];                           \
+        AF[q][0] = __builtin_bit_cast(bf16x8, ap_[0]);                                                     \
+        AF[q][1] = __builtin_bit_cast(bf16x8, ap_[4 * BM]);                                                \
+        AF[q][2] = __builtin_bit_cast(bf16x8, ap_[8 * BM]);                                                \
     }
-    // column tiles nt0 .. nt0+3 (group 0) and nt0+4 .. nt0+6 (group 1; the last one absent on odd waves)
+    // column tiles nt0 .. nt0+3 (group 0) and nt0+4 .. nt0+6 (group 1).  Odd waves own six tiles: their seventh accumulator
+    // repeats tile 12 and is dropped at the end -- no branches in the stage; the SIMDs that run the odd waves have the idle
+    // slots (36 instead of 42 MFMAs per row tile and stage)
 #define D1P_READ_B0(BUF)                                                                                   \
     {                                                                                                      \
-        const uint4 *bp_ = &Bs[(BUF) * D1_B16 + nt0 * 64 + lane];                                          \
+        const uint4 *bp_ = &Bs[(BUF) * D1P_BSTRIDE + nt0 * 64 + lane];                                     \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
         _Pragma("unroll") for (int sp = 0; sp < 3; ++sp) bf0[i][sp] = __builtin_bit_cast(bf16x8, bp_[(sp * D1_NT + i) * 64]); \
     }
-    // (odd waves own six tiles: their seventh accumulator repeats tile 12 and is dropped at the end -- no branches in the stage;
-    // the SIMDs that run the odd waves have the idle slots: 36 instead of 42 MFMAs per wave and stage)
 #define D1P_READ_B1(BUF)                                                                                   \
     {                                                                                                      \
-        const uint4 *bp_ = &Bs[(BUF) * D1_B16 + lane];                                                     \
+        const uint4 *bp_ = &Bs[(BUF) * D1P_BSTRIDE + lane];                                                \
         _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                    \
             const int t_ = (i == 2 && odd) ? D1_NT - 1 : nt0 + 4 + i;                                      \
             _Pragma("unroll") for (int sp = 0; sp < 3; ++sp) bf1[i][sp] = __builtin_bit_cast(bf16x8, bp_[(sp * D1_NT + t_) * 64]); \
         }                                                                                                  \
     }
     // smallest terms first (AF / B index: 0 high, 1 middle, 2 low); the accumulators alternate
-#define D1P_TERM0(AF, SA, SB) \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[SA], bf0[i][SB], acc[i], 0, 0, 0);
+#define D1P_TERM0(AF, SA, SB)                                                                              \
+    _Pragma("unroll") for (int q = 0; q < MTW; ++q)                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+        acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[q][SA], bf0[i][SB], acc[q][i], 0, 0, 0);
 #define D1P_MFMA_G0(AF) D1P_TERM0(AF, 2, 0) D1P_TERM0(AF, 0, 2) D1P_TERM0(AF, 1, 1) D1P_TERM0(AF, 1, 0) D1P_TERM0(AF, 0, 1) D1P_TERM0(AF, 0, 0)
-#define D1P_TERM1(AF, SA, SB) \
-    _Pragma("unroll") for (int i = 0; i < 3; ++i) acc[4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[SA], bf1[i][SB], acc[4 + i], 0, 0, 0);
+#define D1P_TERM1(AF, SA, SB)                                                                              \
+    _Pragma("unroll") for (int q = 0; q < MTW; ++q)                                                        \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                          \
+        acc[q][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[q][SA], bf1[i][SB], acc[q][4 + i], 0, 0, 0);
 #define D1P_MFMA_G1(AF) D1P_TERM1(AF, 2, 0) D1P_TERM1(AF, 0, 2) D1P_TERM1(AF, 1, 1) D1P_TERM1(AF, 1, 0) D1P_TERM1(AF, 0, 1) D1P_TERM1(AF, 0, 0)
     // One stage ST whose successor exists.  On entry: bf0 / AFC hold (or are receiving) stage ST's first group and A fragments;
-    // in flight, oldest first: weight DMA ST+1 (5), rows ST+1 (register PN), and -- if YOUNGER -- DMA ST+2 (5), rows ST+2.
-    // ISSUE: start DMA ST+3 (into the buffer stage ST leaves) and rows ST+3.  BC / BN: weight buffers of ST / ST+1.
+    // in flight, oldest first: weight DMA ST+1 (5), rows ST+1 (registers PN), then YOUNGER more loads of later stages.
+    // ISSUE: start DMA ST+NBUF (into the buffer stage ST leaves) and its rows (into PN).  BC / BN: weight buffers of ST / ST+1.
 #define D1P_STAGE(ST, AFC, AFN, PN, ABN, BC, BN, YOUNGER, ISSUE)                                                    \
     {                                                                                                               \
         D1P_READ_B1(BC)                                                                                             \
         __builtin_amdgcn_sched_barrier(0); /* the reads stay ahead of the MFMAs that cover them */                  \
         D1P_MFMA_G0(AFC)                                                                                            \
-        if (YOUNGER) __asm__ volatile("s_waitcnt vmcnt(6)" : "+v"(PN) : : "memory");                                \
-        else __asm__ volatile("s_waitcnt vmcnt(0)" : "+v"(PN) : : "memory");                                        \
+        D1P_WAIT_A(PN, YOUNGER)                                                                                     \
         D1P_STORE_A(PN, ABN)                                                                                        \
         /* rows ST+1 are written, weights ST+1 have landed (older than the rows just waited for), every wave is */  \
         /* done reading stage ST's buffers */                                                                       \
         __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
         if (ISSUE) {                                                                                                \
-            D1P_FETCH_B((ST) + 3, BC)                                                                               \
-            D1P_LOAD_A(PN, (ST) + 3)                                                                                \
+            D1P_FETCH_B((ST) + NBUF, BC)                                                                            \
+            D1P_LOAD_A(PN, (ST) + NBUF)                                                                             \
         }                                                                                                           \
         D1P_READ_A(AFN, ABN)                                                                                        \
         D1P_READ_B0(BN)                                                                                             \
@@ -1683,44 +1706,66 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1p(const float *__re
         D1P_MFMA_G1(AFC)                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
     }
-    D1P_FETCH_B(0, 0)
-    D1P_LOAD_A(paA, 0)
-    D1P_FETCH_B(1, 1)
-    D1P_LOAD_A(paB, 1)
-    D1P_FETCH_B(2, 2)
-    __asm__ volatile("s_waitcnt vmcnt(11)" : "+v"(paA) : : "memory");  // stage 0: its weights (older) and its rows
-    D1P_STORE_A(paA, 0)
-    D1P_LOAD_A(paA, 2)
+    if (MTW == 1) {
+        D1P_FETCH_B(0, 0)
+        D1P_LOAD_A(paA, 0)
+        D1P_FETCH_B(1, 1)
+        D1P_LOAD_A(paB, 1)
+        D1P_FETCH_B(2, 2)
+        D1P_WAIT_A(paA, PER_STAGE + 5)  // stage 0: its weights (older) and its rows
+        D1P_STORE_A(paA, 0)
+        D1P_LOAD_A(paA, 2)
+    } else {
+        D1P_FETCH_B(0, 0)
+        D1P_LOAD_A(paA, 0)
+        D1P_FETCH_B(1, 1)
+        D1P_WAIT_A(paA, 5)
+        D1P_STORE_A(paA, 0)
+        D1P_LOAD_A(paA, 1)
+    }
     __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     D1P_READ_A(af0, 0)
     D1P_READ_B0(0)
-    int b0 = 0;  // weight buffer of stage st (st % 3)
+    if (MTW == 1) {
+        int b0 = 0;  // weight buffer of stage st (st % 3)
 #pragma unroll 1
-    for (int st = 0; st < NKS - 4; st += 2) {
-        const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
-        D1P_STAGE(st, af0, af1, paB, 1, b0, b1, true, true)
-        D1P_STAGE(st + 1, af1, af0, paA, 0, b1, b2, true, true)
-        b0 = b2;
-    }
-    {
+        for (int st = 0; st < NKS - 4; st += 2) {
+            const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+            D1P_STAGE(st, af0, af1, paB, 1, b0, b1, PER_STAGE, true)
+            D1P_STAGE(st + 1, af1, af0, paA, 0, b1, b2, PER_STAGE, true)
+            b0 = b2;
+        }
         constexpr int c0 = (NKS - 4) % 3, c1 = (NKS - 3) % 3, c2 = (NKS - 2) % 3, c3 = (NKS - 1) % 3;
-        D1P_STAGE(NKS - 4, af0, af1, paB, 1, c0, c1, true, true)
-        D1P_STAGE(NKS - 3, af1, af0, paA, 0, c1, c2, true, false)
-        D1P_STAGE(NKS - 2, af0, af1, paB, 1, c2, c3, false, false)
+        D1P_STAGE(NKS - 4, af0, af1, paB, 1, c0, c1, PER_STAGE, true)
+        D1P_STAGE(NKS - 3, af1, af0, paA, 0, c1, c2, PER_STAGE, false)
+        D1P_STAGE(NKS - 2, af0, af1, paB, 1, c2, c3, 0, false)
         // the last stage: its first group and A fragments are on their way, nothing to prepare
         D1P_READ_B1(c3)
+        __builtin_amdgcn_sched_barrier(0);
+        D1P_MFMA_G0(af1)
+        D1P_MFMA_G1(af1)
+    } else {
+#pragma unroll 1
+        for (int st = 0; st < NKS - 2; st += 2) {
+            D1P_STAGE(st, af0, af1, paA, 1, 0, 1, 0, true)
+            D1P_STAGE(st + 1, af1, af0, paA, 0, 1, 0, 0, true)
+        }
+        D1P_STAGE(NKS - 2, af0, af1, paA, 1, 0, 1, 0, false)
+        D1P_READ_B1(1)
         __builtin_amdgcn_sched_barrier(0);
         D1P_MFMA_G0(af1)
         D1P_MFMA_G1(af1)
     }
     // C rows 4g + r of each tile
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        if (i == 6 && odd) continue;
-        float *dst = part + ((size_t)split * n_rows_pad + row0 + mg * 16 + 4 * g) * DENSE_NP + (nt0 + i) * 16 + n;
+    for (int q = 0; q < MTW; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[(size_t)r * DENSE_NP] = acc[i][r];
-    }
+        for (int i = 0; i < 7; ++i) {
+            if (i == 6 && odd) continue;
+            float *dst = part + ((size_t)split * n_rows_pad + row0 + (mg * MTW + q) * 16 + 4 * g) * DENSE_NP + (nt0 + i) * 16 + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(size_t)r * DENSE_NP] = acc[q][i][r];
+        }
 }
 
 template <int KTOT>
@@ -1731,7 +1776,9 @@ static int dense1_launch(const float *f3, int64_t np, const void *wd1x, float *p
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)k_enc_dense1<KTOT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, D1_LDS_BYTES(3));
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)k_enc_dense1p<KTOT>, hipFuncAttributeMaxDynamicSharedMemorySize, D1P_LDS_BYTES);
+            e = hipFuncSetAttribute((const void *)k_enc_dense1p<KTOT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, D1P_LDS_BYTES(1));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)k_enc_dense1p<KTOT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, D1P_LDS_BYTES(2));
         return e;
     }();
     CAELO_HIP(attr);
@@ -1746,10 +1793,15 @@ static int dense1_launch(const float *f3, int64_t np, const void *wd1x, float *p
     } else {
         dim3 gd((unsigned)(np / 64), D1_SPLIT_OF(KTOT));
         static const bool plain = getenv("CAELO_D1_PLAIN") && atoi(getenv("CAELO_D1_PLAIN")) > 0;  // the older kernel (bit-identical)
+        static const int64_t wide_from = getenv("CAELO_D1_WIDE_FROM") ? atoll(getenv("CAELO_D1_WIDE_FROM")) : 4 * 3072;  // rows
         if (plain)
             k_enc_dense1<KTOT, 1><<<gd, D1_THREADS, D1_LDS_BYTES(1), s>>>(f3, np, (const uint4 *)wd1x, part, in);
-        else
-            k_enc_dense1p<KTOT><<<gd, D1_THREADS, D1P_LDS_BYTES, s>>>(f3, np, (const uint4 *)wd1x, part, in);
+        else if (np % 128 == 0 && np >= wide_from) {
+            // 128-row tiles once the launch fills the chip with them (half the weight stream); same partial sums
+            dim3 gw((unsigned)(np / 128), D1_SPLIT_OF(KTOT));
+            k_enc_dense1p<KTOT, 2><<<gw, D1_THREADS, D1P_LDS_BYTES(2), s>>>(f3, np, (const uint4 *)wd1x, part, in);
+        } else
+            k_enc_dense1p<KTOT, 1><<<gd, D1_THREADS, D1P_LDS_BYTES(1), s>>>(f3, np, (const uint4 *)wd1x, part, in);
     }
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;

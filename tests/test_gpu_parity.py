@@ -916,11 +916,12 @@ for i in range(2):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"CAELO_ENC_WAVE": "1"}, {"CAELO_ENC_SPLIT": "1"}, {"CAELO_D1_PLAIN": "1"}])
+@pytest.mark.parametrize("env", [{"CAELO_ENC_WAVE": "1"}, {"CAELO_ENC_SPLIT": "1"}, {"CAELO_D1_PLAIN": "1"}, {"CAELO_D1_WIDE_FROM": "1"}])
 def test_stage1_variants_are_bit_identical(engine, env):
     """k_enc_stage1w (a patch per wavefront) and the two-kernel variant (k_enc_conv1 + k_enc_conv2) promise the default kernel's
     P2 bit for bit (same sums in the same order), and k_enc_dense1 (two barriers per stage) the partial sums of the software-
-    pipelined k_enc_dense1p (the default): the frame rows (descriptors + key points) of two scans, hashed in a process
+    pipelined k_enc_dense1p (the default), whose 128-row instance (CAELO_D1_WIDE_FROM=1: also for one frame) must equal the 64-row
+    one: the frame rows (descriptors + key points) of two scans, hashed in a process
     that runs the variant, equal this process's."""
     import hashlib
     import subprocess
