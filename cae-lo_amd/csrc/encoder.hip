@@ -1782,26 +1782,23 @@ static int dense1_launch(const float *f3, int64_t np, const void *wd1x, float *p
         return e;
     }();
     CAELO_HIP(attr);
-    // 64-row tiles for K = 2048 (8 stages per workgroup; measured 1 % ahead of 192-row tiles inside the frame
-    // pipeline although 15 % behind in isolation); 192-row tiles for the long-K instance, where the weight stream
-    // from L2 would otherwise bound the kernel
-    static const int force = getenv("CAELO_D1_MTW") ? atoi(getenv("CAELO_D1_MTW")) : 0;
-    const bool big = force ? force == 3 : KTOT > 2048;
-    if (big && np % 192 == 0) {
+    // CAELO_D1_PLAIN=1: the round-1 kernels (two barriers per stage; 192-row tiles for the long-K instance) -- bit-identical
+    static const bool plain = getenv("CAELO_D1_PLAIN") && atoi(getenv("CAELO_D1_PLAIN")) > 0;
+    static const int64_t wide_from = getenv("CAELO_D1_WIDE_FROM") ? atoll(getenv("CAELO_D1_WIDE_FROM")) : 4 * 3072;  // rows
+    if (plain && KTOT > 2048 && np % 192 == 0) {
         dim3 gd((unsigned)(np / 192), D1_SPLIT_OF(KTOT));
         k_enc_dense1<KTOT, 3><<<gd, D1_THREADS, D1_LDS_BYTES(3), s>>>(f3, np, (const uint4 *)wd1x, part, in);
+    } else if (plain) {
+        dim3 gd((unsigned)(np / 64), D1_SPLIT_OF(KTOT));
+        k_enc_dense1<KTOT, 1><<<gd, D1_THREADS, D1_LDS_BYTES(1), s>>>(f3, np, (const uint4 *)wd1x, part, in);
+    } else if (np % 128 == 0 && (np >= wide_from || KTOT > 2048)) {
+        // 128-row tiles once the launch fills the chip with them, and always for the long-K instance (8 k slices per row tile):
+        // half the weight stream; same partial sums
+        dim3 gw((unsigned)(np / 128), D1_SPLIT_OF(KTOT));
+        k_enc_dense1p<KTOT, 2><<<gw, D1_THREADS, D1P_LDS_BYTES(2), s>>>(f3, np, (const uint4 *)wd1x, part, in);
     } else {
         dim3 gd((unsigned)(np / 64), D1_SPLIT_OF(KTOT));
-        static const bool plain = getenv("CAELO_D1_PLAIN") && atoi(getenv("CAELO_D1_PLAIN")) > 0;  // the older kernel (bit-identical)
-        static const int64_t wide_from = getenv("CAELO_D1_WIDE_FROM") ? atoll(getenv("CAELO_D1_WIDE_FROM")) : 4 * 3072;  // rows
-        if (plain)
-            k_enc_dense1<KTOT, 1><<<gd, D1_THREADS, D1_LDS_BYTES(1), s>>>(f3, np, (const uint4 *)wd1x, part, in);
-        else if (np % 128 == 0 && np >= wide_from) {
-            // 128-row tiles once the launch fills the chip with them (half the weight stream); same partial sums
-            dim3 gw((unsigned)(np / 128), D1_SPLIT_OF(KTOT));
-            k_enc_dense1p<KTOT, 2><<<gw, D1_THREADS, D1P_LDS_BYTES(2), s>>>(f3, np, (const uint4 *)wd1x, part, in);
-        } else
-            k_enc_dense1p<KTOT, 1><<<gd, D1_THREADS, D1P_LDS_BYTES(1), s>>>(f3, np, (const uint4 *)wd1x, part, in);
+        k_enc_dense1p<KTOT, 1><<<gd, D1_THREADS, D1P_LDS_BYTES(1), s>>>(f3, np, (const uint4 *)wd1x, part, in);
     }
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
