@@ -155,7 +155,7 @@ class Pipeline:
         out = out or FrameBatch(eng, k)
         assert out.k >= k and (not pairs or len(rands) >= k)
         stream = eng.stream
-        _ffi.check(lib.caelo_pipeline_expect(self.h, k))   # the partial batch first (see caelo.h)
+        _ffi.check(lib.caelo_pipeline_expect(self.h, k))   # an even batch plan for runs that are not whole batches (caelo.h)
         _ffi.check(lib.caelo_pipeline_begin(self.h, stream))
         job = _ffi.FrameJob()
         job.dist_channels, job.mode = int(dist_channels), (1 if exact_voxels else 0) | (0 if dedup else 2)

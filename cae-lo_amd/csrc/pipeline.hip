@@ -53,7 +53,7 @@ struct caelo_pipeline {
     std::vector<caelo_frame_job> pending;
     uint64_t n_batches = 0, submitted = 0;
     int since_begin = 0;  // batches issued since caelo_pipeline_begin
-    int first_batch = 0;  // size of the first batch of the next run (caelo_pipeline_expect), 0 = a full one
+    std::vector<int> plan;  // batch sizes of the next run (caelo_pipeline_expect); empty or used up = full batches
     bool have_last = false;
     caelo_frame_job last = {};
     int64_t stat_jobs = 0, stat_issue_ns = 0, stat_batches = 0;
@@ -126,7 +126,6 @@ int issue_batch(caelo_pipeline *p) {
     p->stat_jobs += n;
     p->stat_batches += 1;
     p->since_begin += 1;
-    p->first_batch = 0;
     p->pending.clear();
     const int64_t t3 = now_ns();
     p->stat_issue_ns += t3 - t0;
@@ -264,13 +263,18 @@ CAELO_API int caelo_pipeline_begin(caelo_pipeline *p, void *stream) {
     return CAELO_OK;
 }
 
-// A run whose length is not a multiple of the batch size has one partial batch; nothing overlaps the front stage of the FIRST
-// batch (the encoder, the critical resource, idles meanwhile), so that is where the short one belongs: 20 frames as 4 + 8 + 8
-// instead of 8 + 8 + 4 is 7.9 -> 8.2 k frames/s.  (A short first batch on top of full ones -- 2 + 8 + 8 + 2 -- costs more in
-// launch sets than it gains: 7.7 k.)  Without the hint every batch is full and the remainder goes last.
+// A run whose length is not a multiple of the batch size: nothing overlaps the front stage of the FIRST batch (the encoder, the
+// critical resource, idles meanwhile) nor the encoder + pair stages of the LAST one, so neither should be the odd one out.  The
+// hint spreads the frames evenly over ceil(n / batch) batches, the smaller ones first: 20 frames go 6 + 7 + 7 (9.8 k frames/s;
+// 4 + 8 + 8: 9.5 k; 8 + 8 + 4: 9.5 k; 4 x 5: 9.0 k; 2 + 8 + 8 + 2 costs more in launch sets than it gains).  Without the hint
+// every batch is full and the remainder goes last.  Results do not depend on the plan (tests/test_gpu_parity.py).
 CAELO_API int caelo_pipeline_expect(caelo_pipeline *p, int64_t n_frames) {
     CAELO_REQUIRE(p && n_frames >= 0, "bad argument");
-    p->first_batch = (int)(n_frames % p->batch);
+    p->plan.clear();
+    if (n_frames > 0 && n_frames % p->batch != 0) {
+        const int64_t k = (n_frames + p->batch - 1) / p->batch, base = n_frames / k, extra = n_frames % k;
+        for (int64_t i = 0; i < k; ++i) p->plan.push_back((int)(base + (i >= k - extra ? 1 : 0)));
+    }
     return CAELO_OK;
 }
 
@@ -292,7 +296,21 @@ CAELO_API int caelo_pipeline_submit(caelo_pipeline *p, const caelo_frame_job *jo
     }
     p->pending.push_back(*job);
     ++p->submitted;
-    const int target = (p->since_begin == 0 && p->first_batch > 0) ? p->first_batch : p->batch;
+    int target = p->since_begin < (int)p->plan.size() ? p->plan[p->since_begin] : p->batch;
+    {   // CAELO_PIPE_PLAN="4,6,6,4": explicit batch sizes since begin (experiments on short runs); full batches after the list
+        static const std::vector<int> env_plan = [] {
+            std::vector<int> v;
+            const char *e = getenv("CAELO_PIPE_PLAN");
+            while (e && *e) {
+                v.push_back(atoi(e));
+                while (*e && *e != ',') ++e;
+                if (*e == ',') ++e;
+            }
+            return v;
+        }();
+        if (p->since_begin < (int)env_plan.size() && env_plan[p->since_begin] >= 1 && env_plan[p->since_begin] <= p->batch)
+            target = env_plan[p->since_begin];
+    }
     if ((int)p->pending.size() >= target) return issue_batch(p);
     return CAELO_OK;
 }
@@ -301,6 +319,7 @@ CAELO_API int caelo_pipeline_flush(caelo_pipeline *p, void *stream) {
     CAELO_REQUIRE(p, "null argument");
     int rc = issue_batch(p);  // a partial last batch
     p->pending.clear();       // after a failure nothing of the batch is kept
+    p->plan.clear();          // the hint of caelo_pipeline_expect holds for one run
     hipStream_t ss[3] = {p->sF, p->sE, p->sP};
     for (int i = 0; i < 3; ++i) {
         CAELO_HIP(hipEventRecord(p->joined[i], ss[i]));

@@ -312,8 +312,10 @@ int caelo_pipeline_submit(caelo_pipeline *pipe, const caelo_frame_job *job);
 int caelo_pipeline_flush(caelo_pipeline *pipe, void *stream);
 /* host-side counters since the last call (then reset): out_host[6] = jobs, ns the calling thread spent issuing their
  * launches, batches launched, batch size, hand-off buffers, HIP streams used */
-/* Optional hint before caelo_pipeline_begin: the run will submit n_frames jobs.  The partial batch (n_frames % batch) is then
- * issued FIRST instead of last -- nothing can overlap the first batch's front stage, so a short one starts the encoder sooner. */
+/* Optional hint before caelo_pipeline_begin: the run will submit n_frames jobs.  If that is not a multiple of the batch size, the
+ * frames are spread evenly over ceil(n_frames / batch) batches (20 on batch 8: 6 + 7 + 7) instead of full batches and a
+ * remainder -- nothing overlaps the first batch's front stage nor the last batch's encoder + pair stages, so neither should be
+ * the odd one out.  The hint holds for one run (cleared by caelo_pipeline_flush); results do not depend on it. */
 int caelo_pipeline_expect(caelo_pipeline *pipe, int64_t n_frames);
 int caelo_pipeline_stats(caelo_pipeline *pipe, int64_t *out_host);
 

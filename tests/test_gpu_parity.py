@@ -942,7 +942,7 @@ def test_stage1_variants_are_bit_identical(engine, env):
 
 @pytest.mark.gpu
 def test_pipeline_batch_plan_does_not_change_results(engine, scans):
-    """caelo_pipeline_expect moves the partial batch of a run to the front (20 frames on batch 8: 4 + 8 + 8); every frame and
+    """caelo_pipeline_expect spreads a run that is not a whole number of batches evenly (20 frames on batch 8: 6 + 7 + 7); every frame and
     every pair must come out as from full batches with the remainder last, and the hardware self-check stays at 0."""
     import ctypes as C
     import torch
