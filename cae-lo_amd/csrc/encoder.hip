@@ -1571,10 +1571,23 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1p(const float *__re
     constexpr int PER_STAGE = 5 + MTW;  // loads a thread has in flight per stage: five DMA pieces + its rows
     static_assert(MTW == 1 || MTW == 2, "two instances");
     static_assert(NKS % 2 == 0 && NKS >= 6, "stages are unrolled in pairs, the last ones peeled");
-    if (in.dedup) {  // a row tile past the frame's distinct patches holds nothing (tiles never straddle frames)
-        const int64_t r0 = (int64_t)blockIdx.x * BM;
-        const int f = (int)(r0 / in.per_frame);
-        if (r0 - (int64_t)f * in.per_frame >= enc_tables(in, f)->count) return;
+    // workgroup -> (row tile, k slice).  De-duplicated launch: only the tiles that hold distinct patches of their frame do work
+    // (tiles never straddle frames), and they are numbered FIRST: with one workgroup per CU (LDS) an idle workgroup in the
+    // middle of the dispatch order still waits for a whole CU to drain before it can start and exit (96 us for the 62 %
+    // of a launch's tiles that are live, against 111 us for all of them, when the idle ones sat where their rows are).
+    int64_t row0 = (int64_t)blockIdx.x * BM;
+    int split = blockIdx.y;
+    if (in.dedup) {
+        const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+        int t = lin / D1_SPLIT_OF(KTOT), f = 0;
+        split = lin - t * D1_SPLIT_OF(KTOT);
+        for (; f < in.n_frames; ++f) {
+            const int live = (enc_tables(in, f)->count + BM - 1) / BM;
+            if (t < live) break;
+            t -= live;
+        }
+        if (f == in.n_frames) return;
+        row0 = (int64_t)f * in.per_frame + (int64_t)t * BM;
     }
     extern __shared__ uint4 d1_lds[];
     uint4 *As = d1_lds;            // [2][split][g][row]
@@ -1582,8 +1595,6 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1p(const float *__re
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, n = lane & 15;
-    const int64_t row0 = (int64_t)blockIdx.x * BM;
-    const int split = blockIdx.y;
     const int ks0 = split * NKS;
     const int mg = wave >> 1;          // rows mg * 16 MTW ... of the tile
     const bool odd = (wave & 1) != 0;  // n-tiles 7..12 (6 of them) instead of 0..6

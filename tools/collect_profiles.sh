@@ -44,6 +44,10 @@ for w in 0 1; do
   rm -rf /tmp/rls; CAELO_ENC_WAVE=$w timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rls -o rl -- python $R/tools/roofline_launch.py 20 > /dev/null 2>&1
   python $R/tools/prof_summary.py /tmp/rls/rl_results.db 2>&1 | grep k_enc_stage1 | head -1 >> $O/pmc_stage1_variants.txt
 done
+# Dense(200): SQ counters of the pipelined kernel and of the round-1 kernel (CAELO_D1_PLAIN=1) on the 8-frame launch, and the
+# HIP-event table of the four encoder kernels for 1 / 8 frames per launch
+bash $R/tools/pmc_dense1.sh > /dev/null 2>&1; cp $R/gpurun_out/d1pmc.txt $O/pmc_dense1.txt
+( py $R/tools/enc_table.py 2>&1 | tail -2; echo "CAELO_D1_PLAIN=1:"; CAELO_D1_PLAIN=1 py $R/tools/enc_table.py 2>&1 | tail -2 ) > $O/enc_table.txt
 # the pair stage under three streams: the shipped library, and one built WITH packed-f32 instructions (if present)
 ( cd $R && timeout 300 python tools/stress_pairs.py 12 2>&1 | tail -1 ) > $O/stress_pairs.txt
 if [ -f $R/tools/_variant_packed_f32.so ]; then
