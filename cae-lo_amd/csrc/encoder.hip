@@ -1802,7 +1802,7 @@ static int dense1_launch(const float *f3, int64_t np, const void *wd1x, float *p
     } else if (plain) {
         dim3 gd((unsigned)(np / 64), D1_SPLIT_OF(KTOT));
         k_enc_dense1<KTOT, 1><<<gd, D1_THREADS, D1_LDS_BYTES(1), s>>>(f3, np, (const uint4 *)wd1x, part, in);
-    } else if (np % 128 == 0 && (np >= wide_from || KTOT > 2048)) {
+    } else if (np % 128 == 0 && (!in.dedup || in.per_frame % 128 == 0) && (np >= wide_from || KTOT > 2048)) {  // (tiles never straddle frames)
         // 128-row tiles once the launch fills the chip with them, and always for the long-K instance (8 k slices per row tile):
         // half the weight stream; same partial sums
         dim3 gw((unsigned)(np / 128), D1_SPLIT_OF(KTOT));
