@@ -140,11 +140,28 @@ def bench_dense128(args, eng, world, rank, backend, dev):
         dom = int(np.argmax(ms))
         table = {n: {"ms": round(float(m), 4), "f32_equiv_tflops": round(float(t), 2), "pipe_peak": round(pk, 1), "pipe_frac": round(float(t / pk), 4)}
                  for n, m, t, pk in zip(names, ms, tf, peaks)}
+        # matrix-pipe busy share by the hardware counters (separate rocprofv3 --pmc passes of the same 8-frame launch, committed):
+        # SQ_VALU_MFMA_BUSY_CYCLES summed over 1024 SIMDs against SQ_BUSY_CYCLES summed over 32 shader engines
+        pmc_busy = None
+        try:
+            cur, vals = None, {}
+            for line in open(os.path.join(REPO, "profiles", "r02_pmc_mfma_busy.txt")):
+                t = line.split()
+                if len(t) >= 1 and not line.startswith(" "):
+                    cur = line.strip().replace("void ", "").split("<")[0]
+                elif cur and len(t) >= 4 and t[0] in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES"):
+                    vals.setdefault(cur, {})[t[0]] = float(t[-1])
+            pmc_busy = {k: round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (v["SQ_BUSY_CYCLES"] / 32.0), 3) for k, v in vals.items()
+                        if len(v) == 2 and v["SQ_VALU_MFMA_BUSY_CYCLES"] > 0 and k in ("k_enc_stage1", "k_enc_conv3", "k_enc_dense1p", "k_enc_dense1")}
+            pmc_busy["source"] = "profiles/r02_pmc_mfma_busy.txt (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over SQ_BUSY_CYCLES / 32 SEs, 8-frame launch)"
+        except Exception:
+            pmc_busy = None
         roofline = {"bound": "mfma", "kernel": names[dom], "achieved": round(float(tf[dom]), 2), "peak": round(peaks[dom], 1),
                     "unit": "TFLOP/s", "frac": round(float(tf[dom] / peaks[dom]), 4), "traffic": None,
                     "launch_ms": round(float(ms[dom]), 4),
                     "achieved_is": "dense (= executed: these kernels skip nothing) f32-equivalent FLOPs of the layer / launch time, "
                                    "against the bf16 matrix peak / 6 (six bf16 MFMAs per f32 product block, DESIGN.md 4.6)",
+                    "mfma_busy_pmc": pmc_busy,
                     "encoder_kernels": table, "encoder_total_ms": round(float(ms.sum()), 4),
                     "encoder_total_f32_equiv_tflops": round(float(flops.sum() / (ms.sum() * 1e-3) / 1e12), 2)}
         cpu = None
