@@ -191,10 +191,13 @@ CAELO_API int caelo_pipeline_create(caelo_ctx *c, int batch, int n_buffers, int6
         // highest priority, so that conv3 / Dense(200) / the head are handed CUs first (12.3 -> 12.5 k frames/s; CAELO_PIPE_ENC_PRIO=0
         // turns it off)
         int lo = 0, hi = 0;
-        if (!(getenv("CAELO_PIPE_ENC_PRIO") && atoi(getenv("CAELO_PIPE_ENC_PRIO")) == 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
-            hip_ok(hipStreamCreateWithPriority(&p->sE, hipStreamNonBlocking, hi), "hipStreamCreate");
-        else
+        const bool want = !(getenv("CAELO_PIPE_ENC_PRIO") && atoi(getenv("CAELO_PIPE_ENC_PRIO")) == 0);
+        if (!want || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&p->sE, hipStreamNonBlocking, hi) != hipSuccess) {
+            (void)hipGetLastError();  // a runtime without stream priorities: an ordinary stream, nothing else changes
+            p->sE = nullptr;
             hip_ok(hipStreamCreateWithFlags(&p->sE, hipStreamNonBlocking), "hipStreamCreate");
+        }
     }
     else p->sE = p->sF;
     // (the pair stream at the highest or lowest priority was tried: 10.59 / 10.60 k frames/s against 10.57 k, and k_match_mfma
