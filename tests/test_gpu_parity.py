@@ -967,6 +967,28 @@ def test_pipeline_batch_plan_does_not_change_results(engine, scans):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n, batches", [(9, 2), (17, 3), (8, 1), (3, 1)])
+def test_pipeline_even_plan_small_runs(engine, scans, n, batches):
+    """Run lengths around the batch size: caelo_pipeline_expect plans ceil(n / 8) batches of near-equal size (9 -> 4 + 5, 17 -> 5 + 6 + 6);
+    every frame's rows equal a plain extract of the same scan, every pose the plain match_pose of the same pair."""
+    import torch
+    from caelo.engine import Pipeline, ransac_draws
+    pcs = [torch.from_numpy(scans(i, quantum=1e-3)).to(engine.device) for i in range(3)]
+    rnd = [torch.from_numpy(ransac_draws(40 + i)).to(engine.device) for i in range(3)]
+    plain = [engine.extract(p) for p in pcs]
+    pipe = Pipeline(engine, 8, 3)
+    out = pipe.run([pcs[i % 3] for i in range(n)], [rnd[i % 3] for i in range(n)], prev=plain[2])
+    torch.cuda.synchronize()
+    st = pipe.stats()
+    assert st["jobs"] == n and st["batches"] == batches
+    for i in range(n):
+        assert torch.equal(out.rows[i], plain[i % 3].rows)
+        want = engine.match_pose(plain[(i - 1) % 3], plain[i % 3], rnd[i % 3])
+        assert torch.equal(out.result[i], want[0]) and torch.equal(out.inlier_mask[i], want[1])
+    assert engine.lane_faults() == 0
+
+
+@pytest.mark.gpu
 def test_match_shape_sweep_vs_oracle(engine, orc):
     """The round-2 match kernel tiles frame 1 in blocks of 32 columns and frame 0 in steps of 128 rows, two column tiles
     x four row quarters per workgroup: every remainder class of both, descriptor widths that are / are not multiples of 4
