@@ -1309,8 +1309,16 @@ __global__ void __launch_bounds__(256, 2) k_enc_conv3(const float *__restrict__ 
             pre1 = q_[1];                                                                        \
         }                                                                                        \
     }
+#ifdef CAELO_ENC_PROF
+    unsigned long long c3_t[4] = {0ull, 0ull, 0ull, 0ull};
+    unsigned c3_prev = (unsigned)clock64();
+#define C3_STAMP(i) do { if (tid == 0) { const unsigned t_ = (unsigned)clock64(); c3_t[i] += t_ - c3_prev; c3_prev = t_; } } while (0)
+#else
+#define C3_STAMP(i) do { } while (0)
+#endif
     C3_FETCH((int)blockIdx.x)
     for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+        C3_STAMP(3);
         {   // split the staged 8 channels into the three bf16 terms: 3 x 16 B into LDS
             const float v[8] = {pre0.x, pre0.y, pre0.z, pre0.w, pre1.x, pre1.y, pre1.z, pre1.w};
             uint32_t h[4], m[4], l[4];
@@ -1321,7 +1329,9 @@ __global__ void __launch_bounds__(256, 2) k_enc_conv3(const float *__restrict__ 
             d[C3X_SPLIT] = make_uint4(m[0], m[1], m[2], m[3]);
             d[2 * C3X_SPLIT] = make_uint4(l[0], l[1], l[2], l[3]);
         }
+        C3_STAMP(0);
         __syncthreads();
+        C3_STAMP(1);
         C3_FETCH(pair + (int)gridDim.x)
         const int item = pair * 2 + slot;
         int patch;
@@ -1367,8 +1377,15 @@ __global__ void __launch_bounds__(256, 2) k_enc_conv3(const float *__restrict__ 
                     for (int r = 0; r < 4; ++r) dst[(((2 * round + j) * 4 + g) * 4 + r) * 32] = enc_tanh(acc[j][r]);
             }
         }
+        C3_STAMP(2);
         __syncthreads();
     }
+#ifdef CAELO_ENC_PROF
+    if (tid == 0) {
+        for (int i = 0; i < 4; ++i) atomicAdd(&g_enc_stamp[8 + i], c3_t[i]);
+        atomicAdd(&g_enc_stamp[12], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
