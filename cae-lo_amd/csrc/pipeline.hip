@@ -318,6 +318,15 @@ CAELO_API int caelo_pipeline_submit(caelo_pipeline *p, const caelo_frame_job *jo
     return CAELO_OK;
 }
 
+CAELO_API int caelo_pipeline_submit_many(caelo_pipeline *p, const caelo_frame_job *jobs, int64_t n) {
+    CAELO_REQUIRE(p && (jobs || n == 0) && n >= 0, "bad argument");
+    for (int64_t i = 0; i < n; ++i) {
+        const int rc = caelo_pipeline_submit(p, jobs + i);
+        if (rc) return rc;
+    }
+    return CAELO_OK;
+}
+
 CAELO_API int caelo_pipeline_flush(caelo_pipeline *p, void *stream) {
     CAELO_REQUIRE(p, "null argument");
     int rc = issue_batch(p);  // a partial last batch

@@ -309,6 +309,9 @@ void caelo_pipeline_destroy(caelo_pipeline *pipe);
 int caelo_pipeline_batch(const caelo_pipeline *pipe);
 int caelo_pipeline_begin(caelo_pipeline *pipe, void *stream);
 int caelo_pipeline_submit(caelo_pipeline *pipe, const caelo_frame_job *job);
+/* n jobs in one call (the same as n caelo_pipeline_submit calls in order; stops at the first error): a host language with a
+ * costly foreign-call path (ctypes: ~10 us per call) hands a whole run over at once -- the odometry loop of PoseEstimation.py:241-267. */
+int caelo_pipeline_submit_many(caelo_pipeline *pipe, const caelo_frame_job *jobs, int64_t n);
 int caelo_pipeline_flush(caelo_pipeline *pipe, void *stream);
 /* host-side counters since the last call (then reset): out_host[6] = jobs, ns the calling thread spent issuing their
  * launches, batches launched, batch size, hand-off buffers, HIP streams used */
