@@ -36,6 +36,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from caelo import synth  # noqa: E402
+import caelo  # noqa: E402
+caelo.configure_runtime()  # before the first device call: 8 hardware queues, so that the pipeline's fourth stream gets its own
 from caelo import dist as cdist  # noqa: E402
 from caelo.engine import Engine, FrameBatch, FrameFeatures, ransac_draws  # noqa: E402
 

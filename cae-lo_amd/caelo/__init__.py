@@ -13,17 +13,29 @@ import importlib
 import os
 import sys
 
-# The frame pipeline overlaps four HIP streams when the runtime has hardware queues for them: ROCclr deals streams onto
-# GPU_MAX_HW_QUEUES queues (default 4, one of which the default stream holds) and reads the variable when HIP initialises, which
-# happens at the first device call -- after this import in every entry point of the repository.  Respecting a value the user set.
-_torch = sys.modules.get("torch")
-if "GPU_MAX_HW_QUEUES" not in os.environ and not (_torch is not None and _torch.cuda.is_initialized()):
-    os.environ["GPU_MAX_HW_QUEUES"] = "8"   # (left alone when HIP is already up: the pipeline then stays on three streams)
+def configure_runtime(hw_queues=8):
+    """Opt in to the pipeline's fourth stream (voxel maps beside the key-point chain).
 
-__all__ = ["api", "engine", "dist", "h5lite", "synth", "_ffi"]
+    ROCclr deals HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable once, when HIP
+    initialises at the first device call.  An entry point that owns its process (bench.py, run_sequence.py, the test
+    session) calls this BEFORE touching the GPU; a library user who imports caelo into a bigger application decides for
+    himself -- importing caelo never changes the environment.  Returns True when the variable is in effect for this
+    process (set here or by the user to >= hw_queues), False when HIP was already up (three streams then; the pipeline
+    reports what it runs with through caelo_pipeline_stats)."""
+    cur = os.environ.get("GPU_MAX_HW_QUEUES")
+    if cur is not None:
+        return int(cur) >= hw_queues
+    torch_mod = sys.modules.get("torch")
+    if torch_mod is not None and torch_mod.cuda.is_initialized():
+        return False
+    os.environ["GPU_MAX_HW_QUEUES"] = str(hw_queues)
+    return True
+
+
+__all__ = ["api", "engine", "dist", "h5lite", "synth", "_ffi", "configure_runtime"]
 
 
 def __getattr__(name):
-    if name in __all__:
+    if name in __all__ and name != "configure_runtime":
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

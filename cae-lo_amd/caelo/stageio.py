@@ -44,28 +44,33 @@ def read_poses(path):
     return np.loadtxt(path, dtype=np.float64).reshape(-1, 12)
 
 
+def _homogeneous(m34):
+    """[3,4] -> [4,4] float32 rigid transform."""
+    h = np.eye(4, dtype=np.float32)
+    h[:3, :] = m34
+    return h
+
+
 def chain_poses(rel_rt, Tr=None):
-    """PoseEstimation.py:230-267: prefix product of per-pair LiDAR motions into camera-frame KITTI
-    poses [F,12].  rel_rt [F-1,12] (R row-major | T); Tr [3,4] calibration (identity if None).
-    float32 end to end, like the reference (Tr, SolveRT's R/T and pose0 are all float32 there)."""
-    rel = np.asarray(rel_rt, dtype=np.float32).reshape(-1, 12)
-    Tr = np.c_[np.eye(3), np.zeros(3)] if Tr is None else np.asarray(Tr)
-    Tr = np.array(Tr.reshape(3, 4), dtype=np.float32)                       # :203
-    R_Tr = Tr[:, 0:3]
-    R_Tr_inv = np.linalg.inv(R_Tr)                                          # :205
-    T_Tr = Tr[:, 3].reshape(3, 1)
-    T_Tr_inv = -np.dot(R_Tr_inv, T_Tr)                                      # :207
-    poses = [np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float32).reshape(12, 1)]  # :232
-    for row in rel:
-        relativeR, relativeT = row[:9].reshape(3, 3), row[9:].reshape(3, 1)
-        pose0 = poses[-1].reshape(3, 4)                                     # Transformations.py:164-168
-        R0, T0 = pose0[:, 0:3], pose0[:, 3].reshape(3, 1)
-        R_poseDiff = np.dot(R_Tr, np.dot(relativeR, R_Tr_inv))             # :259
-        T_poseDiff = np.dot(R_Tr, np.dot(relativeR, T_Tr_inv) + relativeT) + T_Tr  # :260
-        R = np.dot(R0, R_poseDiff)                                          # :261
-        T = np.dot(R0, T_poseDiff) + T0                                     # :262
-        poses.append(np.c_[R, T].reshape((12, 1)))                          # :265-267
-    return np.array(poses, dtype=np.float32).reshape(len(poses), 12)       # :273-274
+    """Per-pair LiDAR motions [F-1,12] (R row-major | T) -> camera-frame KITTI poses [F,12], frame 0 = identity.
+
+    What PoseEstimation.py:230-267 computes, written as homogeneous 4x4 algebra: a LiDAR-frame motion M becomes
+    the camera-frame motion  C = Tr . M . Tr^-1  (calibration ``Tr`` [3,4], identity if None), and pose k+1 is
+    pose k . C_k.  float32 throughout, as the reference's arrays are."""
+    motions = np.asarray(rel_rt, dtype=np.float32).reshape(-1, 12)
+    calib = _homogeneous(np.eye(3, 4) if Tr is None else np.asarray(Tr, dtype=np.float32).reshape(3, 4))
+    calib_inv = np.eye(4, dtype=np.float32)
+    calib_inv[:3, :3] = np.linalg.inv(calib[:3, :3])
+    calib_inv[:3, 3] = -calib_inv[:3, :3] @ calib[:3, 3]
+    out = np.empty((len(motions) + 1, 12), dtype=np.float32)
+    pose = np.eye(4, dtype=np.float32)
+    out[0] = pose[:3].ravel()
+    for k, m in enumerate(motions):
+        lidar = _homogeneous(np.c_[m[:9].reshape(3, 3), m[9:]])
+        pose = pose @ (calib @ (lidar @ calib_inv))
+        pose[3] = (0.0, 0.0, 0.0, 1.0)
+        out[k + 1] = pose[:3].ravel()
+    return out
 
 
 # ---- .mat stage artefacts (8f-2) ------------------------------------------------------------------------

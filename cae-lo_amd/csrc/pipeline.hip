@@ -61,15 +61,17 @@ struct caelo_pipeline {
 
 namespace {
 
-int issue_batch(caelo_pipeline *p) {
+int issue_batch_impl(caelo_pipeline *p) {
     const int n = (int)p->pending.size();
     if (n == 0) return CAELO_OK;
+    // a batch never holds more frames than the pipeline has maps / workspaces for (a caller that kept submitting after a failed
+    // submit used to get here with batch + 1 pending jobs)
+    CAELO_REQUIRE(n <= p->batch && n <= CAELO_FB_MAX, "internal: more pending frames than the batch size");
     const int64_t t0 = now_ns();
-    const uint64_t k = p->n_batches++;
+    const uint64_t k = p->n_batches;
     const int nb = (int)(k % (uint64_t)p->n_buffers);
     const std::vector<caelo_frame_job> &jobs = p->pending;
-    // ---- front: the hand-off buffer is free once the encoder of batch k - n_buffers has read it
-    if (k >= (uint64_t)p->n_buffers) CAELO_HIP(hipStreamWaitEvent(p->sF, p->enc_done[nb], 0));
+    // every argument check comes before the first launch: a rejected batch leaves no trace (n_batches, events, buffers)
     caelo_extract_args xa[CAELO_FB_MAX];
     for (int i = 0; i < n; ++i) {
         const caelo_frame_job &j = jobs[i];
@@ -79,6 +81,9 @@ int issue_batch(caelo_pipeline *p) {
         const int rc = extract_check(xa[i]);
         if (rc) return rc;
     }
+    p->n_batches = k + 1;
+    // ---- front: the hand-off buffer is free once the encoder of batch k - n_buffers has read it
+    if (k >= (uint64_t)p->n_buffers) CAELO_HIP(hipStreamWaitEvent(p->sF, p->enc_done[nb], 0));
     int rc = extract_front_set(xa, n, p->sF, p->sV, p->vox_fork, p->vox_join);
     if (rc) return rc;
     CAELO_HIP(hipEventRecord(p->front_done[nb], p->sF));
@@ -132,6 +137,13 @@ int issue_batch(caelo_pipeline *p) {
     static const bool verbose = getenv("CAELO_PIPE_VERBOSE") != nullptr;
     if (verbose) fprintf(stderr, "batch %llu n=%d issue us: front %.1f enc %.1f pair %.1f\n", (unsigned long long)k, n, (t1 - t0) / 1e3, (t2 - t1) / 1e3, (t3 - t2) / 1e3);
     return CAELO_OK;
+}
+
+// Whatever happens, nothing of a batch is kept: a caller that logs an error and keeps submitting starts a fresh batch.
+int issue_batch(caelo_pipeline *p) {
+    const int rc = issue_batch_impl(p);
+    if (rc) p->pending.clear();
+    return rc;
 }
 
 }  // namespace

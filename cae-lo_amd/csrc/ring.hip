@@ -25,6 +25,10 @@ void caelo_set_error(const char *fmt, ...) {
 
 CAELO_API const char *caelo_last_error(void) { return g_err; }
 CAELO_API int caelo_abi_version(void) { return CAELO_ABI_VERSION; }
+#ifndef CAELO_BUILD_WORD  // csrc/Makefile always defines it; 0 = "not built by the Makefile", which caelo/_ffi.py refuses
+#define CAELO_BUILD_WORD 0
+#endif
+CAELO_API int caelo_build_flags(void) { return CAELO_BUILD_WORD; }
 
 CAELO_API int caelo_create(caelo_ctx **out, int device) {
     CAELO_REQUIRE(out != nullptr, "null ctx pointer");

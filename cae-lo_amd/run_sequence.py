@@ -27,6 +27,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from caelo import _ffi, stageio, synth  # noqa: E402
+import caelo  # noqa: E402
+caelo.configure_runtime()  # this script owns its process: ask for 8 hardware queues before HIP starts
 from caelo import dist as cdist  # noqa: E402
 from caelo.engine import Engine, FrameBatch, FrameFeatures, raise_status, ransac_draws  # noqa: E402
 

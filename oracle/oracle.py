@@ -430,14 +430,39 @@ def GetFeaturesFromPatches(PatchEncoder_, PatchesList):
                  PatchEncoder_.predict(PatchesList[2])]
 
 
+# What orc_respond / orc_encode restate (the .h5's model_config): (class, filters-or-units, kernel, activation).
+# Kept apart from caelo.keras_config on purpose: the checker must not lean on the package under test.
+_RESPOND_STACK = [("Conv2D", 32, [3, 3], "relu"), ("Conv2D", 8, [1, 1], "relu")]
+_ENCODER_STACK = [("Conv3D", 8, [3, 3, 3], "tanh"), ("MaxPooling3D", None, [2, 2, 2], None), ("Conv3D", 16, [3, 3, 3], "tanh"),
+                  ("MaxPooling3D", None, [2, 2, 2], None), ("Conv3D", 32, [3, 3, 3], "tanh"), ("Flatten", None, None, None),
+                  ("Dense", 200, None, "tanh"), ("Dense", 20, None, "tanh")]
+
+
+def _check_stack(h5, want):
+    import json
+    cfg = json.loads(h5.attrs("/")["model_config"].decode("utf8"))["config"]
+    got = []
+    for l in (cfg["layers"] if isinstance(cfg, dict) else cfg):
+        c = l["config"]
+        if l["class_name"] == "InputLayer":
+            continue
+        if l["class_name"].startswith("Conv") and (c["padding"] != "same" or list(c["strides"]) != [1] * len(c["strides"])
+                                                   or c.get("data_format", "channels_last") != "channels_last" or not c["use_bias"]):
+            raise ValueError("oracle: unsupported convolution %s" % c)
+        got.append((l["class_name"], c.get("filters", c.get("units")),
+                    list(c["kernel_size"]) if "kernel_size" in c else (list(c["pool_size"]) if "pool_size" in c else None),
+                    c.get("activation")))
+    if got != want:
+        raise ValueError("oracle: the .h5 holds %s, the restatement implements %s" % (got, want))
+
+
 def load_models(respond_h5, encoder_h5):
     """Read both Keras .h5 files (through caelo.h5lite -- file parsing only, no compute)."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(_HERE), "cae-lo_amd"))
-    from caelo.h5lite import H5File
-    from caelo import keras_config
-    for path, kind in ((respond_h5, "respond"), (encoder_h5, "encoder")):   # the restatement below IS this stack: refuse others
-        keras_config.check(keras_config.layers(path), kind)
+    from caelo.h5lite import H5File   # HDF5 container parsing only; the layer-stack check below is the oracle's own
+    for path, want in ((respond_h5, _RESPOND_STACK), (encoder_h5, _ENCODER_STACK)):   # the restatement IS this stack: refuse others
+        _check_stack(H5File(path), want)
     r = H5File(respond_h5)
     g = lambda h, l, n: h.dataset("/model_weights/%s/%s/%s:0" % (l, l, n))
     resp = RespondLayer(g(r, "conv2d_1", "kernel"), g(r, "conv2d_1", "bias"),

@@ -8,7 +8,8 @@ for p in (os.path.join(REPO, "cae-lo_amd"), os.path.join(REPO, "oracle"), REPO):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import caelo  # noqa: E402,F401  (first: it sets GPU_MAX_HW_QUEUES before anything can initialise HIP)
+import caelo  # noqa: E402  (before anything can initialise HIP)
+caelo.configure_runtime()  # the test session owns its process: four pipeline streams
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
 WEIGHTS = os.path.join(REPO, "weights")

@@ -3,6 +3,7 @@ import os, sys, json, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cae-lo_amd"))
 import torch
 from caelo import synth
+import caelo; caelo.configure_runtime()
 from caelo.engine import default_engine
 
 e = default_engine()

@@ -5,6 +5,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "cae-lo_amd"))
 import numpy as np, torch
 from caelo import synth
+import caelo; caelo.configure_runtime()
 from caelo.engine import Engine
 eng = Engine()
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 8

@@ -4,6 +4,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "cae-lo_amd"))
 import numpy as np, torch
 from caelo import synth
+import caelo; caelo.configure_runtime()
 from caelo.engine import Engine
 eng = Engine()
 pc = torch.from_numpy(synth.make_scan(0)).to(eng.device)

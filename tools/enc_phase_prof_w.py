@@ -5,6 +5,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "cae-lo_amd"))
 import numpy as np, torch
 from caelo import synth, _ffi
+import caelo; caelo.configure_runtime()
 from caelo.engine import Engine
 eng = Engine()
 pc = torch.from_numpy(synth.make_scan(0, quantum=1e-3)).to(eng.device)

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import torch
 from caelo import synth
+import caelo; caelo.configure_runtime()
 from caelo.engine import Engine
 
 eng = Engine()

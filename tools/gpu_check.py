@@ -16,6 +16,7 @@ import torch  # noqa: E402
 
 import oracle as orc  # noqa: E402
 from caelo import synth  # noqa: E402
+import caelo; caelo.configure_runtime()
 from caelo.engine import Engine, ransac_draws  # noqa: E402
 
 results = []

@@ -4,6 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cae-lo_amd"))
 import torch
 from caelo import synth
+import caelo; caelo.configure_runtime()
 from caelo.engine import Engine, Pipeline, FrameBatch, ransac_draws
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 20

@@ -5,6 +5,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "cae-lo_amd"))
 import torch
 from caelo import synth
+import caelo; caelo.configure_runtime()
 from caelo.engine import Engine, ransac_draws
 eng = Engine()
 pcs = [torch.from_numpy(synth.make_scan(i)).to(eng.device) for i in range(6)]

@@ -2,7 +2,7 @@
 single-call results, plus the library's lane-agreement counter (caelo_lane_faults).
 
     python tools/stress_pairs.py [reps]            # expected: 0 mismatching frames, 0 lane faults
-    CAELO_LIB=/path/to/variant.so python tools/stress_pairs.py
+    CAELO_ALLOW_PACKED_F32=1 CAELO_LIB=/path/to/variant.so python tools/stress_pairs.py     (the loader refuses a packed-f32 build otherwise)
 
 With a library built with packed-f32 instructions (`make -C cae-lo_amd/csrc PACKED_F32=1 BUILD=/tmp/pk OUT=/tmp/pk.so`)
 an MI355X shows ~1 faulty hypothesis wavefront per 1 000 and a wrong pose in ~1 frame of 600."""
@@ -11,6 +11,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "cae-lo_amd"))
 import torch
 from caelo import synth, _ffi
+import caelo; caelo.configure_runtime()
 from caelo.engine import Engine, Pipeline, ransac_draws
 
 eng = Engine()
