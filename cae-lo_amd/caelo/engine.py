@@ -440,6 +440,22 @@ class Engine:
         _ffi.check(self.lib.caelo_encode(self.ctx, _ptr(bits), n, group, _ptr(out), 20 * group, _ptr(ws), self.stream))
         return out
 
+    def encode_layers(self, bits):
+        """Test aid: encode (group 1, every patch) and return the activations the four encoder kernels leave in the
+        workspace -- P2 [n,1024] (after pool2), F3 [n,2048] (after conv3), the Dense(200) pre-activations summed over the
+        k slices [n,200] (bias not added) -- and the descriptors [n,20].  Workspace layout (encoder.hip,
+        encode_batch_impl): 2048-byte header | P2 [np][1024] | F3 [np][2048] | partial sums [8][np][208] f32,
+        np = n rounded up to 64; k slices in use: 4."""
+        n = bits.numel() // 64
+        out = self.encode(bits, 1)
+        ws = self._encode_ws(n)
+        np_ = (n + 63) // 64 * 64
+        f = ws[2048:].view(torch.float32)
+        p2 = f[:np_ * 1024].view(np_, 1024)[:n]
+        f3 = f[np_ * 1024:np_ * 3072].view(np_, 2048)[:n]
+        part = f[np_ * 3072:np_ * 3072 + 8 * np_ * 208].view(8, np_, 208)[:4, :n, :200].sum(dim=0)
+        return p2.clone(), f3.clone(), part, out
+
     # ---- BASELINE.json configs[4]: 32^3 patches (stress case, not a reference code path; csrc/config5.hip) -----
     @staticmethod
     def seeded_dense1_32(seed=5):
@@ -496,12 +512,12 @@ class Engine:
         return ff
 
     def encode_profile(self, bits, group=1):
-        """encode + per-kernel HIP-event timings (ms): stage1, conv3, dense1, head, then the conv2 MFMA instructions
-        stage 1 executed (millions).  Synchronises."""
+        """encode + per-kernel HIP-event timings (ms): stage1, conv3, dense1, head, then the MFMA instructions stage 1
+        executed (millions) and the FLOPs of one of them.  Synchronises."""
         n = bits.numel() // 64
         out = self.empty((n // group, 20 * group), torch.float32)
         ws = self._encode_ws(n)
-        ms = (C.c_float * 5)()
+        ms = (C.c_float * 6)()
         _ffi.check(self.lib.caelo_encode_profile(self.ctx, _ptr(bits), n, group, _ptr(out), 20 * group, _ptr(ws),
                                                  self.stream, C.cast(ms, C.c_void_p)))
         return out, list(ms)

@@ -52,6 +52,8 @@ struct caelo_ctx {
     float *enc_c0;   // [512][16] conv2 response of the all-background patch incl. bias, then bg[8]
     float *enc_w3;   // [27][16][32]
     float *enc_b3;   // [32]
+    void *enc_w1f;   // conv1 as k_enc_stage1x's B operand (w1 scattered over the 4^3 receptive field): [k-step 2][n-tile 4][f16 term 2][lane 64] x 16 B
+    void *enc_w2x;   // conv2 as k_enc_stage1x's B operand: [tap row 9][fragment 3][lane 64] x 16 B (f16 terms, enc_stage1x.inc)
     void *enc_w3x;   // W3 as the conv3 kernel's B operand: [ntile 2][tap pair 14][bf16 split 3][lane 64] x 16 B
     void *enc_wd1x;  // dense_1 as the dense-1 kernel's B operand: [k-step 64][bf16 split 3][n-tile 13][lane 64] x 16 B
     float *enc_bd1;  // [208]

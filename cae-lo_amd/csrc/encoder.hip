@@ -29,6 +29,7 @@
 
 #include "caelo_internal.h"
 #include <stdlib.h>
+#include <string.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -50,6 +51,7 @@ __device__ inline float enc_tanh(float x) {
 #define DENSE_K 2048
 #define C3X_NPAIR 14  // tap pairs of the conv3 kernel (see k_enc_conv3)
 static void conv3_split_weights(const float *w3, uint4 *out);
+static void stage1x_split_weights(const float *w1, const float *w2, uint4 *w1f, uint4 *w2x);
 int enc_upload_dense1(const float *wd1, const float *bd1, int K, void **wx_dev, float **bd_dev);
 
 CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const float *b1, const float *w2,
@@ -81,6 +83,17 @@ CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const flo
         for (int ch = 0; ch < 8; ++ch) c0[512 * 16 + ch] = bg[ch];
         if (!c->enc_c0) CAELO_HIP(hipMalloc(&c->enc_c0, sizeof(c0)));
         CAELO_HIP(hipMemcpy(c->enc_c0, c0, sizeof(c0), hipMemcpyHostToDevice));
+    }
+    {
+        const size_t n1 = 16 * 64, n2 = 27 * 64;  // S1X_W1F_U4, S1X_W2X_U4
+        uint4 *wx = (uint4 *)malloc((n1 + n2) * sizeof(uint4));
+        if (!wx) { caelo_set_error("out of host memory"); return CAELO_ERR_ARG; }
+        stage1x_split_weights(w1, w2, wx, wx + n1);
+        if (!c->enc_w1f) CAELO_HIP(hipMalloc(&c->enc_w1f, n1 * sizeof(uint4)));
+        if (!c->enc_w2x) CAELO_HIP(hipMalloc(&c->enc_w2x, n2 * sizeof(uint4)));
+        CAELO_HIP(hipMemcpy(c->enc_w1f, wx, n1 * sizeof(uint4), hipMemcpyHostToDevice));
+        CAELO_HIP(hipMemcpy(c->enc_w2x, wx + n1, n2 * sizeof(uint4), hipMemcpyHostToDevice));
+        free(wx);
     }
     {
         const size_t n = (size_t)2 * C3X_NPAIR * 3 * 64;
@@ -487,6 +500,8 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
         for (int i = 0; i < 8; ++i) atomicAdd(&g_enc_stamp[i], (unsigned long long)L.prof[i]);
 #endif
 }
+
+#include "enc_stage1x.inc"
 
 // ------------------------------------------------------------------------------------------------
 // stage 1, one WAVEFRONT per patch (round 2, CAELO_ENC_WAVE=1; not the default): no workgroup barrier after start-up
@@ -1993,6 +2008,15 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
             return 512;
         return per_cu * cus;
     }(c->device);
+    // CAELO_ENC_S1=f32 selects round 2's k_enc_stage1 (f32-input MFMAs, conv1 on the VALU) for comparison; default: k_enc_stage1x
+    static const bool stage1x = fused_stage1 && !wave_stage1 && !(getenv("CAELO_ENC_S1") && !strcmp(getenv("CAELO_ENC_S1"), "f32"));
+    static const int slots1x = [](int device) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_enc_stage1x<false>, 256, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || per_cu * cus <= 0)
+            return 512;
+        return per_cu * cus;
+    }(c->device);
     int *xcd_counters = (int *)((char *)ws + 1024);  // 8 x one 128-byte line
     static const int slots1 = [](int device) {
         int per_cu = 0, cus = 0;
@@ -2013,6 +2037,19 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
         const int64_t wgs = (n_patches + S1W_WAVES - 1) / S1W_WAVES;
         k_enc_stage1w<<<(unsigned)(wgs < capw ? wgs : capw), 64 * S1W_WAVES, 0, s>>>(ein, n_patches, order_group, xcd_counters, c->enc_w1, c->enc_b1,
                                                                                    c->enc_w2, c->enc_c0, p2);
+        CAELO_LAUNCH_CHECK();
+    } else if (stage1x) {
+        // round 3's default: conv1 on the matrix cores, f16 x 2 products, two 256-register workgroups per CU (enc_stage1x.inc)
+        const int64_t capx = (ein.yield & 1) ? (int64_t)slots1x * 4 / 5 : slots1x;
+        const unsigned gx = (unsigned)(n_patches < capx ? n_patches : capx);
+        if (ev) {   // profiling calls count the MFMAs the kernel executes (bench.py's roofline); same code otherwise
+            CAELO_HIP(hipMemsetAsync(mfma_count, 0, sizeof(unsigned long long), s));
+            CAELO_HIP(hipEventRecord(ev[0], s));
+            k_enc_stage1x<true><<<gx, 256, 0, s>>>(ein, n_patches, order_group, work_counter, (const uint4 *)c->enc_w1f, c->enc_b1,
+                                                   (const uint4 *)c->enc_w2x, c->enc_c0, p2, mfma_count);
+        } else
+            k_enc_stage1x<false><<<gx, 256, 0, s>>>(ein, n_patches, order_group, work_counter, (const uint4 *)c->enc_w1f, c->enc_b1,
+                                                    (const uint4 *)c->enc_w2x, c->enc_c0, p2, mfma_count);
         CAELO_LAUNCH_CHECK();
     } else if (fused_stage1) {
         k_enc_stage1<<<g1, 256, 0, s>>>(ein, n_patches, order_group, work_counter, c->enc_w1, c->enc_b1, c->enc_w2, c->enc_c0, p2);
@@ -2039,7 +2076,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
                                                                 group, outs, out_stride, ein);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[4], s));
-    if (ev && fused_stage1) {
+    if (ev && fused_stage1 && !stage1x) {
         // Profiling calls only, outside the timed events: how many conv2 MFMAs did stage 1 execute?  k_enc_stage1 has no
         // register left for a counter (168 VGPRs / 106 SGPRs at three workgroups per CU: counting cost 50 % of its time), so
         // the two-kernel variant -- the same rows, the same skipping rule, bit-identical P2 -- is run once more to count.
@@ -2090,7 +2127,10 @@ CAELO_API int caelo_encode_profile(caelo_ctx *c, const uint64_t *bits, int64_t n
         for (int i = 0; i < 4; ++i) CAELO_HIP(hipEventElapsedTime(&ms_host[i], ev[i], ev[i + 1]));
         unsigned long long rows = 0;  // conv2 tap rows executed (6 v_mfma_f32_16x16x4_f32 each), counted by the kernel itself
         CAELO_HIP(hipMemcpy(&rows, (char *)ws + 8, sizeof(rows), hipMemcpyDeviceToHost));
-        ms_host[4] = (float)((double)rows * 6.0 / 1e6);
+        // the f32 kernel counts tap rows (6 v_mfma_f32_16x16x4_f32 each), k_enc_stage1x its v_mfma_f32_16x16x32_f16 instructions
+        const bool f32_kernel = getenv("CAELO_ENC_S1") && !strcmp(getenv("CAELO_ENC_S1"), "f32");
+        ms_host[4] = (float)((double)rows * (f32_kernel ? 6.0 : 1.0) / 1e6);
+        ms_host[5] = f32_kernel ? 2.0f * 16 * 16 * 4 : 2.0f * 16 * 16 * 32;   // FLOPs of one counted instruction
     }
     for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ev[i]);
     return rc;

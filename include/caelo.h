@@ -171,8 +171,8 @@ int caelo_encode32_profile(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patch
 
 /* caelo_encode with a HIP event between its four kernels (stage1 = conv1+pool1+conv2+pool2, conv3,
  * dense1, head) on the launch stream; synchronises, writes the durations in ms to ms_host[0..3] and the number of
- * conv2 MFMA instructions stage 1 actually executed, in millions, to ms_host[4] (it skips all-background rows; the
- * dense count is n_patches x 1728).  ms_host holds 5 floats. */
+ * MFMA instructions stage 1 actually executed, in millions, to ms_host[4] (it skips all-background rows) and the FLOPs of
+ * one such instruction to ms_host[5] (16384: v_mfma_f32_16x16x32_f16; 2048: the f32-input kernel).  ms_host holds 6 floats. */
 int caelo_encode_profile(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches, int group, float *out,
                          int out_stride, void *ws, void *stream, float *ms_host);
 

@@ -434,8 +434,21 @@ static void maxpool2(const float *in, int D, int c, float *out) {
     }
 }
 
+static void encode_layers(const uint64_t *bits, int64_t n, const orc_enc_weights_t *W, float *out, int out_stride, int col0,
+                          float *p2_out, float *f3_out, float *h_out);
 ORC_EXPORT void orc_encode(const uint64_t *bits, int64_t n, const orc_enc_weights_t *W, float *out,
                            int out_stride, int col0) {
+    encode_layers(bits, n, W, out, out_stride, col0, NULL, NULL, NULL);
+}
+/* The same network with its intermediate activations written out (test aid: the per-layer error budget of the HIP
+ * encoder): p2 [n][4][4][4][16] after the second pooling, f3 [n][2048] after conv3's tanh (flatten order), h [n][200]
+ * after Dense(200)'s tanh.  Any of the three may be NULL. */
+ORC_EXPORT void orc_encode_layers(const uint64_t *bits, int64_t n, const orc_enc_weights_t *W, float *out, int out_stride,
+                                  float *p2_out, float *f3_out, float *h_out) {
+    encode_layers(bits, n, W, out, out_stride, 0, p2_out, f3_out, h_out);
+}
+static void encode_layers(const uint64_t *bits, int64_t n, const orc_enc_weights_t *W, float *out, int out_stride, int col0,
+                          float *p2_out, float *f3_out, float *h_out) {
 #pragma omp parallel
     {
         float *p0 = (float *)malloc(sizeof(float) * 4096);
@@ -461,6 +474,9 @@ ORC_EXPORT void orc_encode(const uint64_t *bits, int64_t n, const orc_enc_weight
                 for (int j = 0; j < 200; ++j) h[j] += v * row[j];
             }
             for (int j = 0; j < 200; ++j) h[j] = tanhf(h[j]);
+            if (p2_out) memcpy(p2_out + p * 1024, q2, sizeof(float) * 1024);
+            if (f3_out) memcpy(f3_out + p * 2048, a3, sizeof(float) * 2048);
+            if (h_out) memcpy(h_out + p * 200, h, sizeof(float) * 200);
             float *o = out + p * out_stride + col0;
             for (int j = 0; j < 20; ++j) {
                 float acc = W->bd2[j];

@@ -386,6 +386,15 @@ class PatchEncoder:
     def predict(self, patches):
         return self.predict_bits(pack_patches(patches))
 
+    def predict_layers(self, bits):
+        """-> (p2 [K,1024] after pool2, f3 [K,2048] after conv3, h [K,200] after Dense(200), out [K,20]): the activations
+        between the HIP encoder's kernels, for the per-layer error budget test."""
+        bits = np.ascontiguousarray(bits, dtype=np.uint64)
+        k = bits.shape[0]
+        p2, f3, h, out = (np.empty((k, d), dtype=np.float32) for d in (1024, 2048, 200, 20))
+        lib().orc_encode_layers(_p(bits), C.c_int64(k), C.byref(self._s), _p(out), C.c_int(20), _p(p2), _p(f3), _p(h))
+        return p2, f3, h, out
+
 
 # ---- BASELINE.json configs[4]: 32^3 patches (not a reference code path; see caelo_oracle.c) ----------
 def patches32_bits(Pts, AllVoxels, scale):
