@@ -96,7 +96,7 @@ CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const flo
         free(wx);
     }
     {
-        const size_t n = (size_t)2 * C3X_NPAIR * 3 * 64;
+        const size_t n = (size_t)2 * C3X_NPAIR * 3 * 64;   // (room for three terms; the f16 form fills two)
         uint4 *wx = (uint4 *)malloc(n * sizeof(uint4));
         if (!wx) { caelo_set_error("out of host memory"); return CAELO_ERR_ARG; }
         conv3_split_weights(w3, wx);
@@ -1216,7 +1216,15 @@ __global__ void __launch_bounds__(256, 3) k_enc_conv2(const caelo_enc_in in, int
 #define C3X_PLANE 48                 // positions per padded x plane (6 rows of 8)
 #define C3X_ARR 292                  // positions per (split, half) array: 288 used, = 4 mod 16 (bank rotation of half 1)
 #define C3X_SPLIT (2 * C3X_ARR)
-#define C3X_SLOT (3 * C3X_SPLIT)     // positions (x 16 B) per patch slot
+// Round 3: the f32 products of conv3 run as TWO f16 terms per operand (x = hi + lo, |x - hi - lo| <= 2^-22 |x|; the MFMA honours
+// f16 subnormals, tools/micro/f16_mfma_subnormal.hip) and three partial products hi hi + hi lo + lo hi -- 3 MFMAs per K = 32 slab
+// instead of the 6 of the 3-way bf16 split (C3X_F16=0, round 2), 112 instead of 168 B registers, two LDS planes instead of three.
+// The dropped lo lo term is 2^-22 relative; measured against the f32 oracle the descriptors do not move (tools/enc_layer_errors.py).
+#ifndef C3X_F16
+#define C3X_F16 1
+#endif
+#define C3X_NS (C3X_F16 ? 2 : 3)     // terms per operand
+#define C3X_SLOT (C3X_NS * C3X_SPLIT)     // positions (x 16 B) per patch slot
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // tap pairs (A, B): 9 x (kc 0,1) | 3 x (kb 0,1 at kc 2) | (ka 0,1 at kb 2, kc 2) | tap 26 alone
 __host__ __device__ constexpr int c3x_pairA(int p) { return p < 9 ? p * 3 : (p < 12 ? (p - 9) * 9 + 2 : (p == 12 ? 8 : 26)); }
@@ -1254,6 +1262,13 @@ __device__ inline void enc_split3_pk(float x0, float x1, uint32_t &hi, uint32_t 
     const float q0 = r0 - __uint_as_float(mid << 16), q1 = r1 - __uint_as_float(mid & 0xFFFF0000u);
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector((enc_f2){q0, q1}, enc_bf2));
 }
+// two values -> their f16 (hi, lo) terms, packed (value 0 in the low half); hi = RNE f16(x), lo = RNE f16(x - hi)
+__device__ inline void enc_split2h_pk(float x0, float x1, uint32_t &hi, uint32_t &lo) {
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+    hi = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+    lo = (uint32_t)__builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
+}
 #define ENC_PK8(A) make_uint4((A[0] >> 16) | A[1], (A[2] >> 16) | A[3], (A[4] >> 16) | A[5], (A[6] >> 16) | A[7])
 
 // host: W3 [27][16][32] -> [ntile 2][pair 14][split 3][lane 64] uint4, the B operand of lane (n = lane & 15, g = lane >> 4)
@@ -1263,17 +1278,28 @@ static void conv3_split_weights(const float *w3, uint4 *out) {
             for (int lane = 0; lane < 64; ++lane) {
                 const int n = lane & 15, g = lane >> 4;
                 const int tap = g < 2 ? c3x_pairA(p) : c3x_pairB(p);
+                uint4 *o = out + ((size_t)(nt * C3X_NPAIR + p) * C3X_NS) * 64 + lane;
+#if C3X_F16
+                uint16_t h[8], l[8];
+                for (int i = 0; i < 8; ++i)
+                    enc_split2h(tap >= 0 ? w3[(tap * 16 + 8 * (g & 1) + i) * 32 + nt * 16 + n] : 0.0f, h[i], l[i]);
+                o[0] = make_uint4(h[0] | (uint32_t)h[1] << 16, h[2] | (uint32_t)h[3] << 16, h[4] | (uint32_t)h[5] << 16, h[6] | (uint32_t)h[7] << 16);
+                o[64] = make_uint4(l[0] | (uint32_t)l[1] << 16, l[2] | (uint32_t)l[3] << 16, l[4] | (uint32_t)l[5] << 16, l[6] | (uint32_t)l[7] << 16);
+#else
                 uint32_t h[8], m[8], l[8];
                 for (int i = 0; i < 8; ++i)
                     enc_split3(tap >= 0 ? w3[(tap * 16 + 8 * (g & 1) + i) * 32 + nt * 16 + n] : 0.0f, h[i], m[i], l[i]);
-                uint4 *o = out + ((size_t)(nt * C3X_NPAIR + p) * 3) * 64 + lane;
                 o[0] = ENC_PK8(h);
                 o[64] = ENC_PK8(m);
                 o[128] = ENC_PK8(l);
+#endif
             }
 }
 
-__global__ void __launch_bounds__(256, 2) k_enc_conv3(const float *__restrict__ p2, int64_t n_patches, const caelo_enc_in in,
+#ifndef C3X_WGS
+#define C3X_WGS 2   // workgroups per CU the register budget is set for (3 spill at 168 registers: 183 instead of 92 us per 8 frames)
+#endif
+__global__ void __launch_bounds__(256, C3X_WGS) k_enc_conv3(const float *__restrict__ p2, int64_t n_patches, const caelo_enc_in in,
                                                       const uint4 *__restrict__ w3x, const float *__restrict__ b3g,
                                                       float *__restrict__ f3, int *__restrict__ stage1_counter,
                                                       int *__restrict__ xcd_counters) {
@@ -1287,11 +1313,11 @@ __global__ void __launch_bounds__(256, 2) k_enc_conv3(const float *__restrict__ 
     const int wave = tid >> 6;
     const int g = lane >> 4, n = lane & 15;
     const int ntile = wave & 1, slot = __builtin_amdgcn_readfirstlane(wave >> 1);
-    uint4 bq[C3X_NPAIR][3];
+    uint4 bq[C3X_NPAIR][C3X_NS];
 #pragma unroll
     for (int p = 0; p < C3X_NPAIR; ++p)
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) bq[p][sp] = w3x[((size_t)(ntile * C3X_NPAIR + p) * 3 + sp) * 64 + lane];
+        for (int sp = 0; sp < C3X_NS; ++sp) bq[p][sp] = w3x[((size_t)(ntile * C3X_NPAIR + p) * C3X_NS + sp) * 64 + lane];
     const float bias = b3g[16 * ntile + n];
     for (int i = tid; i < 2 * C3X_SLOT; i += 256) S[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
@@ -1336,13 +1362,21 @@ __global__ void __launch_bounds__(256, 2) k_enc_conv3(const float *__restrict__ 
         C3_STAMP(3);
         {   // split the staged 8 channels into the three bf16 terms: 3 x 16 B into LDS
             const float v[8] = {pre0.x, pre0.y, pre0.z, pre0.w, pre1.x, pre1.y, pre1.z, pre1.w};
+            uint4 *d = &S[f_slot * C3X_SLOT + f_h * C3X_ARR + f_q];
+#if C3X_F16
+            uint32_t h[4], l[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) enc_split2h_pk(v[2 * k], v[2 * k + 1], h[k], l[k]);
+            d[0] = make_uint4(h[0], h[1], h[2], h[3]);
+            d[C3X_SPLIT] = make_uint4(l[0], l[1], l[2], l[3]);
+#else
             uint32_t h[4], m[4], l[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) enc_split3_pk(v[2 * k], v[2 * k + 1], h[k], m[k], l[k]);
-            uint4 *d = &S[f_slot * C3X_SLOT + f_h * C3X_ARR + f_q];
             d[0] = make_uint4(h[0], h[1], h[2], h[3]);
             d[C3X_SPLIT] = make_uint4(m[0], m[1], m[2], m[3]);
             d[2 * C3X_SPLIT] = make_uint4(l[0], l[1], l[2], l[3]);
+#endif
         }
         C3_STAMP(0);
         __syncthreads();
@@ -1361,6 +1395,25 @@ __global__ void __launch_bounds__(256, 2) k_enc_conv3(const float *__restrict__ 
             for (int j = 0; j < 2; ++j) acc[j] = (f32x4){bias, bias, bias, bias};
 #pragma unroll
             for (int p = 0; p < C3X_NPAIR; ++p) {
+#if C3X_F16
+                typedef _Float16 c3_h8 __attribute__((ext_vector_type(8)));
+                const c3_h8 bh = __builtin_bit_cast(c3_h8, bq[p][0]), bl = __builtin_bit_cast(c3_h8, bq[p][1]);
+                c3_h8 ah[2], al[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (c3x_dead(2 * round + j, p)) continue;
+                    const uint4 *a = ab[c3x_pairClass(p)] + c3x_tapPos(c3x_pairA(p)) + (2 * round + j) * C3X_PLANE;
+                    ah[j] = __builtin_bit_cast(c3_h8, a[0]);
+                    al[j] = __builtin_bit_cast(c3_h8, a[C3X_SPLIT]);
+                }
+                // smallest terms first; the two accumulators alternate so that no MFMA waits for its predecessor
+#define C3X_MAC(A, B)                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) if (!c3x_dead(2 * round + j, p))                              \
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j], B, acc[j], 0, 0, 0);
+                C3X_MAC(al, bh)
+                C3X_MAC(ah, bl)
+                C3X_MAC(ah, bh)
+#else
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[p][0]), bm = __builtin_bit_cast(bf16x8, bq[p][1]),
                              bl = __builtin_bit_cast(bf16x8, bq[p][2]);
                 bf16x8 ah[2], am[2], al[2];
@@ -1382,6 +1435,7 @@ __global__ void __launch_bounds__(256, 2) k_enc_conv3(const float *__restrict__ 
                 C3X_MAC(am, bh)
                 C3X_MAC(ah, bm)
                 C3X_MAC(ah, bh)
+#endif
             }
             if (item < n_items) {
                 // C rows 4g + r -> (y = g, z = r); flatten index (x,y,z,c) = ((x*4 + y)*4 + z)*32 + c
@@ -2062,7 +2116,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     }
     if (ev) CAELO_HIP(hipEventRecord(ev[1], s));
     const int64_t pairs = (n_patches + 1) / 2;
-    const int64_t cap3 = (ein.yield & 2) ? 256 : ((ein.yield & 4) ? 384 : 512);
+    const int64_t cap3 = ((ein.yield & 2) ? 256 : ((ein.yield & 4) ? 384 : 512)) * C3X_WGS / 2;
     const unsigned g3 = (unsigned)(pairs < cap3 ? pairs : cap3);  // persistent: two 4-wave workgroups per CU
     k_enc_conv3<<<g3, 256, 0, s>>>(p2, n_patches, ein, (const uint4 *)c->enc_w3x, c->enc_b3, f3, work_counter, xcd_counters);
     CAELO_LAUNCH_CHECK();
