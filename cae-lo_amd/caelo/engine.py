@@ -530,7 +530,8 @@ class Engine:
     def match(self, f0, f1, n0=None, n1=None):
         """f0 [k0,dim], f1 [k1,dim] (row-strided views allowed) -> pair_idx [k1] int64."""
         idx = self.zeros((f1.shape[0],), torch.int64)
-        ws = self._ws("match%d" % f1.shape[0], int(self.lib.caelo_match_ws_bytes(f1.shape[0])))   # one per k1_max (caelo.h)
+        kmax = max(int(f0.shape[0]), int(f1.shape[0]))
+        ws = self._ws("match%d" % kmax, int(self.lib.caelo_match_ws_bytes(kmax)))   # sized by the larger frame (caelo.h)
         _ffi.check(self.lib.caelo_match(self.ctx, _ptr(f0), self._ld(f0), f0.shape[0], _ptr(n0), _ptr(f1), self._ld(f1),
                                         f1.shape[0], _ptr(n1), f0.shape[1], _ptr(idx), _ptr(ws), self.stream))
         return idx

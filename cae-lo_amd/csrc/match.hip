@@ -15,6 +15,8 @@
 // Also here: k_icp_nn / k_icp_fit_apply, one iteration of the reference's point-to-point ICP.
 // The workspaces of caelo_match / caelo_ransac are self-cleaning (zero-filled once by their owner).
 #include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 #include "caelo_internal.h"
@@ -58,9 +60,11 @@ typedef double mm_f64x4 __attribute__((ext_vector_type(4)));
 #define MM_TPS 2       // row tiles per wavefront and step: a step stages MM_RQ * MM_TPS tiles (128 rows), one barrier each
 #define MM_STEP_TILES (MM_RQ * MM_TPS)
 
-CAELO_API int64_t caelo_match_ws_bytes(int64_t k1_max) {
-    (void)k1_max;
-    return 256;  // [0] columns re-scanned exactly, [1] columns decided between two rows (statistics only)
+static inline int64_t ms_ws_bytes(int64_t kmax);
+CAELO_API int64_t caelo_match_ws_bytes(int64_t k_max) {
+    // [0] columns re-scanned exactly, [1] columns decided between two rows (statistics only), then the f16 operand images of
+    // both frames (match_screen.inc); k_max = the larger of the two frames' row capacities
+    return ms_ws_bytes(k_max > 0 ? k_max : 1);
 }
 
 __device__ inline double exact_dist(const float *a, const float *b, int dim) {
@@ -328,6 +332,8 @@ __global__ void __launch_bounds__(64 * MM_WAVES) k_match_mfma(const caelo_pair_s
     }
 }
 
+#include "match_screen.inc"
+
 CAELO_API int caelo_match(caelo_ctx *c, const float *f0, int ld0, int64_t k0_max, const int32_t *n0, const float *f1,
                           int ld1, int64_t k1_max, const int32_t *n1, int dim, int64_t *pair_idx, void *ws, void *stream) {
     CAELO_REQUIRE(c && f0 && f1 && pair_idx && ws, "null argument");
@@ -341,6 +347,20 @@ int match_set(const caelo_pair_set &ps, int ld0, int64_t k0_max, int ld1, int64_
     CAELO_REQUIRE(ps.n >= 1 && ps.n <= CAELO_FB_MAX, "bad pair count");
     CAELO_REQUIRE(dim > 0 && dim <= MT_MAXDIM && ld0 >= dim && ld1 >= dim && k0_max > 0 && k1_max > 0, "bad shape");
     CAELO_REQUIRE(k0_max + 16 * MM_STEP_TILES < MM_IDX_MASK, "too many frame-0 rows (the row index travels in 21 key bits)");
+    // default: the f16 screen + exact certification (match_screen.inc); CAELO_MATCH=f64, a dim > 62 (no room for the two norm
+    // slots in K = 64) or more than 1024 frame-0 descriptors: round 2's all-f64 kernel.  Same pair_idx bit for bit.
+    static const bool f64_only = getenv("CAELO_MATCH") && !strcmp(getenv("CAELO_MATCH"), "f64");
+    if (!f64_only && dim <= 62 && k0_max <= 16 * MS_NW * MS_TPW) {
+        const int64_t kpad = ms_pad16(k0_max > k1_max ? k0_max : k1_max);
+        bool v4 = (dim % 4 == 0) && (ld0 % 4 == 0) && (ld1 % 4 == 0);
+        for (int i = 0; i < ps.n; ++i) v4 = v4 && (((uintptr_t)ps.p[i].f0 | (uintptr_t)ps.p[i].f1) & 15u) == 0;
+        k_match_prep<<<dim3((unsigned)((kpad / 16 + 3) / 4), 1, ps.n), 256, 0, s>>>(ps, ld0, k0_max, dim, kpad, v4 ? 1 : 0);
+        CAELO_LAUNCH_CHECK();
+        k_match_screen<<<dim3((unsigned)((k1_max + 16 * MS_CT - 1) / (16 * MS_CT)), 1, ps.n), 64 * MS_NW, 0, s>>>(ps, ld0, k0_max, ld1, k1_max,
+                                                                                                            dim, kpad, v4 ? 1 : 0);
+        CAELO_LAUNCH_CHECK();
+        return CAELO_OK;
+    }
     const int64_t tiles = (k1_max + 16 * MM_CT - 1) / (16 * MM_CT);  // workgroups of MM_CT column tiles
     bool vec = (dim % 4 == 0) && (ld0 % 4 == 0) && (ld1 % 4 == 0);
     for (int i = 0; i < ps.n; ++i) vec = vec && (((uintptr_t)ps.p[i].f0 | (uintptr_t)ps.p[i].f1) & 15u) == 0;

@@ -278,6 +278,18 @@ struct VoxIdx {
     bool ok, oob;
 };
 
+// int(p / d) exactly as the reference's float64 division + truncation gives it (p >= 0, quotient < 1e4), without the division
+// for all but a few points: t = p * (1 / d) is within 3e-12 of the true quotient, and so is the correctly rounded p / d, so
+// whenever t sits further than 1e-6 from an integer both truncate alike; only a point within a micro-voxel of a voxel face (the
+// points that make a metrically quantised scan interesting, 14 of 126 k) pays for v_div_f64's ~40 instructions.
+__device__ inline int vox_trunc_div(double p, double d, double inv_d) {
+    const double t = p * inv_d;
+    const int n = (int)t;
+    const double frac = t - (double)n;
+    if (frac > 1e-6 && frac < 1.0 - 1e-6) return n;
+    return (int)(p / d);
+}
+
 // Voxel.py:89-97,:118-152 for one point; f64 index math
 __device__ inline VoxIdx voxel_indices(float fx, float fy, float fz) {
     VoxIdx r;
@@ -287,12 +299,13 @@ __device__ inline VoxIdx voxel_indices(float fx, float fy, float fz) {
     const double p[3] = {(double)fx + VIS_L, (double)fy + VIS_W, (double)fz + VIS_H};                 // :118-120
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const int b = (int)(p[a] / BLOCK_REAL);                  // :122-124
-        const int v = (int)((p[a] - b * BLOCK_REAL) / VOX_SIZE); // :136-138
+        const int b = vox_trunc_div(p[a], BLOCK_REAL, 1.0 / BLOCK_REAL);                        // :122-124
+        const double rem = p[a] - b * BLOCK_REAL;                                               // :136-138 (may be -ulp: the division below)
+        const int v = rem >= 0.0 ? vox_trunc_div(rem, VOX_SIZE, 1.0 / VOX_SIZE) : (int)(rem / VOX_SIZE);
         if (v < 0 || v >= 64) r.oob = true;
-        r.g[a] = v + b * 64;                                     // :143
-        r.v1[a] = (int)(p[a] / (VOX_SIZE * 8));                  // :147-149
-        r.v2[a] = (int)(p[a] / (VOX_SIZE * 32));                 // :150-152
+        r.g[a] = v + b * 64;                                                                    // :143
+        r.v1[a] = vox_trunc_div(p[a], VOX_SIZE * 8, 1.0 / (VOX_SIZE * 8));                      // :147-149
+        r.v2[a] = vox_trunc_div(p[a], VOX_SIZE * 32, 1.0 / (VOX_SIZE * 32));                    // :150-152
     }
     r.ok = !r.oob;
     return r;

@@ -179,9 +179,12 @@ int caelo_encode_profile(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches
 /* NN match  (Match.py:257-258): pair_idx[j] = argmin_i ||f0[i]-f1[j]|| (f64, first minimum).
  * f0 [k0][ld0], f1 [k1][ld1] (leading dimensions in floats, >= dim, dim <= 64); k0/k1 read from the
  * n0/n1 device words when non-null.
- * ws: caelo_match_ws_bytes(k1_max) bytes (two statistics counters the calls only add to: columns re-scanned exactly,
- * columns decided between two rows); zero-fill it once if you read them.  Nothing crosses workgroups. */
-int64_t caelo_match_ws_bytes(int64_t k1_max);
+ * ws: caelo_match_ws_bytes(max(k0_max, k1_max)) bytes: two statistics counters the calls only add to (columns re-scanned
+ * exactly, columns decided between two rows; zero-fill the first 256 bytes once if you read them) and the scratch images of
+ * the two frames (every call rewrites them).  Nothing crosses workgroups.  The distances are screened on the f16 matrix pipe
+ * inside a rigorous error window and only the rows that can be the minimum are evaluated in float64 like scipy's cdist: the
+ * result is the float64 argmin, bit for bit. */
+int64_t caelo_match_ws_bytes(int64_t k_max);
 int caelo_match(caelo_ctx *ctx, const float *f0, int ld0, int64_t k0_max, const int32_t *n0, const float *f1, int ld1,
                 int64_t k1_max, const int32_t *n1, int dim, int64_t *pair_idx, void *ws, void *stream);
 
