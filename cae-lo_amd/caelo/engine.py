@@ -118,6 +118,14 @@ class FrameBatch:
     def frame(self, i):
         return FrameFeatures(self.rows[i], self.key_pixels[i], self.n_key[i:i + 1], self.status[i], self.flags[i])
 
+    def view(self, start, n):
+        """Frames start .. start + n as a FrameBatch over the same storage."""
+        v = object.__new__(FrameBatch)
+        v.k = n
+        for f in ("rows", "key_pixels", "n_key", "flags", "status", "result", "inlier_mask", "pair_idx"):
+            setattr(v, f, getattr(self, f)[start:start + n])
+        return v
+
 
 class Pipeline:
     """caelo_pipeline (include/caelo.h): `batch` consecutive frames share one launch of every front kernel, one
@@ -146,25 +154,13 @@ class Pipeline:
         return {"jobs": int(out[0]), "issue_us_per_frame": out[1] / n / 1e3, "batches": int(out[2]), "batch": int(out[3]),
                 "buffers": int(out[4]), "streams": int(out[5])}
 
-    def run(self, scans, rands=None, prev=None, dist_channels=5, exact_voxels=False, out=None, pairs=True, dedup=True):
-        """scans: K device tensors [n,4] f32; rands: K device tensors of RANSAC draws ([1500,4] f64).
-        Frame i is matched against frame i-1 (pose in ``result[i]``); frame 0 against ``prev``
-        (FrameFeatures) when given; ``pairs=False`` extracts only (BASELINE configs[1]).  Returns a FrameBatch; the
-        current stream has waited for all lanes."""
-        eng, lib, k = self.eng, self.eng.lib, len(scans)
-        out = out or FrameBatch(eng, k)
-        assert out.k >= k and (not pairs or len(rands) >= k)
-        stream = eng.stream
-        _ffi.check(lib.caelo_pipeline_expect(self.h, k))   # an even batch plan for runs that are not whole batches (caelo.h)
-        _ffi.check(lib.caelo_pipeline_begin(self.h, stream))
-        # the run's jobs as one record array, filled column-wise, handed over in ONE foreign call (a ctypes call per frame costs
-        # ~10 us: 380 us for the driver's 20-frame run, most of it before the first launch)
-        for pc in scans:
-            assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] == 4 and pc.is_contiguous()
+    def _jobs(self, ptrs, counts, rands, prev, out, pairs, dist_channels, exact_voxels, dedup):
+        """The run's jobs as one record array, filled column-wise, handed over in ONE foreign call (a ctypes call per frame
+        costs ~10 us: 380 us for a 20-frame run, most of it before the first launch)."""
+        k = len(ptrs)
         jobs = np.zeros(k, dtype=_ffi.JOB_DTYPE)
         idx = np.arange(k, dtype=np.uint64)
-        jobs["pc"] = [pc.data_ptr() for pc in scans]
-        jobs["n"] = [pc.shape[0] for pc in scans]
+        jobs["pc"], jobs["n"] = ptrs, counts
         jobs["dist_channels"], jobs["mode"] = int(dist_channels), (1 if exact_voxels else 0) | (0 if dedup else 2)
         jobs["rows"] = out.rows.data_ptr() + idx * (MAX_K * 256)
         jobs["key_pixels"] = out.key_pixels.data_ptr() + idx * (MAX_K * 16)
@@ -185,8 +181,70 @@ class Pipeline:
         jobs["result"] = out.result.data_ptr() + idx * out.result.shape[1]
         jobs["inlier_mask"] = out.inlier_mask.data_ptr() + idx * MAX_K
         jobs["pair_idx"] = out.pair_idx.data_ptr() + idx * (MAX_K * 8)
+        return jobs
+
+    def run(self, scans, rands=None, prev=None, dist_channels=5, exact_voxels=False, out=None, pairs=True, dedup=True):
+        """scans: K device tensors [n,4] f32; rands: K device tensors of RANSAC draws ([1500,4] f64).
+        Frame i is matched against frame i-1 (pose in ``result[i]``); frame 0 against ``prev``
+        (FrameFeatures) when given; ``pairs=False`` extracts only (BASELINE configs[1]).  Returns a FrameBatch; the
+        current stream has waited for all lanes."""
+        eng, lib, k = self.eng, self.eng.lib, len(scans)
+        out = out or FrameBatch(eng, k)
+        assert out.k >= k and (not pairs or len(rands) >= k)
+        stream = eng.stream
+        _ffi.check(lib.caelo_pipeline_expect(self.h, k))   # an even batch plan for runs that are not whole batches (caelo.h)
+        _ffi.check(lib.caelo_pipeline_begin(self.h, stream))
+        for pc in scans:
+            assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] == 4 and pc.is_contiguous()
+        jobs = self._jobs([pc.data_ptr() for pc in scans], [pc.shape[0] for pc in scans], rands, prev, out, pairs, dist_channels,
+                          exact_voxels, dedup)
         try:
             _ffi.check(lib.caelo_pipeline_submit_many(self.h, jobs.ctypes.data, k))
+        finally:
+            rc = lib.caelo_pipeline_flush(self.h, stream)
+        _ffi.check(rc)
+        return out
+
+    def run_uploading(self, host_scans, rands=None, prev=None, dist_channels=5, out=None, pairs=True, dedup=True, slots=3):
+        """``run`` for scans that live in (pinned) HOST memory: a copy stream uploads batch b + 1 into one of ``slots`` device
+        buffer sets while the pipeline works on batch b -- the overlap of the reference's producer process, which prepares
+        frame i + 1 while frame i is matched (PoseEstimation.py:214-245).  Events both ways (caelo_pipeline_wait_stream /
+        caelo_pipeline_release_scans); the calling thread never waits."""
+        eng, lib, k, B = self.eng, self.eng.lib, len(host_scans), self.batch
+        out = out or FrameBatch(eng, k)
+        assert out.k >= k and (not pairs or len(rands) >= k) and slots >= 3
+        for pc in host_scans:
+            assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] == 4 and pc.is_contiguous() and not pc.is_cuda
+        big = max(int(pc.shape[0]) for pc in host_scans)
+        key = ("upload", B, slots)
+        st = self._upload.get(key) if hasattr(self, "_upload") else None
+        if st is None or st[1] < big:
+            bufs = [[torch.empty((big, 4), dtype=torch.float32, device=eng.device) for _ in range(B)] for _ in range(slots)]
+            st = (bufs, big, torch.cuda.Stream(device=eng.device))
+            self._upload = {key: st}
+        bufs, _, copy = st
+        stream = eng.stream
+        nb = (k + B - 1) // B
+        jobs = self._jobs([bufs[(i // B) % slots][i % B].data_ptr() for i in range(k)], [int(pc.shape[0]) for pc in host_scans], rands, prev, out,
+                          pairs, dist_channels, False, dedup)
+
+        def upload(b):
+            with torch.cuda.stream(copy):
+                for i in range(b * B, min(k, (b + 1) * B)):
+                    bufs[b % slots][i % B][:host_scans[i].shape[0]].copy_(host_scans[i], non_blocking=True)
+
+        _ffi.check(lib.caelo_pipeline_expect(self.h, 0))   # full batches, the remainder last: the slots are laid out that way
+        copy.wait_stream(torch.cuda.current_stream(eng.device))
+        _ffi.check(lib.caelo_pipeline_begin(self.h, stream))
+        try:
+            upload(0)
+            for b in range(nb):
+                _ffi.check(lib.caelo_pipeline_wait_stream(self.h, copy.cuda_stream))      # batch b's scans have been requested
+                _ffi.check(lib.caelo_pipeline_release_scans(self.h, copy.cuda_stream))    # batches <= b - 1 no longer read theirs
+                lo, hi = b * B, min(k, (b + 1) * B)
+                _ffi.check(lib.caelo_pipeline_submit_many(self.h, jobs[lo:hi].ctypes.data, hi - lo))
+                if b + 1 < nb:
+                    upload(b + 1)   # into the slot batch b + 1 - slots used
         finally:
             rc = lib.caelo_pipeline_flush(self.h, stream)
         _ffi.check(rc)

@@ -51,7 +51,56 @@ def _scene(seed=SCENE_SEED):
     return np.array(boxes, dtype=np.float64)
 
 
+def _clutter(seed):
+    """The "clutter" scene (round 3): vegetation instead of architecture.  No wall, no box: ~10 000 small spheres -- tree crowns as
+    balls of 45 leaves-clumps (radius 10 .. 30 cm) that the rays enter to different depths, bushes as clusters of eight, trunks
+    as thin boxes -- so that a key point's neighbourhood is an irregular VOLUME of returns (dense 16 cm / 64 cm patches, the
+    496-nearest cut of Voxel.py:182 biting on real key points, hardly two equal patches), where the box scene gives planes, edges
+    and many duplicate patches.  Returns (boxes [n,6], spheres [m,4] = centre + radius)."""
+    rs = np.random.RandomState(seed + 77)
+    spheres, boxes = [], []
+
+    def clear_of_track(cx, cy, r):
+        return not ((cx - r < 45.0 and cx + r > -6.0) and abs(cy) - r < 2.5)
+
+    for _ in range(64):                     # trees: a trunk and a crown
+        ang, dist = rs.uniform(0.0, 2.0 * math.pi), rs.uniform(5.0, 40.0)
+        cx, cy = dist * math.cos(ang), dist * math.sin(ang)
+        h = rs.uniform(2.2, 5.5)
+        offs = rs.normal(0.0, 0.6, size=(45, 3))
+        rad = rs.uniform(0.10, 0.30, size=45)
+        if not clear_of_track(cx, cy, 2.0):
+            continue
+        boxes.append((cx - 0.12, cx + 0.12, cy - 0.12, cy + 0.12, GROUND_Z, GROUND_Z + h))
+        for o, r in zip(offs, rad):
+            spheres.append((cx + o[0], cy + o[1], GROUND_Z + h + 0.7 * o[2], r))
+    for _ in range(220):                    # bushes
+        ang, dist = rs.uniform(0.0, 2.0 * math.pi), rs.uniform(4.0, 36.0)
+        cx, cy = dist * math.cos(ang), dist * math.sin(ang)
+        offs = rs.normal(0.0, 0.25, size=(8, 3))
+        rad = rs.uniform(0.10, 0.25, size=8)
+        if not clear_of_track(cx, cy, 1.0):
+            continue
+        for o, r in zip(offs, rad):
+            spheres.append((cx + o[0], cy + o[1], GROUND_Z + 0.25 + abs(o[2]), r))
+    for _ in range(260):                    # a belt of thicket 30 .. 48 m out: it hides the far ground, whose sparse rings would
+        ang, dist = rs.uniform(0.0, 2.0 * math.pi), rs.uniform(30.0, 48.0)   # otherwise collect most of the key points
+        cx, cy = dist * math.cos(ang), dist * math.sin(ang)
+        offs = rs.normal(0.0, 1.0, size=(26, 3))
+        rad = rs.uniform(0.15, 0.45, size=26)
+        for o, r in zip(offs, rad):
+            spheres.append((cx + 0.9 * o[0], cy + 0.9 * o[1], GROUND_Z + 1.4 + 1.1 * o[2], r))
+    return np.array(boxes, dtype=np.float64).reshape(-1, 6), np.array(spheres, dtype=np.float64).reshape(-1, 4)
+
+
 _SCENE_CACHE = {}
+_CLUTTER_CACHE = {}
+
+
+def clutter(seed=SCENE_SEED):
+    if seed not in _CLUTTER_CACHE:
+        _CLUTTER_CACHE[seed] = _clutter(seed)
+    return _CLUTTER_CACHE[seed]
 
 
 def scene(seed=SCENE_SEED):
@@ -66,12 +115,13 @@ def sensor_pose(frame, step=(0.9, 0.05, 0.0), yaw_step=0.01):
 
 
 def make_scan(frame=0, n_beams=64, n_az=2000, seed=None, scene_seed=SCENE_SEED,
-              pose=None, noise_sigma=0.01, quantum=None):
+              pose=None, noise_sigma=0.01, quantum=None, scene_kind="boxes"):
     """Return a [N,4] float32 cloud (x,y,z,intensity) in the sensor frame, file order
     beam-major (all azimuths of beam 0, then beam 1, ...).  ``quantum`` (metres, e.g. 1e-3): coordinates rounded to
     multiples of it, like the metrically quantised values real scanners deliver -- such clouds put points exactly on
     voxel faces (x = 4.0), the case the reference's float64 index arithmetic (Voxel.py:118-152) resolves in its own
-    way and a voxelization has to reproduce."""
+    way and a voxelization has to reproduce.  ``scene_kind``: "boxes" (ground, boxes, poles: the scene of rounds 1-2) or
+    "clutter" (ground, trees and bushes made of spheres)."""
     if seed is None:
         seed = frame
     (tx, ty, tz), yaw = sensor_pose(frame) if pose is None else pose
@@ -96,7 +146,39 @@ def make_scan(frame=0, n_beams=64, n_az=2000, seed=None, scene_seed=SCENE_SEED,
     tg = np.where(down, (GROUND_Z - tz) / np.where(down, wz, -1.0), np.inf)
     t = np.minimum(t, tg)
     big = 1e30
-    for b in scene(scene_seed):
+    balls = np.zeros((0, 4))
+    if scene_kind == "clutter":
+        solids, balls = clutter(scene_seed)
+    else:
+        assert scene_kind == "boxes"
+        solids = scene(scene_seed)
+    if len(balls):
+        # ray / sphere with element-wise IEEE +, -, *, sqrt only (see the module docstring).  A sphere is only tested against the
+        # azimuth columns that can see it (a conservative slice of the [beam, azimuth] grid: skipping a ray that cannot hit changes
+        # nothing), which makes thousands of spheres affordable.
+        t2 = t.reshape(n_beams, n_az)
+        wx2, wy2, wz2 = wx.reshape(n_beams, n_az), wy.reshape(n_beams, n_az), wz.reshape(n_beams, n_az)
+        for cxs, cys, czs, rad in balls:
+            ox, oy, oz = tx - cxs, ty - cys, tz - czs
+            dxy = math.hypot(ox, oy)
+            if dxy > rad * 1.05:
+                half = math.asin(min(1.0, rad * 1.05 / dxy)) + 2.5 * (2.0 * math.pi / n_az)
+                rel = math.atan2(-oy, -ox) - yaw                   # azimuth of the centre in the sensor frame
+                j0 = int(math.floor((rel - half + math.pi) / (2.0 * math.pi) * n_az - 0.5))
+                j1 = int(math.ceil((rel + half + math.pi) / (2.0 * math.pi) * n_az - 0.5))
+                cols = np.arange(j0, j1 + 1) % n_az
+            else:
+                cols = np.arange(n_az)
+            ax, ay, az_ = wx2[:, cols], wy2[:, cols], wz2[:, cols]
+            bq = ox * ax + oy * ay + oz * az_
+            cq = ox * ox + oy * oy + oz * oz - rad * rad
+            disc = bq * bq - cq
+            ok = disc > 0.0
+            th = -bq - np.sqrt(np.where(ok, disc, 0.0))
+            hit = ok & (th > 0.5)
+            t2[:, cols] = np.where(hit, np.minimum(t2[:, cols], th), t2[:, cols])
+        t = t2.reshape(-1)
+    for b in solids:
         x0, x1, y0, y1, z0, z1 = b
         with np.errstate(divide="ignore", invalid="ignore"):
             ix = 1.0 / wx

@@ -520,7 +520,9 @@ __device__ __forceinline__ void ransac_replay(int N, const int32_t *counts, Rans
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(best, o); best = best < t ? best : t; }
     if (lane != 0) return;
-    const int success = (target > 0) || (least <= 0);  // leastInliers == 0 admits every hypothesis
+    // leastInliers == 0 (N < 5) admits every hypothesis.  N == 0 -- a frame without a single key point, where the reference's
+    // sampling raises IndexError (Match.py:182-187) -- is reported as a failed pose, not as a success over nothing.
+    const int success = N > 0 && ((target > 0) || (least <= 0));
     out->iterations = stop;
     out->success = success;
     out->best_trial = (success && target > 0) ? best : -1;  // N < 5: success without any accepted hypothesis -> identity (:177)
@@ -625,7 +627,9 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp(const caelo_pair_s
     const int64_t *__restrict__ pair_idx = P.pair_idx;
     RansacWs *ws = (RansacWs *)P.ws_ransac;
     __shared__ float sP0[RE_LDS_PAIRS * 3], sP1[RE_LDS_PAIRS * 3];
-    const int N = P.n1 ? min(max(*P.n1, 0), (int)k1_max) : (int)k1_max;
+    // no pairs at all when EITHER frame has no key point (frame 0 empty: the match kernel wrote index 0 everywhere, the
+    // reference's argmin over an empty axis raises): the pose fails as a value
+    const int N = (P.n0 && *P.n0 <= 0) ? 0 : (P.n1 ? min(max(*P.n1, 0), (int)k1_max) : (int)k1_max);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // pairs -> LDS (falls back to the global arrays when they do not fit)
     const bool in_lds = N <= RE_LDS_PAIRS;
@@ -699,7 +703,9 @@ __global__ void __launch_bounds__(256) k_ransac_finish(const caelo_pair_set ps, 
     __shared__ RansacVerdict s_v;
     __shared__ double red[4][FIT_TERMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N = P.n1 ? min(max(*P.n1, 0), (int)k1_max) : (int)k1_max;
+    // no pairs at all when EITHER frame has no key point (frame 0 empty: the match kernel wrote index 0 everywhere, the
+    // reference's argmin over an empty axis raises): the pose fails as a value
+    const int N = (P.n0 && *P.n0 <= 0) ? 0 : (P.n1 ? min(max(*P.n1, 0), (int)k1_max) : (int)k1_max);
     // ---- the first level's counts (wavefront 0, eight per lane) are fetched while all four wavefronts gather the matched
     // pairs into LDS once: the winner's sample, the inlier mask and the refit below then never touch global memory again
     // (round 2 before: three passes of dependent global gathers in this one-workgroup kernel, 27 us)

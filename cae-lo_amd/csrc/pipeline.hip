@@ -49,6 +49,7 @@ struct caelo_pipeline {
     void *ws_match[CAELO_FB_MAX] = {nullptr}, *ws_ransac[CAELO_FB_MAX] = {nullptr};
     hipEvent_t front_done[MAX_BUFFERS] = {nullptr}, enc_done[MAX_BUFFERS] = {nullptr};
     hipEvent_t begun = nullptr, joined[3] = {nullptr};
+    hipEvent_t ext_in = nullptr, ext_out = nullptr;  // caelo_pipeline_wait_stream / caelo_pipeline_release_scans
     // host state
     std::vector<caelo_frame_job> pending;
     uint64_t n_batches = 0, submitted = 0;
@@ -166,7 +167,7 @@ CAELO_API void caelo_pipeline_destroy(caelo_pipeline *p) {
     if (p->begun) (void)hipEventDestroy(p->begun);
     for (hipEvent_t e : p->joined)
         if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {p->vox_fork, p->vox_join})
+    for (hipEvent_t e : {p->vox_fork, p->vox_join, p->ext_in, p->ext_out})
         if (e) (void)hipEventDestroy(e);
     if (p->sV) (void)hipStreamDestroy(p->sV);
     if (p->sP && p->sP != p->sF) (void)hipStreamDestroy(p->sP);
@@ -228,6 +229,8 @@ CAELO_API int caelo_pipeline_create(caelo_ctx *c, int batch, int n_buffers, int6
         }
     }
     hip_ok(hipEventCreateWithFlags(&p->begun, hipEventDisableTiming), "hipEventCreate");
+    hip_ok(hipEventCreateWithFlags(&p->ext_in, hipEventDisableTiming), "hipEventCreate");
+    hip_ok(hipEventCreateWithFlags(&p->ext_out, hipEventDisableTiming), "hipEventCreate");
     for (hipEvent_t &e : p->joined) hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
     for (int i = 0; i < n_buffers; ++i) {
         hip_ok(hipEventCreateWithFlags(&p->front_done[i], hipEventDisableTiming), "hipEventCreate");
@@ -336,6 +339,24 @@ CAELO_API int caelo_pipeline_submit_many(caelo_pipeline *p, const caelo_frame_jo
         const int rc = caelo_pipeline_submit(p, jobs + i);
         if (rc) return rc;
     }
+    return CAELO_OK;
+}
+
+// Scans that arrive while the pipeline runs (a copy stream uploading batch b + 1 during batch b, like the producer process of
+// PoseEstimation.py:214-245): the front stage of every batch submitted from now on starts after what `stream` holds now ...
+CAELO_API int caelo_pipeline_wait_stream(caelo_pipeline *p, void *stream) {
+    CAELO_REQUIRE(p, "null argument");
+    CAELO_HIP(hipEventRecord(p->ext_in, caelo_stream(stream)));
+    CAELO_HIP(hipStreamWaitEvent(p->sF, p->ext_in, 0));   // the voxel stream forks from sF inside every batch
+    return CAELO_OK;
+}
+
+// ... and `stream` may overwrite the scan buffers of every batch ISSUED so far once their front stages (the only readers of a
+// scan: projection, ring fill, voxel map) are done.
+CAELO_API int caelo_pipeline_release_scans(caelo_pipeline *p, void *stream) {
+    CAELO_REQUIRE(p, "null argument");
+    CAELO_HIP(hipEventRecord(p->ext_out, p->sF));
+    CAELO_HIP(hipStreamWaitEvent(caelo_stream(stream), p->ext_out, 0));
     return CAELO_OK;
 }
 

@@ -323,6 +323,13 @@ int caelo_pipeline_submit(caelo_pipeline *pipe, const caelo_frame_job *job);
  * costly foreign-call path (ctypes: ~10 us per call) hands a whole run over at once -- the odometry loop of PoseEstimation.py:241-267. */
 int caelo_pipeline_submit_many(caelo_pipeline *pipe, const caelo_frame_job *jobs, int64_t n);
 int caelo_pipeline_flush(caelo_pipeline *pipe, void *stream);
+/* Scans that arrive while the pipeline runs -- the overlap of the reference's producer process, which prepares frame i + 1 while
+ * frame i is matched (PoseEstimation.py:214-245).  caelo_pipeline_wait_stream: the front stage of every batch submitted from
+ * now on starts after the work `stream` holds at this moment (the uploads of those scans).  caelo_pipeline_release_scans:
+ * `stream` waits until the front stages of the batches issued so far are done -- nothing else reads a scan -- before it may
+ * overwrite their buffers.  Both between caelo_pipeline_begin and caelo_pipeline_flush. */
+int caelo_pipeline_wait_stream(caelo_pipeline *p, void *stream);
+int caelo_pipeline_release_scans(caelo_pipeline *p, void *stream);
 /* host-side counters since the last call (then reset): out_host[6] = jobs, ns the calling thread spent issuing their
  * launches, batches launched, batch size, hand-off buffers, HIP streams used */
 /* Optional hint before caelo_pipeline_begin: the run will submit n_frames jobs.  If that is not a multiple of the batch size, the

@@ -46,9 +46,9 @@ def scans():
     from caelo import synth
     cache = {}
 
-    def get(frame, n_beams=64, n_az=2000, quantum=None):
-        key = (frame, n_beams, n_az, quantum)
+    def get(frame, n_beams=64, n_az=2000, quantum=None, scene_kind="boxes"):
+        key = (frame, n_beams, n_az, quantum, scene_kind)
         if key not in cache:
-            cache[key] = synth.make_scan(frame, n_beams=n_beams, n_az=n_az, quantum=quantum)
+            cache[key] = synth.make_scan(frame, n_beams=n_beams, n_az=n_az, quantum=quantum, scene_kind=scene_kind)
         return cache[key]
     return get

@@ -93,10 +93,10 @@ def inconsistent_points(pc):
     return n
 
 
-def frame_golden(frame, n_beams=64, n_az=2000, n_patch_kp=None, tag=None, quantum=None):
+def frame_golden(frame, n_beams=64, n_az=2000, n_patch_kp=None, tag=None, quantum=None, scene_kind="boxes"):
     t0 = time.time()
     g = {}
-    pc = synth.make_scan(frame, n_beams=n_beams, n_az=n_az, quantum=quantum)
+    pc = synth.make_scan(frame, n_beams=n_beams, n_az=n_az, quantum=quantum, scene_kind=scene_kind)
     if quantum:
         g["quantum"] = quantum
         g["n_inconsistent_points"] = inconsistent_points(pc)
@@ -221,6 +221,15 @@ def quantised_golden():
     q0 = frame_golden(0, quantum=1e-3, tag="q0")
     q1 = frame_golden(1, quantum=1e-3, tag="q1")
     pair_golden(q0, q1, seeds=(0, 1), out="pair_q0_q1.npz", hard_cases=False)
+
+
+def clutter_golden():
+    """Round 3: the second scene (synth.make_scan(scene_kind="clutter"): trees and bushes made of spheres, mm-quantised) through
+    the reference -- dense 16 cm / 64 cm patches, the 496-nearest cut of Voxel.py:182,195-196 on REAL key points, few equal
+    patches."""
+    c0 = frame_golden(0, quantum=1e-3, tag="c0", scene_kind="clutter")
+    c1 = frame_golden(1, quantum=1e-3, tag="c1", scene_kind="clutter")
+    pair_golden(c0, c1, seeds=(0, 1), out="pair_c0_c1.npz", hard_cases=False)
 
 
 def trunc_golden():
@@ -601,6 +610,9 @@ if __name__ == "__main__":
     if "--sequence-only" in sys.argv:
         sequence_golden()
         sys.exit(0)
+    if "--clutter-only" in sys.argv:
+        clutter_golden()
+        sys.exit(0)
     if "--quantised-only" in sys.argv:
         quantised_golden()
         sys.exit(0)
@@ -624,6 +636,7 @@ if __name__ == "__main__":
     f1 = frame_golden(1)
     pair_golden(f0, f1)
     quantised_golden()
+    clutter_golden()
     # dense 128-beam scan: exercises the 496-NN truncation of GetPatchesList
     frame_golden(0, n_beams=128, n_az=4000, n_patch_kp=192, tag="dense128")
     sequence_golden()
