@@ -45,28 +45,95 @@ def pose_rows(batch, k):
     return out, ok, thr, nin
 
 
+def _parse_poses(raw, k):
+    out = np.zeros((k, 12), np.float32)
+    ok = np.zeros(k, bool); thr = np.zeros(k, np.float32); nin = np.zeros(k, np.int32)
+    for i in range(k):
+        r = _ffi.PoseResult.from_buffer_copy(raw[i].tobytes())
+        out[i, :9], out[i, 9:] = np.array(r.R, np.float32), np.array(r.T, np.float32)
+        ok[i], thr[i], nin[i] = bool(r.success), r.threshold, r.n_inliers
+    return out, ok, thr, nin
+
+
 def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, keep=None):
     """Frames [lo, hi) of this rank.  Returns per-pair rows for pairs (i-1, i), i in (lo, hi) -- the pair (lo-1, lo)
-    is the caller's (it needs the previous rank's last frame) -- plus the first and last frame's features."""
+    is the caller's (it needs the previous rank's last frame) -- plus the first and last frame's features.
+
+    Three things overlap, as in the reference's producer / consumer split (PoseEstimation.py:214-245, where a generator process
+    prepares frame i + 1 while the main loop matches frame i):
+      * a loader thread reads (or synthesises) the scans and RANSAC draws of chunk c + 1 into pinned host memory;
+      * inside a chunk, a copy stream uploads batch b + 1 while the pipeline works on batch b (Pipeline.run_uploading);
+      * the poses and status words of chunk c come back through pinned buffers on a side stream and are parsed after chunk
+        c + 1 has been issued.
+    """
+    import queue
+    import threading
     pipe = eng.pipeline(batch_frames)
+    chunks = [(c0, min(hi, c0 + chunk)) for c0 in range(lo, hi, chunk)]
+    q = queue.Queue(maxsize=2)
+
+    pinned = {}   # a scan served twice (--pool) is pinned once
+
+    def pin(a):
+        t = pinned.get(id(a))
+        if t is None:
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).pin_memory()
+            if getattr(load, "repeats", False):
+                pinned[id(a)] = t
+        return t
+
+    def loader():
+        try:
+            for c0, c1 in chunks:
+                scans = [pin(load(i)) for i in range(c0, c1)]
+                draws = torch.from_numpy(np.stack([ransac_draws(seed_base + i - 1) for i in range(c0, c1)])).pin_memory()
+                q.put((c0, c1, scans, draws))
+        except BaseException as e:   # surfaced in the consumer
+            q.put(e)
+
+    threading.Thread(target=loader, daemon=True).start()
+    side = torch.cuda.Stream(device=eng.device)
     rel, ok, thr, nin = [], [], [], []
     prev, first = None, None
-    for c0 in range(lo, hi, chunk):
-        c1 = min(hi, c0 + chunk)
-        scans = [torch.from_numpy(load(i)).to(eng.device) for i in range(c0, c1)]
-        draws = [torch.from_numpy(ransac_draws(seed_base + i - 1)).to(eng.device) for i in range(c0, c1)]
-        batch = pipe.run(scans, draws, prev=prev, dist_channels=dist_channels)
-        status = batch.status[:, 0].cpu().numpy()
-        for st in status:
+    pending = None   # (k, has_prev, pinned result, pinned status, event)
+
+    def collect(p):
+        k, has_prev, res_h, st_h, ev = p
+        ev.synchronize()
+        for st in st_h.numpy()[:, 0]:
             raise_status(int(st))
-        r, o, t, n = pose_rows(batch, c1 - c0)
-        s = 0 if prev is not None else 1                           # slot 0 of the first chunk has no predecessor here
+        r, o, t, n = _parse_poses(res_h.numpy(), k)
+        s = 0 if has_prev else 1                                   # slot 0 of the first chunk has no predecessor here
         rel.append(r[s:]); ok.append(o[s:]); thr.append(t[s:]); nin.append(n[s:])
+
+    for _ in chunks:
+        item = q.get()
+        if isinstance(item, BaseException):
+            raise item
+        c0, c1, scans, draws = item
+        draws_d = draws.to(eng.device, non_blocking=True)
+        batch = pipe.run_uploading(scans, [draws_d[i] for i in range(c1 - c0)], prev=prev, dist_channels=dist_channels)
+        # read this chunk's small outputs back without stalling the stream that issues the next chunk
+        done = torch.cuda.Event()
+        done.record()
+        res_h = torch.empty(batch.result[:c1 - c0].shape, dtype=batch.result.dtype).pin_memory()
+        st_h = torch.empty(batch.status[:c1 - c0].shape, dtype=batch.status.dtype).pin_memory()
+        with torch.cuda.stream(side):
+            side.wait_event(done)
+            res_h.copy_(batch.result[:c1 - c0], non_blocking=True)
+            st_h.copy_(batch.status[:c1 - c0], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        if pending is not None:
+            collect(pending)
+        pending = (c1 - c0, prev is not None, res_h, st_h, ev)
         if first is None:
             first = batch.frame(0)
         prev = batch.frame(c1 - c0 - 1)
         if keep is not None:
             keep(c0, batch)
+    if pending is not None:
+        collect(pending)
     cat = (lambda xs, d: np.concatenate(xs) if xs else np.zeros((0,) + d))
     return cat(rel, (12,)), cat(ok, ()), cat(thr, ()), cat(nin, ()), first, prev
 
@@ -81,7 +148,10 @@ def main():
     ap.add_argument("--seed-base", type=int, default=1000)
     ap.add_argument("--chunk", type=int, default=120, help="frames resident on the GPU at a time")
     ap.add_argument("--dist-channels", type=int, default=5, choices=(3, 5), help="5 = demo mode, 3 = batch mode (SURVEY 8a-3')")
-    ap.add_argument("--batch", type=int, default=4, help="frames per launch (caelo_pipeline)")
+    ap.add_argument("--batch", type=int, default=8, help="frames per launch (caelo_pipeline)")
+    ap.add_argument("--scene", default="boxes", choices=("boxes", "clutter"), help="synthetic scene (caelo.synth)")
+    ap.add_argument("--pool", type=int, default=0, help="synthesise only this many distinct scans and walk them back and forth (0 1 .. P-1 "
+                                                        "P-2 .. 0 1 ..: every pair stays a pair of neighbours); ray casting a scan costs ~0.5 s of CPU")
     ap.add_argument("--save-artifacts", action="store_true", help="write Features/*.mat and InliersIdx/*.mat next to the scans")
     args = ap.parse_args()
 
@@ -100,7 +170,17 @@ def main():
         files = sorted(glob.glob(os.path.join(args.scans, "*.bin")))
         n, load = len(files), (lambda i: stageio.read_scan(files[i]))
     else:
-        n, load = args.synthetic, (lambda i: synth.make_scan(i, quantum=args.quantum or None))
+        cache = {}
+
+        def load(i):
+            if args.pool > 1:
+                i %= 2 * (args.pool - 1)
+                i = i if i < args.pool else 2 * (args.pool - 1) - i
+            if i not in cache:
+                cache[i] = synth.make_scan(i, quantum=args.quantum or None, scene_kind=args.scene)
+            return cache[i]
+        load.repeats = args.pool > 1
+        n = args.synthetic
         files = [os.path.join(os.path.dirname(os.path.abspath(args.out)), "synthetic", "velodyne", "%06d.bin" % i) for i in range(n)]
     assert n >= 2, "need at least two scans (--synthetic N or --scans DIR)"
     Tr = stageio.read_calib_tr(args.calib) if args.calib else None
@@ -139,9 +219,10 @@ def main():
     if rank == 0:
         poses = stageio.chain_poses(rel, Tr)
         stageio.write_poses(args.out, poses)
-        for i in range(len(rel)):
+        for i in range(len(rel) if len(rel) <= 200 else 0):
             print("%06d-%06d ok=%d thr=%.1f inliers=%4d T=[% .3f % .3f % .3f]" % (i, i + 1, ok[i], thr[i], nin[i], rel[i, 9], rel[i, 10], rel[i, 11]))
-        print("%d frames, %d pairs on %d GPU(s) in %.2f s (%.1f frames/s incl. scan loading) -> %s" % (n, len(rel), world, dt, n / dt, args.out))
+        print("%d frames, %d pairs on %d GPU(s) in %.2f s (%.1f frames/s incl. scan loading / synthesis, upload and read-back; %d of %d poses solved) -> %s" % (
+            n, len(rel), world, dt, n / dt, int(np.sum(ok)), len(rel), args.out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
