@@ -531,9 +531,9 @@ def run_with_uploads(eng, pipe, runner, host_scans, n, out, rand, pairs=True):
 
 
 def secondary_legs(args, eng, pipe, dev, pool, rand, Runner, frame_patches, encoder_table, host_scans, names):
-    """Short legs after the timed region (each ~16 batches, synchronised on both sides); frames/s each, plus what the scene does to
+    """Short legs after the timed region (each 32 batches, synchronised on both sides); frames/s each, plus what the scene does to
     the shortcuts (distinct patches, executed MFMA share) and the stage-1 time on it."""
-    B, n = pipe.batch, 16 * pipe.batch
+    B, n = pipe.batch, 32 * pipe.batch
 
     def leg(runner, **kw):
         runner.run(2 * B, **kw)

@@ -1,0 +1,35 @@
+"""Frame rate of the batched pipeline with every batch of scans uploaded from pinned host memory on a copy stream
+(Pipeline.run_uploading) beside the same frames resident in HBM (Pipeline.run).  Written for profiles/r03_upload_overlap.txt."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cae-lo_amd"))
+import numpy as np, torch
+import caelo; caelo.configure_runtime()
+from caelo import synth
+from caelo.engine import Engine, FrameBatch, ransac_draws
+eng = Engine()
+pool = [torch.from_numpy(synth.make_scan(i, quantum=1e-3)) for i in range(6)]
+host = [p.pin_memory() for p in pool]
+dev = [p.to(eng.device) for p in pool]
+rnd = [torch.from_numpy(ransac_draws(i)).to(eng.device) for i in range(6)]
+pipe = eng.pipeline(8, 3)
+n = 256
+order = [(0,1,2,3,4,5,4,3,2,1)[i % 10] for i in range(n)]
+prev = eng.extract(dev[1])
+out = FrameBatch(eng, n)
+def t(f, reps=3):
+    f(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): f()
+    torch.cuda.synchronize()
+    return reps * n / (time.perf_counter() - t0)
+print("resident      %.0f frames/s" % t(lambda: pipe.run([dev[j] for j in order], [rnd[j] for j in order], prev=prev, out=out)))
+print("run_uploading %.0f frames/s" % t(lambda: pipe.run_uploading([host[j] for j in order], [rnd[j] for j in order], prev=prev, out=out)))
+# uploads alone
+copy = torch.cuda.Stream()
+bufs = [torch.empty((130000, 4), device=eng.device) for _ in range(8)]
+def up():
+    with torch.cuda.stream(copy):
+        for i, j in enumerate(order):
+            bufs[i % 8][:host[j].shape[0]].copy_(host[j], non_blocking=True)
+    torch.cuda.current_stream().wait_stream(copy)
+print("uploads alone %.0f frames/s (%.1f GB/s)" % (t(up), t(up) * host[0].numel() * 4 / 1e9))
