@@ -1458,10 +1458,10 @@ __global__ void __launch_bounds__(256, C3X_WGS) k_enc_conv3(const float *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// dense1: split-K GEMM  part[s][row][208] = F3[row][k0:k0+KTOT/8] x Wd1[k0:k0+KTOT/8][208] -- bf16 x 3 like conv3
+// dense1: split-K GEMM  part[s][row][208] = F3[row][k0:k0+KTOT/8] x Wd1[k0:k0+KTOT/8][208] -- f16 x 2 like conv3
 // ------------------------------------------------------------------------------------------------
 #define D1_BM 64
-#define D1_BK 32      // one v_mfma_f32_16x16x32_bf16 k-step per stage
+#define D1_BK 32      // one v_mfma_f32_16x16x32_f16 k-step per stage
 #define D1_SPLIT 8  // the most k slices any instance uses: sizes the partial-sum buffer
 // k slices per row tile: 8 for the long-K instance (K = 16384: 16 row tiles x 8 = 128 workgroups per frame); 4 for K = 2048 --
 // one frame still fills the chip (48 x 4 workgroups, 29 us either way), a batch of 8 frames writes and re-reads half the partial
@@ -1470,23 +1470,26 @@ __global__ void __launch_bounds__(256, C3X_WGS) k_enc_conv3(const float *__restr
 #define D1_SPLIT_OF(KTOT) ((KTOT) > 2048 ? 8 : 4)
 #define D1_THREADS 512
 #define D1_NT (DENSE_NP / 16)          // 13 n-tiles
-#define D1_B16 (3 * D1_NT * 64)        // uint4 of a B stage: [split][n-tile][lane]
+// Round 3: like conv3, Dense(200) evaluates its f32 products from TWO f16 terms per operand and three partial products
+// (hi hi + hi lo + lo hi; the dropped lo lo term is 2^-22 relative): 3 MFMAs per K = 32 slab instead of the 6 of the 3-way bf16
+// split, a 26 KB instead of a 39 KB weight stage (the LDS-DMA weight stream was this kernel's ceiling), two A planes instead of three.
+#define D1_NS 2                        // terms per operand
+#define D1_B16 (D1_NS * D1_NT * 64)    // uint4 of a B stage: [term][n-tile][lane]
 #define D1_BSLOTS ((D1_B16 + D1_THREADS - 1) / D1_THREADS)
 
-// host: Wd1 [K][200] -> per 32-deep k-step the LDS image of the B operand: [kstep][split 3][n-tile 13][lane 64] x 16 B,
+// host: Wd1 [K][200] -> per 32-deep k-step the LDS image of the B operand: [kstep][f16 term 2][n-tile 13][lane 64] x 16 B,
 // lane (n = lane & 15, g = lane >> 4) holding k = 32 kstep + 8 g .. + 7 of column 16 ntile + n (zero beyond 200)
 static void dense1_split_weights(const float *wd1, int K, uint4 *out) {
     for (int ks = 0; ks < K / 32; ++ks)
         for (int nt = 0; nt < D1_NT; ++nt)
             for (int lane = 0; lane < 64; ++lane) {
                 const int n = lane & 15, g = lane >> 4, col = nt * 16 + n;
-                uint32_t h[8], m[8], l[8];
+                uint16_t h[8], l[8];
                 for (int i = 0; i < 8; ++i)
-                    enc_split3(col < DENSE_N ? wd1[(size_t)(ks * 32 + 8 * g + i) * DENSE_N + col] : 0.0f, h[i], m[i], l[i]);
+                    enc_split2h(col < DENSE_N ? wd1[(size_t)(ks * 32 + 8 * g + i) * DENSE_N + col] : 0.0f, h[i], l[i]);
                 uint4 *o = out + (size_t)ks * D1_B16 + nt * 64 + lane;
-                o[0] = ENC_PK8(h);
-                o[D1_NT * 64] = ENC_PK8(m);
-                o[2 * D1_NT * 64] = ENC_PK8(l);
+                o[0] = make_uint4(h[0] | (uint32_t)h[1] << 16, h[2] | (uint32_t)h[3] << 16, h[4] | (uint32_t)h[5] << 16, h[6] | (uint32_t)h[7] << 16);
+                o[D1_NT * 64] = make_uint4(l[0] | (uint32_t)l[1] << 16, l[2] | (uint32_t)l[3] << 16, l[4] | (uint32_t)l[5] << 16, l[6] | (uint32_t)l[7] << 16);
             }
 }
 
@@ -1498,7 +1501,7 @@ int enc_upload_dense1(const float *wd1, const float *bd1, int K, void **wx_dev, 
     float bd[DENSE_NP] = {0.0f};
     memcpy(bd, bd1, DENSE_N * sizeof(float));
     hipError_t e = hipSuccess;
-    if (!*wx_dev) e = hipMalloc(wx_dev, (n + 64) * sizeof(uint4));  // + one 1 KB piece: k_enc_dense1p's eighth wave copies a 40th piece per stage
+    if (!*wx_dev) e = hipMalloc(wx_dev, (n + 6 * 64) * sizeof(uint4));  // + six 1 KB pieces: k_enc_dense1p's waves copy 32 pieces per 26-piece stage
     if (e == hipSuccess && !*bd_dev) e = hipMalloc((void **)bd_dev, sizeof(bd));
     if (e == hipSuccess) e = hipMemcpy(*wx_dev, wx, n * sizeof(uint4), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(*bd_dev, bd, sizeof(bd), hipMemcpyHostToDevice);
@@ -1519,12 +1522,14 @@ int enc_upload_dense1(const float *wd1, const float *bd1, int K, void **wx_dev, 
 //     contiguous bytes).
 // Wave w owns the MTW m-tiles of row group w >> 1 and n-tiles 0..6 (even waves) / 7..12 (odd): an A fragment is read
 // once per k-step and serves 7 / 6 tiles, a B fragment serves the 6 MFMAs of MTW tiles (see conv3 for the arithmetic).
-#define D1_LDS_BYTES(MTW) ((3 * 4 * 64 * (MTW) + 2 * D1_B16) * 16)
+#define D1_LDS_BYTES(MTW) ((D1_NS * 4 * 64 * (MTW) + 2 * D1_B16) * 16)
+typedef _Float16 d1_h8 __attribute__((ext_vector_type(8)));
+#define D1_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_f16((A), (B), (C), 0, 0, 0)
 template <int KTOT, int MTW>
 __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1(const float *__restrict__ f3, int64_t n_rows_pad,
                                                               const uint4 *__restrict__ wd1x, float *__restrict__ part,
                                                               const caelo_enc_in in) {
-    constexpr int BM = 64 * MTW, A16 = 3 * 4 * BM, NKS = KTOT / D1_SPLIT_OF(KTOT) / D1_BK;
+    constexpr int BM = 64 * MTW, A16 = D1_NS * 4 * BM, NKS = KTOT / D1_SPLIT_OF(KTOT) / D1_BK;
     if (in.dedup) {  // a row tile past the frame's distinct patches holds nothing (tiles never straddle frames)
         const int64_t r0 = (int64_t)blockIdx.x * BM;
         const int f = (int)(r0 / in.per_frame);
@@ -1556,7 +1561,7 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1(const float *__res
     {                                                                                                            \
         _Pragma("unroll") for (int r = 0; r < 5; ++r) {                                                          \
             const int blk = wave + 8 * r;                                                                        \
-            if (blk < 3 * D1_NT)                                                                                 \
+            if (blk < D1_NS * D1_NT)                                                                             \
                 __builtin_amdgcn_global_load_lds(                                                                \
                     (const void __attribute__((address_space(1))) *)(b_src + (size_t)(KS) * D1_B16 + blk * 64),  \
                     (void __attribute__((address_space(3))) *)(Bs + (BUF) * D1_B16 + blk * 64), 16, 0, 0);       \
@@ -1566,13 +1571,12 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1(const float *__res
     }
 #define D1_STORE_A()                                                                                       \
     _Pragma("unroll") for (int r = 0; r < MTW; ++r) {                                                      \
-        uint32_t h01_, m01_, l01_, h23_, m23_, l23_;                                                       \
-        enc_split3_pk(pa[r].x, pa[r].y, h01_, m01_, l01_);                                                 \
-        enc_split3_pk(pa[r].z, pa[r].w, h23_, m23_, l23_);                                                 \
+        uint32_t h01_, l01_, h23_, l23_;                                                                   \
+        enc_split2h_pk(pa[r].x, pa[r].y, h01_, l01_);                                                      \
+        enc_split2h_pk(pa[r].z, pa[r].w, h23_, l23_);                                                      \
         uint2 *d_ = (uint2 *)&As[(a_kq >> 1) * BM + a_row + 64 * r] + (a_kq & 1);                          \
         d_[0] = make_uint2(h01_, h23_);                                                                    \
-        d_[2 * 4 * BM] = make_uint2(m01_, m23_);                                                           \
-        d_[2 * 8 * BM] = make_uint2(l01_, l23_);                                                           \
+        d_[2 * 4 * BM] = make_uint2(l01_, l23_);                                                           \
     }
     D1_FETCH(0, 0)
 #pragma unroll 1
@@ -1580,33 +1584,30 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1(const float *__res
         D1_STORE_A()
         __syncthreads();  // also waits for the LDS-DMA of this stage (vmcnt)
         if (st + 1 < NKS) D1_FETCH(st + 1, (st + 1) & 1)
-        bf16x8 ah[MTW], am[MTW], al[MTW];
+        d1_h8 ah[MTW], al[MTW];
 #pragma unroll
         for (int q = 0; q < MTW; ++q) {
             const uint4 *ap = &As[g * BM + (mg * MTW + q) * 16 + n];
-            ah[q] = __builtin_bit_cast(bf16x8, ap[0]);
-            am[q] = __builtin_bit_cast(bf16x8, ap[4 * BM]);
-            al[q] = __builtin_bit_cast(bf16x8, ap[8 * BM]);
+            ah[q] = __builtin_bit_cast(d1_h8, ap[0]);
+            al[q] = __builtin_bit_cast(d1_h8, ap[4 * BM]);
         }
         const uint4 *bp = &Bs[(st & 1) * D1_B16 + nt0 * 64 + lane];
         // n-tiles in groups (the 7th absent on odd waves); within a group the accumulators alternate, so that no
         // MFMA waits for its predecessor
 #define D1_GROUP(I0, CNT)                                                                                             \
     {                                                                                                                 \
-        bf16x8 bh[CNT], bm[CNT], bl[CNT];                                                                             \
+        d1_h8 bh[CNT], bl[CNT];                                                                                       \
         _Pragma("unroll") for (int i = 0; i < CNT; ++i) {                                                             \
             if ((I0) + i == 6 && odd) continue;                                                                       \
-            bh[i] = __builtin_bit_cast(bf16x8, bp[((I0) + i) * 64]);                                                  \
-            bm[i] = __builtin_bit_cast(bf16x8, bp[(D1_NT + (I0) + i) * 64]);                                          \
-            bl[i] = __builtin_bit_cast(bf16x8, bp[(2 * D1_NT + (I0) + i) * 64]);                                      \
+            bh[i] = __builtin_bit_cast(d1_h8, bp[((I0) + i) * 64]);                                                   \
+            bl[i] = __builtin_bit_cast(d1_h8, bp[(D1_NT + (I0) + i) * 64]);                                           \
         }                                                                                                             \
-        D1_TERM(al, bh, I0, CNT) D1_TERM(ah, bl, I0, CNT) D1_TERM(am, bm, I0, CNT)                                     \
-        D1_TERM(am, bh, I0, CNT) D1_TERM(ah, bm, I0, CNT) D1_TERM(ah, bh, I0, CNT)                                     \
+        D1_TERM(al, bh, I0, CNT) D1_TERM(ah, bl, I0, CNT) D1_TERM(ah, bh, I0, CNT)                                     \
     }
 #define D1_TERM(A, B, I0, CNT)                                                                                        \
     _Pragma("unroll") for (int q = 0; q < MTW; ++q)                                                                   \
     _Pragma("unroll") for (int i = 0; i < CNT; ++i) if (!((I0) + i == 6 && odd))                                      \
-        acc[q][(I0) + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[q], B[i], acc[q][(I0) + i], 0, 0, 0);
+        acc[q][(I0) + i] = D1_MFMA(A[q], B[i], acc[q][(I0) + i]);
         if (MTW == 1) {
             D1_GROUP(0, 4)
             D1_GROUP(4, 3)
@@ -1634,27 +1635,30 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1(const float *__res
 // dense1, software-pipelined.  k_enc_dense1 above needs 90 KB of LDS, so ONE workgroup runs per CU, and its stage is a chain --
 // write A, barrier, fetch fragments from LDS, 42 MFMAs per wave, barrier -- in which the matrix pipe idles through every LDS
 // round trip (SQ counters, 8-frame launch: MFMA busy 35 %, waves parked at waitcnt / barrier 51 % of their cycles).  This kernel
-// keeps the one workgroup per CU and gives it the whole LDS: A double-buffered, THREE weight stages (144 KB), so that
+// keeps the one workgroup per CU and gives it the whole LDS: A double-buffered, THREE weight stages, so that
 //   - the fragments of the next group of column tiles (and of the next stage, across the barrier) are in flight while the
 //     current group's MFMAs run: the pipe has work on both sides of the single barrier of a stage;
 //   - the weight DMA runs two stages ahead and the rows of F3 (HBM) two stages ahead in alternating registers; the barrier
-//     waits with vmcnt(6): only the older stage must have landed.
+//     waits with vmcnt(one stage's loads): only the older stage must have landed.
 // The weight DMA, the F3 loads and the A stores are inline asm with hand-counted waits: with a compiler-visible LDS-DMA in the
 // loop hipcc waits vmcnt(0) before every use of a loaded register and before every LDS store, and lgkmcnt(0) before every use
 // of an LDS fragment (measured on a three-line kernel); without one its lgkmcnt arithmetic is exact.  Same products in the same order per accumulator as k_enc_dense1: bit-identical partial sums.
-#define D1P_BSTRIDE (40 * 64)  // uint4 per weight buffer: 39 pieces of 1 KB + the 40th the eighth wave brings along
-#define D1P_NBUF(MTW) ((MTW) == 1 ? 3 : 2)
-#define D1P_LDS_BYTES(MTW) ((2 * 3 * 4 * D1_BM * (MTW) + D1P_NBUF(MTW) * D1P_BSTRIDE) * 16)
-// MTW = 1: 64 rows per workgroup, three weight stages (DMA two stages ahead), 144 KB.  MTW = 2: 128 rows -- every wave owns two
-// row tiles, each weight fragment feeds two MFMAs, and the weight stream from L2 (39 KB per stage and workgroup: 983 MB per
-// 8-frame launch at 64 rows, 7.9 TB/s at 125 us -- the LDS-DMA ceiling of the chip) halves; its stages are twice as long, so
-// two weight buffers (DMA one stage ahead) do: 128 KB.
+#define D1P_BSTRIDE (32 * 64)  // uint4 per weight buffer: 26 pieces of 1 KB + the 6 more the eight waves' 4 pieces each bring along
+#define D1P_NBUF(MTW) 3
+#define D1P_LDS_BYTES(MTW) ((2 * D1_NS * 4 * D1_BM * (MTW) + D1P_NBUF(MTW) * D1P_BSTRIDE) * 16)
+// MTW = 1: 64 rows per workgroup, 112 KB.  MTW = 2: 128 rows, 128 KB -- every wave owns two row tiles, each weight fragment feeds
+// two MFMAs, and the weight stream from L2 halves.  History of the 8-frame launch (24 576 rows): bf16 x 3 with 39 KB stages
+// streamed 983 MB at 64 rows (125 us = 7.9 TB/s, the LDS-DMA ceiling of the chip) and 118 us at 128 rows with TWO weight buffers
+// (all the LDS there was); f16 x 2 (26 KB stages, half the MFMAs) 101 us with two buffers -- a stage then cannot be shorter than
+// one L2 -> LDS round trip, ~2 us under this load, whatever the matrix pipe does -- and 81 us with the third buffer the smaller
+// stages leave room for (319 MB of weights + 201 MB of rows per launch = 6.4 TB/s).
 template <int KTOT, int MTW>
 __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1p(const float *__restrict__ f3, int64_t n_rows_pad,
                                                                const uint4 *__restrict__ wd1x, float *__restrict__ part,
                                                                const caelo_enc_in in) {
-    constexpr int BM = D1_BM * MTW, A16 = 3 * 4 * BM, NBUF = D1P_NBUF(MTW), NKS = KTOT / D1_SPLIT_OF(KTOT) / D1_BK;
-    constexpr int PER_STAGE = 5 + MTW;  // loads a thread has in flight per stage: five DMA pieces + its rows
+    constexpr int BM = D1_BM * MTW, A16 = D1_NS * 4 * BM, NBUF = D1P_NBUF(MTW), NKS = KTOT / D1_SPLIT_OF(KTOT) / D1_BK;
+    constexpr int DMA = 4;              // 1 KB pieces a wave copies per stage (8 waves x 4 = 32 >= 26)
+    constexpr int PER_STAGE = DMA + MTW;  // loads a thread has in flight per stage: its DMA pieces + its rows
     static_assert(MTW == 1 || MTW == 2, "two instances");
     static_assert(NKS % 2 == 0 && NKS >= 6, "stages are unrolled in pairs, the last ones peeled");
     // workgroup -> (row tile, k slice).  De-duplicated launch: only the tiles that hold distinct patches of their frame do work
@@ -1696,12 +1700,12 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1p(const float *__re
     const int a_row = wave * 8 + ((lane >> 1) & 7), a_kq = ((lane >> 4) << 1) | (lane & 1);
     const float *a_src = f3 + (size_t)(row0 + a_row) * KTOT + (size_t)ks0 * D1_BK + a_kq * 4;
     // this wave's middle piece (5 wave + 2) of weight buffer 0 in LDS (the DMA adds 16 x lane itself) and of stage ks0 in memory
-    const uint32_t b_lds = (uint32_t)(uintptr_t)(void __attribute__((address_space(3))) *)(Bs + (5 * wave + 2) * 64);
-    const uint4 *b_mid = wd1x + (size_t)ks0 * D1_B16 + (5 * wave + 2) * 64 + lane;
+    const uint32_t b_lds = (uint32_t)(uintptr_t)(void __attribute__((address_space(3))) *)(Bs + (4 * wave + 1) * 64);
+    const uint4 *b_mid = wd1x + (size_t)ks0 * D1_B16 + (4 * wave + 1) * 64 + lane;
     // LDS byte address of this thread's 8 bytes of A buffer 0, high term ([split][g = a_kq >> 1][row] x 16 B, half a_kq & 1)
     const uint32_t a_lds = (uint32_t)(uintptr_t)(void __attribute__((address_space(3))) *)&As[(a_kq >> 1) * BM + a_row] + (a_kq & 1) * 8;
     f32x4 paA[MTW], paB[MTW];
-    bf16x8 af0[MTW][3], af1[MTW][3], bf0[4][3], bf1[3][3];
+    d1_h8 af0[MTW][D1_NS], af1[MTW][D1_NS], bf0[4][D1_NS], bf1[3][D1_NS];
     // five CONSECUTIVE 1 KB pieces per wave and stage, addressed from the middle one by the instruction's immediate offset (it
     // moves the global and the LDS address alike): one M0 write and one address register per stage instead of five of each.
     // The eighth wave's fifth piece is piece 39 -- the first KB of the next stage (the weight image is padded by one piece),
@@ -1712,7 +1716,7 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1p(const float *__re
         const uint4 *gp_ = b_mid + (size_t)(KS) * D1_B16;                                                        \
         const uint32_t la_ = b_lds + (uint32_t)(BUF) * (D1P_BSTRIDE * 16u);                                      \
         __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"                                                       \
-                         "global_load_lds_dwordx4 %1, off offset:-2048\n\tglobal_load_lds_dwordx4 %1, off offset:-1024\n\t" \
+                         "global_load_lds_dwordx4 %1, off offset:-1024\n\t"                                       \
                          "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"    \
                          "global_load_lds_dwordx4 %1, off offset:2048" : : "s"(la_), "v"(gp_) : "memory");       \
     }
@@ -1730,26 +1734,24 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1p(const float *__re
     // (the stores are inline asm as well: a compiler-visible LDS store is ordered behind every LDS-DMA in flight -- vmcnt(0))
 #define D1P_STORE_A(P, ABUF)                                                                               \
     _Pragma("unroll") for (int r = 0; r < MTW; ++r) {                                                      \
-        uint32_t h01_, m01_, l01_, h23_, m23_, l23_;                                                       \
-        enc_split3_pk(P[r][0], P[r][1], h01_, m01_, l01_);                                                 \
-        enc_split3_pk(P[r][2], P[r][3], h23_, m23_, l23_);                                                 \
-        const unsigned long long dh_ = ((unsigned long long)h23_ << 32) | h01_, dm_ = ((unsigned long long)m23_ << 32) | m01_, \
-                                 dl_ = ((unsigned long long)l23_ << 32) | l01_;                            \
+        uint32_t h01_, l01_, h23_, l23_;                                                                   \
+        enc_split2h_pk(P[r][0], P[r][1], h01_, l01_);                                                      \
+        enc_split2h_pk(P[r][2], P[r][3], h23_, l23_);                                                      \
+        const unsigned long long dh_ = ((unsigned long long)h23_ << 32) | h01_, dl_ = ((unsigned long long)l23_ << 32) | l01_; \
         if (r == 0)                                                                                        \
-            __asm__ volatile("ds_write_b64 %0, %1 offset:%4\n\tds_write_b64 %0, %2 offset:%5\n\tds_write_b64 %0, %3 offset:%6" \
-                             : : "v"(a_lds), "v"(dh_), "v"(dm_), "v"(dl_), "n"((ABUF) * A16 * 16),           \
-                                 "n"((ABUF) * A16 * 16 + 4 * BM * 16), "n"((ABUF) * A16 * 16 + 8 * BM * 16) : "memory"); \
+            __asm__ volatile("ds_write_b64 %0, %1 offset:%3\n\tds_write_b64 %0, %2 offset:%4"               \
+                             : : "v"(a_lds), "v"(dh_), "v"(dl_), "n"((ABUF) * A16 * 16),                     \
+                                 "n"((ABUF) * A16 * 16 + 4 * BM * 16) : "memory");                          \
         else                                                                                               \
-            __asm__ volatile("ds_write_b64 %0, %1 offset:%4\n\tds_write_b64 %0, %2 offset:%5\n\tds_write_b64 %0, %3 offset:%6" \
-                             : : "v"(a_lds), "v"(dh_), "v"(dm_), "v"(dl_), "n"((ABUF) * A16 * 16 + 1024),    \
-                                 "n"((ABUF) * A16 * 16 + 4 * BM * 16 + 1024), "n"((ABUF) * A16 * 16 + 8 * BM * 16 + 1024) : "memory"); \
+            __asm__ volatile("ds_write_b64 %0, %1 offset:%3\n\tds_write_b64 %0, %2 offset:%4"               \
+                             : : "v"(a_lds), "v"(dh_), "v"(dl_), "n"((ABUF) * A16 * 16 + 1024),              \
+                                 "n"((ABUF) * A16 * 16 + 4 * BM * 16 + 1024) : "memory");                   \
     }
 #define D1P_READ_A(AF, ABUF)                                                                               \
     _Pragma("unroll") for (int q = 0; q < MTW; ++q) {                                                      \
         const uint4 *ap_ = &As[(ABUF) * A16 + g * BM + (mg * MTW + q) * 16 + n];                           \
-        AF[q][0] = __builtin_bit_cast(bf16x8, ap_[0]);                                                     \
-        AF[q][1] = __builtin_bit_cast(bf16x8, ap_[4 * BM]);                                                \
-        AF[q][2] = __builtin_bit_cast(bf16x8, ap_[8 * BM]);                                                \
+        AF[q][0] = __builtin_bit_cast(d1_h8, ap_[0]);                                                      \
+        AF[q][1] = __builtin_bit_cast(d1_h8, ap_[4 * BM]);                                                 \
     }
     // column tiles nt0 .. nt0+3 (group 0) and nt0+4 .. nt0+6 (group 1).  Odd waves own six tiles: their seventh accumulator
     // repeats tile 12 and is dropped at the end -- no branches in the stage; the SIMDs that run the odd waves have the idle
@@ -1758,27 +1760,27 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1p(const float *__re
     {                                                                                                      \
         const uint4 *bp_ = &Bs[(BUF) * D1P_BSTRIDE + nt0 * 64 + lane];                                     \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
-        _Pragma("unroll") for (int sp = 0; sp < 3; ++sp) bf0[i][sp] = __builtin_bit_cast(bf16x8, bp_[(sp * D1_NT + i) * 64]); \
+        _Pragma("unroll") for (int sp = 0; sp < D1_NS; ++sp) bf0[i][sp] = __builtin_bit_cast(d1_h8, bp_[(sp * D1_NT + i) * 64]); \
     }
 #define D1P_READ_B1(BUF)                                                                                   \
     {                                                                                                      \
         const uint4 *bp_ = &Bs[(BUF) * D1P_BSTRIDE + lane];                                                \
         _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                    \
             const int t_ = (i == 2 && odd) ? D1_NT - 1 : nt0 + 4 + i;                                      \
-            _Pragma("unroll") for (int sp = 0; sp < 3; ++sp) bf1[i][sp] = __builtin_bit_cast(bf16x8, bp_[(sp * D1_NT + t_) * 64]); \
+            _Pragma("unroll") for (int sp = 0; sp < D1_NS; ++sp) bf1[i][sp] = __builtin_bit_cast(d1_h8, bp_[(sp * D1_NT + t_) * 64]); \
         }                                                                                                  \
     }
-    // smallest terms first (AF / B index: 0 high, 1 middle, 2 low); the accumulators alternate
+    // smallest terms first (AF / B index: 0 high, 1 low); the accumulators alternate
 #define D1P_TERM0(AF, SA, SB)                                                                              \
     _Pragma("unroll") for (int q = 0; q < MTW; ++q)                                                        \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
-        acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[q][SA], bf0[i][SB], acc[q][i], 0, 0, 0);
-#define D1P_MFMA_G0(AF) D1P_TERM0(AF, 2, 0) D1P_TERM0(AF, 0, 2) D1P_TERM0(AF, 1, 1) D1P_TERM0(AF, 1, 0) D1P_TERM0(AF, 0, 1) D1P_TERM0(AF, 0, 0)
+        acc[q][i] = D1_MFMA(AF[q][SA], bf0[i][SB], acc[q][i]);
+#define D1P_MFMA_G0(AF) D1P_TERM0(AF, 1, 0) D1P_TERM0(AF, 0, 1) D1P_TERM0(AF, 0, 0)
 #define D1P_TERM1(AF, SA, SB)                                                                              \
     _Pragma("unroll") for (int q = 0; q < MTW; ++q)                                                        \
     _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                          \
-        acc[q][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[q][SA], bf1[i][SB], acc[q][4 + i], 0, 0, 0);
-#define D1P_MFMA_G1(AF) D1P_TERM1(AF, 2, 0) D1P_TERM1(AF, 0, 2) D1P_TERM1(AF, 1, 1) D1P_TERM1(AF, 1, 0) D1P_TERM1(AF, 0, 1) D1P_TERM1(AF, 0, 0)
+        acc[q][4 + i] = D1_MFMA(AF[q][SA], bf1[i][SB], acc[q][4 + i]);
+#define D1P_MFMA_G1(AF) D1P_TERM1(AF, 1, 0) D1P_TERM1(AF, 0, 1) D1P_TERM1(AF, 0, 0)
     // One stage ST whose successor exists.  On entry: bf0 / AFC hold (or are receiving) stage ST's first group and A fragments;
     // in flight, oldest first: weight DMA ST+1 (5), rows ST+1 (registers PN), then YOUNGER more loads of later stages.
     // ISSUE: start DMA ST+NBUF (into the buffer stage ST leaves) and its rows (into PN).  BC / BN: weight buffers of ST / ST+1.
@@ -1803,56 +1805,34 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1p(const float *__re
         D1P_MFMA_G1(AFC)                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
     }
-    if (MTW == 1) {
-        D1P_FETCH_B(0, 0)
-        D1P_LOAD_A(paA, 0)
-        D1P_FETCH_B(1, 1)
-        D1P_LOAD_A(paB, 1)
-        D1P_FETCH_B(2, 2)
-        D1P_WAIT_A(paA, PER_STAGE + 5)  // stage 0: its weights (older) and its rows
-        D1P_STORE_A(paA, 0)
-        D1P_LOAD_A(paA, 2)
-    } else {
-        D1P_FETCH_B(0, 0)
-        D1P_LOAD_A(paA, 0)
-        D1P_FETCH_B(1, 1)
-        D1P_WAIT_A(paA, 5)
-        D1P_STORE_A(paA, 0)
-        D1P_LOAD_A(paA, 1)
-    }
+    D1P_FETCH_B(0, 0)
+    D1P_LOAD_A(paA, 0)
+    D1P_FETCH_B(1, 1)
+    D1P_LOAD_A(paB, 1)
+    D1P_FETCH_B(2, 2)
+    D1P_WAIT_A(paA, PER_STAGE + DMA)  // stage 0: its weights (older) and its rows
+    D1P_STORE_A(paA, 0)
+    D1P_LOAD_A(paA, 2)
     __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     D1P_READ_A(af0, 0)
     D1P_READ_B0(0)
-    if (MTW == 1) {
-        int b0 = 0;  // weight buffer of stage st (st % 3)
+    int b0 = 0;  // weight buffer of stage st (st % 3)
 #pragma unroll 1
-        for (int st = 0; st < NKS - 4; st += 2) {
-            const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
-            D1P_STAGE(st, af0, af1, paB, 1, b0, b1, PER_STAGE, true)
-            D1P_STAGE(st + 1, af1, af0, paA, 0, b1, b2, PER_STAGE, true)
-            b0 = b2;
-        }
-        constexpr int c0 = (NKS - 4) % 3, c1 = (NKS - 3) % 3, c2 = (NKS - 2) % 3, c3 = (NKS - 1) % 3;
-        D1P_STAGE(NKS - 4, af0, af1, paB, 1, c0, c1, PER_STAGE, true)
-        D1P_STAGE(NKS - 3, af1, af0, paA, 0, c1, c2, PER_STAGE, false)
-        D1P_STAGE(NKS - 2, af0, af1, paB, 1, c2, c3, 0, false)
-        // the last stage: its first group and A fragments are on their way, nothing to prepare
-        D1P_READ_B1(c3)
-        __builtin_amdgcn_sched_barrier(0);
-        D1P_MFMA_G0(af1)
-        D1P_MFMA_G1(af1)
-    } else {
-#pragma unroll 1
-        for (int st = 0; st < NKS - 2; st += 2) {
-            D1P_STAGE(st, af0, af1, paA, 1, 0, 1, 0, true)
-            D1P_STAGE(st + 1, af1, af0, paA, 0, 1, 0, 0, true)
-        }
-        D1P_STAGE(NKS - 2, af0, af1, paA, 1, 0, 1, 0, false)
-        D1P_READ_B1(1)
-        __builtin_amdgcn_sched_barrier(0);
-        D1P_MFMA_G0(af1)
-        D1P_MFMA_G1(af1)
+    for (int st = 0; st < NKS - 4; st += 2) {
+        const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+        D1P_STAGE(st, af0, af1, paB, 1, b0, b1, PER_STAGE, true)
+        D1P_STAGE(st + 1, af1, af0, paA, 0, b1, b2, PER_STAGE, true)
+        b0 = b2;
     }
+    constexpr int c0 = (NKS - 4) % 3, c1 = (NKS - 3) % 3, c2 = (NKS - 2) % 3, c3 = (NKS - 1) % 3;
+    D1P_STAGE(NKS - 4, af0, af1, paB, 1, c0, c1, PER_STAGE, true)
+    D1P_STAGE(NKS - 3, af1, af0, paA, 0, c1, c2, PER_STAGE, false)
+    D1P_STAGE(NKS - 2, af0, af1, paB, 1, c2, c3, 0, false)
+    // the last stage: its first group and A fragments are on their way, nothing to prepare
+    D1P_READ_B1(c3)
+    __builtin_amdgcn_sched_barrier(0);
+    D1P_MFMA_G0(af1)
+    D1P_MFMA_G1(af1)
     // C rows 4g + r of each tile
 #pragma unroll
     for (int q = 0; q < MTW; ++q)
