@@ -113,7 +113,7 @@ int caelo_clear_many_set(const caelo_clear_list *lists, int n_frames, hipStream_
 // fused extract
 // ------------------------------------------------------------------------------------------------
 struct ExtractLayout {
-    size_t ring, counter, winner, resp, cand, cand_count, bits, dd, enc, total;
+    size_t ring, winner, resp, cand, cand_count, bits, dd, enc, total;
 };
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -122,9 +122,8 @@ static ExtractLayout extract_layout() {
     ExtractLayout L;
     size_t off = 0;
     const size_t npix = (size_t)CAELO_RING_H * CAELO_RING_W;
-    // winner | counter | cand_count are cleared together: keep them adjacent
+    // winner | cand_count are cleared together: keep them adjacent
     L.winner = off; off += align256(npix * 4);
-    L.counter = off; off += align256(npix * 4);
     L.cand_count = off; off += 256;
     L.ring = off; off += align256(npix * CAELO_RING_C * 4);
     L.resp = off; off += align256((size_t)CAELO_NET_H * CAELO_NET_W * 8 * 4);
@@ -177,7 +176,7 @@ int extract_front_set(const caelo_extract_args *args, int n, hipStream_t s, hipS
         maps[i] = a.map;
         frame_dev_set_map(d, a.map);
         d.pc = a.pc; d.n = a.n; d.pc_stride = 4; d.dist_c = a.dist_channels;
-        d.ring = (float *)(ws + L.ring); d.counter = (int32_t *)(ws + L.counter); d.winner = (int32_t *)(ws + L.winner);
+        d.ring = (float *)(ws + L.ring); d.counter = nullptr; d.winner = (int32_t *)(ws + L.winner);  // (occupied = has a winner)
         d.resp = (float *)(ws + L.resp); d.cand = (unsigned long long *)(ws + L.cand); d.cand_count = (int32_t *)(ws + L.cand_count);
         d.key_pixels = a.key_pixels; d.key_pts = a.key_pts; d.kp_ld = a.kp_ld; d.valid = a.valid; d.valid_ld = a.valid_ld;
         d.n_key = a.n_key; d.flags = a.flags; d.status = a.status;
@@ -185,8 +184,8 @@ int extract_front_set(const caelo_extract_args *args, int n, hipStream_t s, hipS
         d.dd = dd ? (DedupScratch *)(ws + L.dd) : nullptr;
         // ---- one clear for everything the frame accumulates into
         cl[i].n = 0;
-        cl[i].item[cl[i].n++] = {d.winner, L.counter - L.winner, 0xFFFFFFFFu};
-        cl[i].item[cl[i].n++] = {d.counter, L.ring - L.counter, 0u};  // counter | cand_count
+        cl[i].item[cl[i].n++] = {d.winner, L.cand_count - L.winner, 0xFFFFFFFFu};
+        cl[i].item[cl[i].n++] = {d.cand_count, L.ring - L.cand_count, 0u};
         cl[i].item[cl[i].n++] = {a.status, 16, 0u};  // status is int32[4], 16-byte aligned (word 0 carries the bits)
         if (exact_vox) vox_clear_items(a.map, 1, cl[i]);
         dedup_clear_item(ws + L.dd, cl[i]);

@@ -65,16 +65,22 @@ CAELO_API int caelo_lane_faults(caelo_ctx *c, int64_t *count_host) {
     return CAELO_OK;
 }
 
+// k_respond_mfma's per-lane operand fragments live behind the raw weights in ctx->resp_w
+#define RESP_FRAGS 34                 // a1[2][7], c1[2][4], a2[8], c2[4]
+#define RESP_FRAG_OFF 1280            // floats into ctx->resp_w (behind the 1160 raw weights)
+static void respond_fragments(const float *w1, const float *b1, const float *w2, const float *b2, float *out);
+
 CAELO_API int caelo_set_respond_weights(caelo_ctx *c, const float *w1, const float *b1, const float *w2,
                                         const float *b2) {
     CAELO_REQUIRE(c && w1 && b1 && w2 && b2, "null argument");
-    const size_t n = 27 * 32 + 32 + 32 * 8 + 8;
+    const size_t n = RESP_FRAG_OFF + RESP_FRAGS * 64;  // the raw weights (1160 floats), then k_respond_mfma's per-lane fragments
     if (!c->resp_w) CAELO_HIP(hipMalloc(&c->resp_w, n * sizeof(float)));
-    float host[27 * 32 + 32 + 32 * 8 + 8];
+    float host[RESP_FRAG_OFF + RESP_FRAGS * 64] = {0};
     memcpy(host, w1, 27 * 32 * 4);
     memcpy(host + 864, b1, 32 * 4);
     memcpy(host + 896, w2, 256 * 4);
     memcpy(host + 1152, b2, 8 * 4);
+    respond_fragments(w1, b1, w2, b2, host + RESP_FRAG_OFF);
     CAELO_HIP(hipMemcpy(c->resp_w, host, n * sizeof(float), hipMemcpyHostToDevice));
     c->has_resp = true;
     return CAELO_OK;
@@ -111,7 +117,8 @@ __global__ void __launch_bounds__(256) k_project_points(const caelo_frame_set fs
     }
     const int pix = row * CAELO_RING_W + col;
     atomicMax(&winner[pix], (int32_t)i);
-    atomicAdd(&counter[pix], 1);                                                      // :93
+    if (counter) atomicAdd(&counter[pix], 1);                                         // :93 (the fused path keeps no counts:
+                                                                                      //  a pixel is occupied iff it has a winner)
 }
 
 __global__ void __launch_bounds__(256) k_ring_fill(const caelo_frame_set fs) {
@@ -230,6 +237,163 @@ __global__ void __launch_bounds__(256) k_respond(const caelo_frame_set fs, int i
     dst[1] = make_float4(o[4], o[5], o[6], o[7]);
 }
 
+// The same layer on the f32 matrix pipe.  v_mfma_f32_16x16x4_f32 adds its four products to the accumulator as a chain of fused
+// multiply-adds in ascending k (tools/micro/mfma_f32_order.hip: 0 of 1 M results differ from fmaf(a3,b3,fmaf(a2,b2,fmaf(a1,b1,
+// fmaf(a0,b0,c)))), wide exponent ranges included) -- so a GEMM whose k runs in the oracle's canonical order is bit-identical
+// to k_respond.  What it buys is modest: the f32 matrix instruction and the VALU share a datapath (same micro-benchmark: eight
+// MFMAs + 64 v_fma_f32 per step take the SUM of their times with four waves per SIMD), so the layer's 1.26 M MFMAs (18.4 us
+// per 8 frames at 32 cycles each) and everything else the waves execute add up: 37 us (k_respond) -> 31 us.
+// Transposed GEMMs, D[channel][pixel], so that layer 1's accumulators ARE layer 2's B operands (no shuffle, no LDS):
+//   layer 1  A = W1^T tile [16 channels][4 k], B = taps [4 k][16 pixels], k = (ky, kx, ci) ascending + one zero pad, C = b1;
+//            accumulator row 4g + r of tile t is made channel 16t + 4r + g (a row permutation of W1^T), so that
+//   layer 2  step s = 4t + r takes register r of tile t as B: lane group g then holds channel 4s + g -- k ascending again;
+//            A = W2^T [8 outputs (+8 idle rows)][4 k], C = b2.
+// A tap outside the image enters as 0: fmaf(0, w, acc) = acc, the skipped tap of k_respond.
+// One WAVE per workgroup: it walks the 32-pixel blocks blockIdx.x, + gridDim.x, ... of its row, staging the three input rows
+// of a block (+ one pixel either side, channels 0..2, zero outside the image) in its own LDS with coalesced loads -- gathering
+// the taps from memory is 28 scattered loads per lane, 42 us per 8 frames, slower than the VALU kernel -- and the next block's
+// rows are in flight while this block's MFMAs run.  No workgroup barrier: the waves of a SIMD drift apart, and one wave's loads /
+// address arithmetic / relu run under the other's MFMAs (four waves behind one barrier: matrix pipe 54 % busy).
+// The per-lane operand fragments come ready-made from caelo_set_respond_weights (RESP_FRAGS floats per lane).
+#define RESP_PT 2                      // 16-pixel tiles per block
+#define RESP_BPX (16 * RESP_PT)        // pixels per block
+#define RESP_ROW ((RESP_BPX + 2) * 3)  // floats of a staged row: the block + one pixel either side, 3 channels
+#define RESP_STAGE (3 * RESP_ROW)      // floats of a staged block
+typedef float resp_f4 __attribute__((ext_vector_type(4)));
+
+// host: the fragment image, [RESP_FRAGS][64 lanes]
+static void respond_fragments(const float *w1, const float *b1, const float *w2, const float *b2, float *out) {
+    for (int lane = 0; lane < 64; ++lane) {
+        const int g = lane >> 4, n = lane & 15;
+        int f = 0;
+        for (int t = 0; t < 2; ++t)
+            for (int s = 0; s < 7; ++s) {
+                const int k = 4 * s + g;
+                out[(f++) * 64 + lane] = k < 27 ? w1[k * 32 + 16 * t + 4 * (n & 3) + (n >> 2)] : 0.0f;
+            }
+        for (int t = 0; t < 2; ++t)
+            for (int r = 0; r < 4; ++r) out[(f++) * 64 + lane] = b1[16 * t + 4 * r + g];
+        for (int s = 0; s < 8; ++s) out[(f++) * 64 + lane] = n < 8 ? w2[(4 * s + g) * 8 + n] : 0.0f;
+        for (int r = 0; r < 4; ++r) out[(f++) * 64 + lane] = g < 2 ? b2[4 * g + r] : 0.0f;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_respond_mfma(const caelo_frame_set fs, int in_w, int in_c, const float *__restrict__ wts) {
+    const float *__restrict__ in = fs.f[blockIdx.z].ring;
+    float *__restrict__ resp = fs.f[blockIdx.z].resp;
+    const int lane = threadIdx.x, g = lane >> 4, n = lane & 15;
+    const int y = blockIdx.y;
+    constexpr int NBLK = CAELO_NET_W / RESP_BPX, NLD = (RESP_STAGE + 63) / 64;
+    __shared__ float s_in[2][((RESP_STAGE + 63) / 64) * 64];  // (padded: every lane stores NLD elements)
+    // staging: element i = lane + 64 q of [row 3][pixel RESP_BPX + 2][channel 3]; everything but the block's column is loop-invariant
+    int goff[NLD];
+    unsigned int edge = 0u;  // bit q: the element is the left halo pixel; bit 16 + q: the right one
+    float v[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int i = lane + 64 * q;
+        const int row = i / RESP_ROW, j = i - row * RESP_ROW, px = j / 3, ci = j - px * 3;
+        const int yy = y + row - 1;
+        const bool ok = i < RESP_STAGE && (unsigned)yy < (unsigned)CAELO_NET_H;
+        goff[q] = ok ? (yy * in_w + px - 1) * in_c + ci : -1;
+        edge |= (px == 0 ? 1u : 0u) << q | (px == RESP_BPX + 1 ? 1u : 0u) << (16 + q);
+    }
+    // branch-free through a buffer descriptor: an element outside the image gets an offset past the end of the buffer and the
+    // range check returns 0.  (Written as `ok ? in[off] : 0`, hipcc sinks every load under its condition: a branch and an
+    // s_waitcnt vmcnt(0) per element -- ten serial memory round trips per block.)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, CAELO_NET_H * in_w * in_c * 4, 0x00020000);
+#define RESP_LOAD(BLK)                                                                                            \
+    _Pragma("unroll") for (int q = 0; q < NLD; ++q) {                                                              \
+        const unsigned int hide = ((BLK) == 0 ? edge : 0u) | ((BLK) == NBLK - 1 ? edge >> 16 : 0u);               \
+        const bool ok_ = goff[q] >= 0 && !((hide >> q) & 1u);                                                     \
+        const int ob_ = ok_ ? (goff[q] + (BLK) * RESP_BPX * in_c) * 4 : 0x7FFFFFF0;                               \
+        v[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ob_, 0, 0));                  \
+    }
+#define RESP_STORE(BUF)                                                                                           \
+    _Pragma("unroll") for (int q = 0; q < NLD; ++q) s_in[BUF][lane + 64 * q] = v[q];
+    int blk = blockIdx.x, buf = 0;
+    RESP_LOAD(blk)  // (in flight under the fragment loads below)
+    const float *fr = wts + RESP_FRAG_OFF + lane;
+    float a1[2][7], a2[8];
+    resp_f4 c1[2], c2;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 7; ++s) a1[t][s] = fr[(t * 7 + s) * 64];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c1[t][r] = fr[(14 + t * 4 + r) * 64];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) a2[s] = fr[(22 + s) * 64];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c2[r] = fr[(30 + r) * 64];
+    int loff[7];  // this lane's tap of step s: staged row ky, pixel n + kx (relative to the block's column - 1), channel ci
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        const int k = 4 * s + g;
+        const int kc = k < 27 ? k : 26;  // (the pad's weight is 0: any finite tap does)
+        const int ky = kc / 9, kx = (kc / 3) % 3, ci = kc % 3;
+        loff[s] = ky * RESP_ROW + (n + kx) * 3 + ci;
+    }
+    // every fragment has landed before the loop: left to itself hipcc waits for the last of them INSIDE the loop with vmcnt(0),
+    // i.e. for the rows just requested for the next block as well -- a memory round trip per block
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int s = 0; s < 7; ++s) __asm__ volatile("" : "+v"(a1[t][s]));
+        __asm__ volatile("" : "+v"(c1[t]));
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) __asm__ volatile("" : "+v"(a2[s]));
+    __asm__ volatile("" : "+v"(c2));
+    RESP_STORE(0)
+    for (; blk < NBLK; blk += gridDim.x, buf ^= 1) {
+        const bool more = blk + (int)gridDim.x < NBLK;
+        if (more) RESP_LOAD(blk + gridDim.x)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the staged block is complete (one wave: program order + this)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float b[RESP_PT][7];
+#pragma unroll
+        for (int pt = 0; pt < RESP_PT; ++pt)
+#pragma unroll
+            for (int s = 0; s < 7; ++s) b[pt][s] = s_in[buf][loff[s] + 48 * pt];
+        __builtin_amdgcn_sched_barrier(0);  // all taps requested before the first MFMA (hipcc otherwise reads, waits, multiplies)
+        // independent accumulator chains (pixel tiles x channel tiles in layer 1, pixel tiles in layer 2) issued round robin
+        resp_f4 h[RESP_PT][2], o[RESP_PT];
+#pragma unroll
+        for (int pt = 0; pt < RESP_PT; ++pt) { h[pt][0] = c1[0]; h[pt][1] = c1[1]; o[pt] = c2; }
+#pragma unroll
+        for (int s = 0; s < 7; ++s)
+#pragma unroll
+            for (int pt = 0; pt < RESP_PT; ++pt)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) h[pt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t][s], b[pt][s], h[pt][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int pt = 0; pt < RESP_PT; ++pt) {
+                    const float hv = h[pt][t][r] > 0.0f ? h[pt][t][r] : 0.0f;
+                    o[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[4 * t + r], hv, o[pt], 0, 0, 0);
+                }
+        if (g < 2) {
+#pragma unroll
+            for (int pt = 0; pt < RESP_PT; ++pt) {
+                const int x = blk * RESP_BPX + 16 * pt + n;
+                *(float4 *)(resp + ((int64_t)y * CAELO_NET_W + x) * 8 + 4 * g) =
+                    make_float4(o[pt][0] > 0.0f ? o[pt][0] : 0.0f, o[pt][1] > 0.0f ? o[pt][1] : 0.0f, o[pt][2] > 0.0f ? o[pt][2] : 0.0f,
+                                o[pt][3] > 0.0f ? o[pt][3] : 0.0f);
+            }
+        }
+        if (more) RESP_STORE(buf ^ 1)  // (this wave read that buffer an iteration ago: program order)
+    }
+#undef RESP_LOAD
+#undef RESP_STORE
+}
+
 int ring_respond_launch(caelo_ctx *c, const float *in, int in_w, int in_c, float *resp, hipStream_t s) {
     caelo_frame_set fs = {};
     fs.n = 1;
@@ -238,8 +402,17 @@ int ring_respond_launch(caelo_ctx *c, const float *in, int in_w, int in_c, float
 }
 
 int ring_respond_set(caelo_ctx *c, const caelo_frame_set &fs, int in_w, int in_c, hipStream_t s) {
-    dim3 grid((CAELO_NET_W + 255) / 256, CAELO_NET_H, fs.n);
-    k_respond<<<grid, 256, 0, s>>>(fs, in_w, in_c, c->resp_w);
+    static_assert(CAELO_NET_W % RESP_BPX == 0, "k_respond_mfma has no partial blocks");
+    // CAELO_RESPOND=valu: the one-thread-per-pixel kernel (bit-identical; the timing reference)
+    static const bool valu = getenv("CAELO_RESPOND") && !strcmp(getenv("CAELO_RESPOND"), "valu");
+    if (valu) k_respond<<<dim3((CAELO_NET_W + 255) / 256, CAELO_NET_H, fs.n), 256, 0, s>>>(fs, in_w, in_c, c->resp_w);
+    else {
+        // Waves per row.  The dispatcher spreads a grid evenly over the 1024 SIMDs (tools/micro/wave_placement.hip), so the grid
+        // should be a multiple of 1024 waves with equal work each: 8 frames x 64 rows x 8 = 4096 waves of 7 blocks (2048 waves
+        // of 64-pixel blocks left 109 SIMDs with three waves and 109 with one: the matrix pipe of the former set the time)
+        const unsigned gx = fs.n >= 4 ? 8u : (fs.n >= 2 ? 28u : 56u);
+        k_respond_mfma<<<dim3(gx, CAELO_NET_H, fs.n), 64, 0, s>>>(fs, in_w, in_c, c->resp_w);
+    }
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }
@@ -277,7 +450,7 @@ __global__ void __launch_bounds__(256) k_kp_score(const caelo_frame_set fs, int 
     const caelo_frame_dev &F = fs.f[blockIdx.z];
     const float *__restrict__ ring = F.ring;
     const int dist_c = F.dist_c;
-    const int32_t *__restrict__ counter = F.counter;
+    const int32_t *__restrict__ counter = F.counter, *__restrict__ winner = F.winner;  // counter == null: occupied = has a winner
     const float *__restrict__ resp = F.resp;
     unsigned long long *__restrict__ cand = F.cand;
     int32_t *cand_count = F.cand_count;
@@ -294,7 +467,7 @@ __global__ void __launch_bounds__(256) k_kp_score(const caelo_frame_set fs, int 
             const float4 *rq4 = (const float4 *)(resp + ((int64_t)yy * CAELO_NET_W + xx) * 8);
             a = rq4[0];
             b = rq4[1];
-            occ = counter[yy * cnt_w + xx] > 0;
+            occ = counter ? counter[yy * cnt_w + xx] > 0 : winner[yy * cnt_w + xx] >= 0;
         }
         sR[2 * i] = a;
         sR[2 * i + 1] = b;
@@ -329,11 +502,12 @@ __global__ void __launch_bounds__(256) k_kp_score(const caelo_frame_set fs, int 
                 d = __fsub_rn(qb.w, pb.w); const float s7 = __fmul_rn(d, d);
                 const float t = __fadd_rn(__fadd_rn(__fadd_rn(s0, s1), __fadd_rn(s2, s3)),
                                           __fadd_rn(__fadd_rn(s4, s5), __fadd_rn(s6, s7)));
-                const float nd = sqrtf(t);
-                if (!have || nd < best) { best = nd; have = true; }
+                // the square root is monotone (correctly rounded): min over sqrt(t) = sqrt(min t), taken once below
+                if (!have || t < best) { best = t; have = true; }
                 ++cnt;
             }
         }
+        best = sqrtf(best);
         if (cnt >= 5 && (double)best > 0.2) {  // :186, :126,:199
             const float *px = ring + ((int64_t)y * ring_w + x) * ring_c;
             float d2 = __fmul_rn(px[0], px[0]);
@@ -398,7 +572,148 @@ __device__ unsigned long long radix_select_threshold(const unsigned long long *c
     return *s_prefix;
 }
 
-__global__ void __launch_bounds__(SEL_THREADS) k_kp_select(const caelo_frame_set fs, int ring_w, int ring_c) {
+// ---- the multi-workgroup form (k_kp_hist -> k_kp_gather -> k_kp_emit, KP_WGS workgroups per frame each) ----------------------
+// One 1024-thread workgroup reads the ~50 k candidate keys of a frame twice at the bandwidth of one CU and then sorts 2048 keys
+// on one CU: 34 us for a kernel that occupies 8 of 256 CUs.  Spread over KP_WGS workgroups per frame:
+//   k_kp_hist    every workgroup histograms its share of the keys in LDS (the same 2048 bins) and writes its partial histogram;
+//   k_kp_gather  every workgroup adds the partial histograms up, finds the cut bin (all of them get the same one), and appends
+//                the keys of its share from that bin upwards to the frame's selection list (one global atomic per workgroup);
+//   k_kp_emit    every workgroup stages the ~1 100 selected keys in LDS and RANKS its share of them (keys are unique: rank =
+//                number of smaller keys = position in the stable argsort of SphericalRing.py:194); rank decides the output row.
+// Scratch: the tail of the candidate buffer (candidates only come from rows 8..55: entries past 48 x 1792 are never written).
+// A frame the bins cannot split (more than SEL_N keys from the cut bin upwards -- pathological ties) is left to the
+// single-workgroup kernel below, which otherwise returns at once; so is nothing else: M <= 1025 needs no threshold at all.
+#define KP_WGS 16
+#define KP_SCRATCH_OFF (48 * CAELO_NET_W)                                    // u64 entries into `cand`
+#define KP_SEL_OFF (KP_SCRATCH_OFF + KP_WGS * CAELO_KP_HIST_BINS / 2)        // partial histograms: KP_WGS x 2048 u32
+static_assert(KP_SEL_OFF + SEL_N <= CAELO_NET_H * CAELO_NET_W, "selection scratch must fit behind the candidates");
+static_assert(CAELO_KP_HIST_BINS == 2 * SEL_THREADS, "a thread owns two bins");
+#define KP_CC_NSEL 1       // cand_count[1]: keys on the selection list
+#define KP_CC_STATE 2      // cand_count[2]: 0 = not decided, else
+#define KP_STATE_LISTED 1  //   the selection list holds every key from the cut bin upwards
+#define KP_STATE_FALLBACK 2
+
+__global__ void __launch_bounds__(SEL_THREADS) k_kp_hist(const caelo_frame_set fs) {
+    const caelo_frame_dev &F = fs.f[blockIdx.z];
+    const int M = *F.cand_count, tid = threadIdx.x;
+    if (M <= 1025) return;
+    __shared__ unsigned int lh[CAELO_KP_HIST_BINS];
+    lh[2 * tid] = 0u;
+    lh[2 * tid + 1] = 0u;
+    __syncthreads();
+    const int per = (M + KP_WGS - 1) / KP_WGS, i0 = blockIdx.x * per, i1 = min(M, i0 + per);
+    for (int i = i0 + tid; i < i1; i += SEL_THREADS) atomicAdd(&lh[kp_bin((unsigned int)(F.cand[i] >> 32))], 1u);
+    __syncthreads();
+    uint2 *out = (uint2 *)(F.cand + KP_SCRATCH_OFF) + (size_t)blockIdx.x * SEL_THREADS;
+    out[tid] = make_uint2(lh[2 * tid], lh[2 * tid + 1]);
+}
+
+// inclusive suffix sum over the 1024 threads of the workgroup (wave shuffles + one LDS hop)
+__device__ inline unsigned int kp_suffix_sum(unsigned int v, unsigned int *s_wave) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int up = __shfl_down(v, o);
+        if (lane + o < 64) v += up;
+    }
+    if (lane == 0) s_wave[wave] = v;  // the wave's total
+    __syncthreads();
+    unsigned int above = 0u;
+    for (int w = wave + 1; w < SEL_THREADS / 64; ++w) above += s_wave[w];
+    return v + above;
+}
+
+__global__ void __launch_bounds__(SEL_THREADS) k_kp_gather(const caelo_frame_set fs) {
+    const caelo_frame_dev &F = fs.f[blockIdx.z];
+    const int M = *F.cand_count, tid = threadIdx.x;
+    if (M <= 1025) return;
+    __shared__ unsigned int s_wave[SEL_THREADS / 64];
+    __shared__ int s_cut[2], s_n, s_base;
+    __shared__ unsigned long long s_keys[SEL_N];
+    const uint2 *ph = (const uint2 *)(F.cand + KP_SCRATCH_OFF);
+    uint2 hb = make_uint2(0u, 0u);
+#pragma unroll 8
+    for (int w = 0; w < KP_WGS; ++w) {
+        const uint2 t = ph[(size_t)w * SEL_THREADS + tid];
+        hb.x += t.x;
+        hb.y += t.y;
+    }
+    if (tid == 0) s_n = 0;
+    const unsigned int incl = kp_suffix_sum(hb.x + hb.y, s_wave);  // keys in bins >= 2 tid
+    const unsigned int above = incl - hb.x - hb.y;                 // keys in bins > 2 tid + 1
+    const unsigned int keep = 1025u;
+    if (above < keep && incl >= keep) {  // exactly one thread: the cut is bin 2t+1 if that alone reaches `keep`, else bin 2t
+        if (above + hb.y >= keep) { s_cut[0] = 2 * tid + 1; s_cut[1] = (int)(above + hb.y); }
+        else { s_cut[0] = 2 * tid; s_cut[1] = (int)incl; }
+    }
+    __syncthreads();
+    const int cutbin = s_cut[0], nsel = s_cut[1];
+    if (nsel > SEL_N) {
+        if (blockIdx.x == 0 && tid == 0) F.cand_count[KP_CC_STATE] = KP_STATE_FALLBACK;
+        return;
+    }
+    const unsigned long long thresh = cutbin == 0 ? 0ull : ((unsigned long long)(KP_BIN_BASE + cutbin) << 48);
+    const int per = (M + KP_WGS - 1) / KP_WGS, i0 = blockIdx.x * per, i1 = min(M, i0 + per);
+    for (int i = i0 + tid; i < i1; i += SEL_THREADS) {
+        const unsigned long long k = F.cand[i];
+        if (k >= thresh) s_keys[atomicAdd(&s_n, 1)] = k;  // (at most nsel <= SEL_N keys in the whole frame)
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (tid == 0) {
+        s_base = n ? atomicAdd(&F.cand_count[KP_CC_NSEL], n) : 0;
+        if (blockIdx.x == 0) F.cand_count[KP_CC_STATE] = KP_STATE_LISTED;
+    }
+    __syncthreads();
+    unsigned long long *sel = F.cand + KP_SEL_OFF;
+    for (int i = tid; i < n; i += SEL_THREADS) sel[s_base + i] = s_keys[i];
+}
+
+__global__ void __launch_bounds__(SEL_THREADS) k_kp_emit(const caelo_frame_set fs, int ring_w, int ring_c) {
+    const caelo_frame_dev &F = fs.f[blockIdx.z];
+    const int M = *F.cand_count, tid = threadIdx.x;
+    const int state = F.cand_count[KP_CC_STATE];
+    if (M > 1025 && state != KP_STATE_LISTED) return;  // the single-workgroup kernel does this frame
+    // M <= 1025: every candidate is selected, the candidate list is the selection list
+    const unsigned long long *sel = M > 1025 ? F.cand + KP_SEL_OFF : F.cand;
+    const int nsel = M > 1025 ? F.cand_count[KP_CC_NSEL] : M;
+    const int keep = M < 1025 ? M : 1025;
+    const int K = keep > 0 ? keep - 1 : 0;  // drop the single best (:216,:218)
+    const int first = nsel - keep;           // ranks first .. nsel - 2 are rows 0 .. K - 1
+    __shared__ unsigned long long s_keys[SEL_N];
+    for (int i = tid; i < nsel; i += SEL_THREADS) s_keys[i] = sel[i];
+    __syncthreads();
+    // thread (k = tid >> 4, part = tid & 15): key number blockIdx.x * 64 + k against the keys q = part (mod 16)
+    const int e = blockIdx.x * 64 + (tid >> 4), part = tid & 15;
+    const unsigned long long mine = e < nsel ? s_keys[e] : 0ull;
+    int rank = 0;
+    if (e < nsel)
+        for (int q = part; q < nsel; q += 16) rank += s_keys[q] < mine ? 1 : 0;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) rank += __shfl_xor(rank, o);
+    const int i = rank - first;
+    if (e < nsel && part == 0 && i >= 0 && i < K) {
+        const unsigned idx = (unsigned)(mine & 0xFFFFFFFFull);
+        const int y = idx / CAELO_NET_W, x = idx % CAELO_NET_W;
+        F.key_pixels[2 * i] = y;
+        F.key_pixels[2 * i + 1] = x;
+        const float *px = F.ring + ((int64_t)y * ring_w + x) * ring_c;
+        F.key_pts[(size_t)F.kp_ld * i] = px[0];
+        F.key_pts[(size_t)F.kp_ld * i + 1] = px[1];
+        F.key_pts[(size_t)F.kp_ld * i + 2] = px[2];
+    }
+    if (blockIdx.x == 0) {
+        if (F.valid)
+            for (int r = tid; r < CAELO_MAX_KEYPTS; r += SEL_THREADS) F.valid[(size_t)F.valid_ld * r] = r < K ? 1.0f : 0.0f;
+        if (tid == 0) {
+            *F.n_key = K;
+            if (K <= 50) atomicOr(F.status, CAELO_ST_FEW_KEYPTS);  // :286
+        }
+    }
+}
+
+// The single-workgroup form: everything in one kernel.  only_fallback: the frames the three kernels above left over.
+__global__ void __launch_bounds__(SEL_THREADS) k_kp_select(const caelo_frame_set fs, int ring_w, int ring_c, int only_fallback) {
     const caelo_frame_dev &F = fs.f[blockIdx.z];
     const unsigned long long *__restrict__ cand = F.cand;
     const int32_t *cand_count = F.cand_count;
@@ -416,6 +731,7 @@ __global__ void __launch_bounds__(SEL_THREADS) k_kp_select(const caelo_frame_set
     const int tid = threadIdx.x;
     SEL_STAMP(0);
     const int M = *cand_count;
+    if (only_fallback && cand_count[KP_CC_STATE] != KP_STATE_FALLBACK) return;  // k_kp_hist / _gather / _emit did this frame
     const int keep = M < 1025 ? M : 1025;
     unsigned long long thresh = 0ull;
     if (M > 1025) {
@@ -538,7 +854,17 @@ int ring_keypoints_set(const caelo_frame_set &fs, int ring_w, int ring_c, int cn
     dim3 grid(CAELO_NET_W / KS_COLS, 48 / KS_ROWS, fs.n);
     k_kp_score<<<grid, 256, 0, s>>>(fs, ring_w, ring_c, cnt_w);
     CAELO_LAUNCH_CHECK();
-    k_kp_select<<<dim3(1, 1, fs.n), SEL_THREADS, 0, s>>>(fs, ring_w, ring_c);
+    // CAELO_KP_SELECT=single: the one-workgroup kernel alone (bit-identical; the timing reference)
+    static const bool single = getenv("CAELO_KP_SELECT") && !strcmp(getenv("CAELO_KP_SELECT"), "single");
+    if (!single) {
+        k_kp_hist<<<dim3(KP_WGS, 1, fs.n), SEL_THREADS, 0, s>>>(fs);
+        CAELO_LAUNCH_CHECK();
+        k_kp_gather<<<dim3(KP_WGS, 1, fs.n), SEL_THREADS, 0, s>>>(fs);
+        CAELO_LAUNCH_CHECK();
+        k_kp_emit<<<dim3(SEL_N / 64, 1, fs.n), SEL_THREADS, 0, s>>>(fs, ring_w, ring_c);
+        CAELO_LAUNCH_CHECK();
+    }
+    k_kp_select<<<dim3(1, 1, fs.n), SEL_THREADS, 0, s>>>(fs, ring_w, ring_c, single ? 0 : 1);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }

@@ -427,6 +427,9 @@ __global__ void __launch_bounds__(256) k_vox_points(const caelo_frame_set fs) {
     }
     int st = v.oob ? CAELO_ST_VOXEL_OOB : 0;
     unsigned long long key = CAELO_EMPTY_KEY;
+    // every point's scale-0 voxel, for k_vox_suspects_first (the fused build leaves the exact build's first-touch key table
+    // free; it holds >= 2 entries per point)
+    if (i < n) F.vkeys[0][i] = v.ok ? caelo_pack3(v.g[0], v.g[1], v.g[2]) : CAELO_EMPTY_KEY;
     if (v.ok) {
         bool consistent = true;
 #pragma unroll
@@ -563,16 +566,36 @@ __global__ void __launch_bounds__(256) k_vox_coarse2(const caelo_frame_set fs) {
 // read per workgroup -- when no point of the frame was inconsistent.  (A single kernel whose last workgroup resolves
 // would need an agent-scope release per workgroup: on gfx950 that is an L2 write-back walk, 433 us for 8 frames.)
 // (1) first point of every suspect voxel: smallest index over ALL points of the voxel, consistent ones included
+#define SUSPECT_LDS 128
 __global__ void __launch_bounds__(256) k_vox_suspects_first(const caelo_frame_set fs) {
     const caelo_frame_dev &F = fs.f[blockIdx.z];
-    if (F.counts[6] == 0) return;
+    const int nsp = F.counts[6];
+    if (nsp == 0) return;
+    // A handful of voxels (14 of a 126 k-point scan quantised to 1 mm): the workgroup stages their keys in LDS and every point
+    // compares the key k_vox_points stored for it against them -- no index arithmetic, no table probe per point (both together
+    // were 15.7 us per 8 frames for those 14 voxels).  More inconsistent points than the LDS list holds: probe the table.
+    __shared__ unsigned long long s_key[SUSPECT_LDS];
+    __shared__ uint32_t s_slot[SUSPECT_LDS];
+    const bool listed = nsp <= SUSPECT_LDS;
+    if (listed) {
+        if ((int)threadIdx.x < nsp) {
+            const uint32_t ss = F.sp.list[threadIdx.x].y;
+            s_slot[threadIdx.x] = ss;
+            s_key[threadIdx.x] = F.sp.sp_keys[ss];
+        }
+        __syncthreads();
+    }
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= F.n) return;
-    const float *p = F.pc + i * F.pc_stride;
-    const VoxIdx v = voxel_indices(p[0], p[1], p[2]);
-    if (!v.ok) return;
-    const int ss = table_find(F.sp.sp_keys, F.sp.mask, caelo_pack3(v.g[0], v.g[1], v.g[2]));
-    if (ss >= 0) atomicMin(&F.sp.sp_first[ss], (uint32_t)i);
+    const unsigned long long key = F.vkeys[0][i];
+    if (key == CAELO_EMPTY_KEY) return;
+    if (listed) {
+        for (int e = 0; e < nsp; ++e)  // (several inconsistent points of one voxel repeat its key: the same atomicMin twice)
+            if (s_key[e] == key) { atomicMin(&F.sp.sp_first[s_slot[e]], (uint32_t)i); break; }
+    } else {
+        const int ss = table_find(F.sp.sp_keys, F.sp.mask, key);
+        if (ss >= 0) atomicMin(&F.sp.sp_first[ss], (uint32_t)i);
+    }
 }
 
 // (2) that point's own scale-1 / 2 indices are inserted, exactly what the reference's loop does when it meets the voxel

@@ -115,6 +115,20 @@ def test_keypoints_ragged_and_too_few(api, orc, f0):
         api.GetKeyPtsByAE(f0["ring"], cnt, f0["resp"])
 
 
+def test_keypoints_with_thousands_of_equal_scores(api, orc, f0):
+    """A response image quantised so coarsely that thousands of candidates share one score: more than 2048 keys from the cut
+    bin upwards, which the multi-workgroup selection (k_kp_hist / _gather / _emit) hands to the single-workgroup kernel and its
+    radix select over the full keys.  The stable order of SphericalRing.py:194 (ties by flat index) must survive."""
+    resp = (np.round(f0["resp"] / 8.0) * 8.0).astype(np.float32)
+    o = orc.GetKeyPtsByAE(f0["ring"], f0["cnt"], resp, return_score=True)
+    kp, kpix, _ = api.GetKeyPtsByAE(f0["ring"], f0["cnt"], resp)
+    assert len(kpix) == 1024 and np.array_equal(kpix, o[1]) and np.array_equal(kp, o[0])
+    # how tied it is: the scores of the selected key points hold a handful of distinct values, and far more than 2048
+    # candidates carry the smallest of them or more
+    sel = o[3][o[1][:, 0], o[1][:, 1]]
+    assert len(np.unique(sel)) < 16 and (o[3] >= sel.min()).sum() > 2048
+
+
 def test_keypoints_dense_scan_golden(api, orc, models, scans):
     g = np.load(os.path.join(GOLDEN, "frame_dense128.npz"))
     ring, cnt = api.ProjectPC2SphericalRing(scans(0, 128, 4000))
@@ -993,13 +1007,16 @@ def _variant_hashes(env):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("base,env", [({"CAELO_ENC_S1": "f32"}, {"CAELO_ENC_WAVE": "1"}), ({"CAELO_ENC_S1": "f32"}, {"CAELO_ENC_SPLIT": "1"}),
-                                      ({}, {"CAELO_D1_PLAIN": "1"}), ({}, {"CAELO_D1_WIDE_FROM": "1"})])
+                                      ({}, {"CAELO_D1_PLAIN": "1"}), ({}, {"CAELO_D1_WIDE_FROM": "1"}),
+                                      ({}, {"CAELO_RESPOND": "valu"}), ({}, {"CAELO_KP_SELECT": "single"})])
 def test_stage1_variants_are_bit_identical(engine, base, env):
     """Families of kernels that promise each other's results bit for bit (same sums in the same order):
     * round 2's f32-input stage 1 (CAELO_ENC_S1=f32), its one-wavefront-per-patch form k_enc_stage1w and the two-kernel
       form k_enc_conv1 + k_enc_conv2 -- one P2;
     * k_enc_dense1 (two barriers per stage) and the software-pipelined k_enc_dense1p (the default), whose 128-row instance
-      (CAELO_D1_WIDE_FROM=1: also for one frame) must equal the 64-row one -- one set of partial sums.
+      (CAELO_D1_WIDE_FROM=1: also for one frame) must equal the 64-row one -- one set of partial sums;
+    * the response layer on the f32 matrix pipe (k_respond_mfma, the default) and one thread per pixel (CAELO_RESPOND=valu);
+    * the key point selection spread over workgroups (default) and in one workgroup (CAELO_KP_SELECT=single).
     The frame rows (descriptors + key points) of two scans are hashed in one process per variant.  (The default stage 1,
     k_enc_stage1x, evaluates its products as f16 x 2 splits: it is compared with the f32 family by tolerance in
     test_stage1x_agrees_with_the_f32_kernel and layer by layer in test_encoder_layer_error_budget.)"""
