@@ -84,7 +84,7 @@ struct caelo_voxmap {
     unsigned long long *vkeys[3];
     uint32_t *vfirst[3];
     uint32_t vmask[3];
-    int32_t *counts;  // [16] device ints: [0..2] unique voxels per scale, [4],[5] lengths of list0/list1, [6] length of
+    int32_t *counts;  // [16] device ints: [0..2] unique voxels per scale, [4],[5] lengths of list0/list1 (list0 has holes), [6] length of
                       // sp_list
     uint32_t *list0, *list1;  // slots of the occupied scale-0 / scale-1 bricks, in insertion order (fast path)
     // "Suspect" voxels of the fused build (voxel.hip, k_vox_points): scale-0 voxels holding a point whose own
@@ -345,11 +345,10 @@ __device__ inline void caelo_dedup_insert(unsigned long long word, int lane, int
     const unsigned long long mine = (h << 24) | (unsigned)p;
     uint32_t slot = (uint32_t)(caelo_dd_mix(h) & (DD_SLOTS - 1));
     for (;;) {
-        unsigned long long cur = S->table[slot];
-        if (cur == DD_EMPTY) {
-            cur = atomicCAS(&S->table[slot], DD_EMPTY, mine);
-            if (cur == DD_EMPTY) break;
-        }
+        // compare-and-swap first, no look: one memory round trip for the wave to wait out instead of two (the table is mostly
+        // empty at its load factor, and a wave of k_patches lives ~5 round trips in all)
+        const unsigned long long cur = atomicCAS(&S->table[slot], DD_EMPTY, mine);
+        if (cur == DD_EMPTY) break;
         if ((cur >> 24) == h) {
             // hundreds of patches share a popular pattern: only a smaller index than the one seen needs the atomic (a
             // stale larger value only costs an atomic that changes nothing)
@@ -392,6 +391,21 @@ __device__ inline int caelo_block_reserve(int32_t *gcounter, bool pred, int *s_t
     __syncthreads();
     if (threadIdx.x == 0) s_tmp[1] = s_tmp[0] ? atomicAdd(gcounter, s_tmp[0]) : 0;
     __syncthreads();
+    return s_tmp[1] + wbase + __popcll(m & ((1ull << lane) - 1ull));
+}
+// The same with LDS-only barriers: the caller's own global loads / atomics stay in flight across it (a __syncthreads() waits
+// for them: vmcnt(0)).  s_tmp: __shared__ int[2], not otherwise in use.
+__device__ inline int caelo_block_reserve_async(int32_t *gcounter, bool pred, int *s_tmp) {
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) s_tmp[0] = 0;
+    caelo_lds_barrier();
+    const unsigned long long m = __ballot(pred);
+    int wbase = 0;
+    if (m && lane == __ffsll((long long)m) - 1) wbase = atomicAdd(&s_tmp[0], __popcll(m));
+    if (m) wbase = __shfl(wbase, __ffsll((long long)m) - 1);
+    caelo_lds_barrier();
+    if (threadIdx.x == 0) s_tmp[1] = s_tmp[0] ? atomicAdd(gcounter, s_tmp[0]) : 0;
+    caelo_lds_barrier();
     return s_tmp[1] + wbase + __popcll(m & ((1ull << lane) - 1ull));
 }
 __device__ inline void caelo_block_add(int32_t *gcounter, int value, int *s_tmp) {

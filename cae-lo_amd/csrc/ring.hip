@@ -581,8 +581,8 @@ __device__ unsigned long long radix_select_threshold(const unsigned long long *c
 //   k_kp_emit    every workgroup stages the ~1 100 selected keys in LDS and RANKS its share of them (keys are unique: rank =
 //                number of smaller keys = position in the stable argsort of SphericalRing.py:194); rank decides the output row.
 // Scratch: the tail of the candidate buffer (candidates only come from rows 8..55: entries past 48 x 1792 are never written).
-// A frame the bins cannot split (more than SEL_N keys from the cut bin upwards -- pathological ties) is left to the
-// single-workgroup kernel below, which otherwise returns at once; so is nothing else: M <= 1025 needs no threshold at all.
+// A frame the bins cannot split (more than SEL_N keys from the cut bin upwards -- pathological ties) is done by workgroup 0 of
+// k_kp_emit alone, with the single-workgroup code below; M <= 1025 needs no threshold at all.
 #define KP_WGS 16
 #define KP_SCRATCH_OFF (48 * CAELO_NET_W)                                    // u64 entries into `cand`
 #define KP_SEL_OFF (KP_SCRATCH_OFF + KP_WGS * CAELO_KP_HIST_BINS / 2)        // partial histograms: KP_WGS x 2048 u32
@@ -669,52 +669,10 @@ __global__ void __launch_bounds__(SEL_THREADS) k_kp_gather(const caelo_frame_set
     for (int i = tid; i < n; i += SEL_THREADS) sel[s_base + i] = s_keys[i];
 }
 
-__global__ void __launch_bounds__(SEL_THREADS) k_kp_emit(const caelo_frame_set fs, int ring_w, int ring_c) {
-    const caelo_frame_dev &F = fs.f[blockIdx.z];
-    const int M = *F.cand_count, tid = threadIdx.x;
-    const int state = F.cand_count[KP_CC_STATE];
-    if (M > 1025 && state != KP_STATE_LISTED) return;  // the single-workgroup kernel does this frame
-    // M <= 1025: every candidate is selected, the candidate list is the selection list
-    const unsigned long long *sel = M > 1025 ? F.cand + KP_SEL_OFF : F.cand;
-    const int nsel = M > 1025 ? F.cand_count[KP_CC_NSEL] : M;
-    const int keep = M < 1025 ? M : 1025;
-    const int K = keep > 0 ? keep - 1 : 0;  // drop the single best (:216,:218)
-    const int first = nsel - keep;           // ranks first .. nsel - 2 are rows 0 .. K - 1
-    __shared__ unsigned long long s_keys[SEL_N];
-    for (int i = tid; i < nsel; i += SEL_THREADS) s_keys[i] = sel[i];
-    __syncthreads();
-    // thread (k = tid >> 4, part = tid & 15): key number blockIdx.x * 64 + k against the keys q = part (mod 16)
-    const int e = blockIdx.x * 64 + (tid >> 4), part = tid & 15;
-    const unsigned long long mine = e < nsel ? s_keys[e] : 0ull;
-    int rank = 0;
-    if (e < nsel)
-        for (int q = part; q < nsel; q += 16) rank += s_keys[q] < mine ? 1 : 0;
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) rank += __shfl_xor(rank, o);
-    const int i = rank - first;
-    if (e < nsel && part == 0 && i >= 0 && i < K) {
-        const unsigned idx = (unsigned)(mine & 0xFFFFFFFFull);
-        const int y = idx / CAELO_NET_W, x = idx % CAELO_NET_W;
-        F.key_pixels[2 * i] = y;
-        F.key_pixels[2 * i + 1] = x;
-        const float *px = F.ring + ((int64_t)y * ring_w + x) * ring_c;
-        F.key_pts[(size_t)F.kp_ld * i] = px[0];
-        F.key_pts[(size_t)F.kp_ld * i + 1] = px[1];
-        F.key_pts[(size_t)F.kp_ld * i + 2] = px[2];
-    }
-    if (blockIdx.x == 0) {
-        if (F.valid)
-            for (int r = tid; r < CAELO_MAX_KEYPTS; r += SEL_THREADS) F.valid[(size_t)F.valid_ld * r] = r < K ? 1.0f : 0.0f;
-        if (tid == 0) {
-            *F.n_key = K;
-            if (K <= 50) atomicOr(F.status, CAELO_ST_FEW_KEYPTS);  // :286
-        }
-    }
-}
-
-// The single-workgroup form: everything in one kernel.  only_fallback: the frames the three kernels above left over.
-__global__ void __launch_bounds__(SEL_THREADS) k_kp_select(const caelo_frame_set fs, int ring_w, int ring_c, int only_fallback) {
-    const caelo_frame_dev &F = fs.f[blockIdx.z];
+// The single-workgroup form: everything in one workgroup of 1024 threads (histogram, cut bin -- or an 8-bit radix select over
+// the full keys when the bins cannot split the candidates --, gather, bitonic sort, output).  k_kp_emit's workgroup 0 calls it
+// for the frames the three kernels above leave over; k_kp_select is that alone (CAELO_KP_SELECT=single).
+__device__ void kp_select_one_workgroup(const caelo_frame_dev &F, int ring_w, int ring_c) {
     const unsigned long long *__restrict__ cand = F.cand;
     const int32_t *cand_count = F.cand_count;
     const float *__restrict__ ring = F.ring;
@@ -731,7 +689,6 @@ __global__ void __launch_bounds__(SEL_THREADS) k_kp_select(const caelo_frame_set
     const int tid = threadIdx.x;
     SEL_STAMP(0);
     const int M = *cand_count;
-    if (only_fallback && cand_count[KP_CC_STATE] != KP_STATE_FALLBACK) return;  // k_kp_hist / _gather / _emit did this frame
     const int keep = M < 1025 ? M : 1025;
     unsigned long long thresh = 0ull;
     if (M > 1025) {
@@ -837,6 +794,56 @@ __global__ void __launch_bounds__(SEL_THREADS) k_kp_select(const caelo_frame_set
     }
 }
 
+__global__ void __launch_bounds__(SEL_THREADS) k_kp_select(const caelo_frame_set fs, int ring_w, int ring_c) {
+    kp_select_one_workgroup(fs.f[blockIdx.z], ring_w, ring_c);
+}
+
+__global__ void __launch_bounds__(SEL_THREADS) k_kp_emit(const caelo_frame_set fs, int ring_w, int ring_c) {
+    const caelo_frame_dev &F = fs.f[blockIdx.z];
+    const int M = *F.cand_count, tid = threadIdx.x;
+    const int state = F.cand_count[KP_CC_STATE];
+    if (M > 1025 && state != KP_STATE_LISTED) {  // (workgroup-uniform) the bins could not split this frame's candidates
+        if (blockIdx.x == 0) kp_select_one_workgroup(F, ring_w, ring_c);
+        return;
+    }
+    // M <= 1025: every candidate is selected, the candidate list is the selection list
+    const unsigned long long *sel = M > 1025 ? F.cand + KP_SEL_OFF : F.cand;
+    const int nsel = M > 1025 ? F.cand_count[KP_CC_NSEL] : M;
+    const int keep = M < 1025 ? M : 1025;
+    const int K = keep > 0 ? keep - 1 : 0;  // drop the single best (:216,:218)
+    const int first = nsel - keep;           // ranks first .. nsel - 2 are rows 0 .. K - 1
+    __shared__ unsigned long long s_keys[SEL_N];
+    for (int i = tid; i < nsel; i += SEL_THREADS) s_keys[i] = sel[i];
+    __syncthreads();
+    // thread (k = tid >> 4, part = tid & 15): key number blockIdx.x * 64 + k against the keys q = part (mod 16)
+    const int e = blockIdx.x * 64 + (tid >> 4), part = tid & 15;
+    const unsigned long long mine = e < nsel ? s_keys[e] : 0ull;
+    int rank = 0;
+    if (e < nsel)
+        for (int q = part; q < nsel; q += 16) rank += s_keys[q] < mine ? 1 : 0;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) rank += __shfl_xor(rank, o);
+    const int i = rank - first;
+    if (e < nsel && part == 0 && i >= 0 && i < K) {
+        const unsigned idx = (unsigned)(mine & 0xFFFFFFFFull);
+        const int y = idx / CAELO_NET_W, x = idx % CAELO_NET_W;
+        F.key_pixels[2 * i] = y;
+        F.key_pixels[2 * i + 1] = x;
+        const float *px = F.ring + ((int64_t)y * ring_w + x) * ring_c;
+        F.key_pts[(size_t)F.kp_ld * i] = px[0];
+        F.key_pts[(size_t)F.kp_ld * i + 1] = px[1];
+        F.key_pts[(size_t)F.kp_ld * i + 2] = px[2];
+    }
+    if (blockIdx.x == 0) {
+        if (F.valid)
+            for (int r = tid; r < CAELO_MAX_KEYPTS; r += SEL_THREADS) F.valid[(size_t)F.valid_ld * r] = r < K ? 1.0f : 0.0f;
+        if (tid == 0) {
+            *F.n_key = K;
+            if (K <= 50) atomicOr(F.status, CAELO_ST_FEW_KEYPTS);  // :286
+        }
+    }
+}
+
 int ring_keypoints_launch(const float *ring, int ring_w, int ring_c, int dist_c, const int32_t *counter, int cnt_w,
                           const float *resp, unsigned long long *cand, int32_t *cand_count,
                           int64_t *key_pixels, float *key_pts, int kp_ld, float *valid, int valid_ld, int32_t *n_key,
@@ -862,9 +869,9 @@ int ring_keypoints_set(const caelo_frame_set &fs, int ring_w, int ring_c, int cn
         k_kp_gather<<<dim3(KP_WGS, 1, fs.n), SEL_THREADS, 0, s>>>(fs);
         CAELO_LAUNCH_CHECK();
         k_kp_emit<<<dim3(SEL_N / 64, 1, fs.n), SEL_THREADS, 0, s>>>(fs, ring_w, ring_c);
-        CAELO_LAUNCH_CHECK();
+    } else {
+        k_kp_select<<<dim3(1, 1, fs.n), SEL_THREADS, 0, s>>>(fs, ring_w, ring_c);
     }
-    k_kp_select<<<dim3(1, 1, fs.n), SEL_THREADS, 0, s>>>(fs, ring_w, ring_c, single ? 0 : 1);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }

@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(256) k_vox_clear_lists(const caelo_frame_set f
         const int e = (int)(i >> 3), w = (int)(i & 7);
         const caelo_brick_table &t = e < n0 ? b0 : b1;
         const uint32_t slot = e < n0 ? list0[e] : list1[e - n0];
+        if (slot == 0xFFFFFFFFu) continue;  // (a hole of list0: a run of points whose brick another run had created)
         t.bits[(size_t)slot * 8 + w] = 0ull;
         if (w == 0) t.keys[slot] = CAELO_EMPTY_KEY;
     }
@@ -448,31 +449,103 @@ __global__ void __launch_bounds__(256) k_vox_points(const caelo_frame_set fs) {
     }
     // Neighbouring points of a scan line fall into the same 16 cm brick: only the first lane of each run of
     // equal keys walks the hash table (memory-side atomics cost microseconds), the run reuses its slot.
+    // The chain of dependent memory round trips is what this kernel costs (86 % of its wave cycles wait), so it is kept to two:
+    // the scan's point, then ONE compare-and-swap on the key's home slot (no look first: most heads create their brick) with the
+    // workgroup's list reservation in flight beside it -- a slot for every head, reserved before anyone knows which heads are
+    // new (the others leave holes, 0xFFFFFFFF, which the two readers of the list skip); the bit goes out as an atomic OR
+    // nobody waits for.  (Round 2: load key -> CAS -> reserve -> load word -> OR, 44 us per 8 frames.)
     const unsigned long long prev = __shfl_up(key, 1);
     const bool head = v.ok && (lane == 0 || prev != key);
-    int slot = -1;
-    bool is_new = false;
-    if (head) slot = table_insert_new(b0.keys, b0.mask, key, &is_new);
-    if (head && slot < 0) st |= CAELO_ST_MAP_FULL;
+    const uint32_t h0 = caelo_hash64(key) & b0.mask;
+    unsigned long long old = CAELO_EMPTY_KEY;
+    if (head) old = atomicCAS(&b0.keys[h0], CAELO_EMPTY_KEY, key);
     __shared__ int s_tmp[2];
-    const int lpos = caelo_block_reserve(&counts[4], is_new, s_tmp);  // ONE global atomic per workgroup
-    if (is_new) list0[lpos] = (uint32_t)slot;
+    const int lpos = caelo_block_reserve_async(&counts[4], head, s_tmp);  // ONE global atomic per workgroup
+    int slot = -1;
+    if (head) {
+        bool is_new = old == CAELO_EMPTY_KEY;
+        slot = (int)h0;
+        if (!is_new && old != key) slot = table_insert_new(b0.keys, b0.mask, key, &is_new);  // home slot taken: probe on
+        if (slot < 0) st |= CAELO_ST_MAP_FULL;
+        list0[lpos] = is_new ? (uint32_t)slot : 0xFFFFFFFFu;
+    }
+    // The bits.  A memory-side atomic moves a 64-byte line there and back whatever it changes (one OR per point: 76 MB of
+    // traffic for 16 MB of points, and the kernel's time): the wave first ORs its points into an LDS image of the bricks it
+    // touches -- row = run of equal keys, 8 words each -- and then issues one atomic per non-empty word.
+    __shared__ unsigned long long s_agg[4][64][8];
+    __shared__ int s_slot[4][64];
+    const int wave = threadIdx.x >> 6;
     const unsigned long long heads = __ballot(head);
-    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-    const int src = below ? 63 - __clzll(below) : lane;
-    slot = __shfl(slot, src);
-    if (v.ok && slot >= 0) {
-        const unsigned long long bit = 1ull << (((v.g[1] & 7) << 3) | (v.g[2] & 7));
-        unsigned long long *w = &b0.bits[(size_t)slot * 8 + (v.g[0] & 7)];
-        if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit))
-            (void)__hip_atomic_fetch_or(w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long upto = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));  // heads at or below this lane
+    const int run = __popcll(upto) - 1;                                                        // (-1: no head yet -> not ok either)
+    const int nruns = __popcll(heads);
+#pragma unroll
+    for (int w = 0; w < 8; w += 2) *(ulonglong2 *)&s_agg[wave][lane][w] = make_ulonglong2(0ull, 0ull);
+    if (head) s_slot[wave][run] = slot;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (v.ok) atomicOr(&s_agg[wave][run][v.g[0] & 7], 1ull << (((v.g[1] & 7) << 3) | (v.g[2] & 7)));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {   // lane (r, w) = (lane >> 3, lane & 7) flushes word w of runs r, r + 8, ...
+        const int w = lane & 7;
+        for (int r = lane >> 3; r < nruns; r += 8) {
+            const unsigned long long bitsw = s_agg[wave][r][w];
+            const int sl = s_slot[wave][r];
+            if (bitsw && sl >= 0)
+                (void)__hip_atomic_fetch_or(&b0.bits[(size_t)sl * 8 + w], bitsw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (st) atomicOr(status, st);
 }
 
+// The suspect voxels of the frame (see the header of this section) take two steps that have nothing to do -- one word read
+// per workgroup -- when no point of the frame was inconsistent.  (A single kernel whose last workgroup resolves would need an
+// agent-scope release per workgroup: on gfx950 that is an L2 write-back walk, 433 us for 8 frames.)
+// (1) first point of every suspect voxel: smallest index over ALL points of the voxel, consistent ones included.  Runs in extra
+//     workgroups of k_vox_coarse's launch (both only need k_vox_points done; both are chains of dependent memory round trips
+//     that leave the CUs idle: side by side they cost the longer of the two, 32 us, instead of 32 + 14)
+#define SUSPECT_LDS 128
+__device__ inline void vox_suspects_first(const caelo_frame_dev &F, int block) {
+    const int nsp = F.counts[6];
+    if (nsp == 0) return;
+    // A handful of voxels (14 of a 126 k-point scan quantised to 1 mm): the workgroup stages their keys in LDS and every point
+    // compares the key k_vox_points stored for it against them -- no index arithmetic, no table probe per point (both together
+    // were 15.7 us per 8 frames for those 14 voxels).  More inconsistent points than the LDS list holds: probe the table.
+    __shared__ unsigned long long s_key[SUSPECT_LDS];
+    __shared__ uint32_t s_slot[SUSPECT_LDS];
+    const bool listed = nsp <= SUSPECT_LDS;
+    if (listed) {
+        if ((int)threadIdx.x < nsp) {
+            const uint32_t ss = F.sp.list[threadIdx.x].y;
+            s_slot[threadIdx.x] = ss;
+            s_key[threadIdx.x] = F.sp.sp_keys[ss];
+        }
+        __syncthreads();
+    }
+    const int64_t i = (int64_t)block * blockDim.x + threadIdx.x;
+    if (i >= F.n) return;
+    const unsigned long long key = F.vkeys[0][i];
+    if (key == CAELO_EMPTY_KEY) return;
+    if (listed) {
+        for (int e = 0; e < nsp; ++e)  // (several inconsistent points of one voxel repeat its key: the same atomicMin twice)
+            if (s_key[e] == key) { atomicMin(&F.sp.sp_first[s_slot[e]], (uint32_t)i); break; }
+    } else {
+        const int ss = table_find(F.sp.sp_keys, F.sp.mask, key);
+        if (ss >= 0) atomicMin(&F.sp.sp_first[ss], (uint32_t)i);
+    }
+}
+
 // the occupied scale-0 bricks (256 per workgroup iteration): a brick is a scale-1 voxel, and counts its voxels
+#define COARSE_WGS 256
 __global__ void __launch_bounds__(256) k_vox_coarse(const caelo_frame_set fs) {
     const caelo_frame_dev &F = fs.f[blockIdx.z];
+    if (blockIdx.x >= COARSE_WGS) {  // (workgroup-uniform)
+        vox_suspects_first(F, (int)blockIdx.x - COARSE_WGS);
+        return;
+    }
     const caelo_brick_table b0 = F.brick[0], b1 = F.brick[1];
     const uint32_t *list0 = F.list0;
     uint32_t *list1 = F.list1;
@@ -482,12 +555,12 @@ __global__ void __launch_bounds__(256) k_vox_coarse(const caelo_frame_set fs) {
     const int nb = counts[4];
     const bool any_suspect = counts[6] > 0;
     int pop = 0;
-    for (int i0 = blockIdx.x * blockDim.x; i0 < nb; i0 += gridDim.x * blockDim.x) {  // uniform trip count per workgroup
+    for (int i0 = blockIdx.x * blockDim.x; i0 < nb; i0 += COARSE_WGS * blockDim.x) {  // uniform trip count per workgroup
         const int i = i0 + threadIdx.x;
         bool is_new = false;
         int slot1 = -1;
-        if (i < nb) {
-            const uint32_t slot = list0[i];
+        const uint32_t slot = i < nb ? list0[i] : 0xFFFFFFFFu;
+        if (slot != 0xFFFFFFFFu) {  // (list0 has holes, see k_vox_points)
             const unsigned long long k = b0.keys[slot];
             const ulonglong2 *w = (const ulonglong2 *)(b0.bits + (size_t)slot * 8);
             int mine = 0;
@@ -562,42 +635,6 @@ __global__ void __launch_bounds__(256) k_vox_coarse2(const caelo_frame_set fs) {
     caelo_block_add(&counts[2], pop2, s_tmp);
 }
 
-// The suspect voxels of the frame (see the header of this section), two launches that have nothing to do -- one word
-// read per workgroup -- when no point of the frame was inconsistent.  (A single kernel whose last workgroup resolves
-// would need an agent-scope release per workgroup: on gfx950 that is an L2 write-back walk, 433 us for 8 frames.)
-// (1) first point of every suspect voxel: smallest index over ALL points of the voxel, consistent ones included
-#define SUSPECT_LDS 128
-__global__ void __launch_bounds__(256) k_vox_suspects_first(const caelo_frame_set fs) {
-    const caelo_frame_dev &F = fs.f[blockIdx.z];
-    const int nsp = F.counts[6];
-    if (nsp == 0) return;
-    // A handful of voxels (14 of a 126 k-point scan quantised to 1 mm): the workgroup stages their keys in LDS and every point
-    // compares the key k_vox_points stored for it against them -- no index arithmetic, no table probe per point (both together
-    // were 15.7 us per 8 frames for those 14 voxels).  More inconsistent points than the LDS list holds: probe the table.
-    __shared__ unsigned long long s_key[SUSPECT_LDS];
-    __shared__ uint32_t s_slot[SUSPECT_LDS];
-    const bool listed = nsp <= SUSPECT_LDS;
-    if (listed) {
-        if ((int)threadIdx.x < nsp) {
-            const uint32_t ss = F.sp.list[threadIdx.x].y;
-            s_slot[threadIdx.x] = ss;
-            s_key[threadIdx.x] = F.sp.sp_keys[ss];
-        }
-        __syncthreads();
-    }
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= F.n) return;
-    const unsigned long long key = F.vkeys[0][i];
-    if (key == CAELO_EMPTY_KEY) return;
-    if (listed) {
-        for (int e = 0; e < nsp; ++e)  // (several inconsistent points of one voxel repeat its key: the same atomicMin twice)
-            if (s_key[e] == key) { atomicMin(&F.sp.sp_first[s_slot[e]], (uint32_t)i); break; }
-    } else {
-        const int ss = table_find(F.sp.sp_keys, F.sp.mask, key);
-        if (ss >= 0) atomicMin(&F.sp.sp_first[ss], (uint32_t)i);
-    }
-}
-
 // (2) that point's own scale-1 / 2 indices are inserted, exactly what the reference's loop does when it meets the voxel
 __global__ void __launch_bounds__(256) k_vox_suspects_resolve(const caelo_frame_set fs) {
     const caelo_frame_dev &F = fs.f[blockIdx.z];
@@ -653,11 +690,9 @@ int vox_build_fast_set(caelo_voxmap *const *maps, const caelo_frame_set &fs, hip
     const unsigned gp = (unsigned)((vox_set_max_points(fs) + 255) / 256);
     k_vox_points<<<dim3(gp, 1, fs.n), 256, 0, s>>>(fs);
     CAELO_LAUNCH_CHECK();
-    k_vox_coarse<<<dim3(256, 1, fs.n), 256, 0, s>>>(fs);
+    k_vox_coarse<<<dim3(COARSE_WGS + gp, 1, fs.n), 256, 0, s>>>(fs);  // + the suspect voxels' first points
     CAELO_LAUNCH_CHECK();
     k_vox_coarse2<<<dim3(64, 1, fs.n), 256, 0, s>>>(fs);
-    CAELO_LAUNCH_CHECK();
-    k_vox_suspects_first<<<dim3(gp, 1, fs.n), 256, 0, s>>>(fs);
     CAELO_LAUNCH_CHECK();
     k_vox_suspects_resolve<<<dim3(4, 1, fs.n), 256, 0, s>>>(fs);
     CAELO_LAUNCH_CHECK();
@@ -786,6 +821,9 @@ CAELO_API int caelo_voxmap_from_lists(caelo_ctx *c, caelo_voxmap *m, const int16
 // K6: patch gather.  One wavefront per (keypoint, scale).
 // ------------------------------------------------------------------------------------------------
 #define PW_WAVES 4
+#ifndef PW_OCC
+#define PW_OCC 6       // waves per SIMD the register allocation must allow (70 registers: 7 fit; 8 would spill)
+#endif
 #define BALL_R 13      // |d| <= 13 per axis covers every voxel with d2 <= 192
 #define BALL_D2 192    // farthest in-window offset (-8,-8,-8)
 #define NN_CAP 496     // Voxel.py:182
@@ -817,7 +855,7 @@ __device__ inline int wave_sum(int v) {
     return v;
 }
 
-__global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const caelo_frame_set fs, int64_t k_max, int check_counts,
+__global__ void __launch_bounds__(64 * PW_WAVES, PW_OCC) k_patches(const caelo_frame_set fs, int64_t k_max, int check_counts,
                                                            unsigned long long dd_mask) {
     const caelo_frame_dev &F = fs.f[blockIdx.z];
     const float *__restrict__ pts = F.key_pts;
@@ -896,26 +934,30 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const caelo_frame_set
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // lane owns quarter `part` (x planes 2 part, 2 part + 1) of found brick it * 16 + (lane >> 2), it = 0..7
     const int part = lane & 3;
-    ulonglong2 pay[8];
-    int bl[8];  // ball-cube brick index of that brick, -1 = none
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int e = it * 16 + (lane >> 2);
-        const bool ok = e < nfound;
-        const unsigned ent = ok ? L.found[e] : 0u;
-        bl[it] = ok ? (int)(ent & 127u) : -1;
-        pay[it] = make_ulonglong2(0ull, 0ull);
-        if (it * 16 < nfound && ok) pay[it] = ((const ulonglong2 *)(tab.bits + (size_t)(ent >> 7) * 8))[part];
-    }
+    // (the payloads are not kept: the rare wave that needs the 496-NN cut below fetches them again -- from L2 by then -- and
+    //  every other wave runs in 64 registers, eight to a SIMD instead of four: this kernel is bound by memory round trips)
     int pop = 0;
+    {
+        ulonglong2 pay[8];
+        int bl[8];  // ball-cube brick index of that brick, -1 = none
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        pop += __popcll(pay[it].x) + __popcll(pay[it].y);
-        if (bl[it] >= 0) {
-            const int wx = bl[it] / 25 - wx0, wy = (bl[it] / 5) % 5 - wy0, wz = bl[it] % 5 - wz0;
-            if (wx >= 0 && wx < 3 && wy >= 0 && wy < 3 && wz >= 0 && wz < 3) {
-                L.win[((wx * 3 + wy) * 3 + wz) * 8 + 2 * part] = pay[it].x;
-                L.win[((wx * 3 + wy) * 3 + wz) * 8 + 2 * part + 1] = pay[it].y;
+        for (int it = 0; it < 8; ++it) {
+            const int e = it * 16 + (lane >> 2);
+            const bool ok = e < nfound;
+            const unsigned ent = ok ? L.found[e] : 0u;
+            bl[it] = ok ? (int)(ent & 127u) : -1;
+            pay[it] = make_ulonglong2(0ull, 0ull);
+            if (it * 16 < nfound && ok) pay[it] = ((const ulonglong2 *)(tab.bits + (size_t)(ent >> 7) * 8))[part];
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            pop += __popcll(pay[it].x) + __popcll(pay[it].y);
+            if (bl[it] >= 0) {
+                const int wx = bl[it] / 25 - wx0, wy = (bl[it] / 5) % 5 - wy0, wz = bl[it] % 5 - wz0;
+                if (wx >= 0 && wx < 3 && wy >= 0 && wy < 3 && wz >= 0 && wz < 3) {
+                    L.win[((wx * 3 + wy) * 3 + wz) * 8 + 2 * part] = pay[it].x;
+                    L.win[((wx * 3 + wy) * 3 + wz) * 8 + 2 * part + 1] = pay[it].y;
+                }
             }
         }
     }
@@ -956,14 +998,17 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const caelo_frame_set
         if (lane == 0) L.ncls = 0;
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            if (bl[it] < 0) continue;
-            const int xb = (bx0 + bl[it] / 25) * 8 - kx, ybase = (by0 + (bl[it] / 5) % 5) * 8 - ky,
-                      zbase = (bz0 + bl[it] % 5) * 8 - kz;
+#pragma unroll 1
+        for (int it = 0; it * 16 < nfound; ++it) {
+            const int e = it * 16 + (lane >> 2);
+            if (e >= nfound) continue;
+            const unsigned ent = L.found[e];
+            const int bli = (int)(ent & 127u);
+            const ulonglong2 pay = ((const ulonglong2 *)(tab.bits + (size_t)(ent >> 7) * 8))[part];
+            const int xb = (bx0 + bli / 25) * 8 - kx, ybase = (by0 + (bli / 5) % 5) * 8 - ky, zbase = (bz0 + bli % 5) * 8 - kz;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                unsigned long long v = q ? pay[it].y : pay[it].x;
+                unsigned long long v = q ? pay.y : pay.x;
                 const int dx = xb + 2 * part + q;
                 while (v) {
                     const int t = __ffsll((long long)v) - 1;
@@ -1013,13 +1058,17 @@ __global__ void __launch_bounds__(64 * PW_WAVES) k_patches(const caelo_frame_set
         if (cut <= BALL_D2) {
             if (room > 0) {
                 // members of the cut class, for the canonical tie rule (ascending (x,y,z) key)
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    if (bl[it] < 0) continue;
-                    const int xb = (bx0 + bl[it] / 25) * 8, yb = (by0 + (bl[it] / 5) % 5) * 8, zb = (bz0 + bl[it] % 5) * 8;
+#pragma unroll 1
+                for (int it = 0; it * 16 < nfound; ++it) {
+                    const int e = it * 16 + (lane >> 2);
+                    if (e >= nfound) continue;
+                    const unsigned ent = L.found[e];
+                    const int bli = (int)(ent & 127u);
+                    const ulonglong2 pay = ((const ulonglong2 *)(tab.bits + (size_t)(ent >> 7) * 8))[part];
+                    const int xb = (bx0 + bli / 25) * 8, yb = (by0 + (bli / 5) % 5) * 8, zb = (bz0 + bli % 5) * 8;
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        unsigned long long v = q ? pay[it].y : pay[it].x;
+                        unsigned long long v = q ? pay.y : pay.x;
                         const int x = xb + 2 * part + q;
                         while (v) {
                             const int t = __ffsll((long long)v) - 1;
