@@ -310,7 +310,8 @@ class Engine:
 
     def lane_faults(self):
         """caelo_lane_faults: wavefronts of the pose kernels whose lanes disagreed on a hypothesis they all derive from the
-        same inputs (a hardware self-check; synchronises).  0 on healthy hardware."""
+        same inputs, plus descriptors the encoder wrote that are not a finite value within [-1, 1] (self-checks of the two
+        halves; synchronises).  0 on healthy hardware with sane weights."""
         out = C.c_int64(0)
         _ffi.check(self.lib.caelo_lane_faults(self.ctx, C.byref(out)))
         return int(out.value)

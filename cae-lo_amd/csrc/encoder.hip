@@ -1886,7 +1886,7 @@ template <int SPLIT>
 __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part, int64_t n_patches, int64_t n_rows_pad,
                                                   const float *__restrict__ bd1p, const float *__restrict__ wd2,
                                                   const float *__restrict__ bd2, int group, caelo_enc_out outs,
-                                                  int out_stride, const caelo_enc_in in) {
+                                                  int out_stride, const caelo_enc_in in, int32_t *faults) {
     // A wave walks patches p, p + (waves of the grid), ...; no LDS, no barrier.  Lane l < 50 owns the four hidden columns 4l .. 4l+3:
     // one 16-byte load per split-K partial (800 contiguous bytes per row) and the 4 x 20 Dense(20) weights of those columns, which
     // stay in registers across the wave's patches (a wave per patch re-read the 16 KB of weights from L2 per patch: five times
@@ -1966,7 +1966,14 @@ __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part
     const bool holds = (lane & 1) == 0 && (h3 ? !h2 : !(h2 && h1));
     // patches of several frames in one launch: frame f = p / per_frame writes into its own rows
     const unsigned f = p / per_out, q = p - f * per_out, kp = q / (unsigned)group;
-    if (holds) outs.base[f][(size_t)kp * out_stride + (size_t)(q - kp * (unsigned)group) * 20 + o] = enc_tanh(bo + mine);
+    if (holds) {
+        const float dv = enc_tanh(bo + mine);
+        outs.base[f][(size_t)kp * out_stride + (size_t)(q - kp * (unsigned)group) * 20 + o] = dv;
+        // the encoder's own invariant, next to the pose kernels' lane-agreement check (caelo_lane_faults): a descriptor is a
+        // tanh -- finite and within [-1, 1] whatever the patch; anything else is a broken weight image, a stale workspace or
+        // a mis-executed matrix instruction upstream, and is counted instead of flowing into the match unnoticed
+        if (!(fabsf(dv) <= 1.0f)) atomicAdd(faults, 1);
+    }
 #pragma unroll
     for (int sp = 0; sp < SPLIT; ++sp) v[sp] = vn[sp];
     }
@@ -2107,7 +2114,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     }
     if (ev) CAELO_HIP(hipEventRecord(ev[3], s));
     k_enc_head<D1_SPLIT_OF(DENSE_K)><<<enc_head_grid(n_patches), 256, 0, s>>>(part, n_patches, np, c->enc_bd1, c->enc_wd2, c->enc_bd2,
-                                                                group, outs, out_stride, ein);
+                                                                group, outs, out_stride, ein, c->faults);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[4], s));
     if (ev && fused_stage1 && !stage1x) {
@@ -2137,7 +2144,7 @@ int enc_dense32_head_launch(caelo_ctx *c, const float *f3, int64_t n_patches, in
     outs.base[0] = out;
     outs.per_frame = n_patches;
     k_enc_head<D1_SPLIT_OF(16384)><<<enc_head_grid(n_patches, 512), 256, 0, s>>>(part, n_patches, np, c->enc32_bd1, c->enc_wd2,
-                                                                c->enc_bd2, group, outs, out_stride, plain);
+                                                                c->enc_bd2, group, outs, out_stride, plain, c->faults);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }

@@ -1061,6 +1061,28 @@ def test_encoder_layer_error_budget(engine, models):
 
 
 @pytest.mark.gpu
+def test_encoder_invariant_counts_broken_descriptors():
+    """the encoder carries one cheap invariant of its own -- every descriptor is a tanh, finite and
+    within [-1, 1] -- counted in the same device counter as the pose kernels' lane-agreement check.  A weight image with a NaN
+    in Dense(20) must show up there (run in a second process: the poisoned context is thrown away with it)."""
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = ("import sys, ctypes as C, numpy as np, torch; sys.path.insert(0, %r); import caelo; from caelo import _ffi;"
+              "from caelo.engine import Engine, read_keras_weights; e = Engine(device=0);"
+              "b = np.ascontiguousarray(np.load(%r)['patch_bits'].reshape(-1, 64)[:96]);"
+              "t = torch.from_numpy(b.view(np.int64)).to(e.device); e.encode(t, group=3); print('clean', e.lane_faults());"
+              "kind, ws = read_keras_weights(%r); ws = [np.array(w) for w in ws]; ws[-2][3, 5] = np.nan;"
+              "_ffi.check(e.lib.caelo_set_encoder_weights(e.ctx, *[w.ctypes.data_as(C.c_void_p) for w in ws]));"
+              "e.encode(t, group=3); print('poisoned', e.lane_faults())")
+    out = subprocess.run([sys.executable, "-c", script % (os.path.join(repo, "cae-lo_amd"), os.path.join(GOLDEN, "frame_q0.npz"),
+                                                          os.path.join(WEIGHTS, "EncoderModel4VoxelPatch.h5"))],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = dict(l.split() for l in out.stdout.splitlines() if l.startswith(("clean", "poisoned")))
+    assert int(lines["clean"]) == 0 and int(lines["poisoned"]) >= 96   # column 5 of every patch's descriptor
+
+
+@pytest.mark.gpu
 def test_stage1x_agrees_with_the_f32_kernel(engine):
     """k_enc_stage1x (f16 x 2 products, conv1 on the matrix cores) against round 2's exact-f32 k_enc_stage1: the same P2 to
     1e-6 on every patch of the golden frame (run in a second process with CAELO_ENC_S1=f32)."""
