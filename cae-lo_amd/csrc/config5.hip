@@ -615,8 +615,8 @@ static int encode32_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, 
     // persistent grids: the B operand (conv weights) is loaded into registers once per workgroup
     const int items2 = (int)(n_patches * 8), items3 = (int)(n_patches * 2);
     if (x3) {
-        static const hipError_t attr = hipFuncSetAttribute((const void *)k5_conv2_x3, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X2_ARR);
-        CAELO_HIP(attr);
+        // (per call, i.e. for whichever device is current: this path is not a hot one)
+        CAELO_HIP(hipFuncSetAttribute((const void *)k5_conv2_x3, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X2_ARR));
         k5_conv2_x3<<<items2 < 512 ? items2 : 512, 256, 3 * X2_ARR, s>>>(p1, c->enc_w2, c->enc_b2, p2, items2);
     } else {
         k5_conv_mfma<16, 8, 16, true><<<items2 < 768 ? items2 : 768, 256, 0, s>>>(p1, c->enc_w2, c->enc_b2, p2, items2);

@@ -1845,10 +1845,25 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1p(const float *__re
         }
 }
 
+// Per-DEVICE caches of things the runtime is asked once: function attributes and occupancy answers belong to the device that is
+// current when they are set / asked (process-wide statics would serve a second GPU the first one's answers).
+#include <mutex>
+#define CAELO_MAX_DEVICES 64
+template <typename T, typename F>
+static T per_device_once(int device, T (&slot)[CAELO_MAX_DEVICES], bool (&have)[CAELO_MAX_DEVICES], std::mutex &mu, F make) {
+    const int d = device >= 0 && device < CAELO_MAX_DEVICES ? device : 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!have[d]) { slot[d] = make(); have[d] = true; }
+    return slot[d];
+}
+
 template <int KTOT>
-static int dense1_launch(const float *f3, int64_t np, const void *wd1x, float *part, const caelo_enc_in &in, hipStream_t s) {
-    // once per process (thread-safe static initialisation: the pipeline's encoder thread and the caller may race here)
-    static const hipError_t attr = [] {
+static int dense1_launch(int device, const float *f3, int64_t np, const void *wd1x, float *part, const caelo_enc_in &in, hipStream_t s) {
+    // once per device (under a lock: the pipeline's encoder thread and the caller may race here)
+    static hipError_t attr_slot[CAELO_MAX_DEVICES];
+    static bool attr_have[CAELO_MAX_DEVICES];
+    static std::mutex attr_mu;
+    const hipError_t attr = per_device_once(device, attr_slot, attr_have, attr_mu, [] {
         hipError_t e = hipFuncSetAttribute((const void *)k_enc_dense1<KTOT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, D1_LDS_BYTES(1));
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)k_enc_dense1<KTOT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, D1_LDS_BYTES(3));
@@ -1857,7 +1872,7 @@ static int dense1_launch(const float *f3, int64_t np, const void *wd1x, float *p
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)k_enc_dense1p<KTOT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, D1P_LDS_BYTES(2));
         return e;
-    }();
+    });
     CAELO_HIP(attr);
     // CAELO_D1_PLAIN=1: the round-1 kernels (two barriers per stage; 192-row tiles for the long-K instance) -- bit-identical
     static const bool plain = getenv("CAELO_D1_PLAIN") && atoi(getenv("CAELO_D1_PLAIN")) > 0;
@@ -2042,30 +2057,39 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     // k_enc_stage1 (a patch per 4-wave workgroup).  Measured slower: 93 vs 62 us for one frame, 375 vs 292 us for an 8-frame
     // launch -- two wavefronts per SIMD (LDS) do not cover its LDS / dependency waits either.
     static const bool wave_stage1 = fused_stage1 && getenv("CAELO_ENC_WAVE") && atoi(getenv("CAELO_ENC_WAVE")) > 0;
-    static const int slots1w = [](int device) {
+    static int slots1w_slot[CAELO_MAX_DEVICES];
+    static bool slots1w_have[CAELO_MAX_DEVICES];
+    static std::mutex slots1w_mu;
+    const int slots1w = per_device_once(c->device, slots1w_slot, slots1w_have, slots1w_mu, [&] {
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_enc_stage1w, 64 * S1W_WAVES, 0) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || per_cu * cus <= 0)
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || per_cu * cus <= 0)
             return 512;
         return per_cu * cus;
-    }(c->device);
+    });
     // CAELO_ENC_S1=f32 selects round 2's k_enc_stage1 (f32-input MFMAs, conv1 on the VALU) for comparison; default: k_enc_stage1x
     static const bool stage1x = fused_stage1 && !wave_stage1 && !(getenv("CAELO_ENC_S1") && !strcmp(getenv("CAELO_ENC_S1"), "f32"));
-    static const int slots1x = [](int device) {
+    static int slots1x_slot[CAELO_MAX_DEVICES];
+    static bool slots1x_have[CAELO_MAX_DEVICES];
+    static std::mutex slots1x_mu;
+    const int slots1x = per_device_once(c->device, slots1x_slot, slots1x_have, slots1x_mu, [&] {
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_enc_stage1x<false>, 256, 0) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || per_cu * cus <= 0)
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || per_cu * cus <= 0)
             return 512;
         return per_cu * cus;
-    }(c->device);
+    });
     int *xcd_counters = (int *)((char *)ws + 1024);  // 8 x one 128-byte line
-    static const int slots1 = [](int device) {
+    static int slots1_slot[CAELO_MAX_DEVICES];
+    static bool slots1_have[CAELO_MAX_DEVICES];
+    static std::mutex slots1_mu;
+    const int slots1 = per_device_once(c->device, slots1_slot, slots1_have, slots1_mu, [&] {
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_stage1 ? (const void *)k_enc_stage1 : (const void *)k_enc_conv2, 256, 0) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || per_cu * cus <= 0)
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || per_cu * cus <= 0)
             return 768;  // 3 workgroups on each of MI355X's 256 CUs
         return per_cu * cus;
-    }(c->device);
+    });
     // Inside the frame pipeline the persistent grids leave a fifth (stage 1) / a quarter (conv3) of their slots free: stage 1 and
     // conv3 otherwise own every register file for their whole run and the other streams' kernels only get CUs between them
     // (round 1: +3 % frames/s; with the round-2 executor the setting is worth about 1 %, caelo_enc_in::yield bits)
@@ -2081,7 +2105,10 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
         CAELO_LAUNCH_CHECK();
     } else if (stage1x) {
         // round 3's default: conv1 on the matrix cores, f16 x 2 products, two 256-register workgroups per CU (enc_stage1x.inc)
-        const int64_t capx = (ein.yield & 1) ? (int64_t)slots1x * 4 / 5 : slots1x;
+        // CAELO_S1X_SLOTS: grid size by hand (measurement: 128 / 256 / 384 / 512 workgroups take 692 / 376 / 281 / 233 us per 24 576
+        // patches -- a workgroup alone on its CU needs 3.9 us per patch, two sharing one 4.85 us each: latency bound)
+        static const int slots_env = getenv("CAELO_S1X_SLOTS") ? atoi(getenv("CAELO_S1X_SLOTS")) : 0;
+        const int64_t capx = slots_env > 0 ? slots_env : ((ein.yield & 1) ? (int64_t)slots1x * 4 / 5 : slots1x);
         const unsigned gx = (unsigned)(n_patches < capx ? n_patches : capx);
         if (ev) {   // profiling calls count the MFMAs the kernel executes (bench.py's roofline); same code otherwise
             CAELO_HIP(hipMemsetAsync(mfma_count, 0, sizeof(unsigned long long), s));
@@ -2109,7 +2136,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[2], s));
     {
-        const int rc = dense1_launch<DENSE_K>(f3, np, c->enc_wd1x, part, ein, s);
+        const int rc = dense1_launch<DENSE_K>(c->device, f3, np, c->enc_wd1x, part, ein, s);
         if (rc) return rc;
     }
     if (ev) CAELO_HIP(hipEventRecord(ev[3], s));
@@ -2137,7 +2164,7 @@ int enc_dense32_head_launch(caelo_ctx *c, const float *f3, int64_t n_patches, in
                             int out_stride, hipStream_t s) {
     const caelo_enc_in plain = {nullptr, 0, (int32_t)n_patches, 1, 0, 0};
     {
-        const int rc = dense1_launch<16384>(f3, np, c->enc32_wd1x, part, plain, s);
+        const int rc = dense1_launch<16384>(c->device, f3, np, c->enc32_wd1x, part, plain, s);
         if (rc) return rc;
     }
     caelo_enc_out outs = {};

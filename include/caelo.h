@@ -259,7 +259,12 @@ int caelo_icp_step(caelo_ctx *ctx, const float *pc0, int64_t n0, float *pc1, int
  * ValueError at MyICP.py:94 -- GetKeyPtsByAE always returns an empty PlanarPts (SphericalRing.py:219,285).
  * Per iteration: nearest neighbours (exact float64 distance, first minimum) of both sets, the gates, ONE SolveRT over all pairs,
  * R_star / T_star accumulated in float64, the Euler-angle stop rule and the threshold decay -- no host synchronisation; `result`
- * (device) is complete when the stream has passed the call.  ws: caelo_icp_loop_ws_bytes(n1, m1) bytes. */
+ * (device) is complete when the stream has passed the call.  ws: caelo_icp_loop_ws_bytes(n1, m1) bytes.
+ * Regime: the reference's use -- up to 50 iterations on a few thousand extended key points.  Every iteration is an exact
+ * brute-force nearest-neighbour pass (O(n0 n1) float64 distances) and a one-workgroup update, and ALL max_iter (<= 1000)
+ * iterations are enqueued up front (those after convergence return at once): tens of thousands of points or hundreds of
+ * iterations work but are not what this entry point is built for.  Nearest-neighbour ties resolve to the lowest index; sklearn's
+ * kd-tree (MyICP.py:34-38) makes no promise on exact ties, so clouds with duplicated points may pair differently there. */
 typedef struct {
     double threshold0, threshold1, decay0, decay1, small_shift, ep;
     int32_t max_iter, min_iter, min_pairs, fail_only_first, use_planar, reserved;
