@@ -5,15 +5,16 @@ project -> response CNN -> keypoints -> voxelize -> patch gather -> 3D-CAE descr
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one KITTI-shaped scan (64 beams x 2000 azimuths, ~126k points, already resident in HBM)
-taken through the whole path on every rank.  Frames shard across ranks (weak scaling: K frames per
-rank); the timed region per rank is
-    K x (extract, then match + RANSAC against the predecessor frame)  ->  ONE RCCL all-gather of per-frame
-    rows [1024,64] f32 (--gather boundary: each rank's last frame, default; --gather all: every frame)
+A step = one batch of --batch (8) KITTI-shaped scans (64 beams x 2000 azimuths, ~126k points each, already resident in HBM)
+taken through the whole path on every rank.  Frames shard across ranks (weak scaling: K frames per rank; --scaling strong
+splits the steps instead); the timed region per rank is
+    K x (extract, then match + RANSAC against the predecessor frame)  with the RCCL all-gather of per-frame rows [1024,64] f32
+    (--gather all, default: every frame, batch by batch on a side stream as soon as a batch is encoded; --gather boundary:
+    each rank's last frame, one collective at the end)
     ->  (ranks > 0) the pair that straddles the rank boundary (a rank's first frame against the previous rank's last
     one, taken from the gathered rows; rank 0's first frame against the last warm-up frame).
 Rank 0 prints one JSON line (contract in the task statement) including
-    roofline      the dominant kernel (k_enc_stage1, conv1+conv2 of the 3D-CAE encoder), algorithmic
+    roofline      the dominant kernel (k_enc_stage1x, conv1+conv2 of the 3D-CAE encoder), executed MFMA
                   FLOPs / HIP-event time measured live through caelo_encode_profile
     The frames go through the native executor (caelo_pipeline): --batch consecutive frames share ONE launch of every
     front kernel, one encoder launch set and one match / RANSAC launch; the three stages of successive batches overlap
@@ -254,6 +255,10 @@ def main():
     ap.add_argument("--scene", choices=("boxes", "clutter"), default="boxes", help="synthetic scene of the timed region")
     ap.add_argument("--include-h2d", action="store_true", help="the timed region also uploads every scan from pinned host memory "
                                                                "on a copy stream, double buffered (PCIe-inclusive rate; never the headline `value`)")
+    ap.add_argument("--gather-overlap", type=int, default=1,
+                    help="--gather all: 1 (default) = the rows of every batch are gathered on a side stream as soon as the batch is "
+                         "encoded, under the extraction of the next batches (caelo_pipeline_wait_encoded); 0 = one collective after "
+                         "the last frame")
     ap.add_argument("--gather", choices=("boundary", "all"), default="all",
                     help="rows moved by the single all-gather: every frame's [1024,64] rows (the north-star's per-frame descriptor "
                          "gather, default) or each rank's last frame only (all that consecutive-pair matching needs)")
@@ -318,14 +323,39 @@ def main():
             self.pos += n
             return o
 
-        def run(self, n, out=None, pairs=True, scans=None):
+        def run(self, n, out=None, pairs=True, scans=None, on_batch=None):
             o = self.order(n)
             batch = pipe.run(scans if scans is not None else [self.pool[j] for j in o], [rand[j] for j in o],
-                             prev=self.prev if pairs else None, pairs=pairs, out=out, **self.kw)
+                             prev=self.prev if pairs else None, pairs=pairs, out=out, on_batch=on_batch, **self.kw)
             self.prev = batch.frame(n - 1)
             return batch
 
     main_run = Runner(pool)
+
+    overlap = world > 1 and args.gather == "all" and args.gather_overlap and not args.extract_only and not args.include_h2d
+
+    def run_ranks(n, out, gather_stats):
+        """n frames through the pipeline and across the ranks.  Overlapped gather: every batch's rows leave on a side stream as soon
+        as the batch is encoded, under the extraction of the next batches; then the pair that straddles the rank boundary."""
+        if not overlap:
+            batch = main_run.run(n, out, pairs=not args.extract_only)
+            finish_ranks(batch, n, gather_stats)
+            return batch
+        out = out or FrameBatch(eng, n)
+        g = cdist.ChunkedFrameGather(out.rows, n, B)
+
+        def shipped(lo, hi):
+            pipe.wait_encoded(g.side)
+            g.chunk(lo, hi)
+        batch = main_run.run(n, out, on_batch=shipped)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()                     # the pipeline's own work ends here on this stream ...
+        frame_of = g.finish()           # ... and what is left of the gathers after it is the exposed part
+        e1.record()
+        if rank > 0:
+            batch.result[0].copy_(eng.match_pose(FrameFeatures.from_rows(frame_of(rank - 1, n - 1)), batch.frame(0), rand[0])[0])
+        gather_stats.append((e0, e1, g.nbytes(), g))
+        return batch
 
     def finish_ranks(batch, n, gather_stats):
         """ONE collective over xGMI (every frame's rows, or the boundary frames), then the pair that straddles the rank boundary"""
@@ -344,15 +374,15 @@ def main():
         e1.record()
         if rank > 0:   # this rank's first frame pairs with the previous rank's last one (from the gathered rows)
             batch.result[0].copy_(eng.match_pose(FrameFeatures.from_rows(prev_rows), batch.frame(0), rand[0])[0])
-        gather_stats.append((e0, e1, nbytes))
+        gather_stats.append((e0, e1, nbytes, None))
 
     # one-time initialisation, not a warm-up step: the stage streams and every hand-off buffer are touched once (a
     # HIP stream allocates its hardware queue on first use, ~ms), so that a run with a small --warmup does not time that
     gstats = []
-    finish_ranks(main_run.run(pipe.buffers * B), pipe.buffers * B, gstats)
+    run_ranks(pipe.buffers * B, None, gstats)
     torch.cuda.synchronize()
     if W > 0:
-        finish_ranks(main_run.run(W), W, gstats)
+        run_ranks(W, None, gstats)
     torch.cuda.synchronize()
     host_scans = None
     if args.include_h2d:
@@ -367,9 +397,9 @@ def main():
     t0 = time.perf_counter()
     if args.include_h2d:
         batch = run_with_uploads(eng, pipe, main_run, host_scans, K, timed_out, rand, pairs=not args.extract_only)
+        finish_ranks(batch, K, gstats)
     else:
-        batch = main_run.run(K, timed_out, pairs=not args.extract_only)
-    finish_ranks(batch, K, gstats)
+        batch = run_ranks(K, timed_out, gstats)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -391,9 +421,18 @@ def main():
     lane_faults = eng.lane_faults()   # pose kernels' lane-agreement self-check: 0 on healthy hardware
     collective = None
     if gstats:
-        e0, e1, nbytes = gstats[-1]
+        e0, e1, nbytes, g = gstats[-1]
         collective = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "gather": args.gather,
-                      "bytes_received_per_rank": int(nbytes), "all_gather_ms": round(e0.elapsed_time(e1), 4)}
+                      "bytes_received_per_rank": int(nbytes)}
+        if g is None:   # one collective after the last frame: its own time, all of it exposed
+            collective.update({"overlapped": False, "all_gather_ms": round(e0.elapsed_time(e1), 4)})
+        else:           # per-batch collectives under the extraction: their summed durations, and what was left after the last frame
+            collective.update({"overlapped": True, "collectives": len(g.bounds), "all_gather_ms": round(g.collective_ms(), 4),
+                               "all_gather_exposed_ms": round(e0.elapsed_time(e1), 4)})
+            # not timed: the pieces against ONE collective over the same rows
+            whole, frame_of = cdist.all_gather_frames(batch.rows[:K], K * world), g.finish()
+            collective["chunks_equal_one_gather"] = all(bool(torch.equal(whole[r * K + i], frame_of(r, i)))
+                                                        for r in range(world) for i in (0, B - 1, K // 2, K - 1))
         try:
             collective["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:

@@ -82,6 +82,60 @@ def all_gather_frames(local_rows, n_frames, group=None):
     return torch.cat(parts, dim=0)
 
 
+class ChunkedFrameGather:
+    """``all_gather_frames`` in pieces that overlap the extraction: the rows of frames [lo, hi) of EVERY rank are gathered on a side
+    stream as soon as the caller says they are complete there (``chunk`` is called once the side stream has been made to wait
+    for them, e.g. ``Pipeline.wait_encoded(side)``), while the pipeline works on the next batch.  Every rank must call ``chunk``
+    with the same (lo, hi) sequence (equal blocks: n_local frames per rank).  Buffers are allocated up front."""
+
+    def __init__(self, rows, n_local, chunk_frames, group=None, even_alone=False):
+        self.rows, self.n, self.group = rows, n_local, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.alone = self.world == 1 and not (even_alone and dist.is_initialized())   # (a world of one still runs the collectives in tests)
+        self.bounds = [(lo, min(n_local, lo + chunk_frames)) for lo in range(0, n_local, chunk_frames)]
+        self.recv = [rows.new_empty((self.world * (hi - lo),) + tuple(rows.shape[1:])) for lo, hi in self.bounds]
+        self.side = torch.cuda.Stream(device=rows.device) if rows.is_cuda else None
+        self.done = 0
+        self.events = []
+
+    def chunk(self, lo, hi):
+        assert self.bounds[self.done] == (lo, hi), "chunks arrive in order, the same on every rank"
+        recv = self.recv[self.done]
+        self.done += 1
+        if self.alone:
+            return
+        if self.side is None:
+            _all_gather_into(recv, self.rows[lo:hi].contiguous(), self.group)
+            return
+        with torch.cuda.stream(self.side):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _all_gather_into(recv, self.rows[lo:hi], self.group)   # (a contiguous slice of the frame rows)
+            e1.record()
+            self.events.append((e0, e1))
+
+    def finish(self):
+        """the current stream waits for the side stream; returns ``frame(rank, i)`` -> rows [K, 64] of frame i of ``rank``."""
+        assert self.done == len(self.bounds)
+        if self.side is not None:
+            torch.cuda.current_stream(self.rows.device).wait_stream(self.side)
+
+        def frame(rank, i):
+            if self.alone:
+                return self.rows[i]
+            c = next(j for j, (lo, hi) in enumerate(self.bounds) if lo <= i < hi)
+            lo, hi = self.bounds[c]
+            return self.recv[c][rank * (hi - lo) + (i - lo)]
+        return frame
+
+    def nbytes(self):
+        return sum(r.numel() * r.element_size() for r in self.recv) if not self.alone else 0
+
+    def collective_ms(self):
+        """sum of the collectives' own durations on the side stream (after a synchronize)"""
+        return sum(e0.elapsed_time(e1) for e0, e1 in self.events)
+
+
 def all_gather_boundary(last_rows, group=None):
     """last_rows [K, 64] (this rank's LAST frame) -> [world, K, 64]: the only remote rows consecutive-pair
     matching needs (rank r matches its first frame against row r-1).  Same single collective as

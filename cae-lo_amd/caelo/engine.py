@@ -183,26 +183,44 @@ class Pipeline:
         jobs["pair_idx"] = out.pair_idx.data_ptr() + idx * (MAX_K * 8)
         return jobs
 
-    def run(self, scans, rands=None, prev=None, dist_channels=5, exact_voxels=False, out=None, pairs=True, dedup=True):
+    def wait_encoded(self, stream):
+        """caelo_pipeline_wait_encoded: ``stream`` (a torch stream) waits for the rows of every frame of the batches issued so far."""
+        _ffi.check(self.eng.lib.caelo_pipeline_wait_encoded(self.h, C.c_void_p(stream.cuda_stream)))
+
+    def run(self, scans, rands=None, prev=None, dist_channels=5, exact_voxels=False, out=None, pairs=True, dedup=True, on_batch=None):
         """scans: K device tensors [n,4] f32; rands: K device tensors of RANSAC draws ([1500,4] f64).
         Frame i is matched against frame i-1 (pose in ``result[i]``); frame 0 against ``prev``
         (FrameFeatures) when given; ``pairs=False`` extracts only (BASELINE configs[1]).  Returns a FrameBatch; the
-        current stream has waited for all lanes."""
+        current stream has waited for all lanes.  ``on_batch(lo, hi)`` is called after frames [lo, hi) have been issued (full
+        batches, the remainder last): with ``wait_encoded`` a caller ships finished rows while later batches run."""
         eng, lib, k = self.eng, self.eng.lib, len(scans)
         out = out or FrameBatch(eng, k)
         assert out.k >= k and (not pairs or len(rands) >= k)
         stream = eng.stream
-        _ffi.check(lib.caelo_pipeline_expect(self.h, k))   # an even batch plan for runs that are not whole batches (caelo.h)
+        # an even batch plan for runs that are not whole batches (caelo.h); with a per-batch callback: full batches, remainder last
+        _ffi.check(lib.caelo_pipeline_expect(self.h, 0 if on_batch else k))
         _ffi.check(lib.caelo_pipeline_begin(self.h, stream))
         for pc in scans:
             assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] == 4 and pc.is_contiguous()
         jobs = self._jobs([pc.data_ptr() for pc in scans], [pc.shape[0] for pc in scans], rands, prev, out, pairs, dist_channels,
                           exact_voxels, dedup)
+        tail = None   # a partial last batch is only issued by the flush: its callback comes after that
         try:
-            _ffi.check(lib.caelo_pipeline_submit_many(self.h, jobs.ctypes.data, k))
+            if on_batch is None:
+                _ffi.check(lib.caelo_pipeline_submit_many(self.h, jobs.ctypes.data, k))
+            else:
+                for lo in range(0, k, self.batch):
+                    hi = min(k, lo + self.batch)
+                    _ffi.check(lib.caelo_pipeline_submit_many(self.h, jobs[lo:hi].ctypes.data, hi - lo))
+                    if hi - lo == self.batch:
+                        on_batch(lo, hi)
+                    else:
+                        tail = (lo, hi)
         finally:
             rc = lib.caelo_pipeline_flush(self.h, stream)
         _ffi.check(rc)
+        if tail:
+            on_batch(*tail)
         return out
 
     def run_uploading(self, host_scans, rands=None, prev=None, dist_channels=5, out=None, pairs=True, dedup=True, slots=3):

@@ -49,7 +49,7 @@ struct caelo_pipeline {
     void *ws_match[CAELO_FB_MAX] = {nullptr}, *ws_ransac[CAELO_FB_MAX] = {nullptr};
     hipEvent_t front_done[MAX_BUFFERS] = {nullptr}, enc_done[MAX_BUFFERS] = {nullptr};
     hipEvent_t begun = nullptr, joined[3] = {nullptr};
-    hipEvent_t ext_in = nullptr, ext_out = nullptr;  // caelo_pipeline_wait_stream / caelo_pipeline_release_scans
+    hipEvent_t ext_in = nullptr, ext_out = nullptr, ext_enc = nullptr;  // caelo_pipeline_wait_stream / _release_scans / _wait_encoded
     // host state
     std::vector<caelo_frame_job> pending;
     uint64_t n_batches = 0, submitted = 0;
@@ -167,7 +167,7 @@ CAELO_API void caelo_pipeline_destroy(caelo_pipeline *p) {
     if (p->begun) (void)hipEventDestroy(p->begun);
     for (hipEvent_t e : p->joined)
         if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {p->vox_fork, p->vox_join, p->ext_in, p->ext_out})
+    for (hipEvent_t e : {p->vox_fork, p->vox_join, p->ext_in, p->ext_out, p->ext_enc})
         if (e) (void)hipEventDestroy(e);
     if (p->sV) (void)hipStreamDestroy(p->sV);
     if (p->sP && p->sP != p->sF) (void)hipStreamDestroy(p->sP);
@@ -231,6 +231,7 @@ CAELO_API int caelo_pipeline_create(caelo_ctx *c, int batch, int n_buffers, int6
     hip_ok(hipEventCreateWithFlags(&p->begun, hipEventDisableTiming), "hipEventCreate");
     hip_ok(hipEventCreateWithFlags(&p->ext_in, hipEventDisableTiming), "hipEventCreate");
     hip_ok(hipEventCreateWithFlags(&p->ext_out, hipEventDisableTiming), "hipEventCreate");
+    hip_ok(hipEventCreateWithFlags(&p->ext_enc, hipEventDisableTiming), "hipEventCreate");
     for (hipEvent_t &e : p->joined) hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
     for (int i = 0; i < n_buffers; ++i) {
         hip_ok(hipEventCreateWithFlags(&p->front_done[i], hipEventDisableTiming), "hipEventCreate");
@@ -357,6 +358,15 @@ CAELO_API int caelo_pipeline_release_scans(caelo_pipeline *p, void *stream) {
     CAELO_REQUIRE(p, "null argument");
     CAELO_HIP(hipEventRecord(p->ext_out, p->sF));
     CAELO_HIP(hipStreamWaitEvent(caelo_stream(stream), p->ext_out, 0));
+    return CAELO_OK;
+}
+
+// ... and `stream` waits for the rows of every frame of the batches issued so far (the encoder stage writes descriptors, the front
+// stage before it the key points and the validity column; the pair stage only reads them).
+CAELO_API int caelo_pipeline_wait_encoded(caelo_pipeline *p, void *stream) {
+    CAELO_REQUIRE(p, "null argument");
+    CAELO_HIP(hipEventRecord(p->ext_enc, p->sE));
+    CAELO_HIP(hipStreamWaitEvent(caelo_stream(stream), p->ext_enc, 0));
     return CAELO_OK;
 }
 

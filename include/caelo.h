@@ -335,6 +335,11 @@ int caelo_pipeline_flush(caelo_pipeline *pipe, void *stream);
  * overwrite their buffers.  Both between caelo_pipeline_begin and caelo_pipeline_flush. */
 int caelo_pipeline_wait_stream(caelo_pipeline *p, void *stream);
 int caelo_pipeline_release_scans(caelo_pipeline *p, void *stream);
+/* Results that leave while the pipeline runs -- the sharded sequence's descriptor all-gather (PoseEstimation.py:241-251 needs the
+ * previous frame's features wherever that frame was extracted): `stream` waits until the rows (descriptors | key points | valid)
+ * of every frame of the batches ISSUED so far are written, and of nothing later -- a collective enqueued on `stream` then moves
+ * finished rows while the next batches are still being extracted.  Between caelo_pipeline_begin and caelo_pipeline_flush. */
+int caelo_pipeline_wait_encoded(caelo_pipeline *p, void *stream);
 /* host-side counters since the last call (then reset): out_host[6] = jobs, ns the calling thread spent issuing their
  * launches, batches launched, batch size, hand-off buffers, HIP streams used */
 /* Optional hint before caelo_pipeline_begin: the run will submit n_frames jobs.  If that is not a multiple of the batch size, the

@@ -331,6 +331,29 @@ def test_rccl_all_gather_of_frame_rows(engine):
         assert torch.equal(cd.all_gather_frames(rows, 3), rows)
         rt = torch.rand((2, 12), device=engine.device)
         assert torch.equal(cd.gather_poses(rt, 3), rt)
+        # rows shipped while the pipeline runs: every batch's rows go through an RCCL collective on a side stream as soon as the
+        # batch is encoded (caelo_pipeline_wait_encoded) -- what arrives must be the finished rows, not what the buffer held before
+        from caelo import synth
+        from caelo.engine import FrameBatch, ransac_draws
+        n, pipe = 10, engine.pipeline(4, 3)
+        scans = [torch.from_numpy(synth.make_scan(i % 3, quantum=1e-3)).to(engine.device) for i in range(n)]
+        draws = [torch.from_numpy(ransac_draws(i)).to(engine.device) for i in range(n)]
+        out = FrameBatch(engine, n)
+        out.rows.fill_(float("nan"))
+        g = cd.ChunkedFrameGather(out.rows, n, 4, even_alone=True)
+
+        def shipped(lo, hi):
+            pipe.wait_encoded(g.side)
+            g.chunk(lo, hi)
+        batch = pipe.run(scans, draws, out=out, on_batch=shipped)
+        frame_of = g.finish()
+        torch.cuda.synchronize()
+        assert len(g.events) == 3 and g.nbytes() == n * 1024 * 64 * 4
+        for i in range(n):
+            assert torch.equal(frame_of(0, i), batch.rows[i]) and not torch.isnan(frame_of(0, i)).any()
+        ref = pipe.run(scans, draws)
+        torch.cuda.synchronize()
+        assert torch.equal(ref.rows[:n], batch.rows[:n])   # the per-batch submission changes nothing
     finally:
         dist.destroy_process_group()
 
@@ -642,6 +665,13 @@ def test_two_ranks_equal_one_rank(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 8 and d["config"]["poses_solved"] == "64/64" and d["value"] > 0   # a step = a batch of 8 frames
     c = d["config"]["collective"]
     assert c["world_size"] == 2 and c["backend"] == "gloo" and c["bytes_received_per_rank"] == 2 * 64 * 1024 * 64 * 4   # --gather all
+    # the default ships every batch's rows as soon as it is encoded (caelo_pipeline_wait_encoded): eight collectives, the same rows
+    assert c["overlapped"] and c["collectives"] == 8 and c["chunks_equal_one_gather"]
+    r = subprocess.run(launch + ["--master-port", "29543", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3",
+                                 "--warmup", "1", "--no-cpu-baseline", "--gather-overlap", "0"], check=True, env=env,
+                       capture_output=True, timeout=300)
+    d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith('{"metric"')][-1])
+    assert d["config"]["poses_solved"] == "24/24" and d["config"]["collective"]["overlapped"] is False
 
 
 def test_icp_vs_reference_golden(api, orc, models, scans):
