@@ -42,9 +42,12 @@ caelo.configure_runtime()  # before the first device call: 8 hardware queues, so
 from caelo import dist as cdist  # noqa: E402
 from caelo.engine import Engine, FrameBatch, FrameFeatures, ransac_draws  # noqa: E402
 
-POOL = 6  # distinct consecutive synthetic frames per rank, walked back and forth (0 1 .. 5 4 .. 1 0 1 ..) so that every
-          # timed pair is a pair of NEIGHBOURING scans, like a real sequence (cycling 5 -> 0 would make every sixth pair
-          # a 4.5 m jump whose match fails and escalates RANSAC to 1.6 m)
+POOL = 17  # distinct consecutive synthetic frames per rank, walked back and forth (0 1 .. 16 15 .. 1 0 1 ..) so that every
+           # timed pair is a pair of NEIGHBOURING scans, like a real sequence (cycling 16 -> 0 would make a 14 m jump whose
+           # match fails and escalates RANSAC to 1.6 m).  2 x 8 + 1 frames: the walk's period is four batches of 8 and its
+           # turning points fall on batch boundaries, so NO BATCH HOLDS A SCAN TWICE -- equal patches are looked for across
+           # the frames of a batch, and a repeated scan would be encoded for free (a pool of 6 did that: 20.4 k frames/s
+           # instead of 18.x k; a real sequence never repeats a scan)
 QUANTUM = 1e-3  # coordinates in whole millimetres, like the metrically quantised values of real scans: every frame then
                 # holds points exactly on voxel faces (tests/golden/frame_q0.npz: 14 of 126 k), which the voxelization
                 # resolves like the reference's float64 index arithmetic (Voxel.py:118-152)
@@ -295,6 +298,8 @@ def main():
     if world > 1:
         dist.init_process_group(backend=backend, **({"device_id": dev} if backend == "nccl" else {}))
     B = pipe.batch
+    global POOL
+    POOL = 2 * B + 1   # (see the comment at the top: the walk's turning points fall on batch boundaries)
     steps_rank = args.steps if args.scaling == "weak" else max(1, args.steps // world)
     K, W = steps_rank * B, args.warmup * B          # frames per rank in the timed region / in the warm-up
 
@@ -325,6 +330,7 @@ def main():
 
         def run(self, n, out=None, pairs=True, scans=None, on_batch=None):
             o = self.order(n)
+            assert n % B or all(len(set(o[i:i + B])) == B for i in range(0, n, B)), "a batch holds a scan twice"
             batch = pipe.run(scans if scans is not None else [self.pool[j] for j in o], [rand[j] for j in o],
                              prev=self.prev if pairs else None, pairs=pairs, out=out, on_batch=on_batch, **self.kw)
             self.prev = batch.frame(n - 1)
@@ -479,8 +485,11 @@ def main():
         batch_bits = torch.cat([frame_bits[i % len(frame_bits)].reshape(-1, 64) for i in range(B)], dim=0).contiguous()
         table, ms_avg, alg_tf, exec_share, n_patches = encoder_table(batch_bits)
         dom = int(np.argmax(ms_avg))
+        # share of the patches of a batch (B different consecutive scans) that are copies of another patch of the batch; and of
+        # a frame alone (what round 2 exploited)
         distinct = [len(torch.unique(b.reshape(-1, 64), dim=0)) for b in frame_bits]
-        dedup_share = round(1.0 - float(np.mean(distinct)) / 3072.0, 4)
+        dedup_share_frame = round(1.0 - float(np.mean(distinct)) / 3072.0, 4)
+        dedup_share = round(1.0 - len(torch.unique(batch_bits.reshape(-1, 64), dim=0)) / float(batch_bits.numel() // 64), 4)
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; the per-launch
         # FETCH_SIZE / WRITE_SIZE of the same launch (separate rocprofv3 --pmc passes) are committed under profiles/.
         traffic, traffic_note = None, None
@@ -541,8 +550,9 @@ def main():
                                      "operand splits (|x - hi - lo| <= 2^-22 |x|) on the f16 matrix "
                                      "pipe -- f32-grade (descriptors 1.5e-6 from the f32 oracle, which is itself 1.3e-6 from an f64 "
                                      "evaluation; per-layer budget in tests); NN match: f16 screen + float64 certification = the float64 argmin",
-                       "dedup": "bit-identical patches of a frame are encoded once (exact; DESIGN.md 4.7); the roofline "
-                                "object times the encoder kernels on all 3072 patches", "dedup_share": dedup_share,
+                       "dedup": "bit-identical patches of a batch of frames are encoded once (exact; DESIGN.md 4.7, 4.13; no batch "
+                                "holds a scan twice); the roofline object times the encoder kernels on all 3072 patches of every frame",
+                       "dedup_share": dedup_share, "dedup_share_within_frames": dedup_share_frame,
                        "uploads_in_timed_region": bool(args.include_h2d),
                        "points_per_frame": n_points, "keypoints": 1024, "patches_per_frame": 3072,
                        "frames_per_gpu": K, "hip_streams_per_gpu": host["streams"], "hip_streams_note": streams_note,
@@ -607,7 +617,8 @@ def secondary_legs(args, eng, pipe, dev, pool, rand, Runner, frame_patches, enco
     t2, ms2, _, share2, _ = encoder_table(torch.cat([bits2[i % len(bits2)].reshape(-1, 64) for i in range(B)], dim=0).contiguous())
     sec["scene_" + other] = {"frames_per_s": fps2, "poses_solved": "%d/%d" % (ok2, 2 * B),
                              "workload": "configs[2] on the other synthetic scene (%s)" % other,
-                             "dedup_share": round(1.0 - float(np.mean([len(torch.unique(b.reshape(-1, 64), dim=0)) for b in bits2])) / 3072.0, 4),
+                             "dedup_share": round(1.0 - len(torch.unique(torch.cat([b.reshape(-1, 64) for b in bits2]), dim=0)) / float(3072 * len(bits2)), 4),
+                             "dedup_share_within_frames": round(1.0 - float(np.mean([len(torch.unique(b.reshape(-1, 64), dim=0)) for b in bits2])) / 3072.0, 4),
                              "executed_mfma_share": round(share2, 4), "stage1_launch_ms": round(float(ms2[0]), 4),
                              "stage1_pipe_frac": t2[names[0]]["pipe_frac"], "encoder_total_ms_all_patches": round(float(ms2.sum()), 4)}
     # configs[4]: one frame's time through the 32^3 path (bench.py --config dense128 gives its own full line)

@@ -225,22 +225,27 @@ struct caelo_dedup_tables {
     int32_t count;  // distinct patches of the frame
     int32_t pad[63];
     int32_t list[CAELO_FRAME_PATCHES];     // their patch indices (key point * 3 + scale), coarsest scale first
-    int32_t slot_of[CAELO_FRAME_PATCHES];  // patch -> position of its representative in list
+    int32_t slot_of[CAELO_FRAME_PATCHES];  // patch -> ROW of its representative in the launch set: (its frame) * 3072 + position in that frame's list
 };
 #define CAELO_FRAME_BITS_BYTES ((size_t)CAELO_FRAME_PATCHES * 64 * 8)
 #define CAELO_FRAME_BUF_BYTES (CAELO_FRAME_BITS_BYTES + sizeof(caelo_dedup_tables))
 __host__ __device__ inline caelo_dedup_tables *caelo_frame_tables(const uint64_t *frame_bits) {
     return (caelo_dedup_tables *)((char *)frame_bits + CAELO_FRAME_BITS_BYTES);
 }
-#define DD_SLOTS 8192  // >= 2.6 x the 3072 patches of a frame
+// Equal patches are looked for across ALL frames of a launch set (round 3: a batch of 8 consecutive scans shares ~13 % more of
+// its patches than its frames do one by one): the frames of a set enter their patches into ONE table, frame 0's, under the
+// index (frame * 3072 + patch); a set of one frame uses the first DD_SLOTS_FRAME slots only (that is all it has to wipe).
+#define DD_SLOTS_FRAME 8192    // >= 2.6 x the 3072 patches of a frame
+#define DD_SLOTS_SET 65536     // >= 2.6 x the patches of CAELO_FB_MAX frames
 #define DD_EMPTY 0xFFFFFFFFFFFFFFFFull
 struct DedupScratch {
-    unsigned long long table[DD_SLOTS];  // (hash40 << 24) | smallest patch index, DD_EMPTY = free (cleared per frame)
-    int32_t pslot[CAELO_FRAME_PATCHES];
-    int32_t rep[CAELO_FRAME_PATCHES];
+    unsigned long long table[DD_SLOTS_SET];  // (hash40 << 24) | smallest (frame * 3072 + patch), DD_EMPTY = free (cleared per set)
+    int32_t pslot[CAELO_FRAME_PATCHES];      // this frame's patches: their slots in the set's table
+    int32_t rep[CAELO_FRAME_PATCHES];        // ... and their representatives (frame * 3072 + patch; itself: a distinct patch)
 };
+__host__ __device__ inline uint32_t dedup_slot_mask(int n_frames) { return (n_frames > 1 ? DD_SLOTS_SET : DD_SLOTS_FRAME) - 1; }
 int64_t dedup_scratch_bytes();
-void dedup_clear_item(void *scratch, caelo_clear_list &list);
+void dedup_clear_item(void *scratch, int n_frames, caelo_clear_list &list);
 unsigned long long dedup_hash_mask();  // 40 bits unless CAELO_DEDUP_HASH_BITS shrinks it (collision tests)
 bool dedup_enabled(int mode);          // mode bit CAELO_EXTRACT_NO_DEDUP / CAELO_NO_DEDUP=1 switch it off
 int dedup_launch(uint64_t *frame_bits, void *scratch, bool enabled, hipStream_t s);  // after k_patches filled the table
@@ -336,26 +341,28 @@ __device__ inline unsigned long long caelo_dd_mix(unsigned long long k) {
     k ^= k >> 33;
     return k;
 }
-__device__ inline void caelo_dedup_insert(unsigned long long word, int lane, int p, DedupScratch *S, unsigned long long hash_mask) {
+// S: the frame's scratch (pslot); T: the set's table (frame 0's); gp = frame * 3072 + p
+__device__ inline void caelo_dedup_insert(unsigned long long word, int lane, int p, int gp, DedupScratch *S, DedupScratch *T, uint32_t slot_mask,
+                                          unsigned long long hash_mask) {
     unsigned long long h = caelo_dd_mix(word + 0x9E3779B97F4A7C15ull * (unsigned)(lane + 1));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);  // order independent across lanes, position dependent per word
     if (lane != 0) return;
     h = caelo_dd_mix(h) & hash_mask & 0xFFFFFFFFFEull;  // 40 bits, never all ones
-    const unsigned long long mine = (h << 24) | (unsigned)p;
-    uint32_t slot = (uint32_t)(caelo_dd_mix(h) & (DD_SLOTS - 1));
+    const unsigned long long mine = (h << 24) | (unsigned)gp;
+    uint32_t slot = (uint32_t)caelo_dd_mix(h) & slot_mask;
     for (;;) {
         // compare-and-swap first, no look: one memory round trip for the wave to wait out instead of two (the table is mostly
         // empty at its load factor, and a wave of k_patches lives ~5 round trips in all)
-        const unsigned long long cur = atomicCAS(&S->table[slot], DD_EMPTY, mine);
+        const unsigned long long cur = atomicCAS(&T->table[slot], DD_EMPTY, mine);
         if (cur == DD_EMPTY) break;
         if ((cur >> 24) == h) {
             // hundreds of patches share a popular pattern: only a smaller index than the one seen needs the atomic (a
             // stale larger value only costs an atomic that changes nothing)
-            if (mine < cur) atomicMin(&S->table[slot], mine);
+            if (mine < cur) atomicMin(&T->table[slot], mine);
             break;
         }
-        slot = (slot + 1) & (DD_SLOTS - 1);
+        slot = (slot + 1) & slot_mask;
     }
     S->pslot[p] = (int32_t)slot;
 }

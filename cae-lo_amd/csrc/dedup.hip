@@ -21,38 +21,43 @@
 #include "caelo_internal.h"
 
 int64_t dedup_scratch_bytes() { return (int64_t)sizeof(DedupScratch); }
-void dedup_clear_item(void *scratch, caelo_clear_list &list) {
-    list.item[list.n++] = {scratch, sizeof(unsigned long long) * DD_SLOTS, 0xFFFFFFFFu};
+void dedup_clear_item(void *scratch, int n_frames, caelo_clear_list &list) {
+    list.item[list.n++] = {scratch, sizeof(unsigned long long) * ((size_t)dedup_slot_mask(n_frames) + 1), 0xFFFFFFFFu};
 }
 
 // (the per-patch hash + table insert runs at the end of k_patches, voxel.hip: caelo_dedup_insert in caelo_internal.h)
 
 // one wavefront per patch: word-by-word comparison with the group's representative
+// the candidate representative of a patch = the smallest (frame, patch) with its hash; equal only if the 512 bytes are
 __global__ void __launch_bounds__(256) k_dd_verify(const caelo_frame_set fs) {
     const unsigned long long *__restrict__ bits = fs.f[blockIdx.z].bits;
     DedupScratch *S = fs.f[blockIdx.z].dd;
+    const DedupScratch *T = fs.f[0].dd;
     const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int r = (int)(S->table[S->pslot[p]] & 0xFFFFFFull);
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), gp = blockIdx.z * CAELO_FRAME_PATCHES + p;
+    const int r = (int)(T->table[S->pslot[p]] & 0xFFFFFFull);
     bool same = true;
-    if (r != p) same = __all(bits[(size_t)p * 64 + lane] == bits[(size_t)r * 64 + lane]) != 0;
-    if (lane == 0) S->rep[p] = same ? r : p;
+    if (r != gp) {
+        const int fr = r / CAELO_FRAME_PATCHES, rl = r - fr * CAELO_FRAME_PATCHES;
+        same = __all(bits[(size_t)p * 64 + lane] == fs.f[fr].bits[(size_t)rl * 64 + lane]) != 0;
+    }
+    if (lane == 0) S->rep[p] = same ? r : gp;
 }
 
-// one workgroup: the representatives in encoder order (scale 2, 1, 0; key point index within a scale)
+// per frame: the list of its distinct patches (those that represent themselves), coarsest scale first, and their rows
 __global__ void __launch_bounds__(1024) k_dd_scan(const caelo_frame_set fs, int identity) {
     const DedupScratch *S = fs.f[blockIdx.z].dd;
     caelo_dedup_tables *T = caelo_frame_tables((const uint64_t *)fs.f[blockIdx.z].bits);
     __shared__ int wsum[16];
-    __shared__ int pos_of[CAELO_FRAME_PATCHES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int base = blockIdx.z * CAELO_FRAME_PATCHES;
     int flag[3], p[3];
     int mine = 0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int o = tid * 3 + j;  // order index: scale 2 first
         p[j] = (o & 1023) * 3 + (2 - (o >> 10));
-        flag[j] = identity || S->rep[p[j]] == p[j];
+        flag[j] = identity || S->rep[p[j]] == base + p[j];
         mine += flag[j];
     }
     int incl = mine;
@@ -63,26 +68,36 @@ __global__ void __launch_bounds__(1024) k_dd_scan(const caelo_frame_set fs, int 
     }
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    int base = 0, total = 0;
+    int off = 0, total = 0;
     for (int w = 0; w < 16; ++w) {
-        if (w < wave) base += wsum[w];
+        if (w < wave) off += wsum[w];
         total += wsum[w];
     }
-    int pos = base + incl - mine;
+    int pos = off + incl - mine;
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < 3; ++j) {
         if (flag[j]) {
             T->list[pos] = p[j];
-            pos_of[p[j]] = pos;
+            T->slot_of[p[j]] = base + pos;   // its own row
             ++pos;
         }
+    }
     if (tid == 0) T->count = total;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 3; ++j) T->slot_of[p[j]] = pos_of[identity ? p[j] : S->rep[p[j]]];
 }
 
-// bits: the frame's [3072][64] u64 patches, followed by its caelo_dedup_tables (caelo_frame_tables)
+// ... and every other patch takes the row of its representative (any frame of the set); a launch of its own: the
+// representative's row is written by another workgroup of k_dd_scan
+__global__ void __launch_bounds__(256) k_dd_link(const caelo_frame_set fs) {
+    const DedupScratch *S = fs.f[blockIdx.z].dd;
+    caelo_dedup_tables *T = caelo_frame_tables((const uint64_t *)fs.f[blockIdx.z].bits);
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= CAELO_FRAME_PATCHES) return;
+    const int r = S->rep[p];
+    if (r == (int)blockIdx.z * CAELO_FRAME_PATCHES + p) return;
+    const int fr = r / CAELO_FRAME_PATCHES, rl = r - fr * CAELO_FRAME_PATCHES;
+    T->slot_of[p] = caelo_frame_tables((const uint64_t *)fs.f[fr].bits)->slot_of[rl];
+}
+
 unsigned long long dedup_hash_mask() {
     static const unsigned long long mask = [] {
         const char *e = getenv("CAELO_DEDUP_HASH_BITS");
@@ -114,5 +129,9 @@ int dedup_set(const caelo_frame_set &fs, bool enabled, hipStream_t s) {
     }
     k_dd_scan<<<dim3(1, 1, fs.n), 1024, 0, s>>>(fs, enabled ? 0 : 1);
     CAELO_LAUNCH_CHECK();
+    if (enabled) {
+        k_dd_link<<<dim3(CAELO_FRAME_PATCHES / 256, 1, fs.n), 256, 0, s>>>(fs);
+        CAELO_LAUNCH_CHECK();
+    }
     return CAELO_OK;
 }

@@ -1918,7 +1918,7 @@ __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part
         ROW = (P);                                                                \
         if (in.dedup) {                                                           \
             const unsigned f_ = (P) / per_in;                                     \
-            ROW = f_ * per_in + (unsigned)enc_tables(in, (int)f_)->slot_of[(P) - f_ * per_in]; \
+            ROW = (unsigned)enc_tables(in, (int)f_)->slot_of[(P) - f_ * per_in];  /* (a row of the whole launch set) */ \
         }                                                                         \
     }
     const bool ok = lane < DENSE_N / 4;
@@ -2032,6 +2032,8 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
                                  (int64_t)ein.n_frames * ein.per_frame == n_patches),
                   "bad de-duplicated launch");
     CAELO_REQUIRE(outs.per_frame > 0 && (n_patches + outs.per_frame - 1) / outs.per_frame <= CAELO_ENC_MAX_FRAMES, "bad frame table");
+    // (the de-duplication tables address representatives by row of the launch set = frame * 3072 + position: dedup.hip)
+    CAELO_REQUIRE(!ein.dedup || ein.per_frame == CAELO_FRAME_PATCHES, "de-duplicated launches hold whole frames of 3072 patches");
     CAELO_REQUIRE(c->has_enc, "encoder weights not set (caelo_set_encoder_weights)");
     CAELO_REQUIRE(n_patches > 0 && n_patches < 0x7FFFFFFF && group >= 1 && out_stride >= group * 20, "bad shape");
     const int64_t np = pad64(n_patches);

@@ -188,7 +188,7 @@ int extract_front_set(const caelo_extract_args *args, int n, hipStream_t s, hipS
         cl[i].item[cl[i].n++] = {d.cand_count, L.ring - L.cand_count, 0u};
         cl[i].item[cl[i].n++] = {a.status, 16, 0u};  // status is int32[4], 16-byte aligned (word 0 carries the bits)
         if (exact_vox) vox_clear_items(a.map, 1, cl[i]);
-        dedup_clear_item(ws + L.dd, cl[i]);
+        if (i == 0) dedup_clear_item(ws + L.dd, n, cl[i]);  // the set's table lives in frame 0's scratch
     }
     int rc = CAELO_OK;
     if (!exact_vox && (rc = vox_clear_for_fast_build_set(maps, n, cl, s))) return rc;  // wipes the previous frames' bricks only

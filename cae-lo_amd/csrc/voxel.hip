@@ -883,7 +883,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_OCC) k_patches(const caelo_f
     if (kp >= K) {
         out[lane] = 0ull;
         if (lane == 0) flags[pw] = 0;
-        if (dd) caelo_dedup_insert(0ull, lane, (int)pw, dd, dd_mask);
+        if (dd) caelo_dedup_insert(0ull, lane, (int)pw, (int)(blockIdx.z * CAELO_FRAME_PATCHES + pw), dd, fs.f[0].dd, dedup_slot_mask(fs.n), dd_mask);
         return;
     }
     const caelo_brick_table tab = scale == 0 ? t0 : (scale == 1 ? t1 : t2);
@@ -1117,7 +1117,8 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_OCC) k_patches(const caelo_f
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) fl |= __shfl_xor(fl, o);
     out[lane] = word;
-    if (dd) caelo_dedup_insert(word, lane, (int)pw, dd, dd_mask);  // equal patches are encoded once (dedup.hip)
+    if (dd)  // equal patches of the launch set are encoded once (dedup.hip)
+        caelo_dedup_insert(word, lane, (int)pw, (int)(blockIdx.z * CAELO_FRAME_PATCHES + pw), dd, fs.f[0].dd, dedup_slot_mask(fs.n), dd_mask);
     if (lane == 0) flags[pw] = (uint8_t)fl;
     PATCH_STAMP(3);
 }

@@ -7,12 +7,15 @@ from caelo import synth, _ffi
 import caelo; caelo.configure_runtime()
 from caelo.engine import Engine, ransac_draws
 eng = Engine()
-pcs = [torch.from_numpy(synth.make_scan(i, quantum=1e-3)).to(eng.device) for i in range(6)]
-rnd = [torch.from_numpy(ransac_draws(i)).to(eng.device) for i in range(6)]
+# 17 consecutive scans walked back and forth, 8 per batch: no batch holds a scan twice (equal patches are looked for across
+# the frames of a batch; like bench.py)
+pcs = [torch.from_numpy(synth.make_scan(i, quantum=1e-3)).to(eng.device) for i in range(17)]
+rnd = [torch.from_numpy(ransac_draws(i)).to(eng.device) for i in range(17)]
 pipe = eng.pipeline(8)
-order = [0, 1, 2, 3, 4, 5, 4, 3, 2, 1] * 8
+order = ([i for i in range(1, 17)] + [i for i in range(15, -1, -1)]) * 2
 scans = [pcs[i] for i in order[:64]]; draws = [rnd[i] for i in order[:64]]
-prev = eng.extract(pcs[1])
+assert all(len(set(order[i:i + 8])) == 8 for i in range(0, 64, 8))
+prev = eng.extract(pcs[0])
 for _ in range(3):
     pipe.run(scans, draws, prev=prev)
 torch.cuda.synchronize()
