@@ -47,7 +47,7 @@ $R/tools/micro/wave_placement.bin > $O/wave_placement.txt 2>&1
 # the front half: SQ counters per kernel, and the round-2 forms of the response layer / key point selection beside the defaults
 timeout 600 bash $R/tools/pmc_front.sh > $O/pmc_front.txt 2>&1
 ( echo "# defaults"; bash $R/tools/front_times.sh; echo "# CAELO_RESPOND=valu CAELO_KP_SELECT=single (round 2's kernels)"; CAELO_RESPOND=valu CAELO_KP_SELECT=single bash $R/tools/front_times.sh "k_respond|k_kp_" ) > $O/front_times.txt 2>&1
-( cd $R && T=600 py cae-lo_amd/run_sequence.py --synthetic 4541 --pool 48 --quantum 0.001 --chunk 240 --out $O/poses_kitti00_sized.txt 2>&1 | tail -1 ) > $O/run_sequence_4541.txt
+( cd $R && T=600 py cae-lo_amd/run_sequence.py --synthetic 4541 --pool 49 --quantum 0.001 --chunk 240 --out $O/poses_kitti00_sized.txt 2>&1 | tail -1 ) > $O/run_sequence_4541.txt
 ( cd $R && timeout 300 python tools/stress_pairs.py 12 2>&1 | tail -1 ) > $O/stress_pairs.txt
 rm -f $O/poses_kitti00_sized.txt
 ls -la $O

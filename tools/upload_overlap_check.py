@@ -7,14 +7,16 @@ import caelo; caelo.configure_runtime()
 from caelo import synth
 from caelo.engine import Engine, FrameBatch, ransac_draws
 eng = Engine()
-pool = [torch.from_numpy(synth.make_scan(i, quantum=1e-3)) for i in range(6)]
+pool = [torch.from_numpy(synth.make_scan(i, quantum=1e-3)) for i in range(17)]   # 2 x 8 + 1: no batch holds a scan twice (like bench.py)
 host = [p.pin_memory() for p in pool]
 dev = [p.to(eng.device) for p in pool]
-rnd = [torch.from_numpy(ransac_draws(i)).to(eng.device) for i in range(6)]
+rnd = [torch.from_numpy(ransac_draws(i)).to(eng.device) for i in range(17)]
 pipe = eng.pipeline(8, 3)
 n = 256
-order = [(0,1,2,3,4,5,4,3,2,1)[i % 10] for i in range(n)]
-prev = eng.extract(dev[1])
+walk = list(range(1, 17)) + list(range(15, -1, -1))
+order = [walk[i % 32] for i in range(n)]
+assert all(len(set(order[i:i + 8])) == 8 for i in range(0, n, 8))
+prev = eng.extract(dev[0])
 out = FrameBatch(eng, n)
 def t(f, reps=3):
     f(); torch.cuda.synchronize()
