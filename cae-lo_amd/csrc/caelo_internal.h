@@ -202,7 +202,7 @@ int ring_keypoints_launch(const float *ring, int ring_w, int ring_c, int dist_c,
                           int64_t *key_pixels, float *key_pts, int kp_ld, float *valid, int valid_ld, int32_t *n_key,
                           int32_t *status, hipStream_t s);
 int ring_project_set(const caelo_frame_set &fs, hipStream_t s);
-int ring_respond_set(caelo_ctx *c, const caelo_frame_set &fs, int in_w, int in_c, hipStream_t s);
+int ring_respond_set(caelo_ctx *c, const caelo_frame_set &fs, int in_w, int in_c, hipStream_t s, int row0, int rows);
 int ring_keypoints_set(const caelo_frame_set &fs, int ring_w, int ring_c, int cnt_w, hipStream_t s);
 void vox_clear_items(caelo_voxmap *m, int level, caelo_clear_list &list);  // 0 brick keys only, 1 + scale-0 first-touch table, 2 everything
 // clear for a fused build: if the map holds nothing but the previous fused build, its listed bricks are wiped by a

@@ -207,7 +207,8 @@ int extract_front_set(const caelo_extract_args *args, int n, hipStream_t s, hipS
     if (s_vox) CAELO_HIP(hipEventRecord(ev_join, s_vox));
     // ---- ring image, response, keypoints
     if ((rc = ring_project_set(fs, s))) return rc;
-    if ((rc = ring_respond_set(args[0].ctx, fs, CAELO_RING_W, CAELO_RING_C, s))) return rc;
+    // (the key point rule reads response rows 8..55 and their 5 x 5 neighbourhoods: rows 6..57 of 64)
+    if ((rc = ring_respond_set(args[0].ctx, fs, CAELO_RING_W, CAELO_RING_C, s, 6, 52))) return rc;
     if ((rc = ring_keypoints_set(fs, CAELO_RING_W, CAELO_RING_C, CAELO_RING_W, s))) return rc;
     if (s_vox) CAELO_HIP(hipStreamWaitEvent(s, ev_join, 0));
     // ---- patches

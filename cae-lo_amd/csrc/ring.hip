@@ -194,11 +194,11 @@ CAELO_API int caelo_project(caelo_ctx *c, const float *pc, int64_t n, float *rin
 // response image -- and therefore the keypoint indices -- are bit-identical to the oracle's.
 // Weights are indexed uniformly across the wave -> scalar loads.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_respond(const caelo_frame_set fs, int in_w, int in_c, const float *__restrict__ wts) {
+__global__ void __launch_bounds__(256) k_respond(const caelo_frame_set fs, int in_w, int in_c, const float *__restrict__ wts, int row0) {
     const float *__restrict__ in = fs.f[blockIdx.z].ring;
     float *__restrict__ resp = fs.f[blockIdx.z].resp;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
+    const int y = blockIdx.y + row0;
     if (x >= CAELO_NET_W) return;
     const float *w1 = wts, *b1 = wts + 864, *w2 = wts + 896, *b2 = wts + 1152;
     float h[32];
@@ -278,11 +278,11 @@ static void respond_fragments(const float *w1, const float *b1, const float *w2,
     }
 }
 
-__global__ void __launch_bounds__(64) k_respond_mfma(const caelo_frame_set fs, int in_w, int in_c, const float *__restrict__ wts) {
+__global__ void __launch_bounds__(64) k_respond_mfma(const caelo_frame_set fs, int in_w, int in_c, const float *__restrict__ wts, int row0) {
     const float *__restrict__ in = fs.f[blockIdx.z].ring;
     float *__restrict__ resp = fs.f[blockIdx.z].resp;
     const int lane = threadIdx.x, g = lane >> 4, n = lane & 15;
-    const int y = blockIdx.y;
+    const int y = blockIdx.y + row0;
     constexpr int NBLK = CAELO_NET_W / RESP_BPX, NLD = (RESP_STAGE + 63) / 64;
     __shared__ float s_in[2][((RESP_STAGE + 63) / 64) * 64];  // (padded: every lane stores NLD elements)
     // staging: element i = lane + 64 q of [row 3][pixel RESP_BPX + 2][channel 3]; everything but the block's column is loop-invariant
@@ -398,20 +398,23 @@ int ring_respond_launch(caelo_ctx *c, const float *in, int in_w, int in_c, float
     caelo_frame_set fs = {};
     fs.n = 1;
     fs.f[0].ring = const_cast<float *>(in); fs.f[0].resp = resp;
-    return ring_respond_set(c, fs, in_w, in_c, s);
+    return ring_respond_set(c, fs, in_w, in_c, s, 0, CAELO_NET_H);
 }
 
-int ring_respond_set(caelo_ctx *c, const caelo_frame_set &fs, int in_w, int in_c, hipStream_t s) {
+// rows row0 .. row0 + rows - 1 of the response image (the fused path only needs the rows the key point rule reads: 8..55 and two
+// either side; the staged entry point computes all 64)
+int ring_respond_set(caelo_ctx *c, const caelo_frame_set &fs, int in_w, int in_c, hipStream_t s, int row0, int rows) {
     static_assert(CAELO_NET_W % RESP_BPX == 0, "k_respond_mfma has no partial blocks");
     // CAELO_RESPOND=valu: the one-thread-per-pixel kernel (bit-identical; the timing reference)
     static const bool valu = getenv("CAELO_RESPOND") && !strcmp(getenv("CAELO_RESPOND"), "valu");
-    if (valu) k_respond<<<dim3((CAELO_NET_W + 255) / 256, CAELO_NET_H, fs.n), 256, 0, s>>>(fs, in_w, in_c, c->resp_w);
+    if (valu) k_respond<<<dim3((CAELO_NET_W + 255) / 256, rows, fs.n), 256, 0, s>>>(fs, in_w, in_c, c->resp_w, row0);
     else {
         // Waves per row.  The dispatcher spreads a grid evenly over the 1024 SIMDs (tools/micro/wave_placement.hip), so the grid
-        // should be a multiple of 1024 waves with equal work each: 8 frames x 64 rows x 8 = 4096 waves of 7 blocks (2048 waves
-        // of 64-pixel blocks left 109 SIMDs with three waves and 109 with one: the matrix pipe of the former set the time)
-        const unsigned gx = fs.n >= 4 ? 8u : (fs.n >= 2 ? 28u : 56u);
-        k_respond_mfma<<<dim3(gx, CAELO_NET_H, fs.n), 64, 0, s>>>(fs, in_w, in_c, c->resp_w);
+        // should come close to a multiple of 1024 waves with equal work each: 8 frames x 64 rows x 8 = 4096 waves of 7 blocks (2048
+        // waves of 64-pixel blocks left 109 SIMDs with three waves and 109 with one: the matrix pipe of the former set the time).
+        // For the fused path's 52 rows, measured: 4 / 7 / 8 / 14 / 28 waves per row = 40.5 / 32.7 / 30.3 / 28.0 / 29.4 us
+        const unsigned gx = fs.n >= 4 ? (rows == CAELO_NET_H ? 8u : 14u) : (fs.n >= 2 ? 28u : 56u);
+        k_respond_mfma<<<dim3(gx, rows, fs.n), 64, 0, s>>>(fs, in_w, in_c, c->resp_w, row0);
     }
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
