@@ -41,6 +41,11 @@ py $R/tools/stage1_density_sweep.py > $O/stage1_density_sweep.txt 2>&1
 py $R/tools/match_stats.py 2>&1 | tail -4 > $O/match_stats.txt
 py $R/tools/upload_overlap_check.py 2>&1 | tail -3 > $O/upload_overlap.txt
 py $R/tools/micro/h2d_bandwidth.py > $O/h2d_bandwidth.txt 2>&1
+# the micro-benchmarks (binaries are not tracked: built here when missing)
+for m in f16_mfma_subnormal:f16sub mfma_f32_order:mfma_order wave_placement:wave_placement; do
+  src=$R/tools/micro/${m%%:*}.hip; bin=$R/tools/micro/${m##*:}.bin
+  [ -x $bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Wno-unused-result -Xclang -target-feature -Xclang -packed-fp32-ops $src -o $bin > /dev/null 2>&1
+done
 $R/tools/micro/f16sub.bin > $O/f16_mfma_subnormal.txt 2>&1
 $R/tools/micro/mfma_order.bin > $O/mfma_f32_order.txt 2>&1
 $R/tools/micro/wave_placement.bin > $O/wave_placement.txt 2>&1
