@@ -225,7 +225,7 @@ struct caelo_dedup_tables {
     int32_t count;  // distinct patches of the frame
     int32_t pad[63];
     int32_t list[CAELO_FRAME_PATCHES];     // their patch indices (key point * 3 + scale), coarsest scale first
-    int32_t slot_of[CAELO_FRAME_PATCHES];  // patch -> ROW of its representative in the launch set: (its frame) * 3072 + position in that frame's list
+    int32_t slot_of[CAELO_FRAME_PATCHES];  // a distinct patch -> its ROW in the launch set (frame * 3072 + position in the frame's list); a copy -> -(representative + 1), representative = frame * 3072 + patch
 };
 #define CAELO_FRAME_BITS_BYTES ((size_t)CAELO_FRAME_PATCHES * 64 * 8)
 #define CAELO_FRAME_BUF_BYTES (CAELO_FRAME_BITS_BYTES + sizeof(caelo_dedup_tables))

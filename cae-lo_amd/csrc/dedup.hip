@@ -80,22 +80,14 @@ __global__ void __launch_bounds__(1024) k_dd_scan(const caelo_frame_set fs, int 
             T->list[pos] = p[j];
             T->slot_of[p[j]] = base + pos;   // its own row
             ++pos;
+        } else {
+            // a copy: -(representative + 1), the representative being (frame * 3072 + patch) of any frame of the set; the one
+            // reader (k_enc_head) follows it to that patch's own row -- a second lookup for the copies instead of a kernel
+            // (k_dd_link, 5 us on the front stream's serial chain) that resolved it for them
+            T->slot_of[p[j]] = -(S->rep[p[j]] + 1);
         }
     }
     if (tid == 0) T->count = total;
-}
-
-// ... and every other patch takes the row of its representative (any frame of the set); a launch of its own: the
-// representative's row is written by another workgroup of k_dd_scan
-__global__ void __launch_bounds__(256) k_dd_link(const caelo_frame_set fs) {
-    const DedupScratch *S = fs.f[blockIdx.z].dd;
-    caelo_dedup_tables *T = caelo_frame_tables((const uint64_t *)fs.f[blockIdx.z].bits);
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= CAELO_FRAME_PATCHES) return;
-    const int r = S->rep[p];
-    if (r == (int)blockIdx.z * CAELO_FRAME_PATCHES + p) return;
-    const int fr = r / CAELO_FRAME_PATCHES, rl = r - fr * CAELO_FRAME_PATCHES;
-    T->slot_of[p] = caelo_frame_tables((const uint64_t *)fs.f[fr].bits)->slot_of[rl];
 }
 
 unsigned long long dedup_hash_mask() {
@@ -129,9 +121,5 @@ int dedup_set(const caelo_frame_set &fs, bool enabled, hipStream_t s) {
     }
     k_dd_scan<<<dim3(1, 1, fs.n), 1024, 0, s>>>(fs, enabled ? 0 : 1);
     CAELO_LAUNCH_CHECK();
-    if (enabled) {
-        k_dd_link<<<dim3(CAELO_FRAME_PATCHES / 256, 1, fs.n), 256, 0, s>>>(fs);
-        CAELO_LAUNCH_CHECK();
-    }
     return CAELO_OK;
 }

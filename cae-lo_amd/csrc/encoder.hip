@@ -1918,7 +1918,12 @@ __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part
         ROW = (P);                                                                \
         if (in.dedup) {                                                           \
             const unsigned f_ = (P) / per_in;                                     \
-            ROW = (unsigned)enc_tables(in, (int)f_)->slot_of[(P) - f_ * per_in];  /* (a row of the whole launch set) */ \
+            int r_ = enc_tables(in, (int)f_)->slot_of[(P) - f_ * per_in];         /* a row of the whole launch set ... */ \
+            if (r_ < 0) {                                                         /* ... or -(representative + 1): its row */ \
+                const unsigned g_ = (unsigned)(-r_ - 1), fr_ = g_ / per_in;      \
+                r_ = enc_tables(in, (int)fr_)->slot_of[g_ - fr_ * per_in];       \
+            }                                                                     \
+            ROW = (unsigned)r_;                                                   \
         }                                                                         \
     }
     const bool ok = lane < DENSE_N / 4;
