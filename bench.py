@@ -393,6 +393,9 @@ def main():
     host_scans = None
     if args.include_h2d:
         host_scans = [p.cpu().pin_memory() for p in pool]
+        # the upload path's device buffers and copy stream exist before the clock starts (they are created on first use)
+        run_with_uploads(eng, pipe, main_run, host_scans, 2 * B, FrameBatch(eng, 2 * B), rand, pairs=not args.extract_only)
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -888,10 +888,12 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_OCC) k_patches(const caelo_f
     }
     const caelo_brick_table tab = scale == 0 ? t0 : (scale == 1 ? t1 : t2);
     const double vs = scale == 0 ? VOX_SIZE : (scale == 1 ? VOX_SIZE * 8 : VOX_SIZE * 32);  // Voxel.py:31
-    // Voxel.py:185,:193  KeyVoxels = int32((Pts + Visible*) / VoxelSizes[s])  (f64)
-    const int kx = (int)(((double)pts[(size_t)pts_ld * kp] + VIS_L) / vs);
-    const int ky = (int)(((double)pts[(size_t)pts_ld * kp + 1] + VIS_W) / vs);
-    const int kz = (int)(((double)pts[(size_t)pts_ld * kp + 2] + VIS_H) / vs);
+    const double ivs = scale == 0 ? 1.0 / VOX_SIZE : (scale == 1 ? 1.0 / (VOX_SIZE * 8) : 1.0 / (VOX_SIZE * 32));
+    // Voxel.py:185,:193  KeyVoxels = int32((Pts + Visible*) / VoxelSizes[s])  (f64; the division only for a point within a
+    // micro-voxel of a voxel face, vox_trunc_div)
+    const int kx = vox_trunc_div((double)pts[(size_t)pts_ld * kp] + VIS_L, vs, ivs);
+    const int ky = vox_trunc_div((double)pts[(size_t)pts_ld * kp + 1] + VIS_W, vs, ivs);
+    const int kz = vox_trunc_div((double)pts[(size_t)pts_ld * kp + 2] + VIS_H, vs, ivs);
     const int bx0 = (kx - BALL_R) >> 3, by0 = (ky - BALL_R) >> 3, bz0 = (kz - BALL_R) >> 3;
     const int nbx = ((kx + BALL_R) >> 3) - bx0 + 1, nby = ((ky + BALL_R) >> 3) - by0 + 1, nbz = ((kz + BALL_R) >> 3) - bz0 + 1;
     // window bricks: first brick of the window per axis, relative to the ball cube (0 or 1)
@@ -1113,9 +1115,8 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_OCC) k_patches(const caelo_f
             }
         }
     }
-    // OR the flags across the wave
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) fl |= __shfl_xor(fl, o);
+    // OR the flags across the wave (two ballots)
+    fl = (__ballot(fl & 1u) ? 1u : 0u) | (__ballot(fl & 2u) ? 2u : 0u);
     out[lane] = word;
     if (dd)  // equal patches of the launch set are encoded once (dedup.hip)
         caelo_dedup_insert(word, lane, (int)pw, (int)(blockIdx.z * CAELO_FRAME_PATCHES + pw), dd, fs.f[0].dd, dedup_slot_mask(fs.n), dd_mask);
