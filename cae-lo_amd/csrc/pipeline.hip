@@ -49,7 +49,11 @@ struct caelo_pipeline {
     void *ws_match[CAELO_FB_MAX] = {nullptr}, *ws_ransac[CAELO_FB_MAX] = {nullptr};
     hipEvent_t front_done[MAX_BUFFERS] = {nullptr}, enc_done[MAX_BUFFERS] = {nullptr};
     hipEvent_t begun = nullptr, joined[3] = {nullptr};
-    hipEvent_t ext_in = nullptr, ext_out = nullptr, ext_enc = nullptr;  // caelo_pipeline_wait_stream / _release_scans / _wait_encoded
+    // caelo_pipeline_wait_stream / _release_scans / _wait_encoded: a ring of events each, so that an event is not recorded again
+    // while a wait on its previous record may still sit in a queue
+    static constexpr int EXT_RING = 16;
+    hipEvent_t ext_in[EXT_RING] = {nullptr}, ext_out[EXT_RING] = {nullptr}, ext_enc[EXT_RING] = {nullptr};
+    unsigned n_ext_in = 0, n_ext_out = 0, n_ext_enc = 0;
     // host state
     std::vector<caelo_frame_job> pending;
     uint64_t n_batches = 0, submitted = 0;
@@ -167,8 +171,11 @@ CAELO_API void caelo_pipeline_destroy(caelo_pipeline *p) {
     if (p->begun) (void)hipEventDestroy(p->begun);
     for (hipEvent_t e : p->joined)
         if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {p->vox_fork, p->vox_join, p->ext_in, p->ext_out, p->ext_enc})
+    for (hipEvent_t e : {p->vox_fork, p->vox_join})
         if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < caelo_pipeline::EXT_RING; ++i)
+        for (hipEvent_t e : {p->ext_in[i], p->ext_out[i], p->ext_enc[i]})
+            if (e) (void)hipEventDestroy(e);
     if (p->sV) (void)hipStreamDestroy(p->sV);
     if (p->sP && p->sP != p->sF) (void)hipStreamDestroy(p->sP);
     if (p->sE && p->sE != p->sF) (void)hipStreamDestroy(p->sE);
@@ -229,9 +236,11 @@ CAELO_API int caelo_pipeline_create(caelo_ctx *c, int batch, int n_buffers, int6
         }
     }
     hip_ok(hipEventCreateWithFlags(&p->begun, hipEventDisableTiming), "hipEventCreate");
-    hip_ok(hipEventCreateWithFlags(&p->ext_in, hipEventDisableTiming), "hipEventCreate");
-    hip_ok(hipEventCreateWithFlags(&p->ext_out, hipEventDisableTiming), "hipEventCreate");
-    hip_ok(hipEventCreateWithFlags(&p->ext_enc, hipEventDisableTiming), "hipEventCreate");
+    for (int i = 0; i < caelo_pipeline::EXT_RING; ++i) {
+        hip_ok(hipEventCreateWithFlags(&p->ext_in[i], hipEventDisableTiming), "hipEventCreate");
+        hip_ok(hipEventCreateWithFlags(&p->ext_out[i], hipEventDisableTiming), "hipEventCreate");
+        hip_ok(hipEventCreateWithFlags(&p->ext_enc[i], hipEventDisableTiming), "hipEventCreate");
+    }
     for (hipEvent_t &e : p->joined) hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
     for (int i = 0; i < n_buffers; ++i) {
         hip_ok(hipEventCreateWithFlags(&p->front_done[i], hipEventDisableTiming), "hipEventCreate");
@@ -347,8 +356,9 @@ CAELO_API int caelo_pipeline_submit_many(caelo_pipeline *p, const caelo_frame_jo
 // PoseEstimation.py:214-245): the front stage of every batch submitted from now on starts after what `stream` holds now ...
 CAELO_API int caelo_pipeline_wait_stream(caelo_pipeline *p, void *stream) {
     CAELO_REQUIRE(p, "null argument");
-    CAELO_HIP(hipEventRecord(p->ext_in, caelo_stream(stream)));
-    CAELO_HIP(hipStreamWaitEvent(p->sF, p->ext_in, 0));   // the voxel stream forks from sF inside every batch
+    hipEvent_t e = p->ext_in[p->n_ext_in++ % caelo_pipeline::EXT_RING];
+    CAELO_HIP(hipEventRecord(e, caelo_stream(stream)));
+    CAELO_HIP(hipStreamWaitEvent(p->sF, e, 0));   // the voxel stream forks from sF inside every batch
     return CAELO_OK;
 }
 
@@ -356,8 +366,9 @@ CAELO_API int caelo_pipeline_wait_stream(caelo_pipeline *p, void *stream) {
 // scan: projection, ring fill, voxel map) are done.
 CAELO_API int caelo_pipeline_release_scans(caelo_pipeline *p, void *stream) {
     CAELO_REQUIRE(p, "null argument");
-    CAELO_HIP(hipEventRecord(p->ext_out, p->sF));
-    CAELO_HIP(hipStreamWaitEvent(caelo_stream(stream), p->ext_out, 0));
+    hipEvent_t e = p->ext_out[p->n_ext_out++ % caelo_pipeline::EXT_RING];
+    CAELO_HIP(hipEventRecord(e, p->sF));
+    CAELO_HIP(hipStreamWaitEvent(caelo_stream(stream), e, 0));
     return CAELO_OK;
 }
 
@@ -365,8 +376,9 @@ CAELO_API int caelo_pipeline_release_scans(caelo_pipeline *p, void *stream) {
 // stage before it the key points and the validity column; the pair stage only reads them).
 CAELO_API int caelo_pipeline_wait_encoded(caelo_pipeline *p, void *stream) {
     CAELO_REQUIRE(p, "null argument");
-    CAELO_HIP(hipEventRecord(p->ext_enc, p->sE));
-    CAELO_HIP(hipStreamWaitEvent(caelo_stream(stream), p->ext_enc, 0));
+    hipEvent_t e = p->ext_enc[p->n_ext_enc++ % caelo_pipeline::EXT_RING];
+    CAELO_HIP(hipEventRecord(e, p->sE));
+    CAELO_HIP(hipStreamWaitEvent(caelo_stream(stream), e, 0));
     return CAELO_OK;
 }
 

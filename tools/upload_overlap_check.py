@@ -26,6 +26,8 @@ def t(f, reps=3):
     return reps * n / (time.perf_counter() - t0)
 print("resident      %.0f frames/s" % t(lambda: pipe.run([dev[j] for j in order], [rnd[j] for j in order], prev=prev, out=out)))
 print("run_uploading %.0f frames/s" % t(lambda: pipe.run_uploading([host[j] for j in order], [rnd[j] for j in order], prev=prev, out=out)))
+# the same protocol with device-to-device copies instead of PCIe ones: what the batch-by-batch submission itself costs
+print("run_uploading, sources in HBM %.0f frames/s" % t(lambda: pipe.run_uploading([dev[j] for j in order], [rnd[j] for j in order], prev=prev, out=out)))
 # uploads alone
 copy = torch.cuda.Stream()
 bufs = [torch.empty((130000, 4), device=eng.device) for _ in range(8)]
@@ -35,3 +37,8 @@ def up():
             bufs[i % 8][:host[j].shape[0]].copy_(host[j], non_blocking=True)
     torch.cuda.current_stream().wait_stream(copy)
 print("uploads alone %.0f frames/s (%.1f GB/s)" % (t(up), t(up) * host[0].numel() * 4 / 1e9))
+# host side: how long the calling thread needs to ISSUE a run (returns before the GPU is done)
+for name, f in (("run", lambda: pipe.run([dev[j] for j in order], [rnd[j] for j in order], prev=prev, out=out)),
+                ("run_uploading", lambda: pipe.run_uploading([host[j] for j in order], [rnd[j] for j in order], prev=prev, out=out))):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); f(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print("%-14s host issue %.0f us per batch of 8, GPU done after %.0f us per batch" % (name, (t1 - t0) / (n / 8) * 1e6, (t2 - t0) / (n / 8) * 1e6))
