@@ -24,6 +24,15 @@
 #include <vector>
 
 namespace {
+// Events that only order work of THIS device (stage hand-offs, the voxel stream's fork / join, the scans' arrival and release):
+// no system-scope fence when they are recorded -- by default hipEventRecord writes the caches back and invalidates them so that
+// the host and other devices see the data, which nobody behind these events needs (CAELO_PIPE_SYSTEM_FENCES=1 restores it).
+// The events a caller's stream waits on (caelo_pipeline_flush, caelo_pipeline_wait_encoded: results read by the host or by
+// another GPU's collective) keep the fence.
+inline unsigned local_event_flags() {
+    static const bool sys = getenv("CAELO_PIPE_SYSTEM_FENCES") && atoi(getenv("CAELO_PIPE_SYSTEM_FENCES")) != 0;
+    return sys ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+}
 constexpr int MAX_BUFFERS = 4;
 constexpr int64_t FRAME_PATCHES = (int64_t)CAELO_MAX_KEYPTS * 3;
 
@@ -231,20 +240,20 @@ CAELO_API int caelo_pipeline_create(caelo_ctx *c, int batch, int n_buffers, int6
         const bool want = v ? atoi(v) != 0 : (q && atoi(q) >= 8);
         if (n_streams >= 3 && want) {
             hip_ok(hipStreamCreateWithFlags(&p->sV, hipStreamNonBlocking), "hipStreamCreate");
-            hip_ok(hipEventCreateWithFlags(&p->vox_fork, hipEventDisableTiming), "hipEventCreate");
-            hip_ok(hipEventCreateWithFlags(&p->vox_join, hipEventDisableTiming), "hipEventCreate");
+            hip_ok(hipEventCreateWithFlags(&p->vox_fork, local_event_flags()), "hipEventCreate");
+            hip_ok(hipEventCreateWithFlags(&p->vox_join, local_event_flags()), "hipEventCreate");
         }
     }
-    hip_ok(hipEventCreateWithFlags(&p->begun, hipEventDisableTiming), "hipEventCreate");
+    hip_ok(hipEventCreateWithFlags(&p->begun, local_event_flags()), "hipEventCreate");
     for (int i = 0; i < caelo_pipeline::EXT_RING; ++i) {
-        hip_ok(hipEventCreateWithFlags(&p->ext_in[i], hipEventDisableTiming), "hipEventCreate");
-        hip_ok(hipEventCreateWithFlags(&p->ext_out[i], hipEventDisableTiming), "hipEventCreate");
+        hip_ok(hipEventCreateWithFlags(&p->ext_in[i], local_event_flags()), "hipEventCreate");
+        hip_ok(hipEventCreateWithFlags(&p->ext_out[i], local_event_flags()), "hipEventCreate");
         hip_ok(hipEventCreateWithFlags(&p->ext_enc[i], hipEventDisableTiming), "hipEventCreate");
     }
     for (hipEvent_t &e : p->joined) hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
     for (int i = 0; i < n_buffers; ++i) {
-        hip_ok(hipEventCreateWithFlags(&p->front_done[i], hipEventDisableTiming), "hipEventCreate");
-        hip_ok(hipEventCreateWithFlags(&p->enc_done[i], hipEventDisableTiming), "hipEventCreate");
+        hip_ok(hipEventCreateWithFlags(&p->front_done[i], local_event_flags()), "hipEventCreate");
+        hip_ok(hipEventCreateWithFlags(&p->enc_done[i], local_event_flags()), "hipEventCreate");
         hip_ok(hipMalloc((void **)&p->bits[i], (size_t)batch * CAELO_FRAME_BUF_BYTES), "hipMalloc");
     }
     const size_t xws = (size_t)caelo_extract_ws_bytes(), mws = (size_t)caelo_match_ws_bytes(CAELO_MAX_KEYPTS), rws = (size_t)caelo_ransac_ws_bytes();
