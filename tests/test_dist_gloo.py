@@ -44,6 +44,18 @@ def _worker(rank, world, n_frames, port, out_dir):
     assert last.shape == (world, K, cd.ROW)
     for r in range(world):
         assert torch.equal(last[r], frame_rows(cd.shard_frames(n_frames, r, world)[1] - 1))
+    # the gather in pieces (what bench.py overlaps with the extraction): equal blocks, chunks of 3 frames, the same rows
+    if n_frames % world == 0:
+        n_local = n_frames // world
+        g = cd.ChunkedFrameGather(local, n_local, 3)
+        assert g.side is None and len(g.bounds) == -(-n_local // 3)
+        for clo, chi in g.bounds:
+            g.chunk(clo, chi)
+        frame_of = g.finish()
+        for r in range(world):
+            for i in range(n_local):
+                assert torch.equal(frame_of(r, i), frame_rows(r * n_local + i))
+        assert g.nbytes() == world * n_local * K * cd.ROW * 4
     allrt = cd.gather_poses(rts, n_frames)
     assert allrt.shape == (n_frames - 1, 12)
     assert allrt[:, 1].tolist() == [float(f) for f in range(n_frames - 1)]
