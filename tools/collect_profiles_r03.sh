@@ -39,7 +39,7 @@ timeout 900 bash $R/tools/collect_roofline_table.sh > /dev/null 2>&1; cp $R/gpur
 ( py $R/tools/enc_layer_errors.py 2>&1 | tail -4; echo "CAELO_ENC_S1=f32:"; CAELO_ENC_S1=f32 py $R/tools/enc_layer_errors.py 2>&1 | tail -4 ) > $O/layer_errors.txt
 py $R/tools/stage1_density_sweep.py > $O/stage1_density_sweep.txt 2>&1
 py $R/tools/match_stats.py 2>&1 | tail -4 > $O/match_stats.txt
-py $R/tools/upload_overlap_check.py 2>&1 | tail -3 > $O/upload_overlap.txt
+py $R/tools/upload_overlap_check.py 2>&1 | tail -6 > $O/upload_overlap.txt
 py $R/tools/micro/h2d_bandwidth.py > $O/h2d_bandwidth.txt 2>&1
 # the micro-benchmarks (binaries are not tracked: built here when missing)
 for m in f16_mfma_subnormal:f16sub mfma_f32_order:mfma_order wave_placement:wave_placement; do
