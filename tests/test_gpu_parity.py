@@ -672,6 +672,12 @@ def test_two_ranks_equal_one_rank(tmp_path):
                        capture_output=True, timeout=300)
     d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith('{"metric"')][-1])
     assert d["config"]["poses_solved"] == "24/24" and d["config"]["collective"]["overlapped"] is False
+    # strong scaling: the same --steps split over the ranks (the 1 / 2 / 4 / 8 curve over one workload)
+    r = subprocess.run(launch + ["--master-port", "29544", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4",
+                                 "--warmup", "1", "--no-cpu-baseline", "--scaling", "strong"], check=True, env=env,
+                       capture_output=True, timeout=300)
+    d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith('{"metric"')][-1])
+    assert d["scaling"] == "strong" and d["steps"] == 2 and d["config"]["poses_solved"] == "16/16" and d["n_gpus"] == 2
 
 
 def test_icp_vs_reference_golden(api, orc, models, scans):
