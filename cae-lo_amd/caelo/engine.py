@@ -223,52 +223,53 @@ class Pipeline:
             on_batch(*tail)
         return out
 
-    def run_uploading(self, host_scans, rands=None, prev=None, dist_channels=5, out=None, pairs=True, dedup=True, slots=4):
-        """``run`` for scans that live in (pinned) HOST memory: a copy stream uploads batches up to ``slots - 2`` ahead into ``slots``
-        sets of device buffers while the pipeline works on batch b -- the overlap of the reference's producer process, which
-        prepares frame i + 1 while frame i is matched (PoseEstimation.py:214-245).  Events both ways: the front stage of batch b
-        waits for batch b's copies (and only those: caelo_pipeline_wait_stream on a helper stream that waits for that batch's
-        event), the copies into a slot wait for the front stage that last read it (caelo_pipeline_release_scans); the calling
-        thread never waits.  slots: measured 3 / 4 / 6 / 8 = 9.7 / 13.1 / 12.6 / 9.5 k frames/s (resident scans: 17.3 k)."""
+    def run_uploading(self, host_scans, rands=None, prev=None, dist_channels=5, out=None, pairs=True, dedup=True, slots=3, group=4):
+        """``run`` for scans that live in (pinned) HOST memory: a copy stream uploads GROUPS of ``group`` batches, one group ahead,
+        into ``slots`` sets of device buffers while the pipeline works on the group before -- the overlap of the reference's
+        producer process, which prepares frame i + 1 while frame i is matched (PoseEstimation.py:214-245).  Events both ways, once
+        per group: the front stage of a group's first batch waits for the group's copies (caelo_pipeline_wait_stream on a helper
+        stream that waits for that group's event only), the copies into a slot wait for the front stages that last read it
+        (caelo_pipeline_release_scans); the calling thread never waits.  Why groups: every cross-stream event costs this pipeline
+        tens of microseconds of its front stream's chain -- per batch they cost 40 % of the resident rate."""
         eng, lib, k, B = self.eng, self.eng.lib, len(host_scans), self.batch
         out = out or FrameBatch(eng, k)
-        assert out.k >= k and (not pairs or len(rands) >= k) and slots >= 3
+        assert out.k >= k and (not pairs or len(rands) >= k) and slots >= 3 and group >= 1
         for pc in host_scans:
             assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] == 4 and pc.is_contiguous()   # (host tensors, pinned for overlap; device tensors work too)
         big = max(int(pc.shape[0]) for pc in host_scans)
-        key = ("upload", B, slots)
+        G = group * B                                   # frames per group
+        key = ("upload", B, slots, group)
         st = self._upload.get(key) if hasattr(self, "_upload") else None
         if st is None or st[1] < big:
-            bufs = [[torch.empty((big, 4), dtype=torch.float32, device=eng.device) for _ in range(B)] for _ in range(slots)]
+            bufs = [[torch.empty((big, 4), dtype=torch.float32, device=eng.device) for _ in range(G)] for _ in range(slots)]
             st = (bufs, big, torch.cuda.Stream(device=eng.device), torch.cuda.Stream(device=eng.device))
             self._upload = {key: st}
         bufs, _, copy, helper = st
         stream = eng.stream
-        nb, ahead = (k + B - 1) // B, slots - 2
-        jobs = self._jobs([bufs[(i // B) % slots][i % B].data_ptr() for i in range(k)], [int(pc.shape[0]) for pc in host_scans], rands, prev, out,
+        ng = (k + G - 1) // G
+        jobs = self._jobs([bufs[(i // G) % slots][i % G].data_ptr() for i in range(k)], [int(pc.shape[0]) for pc in host_scans], rands, prev, out,
                           pairs, dist_channels, False, dedup)
-        arrived = [torch.cuda.Event() for _ in range(nb)]
+        arrived = [torch.cuda.Event() for _ in range(ng)]
 
-        def upload(b):   # into the slot batch b - slots used: its front stage is two batches or more behind the caller's release
+        def upload(g):   # into the slot group g - slots used: its front stages are behind the release the caller issued
             with torch.cuda.stream(copy):
-                for i in range(b * B, min(k, (b + 1) * B)):
-                    bufs[b % slots][i % B][:host_scans[i].shape[0]].copy_(host_scans[i], non_blocking=True)
-                arrived[b].record(copy)
+                for i in range(g * G, min(k, (g + 1) * G)):
+                    bufs[g % slots][i % G][:host_scans[i].shape[0]].copy_(host_scans[i], non_blocking=True)
+                arrived[g].record(copy)
 
         _ffi.check(lib.caelo_pipeline_expect(self.h, 0))   # full batches, the remainder last: the slots are laid out that way
         copy.wait_stream(torch.cuda.current_stream(eng.device))
         _ffi.check(lib.caelo_pipeline_begin(self.h, stream))
         try:
-            for b in range(min(ahead, nb)):
-                upload(b)
-            for b in range(nb):
-                helper.wait_event(arrived[b])
-                _ffi.check(lib.caelo_pipeline_wait_stream(self.h, helper.cuda_stream))    # batch b's scans have arrived
-                _ffi.check(lib.caelo_pipeline_release_scans(self.h, copy.cuda_stream))    # batches <= b - 1 no longer read theirs
-                lo, hi = b * B, min(k, (b + 1) * B)
+            upload(0)
+            for g in range(ng):
+                helper.wait_event(arrived[g])
+                _ffi.check(lib.caelo_pipeline_wait_stream(self.h, helper.cuda_stream))    # group g's scans have arrived
+                _ffi.check(lib.caelo_pipeline_release_scans(self.h, copy.cuda_stream))    # groups <= g - 1 no longer read theirs
+                if g + 1 < ng:
+                    upload(g + 1)   # (slot (g + 1) % slots was group g + 1 - slots <= g - 2's)
+                lo, hi = g * G, min(k, (g + 1) * G)
                 _ffi.check(lib.caelo_pipeline_submit_many(self.h, jobs[lo:hi].ctypes.data, hi - lo))
-                if b + ahead < nb:
-                    upload(b + ahead)
         finally:
             rc = lib.caelo_pipeline_flush(self.h, stream)
         _ffi.check(rc)
