@@ -570,8 +570,8 @@ __device__ inline void sample_hypothesis(const float *P0, int l0, const int64_t 
 //                    per lane group), residuals of the four poses in one pass, ballot + popcount -> counts[trial].
 //   k_ransac_finish  one workgroup per pair: replays the sequential accept / early-exit rules over the counts
 //                    (Match.py:181-206) as a prefix maximum; if the level failed (no hypothesis reached leastInliers,
-//                    :207-214) it evaluates the next level's 500 hypotheses itself -- rare, so its four wavefronts
-//                    are enough -- up to 1.6 m; then the winner's pose, the inlier mask (:193-194), the inlier count
+//                    :207-214) it evaluates the next level's 500 hypotheses itself, four per wavefront on eight
+//                    wavefronts (150 us per level; one per wavefront on four took 1.2 ms, which a pipeline felt) -- up to 1.6 m; then the winner's pose, the inlier mask (:193-194), the inlier count
 //                    and the refit over all inliers (:273-282).
 // Everything that crosses workgroups crosses a kernel boundary.  Round 1 finished inside the last workgroup of a
 // per-level launch (tickets, a `finished` flag, a self-cleaning workspace) and evaluated the mask from the pairs that
@@ -620,7 +620,49 @@ __device__ inline int hypothesis_count(const float *P0, int l0, const int64_t *p
 // that costs the same for 1 or 64 lanes; the 16 lanes that share a hypothesis must agree -- the hardware self-check),
 // then the four poses are broadcast through scalar registers and ONE pass over the staged pairs counts the inliers of
 // all four (a pair is read from LDS once).  Round 2 before: one hypothesis per wavefront, 35 us per 8 pairs.
+// `rnd`: the draws of the level (trial t at rnd + 4 t); counts[trial0 .. trial0 + 3] are written.
 #define RH_PER_WAVE 4
+__device__ inline void four_hypotheses(const float *sP0, const float *sP1, int N, const double *rnd, int trial0, float thr, int lane,
+                                       int32_t *faults, int32_t *counts) {
+    // ---- lane l: hypothesis trial0 + (l & 3) (a trial past the last repeats the last one; its count is not stored)
+    const int mine = min(trial0 + (lane & (RH_PER_WAVE - 1)), CAELO_RANSAC_MAX_TRIALS - 1);
+    float R[9], T[3];
+    sample_hypothesis(sP0, 3, nullptr, sP1, 3, N, rnd + (size_t)mine * 4, R, T);
+    if (faults) {  // the 16 lanes of a hypothesis hold the same pose, bit for bit
+        unsigned int hsh = 0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) hsh = hsh * 0x9E3779B1u + __float_as_uint(R[q]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) hsh = hsh * 0x9E3779B1u + __float_as_uint(T[q]);
+        const bool bad = hsh != (unsigned int)__shfl_xor((int)hsh, 4) || hsh != (unsigned int)__shfl_xor((int)hsh, 16) ||
+                         hsh != (unsigned int)__shfl_xor((int)hsh, 32);
+        if (__ballot(bad) != 0ull && lane == 0) atomicAdd(faults, 1);
+    }
+    // ---- the four poses in scalar registers, one pass over the pairs
+    float Rs[RH_PER_WAVE][9], Ts[RH_PER_WAVE][3];
+#pragma unroll
+    for (int h = 0; h < RH_PER_WAVE; ++h) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) Rs[h][q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(R[q]), h));
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Ts[h][q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(T[q]), h));
+    }
+    int cnt[RH_PER_WAVE] = {0, 0, 0, 0};
+    for (int i = lane; i < ((N + 63) & ~63); i += 64) {
+        const bool live = i < N;
+        const int ii = live ? i : 0;
+        const float ax = sP0[3 * ii], ay = sP0[3 * ii + 1], az = sP0[3 * ii + 2];
+        const float bx = sP1[3 * ii], by = sP1[3 * ii + 1], bz = sP1[3 * ii + 2];
+#pragma unroll
+        for (int h = 0; h < RH_PER_WAVE; ++h) {
+            const bool in = live && residual(Rs[h], Ts[h], ax, ay, az, bx, by, bz) < thr;
+            cnt[h] += __popcll(__ballot(in));
+        }
+    }
+    if (lane < RH_PER_WAVE && trial0 + lane < CAELO_RANSAC_MAX_TRIALS)
+        counts[trial0 + lane] = lane == 0 ? cnt[0] : (lane == 1 ? cnt[1] : (lane == 2 ? cnt[2] : cnt[3]));
+}
+
 __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp(const caelo_pair_set ps, int ld0, int ld1, int64_t k1_max) {
     const caelo_pair_dev &P = ps.p[blockIdx.z];
     const float *__restrict__ pc0 = P.pc0, *__restrict__ pc1 = P.pc1;
@@ -651,46 +693,11 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp(const caelo_pair_s
         }
         return;
     }
-    // ---- lane l: hypothesis trial0 + (l & 3) (a trial past the last repeats the last one; its count is not stored)
-    const int mine = min(trial0 + (lane & (RH_PER_WAVE - 1)), CAELO_RANSAC_MAX_TRIALS - 1);
-    float R[9], T[3];
-    sample_hypothesis(sP0, 3, nullptr, sP1, 3, N, P.rand + (size_t)mine * 4, R, T);
-    if (ps.faults) {  // the 16 lanes of a hypothesis hold the same pose, bit for bit
-        unsigned int hsh = 0;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) hsh = hsh * 0x9E3779B1u + __float_as_uint(R[q]);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) hsh = hsh * 0x9E3779B1u + __float_as_uint(T[q]);
-        const bool bad = hsh != (unsigned int)__shfl_xor((int)hsh, 4) || hsh != (unsigned int)__shfl_xor((int)hsh, 16) ||
-                         hsh != (unsigned int)__shfl_xor((int)hsh, 32);
-        if (__ballot(bad) != 0ull && lane == 0) atomicAdd(ps.faults, 1);
-    }
-    // ---- the four poses in scalar registers, one pass over the pairs
-    float Rs[RH_PER_WAVE][9], Ts[RH_PER_WAVE][3];
-#pragma unroll
-    for (int h = 0; h < RH_PER_WAVE; ++h) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) Rs[h][q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(R[q]), h));
-#pragma unroll
-        for (int q = 0; q < 3; ++q) Ts[h][q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(T[q]), h));
-    }
-    int cnt[RH_PER_WAVE] = {0, 0, 0, 0};
-    for (int i = lane; i < ((N + 63) & ~63); i += 64) {
-        const bool live = i < N;
-        const int ii = live ? i : 0;
-        const float ax = sP0[3 * ii], ay = sP0[3 * ii + 1], az = sP0[3 * ii + 2];
-        const float bx = sP1[3 * ii], by = sP1[3 * ii + 1], bz = sP1[3 * ii + 2];
-#pragma unroll
-        for (int h = 0; h < RH_PER_WAVE; ++h) {
-            const bool in = live && residual(Rs[h], Ts[h], ax, ay, az, bx, by, bz) < 0.4f;
-            cnt[h] += __popcll(__ballot(in));
-        }
-    }
-    if (lane < RH_PER_WAVE && trial0 + lane < CAELO_RANSAC_MAX_TRIALS)
-        ws->counts[trial0 + lane] = lane == 0 ? cnt[0] : (lane == 1 ? cnt[1] : (lane == 2 ? cnt[2] : cnt[3]));
+    four_hypotheses(sP0, sP1, N, P.rand, trial0, 0.4f, lane, ps.faults, ws->counts);
 }
 
-__global__ void __launch_bounds__(256) k_ransac_finish(const caelo_pair_set ps, int ld0, int ld1, int64_t k1_max) {
+#define RF_WAVES 8   // the accept rules, the mask and the refit use four of them; all eight evaluate a next level's hypotheses
+__global__ void __launch_bounds__(64 * RF_WAVES) k_ransac_finish(const caelo_pair_set ps, int ld0, int ld1, int64_t k1_max) {
     const caelo_pair_dev &P = ps.p[blockIdx.z];
     const float *__restrict__ pc0 = P.pc0, *__restrict__ pc1 = P.pc1;
     const int64_t *__restrict__ pair_idx = P.pair_idx;
@@ -719,7 +726,7 @@ __global__ void __launch_bounds__(256) k_ransac_finish(const caelo_pair_set ps, 
     }
     const bool in_lds = N <= RE_LDS_PAIRS;
     if (in_lds) {
-        for (int i = tid; i < N; i += 256) {
+        for (int i = tid; i < N; i += 64 * RF_WAVES) {
             const float *a = pc0 + (size_t)ld0 * pair_idx[i];
             const float *b = pc1 + (size_t)ld1 * i;
             sP0[3 * i] = a[0]; sP0[3 * i + 1] = a[1]; sP0[3 * i + 2] = a[2];
@@ -730,14 +737,19 @@ __global__ void __launch_bounds__(256) k_ransac_finish(const caelo_pair_set ps, 
     if (tid < 64) ransac_replay(N, ws->counts, &s_v, c0);
     __syncthreads();  // also the end of the staging above
     int level = 0;
-    while (!s_v.success && level < CAELO_RANSAC_LEVELS - 1) {  // rare: the next level's 500 hypotheses, one wavefront each, four at a time
+    while (!s_v.success && level < CAELO_RANSAC_LEVELS - 1) {  // rare: the next level's 500 hypotheses, four per wavefront like k_ransac_hyp
         __syncthreads();  // everyone has read s_v before it is overwritten
         ++level;
         const float thr_l = 0.4f * (float)(1 << level);
-        for (int trial = wave; trial < CAELO_RANSAC_MAX_TRIALS; trial += 4) {
-            const int cnt = hypothesis_count(pc0, ld0, pair_idx, pc1, ld1, N, rnd + ((size_t)level * CAELO_RANSAC_MAX_TRIALS + trial) * 4,
-                                             thr_l, lane, ps.faults);
-            if (lane == 0) ws->counts[trial] = cnt;
+        const double *rnd_l = rnd + (size_t)level * CAELO_RANSAC_MAX_TRIALS * 4;
+        if (in_lds) {
+            for (int trial0 = wave * RH_PER_WAVE; trial0 < CAELO_RANSAC_MAX_TRIALS; trial0 += RF_WAVES * RH_PER_WAVE)
+                four_hypotheses(sP0, sP1, N, rnd_l, trial0, thr_l, lane, ps.faults, ws->counts);
+        } else {
+            for (int trial = wave; trial < CAELO_RANSAC_MAX_TRIALS; trial += RF_WAVES) {
+                const int cnt = hypothesis_count(pc0, ld0, pair_idx, pc1, ld1, N, rnd_l + (size_t)trial * 4, thr_l, lane, ps.faults);
+                if (lane == 0) ws->counts[trial] = cnt;
+            }
         }
         __threadfence_block();
         __syncthreads();
@@ -765,7 +777,7 @@ __global__ void __launch_bounds__(256) k_ransac_finish(const caelo_pair_set ps, 
 #pragma unroll
     for (int t = 0; t < FIT_TERMS; ++t) acc[t] = 0.0;
     const bool word_ok = (((uintptr_t)mask) & 3u) == 0;
-    for (int i0 = tid * 4; i0 < (int)k1_max; i0 += 4 * 256) {
+    for (int i0 = tid * 4; tid < 256 && i0 < (int)k1_max; i0 += 4 * 256) {   // (the first four wavefronts, as before there were eight)
         unsigned int packed = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -794,7 +806,7 @@ __global__ void __launch_bounds__(256) k_ransac_finish(const caelo_pair_set ps, 
     for (int t = 0; t < FIT_TERMS; ++t)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc[t] += __shfl_xor(acc[t], o);
-    if (lane == 0)
+    if (lane == 0 && wave < 4)
 #pragma unroll
         for (int t = 0; t < FIT_TERMS; ++t) red[wave][t] = acc[t];
     __syncthreads();
@@ -851,7 +863,7 @@ int ransac_set(const caelo_pair_set &ps, int ld0, int ld1, int64_t k1_max, hipSt
     CAELO_REQUIRE(k1_max > 0 && ld0 >= 3 && ld1 >= 3, "bad shape");
     k_ransac_hyp<<<dim3((CAELO_RANSAC_MAX_TRIALS + RE_WAVES * RH_PER_WAVE - 1) / (RE_WAVES * RH_PER_WAVE), 1, ps.n), 64 * RE_WAVES, 0, s>>>(ps, ld0, ld1, k1_max);
     CAELO_LAUNCH_CHECK();
-    k_ransac_finish<<<dim3(1, 1, ps.n), 256, 0, s>>>(ps, ld0, ld1, k1_max);
+    k_ransac_finish<<<dim3(1, 1, ps.n), 64 * RF_WAVES, 0, s>>>(ps, ld0, ld1, k1_max);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }
