@@ -260,7 +260,7 @@ def main():
                                                                "on a copy stream, double buffered (PCIe-inclusive rate; never the headline `value`)")
     ap.add_argument("--gather-overlap", type=int, default=1,
                     help="--gather all: 1 (default) = the rows of every batch are gathered on a side stream as soon as the batch is "
-                         "encoded, under the extraction of the next batches (caelo_pipeline_wait_encoded); 0 = one collective after "
+                         "encoded, under the extraction of the next batches (host-paced: caelo_pipeline_sync_encoded); 0 = one collective after "
                          "the last frame")
     ap.add_argument("--gather", choices=("boundary", "all"), default="all",
                     help="rows moved by the single all-gather: every frame's [1024,64] rows (the north-star's per-frame descriptor "
@@ -328,11 +328,11 @@ def main():
             self.pos += n
             return o
 
-        def run(self, n, out=None, pairs=True, scans=None, on_batch=None):
+        def run(self, n, out=None, pairs=True, scans=None, on_encoded=None):
             o = self.order(n)
             assert n % B or all(len(set(o[i:i + B])) == B for i in range(0, n, B)), "a batch holds a scan twice"
             batch = pipe.run(scans if scans is not None else [self.pool[j] for j in o], [rand[j] for j in o],
-                             prev=self.prev if pairs else None, pairs=pairs, out=out, on_batch=on_batch, **self.kw)
+                             prev=self.prev if pairs else None, pairs=pairs, out=out, on_encoded=on_encoded, **self.kw)
             self.prev = batch.frame(n - 1)
             return batch
 
@@ -350,10 +350,7 @@ def main():
         out = out or FrameBatch(eng, n)
         g = cdist.ChunkedFrameGather(out.rows, n, B)
 
-        def shipped(lo, hi):
-            pipe.wait_encoded(g.side)
-            g.chunk(lo, hi)
-        batch = main_run.run(n, out, on_batch=shipped)
+        batch = main_run.run(n, out, on_encoded=g.chunk)   # (host-paced: the rows of [lo, hi) are written when the collective is enqueued)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()                     # the pipeline's own work ends here on this stream ...
         frame_of = g.finish()           # ... and what is left of the gathers after it is the exposed part

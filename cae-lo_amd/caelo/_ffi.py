@@ -108,6 +108,8 @@ SIGNATURES = [
     ("caelo_pipeline_wait_stream", c_int, [c_vp, c_vp]),
     ("caelo_pipeline_release_scans", c_int, [c_vp, c_vp]),
     ("caelo_pipeline_wait_encoded", c_int, [c_vp, c_vp]),
+    ("caelo_pipeline_sync_encoded", c_int, [c_vp, c_int]),
+    ("caelo_pipeline_set_pace", c_int, [c_vp, c_int]),
     ("caelo_pipeline_stats", c_int, [c_vp, C.POINTER(c_i64)]),
     ("caelo_pipeline_expect", c_int, [c_vp, c_i64]),
     ("caelo_lane_faults", c_int, [c_vp, C.POINTER(c_i64)]),

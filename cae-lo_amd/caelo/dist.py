@@ -84,8 +84,9 @@ def all_gather_frames(local_rows, n_frames, group=None):
 
 class ChunkedFrameGather:
     """``all_gather_frames`` in pieces that overlap the extraction: the rows of frames [lo, hi) of EVERY rank are gathered on a side
-    stream as soon as the caller says they are complete there (``chunk`` is called once the side stream has been made to wait
-    for them, e.g. ``Pipeline.wait_encoded(side)``), while the pipeline works on the next batch.  Every rank must call ``chunk``
+    stream as soon as the caller says they are complete (``chunk`` is called once they are WRITTEN -- ``Pipeline.run(on_encoded=
+    g.chunk)``, paced by the host -- or once the side stream has been made to wait for them, ``Pipeline.wait_encoded(g.side)``, the
+    device-side form that costs the pipeline a quarter of its rate), while the pipeline works on the next batch.  Every rank must call ``chunk``
     with the same (lo, hi) sequence (equal blocks: n_local frames per rank).  Buffers are allocated up front."""
 
     def __init__(self, rows, n_local, chunk_frames, group=None, even_alone=False):

@@ -137,6 +137,7 @@ class Pipeline:
         h = C.c_void_p()
         _ffi.check(eng.lib.caelo_pipeline_create(eng.ctx, int(batch), int(buffers), int(max_points or eng.max_points), C.byref(h)))
         self.h, self.batch, self.buffers = h, int(batch), int(buffers)
+        self.pace = None   # the library's default (1, or CAELO_PIPE_PACE) until set_pace
 
     def __del__(self):
         try:
@@ -187,91 +188,126 @@ class Pipeline:
         """caelo_pipeline_wait_encoded: ``stream`` (a torch stream) waits for the rows of every frame of the batches issued so far."""
         _ffi.check(self.eng.lib.caelo_pipeline_wait_encoded(self.h, C.c_void_p(stream.cuda_stream)))
 
-    def run(self, scans, rands=None, prev=None, dist_channels=5, exact_voxels=False, out=None, pairs=True, dedup=True, on_batch=None):
+    def sync_encoded(self, lag=0):
+        """caelo_pipeline_sync_encoded: the calling thread waits until the rows of every batch issued so far, except the last
+        ``lag``, are written (no device-side wait is left in any queue)."""
+        _ffi.check(self.eng.lib.caelo_pipeline_sync_encoded(self.h, int(lag)))
+
+    def run(self, scans, rands=None, prev=None, dist_channels=5, exact_voxels=False, out=None, pairs=True, dedup=True, on_batch=None,
+            on_encoded=None):
         """scans: K device tensors [n,4] f32; rands: K device tensors of RANSAC draws ([1500,4] f64).
         Frame i is matched against frame i-1 (pose in ``result[i]``); frame 0 against ``prev``
         (FrameFeatures) when given; ``pairs=False`` extracts only (BASELINE configs[1]).  Returns a FrameBatch; the
-        current stream has waited for all lanes.  ``on_batch(lo, hi)`` is called after frames [lo, hi) have been issued (full
-        batches, the remainder last): with ``wait_encoded`` a caller ships finished rows while later batches run."""
+        current stream has waited for all lanes.  ``on_encoded(lo, hi)`` is called, in order, once the rows of frames [lo, hi) are
+        WRITTEN (the calling thread has waited for them: caelo_pipeline_sync_encoded, one batch behind the issue) -- what it
+        enqueues on any stream may read them at once; a caller ships finished rows that way while later batches run.
+        ``on_batch(lo, hi)`` is called right after frames [lo, hi) have been issued (with ``wait_encoded`` the device-side form of
+        the same hand-over, which costs the pipeline a quarter of its rate: DESIGN.md 6)."""
         eng, lib, k = self.eng, self.eng.lib, len(scans)
         out = out or FrameBatch(eng, k)
         assert out.k >= k and (not pairs or len(rands) >= k)
         stream = eng.stream
+        per_batch = on_batch is not None or on_encoded is not None
         # an even batch plan for runs that are not whole batches (caelo.h); with a per-batch callback: full batches, remainder last
-        _ffi.check(lib.caelo_pipeline_expect(self.h, 0 if on_batch else k))
+        _ffi.check(lib.caelo_pipeline_expect(self.h, 0 if per_batch else k))
         _ffi.check(lib.caelo_pipeline_begin(self.h, stream))
         for pc in scans:
             assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] == 4 and pc.is_contiguous()
         jobs = self._jobs([pc.data_ptr() for pc in scans], [pc.shape[0] for pc in scans], rands, prev, out, pairs, dist_channels,
                           exact_voxels, dedup)
-        tail = None   # a partial last batch is only issued by the flush: its callback comes after that
+        tail = None   # a partial last batch is only issued by the flush: its callbacks come after that
+        issued = []   # batches issued, not yet reported to on_encoded
         try:
-            if on_batch is None:
+            if not per_batch:
                 _ffi.check(lib.caelo_pipeline_submit_many(self.h, jobs.ctypes.data, k))
             else:
                 for lo in range(0, k, self.batch):
                     hi = min(k, lo + self.batch)
                     _ffi.check(lib.caelo_pipeline_submit_many(self.h, jobs[lo:hi].ctypes.data, hi - lo))
                     if hi - lo == self.batch:
-                        on_batch(lo, hi)
+                        if on_batch:
+                            on_batch(lo, hi)
+                        issued.append((lo, hi))
+                        if on_encoded and len(issued) > 1:
+                            self.sync_encoded(1)      # (returns at once under the default pacing of the issue)
+                            while len(issued) > 1:
+                                on_encoded(*issued.pop(0))
                     else:
                         tail = (lo, hi)
         finally:
             rc = lib.caelo_pipeline_flush(self.h, stream)
         _ffi.check(rc)
         if tail:
-            on_batch(*tail)
+            if on_batch:
+                on_batch(*tail)
+            issued.append(tail)
+        if on_encoded and issued:
+            self.sync_encoded(0)
+            for lo, hi in issued:
+                on_encoded(lo, hi)
         return out
 
-    def run_uploading(self, host_scans, rands=None, prev=None, dist_channels=5, out=None, pairs=True, dedup=True, slots=3, group=4):
-        """``run`` for scans that live in (pinned) HOST memory: a copy stream uploads GROUPS of ``group`` batches, one group ahead,
-        into ``slots`` sets of device buffers while the pipeline works on the group before -- the overlap of the reference's
-        producer process, which prepares frame i + 1 while frame i is matched (PoseEstimation.py:214-245).  Events both ways, once
-        per group: the front stage of a group's first batch waits for the group's copies (caelo_pipeline_wait_stream on a helper
-        stream that waits for that group's event only), the copies into a slot wait for the front stages that last read it
-        (caelo_pipeline_release_scans); the calling thread never waits.  Why groups: every cross-stream event costs this pipeline
-        tens of microseconds of its front stream's chain -- per batch they cost 40 % of the resident rate."""
+    def set_pace(self, lag):
+        """caelo_pipeline_set_pace: after issuing a batch the calling thread waits for the encoder of the batch ``lag`` before it
+        (-1: never)."""
+        _ffi.check(self.eng.lib.caelo_pipeline_set_pace(self.h, int(lag)))
+        self.pace = int(lag)
+
+    def run_uploading(self, host_scans, rands=None, prev=None, dist_channels=5, out=None, pairs=True, dedup=True, ahead=4):
+        """``run`` for scans that live in (pinned) HOST memory: a copy stream uploads batch b + ``ahead`` while the pipeline works on
+        batch b, into ``ahead + 2`` sets of device buffers -- the overlap of the reference's producer process, which prepares
+        frame i + 1 while frame i is matched (PoseEstimation.py:214-245).  The hand-overs are paced by the calling thread, not by
+        waits in the device queues: per batch it issues the launches, then the copies of the batch ``ahead`` further on, then waits
+        for the encoder of the batch before (caelo_pipeline_sync_encoded: the GPU keeps one batch queued; the buffers the next
+        copies overwrite were read by a front stage at least two batches back) and for the arrival of the next batch's scans (an
+        event on the copy stream).  ``ahead``: 13.5 / 15.3 / 15.9 / 16.1 k frames/s for 1 / 2 / 3 / 4 (18.6 k resident; an arrival is
+        late by up to 0.3 ms now and then, and a batch of scans is 17 MB of device memory).  Device-side waits for the same hand-overs (caelo_pipeline_wait_stream / _release_scans) cost
+        8 - 15 % of the resident rate EACH, however rarely they were issued."""
         eng, lib, k, B = self.eng, self.eng.lib, len(host_scans), self.batch
         out = out or FrameBatch(eng, k)
-        assert out.k >= k and (not pairs or len(rands) >= k) and slots >= 3 and group >= 1
+        assert out.k >= k and (not pairs or len(rands) >= k) and ahead >= 1
         for pc in host_scans:
             assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] == 4 and pc.is_contiguous()   # (host tensors, pinned for overlap; device tensors work too)
         big = max(int(pc.shape[0]) for pc in host_scans)
-        G = group * B                                   # frames per group
-        key = ("upload", B, slots, group)
+        slots = ahead + 2
+        key = ("upload", B, slots)
         st = self._upload.get(key) if hasattr(self, "_upload") else None
         if st is None or st[1] < big:
-            bufs = [[torch.empty((big, 4), dtype=torch.float32, device=eng.device) for _ in range(G)] for _ in range(slots)]
-            st = (bufs, big, torch.cuda.Stream(device=eng.device), torch.cuda.Stream(device=eng.device))
+            bufs = [[torch.empty((big, 4), dtype=torch.float32, device=eng.device) for _ in range(B)] for _ in range(slots)]
+            st = (bufs, big, torch.cuda.Stream(device=eng.device))
             self._upload = {key: st}
-        bufs, _, copy, helper = st
+        bufs, _, copy = st
         stream = eng.stream
-        ng = (k + G - 1) // G
-        jobs = self._jobs([bufs[(i // G) % slots][i % G].data_ptr() for i in range(k)], [int(pc.shape[0]) for pc in host_scans], rands, prev, out,
+        nb = (k + B - 1) // B
+        jobs = self._jobs([bufs[(i // B) % slots][i % B].data_ptr() for i in range(k)], [int(pc.shape[0]) for pc in host_scans], rands, prev, out,
                           pairs, dist_channels, False, dedup)
-        arrived = [torch.cuda.Event() for _ in range(ng)]
+        arrived = [torch.cuda.Event() for _ in range(nb)]
 
-        def upload(g):   # into the slot group g - slots used: its front stages are behind the release the caller issued
+        def upload(b):   # into the slot batch b - slots used
             with torch.cuda.stream(copy):
-                for i in range(g * G, min(k, (g + 1) * G)):
-                    bufs[g % slots][i % G][:host_scans[i].shape[0]].copy_(host_scans[i], non_blocking=True)
-                arrived[g].record(copy)
+                for i in range(b * B, min(k, (b + 1) * B)):
+                    bufs[b % slots][i % B][:host_scans[i].shape[0]].copy_(host_scans[i], non_blocking=True)
+                arrived[b].record(copy)
 
         _ffi.check(lib.caelo_pipeline_expect(self.h, 0))   # full batches, the remainder last: the slots are laid out that way
-        copy.wait_stream(torch.cuda.current_stream(eng.device))
+        copy.wait_stream(torch.cuda.current_stream(eng.device))   # (an earlier run may still read the slots)
+        pace = getattr(self, "pace", None)
+        _ffi.check(lib.caelo_pipeline_set_pace(self.h, -1))       # this loop paces itself: the copies go out BEFORE the thread waits
         _ffi.check(lib.caelo_pipeline_begin(self.h, stream))
         try:
-            upload(0)
-            for g in range(ng):
-                helper.wait_event(arrived[g])
-                _ffi.check(lib.caelo_pipeline_wait_stream(self.h, helper.cuda_stream))    # group g's scans have arrived
-                _ffi.check(lib.caelo_pipeline_release_scans(self.h, copy.cuda_stream))    # groups <= g - 1 no longer read theirs
-                if g + 1 < ng:
-                    upload(g + 1)   # (slot (g + 1) % slots was group g + 1 - slots <= g - 2's)
-                lo, hi = g * G, min(k, (g + 1) * G)
+            for b in range(min(ahead, nb)):
+                upload(b)
+            for b in range(nb):
+                arrived[b].synchronize()                 # batch b's scans are in device memory
+                lo, hi = b * B, min(k, (b + 1) * B)
                 _ffi.check(lib.caelo_pipeline_submit_many(self.h, jobs[lo:hi].ctypes.data, hi - lo))
+                if b + ahead < nb:
+                    upload(b + ahead)                    # slot of batch b - 2: encoded (hence read) before batch b was issued
+                if hi - lo == B:
+                    self.sync_encoded(1)                 # (a partial last batch is only issued by the flush)
         finally:
             rc = lib.caelo_pipeline_flush(self.h, stream)
+            lib.caelo_pipeline_set_pace(self.h, 1 if pace is None else pace)
         _ffi.check(rc)
         return out
 

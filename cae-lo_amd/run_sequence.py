@@ -62,7 +62,7 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
     Three things overlap, as in the reference's producer / consumer split (PoseEstimation.py:214-245, where a generator process
     prepares frame i + 1 while the main loop matches frame i):
       * a loader thread reads (or synthesises) the scans and RANSAC draws of chunk c + 1 into pinned host memory;
-      * inside a chunk, a copy stream uploads batch b + 1 while the pipeline works on batch b (Pipeline.run_uploading);
+      * inside a chunk, a copy stream uploads batch b + 4 while the pipeline works on batch b (Pipeline.run_uploading, paced by this thread);
       * the poses and status words of chunk c come back through pinned buffers on a side stream and are parsed after chunk
         c + 1 has been issued.
     """

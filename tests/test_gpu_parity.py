@@ -354,6 +354,27 @@ def test_rccl_all_gather_of_frame_rows(engine):
         ref = pipe.run(scans, draws)
         torch.cuda.synchronize()
         assert torch.equal(ref.rows[:n], batch.rows[:n])   # the per-batch submission changes nothing
+        # the same hand-over paced by the host (caelo_pipeline_sync_encoded: what bench.py and run_sequence.py use): the callback
+        # comes one batch behind the issue, in order, and the rows it is told about are complete -- checked by COPYING them on a side
+        # stream that waits for nothing
+        out2 = FrameBatch(engine, n)
+        out2.rows.fill_(float("nan"))
+        side, seen, copies = torch.cuda.Stream(device=engine.device), [], []
+
+        def encoded(lo, hi):
+            seen.append((lo, hi))
+            with torch.cuda.stream(side):
+                copies.append(out2.rows[lo:hi].clone())
+        batch2 = pipe.run(scans, draws, out=out2, on_encoded=encoded)
+        torch.cuda.synchronize()
+        assert seen == [(0, 4), (4, 8), (8, 10)]
+        got = torch.cat(copies)
+        assert torch.equal(got, ref.rows[:n]) and torch.equal(batch2.rows[:n], ref.rows[:n])
+        g2 = cd.ChunkedFrameGather(out2.rows, n, 4, even_alone=True)
+        batch3 = pipe.run(scans, draws, out=out2, on_encoded=g2.chunk)
+        f2 = g2.finish()
+        torch.cuda.synchronize()
+        assert all(torch.equal(f2(0, i), ref.rows[i]) for i in range(n))
     finally:
         dist.destroy_process_group()
 
@@ -491,9 +512,10 @@ def test_pipeline_equals_single_stream_calls(engine, scans, batch, buffers):
 
 
 def test_pipeline_with_overlapped_uploads_equals_resident_scans(engine, scans):
-    """Pipeline.run_uploading (scans in pinned host memory, a copy stream uploading batch b + 1 while batch b runs, three device
-    buffer sets recycled through caelo_pipeline_wait_stream / caelo_pipeline_release_scans) gives what Pipeline.run gives on
-    resident scans, bit for bit -- including scans of different lengths sharing a slot and a partial last batch."""
+    """Pipeline.run_uploading (scans in pinned host memory, a copy stream uploading batch b + 4 while batch b runs, six device
+    buffer sets recycled under the calling thread's pacing: caelo_pipeline_sync_encoded + an arrival event per batch) gives what
+    Pipeline.run gives on resident scans, bit for bit -- including scans of different lengths sharing a slot and a partial last
+    batch."""
     import torch
     from caelo.engine import ransac_draws
     n = 21
@@ -665,7 +687,7 @@ def test_two_ranks_equal_one_rank(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 8 and d["config"]["poses_solved"] == "64/64" and d["value"] > 0   # a step = a batch of 8 frames
     c = d["config"]["collective"]
     assert c["world_size"] == 2 and c["backend"] == "gloo" and c["bytes_received_per_rank"] == 2 * 64 * 1024 * 64 * 4   # --gather all
-    # the default ships every batch's rows as soon as it is encoded (caelo_pipeline_wait_encoded): eight collectives, the same rows
+    # the default ships every batch's rows as soon as it is encoded (host-paced, caelo_pipeline_sync_encoded): eight collectives, the same rows
     assert c["overlapped"] and c["collectives"] == 8 and c["chunks_equal_one_gather"]
     r = subprocess.run(launch + ["--master-port", "29543", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3",
                                  "--warmup", "1", "--no-cpu-baseline", "--gather-overlap", "0"], check=True, env=env,

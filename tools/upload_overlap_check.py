@@ -37,8 +37,29 @@ def up():
             bufs[i % 8][:host[j].shape[0]].copy_(host[j], non_blocking=True)
     torch.cuda.current_stream().wait_stream(copy)
 print("uploads alone %.0f frames/s (%.1f GB/s)" % (t(up), t(up) * host[0].numel() * 4 / 1e9))
+# the two together with NO dependency between them (copies into buffers nobody reads): what the hardware overlaps
+def both():
+    with torch.cuda.stream(copy):
+        for i, j in enumerate(order):
+            bufs[i % 8][:host[j].shape[0]].copy_(host[j], non_blocking=True)
+    pipe.run([dev[j] for j in order], [rnd[j] for j in order], prev=prev, out=out)
+    torch.cuda.current_stream().wait_stream(copy)
+print("resident run + unrelated uploads beside it %.0f frames/s" % t(both))
 # host side: how long the calling thread needs to ISSUE a run (returns before the GPU is done)
 for name, f in (("run", lambda: pipe.run([dev[j] for j in order], [rnd[j] for j in order], prev=prev, out=out)),
                 ("run_uploading", lambda: pipe.run_uploading([host[j] for j in order], [rnd[j] for j in order], prev=prev, out=out))):
     torch.cuda.synchronize(); t0 = time.perf_counter(); f(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
     print("%-14s host issue %.0f us per batch of 8, GPU done after %.0f us per batch" % (name, (t1 - t0) / (n / 8) * 1e6, (t2 - t0) / (n / 8) * 1e6))
+# how long the calling thread waits for a batch's scans to arrive (Event.synchronize inside run_uploading)
+_orig_sync = torch.cuda.Event.synchronize
+waits = []
+def _timed_sync(self):
+    t0 = time.perf_counter(); _orig_sync(self); waits.append(time.perf_counter() - t0)
+torch.cuda.Event.synchronize = _timed_sync
+try:
+    torch.cuda.synchronize()
+    pipe.run_uploading([host[j] for j in order], [rnd[j] for j in order], prev=prev, out=out)
+    torch.cuda.synchronize()
+finally:
+    torch.cuda.Event.synchronize = _orig_sync
+print("run_uploading: the calling thread waited for arrivals %.0f us per batch (max %.0f)" % (1e6 * sum(waits) / max(len(waits), 1), 1e6 * max(waits)))
