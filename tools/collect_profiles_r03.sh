@@ -39,7 +39,9 @@ timeout 900 bash $R/tools/collect_roofline_table.sh > /dev/null 2>&1; cp $R/gpur
 ( py $R/tools/enc_layer_errors.py 2>&1 | tail -4; echo "CAELO_ENC_S1=f32:"; CAELO_ENC_S1=f32 py $R/tools/enc_layer_errors.py 2>&1 | tail -4 ) > $O/layer_errors.txt
 py $R/tools/stage1_density_sweep.py > $O/stage1_density_sweep.txt 2>&1
 py $R/tools/match_stats.py 2>&1 | tail -4 > $O/match_stats.txt
-py $R/tools/upload_overlap_check.py 2>&1 | tail -6 > $O/upload_overlap.txt
+py $R/tools/upload_overlap_check.py 2>&1 | tail -8 > $O/upload_overlap.txt
+( for m in none wait plain host1 host2; do PROBE_MODE=$m py $R/tools/cadence_probe.py 40 10 | tail -2; done; echo '# GPU_MAX_HW_QUEUES=24:'; GPU_MAX_HW_QUEUES=24 PROBE_MODE=wait py $R/tools/cadence_probe.py 40 10 | tail -1; echo '# CAELO_PIPE_PACE=-1 (the issuing thread never waits), none / wait:'; for m in none wait; do CAELO_PIPE_PACE=-1 PROBE_MODE=$m py $R/tools/cadence_probe.py 40 10 | tail -1; done ) > $O/handover_cost.txt 2>&1
+( for st in 5 10 20 40 80; do py $R/tools/host_prep_probe.py $st | tail -1; done; echo '# CAELO_PIPE_PACE=-1:'; for st in 5 10 20 40 80; do CAELO_PIPE_PACE=-1 py $R/tools/host_prep_probe.py $st | tail -1; done; echo '# a pool walked with a wrap (one failing pair in 17):'; PROBE_ORDER=wrap py $R/tools/host_prep_probe.py 20 | tail -1 ) > $O/host_pacing.txt 2>&1
 py $R/tools/micro/h2d_bandwidth.py > $O/h2d_bandwidth.txt 2>&1
 # the micro-benchmarks (binaries are not tracked: built here when missing)
 for m in f16_mfma_subnormal:f16sub mfma_f32_order:mfma_order wave_placement:wave_placement; do
