@@ -58,6 +58,7 @@ struct caelo_ctx {
     void *enc_wd1x;  // dense_1 as the dense-1 kernel's B operand: [k-step 64][bf16 split 3][n-tile 13][lane 64] x 16 B
     float *enc_bd1;  // [208]
     float *enc_wd2;  // [200][20]
+    void *enc_wd2q;  // the same as k_enc_head_mfma's B operand: [hidden group 13][n-tile 2][lane 64] x float4, zero padded
     float *enc_bd2;  // [20]
     void *enc32_wd1x;  // dense_1 [16384][200] of the 32^3 stress case (config5.hip) in the same operand layout, null until set
     float *enc32_bd1;  // [208]

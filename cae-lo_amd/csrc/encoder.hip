@@ -53,6 +53,8 @@ __device__ inline float enc_tanh(float x) {
 static void conv3_split_weights(const float *w3, uint4 *out);
 static void stage1x_split_weights(const float *w1, const float *w2, uint4 *w1f, uint4 *w2x);
 int enc_upload_dense1(const float *wd1, const float *bd1, int K, void **wx_dev, float **bd_dev);
+#define HEAD_WQ_FLOATS (13 * 2 * 64 * 4)   // Dense(20) as k_enc_head_mfma's B operand
+static void head_weight_fragments(const float *wd2, float *out);
 
 CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const float *b1, const float *w2,
                                         const float *b2, const float *w3, const float *b3, const float *wd1,
@@ -107,6 +109,15 @@ CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const flo
     {
         const int rc = enc_upload_dense1(wd1, bd1, DENSE_K, &c->enc_wd1x, &c->enc_bd1);
         if (rc) return rc;
+    }
+    {
+        const size_t n = (size_t)HEAD_WQ_FLOATS;
+        float *wq = (float *)malloc(n * sizeof(float));
+        if (!wq) { caelo_set_error("out of host memory"); return CAELO_ERR_ARG; }
+        head_weight_fragments(wd2, wq);
+        if (!c->enc_wd2q) CAELO_HIP(hipMalloc(&c->enc_wd2q, n * sizeof(float)));
+        CAELO_HIP(hipMemcpy(c->enc_wd2q, wq, n * sizeof(float), hipMemcpyHostToDevice));
+        free(wq);
     }
     c->has_enc = true;
     return CAELO_OK;
@@ -2002,6 +2013,120 @@ __global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_enc_head_mfma (round 3): the same arithmetic up to the hidden layer (bias + the k slices in slice order, tanh), then Dense(20) of
+// SIXTEEN patches per workgroup on v_mfma_f32_16x16x4_f32 (an exact fmaf chain over k ascending) instead of one patch per
+// wavefront with a 22-shuffle reduce-scatter behind a serial chain per patch.  The four wavefronts of a workgroup split the 13
+// groups of 16 hidden columns (j = wave, wave + 4, ...); everything a wavefront needs after the row lookup is requested at once --
+// its slices of the partial sums, the bias, its fragments of the weights (enc_wd2q, pre-arranged) -- so a tile is two memory
+// round trips deep; the four partial products meet in LDS and are added in wavefront order.
+//   A[m][k]: lane (m = lane & 15, g = lane >> 4) holds hidden columns 16 j + 4 g .. + 3 of patch m; MFMA (j, i) contracts
+//   k = 16 j + 4 g + i over g.  B[k][n] = wd2 zero-padded to [208][32].
+//   C[4 g + i][n]: lane (g, n) holds outputs n (n-tile 0) and 16 + n (n-tile 1: four live columns) of patches 4 g .. 4 g + 3.
+// The sum over the 200 hidden units is four chains in ascending k here and a tree there: descriptors differ from k_enc_head's in
+// the last bits (2e-7), the oracle's tolerance is 1e-4 (CAELO_ENC_HEAD=wave selects the old kernel).
+#define HM_JW ((D1_NT + 3) / 4)   // hidden-column groups per wavefront (4, the last wavefront's fourth is empty)
+// host: wd2 [200][20] -> [j 13][n-tile 2][lane 64] x float4 (i = 0 .. 3): w[16 j + 4 g + i][16 nt + n], zero beyond 200 / 20
+static void head_weight_fragments(const float *wd2, float *out) {
+    for (int j = 0; j < D1_NT; ++j)
+        for (int nt = 0; nt < 2; ++nt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 4; ++i) {
+                    const int k = 16 * j + 4 * (lane >> 4) + i, col = 16 * nt + (lane & 15);
+                    out[(((size_t)j * 2 + nt) * 64 + lane) * 4 + i] = (k < DENSE_N && col < 20) ? wd2[k * 20 + col] : 0.0f;
+                }
+}
+
+template <int SPLIT>
+__global__ void __launch_bounds__(256) k_enc_head_mfma(const float *__restrict__ part, int64_t n_patches, int64_t n_rows_pad,
+                                                       const float *__restrict__ bd1p, const float4 *__restrict__ wd2q,
+                                                       const float *__restrict__ bd2, int group, caelo_enc_out outs,
+                                                       int out_stride, const caelo_enc_in in, int32_t *faults) {
+    __shared__ f32x4 s_c[3][2][64];   // partial products of wavefronts 1 .. 3
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, g = lane >> 4;
+    const unsigned n_all = (unsigned)n_patches, per_in = (unsigned)in.per_frame, per_out = (unsigned)outs.per_frame;
+    const unsigned tile = blockIdx.x;
+    const unsigned p_raw = tile * 16u + (unsigned)m;
+    const unsigned p = p_raw < n_all ? p_raw : n_all - 1u;   // (a lane past the end repeats the last patch; its outputs are not stored)
+    // ---- requests that do not depend on the patch: this wavefront's weight fragments and bias
+    float4 wq[HM_JW][2], b1[HM_JW];
+#pragma unroll
+    for (int c = 0; c < HM_JW; ++c) {
+        const int j = wave + 4 * c;
+        if (j < D1_NT) {
+            wq[c][0] = wd2q[((size_t)j * 2 + 0) * 64 + lane];
+            wq[c][1] = wd2q[((size_t)j * 2 + 1) * 64 + lane];
+            b1[c] = *(const float4 *)(bd1p + 16 * j + 4 * g);
+        }
+    }
+    // ---- the row that holds the patch's result: its representative's with de-duplication
+    unsigned row = p;
+    if (in.dedup) {
+        const unsigned f_ = p / per_in;
+        int r_ = enc_tables(in, (int)f_)->slot_of[p - f_ * per_in];        // a row of the whole launch set ...
+        if (r_ < 0) {                                                       // ... or -(representative + 1): its row
+            const unsigned g_ = (unsigned)(-r_ - 1), fr_ = g_ / per_in;
+            r_ = enc_tables(in, (int)fr_)->slot_of[g_ - fr_ * per_in];
+        }
+        row = (unsigned)r_;
+    }
+    const float *src = part + (size_t)row * DENSE_NP + 4 * g;
+    float4 v[HM_JW][SPLIT];
+#pragma unroll
+    for (int c = 0; c < HM_JW; ++c)
+#pragma unroll
+        for (int sp = 0; sp < SPLIT; ++sp)
+            if (wave + 4 * c < D1_NT) v[c][sp] = *(const float4 *)(src + (size_t)sp * n_rows_pad * DENSE_NP + 16 * (wave + 4 * c));
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < HM_JW; ++c) {
+        if (wave + 4 * c < D1_NT) {
+            float4 sum = b1[c];
+#pragma unroll
+            for (int sp = 0; sp < SPLIT; ++sp) { sum.x += v[c][sp].x; sum.y += v[c][sp].y; sum.z += v[c][sp].z; sum.w += v[c][sp].w; }
+            const float hv[4] = {enc_tanh(sum.x), enc_tanh(sum.y), enc_tanh(sum.z), enc_tanh(sum.w)};
+            const float w0[4] = {wq[c][0].x, wq[c][0].y, wq[c][0].z, wq[c][0].w}, w1[4] = {wq[c][1].x, wq[c][1].y, wq[c][1].z, wq[c][1].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i], w0[i], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i], w1[i], acc1, 0, 0, 0);
+            }
+        }
+    }
+    if (wave > 0) {
+        s_c[wave - 1][0][lane] = acc0;
+        s_c[wave - 1][1][lane] = acc1;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    // ---- wavefront 0: the four partial products in wavefront order, bias, tanh; C row 4 g + i = patch tile * 16 + 4 g + i
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+        acc0 += s_c[w][0][lane];
+        acc1 += s_c[w][1][lane];
+    }
+    const float bo0 = bd2[m], bo1 = m < 4 ? bd2[16 + m] : 0.0f;   // output bias of this lane's two C columns
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned pp = tile * 16u + 4u * (unsigned)g + (unsigned)i;
+        if (pp < n_all) {
+            // patches of several frames in one launch: frame f = p / per_frame writes into its own rows
+            const unsigned f = pp / per_out, q = pp - f * per_out, kp = q / (unsigned)group;
+            float *dst = outs.base[f] + (size_t)kp * out_stride + (size_t)(q - kp * (unsigned)group) * 20;
+            // the encoder's own invariant (see k_enc_head): a descriptor is a tanh -- finite and within [-1, 1]; counted per value
+            const float d0 = enc_tanh(bo0 + acc0[i]);
+            dst[m] = d0;
+            if (!(fabsf(d0) <= 1.0f)) atomicAdd(faults, 1);
+            if (m < 4) {
+                const float d1 = enc_tanh(bo1 + acc1[i]);
+                dst[16 + m] = d1;
+                if (!(fabsf(d1) <= 1.0f)) atomicAdd(faults, 1);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host entry
 // ------------------------------------------------------------------------------------------------
 // k_enc_head: a wave per patch up to three workgroups per CU (two for the 8-slice instance: 176 registers), then the waves loop
@@ -2147,8 +2272,14 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
         if (rc) return rc;
     }
     if (ev) CAELO_HIP(hipEventRecord(ev[3], s));
-    k_enc_head<D1_SPLIT_OF(DENSE_K)><<<enc_head_grid(n_patches), 256, 0, s>>>(part, n_patches, np, c->enc_bd1, c->enc_wd2, c->enc_bd2,
-                                                                group, outs, out_stride, ein, c->faults);
+    // CAELO_ENC_HEAD=wave: the one-patch-per-wavefront kernel of rounds 1 - 3 (comparison)
+    static const bool head_wave = getenv("CAELO_ENC_HEAD") && !strcmp(getenv("CAELO_ENC_HEAD"), "wave");
+    if (head_wave)
+        k_enc_head<D1_SPLIT_OF(DENSE_K)><<<enc_head_grid(n_patches), 256, 0, s>>>(part, n_patches, np, c->enc_bd1, c->enc_wd2, c->enc_bd2,
+                                                                    group, outs, out_stride, ein, c->faults);
+    else
+        k_enc_head_mfma<D1_SPLIT_OF(DENSE_K)><<<(unsigned)((n_patches + 15) / 16), 256, 0, s>>>(part, n_patches, np, c->enc_bd1, (const float4 *)c->enc_wd2q,
+                                                                                           c->enc_bd2, group, outs, out_stride, ein, c->faults);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[4], s));
     if (ev && fused_stage1 && !stage1x) {

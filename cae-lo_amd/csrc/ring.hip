@@ -51,7 +51,7 @@ CAELO_API void caelo_destroy(caelo_ctx *c) {
                      c->enc_b3, c->enc_bd1, c->enc_wd2, c->enc_bd2, c->enc32_bd1};
     for (float *p : ptrs)
         if (p) (void)hipFree(p);
-    for (void *p : {c->enc_w1f, c->enc_w2x, c->enc_w3x, c->enc_wd1x, c->enc32_wd1x, (void *)c->faults})
+    for (void *p : {c->enc_w1f, c->enc_w2x, c->enc_w3x, c->enc_wd1x, c->enc32_wd1x, c->enc_wd2q, (void *)c->faults})
         if (p) (void)hipFree(p);
     delete c;
 }
