@@ -534,6 +534,49 @@ def test_pipeline_with_overlapped_uploads_equals_resident_scans(engine, scans):
             assert torch.equal(a, b)
 
 
+def test_pipeline_pacing_changes_nothing_but_the_issue(engine, scans):
+    """caelo_pipeline_set_pace: the issuing thread one batch ahead of the encoder (default), two ahead, or never waiting -- the
+    rows and poses are the same bit for bit; a lag the hand-off buffers cannot serve is refused; caelo_pipeline_sync_encoded
+    returns with the rows of all but the last `lag` batches written (read back WITHOUT synchronising anything else)."""
+    import torch
+    from caelo import _ffi
+    from caelo.engine import ransac_draws, FrameBatch
+    n = 13
+    dev = [torch.from_numpy(scans(i % 3, quantum=1e-3)).to(engine.device) for i in range(n)]
+    rnd = [torch.from_numpy(ransac_draws(40 + i)).to(engine.device) for i in range(n)]
+    prev = engine.extract(dev[1])
+    pipe = engine.pipeline(4, 3)
+    want = pipe.run(dev, rnd, prev=prev)
+    torch.cuda.synchronize()
+    want = [t.clone() for t in (want.rows, want.pair_idx, want.inlier_mask, want.result, want.status)]
+    try:
+        for lag in (-1, 2, 0, 1):
+            pipe.set_pace(lag)
+            got = pipe.run(dev, rnd, prev=prev)
+            torch.cuda.synchronize()
+            for a, b in zip(want, (got.rows, got.pair_idx, got.inlier_mask, got.result, got.status)):
+                assert torch.equal(a, b), lag
+        with pytest.raises(Exception):
+            pipe.set_pace(3)          # three hand-off buffers: lags -1 .. 2
+        with pytest.raises(Exception):
+            pipe.sync_encoded(3)
+        # host-paced read-back: after sync_encoded(0) inside on_encoded-less use, the rows of every issued batch are complete
+        pipe.set_pace(-1)
+        out = FrameBatch(engine, n)
+        out.rows.fill_(float("nan"))
+        seen = []
+
+        def encoded(lo, hi):
+            seen.append((lo, hi, out.rows[lo:hi].cpu()))     # a blocking copy on the default stream: nothing waits for the pipeline's
+        pipe.run(dev, rnd, prev=prev, out=out, on_encoded=encoded)
+        torch.cuda.synchronize()
+        assert [(a, b) for a, b, _ in seen] == [(0, 4), (4, 8), (8, 12), (12, 13)]
+        for lo, hi, rows in seen:
+            assert torch.equal(rows, want[0][lo:hi].cpu())
+    finally:
+        pipe.set_pace(1)
+
+
 def test_pipeline_degenerate_frames_inside_a_batch(engine, scans):
     """an (almost) empty frame and a frame with K <= 50 key points in the MIDDLE of a pipelined batch, pairs on: their
     status bits are set, their neighbours' rows and poses are exactly what they are without them, nothing faults."""
