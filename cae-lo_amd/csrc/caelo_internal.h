@@ -316,6 +316,21 @@ int extract_encode_launch(const caelo_extract_args &a, hipStream_t s);  // the f
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. stalls the
 // whole workgroup on every global load / store / atomic still in flight (microseconds for a contended
 // atomic); kernels that hand data between waves through LDS and keep global traffic asynchronous use this.
+// Frame <-> XCD: the workgroups of a launch are dealt to the 8 XCDs round robin (workgroup b runs on XCD b % 8).  A launch over
+// (blocks per frame) x (n frames) as ONE row of blocks-per-frame * n workgroups, frame = b % n when n is 8, 4, 2 or 1: the
+// workgroups of a frame then share one XCD (or 2, 4, 8 of them) and that XCD's L2 holds ONE frame's hash tables instead of a slice
+// of all eight (k_patches 50 -> 44 us per 8 frames; the voxel build did not gain: k_vox_points 39 -> 38, k_vox_coarse 30 -> 48 us).  `block`: the workgroup's index within its frame, `per_frame`: their number.
+__device__ inline void caelo_frame_block(int n_frames, unsigned &frame, unsigned &block, unsigned &per_frame) {
+    per_frame = gridDim.x / (unsigned)n_frames;
+    if ((n_frames & (n_frames - 1)) == 0) {
+        frame = blockIdx.x & (unsigned)(n_frames - 1);
+        block = blockIdx.x / (unsigned)n_frames;
+    } else {
+        frame = blockIdx.x / per_frame;
+        block = blockIdx.x - frame * per_frame;
+    }
+}
+
 __device__ inline void caelo_lds_barrier() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __host__ __device__ inline unsigned long long caelo_pack3(int x, int y, int z) {

@@ -831,7 +831,7 @@ CAELO_API int caelo_voxmap_from_lists(caelo_ctx *c, caelo_voxmap *m, const int16
 
 // debug aid: timestamps (100 MHz) of workgroup 0 / wave 0 of the last k_patches launch
 __device__ unsigned long long g_patch_stamp[8];
-#define PATCH_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_patch_stamp[i] = wall_clock64(); } while (0)
+#define PATCH_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_patch_stamp[i] = wall_clock64(); } while (0)
 int patch_debug_copy(unsigned long long *out_host) {
     CAELO_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_patch_stamp), sizeof(unsigned long long) * 8));
     return CAELO_OK;
@@ -857,7 +857,9 @@ __device__ inline int wave_sum(int v) {
 
 __global__ void __launch_bounds__(64 * PW_WAVES, PW_OCC) k_patches(const caelo_frame_set fs, int64_t k_max, int check_counts,
                                                            unsigned long long dd_mask) {
-    const caelo_frame_dev &F = fs.f[blockIdx.z];
+    unsigned fz, bx, per_frame_wgs;   // frame <-> XCD (caelo_frame_block)
+    caelo_frame_block(fs.n, fz, bx, per_frame_wgs);
+    const caelo_frame_dev &F = fs.f[fz];
     const float *__restrict__ pts = F.key_pts;
     const int pts_ld = F.kp_ld;
     const int32_t *__restrict__ n_key = F.n_key;
@@ -867,14 +869,14 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_OCC) k_patches(const caelo_f
     const int32_t *counts = check_counts ? F.counts : nullptr;
     int32_t *status = F.status;
     DedupScratch *dd = F.dd;
-    if (counts && blockIdx.x == 0 && threadIdx.x == 0 && (counts[0] < 496 || counts[1] < 496 || counts[2] < 496))
+    if (counts && bx == 0 && threadIdx.x == 0 && (counts[0] < 496 || counts[1] < 496 || counts[2] < 496))
         atomicOr(status, CAELO_ST_FEW_VOXELS);  // sklearn ValueError at Voxel.py:195-196
     __shared__ PatchWaveLds lds_all[PW_WAVES];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     PATCH_STAMP(0);
     PatchWaveLds &L = lds_all[wave];
-    const int64_t pw = (int64_t)blockIdx.x * PW_WAVES + wave;
+    const int64_t pw = (int64_t)bx * PW_WAVES + wave;
     if (pw >= k_max * 3) return;
     const int64_t kp = pw / 3;
     const int scale = (int)(pw % 3);
@@ -883,7 +885,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_OCC) k_patches(const caelo_f
     if (kp >= K) {
         out[lane] = 0ull;
         if (lane == 0) flags[pw] = 0;
-        if (dd) caelo_dedup_insert(0ull, lane, (int)pw, (int)(blockIdx.z * CAELO_FRAME_PATCHES + pw), dd, fs.f[0].dd, dedup_slot_mask(fs.n), dd_mask);
+        if (dd) caelo_dedup_insert(0ull, lane, (int)pw, (int)(fz * CAELO_FRAME_PATCHES + pw), dd, fs.f[0].dd, dedup_slot_mask(fs.n), dd_mask);
         return;
     }
     const caelo_brick_table tab = scale == 0 ? t0 : (scale == 1 ? t1 : t2);
@@ -1119,7 +1121,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_OCC) k_patches(const caelo_f
     fl = (__ballot(fl & 1u) ? 1u : 0u) | (__ballot(fl & 2u) ? 2u : 0u);
     out[lane] = word;
     if (dd)  // equal patches of the launch set are encoded once (dedup.hip)
-        caelo_dedup_insert(word, lane, (int)pw, (int)(blockIdx.z * CAELO_FRAME_PATCHES + pw), dd, fs.f[0].dd, dedup_slot_mask(fs.n), dd_mask);
+        caelo_dedup_insert(word, lane, (int)pw, (int)(fz * CAELO_FRAME_PATCHES + pw), dd, fs.f[0].dd, dedup_slot_mask(fs.n), dd_mask);
     if (lane == 0) flags[pw] = (uint8_t)fl;
     PATCH_STAMP(3);
 }
@@ -1137,7 +1139,7 @@ int vox_patches_launch(const caelo_voxmap *m, const float *pts, int pts_ld, int6
 
 int vox_patches_set(const caelo_frame_set &fs, int64_t k_max, bool check_counts, hipStream_t s) {
     const int64_t waves = k_max * 3;
-    k_patches<<<dim3((unsigned)((waves + PW_WAVES - 1) / PW_WAVES), 1, fs.n), 64 * PW_WAVES, 0, s>>>(fs, k_max, check_counts ? 1 : 0,
+    k_patches<<<dim3((unsigned)((waves + PW_WAVES - 1) / PW_WAVES) * (unsigned)fs.n), 64 * PW_WAVES, 0, s>>>(fs, k_max, check_counts ? 1 : 0,
                                                                                                    dedup_hash_mask());
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
