@@ -262,6 +262,10 @@ def main():
                     help="--gather all: 1 (default) = the rows of every batch are gathered on a side stream as soon as the batch is "
                          "encoded, under the extraction of the next batches (host-paced: caelo_pipeline_sync_encoded); 0 = one collective after "
                          "the last frame")
+    ap.add_argument("--gather-timed", type=int, default=0,
+                    help="1 = every per-batch collective is issued synchronously on a side stream between two events (config.collective."
+                         "all_gather_ms); 0 = asynchronously on RCCL's stream, nothing waits for it until the end (the default: a wait "
+                         "pending in a queue costs the pipeline throughput)")
     ap.add_argument("--gather", choices=("boundary", "all"), default="all",
                     help="rows moved by the single all-gather: every frame's [1024,64] rows (the north-star's per-frame descriptor "
                          "gather, default) or each rank's last frame only (all that consecutive-pair matching needs)")
@@ -348,7 +352,7 @@ def main():
             finish_ranks(batch, n, gather_stats)
             return batch
         out = out or FrameBatch(eng, n)
-        g = cdist.ChunkedFrameGather(out.rows, n, B)
+        g = cdist.ChunkedFrameGather(out.rows, n, B, timed=args.gather_timed)
 
         batch = main_run.run(n, out, on_encoded=g.chunk)   # (host-paced: the rows of [lo, hi) are written when the collective is enqueued)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -433,7 +437,8 @@ def main():
         if g is None:   # one collective after the last frame: its own time, all of it exposed
             collective.update({"overlapped": False, "all_gather_ms": round(e0.elapsed_time(e1), 4)})
         else:           # per-batch collectives under the extraction: their summed durations, and what was left after the last frame
-            collective.update({"overlapped": True, "collectives": len(g.bounds), "all_gather_ms": round(g.collective_ms(), 4),
+            cms = g.collective_ms()   # None: issued asynchronously (no stream of ours waits for a collective until the end); --gather-timed 1 times them
+            collective.update({"overlapped": True, "collectives": len(g.bounds), "all_gather_ms": None if cms is None else round(cms, 4),
                                "all_gather_exposed_ms": round(e0.elapsed_time(e1), 4)})
             # not timed: the pieces against ONE collective over the same rows
             whole, frame_of = cdist.all_gather_frames(batch.rows[:K], K * world), g.finish()

@@ -21,15 +21,17 @@ import torch.distributed as dist
 ROW = 64  # floats per key point row: descriptor (60) + xyz (3) + valid (1)
 
 
-def _all_gather_into(recv, send, group=None):
+def _all_gather_into(recv, send, group=None, async_op=False):
     """dist.all_gather_into_tensor; device tensors under the gloo backend (functional tests that put several ranks
-    on one GPU) are staged through the host."""
+    on one GPU) are staged through the host (always synchronously).  ``async_op``: returns the Work handle instead of making
+    the current stream wait for the collective (c10d's synchronous form ends with a device-side wait of the current stream for
+    RCCL's stream)."""
     if send.is_cuda and dist.get_backend(group) == "gloo":
         r = torch.empty(recv.shape, dtype=recv.dtype)
         dist.all_gather_into_tensor(r, send.cpu(), group=group)
         recv.copy_(r)
-    else:
-        dist.all_gather_into_tensor(recv, send, group=group)
+        return None
+    return dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)
 
 
 def shard_frames(n_frames, rank, world):
@@ -89,7 +91,11 @@ class ChunkedFrameGather:
     device-side form that costs the pipeline a quarter of its rate), while the pipeline works on the next batch.  Every rank must call ``chunk``
     with the same (lo, hi) sequence (equal blocks: n_local frames per rank).  Buffers are allocated up front."""
 
-    def __init__(self, rows, n_local, chunk_frames, group=None, even_alone=False):
+    def __init__(self, rows, n_local, chunk_frames, group=None, even_alone=False, timed=False):
+        """``timed``: every collective is bracketed by two events on the side stream and issued synchronously there
+        (``collective_ms``); default: issued asynchronously -- the collective runs on RCCL's own stream and NO stream of ours waits
+        for it until ``finish`` (a wait that sits unsatisfied in a queue costs the frame pipeline beside it throughput:
+        DESIGN.md 5)."""
         self.rows, self.n, self.group = rows, n_local, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.alone = self.world == 1 and not (even_alone and dist.is_initialized())   # (a world of one still runs the collectives in tests)
@@ -97,7 +103,9 @@ class ChunkedFrameGather:
         self.recv = [rows.new_empty((self.world * (hi - lo),) + tuple(rows.shape[1:])) for lo, hi in self.bounds]
         self.side = torch.cuda.Stream(device=rows.device) if rows.is_cuda else None
         self.done = 0
+        self.timed = bool(timed)
         self.events = []
+        self.works = []
 
     def chunk(self, lo, hi):
         assert self.bounds[self.done] == (lo, hi), "chunks arrive in order, the same on every rank"
@@ -109,15 +117,24 @@ class ChunkedFrameGather:
             _all_gather_into(recv, self.rows[lo:hi].contiguous(), self.group)
             return
         with torch.cuda.stream(self.side):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            _all_gather_into(recv, self.rows[lo:hi], self.group)   # (a contiguous slice of the frame rows)
-            e1.record()
-            self.events.append((e0, e1))
+            if self.timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _all_gather_into(recv, self.rows[lo:hi], self.group)   # (a contiguous slice of the frame rows)
+                e1.record()
+                self.events.append((e0, e1))
+            else:
+                w = _all_gather_into(recv, self.rows[lo:hi], self.group, async_op=True)
+                if w is not None:
+                    self.works.append(w)
 
     def finish(self):
-        """the current stream waits for the side stream; returns ``frame(rank, i)`` -> rows [K, 64] of frame i of ``rank``."""
+        """the current stream waits for the collectives (and the side stream); returns ``frame(rank, i)`` -> rows [K, 64] of frame
+        i of ``rank``."""
         assert self.done == len(self.bounds)
+        for w in self.works:
+            w.wait()                       # (device-side: the current stream waits for RCCL's)
+        self.works = []
         if self.side is not None:
             torch.cuda.current_stream(self.rows.device).wait_stream(self.side)
 
@@ -133,8 +150,8 @@ class ChunkedFrameGather:
         return sum(r.numel() * r.element_size() for r in self.recv) if not self.alone else 0
 
     def collective_ms(self):
-        """sum of the collectives' own durations on the side stream (after a synchronize)"""
-        return sum(e0.elapsed_time(e1) for e0, e1 in self.events)
+        """sum of the collectives' own durations on the side stream (after a synchronize); None when they were not timed"""
+        return sum(e0.elapsed_time(e1) for e0, e1 in self.events) if self.timed or self.alone or self.side is None else None
 
 
 def all_gather_boundary(last_rows, group=None):

@@ -340,7 +340,7 @@ def test_rccl_all_gather_of_frame_rows(engine):
         draws = [torch.from_numpy(ransac_draws(i)).to(engine.device) for i in range(n)]
         out = FrameBatch(engine, n)
         out.rows.fill_(float("nan"))
-        g = cd.ChunkedFrameGather(out.rows, n, 4, even_alone=True)
+        g = cd.ChunkedFrameGather(out.rows, n, 4, even_alone=True, timed=True)
 
         def shipped(lo, hi):
             pipe.wait_encoded(g.side)
