@@ -1206,6 +1206,31 @@ def test_stage1x_agrees_with_the_f32_kernel(engine):
 
 
 @pytest.mark.gpu
+def test_head_kernels_agree(engine):
+    """k_enc_head_mfma (Dense(20) of 16 patches per workgroup on the f32 matrix cores: four ascending chains over the hidden units)
+    against the one-patch-per-wavefront k_enc_head (a tree): the same descriptors to 1e-6 on every patch of the golden frame (second
+    process with CAELO_ENC_HEAD=wave); the hidden layer in front of them is bit-identical."""
+    import subprocess
+    import tempfile
+    import torch
+    bits = np.ascontiguousarray(np.load(os.path.join(GOLDEN, "frame_q0.npz"))["patch_bits"].reshape(-1, 64))
+    lay = engine.encode_layers(torch.from_numpy(bits.view(np.int64)).to(engine.device))
+    pre, out = lay[2].cpu().numpy(), lay[3].cpu().numpy()
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import caelo; from caelo.engine import Engine; e = Engine(device=0);"
+              "b = np.ascontiguousarray(np.load(%r)['patch_bits'].reshape(-1, 64));"
+              "l = e.encode_layers(torch.from_numpy(b.view(np.int64)).to(e.device)); torch.cuda.synchronize();"
+              "np.savez(sys.argv[1], pre=l[2].cpu().numpy(), out=l[3].cpu().numpy())") % (os.path.join(repo, "cae-lo_amd"), os.path.join(GOLDEN, "frame_q0.npz"))
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "h.npz")
+        r = subprocess.run([sys.executable, "-c", script, path], env=dict(os.environ, CAELO_ENC_HEAD="wave"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        ref = np.load(path)
+        assert np.array_equal(ref["pre"], pre)
+        assert ref["out"].shape == out.shape and np.abs(ref["out"] - out).max() <= 1e-6, np.abs(ref["out"] - out).max()
+
+
+@pytest.mark.gpu
 def test_pipeline_batch_plan_does_not_change_results(engine, scans):
     """caelo_pipeline_expect spreads a run that is not a whole number of batches evenly (20 frames on batch 8: 6 + 7 + 7); every frame and
     every pair must come out as from full batches with the remainder last, and the hardware self-check stays at 0."""
