@@ -137,7 +137,7 @@ class Pipeline:
         h = C.c_void_p()
         _ffi.check(eng.lib.caelo_pipeline_create(eng.ctx, int(batch), int(buffers), int(max_points or eng.max_points), C.byref(h)))
         self.h, self.batch, self.buffers = h, int(batch), int(buffers)
-        self.pace = None   # the library's default (1, or CAELO_PIPE_PACE) until set_pace
+        self.pace = max(-1, min(int(os.environ.get("CAELO_PIPE_PACE", "1")), self.buffers - 1))   # the library's default until set_pace
 
     def __del__(self):
         try:
@@ -291,7 +291,7 @@ class Pipeline:
 
         _ffi.check(lib.caelo_pipeline_expect(self.h, 0))   # full batches, the remainder last: the slots are laid out that way
         copy.wait_stream(torch.cuda.current_stream(eng.device))   # (an earlier run may still read the slots)
-        pace = getattr(self, "pace", None)
+        pace = self.pace
         _ffi.check(lib.caelo_pipeline_set_pace(self.h, -1))       # this loop paces itself: the copies go out BEFORE the thread waits
         _ffi.check(lib.caelo_pipeline_begin(self.h, stream))
         try:
@@ -307,7 +307,7 @@ class Pipeline:
                     self.sync_encoded(1)                 # (a partial last batch is only issued by the flush)
         finally:
             rc = lib.caelo_pipeline_flush(self.h, stream)
-            lib.caelo_pipeline_set_pace(self.h, 1 if pace is None else pace)
+            lib.caelo_pipeline_set_pace(self.h, pace)
         _ffi.check(rc)
         return out
 
