@@ -277,9 +277,10 @@ def main():
     elif args.extract_only:
         args.config = "extract"
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # `python bench.py --gpus N` without a launcher starts its N ranks itself (torch.distributed.run, one per GPU) and exits
+    # with their status; a WORLD_SIZE that differs from --gpus, or fewer than N visible GPUs without the gloo functional-test
+    # backend, is an error (exit 2, no JSON line) -- never a one-rank line (caelo.dist.ensure_ranks)
+    world, rank, local_rank = cdist.ensure_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -289,7 +290,6 @@ def main():
     local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     eng = Engine(device=local_rank)
     if args.config == "dense128":
@@ -448,6 +448,15 @@ def main():
             collective["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
             collective["rccl_version"] = None
+
+    if world > 1:
+        if collective is None:   # extraction only: no data-path collective, the ranks are still one job
+            collective = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "gather": None, "bytes_received_per_rank": 0}
+        # the line below says n_gpus = world: it must be what actually ran, on the backend that was asked for
+        assert collective["world_size"] == args.gpus == world, "ranks that ran != --gpus"
+        assert collective["backend"] == backend and (backend == "nccl" or os.environ.get("CAELO_DIST_BACKEND") == backend), \
+            "multi-rank line on a backend nobody asked for"
+        collective["ranks_on_distinct_gpus"] = bool(torch.cuda.device_count() >= world)
 
     out = None
     if rank == 0:

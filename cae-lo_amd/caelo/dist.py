@@ -14,6 +14,11 @@ of the gathered per-pair (R, T) on rank 0 (host, 3x4 algebra).
 
 Nothing here is device specific: the same code runs under gloo on CPU tensors in tests/.
 """
+import os
+import socket
+import subprocess
+import sys
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -32,6 +37,45 @@ def _all_gather_into(recv, send, group=None, async_op=False):
         recv.copy_(r)
         return None
     return dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)
+
+
+def ensure_ranks(n_ranks, script, argv):
+    """``script --gpus N`` started WITHOUT a launcher (no WORLD_SIZE in the environment) starts its N ranks itself: the process
+    re-executes the script under ``torch.distributed.run`` -- one rank per GPU, rendezvous on 127.0.0.1 and a free port -- and
+    exits with the launcher's status.  The counterpart of the reference's own fan-out (PoseEstimation.py:79-99,
+    BatchPreprocess.py:215-228 start one worker process per slice of the frame list).  Returns (world, rank, local_rank) when
+    this process IS a rank (or N == 1).  Fails loudly -- exit status 2, nothing printed on stdout -- when
+
+    * the launcher's WORLD_SIZE differs from ``--gpus``, or
+    * fewer than N GPUs are visible and the functional-test backend (``CAELO_DIST_BACKEND=gloo``: several ranks share a GPU,
+      rows staged through the host) was not asked for: a run that silently used fewer ranks would print a line that looks
+      like an N-GPU result."""
+    backend = os.environ.get("CAELO_DIST_BACKEND", "nccl")
+    if "WORLD_SIZE" in os.environ:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != n_ranks:
+            sys.stderr.write("%s: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); start it with --nproc-per-node == "
+                             "--gpus, or without a launcher\n" % (os.path.basename(script), n_ranks, world))
+            sys.exit(2)
+        return world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if n_ranks <= 1:
+        return 1, 0, 0
+    visible = torch.cuda.device_count()
+    if backend == "nccl" and visible < n_ranks:
+        sys.stderr.write("%s: --gpus %d needs %d visible GPUs (RCCL: one rank per device), %d visible; "
+                         "CAELO_DIST_BACKEND=gloo runs the ranks on the visible GPU(s) as a functional test\n"
+                         % (os.path.basename(script), n_ranks, n_ranks, visible))
+        sys.exit(2)
+    if visible < 1:
+        sys.stderr.write("%s: no GPU visible\n" % os.path.basename(script))
+        sys.exit(2)
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n_ranks,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def shard_frames(n_frames, rank, world):

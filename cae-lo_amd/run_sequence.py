@@ -35,14 +35,7 @@ from caelo.engine import Engine, FrameBatch, FrameFeatures, raise_status, ransac
 
 def pose_rows(batch, k):
     """FrameBatch.result -> numpy: rel_rt [k,12], success, threshold, n_inliers (one host copy)."""
-    raw = batch.result[:k].cpu().numpy()
-    out = np.zeros((k, 12), np.float32)
-    ok = np.zeros(k, bool); thr = np.zeros(k, np.float32); nin = np.zeros(k, np.int32)
-    for i in range(k):
-        r = _ffi.PoseResult.from_buffer_copy(raw[i].tobytes())
-        out[i, :9], out[i, 9:] = np.array(r.R, np.float32), np.array(r.T, np.float32)
-        ok[i], thr[i], nin[i] = bool(r.success), r.threshold, r.n_inliers
-    return out, ok, thr, nin
+    return _parse_poses(batch.result[:k].cpu().numpy(), k)
 
 
 def _parse_poses(raw, k):
@@ -153,10 +146,11 @@ def main():
     ap.add_argument("--pool", type=int, default=0, help="synthesise only this many distinct scans and walk them back and forth (0 1 .. P-1 "
                                                         "P-2 .. 0 1 ..: every pair stays a pair of neighbours); ray casting a scan costs ~0.5 s of CPU")
     ap.add_argument("--save-artifacts", action="store_true", help="write Features/*.mat and InliersIdx/*.mat next to the scans")
+    ap.add_argument("--gpus", type=int, default=int(os.environ.get("WORLD_SIZE", "1")),
+                    help="ranks = GPUs; without a launcher the script starts them itself (caelo.dist.ensure_ranks)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, local_rank = cdist.ensure_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

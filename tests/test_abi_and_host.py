@@ -92,3 +92,23 @@ def test_pose_chaining_matches_float32_reference_formula():
     Tr = np.array([[0, -1, 0, 0.1], [0, 0, -1, -0.2], [1, 0, 0, 0.3]], np.float32)
     p2 = cd.chain_poses(np.array(rel, np.float32), Tr)
     assert np.allclose(p2[1].reshape(3, 4)[:, :3] @ p2[1].reshape(3, 4)[:, :3].T, np.eye(3), atol=1e-5)
+
+
+def test_multi_rank_request_fails_loudly_or_self_launches():
+    """`bench.py --gpus N` / `run_sequence.py --gpus N` never print a one-rank line for an N-rank request (missing 1):
+    without a launcher they start the ranks themselves (covered on the GPU box); with a launcher whose WORLD_SIZE differs, or
+    with fewer than N visible GPUs and no gloo override, they exit 2 with nothing on stdout.  (PoseEstimation.py:79-99 is the
+    reference's fan-out: it always starts the worker processes it was asked for.)"""
+    import subprocess
+    import sys
+    import torch
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CAELO_DIST_BACKEND")}
+    for script, extra in ((os.path.join(REPO, "bench.py"), ["--steps", "1", "--warmup", "0"]),
+                          (os.path.join(REPO, "cae-lo_amd", "run_sequence.py"), ["--synthetic", "4"])):
+        r = subprocess.run([sys.executable, script, "--gpus", "3"] + extra, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                           capture_output=True, timeout=300)
+        assert r.returncode == 2 and r.stdout == b"" and b"--gpus 3" in r.stderr
+        if torch.cuda.device_count() < 64:
+            r = subprocess.run([sys.executable, script, "--gpus", "64"] + extra, env=env, capture_output=True, timeout=300)
+            assert r.returncode == 2 and r.stdout == b"" and b"visible" in r.stderr

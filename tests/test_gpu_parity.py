@@ -1033,6 +1033,38 @@ def test_refinement_vs_reference_golden(api, orc, models, scans):
     assert not np.allclose(poses_[1], g["rc_poses_in"][1], atol=1e-3)     # the refinement really moved pose 1
 
 
+def test_bench_and_run_sequence_start_their_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher (the form the driver uses) starts two ranks by itself and the line says so;
+    same for run_sequence.py, whose pose file equals the one-rank run's.  On a one-GPU box the functional-test backend has to be
+    asked for (CAELO_DIST_BACKEND=gloo); without it the request is refused (exit 2, no line) instead of running one rank."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    from conftest import REPO
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "CAELO_DIST_BACKEND")}
+    two_gpus = torch.cuda.device_count() >= 2
+    bench = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    if not two_gpus:
+        r = subprocess.run(bench, env=env, capture_output=True, timeout=300)
+        assert r.returncode == 2 and b'"metric"' not in r.stdout
+        env["CAELO_DIST_BACKEND"] = "gloo"
+    r = subprocess.run(bench, env=env, capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith('{"metric"')][-1])
+    c = d["config"]["collective"]
+    assert d["n_gpus"] == 2 and c["world_size"] == 2 and c["backend"] == ("nccl" if two_gpus else "gloo")
+    assert c["ranks_on_distinct_gpus"] == two_gpus and d["config"]["poses_solved"] == "32/32" and len(d["config"]["per_rank_frames_per_s"]) == 2
+    script = os.path.join(REPO, "cae-lo_amd", "run_sequence.py")
+    one, two = str(tmp_path / "w1.txt"), str(tmp_path / "w2.txt")
+    subprocess.run([sys.executable, script, "--synthetic", "9", "--out", one], check=True, env=env, capture_output=True, timeout=300)
+    r = subprocess.run([sys.executable, script, "--gpus", "2", "--synthetic", "9", "--out", two], env=env, capture_output=True, timeout=600)
+    assert r.returncode == 0 and b"on 2 GPU(s)" in r.stdout, r.stderr.decode()[-2000:]
+    assert open(one).read() == open(two).read()
+
+
 def test_two_ranks_over_rccl_when_two_gpus_are_visible(tmp_path):
     """bench.py and run_sequence.py under torch.distributed.run with backend nccl (= RCCL over xGMI), one rank per GPU: needs
     two visible GPUs (the round-end driver's test box has one: skipped there; the 8-GPU scaling run exercises the same path)."""
