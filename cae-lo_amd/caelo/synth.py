@@ -230,3 +230,17 @@ def relative_pose_gt(frame0, frame1):
     R = R0.T @ R1
     T = R0.T @ (np.array(t1) - np.array(t0))
     return R, T.reshape(3, 1)
+
+
+def shuffle_scan(pc, seed, dup_fraction=0.01):
+    """The same scan in a hostile FILE ORDER: ``dup_fraction`` of the points repeated with another intensity (same x, y, z),
+    then everything randomly permuted.  Two rules of the reference depend on the order of the points: the LAST point of a ring
+    pixel wins it (SphericalRing.py:91-93: intensity and range of the pixel) and the FIRST point of a 2 cm voxel decides which
+    16 cm / 64 cm voxels it marks (Voxel.py:139-158).  A beam-major scan never exercises either across distant file
+    positions; this one does."""
+    rng = np.random.RandomState(seed)
+    n = pc.shape[0]
+    dup = pc[rng.randint(0, n, int(round(n * dup_fraction)))].copy()
+    dup[:, 3] = rng.random_sample(len(dup)).astype(np.float32)
+    out = np.concatenate([pc, dup], axis=0)
+    return np.ascontiguousarray(out[rng.permutation(len(out))])

@@ -475,6 +475,48 @@ def test_quantised_scans_fused_path_and_pipeline_vs_reference_golden(engine, api
             assert np.abs(np.array(r.T) - gp["s%d_T" % s].ravel()).max() <= REL_TOL * max(1.0, np.abs(gp["s%d_T" % s]).max())
 
 
+def test_shuffled_file_order_vs_reference_golden(engine, api, scans):
+    """frame_p0 (missing 4): the scan with 1 % repeated points in a randomly permuted FILE ORDER.  The GPU resolves
+    last-writer-wins (SphericalRing.py:91-93) and first-touch (Voxel.py:139-158) with atomics on the point index: ring image,
+    counter, key pixels, the three voxel LISTS in the reference's order, patches -- bit for bit what the reference computed on
+    that order -- through the staged API, the fused call and the pipeline."""
+    import torch
+    from caelo import synth
+    g = np.load(os.path.join(GOLDEN, "frame_p0.npz"))
+    pc = synth.shuffle_scan(scans(0, quantum=1e-3), int(g["shuffle_seed"]))
+    assert synth.cloud_sha256(pc) == str(g["cloud_sha256"])
+    ring, cnt = api.ProjectPC2SphericalRing(pc)
+    assert sha(ring) == str(g["ring_sha256"]) and sha(cnt) == str(g["counter_sha256"])
+    v = api.Voxelization(pc[:, 0:3])
+    assert sha(v[6]) == str(g["voxels0_sha256"]) and np.array_equal(v[7], g["voxels1"]) and np.array_equal(v[8], g["voxels2"])
+    dpc = torch.from_numpy(pc).to(engine.device)
+    ff = engine.extract(dpc)
+    assert int(ff.status[0].item()) == 0 and np.array_equal(ff.key_pixels.cpu().numpy(), g["keypixels_demo"].astype(np.int64))
+    _assert_descriptors(ff.features.cpu().numpy(), g["features"])
+    for build in (engine.voxelize_fast, engine.voxelize):
+        vm, st = build(dpc, engine.voxmap(max(engine.max_points, pc.shape[0]), slot=7))
+        bits, flags = engine.patches(vm, torch.from_numpy(g["patch_kp"]).to(engine.device))
+        assert np.array_equal(bits.cpu().numpy().view(np.uint64), g["patch_bits"]) and int(st.item()) == 0
+    out = engine.pipeline(4).run([dpc, dpc, dpc], pairs=False)
+    torch.cuda.synchronize()
+    assert all(torch.equal(out.rows[i], ff.rows) for i in range(3)) and int(out.status[:, 0].abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("scene,frames", [("boxes", 18), ("clutter", 18), ("boxes_mm", 18), ("shuffled", 6)])
+def test_parity_soak_short(engine, orc, models, scene, frames):
+    """A short leg of tools/parity_soak.py (the committed 200-frame report is profiles/r04_parity_soak.txt): consecutive frames
+    through the batched pipeline against the oracle -- key pixels, voxel sets, patch bits bit-exact; descriptors within 1e-4;
+    caelo_match and caelo_ransac on the oracle's inputs bit-exact; the pipeline's own argmin columns equal to the oracle's except
+    where the float64 margin is below what the pair's descriptor error can move a distance by (listed), and every pair without such
+    a column has the oracle's inlier set bit for bit and its pose within 1e-4."""
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    import parity_soak
+    rep = parity_soak.soak(engine, orc, models, scene, frames, workers=min(frames, 16))
+    assert parity_soak.clean(rep), parity_soak.render(rep)
+    assert rep["columns"] == (frames - 1) * 1024 and rep["patches"] == frames * 3072
+    assert rep["success_mismatch"] == 0 and rep["flips"] <= rep["columns"] // 1000   # flips stay rare (measured: a few per 100 k columns)
+
+
 @pytest.mark.parametrize("batch,buffers", [(1, 2), (3, 2), (4, 3), (8, 2)])
 def test_pipeline_equals_single_stream_calls(engine, scans, batch, buffers):
     """caelo_pipeline (`batch` frames behind every launch of the front kernels, the encoder launch set and the match /

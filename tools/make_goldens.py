@@ -93,10 +93,24 @@ def inconsistent_points(pc):
     return n
 
 
-def frame_golden(frame, n_beams=64, n_az=2000, n_patch_kp=None, tag=None, quantum=None, scene_kind="boxes"):
+def frame_golden(frame, n_beams=64, n_az=2000, n_patch_kp=None, tag=None, quantum=None, scene_kind="boxes", shuffle_seed=None):
     t0 = time.time()
     g = {}
     pc = synth.make_scan(frame, n_beams=n_beams, n_az=n_az, quantum=quantum, scene_kind=scene_kind)
+    if shuffle_seed is not None:
+        # hostile file order (round 4): 1 % of the points repeated with another intensity, everything permuted -- the
+        # last-writer-wins rule of SphericalRing.py:91-93 and the first-touch rule of Voxel.py:139-158 across distant positions
+        ordered = pc
+        pc = synth.shuffle_scan(pc, shuffle_seed)
+        g["shuffle_seed"] = shuffle_seed
+        ring_a, _ = RefSR.ProjectPC2SphericalRing(ordered)
+        ring_b, _ = RefSR.ProjectPC2SphericalRing(pc)
+        g["ring_pixels_changed_by_order"] = int((ring_a != ring_b).any(axis=2).sum())
+        va, vb = RefVoxel.Voxelization(ordered[:, 0:3]), RefVoxel.Voxelization(pc[:, 0:3])
+        g["voxel_lists_reordered"] = np.array([not np.array_equal(va[6 + s_], vb[6 + s_]) for s_ in range(3)])
+        g["voxel1_set_changed_by_order"] = bool({tuple(r) for r in va[7]} != {tuple(r) for r in vb[7]})
+        print("  frame %s: order changes %d ring pixels, voxel lists reordered %s, scale-1 SET changed %s" % (
+            tag, g["ring_pixels_changed_by_order"], g["voxel_lists_reordered"], g["voxel1_set_changed_by_order"]))
     if quantum:
         g["quantum"] = quantum
         g["n_inconsistent_points"] = inconsistent_points(pc)
@@ -230,6 +244,11 @@ def clutter_golden():
     c0 = frame_golden(0, quantum=1e-3, tag="c0", scene_kind="clutter")
     c1 = frame_golden(1, quantum=1e-3, tag="c1", scene_kind="clutter")
     pair_golden(c0, c1, seeds=(0, 1), out="pair_c0_c1.npz", hard_cases=False)
+
+
+def shuffled_golden():
+    """Round 4 (missing 4): frame 0 of the mm-quantised scene in a hostile file order through the reference."""
+    frame_golden(0, quantum=1e-3, tag="p0", shuffle_seed=77)
 
 
 def trunc_golden():
@@ -610,6 +629,9 @@ if __name__ == "__main__":
     if "--sequence-only" in sys.argv:
         sequence_golden()
         sys.exit(0)
+    if "--shuffled-only" in sys.argv:
+        shuffled_golden()
+        sys.exit(0)
     if "--clutter-only" in sys.argv:
         clutter_golden()
         sys.exit(0)
@@ -637,6 +659,7 @@ if __name__ == "__main__":
     pair_golden(f0, f1)
     quantised_golden()
     clutter_golden()
+    shuffled_golden()
     # dense 128-beam scan: exercises the 496-NN truncation of GetPatchesList
     frame_golden(0, n_beams=128, n_az=4000, n_patch_kp=192, tag="dense128")
     sequence_golden()
