@@ -350,7 +350,7 @@ int match_set(const caelo_pair_set &ps, int ld0, int64_t k0_max, int ld1, int64_
     // default: the f16 screen + exact certification (match_screen.inc); CAELO_MATCH=f64, a dim > 62 (no room for the two norm
     // slots in K = 64) or more than 1024 frame-0 descriptors: round 2's all-f64 kernel.  Same pair_idx bit for bit.
     static const bool f64_only = getenv("CAELO_MATCH") && !strcmp(getenv("CAELO_MATCH"), "f64");
-    if (!f64_only && dim <= 62 && k0_max <= 16 * MS_NW * MS_TPW) {
+    if (!f64_only && dim <= 62) {
         const int64_t kpad = ms_pad16(k0_max > k1_max ? k0_max : k1_max);
         bool v4 = (dim % 4 == 0) && (ld0 % 4 == 0) && (ld1 % 4 == 0);
         for (int i = 0; i < ps.n; ++i) v4 = v4 && (((uintptr_t)ps.p[i].f0 | (uintptr_t)ps.p[i].f1) & 15u) == 0;

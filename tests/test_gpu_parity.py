@@ -1375,6 +1375,43 @@ def test_match_shape_sweep_vs_oracle(engine, orc):
 
 
 @pytest.mark.gpu
+def test_match_outside_the_unit_range_vs_oracle(engine, orc):
+    """caelo.h promises the float64 argmin for ANY descriptors, and the f16 screen's window was derived for values of
+    order one.  (a) small descriptors: below 2^-3 the low half of a 2-way f16 split is subnormal and its error is an absolute
+    2^-25, which a purely relative window does not cover (uniform [-1e-3, 1e-3] certified wrong rows) -- the window now carries
+    the absolute term; (b) large ones: |a|^2 between 3e4 and 6.5e4 passed the old sentinel norm of the pad rows (k0 not a multiple
+    of 16: pair_idx >= k0), and beyond 65 504 f16 ends -- rows are masked by index and out-of-range norms take the exact scan;
+    (c) more than 1024 frame-0 rows, which used to leave the screen for the f64 kernel.  All bit-exact against cdist + argmin."""
+    import torch
+    rs = np.random.RandomState(33)
+    cases = [(1e-2, 256, 256, 60), (3e-3, 256, 256, 60), (1e-3, 256, 256, 60), (1e-4, 250, 256, 60), (1e-6, 100, 64, 60),
+             (25.0, 250, 96, 60), (30.0, 1001, 64, 60), (33.0, 17, 40, 60), (200.0, 40, 33, 60), (1e4, 130, 33, 20), (1.0, 1500, 300, 60),
+             (1.0, 2050, 70, 32)]
+    for scale, k0, k1, dim in cases:
+        a = (rs.uniform(-1, 1, (k0, dim)) * scale).astype(np.float32)
+        b = (rs.uniform(-1, 1, (k1, dim)) * scale).astype(np.float32)
+        b[1] = a[k0 - 1]                       # the last real row is the exact answer of a column: pad rows must not shadow it
+        if k0 > 20:
+            b[2] = (a[4] + a[11]) * 0.5        # a near tie
+        idx = engine.match(torch.from_numpy(a).to(engine.device), torch.from_numpy(b).to(engine.device)).cpu().numpy()
+        want = orc.match(a, b)[0]
+        assert idx.max() < k0 and np.array_equal(idx, want), (scale, k0, k1, dim, np.nonzero(idx != want)[0][:8])
+    # repeated descriptors (equal patches give equal descriptors): five copies stay inside the candidate list (exact distances of
+    # the candidates, first minimum), a dozen overflow it (exact scan of the column)
+    a = rs.uniform(-1, 1, (700, 60)).astype(np.float32); b = rs.uniform(-1, 1, (90, 60)).astype(np.float32)
+    a[[650, 20, 333, 21, 500]] = a[9]; b[7] = a[9]; b[8] = a[9] + np.float32(1e-7)
+    a[np.arange(100, 112) * 3] = a[640]; b[40] = a[640]
+    idx = engine.match(torch.from_numpy(a).to(engine.device), torch.from_numpy(b).to(engine.device)).cpu().numpy()
+    want = orc.match(a, b)[0]
+    assert np.array_equal(idx, want) and idx[7] == 9 and idx[40] == 300
+    # mixed magnitudes: one huge row among unit ones (its norm is out of the f16 range: the whole pair takes the exact scan)
+    a = rs.uniform(-1, 1, (300, 60)).astype(np.float32); b = rs.uniform(-1, 1, (100, 60)).astype(np.float32)
+    a[17] *= 1e3; b[3] *= 500.0
+    idx = engine.match(torch.from_numpy(a).to(engine.device), torch.from_numpy(b).to(engine.device)).cpu().numpy()
+    assert np.array_equal(idx, orc.match(a, b)[0])
+
+
+@pytest.mark.gpu
 def test_ransac_pair_count_sweep_vs_oracle(api, orc):
     """RANSAC4RT over pair counts around every boundary of the kernels: fewer than 5 pairs (leastInliers = 0: Match.py:166),
     counts that are not a multiple of 64, exactly the 1024 the LDS stage holds, and more (the hypotheses then read global
