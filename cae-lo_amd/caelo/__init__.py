@@ -24,7 +24,10 @@ def configure_runtime(hw_queues=8):
     reports what it runs with through caelo_pipeline_stats)."""
     cur = os.environ.get("GPU_MAX_HW_QUEUES")
     if cur is not None:
-        return int(cur) >= hw_queues
+        try:
+            return int(cur.strip() or 0) >= hw_queues
+        except ValueError:   # the runtime reads it with atoi: a value it would take for 0 leaves the default of four queues
+            return False
     torch_mod = sys.modules.get("torch")
     if torch_mod is not None and torch_mod.cuda.is_initialized():
         return False

@@ -43,6 +43,7 @@ class FrameJob(C.Structure):
 
 
 PAIR_NONE, PAIR_CHAIN, PAIR_EXPLICIT = 0, 1, 2
+ABI_VERSION = 2   # include/caelo.h CAELO_ABI_VERSION
 BUILD_PACKED_F32, BUILD_PROF, BUILD_STAMPED = 1, 2, 256   # caelo_build_flags() bits (include/caelo.h)
 
 # the same layout as a NumPy record (a run's jobs are filled column-wise and handed over in one call)
@@ -61,6 +62,7 @@ SIGNATURES = [
     ("caelo_destroy", None, [c_vp]),
     ("caelo_set_respond_weights", c_int, [c_vp] + [c_vp] * 4),
     ("caelo_set_encoder_weights", c_int, [c_vp] + [c_vp] * 10),
+    ("caelo_set_encoder_reference", c_int, [c_vp, c_int]),
     ("caelo_project", c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("caelo_respond", c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     ("caelo_keypoints_ws_bytes", c_i64, []),
@@ -110,6 +112,7 @@ SIGNATURES = [
     ("caelo_pipeline_wait_encoded", c_int, [c_vp, c_vp]),
     ("caelo_pipeline_sync_encoded", c_int, [c_vp, c_int]),
     ("caelo_pipeline_set_pace", c_int, [c_vp, c_int]),
+    ("caelo_pipeline_get_pace", c_int, [c_vp]),
     ("caelo_pipeline_stats", c_int, [c_vp, C.POINTER(c_i64)]),
     ("caelo_pipeline_expect", c_int, [c_vp, c_i64]),
     ("caelo_lane_faults", c_int, [c_vp, C.POINTER(c_i64)]),
@@ -133,7 +136,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.caelo_abi_version() != 1:
+        if lib.caelo_abi_version() != ABI_VERSION:
             raise CaeloError("libcaelo.so ABI mismatch")
         word = lib.caelo_build_flags()
         if not word & BUILD_STAMPED or (word & BUILD_PACKED_F32 and not os.environ.get("CAELO_ALLOW_PACKED_F32")):

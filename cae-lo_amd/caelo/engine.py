@@ -137,7 +137,7 @@ class Pipeline:
         h = C.c_void_p()
         _ffi.check(eng.lib.caelo_pipeline_create(eng.ctx, int(batch), int(buffers), int(max_points or eng.max_points), C.byref(h)))
         self.h, self.batch, self.buffers = h, int(batch), int(buffers)
-        self.pace = max(-1, min(int(os.environ.get("CAELO_PIPE_PACE", "1")), self.buffers - 1))   # the library's default until set_pace
+        self.pace = int(eng.lib.caelo_pipeline_get_pace(h))   # the library's default until set_pace (asked, not re-derived from the environment)
 
     def __del__(self):
         try:
@@ -368,6 +368,10 @@ class Engine:
             # zero-filled: caelo_match / caelo_ransac keep their tickets in the workspace and leave them zero
             t = self._wss[key] = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
         return t
+
+    def set_encoder_reference(self, on=True):
+        """caelo_set_encoder_reference: stage 1 of this engine's encoder = the exact-f32 kernel (precision reference; slower)."""
+        _ffi.check(self.lib.caelo_set_encoder_reference(self.ctx, 1 if on else 0))
 
     def lane_faults(self):
         """caelo_lane_faults: wavefronts of the pose kernels whose lanes disagreed on a hypothesis they all derive from the

@@ -63,6 +63,7 @@ struct caelo_ctx {
     void *enc32_wd1x;  // dense_1 [16384][200] of the 32^3 stress case (config5.hip) in the same operand layout, null until set
     float *enc32_bd1;  // [208]
     bool has_enc;
+    bool enc_reference;   // caelo_set_encoder_reference: stage 1 = the exact-f32 k_enc_stage1 (precision reference)
     int32_t *faults;  // device counter of the pair kernels' lane-agreement checks (match.hip); 0 on healthy hardware
 };
 

@@ -83,168 +83,9 @@ __global__ void __launch_bounds__(256) k5_patches(const float *__restrict__ pts,
     }
 }
 
-// ---- conv1 + pool1 from bits on the matrix cores -----------------------------------------------------------------------
-// Cin = 1 and Cout = 8 would leave half of a 16-wide MFMA n-tile empty, so the n index carries the z parity as well:
-// n = dz * 8 + c computes channel c at z = 2 zm + dz, the m index runs over the 16 even z of a row, and k runs over
-// a 3 x 3 x 4 tap window (ka, kb, kc' = k % 4) with B[k][n] = w1[ka][kb][kc' - dz][c] (zero where kc' - dz is not a
-// tap).  K = 36: 9 MFMAs per 32-voxel row instead of 14.  Lane (m, kq) reads the voxel at padded z = 2 m + kq: a
-// ds_read_b32 spans 34 consecutive dwords.  A wave owns the 2 x 2 (x, y) rows of one pooled row (four independent
-// accumulators); MaxPool = register max over the four, then max with lane n ^ 8 (the other z parity).
+// (Round 1's f32-input MFMA kernels for the three conv layers -- k5_conv1pool, k5_conv_mfma: 1.95 ms per frame against 1.28 ms
+// for the split-operand kernels below, DESIGN.md 4.5 -- are gone from the library: one arithmetic, no environment switch.)
 typedef float c5_f32x4 __attribute__((ext_vector_type(4)));
-#define C1_PITCH 36  // floats per padded z row (34 used)
-#define C1_PLANE (34 * C1_PITCH)
-__global__ void __launch_bounds__(256) k5_conv1pool(const unsigned long long *__restrict__ bits, const float *__restrict__ w1,
-                                                    const float *__restrict__ b1, float *__restrict__ p1, int n_items) {
-    __shared__ float vox[4 * C1_PLANE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m = lane & 15, kq = lane >> 4;
-    const int dz = m >> 3, ch = m & 7;  // as the n index of B and C
-    float bf[9];
-#pragma unroll
-    for (int s = 0; s < 9; ++s) {
-        const int kc = kq - dz;  // k = 4 s + kq: (ka, kb) = (s / 3, s % 3), kc' = kq
-        bf[s] = (kc >= 0 && kc < 3) ? w1[(s * 3 + kc) * 8 + ch] : 0.0f;
-    }
-    const float bias = b1[ch];
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int64_t patch = item >> 4;
-        const int px = item & 15;
-        const uint32_t *src = (const uint32_t *)(bits + patch * 512);
-        __syncthreads();
-        // 4 planes x 34 rows of 36 floats: thread -> (row, third of the row)
-        for (int i = tid; i < 4 * 34 * 3; i += 256) {
-            const int row = i / 3, part = i % 3;
-            const int x = 2 * px - 1 + row / 34, y = row % 34 - 1;
-            const uint32_t word = (x >= 0 && x < 32 && y >= 0 && y < 32) ? src[x * 32 + y] : 0u;
-            float *dst = &vox[row * C1_PITCH + part * 12];
-#pragma unroll
-            for (int j = 0; j < 12; ++j) {
-                const int z = part * 12 + j - 1;  // padded index part*12 + j
-                dst[j] = (z >= 0 && z < 32) ? (float)((word >> z) & 1u) : 0.0f;
-            }
-        }
-        __syncthreads();
-        for (int pi = 0; pi < 4; ++pi) {
-            const int py = 4 * wave + pi;
-            // output (xa, y = 2 py + yb, z = 2 m + dz) reads padded (xa + ka, y + kb, 2 m + kq)
-            const float *a00 = &vox[(2 * py) * C1_PITCH + 2 * m + kq];
-            const float *a01 = a00 + C1_PITCH, *a10 = a00 + C1_PLANE, *a11 = a10 + C1_PITCH;
-            c5_f32x4 c00 = {bias, bias, bias, bias}, c01 = c00, c10 = c00, c11 = c00;
-#pragma unroll
-            for (int s = 0; s < 9; ++s) {
-                const int off = (s / 3) * C1_PLANE + (s % 3) * C1_PITCH;
-                c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a00[off], bf[s], c00, 0, 0, 0);
-                c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a01[off], bf[s], c01, 0, 0, 0);
-                c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a10[off], bf[s], c10, 0, 0, 0);
-                c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a11[off], bf[s], c11, 0, 0, 0);
-            }
-            // C row 4 kq + r = pooled z; column = (dz, c)
-            float *dst = p1 + ((((size_t)patch * 16 + px) * 16 + py) * 16 + 4 * kq) * 8 + ch;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = fmaxf(fmaxf(c00[r], c01[r]), fmaxf(c10[r], c11[r]));
-                v = fmaxf(v, __shfl_xor(v, 8));
-                if (dz == (r >> 1)) dst[r * 8] = c5_tanh(v);  // lanes dz = 0 store rows 0,1; dz = 1 rows 2,3
-            }
-        }
-    }
-}
-
-// ---- conv2 / conv3 as implicit GEMMs on the f32 matrix cores (v_mfma_f32_16x16x4_f32) ------------------------------
-// GEMM view: M = output positions, N = COUT, K = 27 taps x CIN (k = tap*CIN + c, the Keras weight order).
-// A workgroup (4 waves) owns XS output x planes of one patch.  Their XS + 2 input planes sit in LDS with a zero halo
-// in y and z, split into 4-channel quads: dword address = ((c >> 2) * NPOS + pos) * 4 + (c & 3).  An m-tile is 16
-// consecutive z (two 8-z rows when D = 8); lane (m, kq) of the A operand reads ONE dword per MFMA -- channel
-// 4*c4 + kq of position pos(m) + tap offset -- so the 64 lanes of a ds_read_b32 cover 64 consecutive dwords
-// (conflict-free; D = 8: two 32-dword runs), and every tap / quad offset is a compile-time constant that folds into
-// the instruction's offset field.  The whole B operand of the wave's n-tile (K/4 dwords per lane: 54 for conv2, 108
-// for conv3) stays in VGPRs across a persistent loop over work items.  Four independent accumulators per wave are
-// interleaved so that no MFMA waits for its predecessor:
-//   conv2 (POOL):  the 2 x 2 (x, y) m-tiles of one pooled row -- MaxPool is then a register max (z pairs are the
-//                  C rows 4g+{0,1} / 4g+{2,3} of a lane), tanh after the max (monotone);
-//   conv3:         four m-tiles of the wave's half of the XS * D / 2 tiles; waves 0,1 own output channels 0..15,
-//                  waves 2,3 own 16..31.
-
-template <int D, int CIN, int COUT, bool POOL>
-__global__ void __launch_bounds__(256, POOL ? 3 : 2) k5_conv_mfma(const float *__restrict__ in, const float *__restrict__ w,
-                                                    const float *__restrict__ b, float *__restrict__ out, int n_items) {
-    static_assert((POOL && D == 16 && COUT == 16) || (!POOL && D == 8 && COUT == 32), "conv2 or conv3 of the 32^3 encoder");
-    constexpr int XS = POOL ? 2 : 4, DP = D + 2, NPOS = (XS + 2) * DP * DP, C4 = CIN / 4, KS = 27 * CIN / 4, NXB = D / XS;
-    __shared__ __attribute__((aligned(16))) float tile[C4 * NPOS * 4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m = lane & 15, kq = lane >> 4;
-    const int nt = POOL ? 0 : wave >> 1;
-    float bf[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) bf[s] = w[(size_t)(4 * s + kq) * COUT + nt * 16 + m];
-    const float bias = b[nt * 16 + m];
-    // dword offset of (tap, channel quad) for k-step s
-#define C5_OFF(S) (((((S) / C4) / 9) * DP * DP + ((((S) / C4) / 3) % 3) * DP + (((S) / C4) % 3)) * 4 + ((S) % C4) * NPOS * 4)
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int64_t patch = item / NXB;
-        const int xb = item % NXB;
-        const float *src = in + (size_t)patch * D * D * D * CIN;
-        __syncthreads();  // the previous item's reads are done
-        for (int i = tid; i < NPOS * C4; i += 256) {
-            const int c4 = i % C4, pos = i / C4;
-            const int x = xb * XS - 1 + pos / (DP * DP), y = (pos / DP) % DP - 1, z = pos % DP - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (x >= 0 && x < D && y >= 0 && y < D && z >= 0 && z < D) v = ((const float4 *)(src + (((size_t)x * D + y) * D + z) * CIN))[c4];
-            ((float4 *)tile)[c4 * NPOS + pos] = v;
-        }
-        __syncthreads();
-        if (POOL) {
-            for (int pi = 0; pi < 2; ++pi) {
-                const int py = 2 * wave + pi;
-                // padded corner (x - 1, y - 1, z - 1) of output (xa, 2 py + yb, z = m)
-                const float *a00 = &tile[(((0 * DP) + 2 * py) * DP + m) * 4 + kq];
-                const float *a01 = a00 + DP * 4, *a10 = a00 + DP * DP * 4, *a11 = a10 + DP * 4;
-                c5_f32x4 c00 = {bias, bias, bias, bias}, c01 = c00, c10 = c00, c11 = c00;
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a00[C5_OFF(s)], bf[s], c00, 0, 0, 0);
-                    c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a01[C5_OFF(s)], bf[s], c01, 0, 0, 0);
-                    c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a10[C5_OFF(s)], bf[s], c10, 0, 0, 0);
-                    c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a11[C5_OFF(s)], bf[s], c11, 0, 0, 0);
-                }
-                float *dst = out + ((((size_t)patch * 8 + xb) * 8 + py) * 8 + 2 * kq) * COUT + m;
-#pragma unroll
-                for (int zp = 0; zp < 2; ++zp) {
-                    float v = fmaxf(fmaxf(c00[2 * zp], c00[2 * zp + 1]), fmaxf(c01[2 * zp], c01[2 * zp + 1]));
-                    v = fmaxf(v, fmaxf(fmaxf(c10[2 * zp], c10[2 * zp + 1]), fmaxf(c11[2 * zp], c11[2 * zp + 1])));
-                    dst[zp * COUT] = c5_tanh(v);
-                }
-            }
-        } else {
-            for (int round = 0; round < 2; ++round) {
-                // m-tiles mt = (wave & 1) * 8 + round * 4 + j, j = 0..3: output plane xl = mt / 4, rows 2 (mt % 4), +1
-                const int xl = (wave & 1) * 2 + round;
-                const float *a0 = &tile[(((xl * DP) + (m >> 3)) * DP + (m & 7)) * 4 + kq];
-                const float *a1 = a0 + 2 * DP * 4, *a2 = a0 + 4 * DP * 4, *a3 = a0 + 6 * DP * 4;
-                c5_f32x4 c0 = {bias, bias, bias, bias}, c1 = c0, c2 = c0, c3 = c0;
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[C5_OFF(s)], bf[s], c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[C5_OFF(s)], bf[s], c1, 0, 0, 0);
-                    c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[C5_OFF(s)], bf[s], c2, 0, 0, 0);
-                    c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[C5_OFF(s)], bf[s], c3, 0, 0, 0);
-                }
-                // C row 4 kq + r of tile j: position (y = 2 j + (row >> 3), z = row & 7)
-                float *dst = out + (((size_t)patch * 8 + xb * XS + xl) * 64) * COUT + nt * 16 + m;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * kq + r, yz = (row >> 3) * 8 + (row & 7);
-                    dst[(size_t)(0 * 16 + yz) * COUT] = c5_tanh(c0[r]);
-                    dst[(size_t)(1 * 16 + yz) * COUT] = c5_tanh(c1[r]);
-                    dst[(size_t)(2 * 16 + yz) * COUT] = c5_tanh(c2[r]);
-                    dst[(size_t)(3 * 16 + yz) * COUT] = c5_tanh(c3[r]);
-                }
-            }
-        }
-    }
-#undef C5_OFF
-}
-
 // ---- conv3 with f32 products evaluated on the bf16 matrix pipe (3-way operand split) ------------------------------------
 // v_mfma_f32_16x16x32_bf16 retires 16x the FLOPs per cycle of the f32-input MFMA.  An f32 value splits exactly into
 // three bf16 terms, x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (both differences
@@ -606,25 +447,18 @@ static int encode32_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, 
     float *part = f3 + np * 16384;
     if (np > n_patches) CAELO_HIP(hipMemsetAsync(f3 + n_patches * 16384, 0, (size_t)(np - n_patches) * 16384 * sizeof(float), s));
     const int items1 = (int)(n_patches * 16);
-    static const bool x3 = !(getenv("CAELO_C5_F32") && atoi(getenv("CAELO_C5_F32")));
     if (ev) CAELO_HIP(hipEventRecord(ev[0], s));
-    if (x3) k5_conv1pool_x3<<<items1 < 1024 ? items1 : 1024, 256, 0, s>>>((const unsigned long long *)bits, c->enc_w1, c->enc_b1, p1, items1);
-    else k5_conv1pool<<<items1 < 1024 ? items1 : 1024, 256, 0, s>>>((const unsigned long long *)bits, c->enc_w1, c->enc_b1, p1, items1);
+    k5_conv1pool_x3<<<items1 < 1024 ? items1 : 1024, 256, 0, s>>>((const unsigned long long *)bits, c->enc_w1, c->enc_b1, p1, items1);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[1], s));
     // persistent grids: the B operand (conv weights) is loaded into registers once per workgroup
     const int items2 = (int)(n_patches * 8), items3 = (int)(n_patches * 2);
-    if (x3) {
-        // (per call, i.e. for whichever device is current: this path is not a hot one)
-        CAELO_HIP(hipFuncSetAttribute((const void *)k5_conv2_x3, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X2_ARR));
-        k5_conv2_x3<<<items2 < 512 ? items2 : 512, 256, 3 * X2_ARR, s>>>(p1, c->enc_w2, c->enc_b2, p2, items2);
-    } else {
-        k5_conv_mfma<16, 8, 16, true><<<items2 < 768 ? items2 : 768, 256, 0, s>>>(p1, c->enc_w2, c->enc_b2, p2, items2);
-    }
+    // (per call, i.e. for whichever device is current: this path is not a hot one)
+    CAELO_HIP(hipFuncSetAttribute((const void *)k5_conv2_x3, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X2_ARR));
+    k5_conv2_x3<<<items2 < 512 ? items2 : 512, 256, 3 * X2_ARR, s>>>(p1, c->enc_w2, c->enc_b2, p2, items2);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[2], s));
-    if (x3) k5_conv3_x3<<<items3 < 512 ? items3 : 512, 256, 6 * X3_ARR, s>>>(p2, c->enc_w3, c->enc_b3, f3, items3);
-    else k5_conv_mfma<8, 16, 32, false><<<items3 < 512 ? items3 : 512, 256, 0, s>>>(p2, c->enc_w3, c->enc_b3, f3, items3);
+    k5_conv3_x3<<<items3 < 512 ? items3 : 512, 256, 6 * X3_ARR, s>>>(p2, c->enc_w3, c->enc_b3, f3, items3);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[3], s));
     const int rc = enc_dense32_head_launch(c, f3, n_patches, np, part, group, out, out_stride, s);

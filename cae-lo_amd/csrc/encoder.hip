@@ -28,6 +28,7 @@
 #include <math.h>
 
 #include "caelo_internal.h"
+#include <vector>
 #include <stdlib.h>
 #include <string.h>
 
@@ -88,23 +89,21 @@ CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const flo
     }
     {
         const size_t n1 = 16 * 64, n2 = 27 * 64;  // S1X_W1F_U4, S1X_W2X_U4
-        uint4 *wx = (uint4 *)malloc((n1 + n2) * sizeof(uint4));
-        if (!wx) { caelo_set_error("out of host memory"); return CAELO_ERR_ARG; }
+        std::vector<uint4> wxv(n1 + n2);   // (a vector: an early return of CAELO_HIP must not leak the staging buffer)
+        uint4 *wx = wxv.data();
         stage1x_split_weights(w1, w2, wx, wx + n1);
         if (!c->enc_w1f) CAELO_HIP(hipMalloc(&c->enc_w1f, n1 * sizeof(uint4)));
         if (!c->enc_w2x) CAELO_HIP(hipMalloc(&c->enc_w2x, n2 * sizeof(uint4)));
         CAELO_HIP(hipMemcpy(c->enc_w1f, wx, n1 * sizeof(uint4), hipMemcpyHostToDevice));
         CAELO_HIP(hipMemcpy(c->enc_w2x, wx + n1, n2 * sizeof(uint4), hipMemcpyHostToDevice));
-        free(wx);
     }
     {
         const size_t n = (size_t)2 * C3X_NPAIR * 3 * 64;   // (room for three terms; the f16 form fills two)
-        uint4 *wx = (uint4 *)malloc(n * sizeof(uint4));
-        if (!wx) { caelo_set_error("out of host memory"); return CAELO_ERR_ARG; }
+        std::vector<uint4> wxv(n);
+        uint4 *wx = wxv.data();
         conv3_split_weights(w3, wx);
         if (!c->enc_w3x) CAELO_HIP(hipMalloc(&c->enc_w3x, n * sizeof(uint4)));
         CAELO_HIP(hipMemcpy(c->enc_w3x, wx, n * sizeof(uint4), hipMemcpyHostToDevice));
-        free(wx);
     }
     {
         const int rc = enc_upload_dense1(wd1, bd1, DENSE_K, &c->enc_wd1x, &c->enc_bd1);
@@ -112,12 +111,11 @@ CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const flo
     }
     {
         const size_t n = (size_t)HEAD_WQ_FLOATS;
-        float *wq = (float *)malloc(n * sizeof(float));
-        if (!wq) { caelo_set_error("out of host memory"); return CAELO_ERR_ARG; }
+        std::vector<float> wqv(n);
+        float *wq = wqv.data();
         head_weight_fragments(wd2, wq);
         if (!c->enc_wd2q) CAELO_HIP(hipMalloc(&c->enc_wd2q, n * sizeof(float)));
         CAELO_HIP(hipMemcpy(c->enc_wd2q, wq, n * sizeof(float), hipMemcpyHostToDevice));
-        free(wq);
     }
     c->has_enc = true;
     return CAELO_OK;
@@ -514,698 +512,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
 
 #include "enc_stage1x.inc"
 
-// ------------------------------------------------------------------------------------------------
-// stage 1, one WAVEFRONT per patch (round 2, CAELO_ENC_WAVE=1; not the default): no workgroup barrier after start-up
-// ------------------------------------------------------------------------------------------------
-// k_enc_stage1 above shares a patch among the 4 wavefronts of a workgroup: five workgroup barriers per patch, the non-
-// background cells of a patch cluster so that one or two wavefronts carry most of its MFMAs while the others wait, and
-// the matrix pipe is busy 26 % of the time.  Here a wavefront owns a patch from its bits to its P2 rows, so wavefronts
-// never wait for each other and the SIMD interleaves the conv1 VALU work of one with the conv2 MFMAs of another.
-// What made this impossible before was LDS: the dense D grid of a patch is 26 KB (one wavefront per SIMD).  conv2's
-// output x pair xp only needs the four input x planes 2xp-1 .. 2xp+2, and the cell list is sorted by x: D lives in a
-// RING of four x planes (10 KB), conv1 fills it plane by plane and conv2 follows two planes behind:
-//     planes 0,1,2 -> conv2(x pair 0) -> planes 3,4 -> conv2(1) -> 5,6 -> conv2(2) -> 7 -> conv2(3)
-// A plane's cells are wiped from their list segment before the slot is reused.  Same sums in the same order as
-// k_enc_stage1 (same CONV2 tile code, same skipping rule): P2 is bit-identical.  The C0 accumulator fragments of all 16
-// tile pairs stay in registers as 9 border classes (see below); nothing in the patch loop reads global memory except
-// the next patch's bits.
-// Work items: per-XCD queues (item j belongs to XCD j % 8; a wavefront's first item is static, further ones come from
-// its XCD's counter): one same-address device atomic costs ~12 ns, 3 072 per frame on ONE counter would be a 37 us floor.
-#define S1W_WAVES 4
-#define S1W_RING_CELLS (4 * 80)                          // 4 x-plane slots of 10 (y, halo) x 8 (z) cells
-#define S1W_PLANE ((S1W_RING_CELLS + 2 * P1_FRONT) * 4)  // floats of one 4-channel half
-#define S1W_CSTRIDE 32                                   // ints between two XCD counters (one 128-byte line each)
-struct Stage1wWave {
-    float ring[2 * S1W_PLANE];
-    unsigned long long mask[512];
-    unsigned short list[512];
-    unsigned int nz[12];         // padded x plane 0..9: bit yp set when some cell (x, yp, *) is non-background
-    unsigned short pstart[12];   // list segment of x plane px = [pstart[px], pstart[px + 1])
-};
-struct Stage1wLds {
-    float w1[27 * 8];
-    float b1[8];
-    float bg[8];
-    Stage1wWave w[S1W_WAVES];
-};
-
-// 3 taps of one m-tile from the x plane AP points into (tap plane KA, tap row KB): 6 MFMAs on two interleaved accumulators
-#define CONV2W_ROW(ACC_A, ACC_B, AP, KA, KB)                                                       \
-    _Pragma("unroll") for (int kc = 0; kc < 3; ++kc) {                                             \
-        const int t = (KA) * 9 + (KB) * 3 + kc;                                                     \
-        float2 av = *(const float2 *)((AP) + ((KB) * 8 + (kc - 1)) * 4);                            \
-        if (kc == 0) { if (!zlo) av = make_float2(0.f, 0.f); }                                      \
-        if (kc == 2) { if (!zhi) av = make_float2(0.f, 0.f); }                                      \
-        ACC_A = MFMA16(av.x, breg[t][0], ACC_A);                                                    \
-        ACC_B = MFMA16(av.y, breg[t][1], ACC_B);                                                    \
-    }
-#define CONV2W_TILE(ACC_A, ACC_B, AP0, AP1, AP2, NZ0, NZ1, NZ2)                                     \
-    if ((NZ0) & 0x3u) { CONV2W_ROW(ACC_A, ACC_B, AP0, 0, 0) }                                       \
-    if ((NZ0) & 0x6u) { CONV2W_ROW(ACC_A, ACC_B, AP0, 0, 1) }                                       \
-    if ((NZ0) & 0xCu) { CONV2W_ROW(ACC_A, ACC_B, AP0, 0, 2) }                                       \
-    if ((NZ1) & 0x3u) { CONV2W_ROW(ACC_A, ACC_B, AP1, 1, 0) }                                       \
-    if ((NZ1) & 0x6u) { CONV2W_ROW(ACC_A, ACC_B, AP1, 1, 1) }                                       \
-    if ((NZ1) & 0xCu) { CONV2W_ROW(ACC_A, ACC_B, AP1, 1, 2) }                                       \
-    if ((NZ2) & 0x3u) { CONV2W_ROW(ACC_A, ACC_B, AP2, 2, 0) }                                       \
-    if ((NZ2) & 0x6u) { CONV2W_ROW(ACC_A, ACC_B, AP2, 2, 1) }                                       \
-    if ((NZ2) & 0xCu) { CONV2W_ROW(ACC_A, ACC_B, AP2, 2, 2) }
-
-#define S1W_WAVE_SYNC()                                        \
-    do {                                                       \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                       \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
-    } while (0)
-
-__global__ void __launch_bounds__(64 * S1W_WAVES, 2) k_enc_stage1w(const caelo_enc_in in, int64_t n_patches, int group,
-                                                                 int *__restrict__ counters, const float *__restrict__ w1g,
-                                                                 const float *__restrict__ b1g, const float *__restrict__ w2g,
-                                                                 const float *__restrict__ c0g, float *__restrict__ p2out) {
-    __shared__ __attribute__((aligned(16))) Stage1wLds L;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4;   // MFMA k-group
-    const int n = lane & 15;   // MFMA column (output channel) for B/C, row for A
-    // ---- one-time: weights.  B fragment for k-step (tap t, h): W2[t][cin = 2g + h][n]
-    float breg[27][2];
-#pragma unroll
-    for (int t = 0; t < 27; ++t) {
-        breg[t][0] = w2g[(t * 8 + 2 * g) * 16 + n];
-        breg[t][1] = w2g[(t * 8 + 2 * g + 1) * 16 + n];
-    }
-    // C0 = b2 + conv2(BG) accumulator fragments.  A wavefront owns all 16 tile pairs of a patch (128 registers of C0), but C0
-    // only depends on which borders a position touches: x in {0, interior, 7}, y likewise (z is fixed per lane), and the
-    // host builds the table with one loop order, so equal border patterns hold equal floats.  9 fragments cover every tile:
-    // c0cls[xc][yc], xc = 0 / 1 / 2 for x = 0 / 1..6 / 7, yc = 0 / 1 / 2 for the row pairs yi = 0 / 1,2 / 3; bgcls = the
-    // outputs tanh(pool2(C0)) of a pair that sees nothing but background, by (x pair 0 / 1,2 / 3, yc).
-    f32x4 c0cls[3][3];
-    float bgcls[3][3][2];
-#pragma unroll
-    for (int xc = 0; xc < 3; ++xc)
-#pragma unroll
-        for (int yc = 0; yc < 3; ++yc) {
-            const int x = xc == 0 ? 0 : (xc == 1 ? 2 : 7), y = (yc == 0 ? 0 : (yc == 1 ? 2 : 6)) + (g >> 1);
-            const float *c0a = c0g + (size_t)(((x * 8 + y) * 8 + 4 * (g & 1)) * 16 + n);
-            c0cls[xc][yc] = (f32x4){c0a[0], c0a[16], c0a[32], c0a[48]};
-        }
-#pragma unroll
-    for (int pc = 0; pc < 3; ++pc)
-#pragma unroll
-        for (int yc = 0; yc < 3; ++yc) {
-            const f32x4 f0 = c0cls[pc == 0 ? 0 : 1][yc], f1 = c0cls[pc == 2 ? 2 : 1][yc];
-            float v0 = fmaxf(fmaxf(f0[0], f0[1]), fmaxf(f1[0], f1[1]));
-            float v1 = fmaxf(fmaxf(f0[2], f0[3]), fmaxf(f1[2], f1[3]));
-            v0 = fmaxf(v0, __shfl_xor(v0, 32));
-            v1 = fmaxf(v1, __shfl_xor(v1, 32));
-            bgcls[pc][yc][0] = enc_tanh(v0);
-            bgcls[pc][yc][1] = enc_tanh(v1);
-        }
-    for (int i = tid; i < 27 * 8; i += 64 * S1W_WAVES) L.w1[i] = w1g[i];
-    if (tid < 8) { L.b1[tid] = b1g[tid]; L.bg[tid] = c0g[512 * 16 + tid]; }  // bg = tanh(b1), from the host table
-    Stage1wWave &W = L.w[wave];
-    for (int i = lane; i < 2 * S1W_PLANE; i += 64) W.ring[i] = 0.0f;  // D == 0: halo, pads, background cells
-#pragma unroll
-    for (int q = 0; q < 8; ++q) W.mask[lane + 64 * q] = 0ull;
-    if (lane < 12) { W.nz[lane] = 0u; W.pstart[lane] = 0; }
-    __syncthreads();  // the only workgroup barrier: from here on every wavefront is on its own
-    const int n_items = enc_items_total(in, n_patches);
-    const int nk = (int)(n_patches / group);
-    // ---- this XCD's queue: items xcd, xcd + 8, ...; the first one per wavefront is static
-    const int xcd = blockIdx.x & 7;
-    const int wg_of_xcd = ((int)gridDim.x - xcd + 7) >> 3;
-    const int first_dyn = wg_of_xcd * S1W_WAVES;  // queue position the counter starts handing out
-    int *ctr = counters + xcd * S1W_CSTRIDE;
-    int J = xcd + 8 * ((int)(blockIdx.x >> 3) * S1W_WAVES + wave);
-    // lane l holds the 16-voxel rows l, l + 64, l + 128, l + 192 of the patch (row r: ix = r >> 4, iy = r & 15, bit = iz)
-    unsigned int rows[4] = {0u, 0u, 0u, 0u};
-    int patch = 0;
-    if (J < n_items) {
-        const unsigned long long *src;
-        enc_item(in, J, nk, group, src, patch);
-        patch = __builtin_amdgcn_readfirstlane(patch);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rows[q] = ((const unsigned short *)src)[lane + 64 * q];
-    }
-    const int yl = n >> 3, z = n & 7;  // A row m = yl*8 + z
-    const bool zlo = z >= 1, zhi = z <= 6;
-    int Jn = n_items;  // the item after J
-    if (J < n_items) {
-        int v = 0;
-        if (lane == 0) v = atomicAdd(ctr, 1);
-        Jn = xcd + 8 * (first_dyn + __builtin_amdgcn_readfirstlane(v));
-    }
-#ifdef CAELO_ENC_PROF
-    unsigned int pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned int pt = (unsigned)wall_clock64();
-#define S1W_STAMP(i) do { const unsigned t_ = (unsigned)wall_clock64(); pf[i] += t_ - pt; pt = t_; } while (0)
-#else
-#define S1W_STAMP(i) do { } while (0)
-#endif
-    while (J < n_items) {
-        S1W_STAMP(7);
-        // ---- scatter every set voxel into the receptive-field masks of the (up to 8) pooled cells that see it
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned int bits16 = rows[q];
-            if (bits16 == 0u) continue;
-            const int r = lane + 64 * q;
-            const int x = r >> 4, y = r & 15;
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                const int px = ((x + 1) >> 1) - dx;
-                if (px < 0 || px > 7) continue;
-                const int a = x + 1 - 2 * px;  // x = 2px - 1 + a
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy) {
-                    const int py = ((y + 1) >> 1) - dy;
-                    if (py < 0 || py > 7) continue;
-                    const int b = y + 1 - 2 * py;
-#pragma unroll
-                    for (int pz = 0; pz < 8; ++pz) {
-                        const unsigned int nib = ((bits16 << 1) >> (2 * pz)) & 0xFu;  // z = 2pz-1 .. 2pz+2
-                        if (nib != 0u) atomicOr(&W.mask[(px * 8 + py) * 8 + pz], (unsigned long long)nib << (a * 16 + b * 4));
-                    }
-                }
-            }
-        }
-        // ---- prefetch, two deep: the rows of the NEXT item (its index arrived during the previous patch) and the index of the
-        // one after (one returning atomic on this XCD's counter).  Both are consumed before the last conv2 block below, a
-        // whole patch later: nothing here waits for memory.
-        unsigned int rows_next[4] = {0u, 0u, 0u, 0u};
-        int patch_next = 0;
-        if (Jn < n_items) {
-            const unsigned long long *src;
-            enc_item(in, Jn, nk, group, src, patch_next);
-            patch_next = __builtin_amdgcn_readfirstlane(patch_next);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) rows_next[q] = ((const unsigned short *)src)[lane + 64 * q];
-        }
-        int fetched = 0;
-        if (lane == 0) fetched = atomicAdd(ctr, 1);
-        S1W_WAVE_SYNC();
-        S1W_STAMP(0);
-        // ---- the cells with a non-empty mask in ascending cell order = x plane by x plane (64 cells each)
-        int nlist = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int cell = lane + 64 * q;
-            const bool hit = W.mask[cell] != 0ull;
-            const unsigned long long bal = __ballot(hit);
-            if (hit) W.list[nlist + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)cell;
-            // byte py of the ballot = the 8 z cells of row (q, py): non-empty rows -> bit py + 1 of the padded plane q + 1
-            unsigned long long m = bal;
-            m |= m >> 4; m |= m >> 2; m |= m >> 1;
-            m &= 0x0101010101010101ull;
-            const unsigned int nzb = (unsigned int)((m * 0x0102040810204080ull) >> 56) << 1;
-            if (lane == 0) { W.pstart[q] = (unsigned short)nlist; W.nz[q + 1] = nzb; }
-            nlist += __popcll(bal);
-        }
-        if (lane == 0) W.pstart[8] = (unsigned short)nlist;
-        S1W_WAVE_SYNC();
-        S1W_STAMP(1);
-        // ---- x plane by x plane: conv1 + pool1 + tanh into the ring, conv2 two planes behind
-#pragma unroll 1
-        for (int px = 0; px < 8; ++px) {
-            if (px >= 4) {  // the slot's previous tenant (plane px - 4): wipe its cells
-                const int s0 = W.pstart[px - 4], s1 = W.pstart[px - 3];
-                const int slot = (px + 1) & 3;
-                for (int i = lane; i < 2 * (s1 - s0); i += 64) {
-                    const int cell = W.list[s0 + (i >> 1)];
-                    const int q = (slot * 10 + ((cell >> 3) & 7) + 1) * 8 + (cell & 7);
-                    *(float4 *)&W.ring[(i & 1) * S1W_PLANE + (P1_FRONT + q) * 4] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-                S1W_WAVE_SYNC();
-            }
-            S1W_STAMP(4);
-            {
-                const int s0 = __builtin_amdgcn_readfirstlane((int)W.pstart[px]), s1 = __builtin_amdgcn_readfirstlane((int)W.pstart[px + 1]);
-                const int slot = (px + 1) & 3;
-                for (int base = s0; base < s1; base += 8) {  // 8 lanes = the 8 positions of a pooling block
-                    const int item = base + (lane >> 3);
-                    const int sub = lane & 7;
-                    float acc[8];
-                    int cell = 0;
-                    if (item < s1) {
-                        cell = W.list[item];
-                        const unsigned long long mask = W.mask[cell];
-                        const int sa = sub >> 2, sb = (sub >> 1) & 1, sc = sub & 1;
-                        unsigned int taps = 0;  // bit (ka*3+kb)*3+kc
-#pragma unroll
-                        for (int ka = 0; ka < 3; ++ka)
-#pragma unroll
-                            for (int kb = 0; kb < 3; ++kb)
-                                taps |= ((unsigned int)(mask >> ((sa + ka) * 16 + (sb + kb) * 4 + sc)) & 7u) << ((ka * 3 + kb) * 3);
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) acc[c] = L.b1[c];
-                        while (taps) {  // ascending tap order == the oracle's (kx,ky,kz) order
-                            const int t = __ffs((int)taps) - 1;
-                            taps &= taps - 1;
-                            const float4 wa = *(const float4 *)&L.w1[t * 8], wb = *(const float4 *)&L.w1[t * 8 + 4];
-                            acc[0] += wa.x; acc[1] += wa.y; acc[2] += wa.z; acc[3] += wa.w;
-                            acc[4] += wb.x; acc[5] += wb.y; acc[6] += wb.z; acc[7] += wb.w;
-                        }
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) acc[c] = -3.0e38f;
-                    }
-                    // max over the pooling block = 8 aligned lanes (tanh is monotone: pool the pre-activations)
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        acc[c] = fmaxf(acc[c], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[c]), 0xB1, 0xF, 0xF, true)));
-                        acc[c] = fmaxf(acc[c], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[c]), 0x4E, 0xF, 0xF, true)));
-                        acc[c] = fmaxf(acc[c], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[c]), 0x141, 0xF, 0xF, true)));
-                    }
-                    if (item < s1) {
-                        float mine = acc[0];  // lane `sub` finishes channel `sub`
-#pragma unroll
-                        for (int c = 1; c < 8; ++c) mine = (sub == c) ? acc[c] : mine;
-                        const int q = (slot * 10 + ((cell >> 3) & 7) + 1) * 8 + (cell & 7);
-                        W.ring[(sub >> 2) * S1W_PLANE + (P1_FRONT + q) * 4 + (sub & 3)] = enc_tanh(mine) - L.bg[sub];
-                    }
-                }
-            }
-            S1W_STAMP(2);
-            if (!(px == 2 || px == 4 || px == 6 || px == 7)) continue;
-            if (px == 7) {  // the prefetches of this patch: waited for HERE, before the last P2 stores are in flight
-                asm volatile("" :: "v"(rows_next[0]), "v"(rows_next[1]), "v"(rows_next[2]), "v"(rows_next[3]), "v"(fetched));
-            }
-            S1W_WAVE_SYNC();
-            // ---- conv2 (8->16) on MFMA for the output x pair xp: input planes (padded) 2xp .. 2xp+3
-            const int xp = px == 7 ? 3 : (px >> 1) - 1;
-            const unsigned int nz0 = (unsigned)__builtin_amdgcn_readfirstlane((int)W.nz[2 * xp]);
-            const unsigned int nz1 = (unsigned)__builtin_amdgcn_readfirstlane((int)W.nz[2 * xp + 1]);
-            const unsigned int nz2 = (unsigned)__builtin_amdgcn_readfirstlane((int)W.nz[2 * xp + 2]);
-            const unsigned int nz3 = (unsigned)__builtin_amdgcn_readfirstlane((int)W.nz[2 * xp + 3]);
-            const float *plane = W.ring + (g >> 1) * S1W_PLANE + 2 * (g & 1) + (P1_FRONT + yl * 8 + z) * 4;
-            const float *pl0 = plane + (((2 * xp) & 3) * 80) * 4, *pl1 = plane + (((2 * xp + 1) & 3) * 80) * 4;
-            const float *pl2 = plane + (((2 * xp + 2) & 3) * 80) * 4, *pl3 = plane + (((2 * xp + 3) & 3) * 80) * 4;
-            const bool x_lo = xp == 0, x_hi = xp == 3;  // wave-uniform
-#pragma unroll
-            for (int yi = 0; yi < 4; ++yi) {
-                const int y0 = 2 * yi;
-                const int yc = yi == 0 ? 0 : (yi == 3 ? 2 : 1);
-                const unsigned int r0 = (nz0 >> y0) & 0xFu, r1 = (nz1 >> y0) & 0xFu, r2 = (nz2 >> y0) & 0xFu, r3 = (nz3 >> y0) & 0xFu;
-                const int pair = xp * 4 + yi;
-                // C column = n (channel), rows 4g..4g+3 -> z = 4*(g&1)+r ; pooled cell (xp, yi, 2*(g&1)+{0,1})
-                float *dst = p2out + (size_t)patch * 1024 + (size_t)((pair * 4 + 2 * (g & 1)) * 16 + n);
-                if ((r0 | r1 | r2 | r3) == 0u) {  // nothing but background feeds this pair: per-model constants
-                    if (g < 2) {
-                        dst[0] = x_lo ? bgcls[0][yc][0] : (x_hi ? bgcls[2][yc][0] : bgcls[1][yc][0]);
-                        dst[16] = x_lo ? bgcls[0][yc][1] : (x_hi ? bgcls[2][yc][1] : bgcls[1][yc][1]);
-                    }
-                    continue;
-                }
-                // accumulators start from C0 = b2 + conv2(BG); two per tile to keep the MFMA chains independent
-                f32x4 acc0, acc1;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    acc0[r] = x_lo ? c0cls[0][yc][r] : c0cls[1][yc][r];
-                    acc1[r] = x_hi ? c0cls[2][yc][r] : c0cls[1][yc][r];
-                }
-                f32x4 acc0b = {0.f, 0.f, 0.f, 0.f}, acc1b = {0.f, 0.f, 0.f, 0.f};
-                const float *a0 = pl0 + y0 * 32, *a1 = pl1 + y0 * 32, *a2 = pl2 + y0 * 32, *a3 = pl3 + y0 * 32;
-                CONV2W_TILE(acc0, acc0b, a0, a1, a2, r0, r1, r2)
-                CONV2W_TILE(acc1, acc1b, a1, a2, a3, r1, r2, r3)
-                acc0 += acc0b;
-                acc1 += acc1b;
-                // ---- pool2: x pair in registers, z pairs in registers, y pair across lanes g <-> g^2
-                float v0 = fmaxf(fmaxf(acc0[0], acc0[1]), fmaxf(acc1[0], acc1[1]));  // pz = 2*(g&1)
-                float v1 = fmaxf(fmaxf(acc0[2], acc0[3]), fmaxf(acc1[2], acc1[3]));  // pz = 2*(g&1)+1
-                v0 = fmaxf(v0, __shfl_xor(v0, 32));
-                v1 = fmaxf(v1, __shfl_xor(v1, 32));
-                if (g < 2) {
-                    dst[0] = enc_tanh(v0);
-                    dst[16] = enc_tanh(v1);
-                }
-            }
-            S1W_STAMP(3);
-        }
-        S1W_STAMP(3);
-        S1W_WAVE_SYNC();
-        // ---- back to D == 0 and empty masks for the next patch (planes 0..3 were wiped when their slots were reused;
-        // wiping their positions again is harmless)
-        for (int i = lane; i < nlist; i += 64) {
-            const int cell = W.list[i];
-            const int q = ((((cell >> 6) + 1) & 3) * 10 + ((cell >> 3) & 7) + 1) * 8 + (cell & 7);
-            *(float4 *)&W.ring[(P1_FRONT + q) * 4] = make_float4(0.f, 0.f, 0.f, 0.f);
-            *(float4 *)&W.ring[S1W_PLANE + (P1_FRONT + q) * 4] = make_float4(0.f, 0.f, 0.f, 0.f);
-            W.mask[cell] = 0ull;
-        }
-        S1W_WAVE_SYNC();
-        S1W_STAMP(4);
-#ifdef CAELO_ENC_PROF
-        pf[5] += 1; pf[6] += (unsigned)nlist;
-#endif
-        J = Jn;
-        Jn = xcd + 8 * (first_dyn + __builtin_amdgcn_readfirstlane(fetched));
-        patch = patch_next;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rows[q] = rows_next[q];
-    }
-#ifdef CAELO_ENC_PROF
-    if (lane == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_enc_stamp[i], (unsigned long long)pf[i]);
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------
-// stage 1 in two kernels (round 2): k_enc_conv1 (sparse conv1 + pool1, one WAVEFRONT per patch) -> k_enc_conv2
-// ------------------------------------------------------------------------------------------------
-// k_enc_stage1 above interleaves, per patch and per 4-wave workgroup, three short VALU / LDS phases (mask scatter,
-// cell queue, conv1) with the conv2 MFMA phase: five workgroup barriers per patch, the matrix pipe busy 26 % of the
-// time.  The split gives each part the shape it wants:
-//   * k_enc_conv1: the conv1 work is proportional to the set voxels (2 / 54 / 67 of 4096) and independent per patch:
-//     one wavefront per patch, 5 KB of LDS each, wave barriers only, many wavefronts per SIMD.  Output = the patch's
-//     non-background cells as a list (cell index ascending, D = tanh(pool(conv1)) - tanh(b1), 8 channels).
-//   * k_enc_conv2: persistent workgroups; per patch ONE workgroup barrier: the list is scattered into one of two D
-//     planes in LDS while the MFMAs of the previous patch read the other (each wavefront owns a quarter of the plane,
-//     so un-scattering the patch before last and scattering the next one need no barrier in between).
-// Arithmetic is unchanged (same sums in the same order as k_enc_stage1), so the two paths are bit-identical.
-#define DL_MAX 512  // a patch has 512 pooled cells: 4 quarters (cell >> 7 = x plane pair) of 128
-#define DL_Q 128
-struct EncLists {
-    int32_t *count;        // [rows][4]: entries per quarter
-    unsigned short *cell;  // [rows][4][DL_Q], ascending inside a quarter
-    float *val;            // [rows][4][DL_Q][8]
-};
-
-__global__ void __launch_bounds__(256) k_enc_conv1(const caelo_enc_in in, int64_t n_patches, int group, const float *__restrict__ w1g,
-                                                   const float *__restrict__ b1g, const float *__restrict__ c0g, EncLists dl,
-                                                   unsigned long long *mfma_count) {
-    __shared__ float s_w1[27 * 8];
-    __shared__ float s_b1[8], s_bg[8];
-    __shared__ unsigned long long s_mask[4][512];
-    __shared__ unsigned short s_list[4][512];
-    __shared__ unsigned char s_qpos[4][512];  // position of the entry inside its quarter (< 128)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (mfma_count && blockIdx.x == 0 && tid == 0) *mfma_count = 0ull;  // k_enc_conv2 (next on the stream) adds to it
-    for (int i = tid; i < 27 * 8; i += 256) s_w1[i] = w1g[i];
-    if (tid < 8) { s_b1[tid] = b1g[tid]; s_bg[tid] = c0g[512 * 16 + tid]; }
-    unsigned long long *cm = s_mask[wave];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) cm[lane + 64 * q] = 0ull;
-    __syncthreads();
-    const int n_items = enc_items_total(in, n_patches);
-    const int nk = (int)(n_patches / group);
-    const int J = blockIdx.x * 4 + wave;  // wave-uniform
-    if (J >= n_items) return;
-    const unsigned long long *src;
-    int row;
-    enc_item(in, J, nk, group, src, row);
-    row = __builtin_amdgcn_readfirstlane(row);
-    // ---- scatter every set voxel into the receptive-field masks of the (up to 8) pooled cells that see it; lane l
-    // holds the 16-voxel rows l, l + 64, l + 128, l + 192 of the patch (row r: ix = r >> 4, iy = r & 15, bit = iz)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = lane + 64 * q;
-        const unsigned int bits16 = ((const unsigned short *)src)[r];
-        if (bits16 == 0u) continue;
-        const int x = r >> 4, y = r & 15;
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            const int px = ((x + 1) >> 1) - dx;
-            if (px < 0 || px > 7) continue;
-            const int a = x + 1 - 2 * px;  // x = 2px - 1 + a
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy) {
-                const int py = ((y + 1) >> 1) - dy;
-                if (py < 0 || py > 7) continue;
-                const int b = y + 1 - 2 * py;
-#pragma unroll
-                for (int pz = 0; pz < 8; ++pz) {
-                    const unsigned int nib = ((bits16 << 1) >> (2 * pz)) & 0xFu;  // z = 2pz-1 .. 2pz+2
-                    if (nib != 0u) atomicOr(&cm[(px * 8 + py) * 8 + pz], (unsigned long long)nib << (a * 16 + b * 4));
-                }
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- the cells with a non-empty mask, in ascending cell order; s_list holds (quarter-local position << 9 | cell)
-    // in global list order, qcnt[k] = entries of quarter k (quarter = cell >> 7 = two 64-cell chunks)
-    int nlist = 0, qcnt[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int cell = lane + 64 * q;
-        const bool hit = cm[cell] != 0ull;
-        const unsigned long long bal = __ballot(hit);
-        const int below = __popcll(bal & ((1ull << lane) - 1ull));
-        if (hit) s_list[wave][nlist + below] = (unsigned short)cell;
-        if (hit) s_qpos[wave][nlist + below] = (unsigned char)(qcnt[q >> 1] + below);
-        nlist += __popcll(bal);
-        qcnt[q >> 1] += __popcll(bal);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- conv1 + pool1 + tanh on the queued cells; 8 lanes = the 8 positions of a pooling block (as in k_enc_stage1)
-    unsigned short *ocell = dl.cell + (size_t)row * DL_MAX;
-    float *oval = dl.val + (size_t)row * DL_MAX * 8;
-    for (int base = 0; base < nlist; base += 8) {
-        const int item = base + (lane >> 3);
-        const int sub = lane & 7;
-        float acc[8];
-        int cell = 0;
-        if (item < nlist) {
-            cell = s_list[wave][item];
-            const unsigned long long mask = cm[cell];
-            const int sa = sub >> 2, sb = (sub >> 1) & 1, sc = sub & 1;
-            unsigned int taps = 0;  // bit (ka*3+kb)*3+kc
-#pragma unroll
-            for (int ka = 0; ka < 3; ++ka)
-#pragma unroll
-                for (int kb = 0; kb < 3; ++kb)
-                    taps |= ((unsigned int)(mask >> ((sa + ka) * 16 + (sb + kb) * 4 + sc)) & 7u) << ((ka * 3 + kb) * 3);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) acc[c] = s_b1[c];
-            while (taps) {  // ascending tap order == the oracle's (kx,ky,kz) order
-                const int t = __ffs((int)taps) - 1;
-                taps &= taps - 1;
-                const float4 wa = *(const float4 *)&s_w1[t * 8], wb = *(const float4 *)&s_w1[t * 8 + 4];
-                acc[0] += wa.x; acc[1] += wa.y; acc[2] += wa.z; acc[3] += wa.w;
-                acc[4] += wb.x; acc[5] += wb.y; acc[6] += wb.z; acc[7] += wb.w;
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) acc[c] = -3.0e38f;
-        }
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            acc[c] = fmaxf(acc[c], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[c]), 0xB1, 0xF, 0xF, true)));
-            acc[c] = fmaxf(acc[c], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[c]), 0x4E, 0xF, 0xF, true)));
-            acc[c] = fmaxf(acc[c], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[c]), 0x141, 0xF, 0xF, true)));
-        }
-        if (item < nlist) {
-            float mine = acc[0];  // lane `sub` finishes channel `sub`
-#pragma unroll
-            for (int c = 1; c < 8; ++c) mine = (sub == c) ? acc[c] : mine;
-            const int slot = (cell >> 7) * DL_Q + s_qpos[wave][item];
-            oval[(size_t)slot * 8 + sub] = enc_tanh(mine) - s_bg[sub];
-            if (sub == 0) ocell[slot] = (unsigned short)cell;
-        }
-    }
-    if (lane < 4) dl.count[(size_t)row * 4 + lane] = lane == 0 ? qcnt[0] : (lane == 1 ? qcnt[1] : (lane == 2 ? qcnt[2] : qcnt[3]));
-}
-
-struct Conv2Lds {
-    float p1[2][2 * P1_PLANE];   // two D buffers (each: two 4-channel planes, halo)
-    unsigned int nzrow[2][12];
-    int next_j[2];
-};
-
-__global__ void __launch_bounds__(256, 3) k_enc_conv2(const caelo_enc_in in, int64_t n_patches, int group, int *__restrict__ work_counter,
-                                                      const float *__restrict__ w2g, const float *__restrict__ c0g, const EncLists dl,
-                                                      float *__restrict__ p2out, unsigned long long *__restrict__ mfma_count) {
-    __shared__ __attribute__((aligned(16))) Conv2Lds L;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int g = lane >> 4;   // MFMA k-group
-    const int n = lane & 15;   // MFMA column (output channel) for B/C, row for A
-    float breg[27][2];
-#pragma unroll
-    for (int t = 0; t < 27; ++t) {
-        breg[t][0] = w2g[(t * 8 + 2 * g) * 16 + n];
-        breg[t][1] = w2g[(t * 8 + 2 * g + 1) * 16 + n];
-    }
-    f32x4 c0r[4][2];
-#pragma unroll
-    for (int yi = 0; yi < 4; ++yi) {
-        const int xp = (wave - 2 * yi) & 3;
-#pragma unroll
-        for (int xt = 0; xt < 2; ++xt) {
-            const float *c0a = c0g + (size_t)((((2 * xp + xt) * 8 + 2 * yi + (g >> 1)) * 8 + 4 * (g & 1)) * 16 + n);
-            c0r[yi][xt] = (f32x4){c0a[0], c0a[16], c0a[32], c0a[48]};
-        }
-    }
-    for (int i = tid; i < 2 * 2 * P1_PLANE; i += 256) (&L.p1[0][0])[i] = 0.0f;  // D == 0: halo, pads, background cells
-    if (tid < 24) (&L.nzrow[0][0])[tid] = 0u;
-    __syncthreads();
-    const int n_items = enc_items_total(in, n_patches);
-    const int nk = (int)(n_patches / group);
-    unsigned int executed = 0;  // MFMA tap rows this wave executed (x 6 MFMAs): measured roofline numerator
-
-    // Wave w owns quarter w of the D planes (cells with cell >> 7 == w: padded planes 2w + 1, 2w + 2) and quarter w of
-    // every patch's cell list.  An entry is fetched into registers two patches ahead (lane = entry; the rare quarter
-    // with more than 64 entries takes a slower path), scattered into LDS one patch ahead and wiped after its patch was
-    // convolved -- from the cell index kept in a register, so the only global loads are the prefetches.
-#define C2_ROW_OF(ITEM, ROW)                                    \
-    {                                                           \
-        const unsigned long long *src_;                         \
-        enc_item(in, (ITEM), nk, group, src_, ROW);             \
-        ROW = __builtin_amdgcn_readfirstlane(ROW);              \
-    }
-#define C2_Q(CELL) (((((CELL) >> 6) + 1) * 10 + ((((CELL) >> 3) & 7) + 1)) * 8 + ((CELL) & 7))
-#define C2_PUT(BUF, CELL, VA, VB)                                                     \
-    {                                                                                 \
-        const int q_ = C2_Q(CELL);                                                    \
-        *(float4 *)&L.p1[BUF][(P1_FRONT + q_) * 4] = VA;                              \
-        *(float4 *)&L.p1[BUF][P1_PLANE + (P1_FRONT + q_) * 4] = VB;                   \
-    }
-    // prefetch registers of the item two ahead, and what each buffer currently holds from this lane
-    int pf_cnt = 0, pf_cell = 0, pf_row = 0;
-    float4 pf_a = make_float4(0.f, 0.f, 0.f, 0.f), pf_b = pf_a;
-    int held_cnt[2] = {0, 0}, held_cell[2] = {0, 0}, held_row[2] = {0, 0};
-#define C2_PREFETCH(ROW)                                                                               \
-    {                                                                                                  \
-        pf_row = (ROW);                                                                                \
-        pf_cnt = __builtin_amdgcn_readfirstlane(dl.count[(size_t)(ROW) * 4 + wave]);                   \
-        const size_t o_ = ((size_t)(ROW) * 4 + wave) * DL_Q + lane;                                    \
-        pf_cell = dl.cell[o_];                                                                         \
-        pf_a = ((const float4 *)dl.val)[2 * o_];                                                       \
-        pf_b = ((const float4 *)dl.val)[2 * o_ + 1];                                                   \
-    }
-    // registers -> buffer BUF (this wave's quarter), occupancy bits of its two padded planes
-#define C2_SCATTER(BUF)                                                                                \
-    {                                                                                                  \
-        unsigned int nz0_ = 0u, nz1_ = 0u;                                                             \
-        if (lane < pf_cnt) {                                                                           \
-            C2_PUT(BUF, pf_cell, pf_a, pf_b)                                                           \
-            const unsigned int bit_ = 1u << (((pf_cell >> 3) & 7) + 1);                                \
-            if ((pf_cell >> 6) & 1) nz1_ = bit_; else nz0_ = bit_;                                     \
-        }                                                                                              \
-        for (int e_ = 64 + lane; e_ < pf_cnt; e_ += 64) { /* rare: more than 64 entries in the quarter */ \
-            const size_t o_ = ((size_t)pf_row * 4 + wave) * DL_Q + e_;                                 \
-            const int cell_ = dl.cell[o_];                                                             \
-            const float4 va_ = ((const float4 *)dl.val)[2 * o_], vb_ = ((const float4 *)dl.val)[2 * o_ + 1]; \
-            C2_PUT(BUF, cell_, va_, vb_)                                                               \
-            const unsigned int bit_ = 1u << (((cell_ >> 3) & 7) + 1);                                  \
-            if ((cell_ >> 6) & 1) nz1_ |= bit_; else nz0_ |= bit_;                                     \
-        }                                                                                              \
-        _Pragma("unroll") for (int o_ = 32; o_ > 0; o_ >>= 1) { nz0_ |= __shfl_xor(nz0_, o_); nz1_ |= __shfl_xor(nz1_, o_); } \
-        if (lane == 0) { L.nzrow[BUF][2 * wave + 1] = nz0_; L.nzrow[BUF][2 * wave + 2] = nz1_; }      \
-        held_cnt[BUF] = pf_cnt; held_cell[BUF] = pf_cell; held_row[BUF] = pf_row;                      \
-    }
-#define C2_WIPE(BUF)                                                                                   \
-    {                                                                                                  \
-        const float4 z4_ = make_float4(0.f, 0.f, 0.f, 0.f);                                            \
-        if (lane < held_cnt[BUF]) C2_PUT(BUF, held_cell[BUF], z4_, z4_)                                \
-        for (int e_ = 64 + lane; e_ < held_cnt[BUF]; e_ += 64) {                                       \
-            const int cell_ = dl.cell[((size_t)held_row[BUF] * 4 + wave) * DL_Q + e_];                 \
-            C2_PUT(BUF, cell_, z4_, z4_)                                                               \
-        }                                                                                              \
-    }
-    // software pipeline over this workgroup's items: cur (being convolved, in buffer `buf`), nxt (scattered in the
-    // other buffer), nn (prefetched in registers), and the work counter is one fetch ahead of that
-    int j_cur = blockIdx.x, j_nxt = n_items, j_nn = n_items, row_cur = 0, row_nxt = 0;
-#ifndef C2_STATIC
-#define C2_STATIC 1
-#endif
-    if (tid == 0) {
-        L.next_j[0] = C2_STATIC ? (int)(blockIdx.x + gridDim.x) : (int)gridDim.x + atomicAdd(work_counter, 1);
-        L.next_j[1] = C2_STATIC ? (int)(blockIdx.x + 2 * gridDim.x) : (int)gridDim.x + atomicAdd(work_counter, 1);
-    }
-    if (j_cur < n_items) {
-        C2_ROW_OF(j_cur, row_cur)
-        C2_PREFETCH(row_cur)
-        C2_SCATTER(0)
-    }
-    __syncthreads();
-    j_nxt = __builtin_amdgcn_readfirstlane(L.next_j[0]);
-    j_nn = __builtin_amdgcn_readfirstlane(L.next_j[1]);
-    if (j_nxt < n_items) {
-        C2_ROW_OF(j_nxt, row_nxt)
-        C2_PREFETCH(row_nxt)
-        C2_SCATTER(1)
-    }
-    __syncthreads();
-    int buf = 0;
-    while (j_cur < n_items) {
-        // the item three ahead: fetched now, published at this iteration's barrier; the item two ahead: into registers
-        int j_fetch = 0;
-        if (tid == 0) j_fetch = C2_STATIC ? j_nn : atomicAdd(work_counter, 1);
-        pf_cnt = 0;
-        if (j_nn < n_items) {
-            int row_nn;
-            C2_ROW_OF(j_nn, row_nn)
-            C2_PREFETCH(row_nn)
-        }
-        // ---- conv2 (8->16) on MFMA from buffer `buf`: per row pair yi this wave owns the x pair xp = (wave - 2 yi) mod 4
-        {
-            const int patch = row_cur;
-            const int yl = n >> 3, z = n & 7;  // A row m = yl*8 + z
-            const float *plane = &L.p1[buf][0] + (g >> 1) * P1_PLANE + 2 * (g & 1);
-            const unsigned int *nzr = L.nzrow[buf];
-            const bool zlo = z >= 1, zhi = z <= 6;
-#pragma unroll
-            for (int yi = 0; yi < 4; ++yi) {
-                const int y0 = 2 * yi;
-                const int xp = (wave - 2 * yi) & 3;
-                const unsigned int r0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((nzr[2 * xp] >> y0) & 0xFu));
-                const unsigned int r1 = (unsigned)__builtin_amdgcn_readfirstlane((int)((nzr[2 * xp + 1] >> y0) & 0xFu));
-                const unsigned int r2 = (unsigned)__builtin_amdgcn_readfirstlane((int)((nzr[2 * xp + 2] >> y0) & 0xFu));
-                const unsigned int r3 = (unsigned)__builtin_amdgcn_readfirstlane((int)((nzr[2 * xp + 3] >> y0) & 0xFu));
-                float *dst = p2out + (size_t)patch * 1024 + (size_t)(((xp * 4 + yi) * 4 + 2 * (g & 1)) * 16 + n);
-                // accumulators start from C0 = b2 + conv2(BG); a pair that nothing but background feeds keeps them as they
-                // are (the pooled constants are recomputed rather than held in 8 more registers)
-                f32x4 acc0 = c0r[yi][0];
-                f32x4 acc1 = c0r[yi][1];
-                if ((r0 | r1 | r2 | r3) != 0u) {
-                f32x4 acc0b = {0.f, 0.f, 0.f, 0.f}, acc1b = {0.f, 0.f, 0.f, 0.f};
-                const int qbase = ((2 * xp) * 10 + (y0 + yl)) * 8 + z;
-                const float *a0 = plane + (P1_FRONT + qbase) * 4;
-                const float *a1 = a0 + 80 * 4;
-                CONV2_TILE(acc0, acc0b, a0, r0, r1, r2)
-                CONV2_TILE(acc1, acc1b, a1, r1, r2, r3)
-#define C2_HITS(R) (unsigned)((((R) & 0x3u) != 0u) + (((R) & 0x6u) != 0u) + (((R) & 0xCu) != 0u))
-                executed += C2_HITS(r0) + 2u * C2_HITS(r1) + 2u * C2_HITS(r2) + C2_HITS(r3);
-                acc0 += acc0b;
-                acc1 += acc1b;
-                }
-                float v0 = fmaxf(fmaxf(acc0[0], acc0[1]), fmaxf(acc1[0], acc1[1]));  // pz = 2*(g&1)
-                float v1 = fmaxf(fmaxf(acc0[2], acc0[3]), fmaxf(acc1[2], acc1[3]));  // pz = 2*(g&1)+1
-                v0 = fmaxf(v0, __shfl_xor(v0, 32));
-                v1 = fmaxf(v1, __shfl_xor(v1, 32));
-                if (g < 2) {
-                    dst[0] = enc_tanh(v0);
-                    dst[16] = enc_tanh(v1);
-                }
-            }
-        }
-        if (tid == 0) L.next_j[buf] = (int)gridDim.x + j_fetch;  // (static: j_nn + gridDim.x) slot by parity: a slow reader of the previous one is never overtaken
-        caelo_lds_barrier();  // every wave is done reading `buf`; next_j is published
-        const int j_n3 = __builtin_amdgcn_readfirstlane(L.next_j[buf]);
-        // ---- this wave's quarter of `buf`: wipe the patch just convolved, bring in the prefetched one (no barrier in
-        // between: nobody else touches this quarter) while the other waves may already be in the next patch's MFMAs
-        C2_WIPE(buf)
-        int row_nn2 = 0;
-        if (j_nn < n_items) {
-            row_nn2 = pf_row;
-            C2_SCATTER(buf)
-        } else {
-            if (lane == 0) { L.nzrow[buf][2 * wave + 1] = 0u; L.nzrow[buf][2 * wave + 2] = 0u; }
-            held_cnt[buf] = 0;
-        }
-        j_cur = j_nxt; row_cur = row_nxt;
-        j_nxt = j_nn; row_nxt = row_nn2;
-        j_nn = j_n3;
-        buf ^= 1;
-    }
-    if (mfma_count && lane == 0 && executed) atomicAdd(mfma_count, (unsigned long long)executed);
-}
-
+#define ENC_XCD_CSTRIDE 32   // ints between two per-XCD work counters (one 128-byte line each)
 // ------------------------------------------------------------------------------------------------
 // conv3 (16->32) implicit GEMM: M = 64 positions/patch, N = 32, K = 27*16 -- f32 products on the bf16 matrix pipe
 // ------------------------------------------------------------------------------------------------
@@ -1318,7 +625,7 @@ __global__ void __launch_bounds__(256, C3X_WGS) k_enc_conv3(const float *__restr
     // stage 1 (the previous kernel on this stream) is complete: hand its work counter back at zero, so that no
     // memset launch sits on the encoder stream's critical path
     if (blockIdx.x == 0 && threadIdx.x == 0) *stage1_counter = 0;
-    if (blockIdx.x == 0 && threadIdx.x < 8) xcd_counters[threadIdx.x * S1W_CSTRIDE] = 0;  // k_enc_stage1w's queues
+    if (blockIdx.x == 0 && threadIdx.x < 8) xcd_counters[threadIdx.x * ENC_XCD_CSTRIDE] = 0;  // stage 1's per-XCD queues, for the next launch set
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -1521,126 +828,8 @@ int enc_upload_dense1(const float *wd1, const float *bd1, int K, void **wx_dev, 
     return CAELO_OK;
 }
 
-// (64 MTW) rows x 208 columns x KTOT/8 k per workgroup of 8 waves, one workgroup per CU.  A stage is one 32-deep
-// k-step:
-//   * the weight stage is a straight 39 KB copy of the host-built image, moved by LDS-DMA (global_load_lds_dwordx4:
-//     1 KB per wave instruction, no VGPRs, no ds_write pass) into one of two buffers while the MFMAs of the
-//     previous stage run.  Every workgroup streams its whole K chunk of the weights from L2, so the rows per
-//     workgroup set the L2 traffic: 64-row tiles move 245 MB per 6144-row launch and are bound by it (45 us), 192-row
-//     tiles 82 MB;
-//   * the f32 activations are fetched into registers a stage ahead and split into their three bf16 terms on the
-//     way into LDS ([split][g][row] x 16 B: the A operand of lane (m, g) is one ds_read_b128, 16 lanes = 256
-//     contiguous bytes).
-// Wave w owns the MTW m-tiles of row group w >> 1 and n-tiles 0..6 (even waves) / 7..12 (odd): an A fragment is read
-// once per k-step and serves 7 / 6 tiles, a B fragment serves the 6 MFMAs of MTW tiles (see conv3 for the arithmetic).
-#define D1_LDS_BYTES(MTW) ((D1_NS * 4 * 64 * (MTW) + 2 * D1_B16) * 16)
 typedef _Float16 d1_h8 __attribute__((ext_vector_type(8)));
 #define D1_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_f16((A), (B), (C), 0, 0, 0)
-template <int KTOT, int MTW>
-__global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1(const float *__restrict__ f3, int64_t n_rows_pad,
-                                                              const uint4 *__restrict__ wd1x, float *__restrict__ part,
-                                                              const caelo_enc_in in) {
-    constexpr int BM = 64 * MTW, A16 = D1_NS * 4 * BM, NKS = KTOT / D1_SPLIT_OF(KTOT) / D1_BK;
-    if (in.dedup) {  // a row tile past the frame's distinct patches holds nothing (tiles never straddle frames)
-        const int64_t r0 = (int64_t)blockIdx.x * BM;
-        const int f = (int)(r0 / in.per_frame);
-        if (r0 - (int64_t)f * in.per_frame >= enc_tables(in, f)->count) return;
-    }
-    extern __shared__ uint4 d1_lds[];
-    uint4 *As = d1_lds;        // [split][g][row]
-    uint4 *Bs = d1_lds + A16;  // two stages of [split][n-tile][lane]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, n = lane & 15;
-    const int64_t row0 = (int64_t)blockIdx.x * BM;
-    const int split = blockIdx.y;
-    const int ks0 = split * NKS;
-    const int mg = wave >> 1;          // rows mg * 16 MTW ... of the tile
-    const bool odd = (wave & 1) != 0;  // n-tiles 7..12 (6 of them) instead of 0..6
-    const int nt0 = odd ? 7 : 0;
-    f32x4 acc[MTW][7];
-#pragma unroll
-    for (int q = 0; q < MTW; ++q)
-#pragma unroll
-        for (int i = 0; i < 7; ++i) acc[q][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int a_row = tid >> 3, a_kq = tid & 7;  // A fetch: rows a_row + 64 r, 4 consecutive k
-    const float *a_src = f3 + (size_t)(row0 + a_row) * KTOT + (size_t)ks0 * D1_BK + a_kq * 4;
-    const uint4 *b_src = wd1x + (size_t)ks0 * D1_B16 + lane;
-    float4 pa[MTW];
-    // B stage KS -> buffer BUF: 39 blocks of 64 x 16 B, block w, w + 8, ... by wave w
-#define D1_FETCH(KS, BUF)                                                                                        \
-    {                                                                                                            \
-        _Pragma("unroll") for (int r = 0; r < 5; ++r) {                                                          \
-            const int blk = wave + 8 * r;                                                                        \
-            if (blk < D1_NS * D1_NT)                                                                             \
-                __builtin_amdgcn_global_load_lds(                                                                \
-                    (const void __attribute__((address_space(1))) *)(b_src + (size_t)(KS) * D1_B16 + blk * 64),  \
-                    (void __attribute__((address_space(3))) *)(Bs + (BUF) * D1_B16 + blk * 64), 16, 0, 0);       \
-        }                                                                                                        \
-        _Pragma("unroll") for (int r = 0; r < MTW; ++r)                                                          \
-            pa[r] = *(const float4 *)(a_src + (size_t)(64 * r) * KTOT + (size_t)(KS) * D1_BK);                   \
-    }
-#define D1_STORE_A()                                                                                       \
-    _Pragma("unroll") for (int r = 0; r < MTW; ++r) {                                                      \
-        uint32_t h01_, l01_, h23_, l23_;                                                                   \
-        enc_split2h_pk(pa[r].x, pa[r].y, h01_, l01_);                                                      \
-        enc_split2h_pk(pa[r].z, pa[r].w, h23_, l23_);                                                      \
-        uint2 *d_ = (uint2 *)&As[(a_kq >> 1) * BM + a_row + 64 * r] + (a_kq & 1);                          \
-        d_[0] = make_uint2(h01_, h23_);                                                                    \
-        d_[2 * 4 * BM] = make_uint2(l01_, l23_);                                                           \
-    }
-    D1_FETCH(0, 0)
-#pragma unroll 1
-    for (int st = 0; st < NKS; ++st) {
-        D1_STORE_A()
-        __syncthreads();  // also waits for the LDS-DMA of this stage (vmcnt)
-        if (st + 1 < NKS) D1_FETCH(st + 1, (st + 1) & 1)
-        d1_h8 ah[MTW], al[MTW];
-#pragma unroll
-        for (int q = 0; q < MTW; ++q) {
-            const uint4 *ap = &As[g * BM + (mg * MTW + q) * 16 + n];
-            ah[q] = __builtin_bit_cast(d1_h8, ap[0]);
-            al[q] = __builtin_bit_cast(d1_h8, ap[4 * BM]);
-        }
-        const uint4 *bp = &Bs[(st & 1) * D1_B16 + nt0 * 64 + lane];
-        // n-tiles in groups (the 7th absent on odd waves); within a group the accumulators alternate, so that no
-        // MFMA waits for its predecessor
-#define D1_GROUP(I0, CNT)                                                                                             \
-    {                                                                                                                 \
-        d1_h8 bh[CNT], bl[CNT];                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < CNT; ++i) {                                                             \
-            if ((I0) + i == 6 && odd) continue;                                                                       \
-            bh[i] = __builtin_bit_cast(d1_h8, bp[((I0) + i) * 64]);                                                   \
-            bl[i] = __builtin_bit_cast(d1_h8, bp[(D1_NT + (I0) + i) * 64]);                                           \
-        }                                                                                                             \
-        D1_TERM(al, bh, I0, CNT) D1_TERM(ah, bl, I0, CNT) D1_TERM(ah, bh, I0, CNT)                                     \
-    }
-#define D1_TERM(A, B, I0, CNT)                                                                                        \
-    _Pragma("unroll") for (int q = 0; q < MTW; ++q)                                                                   \
-    _Pragma("unroll") for (int i = 0; i < CNT; ++i) if (!((I0) + i == 6 && odd))                                      \
-        acc[q][(I0) + i] = D1_MFMA(A[q], B[i], acc[q][(I0) + i]);
-        if (MTW == 1) {
-            D1_GROUP(0, 4)
-            D1_GROUP(4, 3)
-        } else {
-            D1_GROUP(0, 2)
-            D1_GROUP(2, 2)
-            D1_GROUP(4, 2)
-            D1_GROUP(6, 1)
-        }
-        caelo_lds_barrier();  // LDS reads done; the DMA of the next stage stays in flight
-    }
-    // C rows 4g + r of each tile
-#pragma unroll
-    for (int q = 0; q < MTW; ++q)
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            if (i == 6 && odd) continue;
-            float *dst = part + ((size_t)split * n_rows_pad + row0 + (mg * MTW + q) * 16 + 4 * g) * DENSE_NP + (nt0 + i) * 16 + n;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dst[(size_t)r * DENSE_NP] = acc[q][i][r];
-        }
-}
 
 // ------------------------------------------------------------------------------------------------
 // dense1, software-pipelined.  k_enc_dense1 above needs 90 KB of LDS, so ONE workgroup runs per CU, and its stage is a chain --
@@ -1875,26 +1064,16 @@ static int dense1_launch(int device, const float *f3, int64_t np, const void *wd
     static bool attr_have[CAELO_MAX_DEVICES];
     static std::mutex attr_mu;
     const hipError_t attr = per_device_once(device, attr_slot, attr_have, attr_mu, [] {
-        hipError_t e = hipFuncSetAttribute((const void *)k_enc_dense1<KTOT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, D1_LDS_BYTES(1));
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)k_enc_dense1<KTOT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, D1_LDS_BYTES(3));
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)k_enc_dense1p<KTOT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, D1P_LDS_BYTES(1));
+        hipError_t e = hipFuncSetAttribute((const void *)k_enc_dense1p<KTOT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, D1P_LDS_BYTES(1));
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)k_enc_dense1p<KTOT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, D1P_LDS_BYTES(2));
         return e;
     });
     CAELO_HIP(attr);
-    // CAELO_D1_PLAIN=1: the round-1 kernels (two barriers per stage; 192-row tiles for the long-K instance) -- bit-identical
-    static const bool plain = getenv("CAELO_D1_PLAIN") && atoi(getenv("CAELO_D1_PLAIN")) > 0;
+    // CAELO_D1_WIDE_FROM: launch size (rows) from which the 128-row instance is used -- a tuning threshold, the partial sums of the two
+    // instances are bit-identical (tests/test_gpu_parity.py::test_dense1_tile_sizes_are_bit_identical)
     static const int64_t wide_from = getenv("CAELO_D1_WIDE_FROM") ? atoll(getenv("CAELO_D1_WIDE_FROM")) : 4 * 3072;  // rows
-    if (plain && KTOT > 2048 && np % 192 == 0) {
-        dim3 gd((unsigned)(np / 192), D1_SPLIT_OF(KTOT));
-        k_enc_dense1<KTOT, 3><<<gd, D1_THREADS, D1_LDS_BYTES(3), s>>>(f3, np, (const uint4 *)wd1x, part, in);
-    } else if (plain) {
-        dim3 gd((unsigned)(np / 64), D1_SPLIT_OF(KTOT));
-        k_enc_dense1<KTOT, 1><<<gd, D1_THREADS, D1_LDS_BYTES(1), s>>>(f3, np, (const uint4 *)wd1x, part, in);
-    } else if (np % 128 == 0 && (!in.dedup || in.per_frame % 128 == 0) && (np >= wide_from || KTOT > 2048)) {  // (tiles never straddle frames)
+    if (np % 128 == 0 && (!in.dedup || in.per_frame % 128 == 0) && (np >= wide_from || KTOT > 2048)) {  // (tiles never straddle frames)
         // 128-row tiles once the launch fills the chip with them, and always for the long-K instance (8 k slices per row tile):
         // half the weight stream; same partial sums
         dim3 gw((unsigned)(np / 128), D1_SPLIT_OF(KTOT));
@@ -1905,111 +1084,6 @@ static int dense1_launch(int device, const float *f3, int64_t np, const void *wd
     }
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-template <int SPLIT>
-__global__ void __launch_bounds__(256) k_enc_head(const float *__restrict__ part, int64_t n_patches, int64_t n_rows_pad,
-                                                  const float *__restrict__ bd1p, const float *__restrict__ wd2,
-                                                  const float *__restrict__ bd2, int group, caelo_enc_out outs,
-                                                  int out_stride, const caelo_enc_in in, int32_t *faults) {
-    // A wave walks patches p, p + (waves of the grid), ...; no LDS, no barrier.  Lane l < 50 owns the four hidden columns 4l .. 4l+3:
-    // one 16-byte load per split-K partial (800 contiguous bytes per row) and the 4 x 20 Dense(20) weights of those columns, which
-    // stay in registers across the wave's patches (a wave per patch re-read the 16 KB of weights from L2 per patch: five times
-    // the bytes of the partial sums).  The next patch's partial sums are fetched under this patch's arithmetic.  The 20 outputs
-    // are 64-lane sums of per-lane partial dot products (reduce-scatter butterfly below).
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // 32-bit patch arithmetic (the host entry refuses launches of 2^31 patches): 64-bit divisions are long software loops here
-    const unsigned n_all = (unsigned)n_patches, stride = gridDim.x * 4u, per_in = (unsigned)in.per_frame, per_out = (unsigned)outs.per_frame;
-    unsigned p = blockIdx.x * 4u + (unsigned)wave;
-    if (p >= n_all) return;
-    // the row that holds a patch's result: its representative's with de-duplication
-#define HEAD_ROW(P, ROW)                                                          \
-    {                                                                             \
-        ROW = (P);                                                                \
-        if (in.dedup) {                                                           \
-            const unsigned f_ = (P) / per_in;                                     \
-            int r_ = enc_tables(in, (int)f_)->slot_of[(P) - f_ * per_in];         /* a row of the whole launch set ... */ \
-            if (r_ < 0) {                                                         /* ... or -(representative + 1): its row */ \
-                const unsigned g_ = (unsigned)(-r_ - 1), fr_ = g_ / per_in;      \
-                r_ = enc_tables(in, (int)fr_)->slot_of[g_ - fr_ * per_in];       \
-            }                                                                     \
-            ROW = (unsigned)r_;                                                   \
-        }                                                                         \
-    }
-    const bool ok = lane < DENSE_N / 4;
-    // (lanes 50..63 read lane 49's addresses and are masked out of the sums by hv = 0 below: no pointer selects, no branches)
-    const int cl = ok ? lane : DENSE_N / 4 - 1;
-    const float4 bias4 = *(const float4 *)(bd1p + 4 * cl);
-    float4 w[4][5];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int q = 0; q < 5; ++q) w[c][q] = ((const float4 *)(wd2 + (4 * cl + c) * 20))[q];
-    float4 v[SPLIT], vn[SPLIT];
-#define HEAD_FETCH(V, ROW)                                               \
-    _Pragma("unroll") for (int sp = 0; sp < SPLIT; ++sp)                 \
-        V[sp] = *(const float4 *)(part + ((size_t)sp * n_rows_pad + (ROW)) * DENSE_NP + 4 * cl);
-    unsigned prow, prow_next = 0u;
-    HEAD_ROW(p, prow)
-    HEAD_FETCH(v, prow)
-    if (p + stride < n_all) HEAD_ROW(p + stride, prow_next)
-    const int o_mine = (lane & 32 ? 10 : 0) + (lane & 16 ? 5 : 0) + (lane & 8 ? 3 : 0) + (lane & 4 ? 2 : 0) + (lane & 2 ? 1 : 0);
-    const float bo = o_mine < 20 ? bd2[o_mine] : 0.0f;  // (padding lanes of the butterfly count past 19)
-    for (; p < n_all; p += stride) {
-    if (p + stride < n_all) HEAD_FETCH(vn, prow_next)
-    if (p + 2 * stride < n_all) HEAD_ROW(p + 2 * stride, prow_next)
-    float4 s = bias4;
-#pragma unroll
-    for (int sp = 0; sp < SPLIT; ++sp) { s.x += v[sp].x; s.y += v[sp].y; s.z += v[sp].z; s.w += v[sp].w; }
-    const float hv[4] = {ok ? enc_tanh(s.x) : 0.f, ok ? enc_tanh(s.y) : 0.f, ok ? enc_tanh(s.z) : 0.f, ok ? enc_tanh(s.w) : 0.f};
-    float acc[20];
-#pragma unroll
-    for (int o = 0; o < 20; ++o) acc[o] = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            acc[4 * q + 0] += hv[c] * w[c][q].x;
-            acc[4 * q + 1] += hv[c] * w[c][q].y;
-            acc[4 * q + 2] += hv[c] * w[c][q].z;
-            acc[4 * q + 3] += hv[c] * w[c][q].w;
-        }
-    // The 20 outputs = sums of acc[o] over the 64 lanes.  Reduce-scatter butterfly: at every step a lane keeps one half of its
-    // values and hands the other half to its partner (20 -> 10 -> 5 -> 3 -> 2 -> 1 values, 22 shuffles instead of the 120 of
-    // twenty full butterflies).  Every partial sum is the sum of the same two operands as in the full butterfly, so the result
-    // is bit-identical to it.  Lane l ends with output o = 10 b5 + 5 b4 + 3 b3 + 2 b2 + b1 (bits of l; some lanes hold padding).
-    const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0, h2 = (lane & 4) != 0, h1 = (lane & 2) != 0;
-    float a10[10], a5[6], a3[4], a2[2];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) a10[i] = (h5 ? acc[10 + i] : acc[i]) + __shfl_xor(h5 ? acc[i] : acc[10 + i], 32);
-#pragma unroll
-    for (int i = 0; i < 5; ++i) a5[i] = (h4 ? a10[5 + i] : a10[i]) + __shfl_xor(h4 ? a10[i] : a10[5 + i], 16);
-    a5[5] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) a3[i] = (h3 ? a5[3 + i] : a5[i]) + __shfl_xor(h3 ? a5[i] : a5[3 + i], 8);
-    a3[3] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) a2[i] = (h2 ? a3[2 + i] : a3[i]) + __shfl_xor(h2 ? a3[i] : a3[2 + i], 4);
-    float mine = (h1 ? a2[1] : a2[0]) + __shfl_xor(h1 ? a2[0] : a2[1], 2);
-    mine += __shfl_xor(mine, 1);
-    const int o = (h5 ? 10 : 0) + (h4 ? 5 : 0) + (h3 ? 3 : 0) + (h2 ? 2 : 0) + (h1 ? 1 : 0);
-    const bool holds = (lane & 1) == 0 && (h3 ? !h2 : !(h2 && h1));
-    // patches of several frames in one launch: frame f = p / per_frame writes into its own rows
-    const unsigned f = p / per_out, q = p - f * per_out, kp = q / (unsigned)group;
-    if (holds) {
-        const float dv = enc_tanh(bo + mine);
-        outs.base[f][(size_t)kp * out_stride + (size_t)(q - kp * (unsigned)group) * 20 + o] = dv;
-        // the encoder's own invariant, next to the pose kernels' lane-agreement check (caelo_lane_faults): a descriptor is a
-        // tanh -- finite and within [-1, 1] whatever the patch; anything else is a broken weight image, a stale workspace or
-        // a mis-executed matrix instruction upstream, and is counted instead of flowing into the match unnoticed
-        if (!(fabsf(dv) <= 1.0f)) atomicAdd(faults, 1);
-    }
-#pragma unroll
-    for (int sp = 0; sp < SPLIT; ++sp) v[sp] = vn[sp];
-    }
-#undef HEAD_ROW
-#undef HEAD_FETCH
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2129,19 +1203,13 @@ __global__ void __launch_bounds__(256) k_enc_head_mfma(const float *__restrict__
 // ------------------------------------------------------------------------------------------------
 // host entry
 // ------------------------------------------------------------------------------------------------
-// k_enc_head: a wave per patch up to three workgroups per CU (two for the 8-slice instance: 176 registers), then the waves loop
-static inline unsigned enc_head_grid(int64_t n_patches, int64_t cap = 768) {
-    const int64_t wgs = (n_patches + 3) / 4;
-    return (unsigned)(wgs < cap ? wgs : cap);
-}
 static inline int64_t pad64(int64_t n) { return (n + D1_BM - 1) / D1_BM * D1_BM; }  // rows padded to whole dense-1 tiles
 
 // per row: counts (4 quarters x 4 B) + cells (512 x 2 B) + values (512 x 8 x 4 B) of the non-background cells after conv1 + pool1
-static inline int64_t dl_bytes(int64_t np) { return np * (4 * 4 + DL_MAX * 2 + (int64_t)DL_MAX * 8 * 4); }
 
 CAELO_API int64_t caelo_encode_ws_bytes(int64_t n_patches) {
     const int64_t np = pad64(n_patches);
-    return CAELO_ENC_WS_HEADER + (np * 1024 + np * 2048 + (int64_t)D1_SPLIT * np * DENSE_NP) * (int64_t)sizeof(float) + dl_bytes(np);
+    return CAELO_ENC_WS_HEADER + (np * 1024 + np * 2048 + (int64_t)D1_SPLIT * np * DENSE_NP) * (int64_t)sizeof(float);
 }
 
 int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
@@ -2174,33 +1242,16 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     float *p2 = (float *)((char *)ws + CAELO_ENC_WS_HEADER);
     float *f3 = p2 + np * 1024;
     float *part = f3 + np * 2048;
-    EncLists dl;
-    dl.val = part + (size_t)D1_SPLIT * np * DENSE_NP;
-    dl.count = (int32_t *)(dl.val + (size_t)np * DL_MAX * 8);
-    dl.cell = (unsigned short *)(dl.count + np * 4);
     if (np > n_patches)  // rows of the last 64-row tile that no patch writes
         CAELO_HIP(hipMemsetAsync(f3 + n_patches * 2048, 0, (size_t)(np - n_patches) * 2048 * sizeof(float), s));
     // persistent grid = exactly the resident workgroup slots (weights stay in registers across patches,
     // no second partially filled round)
-    // k_enc_stage1 (conv1 + conv2 in one persistent kernel) is the default; CAELO_ENC_SPLIT=1 selects the two-kernel
-    // variant (k_enc_conv1 + k_enc_conv2, bit-identical results), measured 25 % slower
-    static const bool fused_stage1 = !(getenv("CAELO_ENC_SPLIT") && atoi(getenv("CAELO_ENC_SPLIT")) > 0);
-    // CAELO_ENC_WAVE=1 selects k_enc_stage1w (a patch per wavefront, no workgroup barriers; bit-identical P2) instead of
-    // k_enc_stage1 (a patch per 4-wave workgroup).  Measured slower: 93 vs 62 us for one frame, 375 vs 292 us for an 8-frame
-    // launch -- two wavefronts per SIMD (LDS) do not cover its LDS / dependency waits either.
-    static const bool wave_stage1 = fused_stage1 && getenv("CAELO_ENC_WAVE") && atoi(getenv("CAELO_ENC_WAVE")) > 0;
-    static int slots1w_slot[CAELO_MAX_DEVICES];
-    static bool slots1w_have[CAELO_MAX_DEVICES];
-    static std::mutex slots1w_mu;
-    const int slots1w = per_device_once(c->device, slots1w_slot, slots1w_have, slots1w_mu, [&] {
-        int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_enc_stage1w, 64 * S1W_WAVES, 0) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || per_cu * cus <= 0)
-            return 512;
-        return per_cu * cus;
-    });
-    // CAELO_ENC_S1=f32 selects round 2's k_enc_stage1 (f32-input MFMAs, conv1 on the VALU) for comparison; default: k_enc_stage1x
-    static const bool stage1x = fused_stage1 && !wave_stage1 && !(getenv("CAELO_ENC_S1") && !strcmp(getenv("CAELO_ENC_S1"), "f32"));
+    // Stage 1 = k_enc_stage1x (enc_stage1x.inc: conv1 on the matrix cores, f16 x 2 products, two 256-register workgroups per CU).
+    // The exact-f32 k_enc_stage1 of round 2 stays as the PRECISION REFERENCE, chosen per context by caelo_set_encoder_reference --
+    // never by the environment: the library reads no variable that changes arithmetic.  (The kernels rounds 1-3 measured and lost
+    // with -- one wavefront per patch, conv1 / conv2 as two kernels, the two-barrier Dense(200), the one-patch-per-wavefront head, the
+    // VALU response layer, the all-f64 match as a default -- are gone from the library; DESIGN.md 4 keeps their numbers.)
+    const bool stage1x = !c->enc_reference;
     static int slots1x_slot[CAELO_MAX_DEVICES];
     static bool slots1x_have[CAELO_MAX_DEVICES];
     static std::mutex slots1x_mu;
@@ -2217,7 +1268,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     static std::mutex slots1_mu;
     const int slots1 = per_device_once(c->device, slots1_slot, slots1_have, slots1_mu, [&] {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_stage1 ? (const void *)k_enc_stage1 : (const void *)k_enc_conv2, 256, 0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_enc_stage1, 256, 0) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || per_cu * cus <= 0)
             return 768;  // 3 workgroups on each of MI355X's 256 CUs
         return per_cu * cus;
@@ -2229,14 +1280,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     const unsigned g1 = (unsigned)(n_patches < cap1 ? n_patches : cap1);
     if (ev) CAELO_HIP(hipEventRecord(ev[0], s));
     const int order_group = (n_patches % group == 0) ? group : 1;
-    if (wave_stage1) {
-        const int64_t capw = ein.yield ? (int64_t)slots1w * 4 / 5 : slots1w;
-        const int64_t wgs = (n_patches + S1W_WAVES - 1) / S1W_WAVES;
-        k_enc_stage1w<<<(unsigned)(wgs < capw ? wgs : capw), 64 * S1W_WAVES, 0, s>>>(ein, n_patches, order_group, xcd_counters, c->enc_w1, c->enc_b1,
-                                                                                   c->enc_w2, c->enc_c0, p2);
-        CAELO_LAUNCH_CHECK();
-    } else if (stage1x) {
-        // round 3's default: conv1 on the matrix cores, f16 x 2 products, two 256-register workgroups per CU (enc_stage1x.inc)
+    if (stage1x) {
         // CAELO_S1X_SLOTS: grid size by hand (measurement: 128 / 256 / 384 / 512 workgroups take 692 / 376 / 281 / 233 us per 24 576
         // patches -- a workgroup alone on its CU needs 3.9 us per patch, two sharing one 4.85 us each: latency bound)
         static const int slots_env = getenv("CAELO_S1X_SLOTS") ? atoi(getenv("CAELO_S1X_SLOTS")) : 0;
@@ -2251,13 +1295,9 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
             k_enc_stage1x<false><<<gx, 256, 0, s>>>(ein, n_patches, order_group, work_counter, (const uint4 *)c->enc_w1f, c->enc_b1,
                                                     (const uint4 *)c->enc_w2x, c->enc_c0, p2, mfma_count);
         CAELO_LAUNCH_CHECK();
-    } else if (fused_stage1) {
-        k_enc_stage1<<<g1, 256, 0, s>>>(ein, n_patches, order_group, work_counter, c->enc_w1, c->enc_b1, c->enc_w2, c->enc_c0, p2);
-        CAELO_LAUNCH_CHECK();
     } else {
-        k_enc_conv1<<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(ein, n_patches, order_group, c->enc_w1, c->enc_b1, c->enc_c0, dl, mfma_count);
-        CAELO_LAUNCH_CHECK();
-        k_enc_conv2<<<g1, 256, 0, s>>>(ein, n_patches, order_group, work_counter, c->enc_w2, c->enc_c0, dl, p2, mfma_count);
+        if (ev) CAELO_HIP(hipMemsetAsync(mfma_count, 0, sizeof(unsigned long long), s));   // (the f32 kernel has no register left to count)
+        k_enc_stage1<<<g1, 256, 0, s>>>(ein, n_patches, order_group, work_counter, c->enc_w1, c->enc_b1, c->enc_w2, c->enc_c0, p2);
         CAELO_LAUNCH_CHECK();
     }
     if (ev) CAELO_HIP(hipEventRecord(ev[1], s));
@@ -2272,26 +1312,10 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
         if (rc) return rc;
     }
     if (ev) CAELO_HIP(hipEventRecord(ev[3], s));
-    // CAELO_ENC_HEAD=wave: the one-patch-per-wavefront kernel of rounds 1 - 3 (comparison)
-    static const bool head_wave = getenv("CAELO_ENC_HEAD") && !strcmp(getenv("CAELO_ENC_HEAD"), "wave");
-    if (head_wave)
-        k_enc_head<D1_SPLIT_OF(DENSE_K)><<<enc_head_grid(n_patches), 256, 0, s>>>(part, n_patches, np, c->enc_bd1, c->enc_wd2, c->enc_bd2,
-                                                                    group, outs, out_stride, ein, c->faults);
-    else
-        k_enc_head_mfma<D1_SPLIT_OF(DENSE_K)><<<(unsigned)((n_patches + 15) / 16), 256, 0, s>>>(part, n_patches, np, c->enc_bd1, (const float4 *)c->enc_wd2q,
-                                                                                           c->enc_bd2, group, outs, out_stride, ein, c->faults);
+    k_enc_head_mfma<D1_SPLIT_OF(DENSE_K)><<<(unsigned)((n_patches + 15) / 16), 256, 0, s>>>(part, n_patches, np, c->enc_bd1, (const float4 *)c->enc_wd2q,
+                                                                                       c->enc_bd2, group, outs, out_stride, ein, c->faults);
     CAELO_LAUNCH_CHECK();
     if (ev) CAELO_HIP(hipEventRecord(ev[4], s));
-    if (ev && fused_stage1 && !stage1x) {
-        // Profiling calls only, outside the timed events: how many conv2 MFMAs did stage 1 execute?  k_enc_stage1 has no
-        // register left for a counter (168 VGPRs / 106 SGPRs at three workgroups per CU: counting cost 50 % of its time), so
-        // the two-kernel variant -- the same rows, the same skipping rule, bit-identical P2 -- is run once more to count.
-        k_enc_conv1<<<(unsigned)((n_patches + 3) / 4), 256, 0, s>>>(ein, n_patches, order_group, c->enc_w1, c->enc_b1, c->enc_c0, dl, mfma_count);
-        CAELO_LAUNCH_CHECK();
-        k_enc_conv2<<<g1, 256, 0, s>>>(ein, n_patches, order_group, work_counter, c->enc_w2, c->enc_c0, dl, p2, mfma_count);
-        CAELO_LAUNCH_CHECK();
-        CAELO_HIP(hipMemsetAsync(work_counter, 0, sizeof(int), s));  // conv3 is not there to hand it back at zero
-    }
     return CAELO_OK;
 }
 
@@ -2308,8 +1332,8 @@ int enc_dense32_head_launch(caelo_ctx *c, const float *f3, int64_t n_patches, in
     caelo_enc_out outs = {};
     outs.base[0] = out;
     outs.per_frame = n_patches;
-    k_enc_head<D1_SPLIT_OF(16384)><<<enc_head_grid(n_patches, 512), 256, 0, s>>>(part, n_patches, np, c->enc32_bd1, c->enc_wd2,
-                                                                c->enc_bd2, group, outs, out_stride, plain, c->faults);
+    k_enc_head_mfma<D1_SPLIT_OF(16384)><<<(unsigned)((n_patches + 15) / 16), 256, 0, s>>>(part, n_patches, np, c->enc32_bd1, (const float4 *)c->enc_wd2q,
+                                                                                     c->enc_bd2, group, outs, out_stride, plain, c->faults);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }
@@ -2334,10 +1358,19 @@ CAELO_API int caelo_encode_profile(caelo_ctx *c, const uint64_t *bits, int64_t n
         unsigned long long rows = 0;  // conv2 tap rows executed (6 v_mfma_f32_16x16x4_f32 each), counted by the kernel itself
         CAELO_HIP(hipMemcpy(&rows, (char *)ws + 8, sizeof(rows), hipMemcpyDeviceToHost));
         // the f32 kernel counts tap rows (6 v_mfma_f32_16x16x4_f32 each), k_enc_stage1x its v_mfma_f32_16x16x32_f16 instructions
-        const bool f32_kernel = getenv("CAELO_ENC_S1") && !strcmp(getenv("CAELO_ENC_S1"), "f32");
+        const bool f32_kernel = c->enc_reference;   // (it does not count: 0 MFMAs reported)
         ms_host[4] = (float)((double)rows * (f32_kernel ? 6.0 : 1.0) / 1e6);
         ms_host[5] = f32_kernel ? 2.0f * 16 * 16 * 4 : 2.0f * 16 * 16 * 32;   // FLOPs of one counted instruction
     }
     for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ev[i]);
     return rc;
+}
+
+// The exact-f32 stage 1 of round 2 (k_enc_stage1: f32-input MFMAs for conv2, conv1 on the VALU) as this context's stage 1: the
+// precision reference the f16 x 2 kernel is measured against (tests, tools/enc_layer_errors.py).  Slower (346 vs 224 us per
+// 24 576 patches); everything behind stage 1 is unchanged.
+CAELO_API int caelo_set_encoder_reference(caelo_ctx *c, int on) {
+    CAELO_REQUIRE(c, "null argument");
+    c->enc_reference = on != 0;
+    return CAELO_OK;
 }

@@ -347,10 +347,10 @@ int match_set(const caelo_pair_set &ps, int ld0, int64_t k0_max, int ld1, int64_
     CAELO_REQUIRE(ps.n >= 1 && ps.n <= CAELO_FB_MAX, "bad pair count");
     CAELO_REQUIRE(dim > 0 && dim <= MT_MAXDIM && ld0 >= dim && ld1 >= dim && k0_max > 0 && k1_max > 0, "bad shape");
     CAELO_REQUIRE(k0_max + 16 * MM_STEP_TILES < MM_IDX_MASK, "too many frame-0 rows (the row index travels in 21 key bits)");
-    // default: the f16 screen + exact certification (match_screen.inc); CAELO_MATCH=f64, a dim > 62 (no room for the two norm
-    // slots in K = 64) or more than 1024 frame-0 descriptors: round 2's all-f64 kernel.  Same pair_idx bit for bit.
-    static const bool f64_only = getenv("CAELO_MATCH") && !strcmp(getenv("CAELO_MATCH"), "f64");
-    if (!f64_only && dim <= 62) {
+    // the f16 screen + exact certification (match_screen.inc) for every descriptor width that leaves room for the two norm slots in
+    // K = 64 (the reference's descriptors are 60 wide); wider ones: the all-f64 kernel.  Same pair_idx bit for bit
+    // (tests/test_gpu_parity.py::test_match_shape_sweep_vs_oracle covers both).
+    if (dim <= 62) {
         const int64_t kpad = ms_pad16(k0_max > k1_max ? k0_max : k1_max);
         bool v4 = (dim % 4 == 0) && (ld0 % 4 == 0) && (ld1 % 4 == 0);
         for (int i = 0; i < ps.n; ++i) v4 = v4 && (((uintptr_t)ps.p[i].f0 | (uintptr_t)ps.p[i].f1) & 15u) == 0;

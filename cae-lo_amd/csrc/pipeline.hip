@@ -27,8 +27,8 @@ namespace {
 // Events that only order work of THIS device (stage hand-offs, the voxel stream's fork / join, the scans' arrival and release):
 // no system-scope fence when they are recorded -- by default hipEventRecord writes the caches back and invalidates them so that
 // the host and other devices see the data, which nobody behind these events needs (CAELO_PIPE_SYSTEM_FENCES=1 restores it).
-// The events a caller's stream waits on (caelo_pipeline_flush, caelo_pipeline_wait_encoded: results read by the host or by
-// another GPU's collective) keep the fence.
+// The events a caller's stream or the host waits on (caelo_pipeline_flush, caelo_pipeline_wait_encoded, and enc_done, which
+// caelo_pipeline_sync_encoded synchronises on: results read by the host or by another GPU's collective) keep the fence.
 inline unsigned local_event_flags() {
     static const bool sys = getenv("CAELO_PIPE_SYSTEM_FENCES") && atoi(getenv("CAELO_PIPE_SYSTEM_FENCES")) != 0;
     return sys ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
@@ -70,6 +70,8 @@ struct caelo_pipeline {
     int pace = 1;         // caelo_pipeline_set_pace
     std::vector<int> plan;  // batch sizes of the next run (caelo_pipeline_expect); empty or used up = full batches
     bool have_last = false;
+    bool failed = false;  // a launch of a batch failed after the batch was counted: its enc_done was never recorded, so nothing may
+                          // pace on or wait for "the batch before" until caelo_pipeline_begin starts a new run
     caelo_frame_job last = {};
     int64_t stat_jobs = 0, stat_issue_ns = 0, stat_batches = 0;
 };
@@ -161,8 +163,17 @@ int issue_batch_impl(caelo_pipeline *p) {
 
 // Whatever happens, nothing of a batch is kept: a caller that logs an error and keeps submitting starts a fresh batch.
 int issue_batch(caelo_pipeline *p) {
+    if (p->failed) {
+        p->pending.clear();
+        caelo_set_error("caelo_pipeline: a batch of this run failed; caelo_pipeline_begin starts a new run");
+        return CAELO_ERR_ARG;
+    }
+    const uint64_t counted = p->n_batches;
     const int rc = issue_batch_impl(p);
-    if (rc) p->pending.clear();
+    if (rc) {
+        p->pending.clear();
+        if (p->n_batches != counted) p->failed = true;   // (a rejected argument leaves no trace; a failed launch does)
+    }
     return rc;
 }
 
@@ -264,7 +275,9 @@ CAELO_API int caelo_pipeline_create(caelo_ctx *c, int batch, int n_buffers, int6
     for (hipEvent_t &e : p->joined) hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
     for (int i = 0; i < n_buffers; ++i) {
         hip_ok(hipEventCreateWithFlags(&p->front_done[i], local_event_flags()), "hipEventCreate");
-        hip_ok(hipEventCreateWithFlags(&p->enc_done[i], local_event_flags()), "hipEventCreate");
+        // enc_done is what caelo_pipeline_sync_encoded blocks the HOST on before the rows are read back or handed to another
+        // GPU's collective: it keeps the system-scope release (the other internal events order this device's work only)
+        hip_ok(hipEventCreateWithFlags(&p->enc_done[i], hipEventDisableTiming), "hipEventCreate");
         hip_ok(hipMalloc((void **)&p->bits[i], (size_t)batch * CAELO_FRAME_BUF_BYTES), "hipMalloc");
     }
     const size_t xws = (size_t)caelo_extract_ws_bytes(), mws = (size_t)caelo_match_ws_bytes(CAELO_MAX_KEYPTS), rws = (size_t)caelo_ransac_ws_bytes();
@@ -306,6 +319,12 @@ CAELO_API int caelo_pipeline_begin(caelo_pipeline *p, void *stream) {
     CAELO_REQUIRE(p, "null argument");
     p->pending.clear();
     p->since_begin = 0;
+    if (p->failed) {   // the stage streams may hold half a batch: drain them, forget the chain
+        for (hipStream_t s : {p->sF, p->sE, p->sP, p->sV})
+            if (s) (void)hipStreamSynchronize(s);
+        p->failed = false;
+        p->have_last = false;
+    }
     CAELO_HIP(hipEventRecord(p->begun, caelo_stream(stream)));
     for (hipStream_t s : {p->sF, p->sE, p->sP}) CAELO_HIP(hipStreamWaitEvent(s, p->begun, 0));
     return CAELO_OK;
@@ -316,6 +335,8 @@ CAELO_API int caelo_pipeline_begin(caelo_pipeline *p, void *stream) {
 // hint spreads the frames evenly over ceil(n / batch) batches, the smaller ones first: 20 frames go 6 + 7 + 7 (9.8 k frames/s;
 // 4 + 8 + 8: 9.5 k; 8 + 8 + 4: 9.5 k; 4 x 5: 9.0 k; 2 + 8 + 8 + 2 costs more in launch sets than it gains).  Without the hint
 // every batch is full and the remainder goes last.  Results do not depend on the plan (tests/test_gpu_parity.py).
+CAELO_API int caelo_pipeline_get_pace(const caelo_pipeline *p) { return p ? p->pace : 0; }
+
 CAELO_API int caelo_pipeline_set_pace(caelo_pipeline *p, int lag) {
     CAELO_REQUIRE(p, "null argument");
     CAELO_REQUIRE(lag >= -1 && lag < p->n_buffers, "pace: -1 (the issuing thread never waits) .. buffers - 1");
@@ -416,6 +437,7 @@ CAELO_API int caelo_pipeline_wait_encoded(caelo_pipeline *p, void *stream) {
 CAELO_API int caelo_pipeline_sync_encoded(caelo_pipeline *p, int lag) {
     CAELO_REQUIRE(p, "null argument");
     CAELO_REQUIRE(lag >= 0 && lag < p->n_buffers, "lag must be below the number of hand-off buffers");
+    CAELO_REQUIRE(!p->failed, "a batch of this run failed: its rows were never written");
     if (p->since_begin <= lag) return CAELO_OK;   // nothing that old in this run
     const uint64_t k = p->n_batches - 1 - (uint64_t)lag;
     CAELO_HIP(hipEventSynchronize(p->enc_done[(int)(k % (uint64_t)p->n_buffers)]));

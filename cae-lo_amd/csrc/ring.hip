@@ -189,53 +189,11 @@ CAELO_API int caelo_project(caelo_ctx *c, const float *pc, int64_t n, float *rin
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: response layer, fused conv3x3(3->32)+relu+conv1x1(32->8)+relu, one thread per pixel.
+// K2: response layer, fused conv3x3(3->32)+relu+conv1x1(32->8)+relu.
 // Summation order is the canonical one documented in oracle/caelo_oracle.c (orc_respond) so the
 // response image -- and therefore the keypoint indices -- are bit-identical to the oracle's.
-// Weights are indexed uniformly across the wave -> scalar loads.
+// (Rounds 1-2 ran it one thread per pixel on the VALU, 37 us per 8 frames; the matrix-pipe form below is bit-identical.)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_respond(const caelo_frame_set fs, int in_w, int in_c, const float *__restrict__ wts, int row0) {
-    const float *__restrict__ in = fs.f[blockIdx.z].ring;
-    float *__restrict__ resp = fs.f[blockIdx.z].resp;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y + row0;
-    if (x >= CAELO_NET_W) return;
-    const float *w1 = wts, *b1 = wts + 864, *w2 = wts + 896, *b2 = wts + 1152;
-    float h[32];
-#pragma unroll
-    for (int c = 0; c < 32; ++c) h[c] = b1[c];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int yy = y + ky - 1;
-        if (yy < 0 || yy >= CAELO_NET_H) continue;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int xx = x + kx - 1;
-            if (xx < 0 || xx >= CAELO_NET_W) continue;
-            const float *px = in + ((int64_t)yy * in_w + xx) * in_c;
-#pragma unroll
-            for (int ci = 0; ci < 3; ++ci) {
-                const float v = px[ci];
-                const float *w = w1 + ((ky * 3 + kx) * 3 + ci) * 32;
-#pragma unroll
-                for (int c = 0; c < 32; ++c) h[c] = fmaf(v, w[c], h[c]);
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 32; ++c) h[c] = h[c] > 0.0f ? h[c] : 0.0f;
-    float o[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        float a = b2[k];
-#pragma unroll
-        for (int c = 0; c < 32; ++c) a = fmaf(h[c], w2[c * 8 + k], a);
-        o[k] = a > 0.0f ? a : 0.0f;
-    }
-    float4 *dst = (float4 *)(resp + ((int64_t)y * CAELO_NET_W + x) * 8);
-    dst[0] = make_float4(o[0], o[1], o[2], o[3]);
-    dst[1] = make_float4(o[4], o[5], o[6], o[7]);
-}
 
 // The same layer on the f32 matrix pipe.  v_mfma_f32_16x16x4_f32 adds its four products to the accumulator as a chain of fused
 // multiply-adds in ascending k (tools/micro/mfma_f32_order.hip: 0 of 1 M results differ from fmaf(a3,b3,fmaf(a2,b2,fmaf(a1,b1,
@@ -405,10 +363,7 @@ int ring_respond_launch(caelo_ctx *c, const float *in, int in_w, int in_c, float
 // either side; the staged entry point computes all 64)
 int ring_respond_set(caelo_ctx *c, const caelo_frame_set &fs, int in_w, int in_c, hipStream_t s, int row0, int rows) {
     static_assert(CAELO_NET_W % RESP_BPX == 0, "k_respond_mfma has no partial blocks");
-    // CAELO_RESPOND=valu: the one-thread-per-pixel kernel (bit-identical; the timing reference)
-    static const bool valu = getenv("CAELO_RESPOND") && !strcmp(getenv("CAELO_RESPOND"), "valu");
-    if (valu) k_respond<<<dim3((CAELO_NET_W + 255) / 256, rows, fs.n), 256, 0, s>>>(fs, in_w, in_c, c->resp_w, row0);
-    else {
+    {
         // Waves per row.  The dispatcher spreads a grid evenly over the 1024 SIMDs (tools/micro/wave_placement.hip), so the grid
         // should come close to a multiple of 1024 waves with equal work each: 8 frames x 64 rows x 8 = 4096 waves of 7 blocks (2048
         // waves of 64-pixel blocks left 109 SIMDs with three waves and 109 with one: the matrix pipe of the former set the time).
@@ -674,7 +629,7 @@ __global__ void __launch_bounds__(SEL_THREADS) k_kp_gather(const caelo_frame_set
 
 // The single-workgroup form: everything in one workgroup of 1024 threads (histogram, cut bin -- or an 8-bit radix select over
 // the full keys when the bins cannot split the candidates --, gather, bitonic sort, output).  k_kp_emit's workgroup 0 calls it
-// for the frames the three kernels above leave over; k_kp_select is that alone (CAELO_KP_SELECT=single).
+// for the frames the three kernels above leave over; round 2 ran it alone as k_kp_select (34 us per 8 frames).
 __device__ void kp_select_one_workgroup(const caelo_frame_dev &F, int ring_w, int ring_c) {
     const unsigned long long *__restrict__ cand = F.cand;
     const int32_t *cand_count = F.cand_count;
@@ -797,10 +752,6 @@ __device__ void kp_select_one_workgroup(const caelo_frame_dev &F, int ring_w, in
     }
 }
 
-__global__ void __launch_bounds__(SEL_THREADS) k_kp_select(const caelo_frame_set fs, int ring_w, int ring_c) {
-    kp_select_one_workgroup(fs.f[blockIdx.z], ring_w, ring_c);
-}
-
 __global__ void __launch_bounds__(SEL_THREADS) k_kp_emit(const caelo_frame_set fs, int ring_w, int ring_c) {
     const caelo_frame_dev &F = fs.f[blockIdx.z];
     const int M = *F.cand_count, tid = threadIdx.x;
@@ -864,17 +815,11 @@ int ring_keypoints_set(const caelo_frame_set &fs, int ring_w, int ring_c, int cn
     dim3 grid(CAELO_NET_W / KS_COLS, 48 / KS_ROWS, fs.n);
     k_kp_score<<<grid, 256, 0, s>>>(fs, ring_w, ring_c, cnt_w);
     CAELO_LAUNCH_CHECK();
-    // CAELO_KP_SELECT=single: the one-workgroup kernel alone (bit-identical; the timing reference)
-    static const bool single = getenv("CAELO_KP_SELECT") && !strcmp(getenv("CAELO_KP_SELECT"), "single");
-    if (!single) {
-        k_kp_hist<<<dim3(KP_WGS, 1, fs.n), SEL_THREADS, 0, s>>>(fs);
-        CAELO_LAUNCH_CHECK();
-        k_kp_gather<<<dim3(KP_WGS, 1, fs.n), SEL_THREADS, 0, s>>>(fs);
-        CAELO_LAUNCH_CHECK();
-        k_kp_emit<<<dim3(SEL_N / 64, 1, fs.n), SEL_THREADS, 0, s>>>(fs, ring_w, ring_c);
-    } else {
-        k_kp_select<<<dim3(1, 1, fs.n), SEL_THREADS, 0, s>>>(fs, ring_w, ring_c);
-    }
+    k_kp_hist<<<dim3(KP_WGS, 1, fs.n), SEL_THREADS, 0, s>>>(fs);
+    CAELO_LAUNCH_CHECK();
+    k_kp_gather<<<dim3(KP_WGS, 1, fs.n), SEL_THREADS, 0, s>>>(fs);
+    CAELO_LAUNCH_CHECK();
+    k_kp_emit<<<dim3(SEL_N / 64, 1, fs.n), SEL_THREADS, 0, s>>>(fs, ring_w, ring_c);   // (falls back to the one-workgroup select on > 2048 tied keys)
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;
 }

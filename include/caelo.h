@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CAELO_ABI_VERSION 1
+#define CAELO_ABI_VERSION 2   /* 2: caelo_match workspace sized by max(k0, k1) and holds the fragment image; caelo_encode_profile writes 6 floats */
 
 /* geometry fixed by the reference: SphericalRing.py:28-58, Voxel.py:15-52 */
 #define CAELO_RING_H 69
@@ -85,6 +85,11 @@ int caelo_set_encoder_weights(caelo_ctx *ctx, const float *w1_host /*[27][1][8]*
                               const float *w3_host /*[27][16][32]*/, const float *b3_host,
                               const float *wd1_host /*[2048][200]*/, const float *bd1_host,
                               const float *wd2_host /*[200][20]*/, const float *bd2_host);
+/* on != 0: this context's encoder runs conv1 / conv2 with the exact-f32 kernel of round 2 instead of the default (f32 products
+ * from 2-way f16 splits on the f16 matrix pipe) -- the precision reference of the tests and of tools/enc_layer_errors.py; slower.
+ * An explicit, per-context choice: the library reads NO environment variable that changes arithmetic (no reference counterpart:
+ * PatchEncoder.predict, Match.py:131-133, has one arithmetic). */
+int caelo_set_encoder_reference(caelo_ctx *ctx, int on);
 
 /* ProjectPC2SphericalRing  (SphericalRing.py:72-94)
  * pc [n][4] f32 -> ring [69][1800][5] f32, counter [69][1800] i32.  workspace: winner [69*1800] i32. */
@@ -349,6 +354,7 @@ int caelo_pipeline_sync_encoded(caelo_pipeline *p, int lag);
  * unsatisfied in the hardware queues cost throughput, and a thread running far ahead leaves many: 16.5 k -> 17.3 k frames/s on
  * a 20-batch run.  A caller that paces itself (caelo_pipeline_sync_encoded between its own work) turns this off. */
 int caelo_pipeline_set_pace(caelo_pipeline *p, int lag);
+int caelo_pipeline_get_pace(const caelo_pipeline *p);   /* the pacing in effect (the library's default until set) */
 /* host-side counters since the last call (then reset): out_host[6] = jobs, ns the calling thread spent issuing their
  * launches, batches launched, batch size, hand-off buffers, HIP streams used */
 /* Optional hint before caelo_pipeline_begin: the run will submit n_frames jobs.  If that is not a multiple of the batch size, the

@@ -1181,33 +1181,40 @@ def _variant_hashes(env):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("base,env", [({"CAELO_ENC_S1": "f32"}, {"CAELO_ENC_WAVE": "1"}), ({"CAELO_ENC_S1": "f32"}, {"CAELO_ENC_SPLIT": "1"}),
-                                      ({}, {"CAELO_D1_PLAIN": "1"}), ({}, {"CAELO_D1_WIDE_FROM": "1"}),
-                                      ({}, {"CAELO_RESPOND": "valu"}), ({}, {"CAELO_KP_SELECT": "single"})])
-def test_stage1_variants_are_bit_identical(engine, base, env):
-    """Families of kernels that promise each other's results bit for bit (same sums in the same order):
-    * round 2's f32-input stage 1 (CAELO_ENC_S1=f32), its one-wavefront-per-patch form k_enc_stage1w and the two-kernel
-      form k_enc_conv1 + k_enc_conv2 -- one P2;
-    * k_enc_dense1 (two barriers per stage) and the software-pipelined k_enc_dense1p (the default), whose 128-row instance
-      (CAELO_D1_WIDE_FROM=1: also for one frame) must equal the 64-row one -- one set of partial sums;
-    * the response layer on the f32 matrix pipe (k_respond_mfma, the default) and one thread per pixel (CAELO_RESPOND=valu);
-    * the key point selection spread over workgroups (default) and in one workgroup (CAELO_KP_SELECT=single).
-    The frame rows (descriptors + key points) of two scans are hashed in one process per variant.  (The default stage 1,
-    k_enc_stage1x, evaluates its products as f16 x 2 splits: it is compared with the f32 family by tolerance in
-    test_stage1x_agrees_with_the_f32_kernel and layer by layer in test_encoder_layer_error_budget.)"""
+def test_dense1_tile_sizes_are_bit_identical(engine):
+    """The one tuning switch left in the encoder that picks between two instances of a kernel: k_enc_dense1p on 64-row tiles
+    (launches below four frames) and on 128-row tiles (CAELO_D1_WIDE_FROM=1: also for one frame) must give the same partial sums,
+    hence the same frame rows bit for bit.  (Round 4 removed the other kernel families -- one wavefront per patch, conv1 / conv2 as
+    two kernels, the two-barrier Dense(200), the VALU response layer, the one-workgroup key point selection as a default, the
+    one-patch-per-wavefront head -- together with their environment switches; the exact-f32 stage 1 is chosen per context,
+    test_stage1x_agrees_with_the_f32_kernel.)"""
     import hashlib
     import torch
     from caelo import synth
-    if base:
-        want = _variant_hashes(base)
-    else:
-        want = []
-        for i in range(2):
-            f = engine.extract(torch.from_numpy(synth.make_scan(i, quantum=1e-3)).to(engine.device))
-            torch.cuda.synchronize()
-            want.append(hashlib.sha256(f.rows.cpu().numpy().tobytes()).hexdigest())
-    got = _variant_hashes(dict(base, **env))
+    want = []
+    for i in range(2):
+        f = engine.extract(torch.from_numpy(synth.make_scan(i, quantum=1e-3)).to(engine.device))
+        torch.cuda.synchronize()
+        want.append(hashlib.sha256(f.rows.cpu().numpy().tobytes()).hexdigest())
+    got = _variant_hashes({"CAELO_D1_WIDE_FROM": "1"})
     assert len(want) == 2 and got == want
+
+
+@pytest.mark.gpu
+def test_library_reads_no_arithmetic_switch_from_the_environment():
+    """the shipped library reads no environment variable that changes arithmetic.  What it still reads are
+    scheduling / tuning / diagnostic knobs; every one of them is listed here, and the kernels' results under them are covered by
+    the bit-identity tests of the pipeline (pacing, plans, streams) and of the Dense(200) tile size."""
+    import re
+    src = os.path.join(os.path.dirname(GOLDEN), "..", "cae-lo_amd", "csrc")
+    seen = set()
+    for fn in os.listdir(src):
+        if fn.endswith((".hip", ".inc", ".h")):
+            seen |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(os.path.join(src, fn)).read()))
+    allowed = {"CAELO_D1_WIDE_FROM", "CAELO_S1X_SLOTS", "CAELO_ENC_YIELD", "CAELO_DEDUP_HASH_BITS", "CAELO_NO_DEDUP",
+               "CAELO_PIPE_SYSTEM_FENCES", "CAELO_PIPE_VERBOSE", "CAELO_PIPE_PACE", "CAELO_PIPE_STREAMS", "CAELO_PIPE_ENC_PRIO",
+               "CAELO_PIPE_VOX_STREAM", "CAELO_PIPE_PLAN", "GPU_MAX_HW_QUEUES"}
+    assert seen <= allowed, sorted(seen - allowed)
 
 
 # what tools/enc_layer_errors.py measures on MI355X for the default kernels, x 3 (absolute, against the f32 CPU oracle, which is
@@ -1259,49 +1266,22 @@ def test_encoder_invariant_counts_broken_descriptors():
 
 @pytest.mark.gpu
 def test_stage1x_agrees_with_the_f32_kernel(engine):
-    """k_enc_stage1x (f16 x 2 products, conv1 on the matrix cores) against round 2's exact-f32 k_enc_stage1: the same P2 to
-    1e-6 on every patch of the golden frame (run in a second process with CAELO_ENC_S1=f32)."""
-    import subprocess
+    """k_enc_stage1x (f16 x 2 products, conv1 on the matrix cores) against the exact-f32 k_enc_stage1 kept as the precision
+    reference (caelo_set_encoder_reference, a per-context choice): the same P2 to 1e-6 on every patch of the golden frame, the
+    descriptors behind it within the same bound; switching back restores the default bit for bit."""
     import torch
     bits = np.ascontiguousarray(np.load(os.path.join(GOLDEN, "frame_q0.npz"))["patch_bits"].reshape(-1, 64))
-    p2 = engine.encode_layers(torch.from_numpy(bits.view(np.int64)).to(engine.device))[0].cpu().numpy()
-    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import caelo; from caelo.engine import Engine; e = Engine(device=0);"
-              "b = np.ascontiguousarray(np.load(%r)['patch_bits'].reshape(-1, 64));"
-              "p2 = e.encode_layers(torch.from_numpy(b.view(np.int64)).to(e.device))[0]; torch.cuda.synchronize();"
-              "np.save(sys.argv[1], p2.cpu().numpy())") % (os.path.join(repo, "cae-lo_amd"), os.path.join(GOLDEN, "frame_q0.npz"))
-    import tempfile
-    with tempfile.TemporaryDirectory() as td:
-        path = os.path.join(td, "p2.npy")
-        out = subprocess.run([sys.executable, "-c", script, path], env=dict(os.environ, CAELO_ENC_S1="f32"), capture_output=True, text=True, timeout=600)
-        assert out.returncode == 0, out.stderr[-2000:]
-        ref = np.load(path)
-    assert ref.shape == p2.shape and np.abs(ref - p2).max() <= 1e-6, np.abs(ref - p2).max()
-
-
-@pytest.mark.gpu
-def test_head_kernels_agree(engine):
-    """k_enc_head_mfma (Dense(20) of 16 patches per workgroup on the f32 matrix cores: four ascending chains over the hidden units)
-    against the one-patch-per-wavefront k_enc_head (a tree): the same descriptors to 1e-6 on every patch of the golden frame (second
-    process with CAELO_ENC_HEAD=wave); the hidden layer in front of them is bit-identical."""
-    import subprocess
-    import tempfile
-    import torch
-    bits = np.ascontiguousarray(np.load(os.path.join(GOLDEN, "frame_q0.npz"))["patch_bits"].reshape(-1, 64))
-    lay = engine.encode_layers(torch.from_numpy(bits.view(np.int64)).to(engine.device))
-    pre, out = lay[2].cpu().numpy(), lay[3].cpu().numpy()
-    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import caelo; from caelo.engine import Engine; e = Engine(device=0);"
-              "b = np.ascontiguousarray(np.load(%r)['patch_bits'].reshape(-1, 64));"
-              "l = e.encode_layers(torch.from_numpy(b.view(np.int64)).to(e.device)); torch.cuda.synchronize();"
-              "np.savez(sys.argv[1], pre=l[2].cpu().numpy(), out=l[3].cpu().numpy())") % (os.path.join(repo, "cae-lo_amd"), os.path.join(GOLDEN, "frame_q0.npz"))
-    with tempfile.TemporaryDirectory() as td:
-        path = os.path.join(td, "h.npz")
-        r = subprocess.run([sys.executable, "-c", script, path], env=dict(os.environ, CAELO_ENC_HEAD="wave"), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        ref = np.load(path)
-        assert np.array_equal(ref["pre"], pre)
-        assert ref["out"].shape == out.shape and np.abs(ref["out"] - out).max() <= 1e-6, np.abs(ref["out"] - out).max()
+    t = torch.from_numpy(bits.view(np.int64)).to(engine.device)
+    lay = [x.cpu().numpy() for x in engine.encode_layers(t)]
+    try:
+        engine.set_encoder_reference(True)
+        ref = [x.cpu().numpy() for x in engine.encode_layers(t)]
+    finally:
+        engine.set_encoder_reference(False)
+    again = [x.cpu().numpy() for x in engine.encode_layers(t)]
+    assert ref[0].shape == lay[0].shape and 0 < np.abs(ref[0] - lay[0]).max() <= 1e-6, np.abs(ref[0] - lay[0]).max()
+    assert np.abs(ref[3] - lay[3]).max() <= 2e-6
+    assert all(np.array_equal(a, b) for a, b in zip(lay, again))
 
 
 @pytest.mark.gpu

@@ -13,6 +13,8 @@ import oracle as orc
 from caelo.engine import Engine
 
 eng = Engine(device=0)
+if os.environ.get("CAELO_ENC_S1") == "f32":   # (read HERE, by the tool: the library has no environment switch for arithmetic)
+    eng.set_encoder_reference(True)
 _, enc_m = orc.load_models(os.path.join(REPO, "weights", "SphericalRingPCRespondLayer.h5"), os.path.join(REPO, "weights", "EncoderModel4VoxelPatch.h5"))
 bits = np.ascontiguousarray(np.load(os.path.join(REPO, "tests", "golden", "frame_q0.npz"))["patch_bits"].reshape(-1, 64))
 o_p2, o_f3, o_h, o_out = enc_m.predict_layers(bits)

@@ -9,6 +9,8 @@ from caelo import synth
 import caelo; caelo.configure_runtime()
 from caelo.engine import Engine
 eng = Engine()
+if os.environ.get("CAELO_ENC_S1") == "f32":   # (read HERE, by the tool: the library has no environment switch for arithmetic)
+    eng.set_encoder_reference(True)
 parts = []
 for i in range(6):
     pc = torch.from_numpy(synth.make_scan(i, quantum=1e-3)).to(eng.device)

@@ -9,6 +9,8 @@ import caelo; caelo.configure_runtime()
 from caelo.engine import Engine
 
 eng = Engine()
+if os.environ.get("CAELO_ENC_S1") == "f32":   # (read HERE, by the tool: the library has no environment switch for arithmetic)
+    eng.set_encoder_reference(True)
 pool = [torch.from_numpy(synth.make_scan(i, quantum=1e-3)).to(eng.device) for i in range(8)]
 bits = [eng.patches(eng.voxelize(p)[0], eng.extract(p).key_pts.contiguous())[0] for p in pool]
 for frames in (1, 8):

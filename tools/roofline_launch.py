@@ -9,6 +9,8 @@ from caelo import synth
 import caelo; caelo.configure_runtime()
 from caelo.engine import Engine
 eng = Engine()
+if os.environ.get("CAELO_ENC_S1") == "f32":   # (read HERE, by the tool: the library has no environment switch for arithmetic)
+    eng.set_encoder_reference(True)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 1      # frames per launch: 8 = the pipeline's launch shape (bench.py's headline roofline)
 parts = []

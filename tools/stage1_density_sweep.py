@@ -9,6 +9,8 @@ import numpy as np, torch
 import caelo; caelo.configure_runtime()
 from caelo.engine import Engine
 eng = Engine()
+if os.environ.get("CAELO_ENC_S1") == "f32":   # (read HERE, by the tool: the library has no environment switch for arithmetic)
+    eng.set_encoder_reference(True)
 n = 24576
 rs = np.random.RandomState(3)
 print("%-10s %10s %14s" % ("set share", "launch us", "MFMAs / patch"))
