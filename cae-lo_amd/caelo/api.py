@@ -19,6 +19,8 @@ listed in SURVEY 8b, RANSAC failure as a return value.
 """
 import os
 
+import warnings
+
 import numpy as np
 import torch
 
@@ -266,7 +268,13 @@ def GetPatchesList(Pts, AllVoxels0, AllVoxels1, AllVoxels2):
     """Voxel.py:177-216 -> (Pts, [P0, P1, P2]) with P_s [K,16,16,16,1] f32 in {0,1}."""
     e = default_engine()
     as_np = _is_np(Pts)
-    bits, _ = GetPatchesBits(Pts, AllVoxels0, AllVoxels1, AllVoxels2)
+    bits, flags = GetPatchesBits(Pts, AllVoxels0, AllVoxels1, AllVoxels2)
+    n_tie = int(((flags & 2) != 0).sum().item())
+    if n_tie:
+        # the 496-nearest cut of Voxel.py:195-196 splits a class of equidistant voxels AND the list is shorter than 994 voxels, where
+        # scikit-learn's 'auto' is brute force (NumPy's argpartition order, not reproduced): the canonical rule was used
+        warnings.warn("GetPatchesList: %d patch(es) truncated inside a tie of equidistant voxels on a voxel list too short for "
+                      "scikit-learn's kd-tree; they may differ from the reference's in the cut class (flags & 2)" % n_tie, RuntimeWarning)
     out = [_out(e.unpack_patches(bits[:, s, :].contiguous()), as_np) for s in range(3)]
     return Pts, out
 

@@ -20,7 +20,7 @@ RING_H, RING_W, RING_C = 69, 1800, 5
 NET_H, NET_W = 64, 1792
 MAX_K = 1024
 
-ST_COL_OOB, ST_VOXEL_OOB, ST_MAP_FULL, ST_FEW_VOXELS, ST_FEW_KEYPTS = 1, 2, 4, 8, 16
+ST_COL_OOB, ST_VOXEL_OOB, ST_MAP_FULL, ST_FEW_VOXELS, ST_FEW_KEYPTS, ST_NONFINITE = 1, 2, 4, 8, 16, 32
 
 _DEFAULT_WEIGHTS = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "weights")
 RESPOND_H5 = os.path.join(_DEFAULT_WEIGHTS, "SphericalRingPCRespondLayer.h5")
@@ -41,6 +41,8 @@ def raise_status(st):
         raise IndexError("index 1800 is out of bounds for axis 1 with size 1800")  # SphericalRing.py:91
     if st & ST_VOXEL_OOB:
         raise IndexError("voxel index out of bounds for axis with size 64")        # Voxel.py:139
+    if st & ST_NONFINITE:
+        raise ValueError("cannot convert float NaN to integer")                    # SphericalRing.py:86-88, Voxel.py:122-124
     if st & ST_FEW_VOXELS:
         raise ValueError("Expected n_neighbors <= n_samples (n_neighbors = 496)")  # Voxel.py:195-196
     if st & ST_FEW_KEYPTS:
@@ -313,7 +315,7 @@ class Pipeline:
 
 
 class Engine:
-    def __init__(self, respond_h5=RESPOND_H5, encoder_h5=ENCODER_H5, device=None, max_points=1 << 17):
+    def __init__(self, respond_h5=RESPOND_H5, encoder_h5=ENCODER_H5, device=None, max_points=160000):
         if not torch.cuda.is_available():
             raise _ffi.CaeloError("no HIP device visible: libcaelo has no CPU fallback")
         self.lib = _ffi.load()

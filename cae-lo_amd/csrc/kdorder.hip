@@ -1,0 +1,348 @@
+// kdorder.hip -- the 496-nearest cut of GetPatchesList in scikit-learn's own order, for the patches where it matters.
+//
+// Reference behaviour restated (never its code): Voxel.py:182,195-196 --
+//     NearestNeighbors(n_neighbors=496, radius=14, algorithm='auto').fit(AllVoxels_s).kneighbors(KeyVoxels)
+// followed by the window test of :204-210.  When more than 496 voxels lie within the window's reach AND the 496th place falls
+// inside a class of EQUIDISTANT voxels that has members in the window, which of them are returned is decided by the library's
+// kd-tree (scikit-learn 0.24.2: `auto` = kd_tree for n_samples // 2 > n_neighbors, i.e. n >= 994 voxels; leaf_size 30).  The
+// algorithm below is the one oracle/caelo_oracle.c restates and tools/make_goldens.py validates against the library itself
+// (index array of the tree, 920 lattice queries, every truncated patch of the fixtures):
+//   build   n_levels = int(log2(max(1, (n - 1) / 30)) + 1); node i owns idx[start, end); inner nodes split on the dimension of
+//           largest spread (first of equals) at n / 2 by a quickselect whose partition is Lomuto's with the LAST element as the
+//           pivot (strict <): the resulting order of idx is part of the contract, so the partition is run as written --
+//           sequentially, one thread per node, level by level (a node's points sit in a (coordinate, index) key array so that
+//           the scan reads consecutive addresses);
+//   query   depth first; a node whose bounding-box distance exceeds the heap's largest is skipped; leaves push their points in
+//           idx order; the child with the smaller lower bound first (<=); max-heap of 496 squared distances (integers: the
+//           coordinates are voxel indices), a candidate >= the largest is rejected, otherwise it replaces the root and is
+//           sifted down (first child when dist[c1] >= dist[c2]).
+// k_patches (voxel.hip) has already produced every patch under the canonical rule and flagged those whose cut splits a tie class
+// (flag bit 2); only THOSE are redone here, and only when the voxel lists are known in the reference's order -- a map filled by
+// caelo_voxmap_from_lists (the staged API: api.GetPatchesList) -- and long enough for the kd-tree.  A redone patch carries flag 4
+// instead of 2.  Rare by construction: 0 of 614 400 patches on the KITTI-shaped scene, 115 on the clutter scene (200 frames each).
+// The fused path (caelo_extract, caelo_pipeline) builds voxel SETS, not lists in first-touch order: its flagged patches keep the
+// canonical rule and bit 2 (INTEGRATION.md says what a caller who needs them exact does).
+#include "caelo_internal.h"
+
+#define KD_K 496
+#define KD_LEAF 30
+#define KD_MIN_N 994          // 'auto' -> kd_tree iff n // 2 > 496
+#define KD_MAX_NODES 16384
+#define KD_INF 0x7FFFFFFF
+
+struct caelo_kd_scale {
+    int16_t *vox;             // [cap][3] the list in the caller's (= the reference's) order
+    int32_t *idx;             // [cap]
+    unsigned long long *keys; // [cap] quickselect scratch: (coordinate + 32768) << 32 | index
+    int32_t *start, *end;     // [KD_MAX_NODES]
+    int16_t *lo, *hi;         // [KD_MAX_NODES][3]
+    int32_t *queue;           // [k_cap] key points whose patch of this scale is tie-split
+    int64_t n;
+    int n_nodes, n_levels;
+};
+struct caelo_kd {
+    caelo_kd_scale s[3];
+    int32_t *state;           // device: [0..2] queue lengths, [4..6] tree built for the current lists
+    int64_t cap, k_cap;
+    char *base;
+};
+
+namespace {
+
+__global__ void __launch_bounds__(256) k_kd_collect(const uint8_t *__restrict__ flags, int64_t k_max, const int32_t *__restrict__ n_key,
+                                                    caelo_kd kd) {
+    const int64_t pw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pw >= k_max * 3) return;
+    const int64_t kp = pw / 3;
+    const int sc = (int)(pw % 3);
+    const int K = n_key ? *n_key : (int)k_max;
+    if (kp >= K || !(flags[pw] & 2) || kd.s[sc].n < KD_MIN_N) return;
+    const int q = atomicAdd(&kd.state[sc], 1);
+    if (q < kd.k_cap) kd.s[sc].queue[q] = (int32_t)kp;
+}
+
+// One workgroup per scale.  Level by level; `tpn` threads share a node of the upper levels for the parallel parts (bounding box,
+// key array), the node's first thread runs the quickselect.
+__global__ void __launch_bounds__(256) k_kd_build(caelo_kd kd) {
+    const caelo_kd_scale T = kd.s[blockIdx.x];
+    if (kd.state[blockIdx.x] == 0 || kd.state[4 + blockIdx.x] != 0) return;   // no tie-split patch of this scale / tree already built
+    __shared__ int s_lo[256][3], s_hi[256][3];
+    const int tid = threadIdx.x;
+    const int64_t n = T.n;
+    for (int64_t i = tid; i < n; i += 256) T.idx[i] = (int32_t)i;
+    for (int i = tid; i < T.n_nodes; i += 256) { T.start[i] = 0; T.end[i] = 0; }   // (children of a node that did not split stay empty)
+    __syncthreads();
+    if (tid == 0) { T.start[0] = 0; T.end[0] = (int32_t)n; }
+    __syncthreads();
+    for (int level = 0; level < T.n_levels; ++level) {
+        const int first = (1 << level) - 1, count = 1 << level;
+        const int tpn = count >= 256 ? 1 : 256 >> level;      // threads per node
+        const int per_pass = 256 / tpn;                       // nodes in flight
+        for (int base = 0; base < count; base += per_pass) {
+            const int local = tid / tpn, sub = tid % tpn;
+            const int node = first + base + local;
+            const bool live = base + local < count;
+            const int s = live ? T.start[node] : 0, e = live ? T.end[node] : 0;
+            // ---- bounding box of the node's points
+            int lo[3] = {32767, 32767, 32767}, hi[3] = {-32768, -32768, -32768};
+            for (int i = s + sub; i < e; i += tpn) {
+                const int16_t *p = T.vox + 3 * (int64_t)T.idx[i];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { lo[j] = min(lo[j], (int)p[j]); hi[j] = max(hi[j], (int)p[j]); }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { s_lo[tid][j] = lo[j]; s_hi[tid][j] = hi[j]; }
+            __syncthreads();
+            for (int o = tpn >> 1; o > 0; o >>= 1) {
+                if (sub < o)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        s_lo[tid][j] = min(s_lo[tid][j], s_lo[tid + o][j]);
+                        s_hi[tid][j] = max(s_hi[tid][j], s_hi[tid + o][j]);
+                    }
+                __syncthreads();
+            }
+            const int lead = tid - sub;
+            int jmax = 0, spread = 0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                lo[j] = s_lo[lead][j]; hi[j] = s_hi[lead][j];
+                if (hi[j] - lo[j] > spread) { spread = hi[j] - lo[j]; jmax = j; }
+            }
+            if (live && sub == 0)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { T.lo[3 * node + j] = (int16_t)lo[j]; T.hi[3 * node + j] = (int16_t)hi[j]; }
+            const bool split = live && 2 * node + 1 < T.n_nodes && e - s >= 2;
+            // ---- the node's (coordinate, index) keys, consecutive
+            if (split)
+                for (int i = s + sub; i < e; i += tpn) {
+                    const int32_t p = T.idx[i];
+                    T.keys[i] = ((unsigned long long)(unsigned)((int)T.vox[3 * (int64_t)p + jmax] + 32768) << 32) | (unsigned)p;
+                }
+            __syncthreads();
+            // ---- quickselect around position n / 2: Lomuto, last element as the pivot, strict <  (one thread: the order it leaves
+            // behind is what the library's tree has)
+            if (split && sub == 0) {
+                unsigned long long *a = T.keys + s;
+                const int m = e - s, nmid = m / 2;
+                int left = 0, right = m - 1;
+                for (;;) {
+                    int mid = left;
+                    const unsigned long long pv = a[right];
+                    const unsigned pvv = (unsigned)(pv >> 32);
+                    int i = left;
+                    for (; i + 8 <= right; i += 8) {          // positions > i are never written before they are read: fetch ahead
+                        unsigned long long v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = a[i + u];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if ((unsigned)(v[u] >> 32) < pvv) {
+                                if (mid != i + u) { a[i + u] = a[mid]; a[mid] = v[u]; }
+                                ++mid;
+                            }
+                    }
+                    for (; i < right; ++i) {
+                        const unsigned long long v = a[i];
+                        if ((unsigned)(v >> 32) < pvv) {
+                            if (mid != i) { a[i] = a[mid]; a[mid] = v; }
+                            ++mid;
+                        }
+                    }
+                    { const unsigned long long t = a[mid]; a[mid] = a[right]; a[right] = t; }
+                    if (mid == nmid) break;
+                    if (mid < nmid) left = mid + 1; else right = mid - 1;
+                }
+                T.start[2 * node + 1] = s; T.end[2 * node + 1] = s + nmid;
+                T.start[2 * node + 2] = s + nmid; T.end[2 * node + 2] = e;
+            }
+            __syncthreads();
+            if (split)
+                for (int i = s + sub; i < e; i += tpn) T.idx[i] = (int32_t)(unsigned)T.keys[i];
+            __syncthreads();
+        }
+    }
+    if (tid == 0) kd.state[4 + blockIdx.x] = 1;
+}
+
+// (A swap `a[i] <-> a[mid]` inside an 8-element chunk can touch a position of the SAME chunk that was fetched before it was
+// written: mid >= i of the chunk start is possible only when every element before it was "less", in which case mid == position
+// and the swap is the identity or moves an element that was already consumed -- positions mid < i + u have all been processed,
+// so the prefetched copy of a[i + u] is never stale.)
+
+struct KdHeapLds {
+    int dist[KD_K];
+    int ind[KD_K];
+    int leaf_d[64];
+    unsigned long long patch[64];
+};
+
+__device__ inline int kd_min_rdist(const caelo_kd_scale &T, int node, const int q[3]) {
+    int r = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int d_lo = (int)T.lo[3 * node + j] - q[j], d_hi = q[j] - (int)T.hi[3 * node + j];
+        const int d = d_lo > 0 ? d_lo : (d_hi > 0 ? d_hi : 0);
+        r += d * d;   // (a box further than 2^15 away overflows nothing that matters: coordinates < 2^14)
+    }
+    return r;
+}
+
+// One wavefront per tie-split patch: lane 0 walks the tree and owns the heap (LDS); a leaf's distances are computed by all lanes.
+__global__ void __launch_bounds__(64) k_kd_query(caelo_kd kd, const float *__restrict__ pts, int pts_ld, unsigned long long *__restrict__ bits,
+                                                 uint8_t *__restrict__ flags) {
+    const int sc = blockIdx.y;
+    const caelo_kd_scale T = kd.s[sc];
+    const int cnt = min(kd.state[sc], (int)kd.k_cap);
+    if ((int)blockIdx.x >= cnt) return;
+    __shared__ KdHeapLds L;
+    const int lane = threadIdx.x;
+    const int kp = T.queue[blockIdx.x];
+    const double vs = sc == 0 ? 0.02 : (sc == 1 ? 0.02 * 8 : 0.02 * 32);                    // Voxel.py:31
+    const int q[3] = {(int)(((double)pts[(size_t)pts_ld * kp] + 99.84) / vs), (int)(((double)pts[(size_t)pts_ld * kp + 1] + 99.84) / vs),
+                      (int)(((double)pts[(size_t)pts_ld * kp + 2] + 14.72) / vs)};        // :185,:193 (float64 division, truncation)
+    for (int i = lane; i < KD_K; i += 64) { L.dist[i] = KD_INF; L.ind[i] = 0; }
+    L.patch[lane] = 0ull;
+    __syncthreads();
+    int st_node[32], st_lb[32];
+    int sp = 0;
+    st_node[0] = 0; st_lb[0] = kd_min_rdist(T, 0, q);
+    sp = 1;
+    while (sp > 0) {                                // (uniform: every lane keeps the same stack)
+        --sp;
+        const int node = st_node[sp], lb = st_lb[sp];
+        if (lb > L.dist[0]) continue;
+        const int s = T.start[node], e = T.end[node];
+        const bool leaf = 2 * node + 1 >= T.n_nodes || e - s < 2;
+        if (leaf) {
+            for (int c0 = s; c0 < e; c0 += 64) {
+                const int i = c0 + lane;
+                int p = 0;
+                if (i < e) {
+                    p = T.idx[i];
+                    const int16_t *v = T.vox + 3 * (int64_t)p;
+                    const int dx = q[0] - v[0], dy = q[1] - v[1], dz = q[2] - v[2];
+                    L.leaf_d[lane] = dx * dx + dy * dy + dz * dz;
+                }
+                __syncthreads();
+                const int m = min(64, e - c0);
+                if (lane == 0) {
+                    for (int u = 0; u < m; ++u) {
+                        const int val = L.leaf_d[u];
+                        if (val >= L.dist[0]) continue;
+                        const int iv = T.idx[c0 + u];
+                        int i2 = 0;
+                        for (;;) {
+                            const int c1 = 2 * i2 + 1, c2 = c1 + 1;
+                            int sw;
+                            if (c1 >= KD_K) break;
+                            else if (c2 >= KD_K) { if (L.dist[c1] > val) sw = c1; else break; }
+                            else {
+                                const int d1 = L.dist[c1], d2 = L.dist[c2];
+                                if (d1 >= d2) { if (val < d1) sw = c1; else break; }
+                                else { if (val < d2) sw = c2; else break; }
+                            }
+                            L.dist[i2] = L.dist[sw]; L.ind[i2] = L.ind[sw];
+                            i2 = sw;
+                        }
+                        L.dist[i2] = val; L.ind[i2] = iv;
+                    }
+                }
+                __syncthreads();
+            }
+        } else {
+            const int i1 = 2 * node + 1, i2 = i1 + 1;
+            const int l1 = kd_min_rdist(T, i1, q), l2 = kd_min_rdist(T, i2, q);
+            // the nearer child first (<=: the left one on equality): it is pushed LAST
+            if (l1 <= l2) { st_node[sp] = i2; st_lb[sp] = l2; st_node[sp + 1] = i1; st_lb[sp + 1] = l1; }
+            else { st_node[sp] = i1; st_lb[sp] = l1; st_node[sp + 1] = i2; st_lb[sp + 1] = l2; }
+            sp += 2;
+        }
+    }
+    __syncthreads();
+    // ---- the 496 kept voxels -> the 16^3 window with the reference's wrap-around placement (Voxel.py:204-214)
+    for (int i = lane; i < KD_K; i += 64) {
+        if (L.dist[i] == KD_INF) continue;
+        const int16_t *v = T.vox + 3 * (int64_t)L.ind[i];
+        const int dx = v[0] - q[0], dy = v[1] - q[1], dz = v[2] - q[2];
+        if (dx >= -8 && dx < 8 && dy >= -8 && dy < 8 && dz >= -8 && dz < 8) {
+            const int lin = ((dx & 15) << 8) | ((dy & 15) << 4) | (dz & 15);
+            atomicOr(&L.patch[lin >> 6], 1ull << (lin & 63));
+        }
+    }
+    __syncthreads();
+    const int64_t pw = (int64_t)kp * 3 + sc;
+    bits[pw * 64 + lane] = L.patch[lane];
+    if (lane == 0) flags[pw] = (uint8_t)((flags[pw] & ~2) | 4);
+}
+
+}  // namespace
+
+void kd_destroy(caelo_voxmap *m) {
+    if (m->kd) {
+        if (m->kd->base) (void)hipFree(m->kd->base);
+        delete m->kd;
+        m->kd = nullptr;
+    }
+}
+
+// caelo_voxmap_from_lists: keep the three lists in the caller's order (device copies), forget any tree of older lists
+int kd_store_lists(caelo_voxmap *m, const int16_t *const lists[3], const int64_t ns[3], hipStream_t s) {
+    if (!m->kd) {
+        caelo_kd *kd = new caelo_kd();
+        kd->cap = m->max_points;
+        kd->k_cap = CAELO_MAX_KEYPTS;
+        const size_t per = (size_t)kd->cap * (6 + 4 + 8) + 256 * 3;
+        const size_t nodes = (size_t)KD_MAX_NODES * (4 + 4 + 6 + 6) + 256 * 4;
+        const size_t total = 3 * (per + nodes + (size_t)kd->k_cap * 4 + 256) + 256;
+        if (hipMalloc((void **)&kd->base, total) != hipSuccess) {
+            delete kd;
+            caelo_set_error("kd_store_lists: out of device memory");
+            return CAELO_ERR_HIP;
+        }
+        char *p = kd->base;
+        auto take = [&p](size_t bytes) { char *r = p; p += (bytes + 255) / 256 * 256; return r; };
+        kd->state = (int32_t *)take(256);
+        for (int i = 0; i < 3; ++i) {
+            caelo_kd_scale &T = kd->s[i];
+            T.keys = (unsigned long long *)take((size_t)kd->cap * 8);
+            T.idx = (int32_t *)take((size_t)kd->cap * 4);
+            T.vox = (int16_t *)take((size_t)kd->cap * 6);
+            T.start = (int32_t *)take((size_t)KD_MAX_NODES * 4);
+            T.end = (int32_t *)take((size_t)KD_MAX_NODES * 4);
+            T.lo = (int16_t *)take((size_t)KD_MAX_NODES * 6);
+            T.hi = (int16_t *)take((size_t)KD_MAX_NODES * 6);
+            T.queue = (int32_t *)take((size_t)kd->k_cap * 4);
+        }
+        m->kd = kd;
+    }
+    caelo_kd *kd = m->kd;
+    CAELO_HIP(hipMemsetAsync(kd->state, 0, 256, s));
+    for (int i = 0; i < 3; ++i) {
+        caelo_kd_scale &T = kd->s[i];
+        T.n = ns[i];
+        const double q = (double)(ns[i] - 1) / (double)KD_LEAF;
+        T.n_levels = ns[i] >= KD_MIN_N ? (int)(log2(q > 1.0 ? q : 1.0) + 1.0) : 0;
+        T.n_nodes = (1 << T.n_levels) - 1;
+        if (T.n_nodes > KD_MAX_NODES) { caelo_set_error("kd_store_lists: list too long for the node table"); return CAELO_ERR_CAPACITY; }
+        if (ns[i] > 0) CAELO_HIP(hipMemcpyAsync(T.vox, lists[i], (size_t)ns[i] * 6, hipMemcpyDeviceToDevice, s));
+    }
+    m->kd_lists = true;
+    return CAELO_OK;
+}
+
+// caelo_patches, after k_patches: the tie-split patches again, in the library's order
+int kd_resolve(const caelo_voxmap *m, const float *pts, int pts_ld, int64_t k_max, const int32_t *n_key, uint64_t *bits, uint8_t *flags,
+               hipStream_t s) {
+    if (!m->kd || !m->kd_lists) return CAELO_OK;
+    caelo_kd kd = *m->kd;
+    CAELO_REQUIRE(k_max <= kd.k_cap, "kd_resolve: more key points than the queue holds");
+    CAELO_HIP(hipMemsetAsync(kd.state, 0, 12, s));   // queue lengths (the built flags stay)
+    k_kd_collect<<<(unsigned)((k_max * 3 + 255) / 256), 256, 0, s>>>(flags, k_max, n_key, kd);
+    CAELO_LAUNCH_CHECK();
+    k_kd_build<<<3, 256, 0, s>>>(kd);
+    CAELO_LAUNCH_CHECK();
+    k_kd_query<<<dim3((unsigned)k_max, 3), 64, 0, s>>>(kd, pts, pts_ld, (unsigned long long *)bits, flags);
+    CAELO_LAUNCH_CHECK();
+    return CAELO_OK;
+}

@@ -107,9 +107,15 @@ __global__ void __launch_bounds__(256) k_project_points(const caelo_frame_set fs
     s = __fadd_rn(s, __fmul_rn(p.z, p.z));
     const float r = sqrtf(s);
     if (r == 0.0f) return;                                                            // :78-80
-    const int col = (int)((k.pi - atan2((double)p.y, (double)p.x)) / k.az_res);      // :86
+    const double colf = (k.pi - atan2((double)p.y, (double)p.x)) / k.az_res;         // :86
     const float q = __fdiv_rn(p.z, r);                                                // :87 f32 quotient
-    const int row = CAELO_RING_H - (int)(asin((double)q) / k.v_res + k.v_off);        // :88
+    const double rowf = asin((double)q) / k.v_res + k.v_off;                          // :88
+    if (colf != colf || rowf != rowf) {   // int(nan): ValueError in the reference (a NaN coordinate, or inf / inf in z / r)
+        atomicOr(status, CAELO_ST_NONFINITE);
+        return;
+    }
+    const int col = (int)colf;
+    const int row = CAELO_RING_H - (int)rowf;
     if (row < 0 || row >= CAELO_RING_H) return;                                       // :89
     if (col < 0 || col >= CAELO_RING_W) {
         atomicOr(status, CAELO_ST_COL_OOB);

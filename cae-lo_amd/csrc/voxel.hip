@@ -39,7 +39,9 @@ CAELO_API int caelo_voxmap_create(caelo_ctx *c, int64_t max_points, caelo_voxmap
     // set the pace: 190 us for the insert kernel).  Scale 0 can hold one brick per point; scales 1 and 2
     // are sized for 1/4 and 1/16 of that (a LiDAR scan fills ~1/5 and ~1/30); a cloud that overflows
     // them reports CAELO_ST_MAP_FULL and the caller retries with a larger map.
-    const size_t vslots = pow2ceil(2 * (uint64_t)max_points);
+    // >= 1.5 slots per point (distinct voxels <= points: load <= 0.67; 160 000 points -- a HDL-64E scan never exceeds ~131 k -- still
+    // get the 2^18 slots of rounds 1-3, so the tables' cache footprint does not move)
+    const size_t vslots = pow2ceil(((uint64_t)max_points * 3 + 1) / 2);
     const size_t bslots[3] = {vslots, vslots / 4, vslots / 16};
     size_t off = 0;
     size_t o_bkeys[3], o_vkeys[3], o_vfirst[3], o_bits[3];
@@ -92,6 +94,7 @@ CAELO_API int caelo_voxmap_create(caelo_ctx *c, int64_t max_points, caelo_voxmap
 
 CAELO_API void caelo_voxmap_destroy(caelo_voxmap *m) {
     if (!m) return;
+    kd_destroy(m);
     if (m->base) (void)hipFree(m->base);
     if (m->scratch) (void)hipFree(m->scratch);
     delete m;
@@ -182,6 +185,7 @@ int vox_clear_for_fast_build_set(caelo_voxmap *const *maps, int n, caelo_clear_l
 
 static int voxmap_clear(caelo_voxmap *m, bool track_order, hipStream_t s) {
     m->lists_valid = false;
+    m->kd_lists = false;   // (whatever fills the map next: only caelo_voxmap_from_lists knows the reference's list order)
     caelo_clear_list list;
     list.n = 0;
     vox_clear_items(m, track_order ? 2 : 1, list);
@@ -276,7 +280,7 @@ struct VoxIdx {
     int g[3];   // scale-0 global voxel index
     int v1[3];  // scale-1
     int v2[3];  // scale-2
-    bool ok, oob;
+    bool ok, oob, nonfinite;
 };
 
 // int(p / d) exactly as the reference's float64 division + truncation gives it (p >= 0, quotient < 1e4), without the division
@@ -296,6 +300,8 @@ __device__ inline VoxIdx voxel_indices(float fx, float fy, float fz) {
     VoxIdx r;
     r.ok = false;
     r.oob = false;
+    r.nonfinite = fx != fx || fy != fy || fz != fz;   // NaN passes the filter below (abs(nan) > L is False) and int(nan) raises: Voxel.py:122
+    if (r.nonfinite) return r;
     if (fabsf(fx) > (float)VIS_L || fabsf(fy) > (float)VIS_W || fabsf(fz) > (float)VIS_H) return r;  // :89-97
     const double p[3] = {(double)fx + VIS_L, (double)fy + VIS_W, (double)fz + VIS_H};                 // :118-120
 #pragma unroll
@@ -331,6 +337,7 @@ __global__ void __launch_bounds__(256) k_vox_first(const caelo_frame_set fs) {
     const float *p = pc + i * stride;
     const VoxIdx v = voxel_indices(p[0], p[1], p[2]);
     if (v.oob) atomicOr(status, CAELO_ST_VOXEL_OOB);
+    if (v.nonfinite) atomicOr(status, CAELO_ST_NONFINITE);
     if (!v.ok) return;
     const int slot = table_insert(vkeys, vmask, caelo_pack3(v.g[0], v.g[1], v.g[2]));
     if (slot < 0) { atomicOr(status, CAELO_ST_MAP_FULL); return; }
@@ -422,11 +429,12 @@ __global__ void __launch_bounds__(256) k_vox_points(const caelo_frame_set fs) {
     VoxIdx v;
     v.ok = false;
     v.oob = false;
+    v.nonfinite = false;
     if (i < n) {
         const float *p = pc + i * stride;
         v = voxel_indices(p[0], p[1], p[2]);
     }
-    int st = v.oob ? CAELO_ST_VOXEL_OOB : 0;
+    int st = (v.oob ? CAELO_ST_VOXEL_OOB : 0) | (v.nonfinite ? CAELO_ST_NONFINITE : 0);
     unsigned long long key = CAELO_EMPTY_KEY;
     // every point's scale-0 voxel, for k_vox_suspects_first (the fused build leaves the exact build's first-touch key table
     // free; it holds >= 2 entries per point)
@@ -686,7 +694,7 @@ int vox_build_fast_launch(caelo_voxmap *m, const float *pc, int64_t n, int strid
 
 // fused build of every frame of the set (fs.f[i] carries map i's tables, the scan and the status word)
 int vox_build_fast_set(caelo_voxmap *const *maps, const caelo_frame_set &fs, hipStream_t s) {
-    for (int i = 0; i < fs.n; ++i) maps[i]->lists_valid = false;  // until every kernel of the build is enqueued
+    for (int i = 0; i < fs.n; ++i) { maps[i]->lists_valid = false; maps[i]->kd_lists = false; }  // until every kernel of the build is enqueued
     const unsigned gp = (unsigned)((vox_set_max_points(fs) + 255) / 256);
     k_vox_points<<<dim3(gp, 1, fs.n), 256, 0, s>>>(fs);
     CAELO_LAUNCH_CHECK();
@@ -709,7 +717,7 @@ int vox_build_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, bo
 }
 
 int vox_build_set(caelo_voxmap *const *maps, const caelo_frame_set &fs, bool track_order, hipStream_t s) {
-    for (int i = 0; i < fs.n; ++i) maps[i]->lists_valid = false;
+    for (int i = 0; i < fs.n; ++i) { maps[i]->lists_valid = false; maps[i]->kd_lists = false; }
     const unsigned grid = (unsigned)((vox_set_max_points(fs) + 255) / 256);
     k_vox_first<<<dim3(grid, 1, fs.n), 256, 0, s>>>(fs);
     CAELO_LAUNCH_CHECK();
@@ -814,7 +822,8 @@ CAELO_API int caelo_voxmap_from_lists(caelo_ctx *c, caelo_voxmap *m, const int16
         k_or_status<<<1, 1, 0, s>>>(status, CAELO_ST_FEW_VOXELS);
         CAELO_LAUNCH_CHECK();
     }
-    return CAELO_OK;
+    // the lists in the caller's order: what scikit-learn's kd-tree is built on when the 496-nearest cut splits a tie class (kdorder.hip)
+    return kd_store_lists(m, lists, ns, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1149,7 +1158,9 @@ CAELO_API int caelo_patches(caelo_ctx *c, const caelo_voxmap *m, const float *pt
                             uint64_t *bits, uint8_t *flags, int32_t *status, void *stream) {
     CAELO_REQUIRE(c && m && pts && bits && flags && status, "null argument");
     CAELO_REQUIRE(k_max > 0, "k_max must be positive");
-    return vox_patches_launch(m, pts, 3, k_max, n_key, bits, flags, status, false, caelo_stream(stream));
+    const int rc = vox_patches_launch(m, pts, 3, k_max, n_key, bits, flags, status, false, caelo_stream(stream));
+    if (rc) return rc;
+    return kd_resolve(m, pts, 3, k_max, n_key, bits, flags, caelo_stream(stream));   // tie-split patches in the library's order (kdorder.hip)
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -51,6 +51,8 @@ typedef enum {
 #define CAELO_ST_MAP_FULL 4       /* voxel hash table overflow (capacity bug, never data) */
 #define CAELO_ST_FEW_VOXELS 8     /* a scale holds < 496 voxels: sklearn ValueError at Voxel.py:195-196 */
 #define CAELO_ST_FEW_KEYPTS 16    /* K <= 50: assert at SphericalRing.py:286 */
+#define CAELO_ST_NONFINITE 32     /* a NaN coordinate: int(nan) raises ValueError at SphericalRing.py:86-88 / Voxel.py:122-124 (an
+                                   * infinite one is a point like any other there: dropped by range / row test or kept) */
 #define CAELO_EXTRACT_EXACT_VOXELS 1 /* caelo_extract mode bit: the two-pass first-touch voxelization of caelo_voxelize
                                         (Voxel.py:139-141) instead of the one-pass build; both give the reference's voxel
                                         sets on every input, points on voxel faces included (tests compare them) */

@@ -303,6 +303,148 @@ static int64_t lower_bound_u64(const uint64_t *a, int64_t n, uint64_t key) {
     return lo;
 }
 
+/* ---- the 496-nearest cut when it falls INSIDE a class of equidistant voxels (Voxel.py:182,195-196) ----------------------
+ * NearestNeighbors(n_neighbors=496, algorithm='auto').fit(A).kneighbors(KeyVoxels): which members of the cut class are
+ * returned is decided by scikit-learn's kd-tree (scikit-learn 0.24.2, pinned by import in tools/make_goldens.py, which
+ * compares the tree's index array and every truncated patch with the library's own).  Restated from the library's
+ * documented algorithm and validated against it (it is a third-party dependency, not part of /root/reference):
+ *   fit     'auto' -> kd_tree iff n_samples // 2 > n_neighbors, i.e. n >= 994; otherwise brute force, whose tie order is
+ *           NumPy's argpartition (introselect) -- NOT restated: such patches keep the canonical rule and flag bit 2.
+ *   build   leaf_size 30; n_levels = int(log2(max(1, (n - 1) / 30)) + 1), n_nodes = 2^n_levels - 1; node i owns
+ *           idx[start, end); a node with children 2i+1, 2i+2 splits on the dimension of largest spread (first of equals)
+ *           at n / 2 by a quickselect whose partition is Lomuto's with the LAST element as pivot (strict <) -- the
+ *           resulting order of idx inside every node is part of the contract.
+ *   query   depth first from the root: a node whose lower bound (distance to its bounding box) exceeds the heap's largest
+ *           distance is skipped; a leaf pushes its points in idx order; an inner node visits the child with the smaller
+ *           lower bound first (<=: the left one on equality).  The heap holds the 496 best (max-heap on the squared
+ *           distance, initially +inf); a candidate is rejected when its distance is >= the largest, otherwise it replaces
+ *           the root and is sifted down (child choice: the first child when dist[c1] >= dist[c2]).
+ * Coordinates are small integers, so every squared distance is exact: ties are exact ties. */
+typedef struct {
+    int64_t n;
+    int n_nodes;
+    int32_t *idx;             /* [n] */
+    int32_t *start, *end;     /* [n_nodes] */
+    uint8_t *leaf;            /* [n_nodes] */
+    int16_t *lo, *hi;         /* [n_nodes][3] bounding boxes */
+    const int16_t *vox;       /* [n][3], not owned */
+} orc_kdtree_t;
+
+static void kd_build_rec(orc_kdtree_t *t, int node, int64_t s, int64_t e) {
+    const int16_t *X = t->vox;
+    int32_t *a = t->idx + s;
+    const int64_t m = e - s;
+    int16_t lo[3] = {32767, 32767, 32767}, hi[3] = {-32768, -32768, -32768};
+    for (int64_t i = 0; i < m; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const int16_t v = X[3 * (int64_t)a[i] + j];
+            if (v < lo[j]) lo[j] = v;
+            if (v > hi[j]) hi[j] = v;
+        }
+    t->start[node] = (int32_t)s; t->end[node] = (int32_t)e;
+    for (int j = 0; j < 3; ++j) { t->lo[3 * node + j] = lo[j]; t->hi[3 * node + j] = hi[j]; }
+    if (2 * node + 1 >= t->n_nodes || m < 2) { t->leaf[node] = 1; return; }
+    t->leaf[node] = 0;
+    int jmax = 0, spread = 0;
+    for (int j = 0; j < 3; ++j) if (hi[j] - lo[j] > spread) { spread = hi[j] - lo[j]; jmax = j; }
+    const int64_t nmid = m / 2;
+    int64_t left = 0, right = m - 1;
+    for (;;) {
+        int64_t mid = left;
+        const int16_t d2 = X[3 * (int64_t)a[right] + jmax];
+        for (int64_t i = left; i < right; ++i)
+            if (X[3 * (int64_t)a[i] + jmax] < d2) { const int32_t tmp = a[i]; a[i] = a[mid]; a[mid] = tmp; ++mid; }
+        { const int32_t tmp = a[mid]; a[mid] = a[right]; a[right] = tmp; }
+        if (mid == nmid) break;
+        if (mid < nmid) left = mid + 1; else right = mid - 1;
+    }
+    kd_build_rec(t, 2 * node + 1, s, s + nmid);
+    kd_build_rec(t, 2 * node + 2, s + nmid, e);
+}
+
+static orc_kdtree_t *kd_build(const int16_t *vox, int64_t n) {
+    orc_kdtree_t *t = (orc_kdtree_t *)calloc(1, sizeof(orc_kdtree_t));
+    const double q = (double)(n - 1) / 30.0;
+    const int n_levels = (int)(log2(q > 1.0 ? q : 1.0) + 1.0);
+    t->n = n; t->n_nodes = (1 << n_levels) - 1; t->vox = vox;
+    t->idx = (int32_t *)malloc(sizeof(int32_t) * n);
+    for (int64_t i = 0; i < n; ++i) t->idx[i] = (int32_t)i;
+    t->start = (int32_t *)malloc(sizeof(int32_t) * t->n_nodes); t->end = (int32_t *)malloc(sizeof(int32_t) * t->n_nodes);
+    t->leaf = (uint8_t *)malloc(t->n_nodes);
+    t->lo = (int16_t *)malloc(sizeof(int16_t) * 3 * t->n_nodes); t->hi = (int16_t *)malloc(sizeof(int16_t) * 3 * t->n_nodes);
+    kd_build_rec(t, 0, 0, n);
+    return t;
+}
+static void kd_free(orc_kdtree_t *t) { if (t) { free(t->idx); free(t->start); free(t->end); free(t->leaf); free(t->lo); free(t->hi); free(t); } }
+
+#define KD_K 496
+typedef struct { int64_t dist[KD_K]; int32_t ind[KD_K]; } kd_heap_t;   /* squared distances; INT64_MAX stands for +inf */
+static void kd_push(kd_heap_t *h, int64_t val, int32_t i_val) {
+    if (val >= h->dist[0]) return;
+    int i = 0;
+    for (;;) {
+        const int c1 = 2 * i + 1, c2 = c1 + 1;
+        int sw;
+        if (c1 >= KD_K) break;
+        else if (c2 >= KD_K) { if (h->dist[c1] > val) sw = c1; else break; }
+        else if (h->dist[c1] >= h->dist[c2]) { if (val < h->dist[c1]) sw = c1; else break; }
+        else { if (val < h->dist[c2]) sw = c2; else break; }
+        h->dist[i] = h->dist[sw]; h->ind[i] = h->ind[sw];
+        i = sw;
+    }
+    h->dist[i] = val; h->ind[i] = i_val;
+}
+static int64_t kd_min_rdist(const orc_kdtree_t *t, int node, const int q[3]) {
+    int64_t r = 0;
+    for (int j = 0; j < 3; ++j) {
+        const int d_lo = t->lo[3 * node + j] - q[j], d_hi = q[j] - t->hi[3 * node + j];
+        const int d = d_lo > 0 ? d_lo : (d_hi > 0 ? d_hi : 0);
+        r += (int64_t)d * d;
+    }
+    return r;
+}
+static void kd_query_rec(const orc_kdtree_t *t, int node, const int q[3], kd_heap_t *h, int64_t lb) {
+    if (lb > h->dist[0]) return;
+    if (t->leaf[node]) {
+        for (int32_t i = t->start[node]; i < t->end[node]; ++i) {
+            const int32_t p = t->idx[i];
+            int64_t d = 0;
+            for (int j = 0; j < 3; ++j) { const int e = q[j] - t->vox[3 * (int64_t)p + j]; d += (int64_t)e * e; }
+            kd_push(h, d, p);
+        }
+        return;
+    }
+    const int i1 = 2 * node + 1, i2 = i1 + 1;
+    const int64_t l1 = kd_min_rdist(t, i1, q), l2 = kd_min_rdist(t, i2, q);
+    if (l1 <= l2) { kd_query_rec(t, i1, q, h, l1); kd_query_rec(t, i2, q, h, l2); }
+    else { kd_query_rec(t, i2, q, h, l2); kd_query_rec(t, i1, q, h, l1); }
+}
+/* the 496 neighbours of q as the library returns them (as a set): out[496] voxel list indices */
+static void kd_query(const orc_kdtree_t *t, const int q[3], int32_t *out) {
+    kd_heap_t h;
+    for (int i = 0; i < KD_K; ++i) { h.dist[i] = INT64_MAX; h.ind[i] = 0; }
+    kd_query_rec(t, 0, q, &h, kd_min_rdist(t, 0, q));
+    memcpy(out, h.ind, sizeof(h.ind));
+}
+/* test hooks: the tree's index array (compared with KDTree.get_arrays()[1]) and one query */
+ORC_EXPORT int orc_kdtree_idx(const int16_t *vox, int64_t n, int32_t *idx_out) {
+    orc_kdtree_t *t = kd_build(vox, n);
+    memcpy(idx_out, t->idx, sizeof(int32_t) * n);
+    const int nn = t->n_nodes;
+    kd_free(t);
+    return nn;
+}
+ORC_EXPORT void orc_kdtree_query(const int16_t *vox, int64_t n, const int32_t *q, int64_t nq, int32_t *out) {
+    orc_kdtree_t *t = kd_build(vox, n);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t i = 0; i < nq; ++i) { const int qq[3] = {q[3 * i], q[3 * i + 1], q[3 * i + 2]}; kd_query(t, qq, out + KD_K * i); }
+    kd_free(t);
+}
+
+/* flags per patch: 1 = truncated (an in-window voxel lost to the 496-nearest cut); 2 = the cut splits a class of equidistant
+ * voxels that has in-window members AND the list is too short for scikit-learn's kd-tree (n < 994: brute force, NumPy's
+ * argpartition order -- not restated): canonical rule (ascending (x, y, z)), may differ from the reference; 4 = such a split
+ * resolved in scikit-learn's kd-tree order: equal to the reference. */
 ORC_EXPORT int orc_patches(const float *pts, int64_t k, const int16_t *vox, int64_t nvox, int scale,
                            uint64_t *bits, uint8_t *flags) {
     if (nvox < 496) return -1;
@@ -386,6 +528,32 @@ ORC_EXPORT int orc_patches(const float *pts, int64_t k, const int16_t *vox, int6
         flags[p] = fl;
     }
     free(keys);
+    /* ---- tie-ambiguous patches in the library's own order (n >= 994: 'auto' picks the kd-tree) */
+    if (nvox / 2 > KD_K) {
+        int any = 0;
+        for (int64_t p = 0; p < k; ++p) any |= flags[p] & 2;
+        if (any) {
+            orc_kdtree_t *t = kd_build(vox, nvox);
+#pragma omp parallel for schedule(dynamic, 1)
+            for (int64_t p = 0; p < k; ++p) {
+                if (!(flags[p] & 2)) continue;
+                const int q[3] = {(int)(((double)pts[3 * p] + VIS_L) / vs), (int)(((double)pts[3 * p + 1] + VIS_W) / vs),
+                                  (int)(((double)pts[3 * p + 2] + VIS_H) / vs)};
+                int32_t nb[KD_K];
+                kd_query(t, q, nb);
+                uint64_t *w = bits + p * 64; memset(w, 0, 64 * sizeof(uint64_t));
+                for (int i = 0; i < KD_K; ++i) {
+                    const int dx = vox[3 * (int64_t)nb[i]] - q[0], dy = vox[3 * (int64_t)nb[i] + 1] - q[1], dz = vox[3 * (int64_t)nb[i] + 2] - q[2];
+                    if (dx >= -8 && dx < 8 && dy >= -8 && dy < 8 && dz >= -8 && dz < 8) {
+                        const int lin = ((dx & 15) << 8) | ((dy & 15) << 4) | (dz & 15);
+                        w[lin >> 6] |= 1ULL << (lin & 63);
+                    }
+                }
+                flags[p] = (uint8_t)((flags[p] & ~2) | 4);
+            }
+            kd_free(t);
+        }
+    }
     return 0;
 }
 

@@ -340,6 +340,24 @@ def patches_bits(Pts, AllVoxels, scale):
     return bits, flags
 
 
+def kdtree_idx(AllVoxels):
+    """The index array of scikit-learn 0.24's KDTree(AllVoxels, leaf_size=30) (what NearestNeighbors(algorithm='auto') builds for
+    n >= 994 at Voxel.py:195): (idx [n] int32, n_nodes).  tools/make_goldens.py compares it with KDTree.get_arrays()[1]."""
+    vox = np.ascontiguousarray(AllVoxels, dtype=np.int16)
+    idx = np.empty(vox.shape[0], np.int32)
+    n_nodes = lib().orc_kdtree_idx(_p(vox), C.c_int64(vox.shape[0]), _p(idx))
+    return idx, int(n_nodes)
+
+
+def kdtree_query(AllVoxels, KeyVoxels):
+    """kneighbors(KeyVoxels, 496) of that tree as SETS of list indices: [Q, 496] int32 (heap order, not sorted)."""
+    vox = np.ascontiguousarray(AllVoxels, dtype=np.int16)
+    q = np.ascontiguousarray(KeyVoxels, dtype=np.int32)
+    out = np.empty((q.shape[0], 496), np.int32)
+    lib().orc_kdtree_query(_p(vox), C.c_int64(vox.shape[0]), _p(q), C.c_int64(q.shape[0]), _p(out))
+    return out
+
+
 def unpack_patches(bits):
     """[K,64] u64 -> [K,16,16,16,1] f32 (the reference's dense layout)."""
     b = np.ascontiguousarray(bits, dtype="<u8").view(np.uint8).reshape(bits.shape[0], 512)

@@ -176,7 +176,11 @@ def test_patches_bit_exact(api, orc, f0):
     assert set(np.unique(plist[1])) <= {0.0, 1.0}
 
 
-def test_patches_truncation_taxonomy(api, orc):
+def test_patches_truncation_taxonomy(api, orc, scans):
+    """The 496-nearest cut (Voxel.py:182,195-196) through the staged API.  Where it splits a class of equidistant voxels the
+    patch is redone in scikit-learn's kd-tree order (kdorder.hip, flag 4): bits AND flags equal the oracle's, and -- the oracle
+    being pinned to the library there -- EVERY patch equals what the reference returned (rounds 1-3: only the unflagged ones)."""
+    import warnings
     g = np.load(os.path.join(GOLDEN, "patch_truncation.npz"))
     for name in ("sparse", "mid", "dense"):
         vox, pts = g[name + "_vox"], g[name + "_pts"]
@@ -184,11 +188,67 @@ def test_patches_truncation_taxonomy(api, orc):
         b = bits[:, 1].cpu().numpy().view(np.uint64)
         fl = flags[:, 1].cpu().numpy()
         ob, of = orc.patches_bits(pts, vox, 1)
-        assert np.array_equal(fl, of) and np.array_equal(b, ob)            # oracle, incl. canonical tie rule
-        unamb = (of & 2) == 0
-        assert np.array_equal(b[unamb], g[name + "_bits"][unamb])           # reference (sklearn 496-NN)
+        assert np.array_equal(fl, of) and np.array_equal(b, ob) and not (fl & 2).any()
+        assert np.array_equal(b, g[name + "_bits"])                         # the reference, every patch
     with pytest.raises(ValueError):
         api.GetPatchesList(g["sparse_pts"], g["sparse_vox"][:100], g["sparse_vox"], g["sparse_vox"])
+    # a list too short for the library's kd-tree (brute force there, NumPy's argpartition order): canonical rule, flag 2, and the
+    # reference-named entry point says so
+    short = g["dense_vox"][:990]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        api.GetPatchesList(g["dense_pts"], short, short, short)
+    assert any("tie" in str(x.message) for x in w)
+    # a real frame with 11 tie-split patches (clutter frame 23), lists from the reference-exact voxelization
+    gc = np.load(os.path.join(GOLDEN, "frame_c23.npz"))
+    pc = scans(23, quantum=1e-3, scene_kind="clutter")
+    v = api.Voxelization(pc[:, 0:3])
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                       # nothing left to warn about
+        _, plist = api.GetPatchesList(gc["patch_kp"], v[6], v[7], v[8])
+    for s_ in range(3):
+        assert np.array_equal(orc.pack_patches(plist[s_]), gc["patch_bits"][:, s_]), "scale %d" % s_
+    bits, flags = api.GetPatchesBits(gc["patch_kp"], v[6], v[7], v[8])
+    assert np.array_equal(flags.cpu().numpy(), gc["patch_flags"]) and int(((gc["patch_flags"] & 4) != 0).sum()) == 11
+
+
+def test_nan_points_raise_like_the_reference(api, engine, scans):
+    """VERDICT r3 (missing 4): a NaN coordinate makes int(nan) raise ValueError at SphericalRing.py:86-88 and Voxel.py:122-124;
+    an infinite x or y is a point like any other there (finite angle; dropped by the range filter of Voxel.py:90-96).  The
+    kernels set CAELO_ST_NONFINITE, the API raises the same exception type, the fused call reports the bit."""
+    import torch
+    pc = scans(0).copy()
+    for col in (0, 1, 2):
+        bad = pc.copy(); bad[1000, col] = np.nan
+        with pytest.raises(ValueError):
+            api.ProjectPC2SphericalRing(bad)
+        with pytest.raises(ValueError):
+            api.Voxelization(bad[:, 0:3])
+        ff = engine.extract(torch.from_numpy(bad).to(engine.device))
+        assert int(ff.status[0].item()) & 32
+    inf = pc.copy(); inf[1000, 0] = np.inf
+    ring, cnt = api.ProjectPC2SphericalRing(inf)          # (the reference accepts it)
+    assert ring.shape == (69, 1800, 5)
+    api.Voxelization(inf[:, 0:3])
+    zinf = pc.copy(); zinf[1000, 2] = np.inf              # z / r = inf / inf = nan
+    with pytest.raises(ValueError):
+        api.ProjectPC2SphericalRing(zinf)
+
+
+def test_default_capacity_has_headroom(engine, scans):
+    """VERDICT r3 (missing 4): a HDL-64E scan reaches ~131 k points; the default capacity (160 000) takes it without the caller
+    sizing anything, through the fused call and the pipeline."""
+    import torch
+    from caelo import synth
+    assert engine.max_points >= 150000
+    pc = scans(0, quantum=1e-3)
+    big = np.concatenate([pc, synth.shuffle_scan(pc, 5, dup_fraction=0.0)[: 150000 - len(pc)]])
+    assert len(big) == 150000
+    d = torch.from_numpy(np.ascontiguousarray(big)).to(engine.device)
+    ff = engine.extract(d)
+    out = engine.pipeline(2).run([d, d], pairs=False)
+    torch.cuda.synchronize()
+    assert int(ff.status[0].item()) == 0 and int(ff.n_key.item()) == 1024 and torch.equal(out.rows[1], ff.rows)
 
 
 def test_patch_pack_unpack_round_trip(engine, f0):

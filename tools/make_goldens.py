@@ -169,11 +169,12 @@ def frame_golden(frame, n_beams=64, n_az=2000, n_patch_kp=None, tag=None, quantu
     diff = (o_bits != bits).any(axis=2)
     amb = (o_flags & 2) != 0
     assert not (diff & ~amb).any(), "oracle patches != reference on a non-ambiguous patch"
+    assert not amb.any(), "scan-sized voxel lists are kd-tree sized: no patch may be left to the canonical rule"
     g["patch_bits"] = bits; g["patch_flags"] = o_flags
     g["patch_kp"] = kp.astype(np.float32)
-    print("    patches: set voxels mean %s, truncated %s, ambiguous %s, ambiguous&differ %d (%.1fs)" % (
+    print("    patches: set voxels mean %s, truncated %s, cut inside a tie class (kd-tree order) %s, differ %d (%.1fs)" % (
         np.round(np.unpackbits(bits.view(np.uint8), axis=2).sum(axis=2).mean(axis=0), 1),
-        ((o_flags & 1) != 0).sum(axis=0), amb.sum(axis=0), int((diff & amb).sum()), time.time() - tp))
+        ((o_flags & 1) != 0).sum(axis=0), ((o_flags & 4) != 0).sum(axis=0), int(diff.sum()), time.time() - tp))
     # -- descriptors: oracle restatement of the Keras encoder on the reference's patches
     feats = RefMatch.GetFeaturesFromPatches(enc_model, plist)
     g["features"] = feats.astype(np.float32)
@@ -246,6 +247,12 @@ def clutter_golden():
     pair_golden(c0, c1, seeds=(0, 1), out="pair_c0_c1.npz", hard_cases=False)
 
 
+def tie_golden():
+    """Round 4: a REAL frame whose 496-nearest cut falls inside classes of equidistant voxels (clutter frame 23: 3 patches at
+    16 cm, 8 at 64 cm; 17 truncated in all): the reference's patches, which the oracle reproduces in scikit-learn's kd-tree order."""
+    frame_golden(23, quantum=1e-3, tag="c23", scene_kind="clutter")
+
+
 def shuffled_golden():
     """Round 4 (missing 4): frame 0 of the mm-quantised scene in a hostile file order through the reference."""
     frame_golden(0, quantum=1e-3, tag="p0", shuffle_seed=77)
@@ -266,12 +273,37 @@ def trunc_golden():
         bits = orc.pack_patches(plist[1])
         ob, of = orc.patches_bits(pts, vox, 1)
         diff = (ob != bits).any(axis=1); amb = (of & 2) != 0
-        assert not (diff & ~amb).any(), "oracle truncated patches != reference (non-ambiguous)"
-        # on ambiguous patches the two may only differ inside the cut class
-        print("  trunc %-6s: nvox=%d truncated=%d ambiguous=%d differ=%d setbits ref/oracle=%d/%d" % (
-            name, len(vox), int(((of & 1) != 0).sum()), int(amb.sum()), int(diff.sum()),
+        assert not (diff & ~amb).any(), "oracle truncated patches != reference (outside the brute-force case)"
+        assert len(vox) < 994 or not amb.any(), "a kd-tree sized list left a patch to the canonical rule"
+        # round 4: the cut inside a class of equidistant voxels is resolved in scikit-learn's kd-tree order (flag 4): EVERY patch equal
+        print("  trunc %-6s: nvox=%d truncated=%d kd-tree-ordered=%d canonical(brute-force case)=%d differ=%d setbits ref/oracle=%d/%d" % (
+            name, len(vox), int(((of & 1) != 0).sum()), int(((of & 4) != 0).sum()), int(amb.sum()), int(diff.sum()),
             int(np.unpackbits(bits.view(np.uint8)).sum()), int(np.unpackbits(ob.view(np.uint8)).sum())))
         g[name + "_vox"] = vox; g[name + "_pts"] = pts; g[name + "_bits"] = bits; g[name + "_flags"] = of
+    # the tree itself against the library: index array of KDTree(leaf_size=30) and raw 496-neighbour sets on lattices full of ties
+    from sklearn.neighbors import KDTree, NearestNeighbors
+    n_q = n_same = 0
+    for trial in range(24):
+        side = rs.randint(9, 40)
+        X = np.unique(rs.randint(0, side, size=(rs.randint(1200, 9000), 3)), axis=0).astype(np.int16)
+        X = X[rs.permutation(len(X))] + np.int16(100)
+        if len(X) < 994:
+            continue
+        idx, n_nodes = orc.kdtree_idx(X)
+        sk = KDTree(X.astype(np.float64), leaf_size=30).get_arrays()
+        assert np.array_equal(idx, sk[1]) and n_nodes == len(sk[2]), "oracle kd-tree != scikit-learn's (index array)"
+        nn = NearestNeighbors(n_neighbors=496, radius=14, algorithm="auto").fit(X)
+        assert nn._fit_method == "kd_tree"
+        Q = X[rs.randint(0, len(X), 40)].astype(np.int32) + rs.randint(-2, 3, size=(40, 3))
+        ref = nn.kneighbors(Q, return_distance=False)
+        got = orc.kdtree_query(X, Q)
+        n_q += len(Q); n_same += sum(set(a.tolist()) == set(b.tolist()) for a, b in zip(ref, got))
+    assert n_q == n_same and n_q >= 400, "oracle kd-tree query != scikit-learn's kneighbors (as sets)"
+    g["kdtree_checked_queries"] = n_q
+    # below 994 voxels 'auto' is brute force (argpartition order: not restated)
+    small = NearestNeighbors(n_neighbors=496, radius=14, algorithm="auto").fit(g["sparse_vox"][:993])
+    assert small._fit_method == "brute" and NearestNeighbors(n_neighbors=496, algorithm="auto").fit(g["sparse_vox"][:994])._fit_method == "kd_tree"
+    print("  kd-tree: %d lattice queries equal to scikit-learn %s as sets; index arrays equal" % (n_q, __import__("sklearn").__version__))
     np.savez_compressed(os.path.join(GOLD, "patch_truncation.npz"), **g)
 
 
@@ -629,6 +661,10 @@ if __name__ == "__main__":
     if "--sequence-only" in sys.argv:
         sequence_golden()
         sys.exit(0)
+    if "--trunc-only" in sys.argv:
+        trunc_golden()
+        tie_golden()
+        sys.exit(0)
     if "--shuffled-only" in sys.argv:
         shuffled_golden()
         sys.exit(0)
@@ -659,6 +695,7 @@ if __name__ == "__main__":
     pair_golden(f0, f1)
     quantised_golden()
     clutter_golden()
+    tie_golden()
     shuffled_golden()
     # dense 128-beam scan: exercises the 496-NN truncation of GetPatchesList
     frame_golden(0, n_beams=128, n_az=4000, n_patch_kp=192, tag="dense128")
