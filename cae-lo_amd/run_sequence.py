@@ -48,7 +48,7 @@ def _parse_poses(raw, k):
     return out, ok, thr, nin
 
 
-def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, keep=None):
+def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, keep=None, strict_ties=True, tie_log=None):
     """Frames [lo, hi) of this rank.  Returns per-pair rows for pairs (i-1, i), i in (lo, hi) -- the pair (lo-1, lo)
     is the caller's (it needs the previous rank's last frame) -- plus the first and last frame's features.
 
@@ -106,6 +106,18 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
         c0, c1, scans, draws = item
         draws_d = draws.to(eng.device, non_blocking=True)
         batch = pipe.run_uploading(scans, [draws_d[i] for i in range(c1 - c0)], prev=prev, dist_channels=dist_channels)
+        if strict_ties:
+            # Frames whose 496-nearest cut (Voxel.py:195-196) splits a class of equidistant voxels: the fused path's canonical rule is
+            # replaced by scikit-learn's kd-tree order (Engine.resolve_ties: ordered voxel lists, all on the device), then the pairs
+            # such a frame is part of are matched again.  One synchronisation per chunk; rare (none on KITTI-shaped scans).
+            tied = torch.nonzero((batch.flags[:c1 - c0] & 2).reshape(c1 - c0, -1).any(dim=1)).reshape(-1).tolist()
+            for j in tied:
+                n_t = eng.resolve_ties(batch.frame(j), scans[j].to(eng.device))
+                if tie_log is not None:
+                    tie_log.append((c0 + j, n_t))
+            for j in sorted({t for u in tied for t in (u, u + 1) if t < c1 - c0 and (t > 0 or prev is not None)}):
+                r_, m_, x_ = eng.match_pose(prev if j == 0 else batch.frame(j - 1), batch.frame(j), draws_d[j])
+                batch.result[j].copy_(r_); batch.inlier_mask[j].copy_(m_); batch.pair_idx[j].copy_(x_)
         # read this chunk's small outputs back without stalling the stream that issues the next chunk
         done = torch.cuda.Event()
         done.record()
@@ -146,6 +158,8 @@ def main():
     ap.add_argument("--pool", type=int, default=0, help="synthesise only this many distinct scans and walk them back and forth (0 1 .. P-1 "
                                                         "P-2 .. 0 1 ..: every pair stays a pair of neighbours); ray casting a scan costs ~0.5 s of CPU")
     ap.add_argument("--save-artifacts", action="store_true", help="write Features/*.mat and InliersIdx/*.mat next to the scans")
+    ap.add_argument("--no-strict-ties", action="store_true", help="keep the fused path's canonical rule where the 496-nearest cut splits a "
+                                                                  "tie class (default: such frames are redone in scikit-learn's kd-tree order)")
     ap.add_argument("--gpus", type=int, default=int(os.environ.get("WORLD_SIZE", "1")),
                     help="ranks = GPUs; without a launcher the script starts them itself (caelo.dist.ensure_ranks)")
     args = ap.parse_args()
@@ -194,8 +208,12 @@ def main():
                 m = mask[j, :k]
                 stageio.save_inliers(os.path.dirname(os.path.dirname(files[c0 + j])), c0 + j - 1, c0 + j, idx[j, :k][m], np.arange(k)[m])
 
+    tie_log = []
     rel, ok, thr, nin, first, last = run_local(eng, load, lo, hi, args.seed_base, args.chunk, args.dist_channels,
-                                               args.batch, keep)
+                                               args.batch, keep, strict_ties=not args.no_strict_ties, tie_log=tie_log)
+    if tie_log:
+        print("rank %d: %d frame(s) redone in scikit-learn's tie order (%d patches): %s" % (
+            rank, len(tie_log), sum(n for _, n in tie_log), [f for f, _ in tie_log][:20]), file=sys.stderr)
     if world > 1:   # the pair that straddles the rank boundary: ONE all-gather of the boundary rows
         gathered = cdist.all_gather_boundary(last.rows)
         if rank > 0:

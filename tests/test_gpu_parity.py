@@ -194,7 +194,8 @@ def test_patches_truncation_taxonomy(api, orc, scans):
         api.GetPatchesList(g["sparse_pts"], g["sparse_vox"][:100], g["sparse_vox"], g["sparse_vox"])
     # a list too short for the library's kd-tree (brute force there, NumPy's argpartition order): canonical rule, flag 2, and the
     # reference-named entry point says so
-    short = g["dense_vox"][:990]
+    dv = g["dense_vox"].astype(np.int64)
+    short = g["dense_vox"][np.argsort(((dv - np.array([600, 640, 90])) ** 2).sum(1), kind="stable")[:990]]   # a dense ball of 990 voxels
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         api.GetPatchesList(g["dense_pts"], short, short, short)

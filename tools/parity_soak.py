@@ -142,11 +142,20 @@ def soak(engine, orc, models, scene, n_frames, seed_base=5000, batch=8, log=None
     rnd = [torch.from_numpy(d).to(dev) for d in draws]
     out = engine.pipeline(batch).run(dpcs, rnd)
     torch.cuda.synchronize()
+    # frames whose 496-nearest cut splits a tie class: the fused path used its canonical rule there (flag bit 2); redone the
+    # reference's way (Engine.resolve_ties: ordered voxel lists, scikit-learn's kd-tree order), then the two pairs they are part of
+    fl = out.flags.cpu().numpy()
+    tied = [i for i in range(n_frames) if (fl[i] & 2).any()]
+    n_tied_patches = sum(engine.resolve_ties(out.frame(i), dpcs[i]) for i in tied)
+    for i in sorted({j for t in tied for j in (t, t + 1) if 1 <= j < n_frames}):
+        r_, m_, x_ = engine.match_pose(out.frame(i - 1), out.frame(i), rnd[i])
+        out.result[i].copy_(r_); out.inlier_mask[i].copy_(m_); out.pair_idx[i].copy_(x_)
+    torch.cuda.synchronize()
     rows = out.rows.cpu().numpy(); kpix = out.key_pixels.cpu().numpy(); nkey = out.n_key.cpu().numpy()
     pidx = out.pair_idx.cpu().numpy(); mask = out.inlier_mask.cpu().numpy().astype(bool); res = out.result.cpu().numpy()
     status = out.status.cpu().numpy()
-    rep = dict(scene=scene, frames=n_frames, pairs=n_frames - 1, keypixel_mismatch_frames=0, keypoint_mismatch_frames=0,
-               voxel_set_mismatch=[0, 0, 0], patch_mismatch=0, patches=0, patches_truncated=0, patches_tie_ambiguous=0,
+    rep = dict(scene=scene, frames=n_frames, pairs=n_frames - 1, frames_with_tie_split=len(tied), tie_split_patches=n_tied_patches, keypixel_mismatch_frames=0, keypoint_mismatch_frames=0,
+               voxel_set_mismatch=[0, 0, 0], patch_mismatch=0, patch_mismatch_canonical_rule=0, patches=0, patches_truncated=0, patches_tie_ambiguous=0,
                desc_max_abs=0.0, desc_max_rel=0.0, desc_over_tol=0, status_or=int(np.bitwise_or.reduce(status[:, 0])),
                match_kernel_mismatch_cols=0, ransac_kernel_mismatch_pairs=0, ransac_kernel_max_rt=0.0,
                columns=0, flips=0, flips_unexplained=0, pairs_with_flip=0, exact_pairs_inlier_mismatch=0, exact_pairs_max_rt=0.0,
@@ -169,8 +178,13 @@ def soak(engine, orc, models, scene, n_frames, seed_base=5000, batch=8, log=None
         gbits, gflags = engine.patches(vm, torch.from_numpy(np.ascontiguousarray(o["kp"])).to(dev))
         gbits = gbits.cpu().numpy().view(np.uint64)
         bad = (gbits != o["bits"]).any(axis=2)
+        # the set-based map knows no list order: its tie-split patches (device flag 2 = oracle flag 4) follow the canonical rule
+        split = (gflags.cpu().numpy() & 2) != 0
+        assert np.array_equal(split, (o["flags"] & 4) != 0), "tie-split patches: device and oracle disagree on which"
+        rep["patch_mismatch_canonical_rule"] += int((bad & split).sum())
+        bad &= ~split
         rep["patch_mismatch"] += int(bad.sum()); rep["patches"] += bad.size
-        rep["patches_truncated"] += int(((o["flags"] & 1) != 0).sum()); rep["patches_tie_ambiguous"] += int(((o["flags"] & 2) != 0).sum())
+        rep["patches_truncated"] += int(((o["flags"] & 1) != 0).sum()); rep["patches_tie_ambiguous"] += int(((o["flags"] & 6) != 0).sum())
         if same_pts:
             d = np.abs(rows[i, :k, 0:60].astype(np.float64) - o["feats"])
             rel = d / np.maximum(np.abs(o["feats"]), FLOOR)
@@ -244,8 +258,10 @@ def render(rep):
          "  key pixels: %d frames differ; key points: %d; status OR 0x%x; lane faults %d" % (
              rep["keypixel_mismatch_frames"], rep["keypoint_mismatch_frames"], rep["status_or"], rep["lane_faults"]),
          "  voxel sets differing (frames, scale 0/1/2): %s" % rep["voxel_set_mismatch"],
-         "  patches: %d of %d differ (truncated at the 496-NN cut: %d, of which tie-ambiguous: %d)" % (
-             rep["patch_mismatch"], rep["patches"], rep["patches_truncated"], rep["patches_tie_ambiguous"]),
+         "  patches: %d of %d differ (truncated at the 496-NN cut: %d; cut inside a tie class: %d in %d frames -- the set-based fused build "
+         "uses a canonical rule there (%d of them differ from the reference's choice) and Engine.resolve_ties redid those frames from ordered lists in scikit-learn's kd-tree order)" % (
+             rep["patch_mismatch"], rep["patches"], rep["patches_truncated"], rep["tie_split_patches"], rep["frames_with_tie_split"],
+             rep["patch_mismatch_canonical_rule"]),
          "  descriptors: max |err| %.3g, max relative (0.1 floor) %.3g, elements over 1e-4: %d" % (rep["desc_max_abs"], rep["desc_max_rel"], rep["desc_over_tol"]),
          "  kernels on the oracle's inputs: caelo_match %d wrong columns; caelo_ransac %d pairs differ (max R/T err %.2g)" % (
              rep["match_kernel_mismatch_cols"], rep["ransac_kernel_mismatch_pairs"], rep["ransac_kernel_max_rt"]),
