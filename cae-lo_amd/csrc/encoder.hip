@@ -57,6 +57,9 @@ int enc_upload_dense1(const float *wd1, const float *bd1, int K, void **wx_dev, 
 #define HEAD_WQ_FLOATS (13 * 2 * 64 * 4)   // Dense(20) as k_enc_head_mfma's B operand
 static void head_weight_fragments(const float *wd2, float *out);
 
+#define S1X_BGO_OFF (512 * 16 + 16)
+__global__ void k_enc_bgo_table(float *c0g);
+
 CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const float *b1, const float *w2,
                                         const float *b2, const float *w3, const float *b3, const float *wd1,
                                         const float *bd1, const float *wd2, const float *bd2) {
@@ -84,11 +87,16 @@ CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const flo
                 c0[((x * 8 + y) * 8 + z) * 16 + o] = acc;
             }
         for (int ch = 0; ch < 8; ++ch) c0[512 * 16 + ch] = bg[ch];
-        if (!c->enc_c0) CAELO_HIP(hipMalloc(&c->enc_c0, sizeof(c0)));
+        // + the pooled outputs of a tile pair that sees nothing but background, per pair and lane of k_enc_stage1x (S1X_BGO_OFF floats
+        // in: [16 pairs][64 lanes] float2), computed on the DEVICE with the kernel's own tanh (k_enc_bgo_table)
+        if (!c->enc_c0) CAELO_HIP(hipMalloc(&c->enc_c0, (S1X_BGO_OFF + 16 * 64 * 2) * sizeof(float)));
         CAELO_HIP(hipMemcpy(c->enc_c0, c0, sizeof(c0), hipMemcpyHostToDevice));
+        k_enc_bgo_table<<<16, 64>>>(c->enc_c0);
+        CAELO_LAUNCH_CHECK();
+        CAELO_HIP(hipDeviceSynchronize());
     }
     {
-        const size_t n1 = 16 * 64, n2 = 27 * 64;  // S1X_W1F_U4, S1X_W2X_U4
+        const size_t n1 = 16 * 64, n2 = 18 * 64;  // S1X_W1F_U4, S1X_W2X_U4 (enc_stage1x.inc)
         std::vector<uint4> wxv(n1 + n2);   // (a vector: an early return of CAELO_HIP must not leak the staging buffer)
         uint4 *wx = wxv.data();
         stage1x_split_weights(w1, w2, wx, wx + n1);
