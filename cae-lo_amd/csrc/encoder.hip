@@ -1292,7 +1292,10 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
         // CAELO_S1X_SLOTS: grid size by hand (measurement: 128 / 256 / 384 / 512 workgroups take 692 / 376 / 281 / 233 us per 24 576
         // patches -- a workgroup alone on its CU needs 3.9 us per patch, two sharing one 4.85 us each: latency bound)
         static const int slots_env = getenv("CAELO_S1X_SLOTS") ? atoi(getenv("CAELO_S1X_SLOTS")) : 0;
-        const int64_t capx = slots_env > 0 ? slots_env : ((ein.yield & 1) ? (int64_t)slots1x * 4 / 5 : slots1x);
+        // inside the pipeline (yield bit 0): two of the three workgroups a CU can hold -- the third's registers and LDS go to the front
+        // and pair kernels of the other streams (frames/s at 120 batches against the grid: 448 / 512 / 576 / 640 / 704 / 768 workgroups
+        // = 20.0 / 20.4 / 20.2 / 19.6 / 19.2 / 17.8 k, profiles/r04_pipe_sweep.txt); alone, all three (207 against 248 us)
+        const int64_t capx = slots_env > 0 ? slots_env : ((ein.yield & 1) ? (int64_t)slots1x * 2 / 3 : slots1x);
         const unsigned gx = (unsigned)(n_patches < capx ? n_patches : capx);
         if (ev) {   // profiling calls count the MFMAs the kernel executes (bench.py's roofline); same code otherwise
             CAELO_HIP(hipMemsetAsync(mfma_count, 0, sizeof(unsigned long long), s));
