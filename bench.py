@@ -220,7 +220,7 @@ def cpu_baseline_dense128(n_patches=96):
 def _pmc_busy():
     """matrix-pipe busy share by the hardware counters (separate rocprofv3 --pmc passes of the same 8-frame launch, committed):
     SQ_VALU_MFMA_BUSY_CYCLES summed over 1024 SIMDs against SQ_BUSY_CYCLES summed over 32 shader engines"""
-    for name in ("r03_pmc_mfma_busy.txt", "r02_pmc_mfma_busy.txt"):
+    for name in ("r04_pmc_mfma_busy.txt", "r03_pmc_mfma_busy.txt", "r02_pmc_mfma_busy.txt"):
         try:
             cur, vals = None, {}
             for line in open(os.path.join(REPO, "profiles", name)):
@@ -507,7 +507,7 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; the per-launch
         # FETCH_SIZE / WRITE_SIZE of the same launch (separate rocprofv3 --pmc passes) are committed under profiles/.
         traffic, traffic_note = None, None
-        for pmc_file in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        for pmc_file in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(REPO, "profiles", pmc_file)))
                 k = pmc["kernels"][names[dom]] if names[dom] in pmc["kernels"] else pmc["kernels"][names[dom].rstrip("x")]
@@ -523,9 +523,9 @@ def main():
                     "launch_ms": round(float(ms_avg[dom]), 4),
                     "achieved_is": "FLOPs of the MFMA instructions the kernel EXECUTED (counted by the kernel: v_mfma_f32_16x16x32_f16, "
                                    "16 384 FLOP each) / launch time, against the dense peak of the f16 / bf16 matrix pipe; always <= 1.  "
-                                   "Round 3 moved stage 1 from the f32 pipe (0.39 of 157 TFLOP/s, 341 us) to 2-way f16 splits: the pipe is no "
-                                   "longer what bounds the kernel (LDS round trips and instruction issue do), the launch time is the figure "
-                                   "to compare across rounds",
+                                   "Round 3 moved stage 1 from the f32 pipe (0.39 of 157 TFLOP/s, 341 us) to 2-way f16 splits (224 us), round 4 to "
+                                   "three workgroups per CU (207 us): the pipe is not what bounds the kernel (LDS round trips and instruction "
+                                   "issue do), the launch time is the figure to compare across rounds",
                     "algorithmic_tflops": round(float(alg_tf[dom]), 2),
                     "algorithmic_note": "dense Keras FLOPs of the layers the kernel replaces / launch time; stage 1 executes %.1f %% of "
                                         "the dense conv2 MFMAs on this scene (all-background rows add exact zeros and are skipped)" % (100.0 * exec_share),
@@ -561,7 +561,7 @@ def main():
                        "step": "one batch of %d consecutive frames = one launch set of the pipeline (front kernels, encoder, match + RANSAC)" % B,
                        "frames_per_step": B, "frames_timed_per_gpu": K, "timed_region_ms": round(dt * 1e3, 3),
                        "arithmetic": "f32 in / out / accumulate; conv1, conv2, conv3 and Dense(200) evaluate every f32 product from 2-way f16 "
-                                     "operand splits (|x - hi - lo| <= 2^-22 |x|) on the f16 matrix "
+                                     "operand splits (|x - hi - lo| <= max(2^-22 |x|, 2^-25): the low half of a small value is an f16 subnormal) on the f16 matrix "
                                      "pipe -- f32-grade (descriptors 1.5e-6 from the f32 oracle, which is itself 1.3e-6 from an f64 "
                                      "evaluation; per-layer budget in tests); NN match: f16 screen + float64 certification = the float64 argmin",
                        "dedup": "bit-identical patches of a batch of frames are encoded once (exact; DESIGN.md 4.7, 4.13; no batch "

@@ -542,7 +542,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
 #define C3X_PLANE 48                 // positions per padded x plane (6 rows of 8)
 #define C3X_ARR 292                  // positions per (split, half) array: 288 used, = 4 mod 16 (bank rotation of half 1)
 #define C3X_SPLIT (2 * C3X_ARR)
-// Round 3: the f32 products of conv3 run as TWO f16 terms per operand (x = hi + lo, |x - hi - lo| <= 2^-22 |x|; the MFMA honours
+// Round 3: the f32 products of conv3 run as TWO f16 terms per operand (x = hi + lo, |x - hi - lo| <= max(2^-22 |x|, 2^-25); the MFMA honours
 // f16 subnormals, tools/micro/f16_mfma_subnormal.hip) and three partial products hi hi + hi lo + lo hi -- 3 MFMAs per K = 32 slab
 // instead of the 6 of the 3-way bf16 split (C3X_F16=0, round 2), 112 instead of 168 B registers, two LDS planes instead of three.
 // The dropped lo lo term is 2^-22 relative; measured against the f32 oracle the descriptors do not move (tools/enc_layer_errors.py).
