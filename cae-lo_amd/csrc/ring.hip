@@ -419,14 +419,16 @@ __global__ void __launch_bounds__(256) k_kp_score(const caelo_frame_set fs, int 
     unsigned long long *__restrict__ cand = F.cand;
     int32_t *cand_count = F.cand_count;
     __shared__ float4 sR[KS_HR * KS_HC * 2];
-    __shared__ unsigned char sOcc[KS_HR * KS_HC];
+    __shared__ unsigned int sBits[KS_HR][4];   // occupancy of a halo row as bits (68 columns: three words)
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * KS_COLS, y0 = 8 + blockIdx.y * KS_ROWS;  // rows 8..55 only
+    if (tid < KS_HR * 4) (&sBits[0][0])[tid] = 0u;
+    __syncthreads();
     for (int i = tid; i < KS_HR * KS_HC; i += 256) {
         const int hy = i / KS_HC, hx = i % KS_HC;
         const int yy = y0 - 2 + hy, xx = x0 - 2 + hx;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        unsigned char occ = 0;
+        bool occ = false;
         if (xx >= 0 && xx < CAELO_NET_W && yy >= 0 && yy < CAELO_NET_H) {
             const float4 *rq4 = (const float4 *)(resp + ((int64_t)yy * CAELO_NET_W + xx) * 8);
             a = rq4[0];
@@ -435,7 +437,7 @@ __global__ void __launch_bounds__(256) k_kp_score(const caelo_frame_set fs, int 
         }
         sR[2 * i] = a;
         sR[2 * i + 1] = b;
-        sOcc[i] = occ;
+        if (occ) atomicOr(&sBits[hy][hx >> 5], 1u << (hx & 31));
     }
     __syncthreads();
     const int lx = tid & (KS_COLS - 1), ly = tid / KS_COLS;
@@ -443,35 +445,52 @@ __global__ void __launch_bounds__(256) k_kp_score(const caelo_frame_set fs, int 
     float best = 0.0f;
     bool is_cand = false;
     const int c = (ly + 2) * KS_HC + lx + 2;
-    if (x >= 8 && x < CAELO_NET_W - 8 && !(x >= 56 && x < 64) && sOcc[c]) {  // :163-167 (incl. the 56..63 quirk), :210-213
+    // the 5 x 5 window's occupancy as 25 bits (row oy at bits 5 (oy + 2) ..): one look at LDS instead of a test in front of every
+    // neighbour -- round 3 read a flag byte, branched, and only then fetched the neighbour's vector: 24 dependent round trips per pixel
+    unsigned int win = 0u;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const unsigned int *w = sBits[ly + r];
+        const int k = lx >> 5, sh = lx & 31;
+        const unsigned long long two = (unsigned long long)w[k] | ((unsigned long long)w[k + 1] << 32);
+        win |= ((unsigned int)(two >> sh) & 31u) << (5 * r);
+    }
+    if (x >= 8 && x < CAELO_NET_W - 8 && !(x >= 56 && x < 64) && ((win >> 12) & 1u)) {  // :163-167 (incl. the 56..63 quirk), :210-213
         const float4 pa = sR[2 * c], pb = sR[2 * c + 1];
-        int cnt = 0;
-        bool have = false;
+        const int cnt = __popc(win & ~(1u << 12));
+        best = __builtin_inff();
 #pragma unroll
         for (int oy = -2; oy <= 2; ++oy) {
+            // one row of the window at a time: its five vectors are requested together (ten 16-byte reads in flight), unconditionally;
+            // an unoccupied neighbour's sum is computed and dropped
+            float4 qa[5], qb[5];
+#pragma unroll
+            for (int ox = -2; ox <= 2; ++ox) {
+                const int q = c + oy * KS_HC + ox;
+                qa[ox + 2] = sR[2 * q];
+                qb[ox + 2] = sR[2 * q + 1];
+            }
 #pragma unroll
             for (int ox = -2; ox <= 2; ++ox) {
                 if (oy == 0 && ox == 0) continue;
-                const int q = c + oy * KS_HC + ox;
-                if (!sOcc[q]) continue;
-                const float4 qa = sR[2 * q], qb = sR[2 * q + 1];
+                const float4 va = qa[ox + 2], vb = qb[ox + 2];
                 float d;
-                d = __fsub_rn(qa.x, pa.x); const float s0 = __fmul_rn(d, d);
-                d = __fsub_rn(qa.y, pa.y); const float s1 = __fmul_rn(d, d);
-                d = __fsub_rn(qa.z, pa.z); const float s2 = __fmul_rn(d, d);
-                d = __fsub_rn(qa.w, pa.w); const float s3 = __fmul_rn(d, d);
-                d = __fsub_rn(qb.x, pb.x); const float s4 = __fmul_rn(d, d);
-                d = __fsub_rn(qb.y, pb.y); const float s5 = __fmul_rn(d, d);
-                d = __fsub_rn(qb.z, pb.z); const float s6 = __fmul_rn(d, d);
-                d = __fsub_rn(qb.w, pb.w); const float s7 = __fmul_rn(d, d);
+                d = __fsub_rn(va.x, pa.x); const float s0 = __fmul_rn(d, d);
+                d = __fsub_rn(va.y, pa.y); const float s1 = __fmul_rn(d, d);
+                d = __fsub_rn(va.z, pa.z); const float s2 = __fmul_rn(d, d);
+                d = __fsub_rn(va.w, pa.w); const float s3 = __fmul_rn(d, d);
+                d = __fsub_rn(vb.x, pb.x); const float s4 = __fmul_rn(d, d);
+                d = __fsub_rn(vb.y, pb.y); const float s5 = __fmul_rn(d, d);
+                d = __fsub_rn(vb.z, pb.z); const float s6 = __fmul_rn(d, d);
+                d = __fsub_rn(vb.w, pb.w); const float s7 = __fmul_rn(d, d);
                 const float t = __fadd_rn(__fadd_rn(__fadd_rn(s0, s1), __fadd_rn(s2, s3)),
                                           __fadd_rn(__fadd_rn(s4, s5), __fadd_rn(s6, s7)));
                 // the square root is monotone (correctly rounded): min over sqrt(t) = sqrt(min t), taken once below
-                if (!have || t < best) { best = t; have = true; }
-                ++cnt;
+                const bool o = (win >> (5 * (oy + 2) + ox + 2)) & 1u;
+                best = (o && t < best) ? t : best;
             }
         }
-        best = sqrtf(best);
+        best = cnt > 0 ? sqrtf(best) : 0.0f;
         if (cnt >= 5 && (double)best > 0.2) {  // :186, :126,:199
             const float *px = ring + ((int64_t)y * ring_w + x) * ring_c;
             float d2 = __fmul_rn(px[0], px[0]);
