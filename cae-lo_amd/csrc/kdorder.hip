@@ -49,16 +49,16 @@ struct caelo_kd {
 
 namespace {
 
-__global__ void __launch_bounds__(256) k_kd_collect(const uint8_t *__restrict__ flags, int64_t k_max, const int32_t *__restrict__ n_key,
+__global__ void __launch_bounds__(256) k_kd_collect(const uint8_t *__restrict__ flags, int64_t k0, int64_t k_max, const int32_t *__restrict__ n_key,
                                                     caelo_kd kd) {
-    const int64_t pw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pw >= k_max * 3) return;
-    const int64_t kp = pw / 3;
+    const int64_t pw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (key point of this chunk, scale)
+    if (pw >= kd.k_cap * 3) return;
+    const int64_t kp = k0 + pw / 3;
     const int sc = (int)(pw % 3);
-    const int K = n_key ? *n_key : (int)k_max;
-    if (kp >= K || !(flags[pw] & 2) || kd.s[sc].n < KD_MIN_N) return;
+    const int64_t K = n_key ? min((int64_t)*n_key, k_max) : k_max;
+    if (kp >= K || !(flags[kp * 3 + sc] & 2) || kd.s[sc].n < KD_MIN_N) return;
     const int q = atomicAdd(&kd.state[sc], 1);
-    if (q < kd.k_cap) kd.s[sc].queue[q] = (int32_t)kp;
+    kd.s[sc].queue[q] = (int32_t)kp;   // (at most k_cap entries per scale and chunk)
 }
 
 // One workgroup per scale.  Level by level; `tpn` threads share a node of the upper levels for the parallel parts (bounding box,
@@ -336,13 +336,14 @@ int kd_resolve(const caelo_voxmap *m, const float *pts, int pts_ld, int64_t k_ma
                hipStream_t s) {
     if (!m->kd || !m->kd_lists) return CAELO_OK;
     caelo_kd kd = *m->kd;
-    CAELO_REQUIRE(k_max <= kd.k_cap, "kd_resolve: more key points than the queue holds");
-    CAELO_HIP(hipMemsetAsync(kd.state, 0, 12, s));   // queue lengths (the built flags stay)
-    k_kd_collect<<<(unsigned)((k_max * 3 + 255) / 256), 256, 0, s>>>(flags, k_max, n_key, kd);
-    CAELO_LAUNCH_CHECK();
-    k_kd_build<<<3, 256, 0, s>>>(kd);
-    CAELO_LAUNCH_CHECK();
-    k_kd_query<<<dim3((unsigned)k_max, 3), 64, 0, s>>>(kd, pts, pts_ld, (unsigned long long *)bits, flags);
-    CAELO_LAUNCH_CHECK();
+    for (int64_t k0 = 0; k0 < k_max; k0 += kd.k_cap) {   // (the queues hold k_cap key points: longer point lists go chunk by chunk)
+        CAELO_HIP(hipMemsetAsync(kd.state, 0, 12, s));   // queue lengths (the built flags stay)
+        k_kd_collect<<<(unsigned)((kd.k_cap * 3 + 255) / 256), 256, 0, s>>>(flags, k0, k_max, n_key, kd);
+        CAELO_LAUNCH_CHECK();
+        k_kd_build<<<3, 256, 0, s>>>(kd);
+        CAELO_LAUNCH_CHECK();
+        k_kd_query<<<dim3((unsigned)kd.k_cap, 3), 64, 0, s>>>(kd, pts, pts_ld, (unsigned long long *)bits, flags);
+        CAELO_LAUNCH_CHECK();
+    }
     return CAELO_OK;
 }

@@ -192,6 +192,10 @@ def test_patches_truncation_taxonomy(api, orc, scans):
         assert np.array_equal(b, g[name + "_bits"])                         # the reference, every patch
     with pytest.raises(ValueError):
         api.GetPatchesList(g["sparse_pts"], g["sparse_vox"][:100], g["sparse_vox"], g["sparse_vox"])
+    # more key points than one queue holds (1 536: the tie-split patches go chunk by chunk)
+    many = np.tile(g["dense_pts"], (32, 1))
+    bits, flags = api.GetPatchesBits(many, g["dense_vox"], g["dense_vox"], g["dense_vox"])
+    assert np.array_equal(bits[:, 1].cpu().numpy().view(np.uint64), np.tile(g["dense_bits"], (32, 1))) and not (flags.cpu().numpy() & 2).any()
     # a list too short for the library's kd-tree (brute force there, NumPy's argpartition order): canonical rule, flag 2, and the
     # reference-named entry point says so
     dv = g["dense_vox"].astype(np.int64)
