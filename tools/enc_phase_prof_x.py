@@ -34,9 +34,9 @@ for frames in (1, 8):
     _, ms = eng.encode_profile(bits, group=3)
     eng.lib.caelo_debug_read(C.cast(buf, C.c_void_p))
     d = np.array(buf[16:32], dtype=np.int64) - before
-    tot = d[0:6].sum() + d[8:11].sum()
+    tot = d[0:6].sum() + d[8:12].sum()
     print("%d frame(s): stage1 %.1f us; patches %d, queued cells/patch %.1f, cycles/patch (one workgroup) %.0f" % (frames, ms[0] * 1e3, d[6], d[7] / max(d[6], 1), tot / max(d[6], 1)))
     for i in range(6):
         print("  %-18s %8.0f cycles/patch  %5.1f%%" % (names[i], d[i] / max(d[6], 1), 100.0 * d[i] / tot))
-    for nm, k in (("conv2 (pairs)", 8), ("wait for next rows / item", 9), ("P2 stores", 10)):
+    for nm, k in (("conv2 (pairs)", 8), ("wait: all memory back", 11), ("next rows to LDS", 9), ("P2 stores", 10)):
         print("  %-26s %8.0f cycles/patch  %5.1f%%" % (nm, d[k] / max(d[6], 1), 100.0 * d[k] / tot))
