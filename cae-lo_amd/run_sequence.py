@@ -48,7 +48,8 @@ def _parse_poses(raw, k):
     return out, ok, thr, nin
 
 
-def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, keep=None, strict_ties=True, tie_log=None):
+def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, keep=None, strict_ties=True, tie_log=None, host_times=None,
+              loader_threads=4):
     """Frames [lo, hi) of this rank.  Returns per-pair rows for pairs (i-1, i), i in (lo, hi) -- the pair (lo-1, lo)
     is the caller's (it needs the previous rank's last frame) -- plus the first and last frame's features.
 
@@ -75,11 +76,32 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
                 pinned[id(a)] = t
         return t
 
+    ht = host_times if host_times is not None else {}   # seconds per host activity (what a "frames/s incl. loading" figure is made of)
+    for k_ in ("load", "pin", "draws", "starved", "pipeline", "ties", "parse"):
+        ht.setdefault(k_, 0.0)
+
+    # The loader works with a few threads (file reads, NumPy's Mersenne Twister and the ray caster all release the GIL for most of
+    # their time) and fills pinned buffers that are allocated once: a pinned allocation per chunk cost more than the copy it serves.
+    from concurrent.futures import ThreadPoolExecutor
+    n_thr = max(1, loader_threads)
+    workers = ThreadPoolExecutor(max_workers=n_thr)
+    draw_ring = [torch.empty((min(chunk, hi - lo), 6000), dtype=torch.float64).pin_memory() for _ in range(4)]   # queue of 2 + one in use + one being filled
+
     def loader():
         try:
-            for c0, c1 in chunks:
-                scans = [pin(load(i)) for i in range(c0, c1)]
-                draws = torch.from_numpy(np.stack([ransac_draws(seed_base + i - 1) for i in range(c0, c1)])).pin_memory()
+            for ci, (c0, c1) in enumerate(chunks):
+                t_ = time.time()
+                raw = list(workers.map(load, range(c0, c1)))
+                t1_ = time.time()
+                scans = [pin(a) for a in raw]
+                t2_ = time.time()
+                draws = draw_ring[ci % len(draw_ring)][:c1 - c0]
+                dn = draws.numpy()
+
+                def fill(j):
+                    dn[j] = ransac_draws(seed_base + c0 + j - 1)
+                list(workers.map(fill, range(c1 - c0)))
+                ht["load"] += t1_ - t_; ht["pin"] += t2_ - t1_; ht["draws"] += time.time() - t2_
                 q.put((c0, c1, scans, draws))
         except BaseException as e:   # surfaced in the consumer
             q.put(e)
@@ -89,23 +111,31 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
     rel, ok, thr, nin = [], [], [], []
     prev, first = None, None
     pending = None   # (k, has_prev, pinned result, pinned status, event)
+    back_ring, n_back = [], 0
 
     def collect(p):
         k, has_prev, res_h, st_h, ev = p
         ev.synchronize()
+        t_ = time.time()
         for st in st_h.numpy()[:, 0]:
             raise_status(int(st))
         r, o, t, n = _parse_poses(res_h.numpy(), k)
         s = 0 if has_prev else 1                                   # slot 0 of the first chunk has no predecessor here
         rel.append(r[s:]); ok.append(o[s:]); thr.append(t[s:]); nin.append(n[s:])
+        ht["parse"] += time.time() - t_
 
     for _ in chunks:
+        t_ = time.time()
         item = q.get()
+        ht["starved"] += time.time() - t_
         if isinstance(item, BaseException):
             raise item
         c0, c1, scans, draws = item
+        t_ = time.time()
         draws_d = draws.to(eng.device, non_blocking=True)
         batch = pipe.run_uploading(scans, [draws_d[i] for i in range(c1 - c0)], prev=prev, dist_channels=dist_channels)
+        ht["pipeline"] += time.time() - t_
+        t_ = time.time()
         if strict_ties:
             # Frames whose 496-nearest cut (Voxel.py:195-196) splits a class of equidistant voxels: the fused path's canonical rule is
             # replaced by scikit-learn's kd-tree order (Engine.resolve_ties: ordered voxel lists, all on the device), then the pairs
@@ -118,11 +148,16 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
             for j in sorted({t for u in tied for t in (u, u + 1) if t < c1 - c0 and (t > 0 or prev is not None)}):
                 r_, m_, x_ = eng.match_pose(prev if j == 0 else batch.frame(j - 1), batch.frame(j), draws_d[j])
                 batch.result[j].copy_(r_); batch.inlier_mask[j].copy_(m_); batch.pair_idx[j].copy_(x_)
+        ht["ties"] += time.time() - t_
         # read this chunk's small outputs back without stalling the stream that issues the next chunk
         done = torch.cuda.Event()
         done.record()
-        res_h = torch.empty(batch.result[:c1 - c0].shape, dtype=batch.result.dtype).pin_memory()
-        st_h = torch.empty(batch.status[:c1 - c0].shape, dtype=batch.status.dtype).pin_memory()
+        if not back_ring:   # pinned read-back buffers, allocated once (three: one being parsed, one in flight, one being issued)
+            for _i in range(3):
+                back_ring.append((torch.empty((min(chunk, hi - lo),) + tuple(batch.result.shape[1:]), dtype=batch.result.dtype).pin_memory(),
+                                  torch.empty((min(chunk, hi - lo),) + tuple(batch.status.shape[1:]), dtype=batch.status.dtype).pin_memory()))
+        res_h, st_h = (t[:c1 - c0] for t in back_ring[n_back % 3])
+        n_back += 1
         with torch.cuda.stream(side):
             side.wait_event(done)
             res_h.copy_(batch.result[:c1 - c0], non_blocking=True)
@@ -157,6 +192,7 @@ def main():
     ap.add_argument("--scene", default="boxes", choices=("boxes", "clutter"), help="synthetic scene (caelo.synth)")
     ap.add_argument("--pool", type=int, default=0, help="synthesise only this many distinct scans and walk them back and forth (0 1 .. P-1 "
                                                         "P-2 .. 0 1 ..: every pair stays a pair of neighbours); ray casting a scan costs ~0.5 s of CPU")
+    ap.add_argument("--loader-threads", type=int, default=min(16, os.cpu_count() or 1), help="threads that read / synthesise scans and draw RANSAC's random numbers")
     ap.add_argument("--save-artifacts", action="store_true", help="write Features/*.mat and InliersIdx/*.mat next to the scans")
     ap.add_argument("--no-strict-ties", action="store_true", help="keep the fused path's canonical rule where the 496-nearest cut splits a "
                                                                   "tie class (default: such frames are redone in scikit-learn's kd-tree order)")
@@ -178,14 +214,19 @@ def main():
         files = sorted(glob.glob(os.path.join(args.scans, "*.bin")))
         n, load = len(files), (lambda i: stageio.read_scan(files[i]))
     else:
-        cache = {}
+        import threading
+        cache, locks, guard = {}, {}, threading.Lock()
 
-        def load(i):
-            if args.pool > 1:
-                i %= 2 * (args.pool - 1)
-                i = i if i < args.pool else 2 * (args.pool - 1) - i
-            if i not in cache:
-                cache[i] = synth.make_scan(i, quantum=args.quantum or None, scene_kind=args.scene)
+        def load(i):   # (called from the loader's threads: a pooled scan is synthesised once, by whoever asks first)
+            if args.pool <= 1:
+                return synth.make_scan(i, quantum=args.quantum or None, scene_kind=args.scene)
+            i %= 2 * (args.pool - 1)
+            i = i if i < args.pool else 2 * (args.pool - 1) - i
+            with guard:
+                lk = locks.setdefault(i, threading.Lock())
+            with lk:
+                if i not in cache:
+                    cache[i] = synth.make_scan(i, quantum=args.quantum or None, scene_kind=args.scene)
             return cache[i]
         load.repeats = args.pool > 1
         n = args.synthetic
@@ -209,8 +250,10 @@ def main():
                 stageio.save_inliers(os.path.dirname(os.path.dirname(files[c0 + j])), c0 + j - 1, c0 + j, idx[j, :k][m], np.arange(k)[m])
 
     tie_log = []
+    host_times = {}
     rel, ok, thr, nin, first, last = run_local(eng, load, lo, hi, args.seed_base, args.chunk, args.dist_channels,
-                                               args.batch, keep, strict_ties=not args.no_strict_ties, tie_log=tie_log)
+                                               args.batch, keep, strict_ties=not args.no_strict_ties, tie_log=tie_log, host_times=host_times,
+                                               loader_threads=args.loader_threads)
     if tie_log:
         print("rank %d: %d frame(s) redone in scikit-learn's tie order (%d patches): %s" % (
             rank, len(tie_log), sum(n for _, n in tie_log), [f for f, _ in tie_log][:20]), file=sys.stderr)
@@ -235,6 +278,10 @@ def main():
             print("%06d-%06d ok=%d thr=%.1f inliers=%4d T=[% .3f % .3f % .3f]" % (i, i + 1, ok[i], thr[i], nin[i], rel[i, 9], rel[i, 10], rel[i, 11]))
         print("%d frames, %d pairs on %d GPU(s) in %.2f s (%.1f frames/s incl. scan loading / synthesis, upload and read-back; %d of %d poses solved) -> %s" % (
             n, len(rel), world, dt, n / dt, int(np.sum(ok)), len(rel), args.out))
+        h = host_times
+        print("rank 0 host seconds -- loader thread: reading / synthesising scans %.2f, pinning %.2f, RANSAC draws %.2f; issuing thread: "
+              "waiting for the loader (%d threads) %.2f, pipeline calls (uploads paced, %d frames) %.2f, tie check + read-back issue %.2f, parsing results %.2f"
+              % (h["load"], h["pin"], h["draws"], args.loader_threads, h["starved"], hi - lo, h["pipeline"], h["ties"], h["parse"]))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

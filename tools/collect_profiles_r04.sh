@@ -42,7 +42,7 @@ py $R/tools/upload_overlap_check.py 2>&1 | tail -8 > $O/upload_overlap.txt
 # the front half: SQ counters per kernel, and the round-2 forms of the response layer / key point selection beside the defaults
 timeout 600 bash $R/tools/pmc_front.sh > $O/pmc_front.txt 2>&1
 bash $R/tools/front_times.sh > $O/front_times.txt 2>&1
-( cd $R && T=600 py cae-lo_amd/run_sequence.py --synthetic 4541 --pool 49 --quantum 0.001 --chunk 240 --out $O/poses_kitti00_sized.txt 2>&1 | tail -1 ) > $O/run_sequence_4541.txt
+( cd $R && T=600 py cae-lo_amd/run_sequence.py --synthetic 4541 --pool 49 --quantum 0.001 --chunk 240 --out $O/poses_kitti00_sized.txt 2>&1 | tail -2 ) > $O/run_sequence_4541.txt
 ( cd $R && timeout 300 python tools/stress_pairs.py 12 2>&1 | tail -1 ) > $O/stress_pairs.txt
 ( cd $R && bash tools/s1x_sweep.sh ) > $O/stage1_slots.txt 2>&1
 ( cd $R && T=1500 py tools/parity_soak.py --frames 200 --out $O/parity_soak.txt ) > $O/parity_soak.log 2>&1
