@@ -113,6 +113,7 @@ SIGNATURES = [
     ("caelo_pipeline_sync_encoded", c_int, [c_vp, c_int]),
     ("caelo_pipeline_set_pace", c_int, [c_vp, c_int]),
     ("caelo_pipeline_get_pace", c_int, [c_vp]),
+    ("caelo_upload_many", c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
     ("caelo_pipeline_stats", c_int, [c_vp, C.POINTER(c_i64)]),
     ("caelo_pipeline_expect", c_int, [c_vp, c_i64]),
     ("caelo_lane_faults", c_int, [c_vp, C.POINTER(c_i64)]),

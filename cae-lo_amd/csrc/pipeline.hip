@@ -337,6 +337,15 @@ CAELO_API int caelo_pipeline_begin(caelo_pipeline *p, void *stream) {
 // every batch is full and the remainder goes last.  Results do not depend on the plan (tests/test_gpu_parity.py).
 CAELO_API int caelo_pipeline_get_pace(const caelo_pipeline *p) { return p ? p->pace : 0; }
 
+CAELO_API int caelo_upload_many(void *const *dst, const void *const *src, const size_t *bytes, int n, void *stream) {
+    CAELO_REQUIRE(n >= 0 && (n == 0 || (dst && src && bytes)), "caelo_upload_many: null argument");
+    for (int i = 0; i < n; ++i) {
+        CAELO_REQUIRE(dst[i] && src[i], "caelo_upload_many: null buffer");
+        if (bytes[i]) CAELO_HIP(hipMemcpyAsync(dst[i], src[i], bytes[i], hipMemcpyHostToDevice, caelo_stream(stream)));
+    }
+    return CAELO_OK;
+}
+
 CAELO_API int caelo_pipeline_set_pace(caelo_pipeline *p, int lag) {
     CAELO_REQUIRE(p, "null argument");
     CAELO_REQUIRE(lag >= -1 && lag < p->n_buffers, "pace: -1 (the issuing thread never waits) .. buffers - 1");

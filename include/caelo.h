@@ -357,6 +357,10 @@ int caelo_pipeline_sync_encoded(caelo_pipeline *p, int lag);
  * a 20-batch run.  A caller that paces itself (caelo_pipeline_sync_encoded between its own work) turns this off. */
 int caelo_pipeline_set_pace(caelo_pipeline *p, int lag);
 int caelo_pipeline_get_pace(const caelo_pipeline *p);   /* the pacing in effect (the library's default until set) */
+/* n host -> device copies on `stream` behind one call (the scans of a batch that live in pinned host memory, the producer side of
+ * PoseEstimation.py:214-245): dst[i] <- src[i], bytes[i] each, asynchronous like hipMemcpyAsync.  The pipeline does not take part --
+ * the caller orders the copies against it (caelo_pipeline_wait_stream / an event of its own / caelo_pipeline_sync_encoded). */
+int caelo_upload_many(void *const *dst, const void *const *src, const size_t *bytes, int n, void *stream);
 /* host-side counters since the last call (then reset): out_host[6] = jobs, ns the calling thread spent issuing their
  * launches, batches launched, batch size, hand-off buffers, HIP streams used */
 /* Optional hint before caelo_pipeline_begin: the run will submit n_frames jobs.  If that is not a multiple of the batch size, the
