@@ -79,6 +79,7 @@ SIGNATURES = [
     ("caelo_unpack_patches", c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     ("caelo_pack_patches", c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     ("caelo_encode_ws_bytes", c_i64, [c_i64]),
+    ("caelo_encode_ws_layout", c_int, [c_i64, c_vp]),
     ("caelo_encode", c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp]),
     ("caelo_encode_profile", c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     ("caelo_patches32", c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_vp]),

@@ -581,17 +581,16 @@ class Engine:
     def encode_layers(self, bits):
         """Test aid: encode (group 1, every patch) and return the activations the four encoder kernels leave in the
         workspace -- P2 [n,1024] (after pool2), F3 [n,2048] (after conv3), the Dense(200) pre-activations summed over the
-        k slices [n,200] (bias not added) -- and the descriptors [n,20].  Workspace layout (encoder.hip,
-        encode_batch_impl): 2048-byte header | P2 [np][1024] | F3 [np][2048] | partial sums [8][np][208] f32,
-        np = n rounded up to 64; k slices in use: 4."""
+        k slices [n,200] (bias not added) -- and the descriptors [n,20].  Workspace layout: caelo_encode_ws_layout."""
         n = bits.numel() // 64
         out = self.encode(bits, 1)
         ws = self._encode_ws(n)
-        np_ = (n + 63) // 64 * 64
-        f = ws[2048:].view(torch.float32)
-        p2 = f[:np_ * 1024].view(np_, 1024)[:n]
-        f3 = f[np_ * 1024:np_ * 3072].view(np_, 2048)[:n]
-        part = f[np_ * 3072:np_ * 3072 + 8 * np_ * 208].view(8, np_, 208)[:4, :n, :200].sum(dim=0)
+        lay = (C.c_int64 * 6)()
+        _ffi.check(self.lib.caelo_encode_ws_layout(n, C.cast(lay, C.c_void_p)))
+        o_p2, o_f3, o_part, np_, used, sized = (int(v) for v in lay)
+        p2 = ws[o_p2:o_p2 + np_ * 4096].view(torch.float32).view(np_, 1024)[:n]
+        f3 = ws[o_f3:o_f3 + np_ * 8192].view(torch.float32).view(np_, 2048)[:n]
+        part = ws[o_part:o_part + sized * np_ * 208 * 4].view(torch.float32).view(sized, np_, 208)[:used, :n, :200].sum(dim=0)
         return p2.clone(), f3.clone(), part, out
 
     # ---- BASELINE.json configs[4]: 32^3 patches (stress case, not a reference code path; csrc/config5.hip) -----

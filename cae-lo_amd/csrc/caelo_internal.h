@@ -272,8 +272,9 @@ struct caelo_enc_out {
 // distinct patches of each frame are encoded, into rows f * per_frame + (position in the frame's list), and
 // k_enc_head hands patch p of frame f the result of row f * per_frame + slot_of[p].
 // encoder workspace header: [0] work counter of the per-workgroup stage-1 / conv-2 kernels, [8..15] executed-MFMA count of the
-// last counting launch, [1024..2047] eight per-XCD queue counters of k_enc_stage1w (a 128-byte line each).  Zero between calls.
-#define CAELO_ENC_WS_HEADER 2048
+// last counting launch, [1024..2047] eight per-XCD queue counters of k_enc_stage1x (a 128-byte line each), [2048..3071] the same for
+// k_enc_conv3 (each kernel zeroes the other's).  Zero between calls.
+#define CAELO_ENC_WS_HEADER 4096
 struct caelo_enc_in {
     const unsigned long long *bits;
     int64_t frame_stride;

@@ -51,6 +51,7 @@ __device__ inline float enc_tanh(float x) {
 #define DENSE_NP 208  // padded to 13 MFMA n-tiles
 #define DENSE_K 2048
 #define C3X_NPAIR 14  // tap pairs of the conv3 kernel (see k_enc_conv3)
+#define C3X_TICKET_INT 512   // conv3's eight per-XCD ticket counters: ints 512 + 32 x of the workspace header (bytes 2048 + 128 x)
 static void conv3_split_weights(const float *w3, uint4 *out);
 static void stage1x_split_weights(const float *w1, const float *w2, uint4 *w1f, uint4 *w2x);
 int enc_upload_dense1(const float *wd1, const float *bd1, int K, void **wx_dev, float **bd_dev);
@@ -316,6 +317,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
     // group-1 - j / nk, keypoint j % nk, i.e. coarsest scale first; a persistent workgroup takes the items
     // j = blockIdx.x + k * gridDim.x and so meets a mix of scales instead of one scale only.
     const int nk = (int)(n_patches / group);
+    if (blockIdx.x == 0 && tid < 8) work_counter[C3X_TICKET_INT + 32 * tid] = 0;   // conv3 (the next kernel on this stream) draws its pairs from here
     int j = blockIdx.x;
     // thread = one 16-voxel row of the patch (ix = tid >> 4, iy = tid & 15, bit = iz); fetched one patch ahead
     unsigned int row = 0u;
@@ -683,8 +685,20 @@ __global__ void __launch_bounds__(256, C3X_WGS) k_enc_conv3(const float *__restr
 #else
 #define C3_STAMP(i) do { } while (0)
 #endif
-    C3_FETCH((int)blockIdx.x)
-    for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+    // Work distribution: eight per-XCD queues as in stage 1 (pair p belongs to XCD p % 8; ONE counter for the 12 288 pairs of an
+    // 8-frame launch would retire its same-address atomics in ~150 us).  A workgroup's first two queue positions are static (its
+    // rank among the XCD's workgroups, then rank + their number), later ones are tickets drawn one iteration before they are needed
+    // as `next` (stage 1 zeroes the counters).  Inside the frame pipeline the grid leaves a quarter of the slots free and the other
+    // streams' kernels slow the workgroups of SOME CUs: with the static stride every workgroup did the same number of pairs and the
+    // launch ended with its slowest CU.
+    __shared__ int s_after[2];   // by iteration parity: thread 0 may be an iteration ahead of the slowest reader
+    const int xcd = (int)(blockIdx.x & 7u), wgs_of_xcd = ((int)gridDim.x - xcd + 7) >> 3;
+    int *const ticket = stage1_counter + C3X_TICKET_INT + 32 * xcd;
+    int pair = xcd + 8 * (int)(blockIdx.x >> 3), next = pair + 8 * wgs_of_xcd;
+    int drawn = 0;   // thread 0: the ticket drawn in the previous iteration
+    if (tid == 0) drawn = atomicAdd(ticket, 1);
+    C3_FETCH(pair)
+    for (int it = 0; pair < n_pairs; pair = next, next = __builtin_amdgcn_readfirstlane(s_after[it & 1]), ++it) {
         C3_STAMP(3);
         {   // split the staged 8 channels into the three bf16 terms: 3 x 16 B into LDS
             const float v[8] = {pre0.x, pre0.y, pre0.z, pre0.w, pre1.x, pre1.y, pre1.z, pre1.w};
@@ -704,10 +718,12 @@ __global__ void __launch_bounds__(256, C3X_WGS) k_enc_conv3(const float *__restr
             d[2 * C3X_SPLIT] = make_uint4(l[0], l[1], l[2], l[3]);
 #endif
         }
+        if (tid == 0) s_after[it & 1] = xcd + 8 * (2 * wgs_of_xcd + drawn);   // the pair after `next` (read after the loop's second barrier)
         C3_STAMP(0);
         __syncthreads();
         C3_STAMP(1);
-        C3_FETCH(pair + (int)gridDim.x)
+        if (tid == 0) drawn = atomicAdd(ticket, 1);
+        C3_FETCH(next)
         const int item = pair * 2 + slot;
         int patch;
         C3_ROW(item, patch)
@@ -1218,6 +1234,18 @@ static inline int64_t pad64(int64_t n) { return (n + D1_BM - 1) / D1_BM * D1_BM;
 CAELO_API int64_t caelo_encode_ws_bytes(int64_t n_patches) {
     const int64_t np = pad64(n_patches);
     return CAELO_ENC_WS_HEADER + (np * 1024 + np * 2048 + (int64_t)D1_SPLIT * np * DENSE_NP) * (int64_t)sizeof(float);
+}
+
+CAELO_API int caelo_encode_ws_layout(int64_t n_patches, int64_t out[6]) {
+    CAELO_REQUIRE(out && n_patches > 0, "caelo_encode_ws_layout: bad argument");
+    const int64_t np = pad64(n_patches);
+    out[0] = CAELO_ENC_WS_HEADER;
+    out[1] = out[0] + np * 1024 * (int64_t)sizeof(float);
+    out[2] = out[1] + np * 2048 * (int64_t)sizeof(float);
+    out[3] = np;
+    out[4] = D1_SPLIT_OF(DENSE_K);
+    out[5] = D1_SPLIT;
+    return CAELO_OK;
 }
 
 int encode_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,

@@ -150,8 +150,12 @@ int caelo_pack_patches(caelo_ctx *ctx, const float *dense, int64_t n_patches, ui
  * bits [n_patches][64] u64 -> out[(p / group) * out_stride + (p % group) * 20 + j].
  * group = 1, out_stride = 20: plain predict; group = 3, out_stride = 60 on [K][3][64]: Features [K][60].
  * workspace: ws of caelo_encode_ws_bytes(n_patches) bytes, zero-filled ONCE by its owner before the first call
- * (its first 2 048 bytes hold work counters that every call returns to zero), one ws per stream. */
+ * (its header holds work counters that every call returns to zero), one ws per stream.
+ * caelo_encode_ws_layout (test aid): byte offsets in ws of what the four kernels leave behind -- out[0] P2 [np][1024] f32 (after
+ * pool2), out[1] F3 [np][2048] (after conv3), out[2] Dense(200) partial sums [slices][np][208]; out[3] = np (rows padded to whole
+ * row tiles), out[4] = k slices in use, out[5] = k slices the buffer is sized for. */
 int64_t caelo_encode_ws_bytes(int64_t n_patches);
+int caelo_encode_ws_layout(int64_t n_patches, int64_t out[6]);
 int caelo_encode(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches, int group, float *out, int out_stride,
                  void *ws, void *stream);
 
