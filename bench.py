@@ -526,10 +526,8 @@ def main():
                                    "Round 3 moved stage 1 from the f32 pipe (0.39 of 157 TFLOP/s, 341 us) to 2-way f16 splits (224 us), round 4 to "
                                    "three workgroups per CU and plane-wise fragment fetches (195 us): the pipe is not what bounds the kernel (LDS "
                                    "round trips and instruction issue do), the launch time is the figure to compare across rounds",
-                    "sustained_pipe_rate_measured": {"tflops": 1341.0, "frac_of_it": round(float(table[names[dom]]["pipe_tflops"]) / 1341.0, 4),
-                                                     "source": "profiles/r03_f16_mfma_subnormal.txt: a bare loop of v_mfma_f32_16x16x32_f16 (4 waves per SIMD, 8 "
-                                                               "independent accumulators) on this chip; the clock gives way to the power budget "
-                                                               "(MI355X_MICROARCH.md, DVFS give-back).  Context only: `peak` and `frac` stay the guide's dense figure"},
+                    "pipe_rate_in_a_bare_loop": {"tflops": 2420.0, "source": "profiles/r04_mfma_rates.txt (tools/micro/mfma_rates.hip): v_mfma_f32_16x16x32_f16 and "
+                                                 "v_mfma_f32_32x32x16_f16 both sustain 2.41-2.44 PFLOP/s on this chip; `peak` stays the guide's dense figure"},
                     "algorithmic_tflops": round(float(alg_tf[dom]), 2),
                     "algorithmic_note": "dense Keras FLOPs of the layers the kernel replaces / launch time; stage 1 executes %.1f %% of "
                                         "the dense conv2 MFMAs on this scene (all-background rows add exact zeros and are skipped)" % (100.0 * exec_share),
