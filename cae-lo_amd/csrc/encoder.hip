@@ -678,7 +678,7 @@ __global__ void __launch_bounds__(256, C3X_WGS) k_enc_conv3(const float *__restr
             pre1 = q_[1];                                                                        \
         }                                                                                        \
     }
-#ifdef CAELO_ENC_PROF
+#ifdef CAELO_C3_PROF   // make C3PROF=1 (NOT together with PROF=1: stage 1's profile uses the same slots of g_enc_stamp)
     unsigned long long c3_t[4] = {0ull, 0ull, 0ull, 0ull};
     unsigned c3_prev = (unsigned)clock64();
 #define C3_STAMP(i) do { if (tid == 0) { const unsigned t_ = (unsigned)clock64(); c3_t[i] += t_ - c3_prev; c3_prev = t_; } } while (0)
@@ -791,7 +791,7 @@ __global__ void __launch_bounds__(256, C3X_WGS) k_enc_conv3(const float *__restr
         C3_STAMP(2);
         __syncthreads();
     }
-#ifdef CAELO_ENC_PROF
+#ifdef CAELO_C3_PROF
     if (tid == 0) {
         for (int i = 0; i < 4; ++i) atomicAdd(&g_enc_stamp[8 + i], c3_t[i]);
         atomicAdd(&g_enc_stamp[12], 1ull);
