@@ -851,10 +851,17 @@ int patch_debug_copy(unsigned long long *out_host) {
 // lane (they only matter for the 496-NN count).  Small LDS footprint = many resident wavefronts: the kernel is latency bound
 // (two dependent random accesses into tables that live at the memory side after the atomic build).
 struct PatchWaveLds {
-    unsigned long long win[27 * 8];
+    // The window bricks are read once (into each lane's output word) BEFORE the rare 496-nearest path starts: its histogram and the
+    // members of its cut class live in the same bytes (round 4: 4.5 -> 2.8 KB per wavefront -- beside the encoder's persistent
+    // workgroups the LDS that is left decides how many of this kernel's workgroups a CU takes).
+    union {
+        unsigned long long win[27 * 8];
+        struct {
+            unsigned long long cls[CLASS_CAP];
+            unsigned int hist[BALL_D2 + 1];
+        };
+    };
     unsigned int found[128];  // (table slot << 7 | ball-cube brick index) of the bricks that exist
-    unsigned int hist[BALL_D2 + 1];
-    unsigned long long cls[CLASS_CAP];
     int ncls, cut, room;
 };
 
