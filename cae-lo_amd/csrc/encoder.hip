@@ -867,10 +867,12 @@ typedef _Float16 d1_h8 __attribute__((ext_vector_type(8)));
 // The weight DMA, the F3 loads and the A stores are inline asm with hand-counted waits: with a compiler-visible LDS-DMA in the
 // loop hipcc waits vmcnt(0) before every use of a loaded register and before every LDS store, and lgkmcnt(0) before every use
 // of an LDS fragment (measured on a three-line kernel); without one its lgkmcnt arithmetic is exact.  Same products in the same order per accumulator as k_enc_dense1: bit-identical partial sums.
-#define D1P_BSTRIDE (32 * 64)  // uint4 per weight buffer: 26 pieces of 1 KB + the 6 more the eight waves' 4 pieces each bring along
+#define D1P_BSTRIDE (26 * 64)  // uint4 per weight buffer: the 26 pieces of 1 KB of a stage (waves 6 and 7 copy pieces 22..25, twice over: every wave issues
+                               // four loads per stage, which the vmcnt arithmetic relies on, and nothing lands outside the buffer -- round 3's buffers
+                               // were 32 KB for the six pieces the last waves brought along: 128 KB of LDS for the 128-row instance, now 110)
 #define D1P_NBUF(MTW) 3
 #define D1P_LDS_BYTES(MTW) ((2 * D1_NS * 4 * D1_BM * (MTW) + D1P_NBUF(MTW) * D1P_BSTRIDE) * 16)
-// MTW = 1: 64 rows per workgroup, 112 KB.  MTW = 2: 128 rows, 128 KB -- every wave owns two row tiles, each weight fragment feeds
+// MTW = 1: 64 rows per workgroup, 94 KB.  MTW = 2: 128 rows, 110 KB -- every wave owns two row tiles, each weight fragment feeds
 // two MFMAs, and the weight stream from L2 halves.  History of the 8-frame launch (24 576 rows): bf16 x 3 with 39 KB stages
 // streamed 983 MB at 64 rows (125 us = 7.9 TB/s, the LDS-DMA ceiling of the chip) and 118 us at 128 rows with TWO weight buffers
 // (all the LDS there was); f16 x 2 (26 KB stages, half the MFMAs) 101 us with two buffers -- a stage then cannot be shorter than
@@ -924,8 +926,9 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1p(const float *__re
     const int a_row = wave * 8 + ((lane >> 1) & 7), a_kq = ((lane >> 4) << 1) | (lane & 1);
     const float *a_src = f3 + (size_t)(row0 + a_row) * KTOT + (size_t)ks0 * D1_BK + a_kq * 4;
     // this wave's middle piece (5 wave + 2) of weight buffer 0 in LDS (the DMA adds 16 x lane itself) and of stage ks0 in memory
-    const uint32_t b_lds = (uint32_t)(uintptr_t)(void __attribute__((address_space(3))) *)(Bs + (4 * wave + 1) * 64);
-    const uint4 *b_mid = wd1x + (size_t)ks0 * D1_B16 + (4 * wave + 1) * 64 + lane;
+    const int pb = wave < 6 ? 4 * wave : 22;   // first of this wave's four pieces
+    const uint32_t b_lds = (uint32_t)(uintptr_t)(void __attribute__((address_space(3))) *)(Bs + (pb + 1) * 64);
+    const uint4 *b_mid = wd1x + (size_t)ks0 * D1_B16 + (pb + 1) * 64 + lane;
     // LDS byte address of this thread's 8 bytes of A buffer 0, high term ([split][g = a_kq >> 1][row] x 16 B, half a_kq & 1)
     const uint32_t a_lds = (uint32_t)(uintptr_t)(void __attribute__((address_space(3))) *)&As[(a_kq >> 1) * BM + a_row] + (a_kq & 1) * 8;
     f32x4 paA[MTW], paB[MTW];
