@@ -36,6 +36,24 @@ def test_no_cpu_fallback():
         Engine()
 
 
+def test_host_only_entry_points_without_a_gpu():
+    """Entry points that touch no device: the encoder workspace layout agrees with the size the library asks for (a test that
+    looks into the workspace asks for offsets instead of knowing a header size), and caelo_upload_many rejects null tables
+    before any HIP call (n = 0 is a no-op)."""
+    from caelo import _ffi
+    lib = _ffi.load()
+    for n in (1, 64, 3072, 24576):
+        lay = (ctypes.c_int64 * 6)()
+        assert lib.caelo_encode_ws_layout(n, ctypes.cast(lay, ctypes.c_void_p)) == 0
+        o_p2, o_f3, o_part, np_, used, sized = (int(v) for v in lay)
+        assert np_ >= n and np_ % 64 == 0 and 0 < used <= sized
+        assert 0 < o_p2 < o_f3 < o_part and o_f3 - o_p2 == np_ * 1024 * 4 and o_part - o_f3 == np_ * 2048 * 4
+        assert o_part + sized * np_ * 208 * 4 == lib.caelo_encode_ws_bytes(n)
+    assert lib.caelo_encode_ws_layout(0, None) != 0
+    assert lib.caelo_upload_many(None, None, None, 0, None) == 0
+    assert lib.caelo_upload_many(None, None, None, 1, None) != 0 and lib.caelo_last_error()
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(REPO, "cae-lo_amd")
     for root, _, files in os.walk(pkg):
