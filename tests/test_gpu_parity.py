@@ -1220,6 +1220,28 @@ def test_run_sequence_saves_consistent_artifacts_on_quantised_scans(tmp_path):
     assert len(open(out).read().splitlines()) == 6
 
 
+@pytest.mark.gpu
+def test_run_sequence_from_files_equals_the_synthetic_run(tmp_path):
+    """run_sequence.py --scans DIR (KITTI velodyne layout, BatchPreprocess.py:46-47): every .bin file is read straight into a reused
+    page-locked slot, in chunks smaller than the sequence so that slots ARE reused; the pose file equals the one of the run that
+    takes the same scans from memory, and a scan that does not fit a slot takes the per-scan path."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    from caelo import synth
+    d = tmp_path / "velodyne"
+    d.mkdir()
+    for i in range(11):
+        synth.make_scan(i).astype(np.float32).tofile(str(d / ("%06d.bin" % i)))
+    script = os.path.join(REPO, "cae-lo_amd", "run_sequence.py")
+    a, b, c = str(tmp_path / "a.txt"), str(tmp_path / "b.txt"), str(tmp_path / "c.txt")
+    subprocess.run([sys.executable, script, "--scans", str(d), "--chunk", "2", "--out", a], check=True, capture_output=True, timeout=300)
+    subprocess.run([sys.executable, script, "--synthetic", "11", "--out", b], check=True, capture_output=True, timeout=300)
+    env = dict(os.environ, CAELO_RUN_NO_PINNED_RING="1")
+    subprocess.run([sys.executable, script, "--scans", str(d), "--chunk", "3", "--out", c], check=True, capture_output=True, timeout=300, env=env)
+    assert open(a).read() == open(b).read() == open(c).read() and len(open(a).read().splitlines()) == 11
+
+
 # ---- round 2: the variants that claim bit-identical results, and the pipeline's batch plan -------------------------------------
 _VARIANT_SCRIPT = r"""
 import os, sys, hashlib
