@@ -105,6 +105,12 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
         try:
             for ci, (c0, c1) in enumerate(chunks):
                 t_ = time.time()
+                draws = draw_ring[ci % len(draw_ring)][:c1 - c0]
+                dn = draws.numpy()
+
+                def fill(j):
+                    dn[j] = ransac_draws(seed_base + c0 + j - 1)
+                drawn = [workers.submit(fill, j) for j in range(c1 - c0)]   # (beside the reads: both release the GIL for most of their time)
                 if hasattr(load, "into"):
                     scans = list(workers.map(lambda j: load.into(c0 + j, pinned_slot(ci, j), pin), range(c1 - c0)))
                     t1_ = t2_ = time.time()
@@ -113,13 +119,9 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
                     t1_ = time.time()
                     scans = [pin(a) for a in raw]
                     t2_ = time.time()
-                draws = draw_ring[ci % len(draw_ring)][:c1 - c0]
-                dn = draws.numpy()
-
-                def fill(j):
-                    dn[j] = ransac_draws(seed_base + c0 + j - 1)
-                list(workers.map(fill, range(c1 - c0)))
-                ht["load"] += t1_ - t_; ht["pin"] += t2_ - t1_; ht["draws"] += time.time() - t2_
+                for f_ in drawn:
+                    f_.result()
+                ht["load"] += t1_ - t_; ht["pin"] += t2_ - t1_; ht["draws"] += time.time() - t2_   # (draws: what was left of them after the scans)
                 q.put((c0, c1, scans, draws))
         except BaseException as e:   # surfaced in the consumer
             q.put(e)
