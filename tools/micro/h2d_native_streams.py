@@ -23,3 +23,20 @@ for ns in (1, 2, 4):
                     _ffi.check(lib.caelo_upload_many(d_.ctypes.data, s_.ctypes.data, n_.ctypes.data, len(idx), C.c_void_p(ss[k].cuda_stream)))
         torch.cuda.synchronize(); dt = time.perf_counter() - t
     print("640 copies of 2.1 MB over %d stream(s): %.1f GB/s" % (ns, 640 * N / dt / 1e9))
+
+# the same eight scans per batch as ONE copy of the span (caelo_upload_many: equal constant strides on both sides)
+cap = 160000 * 16
+hring = torch.empty(32 * cap // 4, dtype=torch.float32).pin_memory()
+dring = torch.empty(8 * cap // 4, dtype=torch.float32, device="cuda")
+src2 = np.array([hring.data_ptr() + i * cap for i in range(32)], dtype=np.uint64)
+dst2 = np.array([dring.data_ptr() + i * cap for i in range(8)], dtype=np.uint64)
+nb2 = np.full(8, N, dtype=np.uint64)
+st = torch.cuda.Stream()
+for rep in range(2):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for it in range(20):
+        for b in range(4):
+            s_ = src2[b * 8:b * 8 + 8].copy()
+            _ffi.check(lib.caelo_upload_many(dst2.ctypes.data, s_.ctypes.data, nb2.ctypes.data, 8, C.c_void_p(st.cuda_stream)))
+    torch.cuda.synchronize(); dt = time.perf_counter() - t
+print("80 span copies of 8 x 2.56 MB slots (one call each; 2.1 MB of each slot is payload): %.1f GB/s" % (640 * N / dt / 1e9))
