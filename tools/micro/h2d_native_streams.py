@@ -24,7 +24,8 @@ for ns in (1, 2, 4):
         torch.cuda.synchronize(); dt = time.perf_counter() - t
     print("640 copies of 2.1 MB over %d stream(s): %.1f GB/s" % (ns, 640 * N / dt / 1e9))
 
-# the same eight scans per batch as ONE copy of the span (caelo_upload_many: equal constant strides on both sides)
+# eight scans per call from consecutive slots of ONE pinned ring into consecutive slots of one device allocation (an experiment build of
+# caelo_upload_many turned such a batch into one pitched / one span copy: 55 / 46 GB/s here, slower inside the pipeline -- DESIGN 4.18)
 cap = 160000 * 16
 hring = torch.empty(32 * cap // 4, dtype=torch.float32).pin_memory()
 dring = torch.empty(8 * cap // 4, dtype=torch.float32, device="cuda")
@@ -39,4 +40,4 @@ for rep in range(2):
             s_ = src2[b * 8:b * 8 + 8].copy()
             _ffi.check(lib.caelo_upload_many(dst2.ctypes.data, s_.ctypes.data, nb2.ctypes.data, 8, C.c_void_p(st.cuda_stream)))
     torch.cuda.synchronize(); dt = time.perf_counter() - t
-print("80 span copies of 8 x 2.56 MB slots (one call each; 2.1 MB of each slot is payload): %.1f GB/s" % (640 * N / dt / 1e9))
+print("80 calls of 8 x 2.1 MB from a contiguous ring: %.1f GB/s" % (640 * N / dt / 1e9))
