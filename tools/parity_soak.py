@@ -73,10 +73,13 @@ def make_scans(scene, n, workers=None):
         return list(ex.map(_make, jobs, chunksize=max(1, n // (4 * workers))))
 
 
-def oracle_frame(orc, models, pc):
+def oracle_frame(orc, models, pc, dist_channels=5):
     ring, cnt = orc.ProjectPC2SphericalRing(pc)
     resp = models[0].predict(ring[None, 0:64, 0:1792, 0:3])[0]
-    kp, kpix, _ = orc.GetKeyPtsByAE(ring, cnt, resp)
+    if dist_channels == 3:   # batch mode (BatchPreprocess.py:97-98,131-136): the cropped three-channel ring, the full counter
+        kp, kpix, _ = orc.GetKeyPtsByAE(np.ascontiguousarray(ring[0:64, 0:1792, 0:3]), cnt, resp)
+    else:
+        kp, kpix, _ = orc.GetKeyPtsByAE(ring, cnt, resp)
     v = orc.Voxelization(pc[:, 0:3])
     bits, flags = zip(*[orc.patches_bits(kp, v[6 + s], s) for s in range(3)])
     feats = np.concatenate([models[1].predict_bits(b) for b in bits], axis=1)
@@ -141,7 +144,7 @@ def _sorted_rows(a):
     return a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
 
 
-def soak(engine, orc, models, scene, n_frames, seed_base=5000, batch=8, log=None, scans=None, workers=None):
+def soak(engine, orc, models, scene, n_frames, seed_base=5000, batch=8, log=None, scans=None, workers=None, dist_channels=5):
     """-> report dict (counts; `exceptions` = list of per-column records) for `n_frames` consecutive frames of `scene`."""
     import torch
     from caelo import _ffi
@@ -154,7 +157,7 @@ def soak(engine, orc, models, scene, n_frames, seed_base=5000, batch=8, log=None
     dpcs = [torch.from_numpy(pc).to(dev) for pc in scans]
     draws = [ransac_draws(seed_base + i) for i in range(n_frames)]
     rnd = [torch.from_numpy(d).to(dev) for d in draws]
-    out = engine.pipeline(batch).run(dpcs, rnd)
+    out = engine.pipeline(batch).run(dpcs, rnd, dist_channels=dist_channels)
     torch.cuda.synchronize()
     # frames whose 496-nearest cut splits a tie class: the fused path used its canonical rule there (flag bit 2); redone the
     # reference's way (Engine.resolve_ties: ordered voxel lists, scikit-learn's kd-tree order), then the two pairs they are part of
@@ -178,7 +181,7 @@ def soak(engine, orc, models, scene, n_frames, seed_base=5000, batch=8, log=None
     prev = None
     vm = engine.voxmap(max(engine.max_points, max(p.shape[0] for p in scans)), slot=6)
     for i in range(n_frames):
-        o = oracle_frame(orc, models, scans[i])
+        o = oracle_frame(orc, models, scans[i], dist_channels)
         k = len(o["kp"])
         same_pix = int(nkey[i]) == k and np.array_equal(kpix[i, :k], o["kpix"].astype(np.int64))
         same_pts = same_pix and np.array_equal(rows[i, :k, 60:63], o["kp"])
@@ -304,6 +307,7 @@ def main():
     ap.add_argument("--shuffled-frames", type=int, default=24, help="frames of the `shuffled` scene (an order check, not a soak)")
     ap.add_argument("--out", default=None)
     ap.add_argument("--seed-base", type=int, default=5000)
+    ap.add_argument("--dist-channels", type=int, default=5, choices=(3, 5), help="5 = demo mode, 3 = batch mode of the key point rule (SURVEY 8a-3')")
     args = ap.parse_args()
     names = args.scenes.split(",")
     plan = {s: (args.shuffled_frames if s == "shuffled" else args.frames) for s in names}
@@ -315,10 +319,12 @@ def main():
     orc.build()
     models = orc.load_models(os.path.join(REPO, "weights", "SphericalRingPCRespondLayer.h5"), os.path.join(REPO, "weights", "EncoderModel4VoxelPatch.h5"))
     eng = Engine()
-    text = ["parity soak: HIP pipeline vs CPU oracle, %s, oracle on %d threads" % (time.strftime("%Y-%m-%d"), orc.num_threads())]
+    text = ["parity soak: HIP pipeline vs CPU oracle, %s, oracle on %d threads, key point rule in %s mode (dist_channels %d)" % (
+        time.strftime("%Y-%m-%d"), orc.num_threads(), "demo" if args.dist_channels == 5 else "batch", args.dist_channels)]
     ok = True
     for s in names:
-        rep = soak(eng, orc, models, s, plan[s], seed_base=args.seed_base, log=lambda m: print(m, file=sys.stderr, flush=True), scans=all_scans[s])
+        rep = soak(eng, orc, models, s, plan[s], seed_base=args.seed_base, log=lambda m: print(m, file=sys.stderr, flush=True), scans=all_scans[s],
+                   dist_channels=args.dist_channels)
         ok &= clean(rep)
         text.append(render(rep))
         print(text[-1], flush=True)
