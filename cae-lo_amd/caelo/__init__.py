@@ -35,7 +35,7 @@ def configure_runtime(hw_queues=8):
     return True
 
 
-__all__ = ["api", "engine", "dist", "h5lite", "synth", "_ffi", "configure_runtime"]
+__all__ = ["api", "engine", "dist", "h5lite", "synth", "_ffi", "hostblas", "hostexact", "configure_runtime"]
 
 
 def __getattr__(name):

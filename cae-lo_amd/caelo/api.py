@@ -296,13 +296,31 @@ def SolveRT(Pairs0, Pairs1):
 def _ransac(pc0, pc1, pair_idx, rng):
     """Shared by RANSAC4RT / SolveRelativePose.  ``rng``: RandomState or None (NumPy's global RNG,
     like the reference).  The stream is advanced by exactly the draws the reference's loop would
-    have consumed (4 per iteration), whatever was pre-drawn for the GPU."""
+    have consumed (4 per iteration), whatever was pre-drawn for the GPU.
+
+    The kernels score the 500 hypotheses of a level and leave a certificate (an upper bound per hypothesis on the count the
+    reference's own float32 / BLAS arithmetic can reach); the host half (caelo.hostexact, csrc/certify.hip) replays
+    Match.py:181-214 over the bounds and re-evaluates the deciding hypotheses through NumPy's BLAS / LAPACK entry points:
+    the inlier mask, R_star / T_star and the refit are the reference's bits on this host."""
+    from . import hostexact
     e = default_engine()
     rs = np.random.mtrand._rand if rng is None else rng
     state = rs.get_state()
     draws = rs.random_sample(6000)
-    res, mask = e.ransac(pc0, pc1, pair_idx, torch.from_numpy(draws).to(e.device))
-    r = e.pose_result(res)
+    cert = e.new_cert(1)
+    res, mask = e.ransac(pc0, pc1, pair_idx, torch.from_numpy(draws).to(e.device), cert=cert[0])
+    results, masks, _, status = e.certify(cert, [draws])
+    n = int(pc1.shape[0])
+    if status[0] == 2:   # more than 1024 pairs: no certificate -- the reference's loop on the host arrays, hypothesis by hypothesis
+        p0 = pc0[:, :3][pair_idx].detach().cpu().numpy()
+        p1 = pc1[:, :3].detach().cpu().numpy()
+        r, m, _ = hostexact.ransac(p0, p1, draws)
+        r = np.array([r], dtype=results.dtype).view(np.recarray)[0]
+        mask = torch.from_numpy(m.astype(np.uint8)).to(e.device)
+    else:
+        assert status[0] == 0
+        r = results.view(np.recarray)[0]
+        mask = torch.from_numpy(masks[0, :n].copy()).to(e.device)
     used = 4 * (r.best_trial // 500 * 500 + r.iterations if r.success else 1500)
     rs.set_state(state)
     rs.random_sample(used)

@@ -116,6 +116,13 @@ class FrameBatch:
         self.result = eng.zeros((k, C.sizeof(_ffi.PoseResult)), torch.uint8)   # pair (i-1, i) in slot i
         self.inlier_mask = eng.zeros((k, MAX_K), torch.uint8)
         self.pair_idx = eng.zeros((k, MAX_K), torch.int64)
+        self.cert = None       # [k, sizeof(caelo_ransac_cert)] u8 once a run asked for certificates (Pipeline.run(certify=True))
+        self.exact = None      # host copy of the certified results (Engine.certify_batch)
+
+    def ensure_cert(self, eng):
+        if self.cert is None:
+            self.cert = eng.zeros((self.k, _ffi.CERT_DTYPE.itemsize), torch.uint8)
+        return self.cert
 
     def frame(self, i):
         return FrameFeatures(self.rows[i], self.key_pixels[i], self.n_key[i:i + 1], self.status[i], self.flags[i])
@@ -126,6 +133,8 @@ class FrameBatch:
         v.k = n
         for f in ("rows", "key_pixels", "n_key", "flags", "status", "result", "inlier_mask", "pair_idx"):
             setattr(v, f, getattr(self, f)[start:start + n])
+        v.cert = self.cert[start:start + n] if self.cert is not None else None
+        v.exact = None
         return v
 
 
@@ -157,7 +166,7 @@ class Pipeline:
         return {"jobs": int(out[0]), "issue_us_per_frame": out[1] / n / 1e3, "batches": int(out[2]), "batch": int(out[3]),
                 "buffers": int(out[4]), "streams": int(out[5])}
 
-    def _jobs(self, ptrs, counts, rands, prev, out, pairs, dist_channels, exact_voxels, dedup):
+    def _jobs(self, ptrs, counts, rands, prev, out, pairs, dist_channels, exact_voxels, dedup, certify=False):
         """The run's jobs as one record array, filled column-wise, handed over in ONE foreign call (a ctypes call per frame
         costs ~10 us: 380 us for a 20-frame run, most of it before the first launch)."""
         k = len(ptrs)
@@ -184,6 +193,8 @@ class Pipeline:
         jobs["result"] = out.result.data_ptr() + idx * out.result.shape[1]
         jobs["inlier_mask"] = out.inlier_mask.data_ptr() + idx * MAX_K
         jobs["pair_idx"] = out.pair_idx.data_ptr() + idx * (MAX_K * 8)
+        if certify and pairs and k > 0:
+            jobs["cert"] = out.ensure_cert(self.eng).data_ptr() + idx * _ffi.CERT_DTYPE.itemsize
         return jobs
 
     def wait_encoded(self, stream):
@@ -196,11 +207,12 @@ class Pipeline:
         _ffi.check(self.eng.lib.caelo_pipeline_sync_encoded(self.h, int(lag)))
 
     def run(self, scans, rands=None, prev=None, dist_channels=5, exact_voxels=False, out=None, pairs=True, dedup=True, on_batch=None,
-            on_encoded=None):
+            on_encoded=None, certify=False):
         """scans: K device tensors [n,4] f32; rands: K device tensors of RANSAC draws ([1500,4] f64).
         Frame i is matched against frame i-1 (pose in ``result[i]``); frame 0 against ``prev``
         (FrameFeatures) when given; ``pairs=False`` extracts only (BASELINE configs[1]).  Returns a FrameBatch; the
-        current stream has waited for all lanes.  ``on_encoded(lo, hi)`` is called, in order, once the rows of frames [lo, hi) are
+        current stream has waited for all lanes.  ``certify=True``: every pair also leaves its certificate (``out.cert``) for
+        ``Engine.certify_batch`` -- the host half that makes inlier sets and poses the reference's bits.  ``on_encoded(lo, hi)`` is called, in order, once the rows of frames [lo, hi) are
         WRITTEN (the calling thread has waited for them: caelo_pipeline_sync_encoded, one batch behind the issue) -- what it
         enqueues on any stream may read them at once; a caller ships finished rows that way while later batches run.
         ``on_batch(lo, hi)`` is called right after frames [lo, hi) have been issued (with ``wait_encoded`` the device-side form of
@@ -216,7 +228,7 @@ class Pipeline:
         for pc in scans:
             assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] == 4 and pc.is_contiguous()
         jobs = self._jobs([pc.data_ptr() for pc in scans], [pc.shape[0] for pc in scans], rands, prev, out, pairs, dist_channels,
-                          exact_voxels, dedup)
+                          exact_voxels, dedup, certify)
         tail = None   # a partial last batch is only issued by the flush: its callbacks come after that
         issued = []   # batches issued, not yet reported to on_encoded
         try:
@@ -255,7 +267,7 @@ class Pipeline:
         _ffi.check(self.eng.lib.caelo_pipeline_set_pace(self.h, int(lag)))
         self.pace = int(lag)
 
-    def run_uploading(self, host_scans, rands=None, prev=None, dist_channels=5, out=None, pairs=True, dedup=True, ahead=4):
+    def run_uploading(self, host_scans, rands=None, prev=None, dist_channels=5, out=None, pairs=True, dedup=True, ahead=4, certify=False):
         """``run`` for scans that live in (pinned) HOST memory: a copy stream uploads batch b + ``ahead`` while the pipeline works on
         batch b, into ``ahead + 2`` sets of device buffers -- the overlap of the reference's producer process, which prepares
         frame i + 1 while frame i is matched (PoseEstimation.py:214-245).  The hand-overs are paced by the calling thread, not by
@@ -282,7 +294,7 @@ class Pipeline:
         stream = eng.stream
         nb = (k + B - 1) // B
         jobs = self._jobs([bufs[(i // B) % slots][i % B].data_ptr() for i in range(k)], [int(pc.shape[0]) for pc in host_scans], rands, prev, out,
-                          pairs, dist_channels, False, dedup)
+                          pairs, dist_channels, False, dedup, certify)
         arrived = [torch.cuda.Event() for _ in range(nb)]
 
         # the copies of a batch go out behind ONE native call (caelo_upload_many): eight sliced torch copies cost the issuing thread
@@ -681,16 +693,64 @@ class Engine:
         _ffi.check(self.lib.caelo_solve_rt(self.ctx, _ptr(p0), _ptr(p1), p0.shape[0], _ptr(R), _ptr(T), _ptr(cred), self.stream))
         return R, T, cred
 
-    def ransac(self, pc0, pc1, pair_idx, rand, n1=None):
-        """rand: [1500,4] f64 uniform draws (device).  -> (result bytes tensor, mask [k1] uint8)."""
+    def ransac(self, pc0, pc1, pair_idx, rand, n1=None, cert=None):
+        """rand: [1500,4] f64 uniform draws (device).  -> (result bytes tensor, mask [k1] uint8).  ``cert``: a
+        [sizeof(caelo_ransac_cert)] u8 device tensor that receives the pair's certificate (``new_cert``)."""
         assert pair_idx.dtype == torch.int64 and pair_idx.is_contiguous()
         assert rand.dtype == torch.float64 and rand.numel() >= 6000 and rand.is_contiguous()
         res = self.empty((C.sizeof(_ffi.PoseResult),), torch.uint8)
         mask = self.empty((pc1.shape[0],), torch.uint8)
         _ffi.check(self.lib.caelo_ransac(self.ctx, _ptr(pc0), self._ld(pc0), _ptr(pc1), self._ld(pc1), _ptr(pair_idx),
                                          pc1.shape[0], _ptr(n1), _ptr(rand), _ptr(res), _ptr(mask),
-                                         _ptr(self._ws("ransac", self.lib.caelo_ransac_ws_bytes())), self.stream))
+                                         _ptr(self._ws("ransac", self.lib.caelo_ransac_ws_bytes())), _ptr(cert), self.stream))
         return res, mask
+
+    def new_cert(self, k=1):
+        """k zeroed caelo_ransac_cert records on the device."""
+        return self.zeros((k, _ffi.CERT_DTYPE.itemsize), torch.uint8)
+
+    # ---- the host half of the exact RANSAC (csrc/certify.hip, caelo/hostexact.py) ------------------------------------
+    def certify(self, certs, rands=None, threads=None):
+        """certs: [k, sizeof(caelo_ransac_cert)] u8 device tensor.  Copies the records to the host (synchronises) and runs
+        caelo_host_certify: Match.py:181-214 replayed over the device's bounds, the deciding hypotheses re-evaluated through
+        NumPy's own BLAS / LAPACK entry points.  ``rands``: the pairs' draws (list of host arrays or device tensors, or None) --
+        only read for a pair that escalates beyond the 0.4 m level.  -> (results record array [k] (_ffi.POSE_DTYPE),
+        masks [k,1024] u8, evals [k] i32, status [k] i32: 0 exact, 2 no bounds in the record (> 1024 pairs), 3 no record)."""
+        k = int(certs.shape[0])
+        nb = _ffi.CERT_DTYPE.itemsize
+        assert certs.dtype == torch.uint8 and certs.dim() == 2 and certs.shape[1] == nb and certs.is_contiguous()
+        host = self._pinned("cert", k * nb)[:k * nb].view(k, nb)
+        host.copy_(certs, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        from . import hostexact
+        return hostexact.certify_records(host.numpy(), rands, threads)
+
+    def certify_batch(self, out, rands=None, threads=None):
+        """Engine.certify over a FrameBatch that ran with ``certify=True``: the exact results replace ``out.result`` /
+        ``out.inlier_mask`` on the device (frames without a pair keep what they had) and stay on the host in ``out.exact`` =
+        (results, masks, evals, status).  Synchronises."""
+        assert out.cert is not None, "run the pipeline with certify=True"
+        res, masks, evals, status = self.certify(out.cert[:out.k], rands, threads)
+        ok = status == 0
+        if (status == 2).any():
+            raise _ffi.CaeloError("a pair holds more than 1024 matches: no certificate (use api.RANSAC4RT for such inputs)")
+        if ok.all():
+            out.result[:out.k].copy_(torch.from_numpy(res.view(np.uint8).reshape(out.k, -1)), non_blocking=False)
+            out.inlier_mask[:out.k].copy_(torch.from_numpy(masks), non_blocking=False)
+        elif ok.any():
+            sel = torch.from_numpy(np.flatnonzero(ok)).to(self.device)
+            out.result[sel] = torch.from_numpy(np.ascontiguousarray(res.view(np.uint8).reshape(out.k, -1)[ok])).to(self.device)
+            out.inlier_mask[sel] = torch.from_numpy(np.ascontiguousarray(masks[ok])).to(self.device)
+        out.exact = (res, masks, evals, status)
+        return out.exact
+
+    def _pinned(self, kind, nbytes):
+        t = self._pin.get(kind) if hasattr(self, "_pin") else None
+        if t is None or t.numel() < nbytes:
+            if not hasattr(self, "_pin"):
+                self._pin = {}
+            t = self._pin[kind] = torch.empty(int(nbytes), dtype=torch.uint8).pin_memory()
+        return t
 
     @staticmethod
     def pose_result(res):

@@ -180,6 +180,7 @@ struct caelo_pair_dev {
     const double *rand;
     caelo_pose_result *result;
     uint8_t *mask;
+    caelo_ransac_cert *cert;     // nullable: the certificate for the host half (certify.hip)
 };
 struct caelo_pair_set {
     caelo_pair_dev p[CAELO_FB_MAX];

@@ -85,6 +85,53 @@ __device__ inline int rigid_from_H_jacobi(const double Hin[9], const double m0[3
     return det < 0 ? -1 : 1;  // isCredible (:139,:152)
 }
 
+// The two poses SolveRT can return for a (numerically) RANK-2 covariance H (Match.py:148-157).  With sigma_3 = 0 the third
+// singular vectors are fixed up to a sign each, the SVD routine picks them, and the product V U^T comes out proper or
+// improper accordingly; the reference then either keeps it or applies its reflection quirk (Vh[:, 2] *= -1, i.e. row 2 of R
+// negated).  So the reference returns either Ra = w1 u1^T + w2 u2^T + w3 u3^T (u3 = u1 x u2, w3 = w1 x w2: det +1) or
+// Rb = diag(1, 1, -1) (Ra - 2 w3 u3^T).  Both are built here from the one-sided Jacobi SVD; the caller scores both.
+// Returns false when sigma_2 vanishes too (rank <= 1: a one-parameter family of poses, no finite list of candidates).
+__device__ inline bool rigid_two_candidates(const double Hin[9], const double m0[3], const double m1[3], float Ra[9], float Ta[3], float Rb[9],
+                                            float Tb[3]) {
+    double a00 = Hin[0], a01 = Hin[1], a02 = Hin[2], a10 = Hin[3], a11 = Hin[4], a12 = Hin[5], a20 = Hin[6], a21 = Hin[7], a22 = Hin[8];
+    double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
+#pragma unroll 1
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        double offmax = 0.0;
+        JAC_PAIR(a00, a10, a20, a01, a11, a21, v00, v10, v20, v01, v11, v21)
+        JAC_PAIR(a00, a10, a20, a02, a12, a22, v00, v10, v20, v02, v12, v22)
+        JAC_PAIR(a01, a11, a21, a02, a12, a22, v01, v11, v21, v02, v12, v22)
+        if (offmax == 0.0) break;
+    }
+    double s0 = sqrt(a00 * a00 + a10 * a10 + a20 * a20), s1 = sqrt(a01 * a01 + a11 * a11 + a21 * a21), s2 = sqrt(a02 * a02 + a12 * a12 + a22 * a22);
+    if (s1 > s0) { JAC_SWAP(s0, s1) JAC_SWAP(a00, a01) JAC_SWAP(a10, a11) JAC_SWAP(a20, a21) JAC_SWAP(v00, v01) JAC_SWAP(v10, v11) JAC_SWAP(v20, v21) }
+    if (s2 > s0) { JAC_SWAP(s0, s2) JAC_SWAP(a00, a02) JAC_SWAP(a10, a12) JAC_SWAP(a20, a22) JAC_SWAP(v00, v02) JAC_SWAP(v10, v12) JAC_SWAP(v20, v22) }
+    if (s2 > s1) { JAC_SWAP(s1, s2) JAC_SWAP(a01, a02) JAC_SWAP(a11, a12) JAC_SWAP(a21, a22) JAC_SWAP(v01, v02) JAC_SWAP(v11, v12) JAC_SWAP(v21, v22) }
+    if (!(s1 > 1e-7 * s0) || !(s0 > 0.0)) return false;
+    const double i0 = 1.0 / s0, i1 = 1.0 / s1;
+    const double u00 = a00 * i0, u10 = a10 * i0, u20 = a20 * i0, u01 = a01 * i1, u11 = a11 * i1, u21 = a21 * i1;
+    // third vectors by orthogonality (right-handed both): u3 = u1 x u2, w3 = w1 x w2
+    const double u02 = u10 * u21 - u20 * u11, u12 = u20 * u01 - u00 * u21, u22 = u00 * u11 - u10 * u01;
+    const double w02 = v10 * v21 - v20 * v11, w12 = v20 * v01 - v00 * v21, w22 = v00 * v11 - v10 * v01;
+    // Ra = W U^T with those columns
+    const double r0 = v00 * u00 + v01 * u01 + w02 * u02, r1 = v00 * u10 + v01 * u11 + w02 * u12, r2 = v00 * u20 + v01 * u21 + w02 * u22;
+    const double r3 = v10 * u00 + v11 * u01 + w12 * u02, r4 = v10 * u10 + v11 * u11 + w12 * u12, r5 = v10 * u20 + v11 * u21 + w12 * u22;
+    const double r6 = v20 * u00 + v21 * u01 + w22 * u02, r7 = v20 * u10 + v21 * u11 + w22 * u12, r8 = v20 * u20 + v21 * u21 + w22 * u22;
+    // Rb = D (Ra - 2 w3 u3^T), D = diag(1, 1, -1)
+    const double q0 = r0 - 2.0 * w02 * u02, q1 = r1 - 2.0 * w02 * u12, q2 = r2 - 2.0 * w02 * u22;
+    const double q3 = r3 - 2.0 * w12 * u02, q4 = r4 - 2.0 * w12 * u12, q5 = r5 - 2.0 * w12 * u22;
+    const double q6 = -(r6 - 2.0 * w22 * u02), q7 = -(r7 - 2.0 * w22 * u12), q8 = -(r8 - 2.0 * w22 * u22);
+    Ra[0] = (float)r0; Ra[1] = (float)r1; Ra[2] = (float)r2; Ra[3] = (float)r3; Ra[4] = (float)r4; Ra[5] = (float)r5; Ra[6] = (float)r6; Ra[7] = (float)r7; Ra[8] = (float)r8;
+    Rb[0] = (float)q0; Rb[1] = (float)q1; Rb[2] = (float)q2; Rb[3] = (float)q3; Rb[4] = (float)q4; Rb[5] = (float)q5; Rb[6] = (float)q6; Rb[7] = (float)q7; Rb[8] = (float)q8;
+    Ta[0] = (float)(m0[0] - (r0 * m1[0] + r1 * m1[1] + r2 * m1[2]));
+    Ta[1] = (float)(m0[1] - (r3 * m1[0] + r4 * m1[1] + r5 * m1[2]));
+    Ta[2] = (float)(m0[2] - (r6 * m1[0] + r7 * m1[1] + r8 * m1[2]));
+    Tb[0] = (float)(m0[0] - (q0 * m1[0] + q1 * m1[1] + q2 * m1[2]));
+    Tb[1] = (float)(m0[1] - (q3 * m1[0] + q4 * m1[1] + q5 * m1[2]));
+    Tb[2] = (float)(m0[2] - (q6 * m1[0] + q7 * m1[1] + q8 * m1[2]));
+    return true;
+}
+
 // Fast path: R = V U^T is the orthogonal polar factor of H^T.  Scaled Newton iteration
 // X <- (g X + X^-T / g) / 2 (Higham) converges quadratically in f64 (5-7 steps, no sqrt/div chains of a
 // Jacobi SVD: ~10x shorter dependency chain, and every hypothesis wavefront runs this serially).

@@ -528,8 +528,44 @@ __device__ __forceinline__ void ransac_replay(int N, const int32_t *counts, Rans
     out->best_trial = (success && target > 0) ? best : -1;  // N < 5: success without any accepted hypothesis -> identity (:177)
 }
 
-// hypothesis from 4 sampled pairs (SolveRT on the sample, Match.py:141-157; means / centring in f32 like
-// np.mean on f32 rows, covariance in f64)
+// the four sampled pairs of a hypothesis as SolveRT sees them (Match.py:141-146; means / centring in f32 like np.mean on
+// f32 rows, covariance in f64)
+struct Sample4 {
+    double m0[3], m1[3], H[9];
+    float c0[4][3], c1[4][3];
+    int idx[4];
+};
+__device__ inline void sample4(const float *P0, int l0, const int64_t *pidx, const float *P1, int l1, int N, const double *r4, Sample4 &s) {
+    float s0[4][3], s1[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = (int)(r4[q] * (double)N);  // :182-184 idx = int32(u * N), with replacement
+        s.idx[q] = idx;
+        const float *a = P0 + (size_t)l0 * (pidx ? pidx[idx] : idx);
+        const float *b = P1 + (size_t)l1 * idx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { s0[q][c] = a[c]; s1[q][c] = b[c]; }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float mm0 = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(s0[0][a], s0[1][a]), s0[2][a]), s0[3][a]), 4.0f);
+        const float mm1 = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(s1[0][a], s1[1][a]), s1[2][a]), s1[3][a]), 4.0f);
+        s.m0[a] = mm0; s.m1[a] = mm1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s.c0[q][a] = __fsub_rn(s0[q][a], mm0); s.c1[q][a] = __fsub_rn(s1[q][a], mm1); }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double h = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) h += (double)s.c1[q][i] * (double)s.c0[q][j];
+            s.H[3 * i + j] = h;
+        }
+}
+
+// hypothesis from 4 sampled pairs (SolveRT on the sample, Match.py:141-157)
 __device__ inline void sample_hypothesis(const float *P0, int l0, const int64_t *pidx, const float *P1, int l1, int N,
                                          const double *r4, float R[9], float T[3]) {
     float s0[4][3], s1[4][3];
@@ -561,6 +597,64 @@ __device__ inline void sample_hypothesis(const float *P0, int l0, const int64_t 
             H[3 * i + j] = h;
         }
     rigid_from_H(H, m0, m1, R, T);
+}
+
+// ---- how far the reference's own arithmetic can move a residual of this hypothesis (the certificate of caelo.h) ----------
+// The reference forms H = P1^T P0 in float32 through its BLAS (rounding error <= ~4 eps32 sum |c1||c0| per entry, order and
+// fusing unknown), takes the float64 SVD of THAT matrix, rounds U and Vh to float32, multiplies R and T in float32 and
+// evaluates the residuals in float32 (Match.py:146-157,:190-192); this kernel fits the exact float64 covariance of the same
+// centred float32 points.  The rotation of a Kabsch fit moves by at most 2 |dH| / (s2 + s3) under a perturbation dH of the
+// covariance, so with kappa = s1 / s2 the two poses differ by O(eps32 (1 + kappa)) in R, and the residual of pair j by at most
+//     band_j = CB eps32 [ (1 + kappa) |p1_j - mean1| + |p0_j| + |p1_j| + |T| ],      CB = 16
+// (measured over 54 000 samples of the golden pairs against NumPy: the largest ratio residual difference / bracket is 3.5,
+// the 99.9th percentile 2.7 -- tools/ransac_bound_calibration.py; CB = 16 leaves a factor 4.5).  kappa is bounded from the
+// invariants I1 = |H|_F^2, I2 = |cof H|_F^2: kappa <= sqrt(2) I1 / sqrt(I2).  |p1_j - mean1| <= |p1_j| + |mean1|.  So
+//     residual_ref_j < thr   ==>   residual_j < thr + a + b |p1_j| + g |p0_j|,   g = CB eps32, b = g (2 + kappa),
+//                                                                                a = g ((2 + kappa) |mean1| + |mean0|)   (|T| <= |mean0| + |mean1|)
+// and the number of pairs passing the right-hand test is an upper bound `hi` on the reference's inlier count.
+// kind 1 -- the sign of det H is not safe against the float32 rounding of H (|det| <= 64 eps32 sum |cof_ij| A_ij: a sample with
+// a repeated point, four coplanar points): the reference's SVD picks the third singular vectors' signs, its pose is one of the
+// two of rigid_two_candidates; both are scored and the larger bound is kept.  kind 2 -- rank <= 1: no bound (hi = N).
+// Evaluated BEFORE the pose is derived, so that nothing of the sample but (a, b, kind) stays live across the residual pass.
+#define RB_G 9.5367431640625e-7f  // CB eps32 = 16 * 2^-24
+struct HypBound {
+    float a, b;
+    int kind;
+};
+__device__ inline void hypothesis_bound(const Sample4 &s, HypBound &hb) {
+    const double *H = s.H;
+    const double C0 = H[4] * H[8] - H[5] * H[7], C1 = H[5] * H[6] - H[3] * H[8], C2 = H[3] * H[7] - H[4] * H[6];
+    const double C3 = H[2] * H[7] - H[1] * H[8], C4 = H[0] * H[8] - H[2] * H[6], C5 = H[1] * H[6] - H[0] * H[7];
+    const double C6 = H[1] * H[5] - H[2] * H[4], C7 = H[2] * H[3] - H[0] * H[5], C8 = H[0] * H[4] - H[1] * H[3];
+    const double det = H[0] * C0 + H[1] * C1 + H[2] * C2;
+    double I1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) I1 += H[i] * H[i];
+    const double I2 = C0 * C0 + C1 * C1 + C2 * C2 + C3 * C3 + C4 * C4 + C5 * C5 + C6 * C6 + C7 * C7 + C8 * C8;
+    // sum |cof_ij| A_ij, A_ij = sum_q |c1_qi| |c0_qj|: what a relative rounding error of every product can do to det H
+    float sumCA = 0.f;
+    const float aC[9] = {(float)fabs(C0), (float)fabs(C1), (float)fabs(C2), (float)fabs(C3), (float)fabs(C4), (float)fabs(C5), (float)fabs(C6), (float)fabs(C7), (float)fabs(C8)};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t += fabsf(s.c1[q][i]) * fabsf(s.c0[q][j]);
+            sumCA += aC[3 * i + j] * t;
+        }
+    hb.kind = 0;
+    hb.a = 0.f;
+    hb.b = 0.f;
+    if (!(I2 > 1e-10 * I1 * I1) || !(I1 > 0.0)) { hb.kind = 2; return; }
+    const double kappa = 1.41421356237309515 * I1 / sqrt(I2);
+    if (fabs(det) <= 64.0 * 5.9604644775390625e-8 * 1.001 * (double)sumCA) hb.kind = 1;
+    const double nm0 = sqrt(s.m0[0] * s.m0[0] + s.m0[1] * s.m0[1] + s.m0[2] * s.m0[2]);
+    const double nm1 = sqrt(s.m1[0] * s.m1[0] + s.m1[1] * s.m1[1] + s.m1[2] * s.m1[2]);
+    // |T|_inf <= |mean0| + |R mean1| = |mean0| + |mean1| for every candidate pose (T = mean0 - R mean1, Match.py:157)
+    // (rounded up: the float conversions and the float evaluation of the test are covered by the 1.0001)
+    hb.a = (float)(1.0001 * (double)RB_G * ((2.0 + kappa) * nm1 + nm0));
+    hb.b = (float)(1.0001 * (double)RB_G * (2.0 + kappa));
 }
 
 // Two launches per set of pairs.
@@ -622,12 +716,25 @@ __device__ inline int hypothesis_count(const float *P0, int l0, const int64_t *p
 // all four (a pair is read from LDS once).  Round 2 before: one hypothesis per wavefront, 35 us per 8 pairs.
 // `rnd`: the draws of the level (trial t at rnd + 4 t); counts[trial0 .. trial0 + 3] are written.
 #define RH_PER_WAVE 4
+// CERT: also the certificate's bound (sN: per pair (|p1_j|, g |p0_j|); cert: the record `hi` / `idx` of the trials go to)
+template <bool CERT>
 __device__ inline void four_hypotheses(const float *sP0, const float *sP1, int N, const double *rnd, int trial0, float thr, int lane,
-                                       int32_t *faults, int32_t *counts) {
+                                       int32_t *faults, int32_t *counts, const float2 *sN = nullptr, caelo_ransac_cert *cert = nullptr) {
     // ---- lane l: hypothesis trial0 + (l & 3) (a trial past the last repeats the last one; its count is not stored)
     const int mine = min(trial0 + (lane & (RH_PER_WAVE - 1)), CAELO_RANSAC_MAX_TRIALS - 1);
     float R[9], T[3];
-    sample_hypothesis(sP0, 3, nullptr, sP1, 3, N, rnd + (size_t)mine * 4, R, T);
+    HypBound hb = {0.f, 0.f, 0};
+    if (CERT) {
+        Sample4 smp;
+        sample4(sP0, 3, nullptr, sP1, 3, N, rnd + (size_t)mine * 4, smp);
+        hypothesis_bound(smp, hb);
+        if (lane < RH_PER_WAVE && trial0 + lane < CAELO_RANSAC_MAX_TRIALS)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cert->idx[trial0 + lane][q] = smp.idx[q];
+        rigid_from_H(smp.H, smp.m0, smp.m1, R, T);
+    } else {
+        sample_hypothesis(sP0, 3, nullptr, sP1, 3, N, rnd + (size_t)mine * 4, R, T);
+    }
     if (faults) {  // the 16 lanes of a hypothesis hold the same pose, bit for bit
         unsigned int hsh = 0;
 #pragma unroll
@@ -648,16 +755,90 @@ __device__ inline void four_hypotheses(const float *sP0, const float *sP1, int N
         for (int q = 0; q < 3; ++q) Ts[h][q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(T[q]), h));
     }
     int cnt[RH_PER_WAVE] = {0, 0, 0, 0};
-    for (int i = lane; i < ((N + 63) & ~63); i += 64) {
-        const bool live = i < N;
-        const int ii = live ? i : 0;
-        const float ax = sP0[3 * ii], ay = sP0[3 * ii + 1], az = sP0[3 * ii + 2];
-        const float bx = sP1[3 * ii], by = sP1[3 * ii + 1], bz = sP1[3 * ii + 2];
+    if (!CERT) {
+        for (int i = lane; i < ((N + 63) & ~63); i += 64) {
+            const bool live = i < N;
+            const int ii = live ? i : 0;
+            const float ax = sP0[3 * ii], ay = sP0[3 * ii + 1], az = sP0[3 * ii + 2];
+            const float bx = sP1[3 * ii], by = sP1[3 * ii + 1], bz = sP1[3 * ii + 2];
+#pragma unroll
+            for (int h = 0; h < RH_PER_WAVE; ++h) {
+                const bool in = live && residual(Rs[h], Ts[h], ax, ay, az, bx, by, bz) < thr;
+                cnt[h] += __popcll(__ballot(in));
+            }
+        }
+    } else {
+        // ---- the same pass with the certificate's second test (hypothesis_bound); rank-2 samples get their two candidate poses
+        // scored as well, rank-1 samples no bound
+        float as[RH_PER_WAVE], bs[RH_PER_WAVE];
+        int kinds[RH_PER_WAVE];
 #pragma unroll
         for (int h = 0; h < RH_PER_WAVE; ++h) {
-            const bool in = live && residual(Rs[h], Ts[h], ax, ay, az, bx, by, bz) < thr;
-            cnt[h] += __popcll(__ballot(in));
+            as[h] = thr + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hb.a), h));
+            bs[h] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hb.b), h));
+            kinds[h] = __builtin_amdgcn_readlane(hb.kind, h);
         }
+        int hi[RH_PER_WAVE] = {0, 0, 0, 0};
+        for (int i = lane; i < ((N + 63) & ~63); i += 64) {
+            const bool live = i < N;
+            const int ii = live ? i : 0;
+            const float ax = sP0[3 * ii], ay = sP0[3 * ii + 1], az = sP0[3 * ii + 2];
+            const float bx = sP1[3 * ii], by = sP1[3 * ii + 1], bz = sP1[3 * ii + 2];
+            const float2 nn = sN[ii];
+#pragma unroll
+            for (int h = 0; h < RH_PER_WAVE; ++h) {
+                const float r = residual(Rs[h], Ts[h], ax, ay, az, bx, by, bz);
+                cnt[h] += __popcll(__ballot(live && r < thr));
+                hi[h] += __popcll(__ballot(live && r < as[h] + fmaf(bs[h], nn.x, nn.y)));
+            }
+        }
+        if ((kinds[0] | kinds[1] | kinds[2] | kinds[3]) & 1) {  // wave-uniform: some hypothesis of this wavefront has two candidate poses
+            // (derived again from the sample: cheaper than carrying 24 more registers through the pass every wavefront runs)
+            float Ra[9], Ta[3], Rb[9], Tb[3];
+            bool two;
+            {
+                Sample4 smp;
+                sample4(sP0, 3, nullptr, sP1, 3, N, rnd + (size_t)mine * 4, smp);
+                two = rigid_two_candidates(smp.H, smp.m0, smp.m1, Ra, Ta, Rb, Tb);
+            }
+            int ha[RH_PER_WAVE] = {0, 0, 0, 0};
+#pragma unroll 1
+            for (int h = 0; h < RH_PER_WAVE; ++h) {
+                if (kinds[h] != 1) continue;  // (scalar condition)
+                if (!__builtin_amdgcn_readlane((int)two, h)) { ha[h] = N; continue; }
+                float Ras[9], Tas[3], Rbs[9], Tbs[3];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    Ras[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Ra[q]), h));
+                    Rbs[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Rb[q]), h));
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    Tas[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Ta[q]), h));
+                    Tbs[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tb[q]), h));
+                }
+                int na = 0, nb = 0;
+                for (int i = lane; i < ((N + 63) & ~63); i += 64) {
+                    const bool live = i < N;
+                    const int ii = live ? i : 0;
+                    const float ax = sP0[3 * ii], ay = sP0[3 * ii + 1], az = sP0[3 * ii + 2];
+                    const float bx = sP1[3 * ii], by = sP1[3 * ii + 1], bz = sP1[3 * ii + 2];
+                    const float2 nn = sN[ii];
+                    const float lim = as[h] + fmaf(bs[h], nn.x, nn.y);
+                    na += __popcll(__ballot(live && residual(Ras, Tas, ax, ay, az, bx, by, bz) < lim));
+                    nb += __popcll(__ballot(live && residual(Rbs, Tbs, ax, ay, az, bx, by, bz) < lim));
+                }
+                ha[h] = max(na, nb);
+            }
+#pragma unroll
+            for (int h = 0; h < RH_PER_WAVE; ++h)
+                if (kinds[h] == 1) hi[h] = max(hi[h], ha[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < RH_PER_WAVE; ++h)
+            if (kinds[h] == 2) hi[h] = N;
+        if (lane < RH_PER_WAVE && trial0 + lane < CAELO_RANSAC_MAX_TRIALS)
+            cert->hi[trial0 + lane] = lane == 0 ? hi[0] : (lane == 1 ? hi[1] : (lane == 2 ? hi[2] : hi[3]));
     }
     if (lane < RH_PER_WAVE && trial0 + lane < CAELO_RANSAC_MAX_TRIALS)
         counts[trial0 + lane] = lane == 0 ? cnt[0] : (lane == 1 ? cnt[1] : (lane == 2 ? cnt[2] : cnt[3]));
@@ -669,6 +850,8 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp(const caelo_pair_s
     const int64_t *__restrict__ pair_idx = P.pair_idx;
     RansacWs *ws = (RansacWs *)P.ws_ransac;
     __shared__ float sP0[RE_LDS_PAIRS * 3], sP1[RE_LDS_PAIRS * 3];
+    __shared__ float2 sN[RE_LDS_PAIRS];  // certificate: (|p1_j|, g |p0_j|) of hypothesis_bound
+    caelo_ransac_cert *cert = P.cert;
     // no pairs at all when EITHER frame has no key point (frame 0 empty: the match kernel wrote index 0 everywhere, the
     // reference's argmin over an empty axis raises): the pose fails as a value
     const int N = (P.n0 && *P.n0 <= 0) ? 0 : (P.n1 ? min(max(*P.n1, 0), (int)k1_max) : (int)k1_max);
@@ -679,8 +862,10 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp(const caelo_pair_s
         for (int i = tid; i < N; i += 64 * RE_WAVES) {
             const float *a = pc0 + (size_t)ld0 * pair_idx[i];
             const float *b = pc1 + (size_t)ld1 * i;
-            sP0[3 * i] = a[0]; sP0[3 * i + 1] = a[1]; sP0[3 * i + 2] = a[2];
-            sP1[3 * i] = b[0]; sP1[3 * i + 1] = b[1]; sP1[3 * i + 2] = b[2];
+            const float a0 = a[0], a1 = a[1], a2 = a[2], b0 = b[0], b1 = b[1], b2 = b[2];
+            sP0[3 * i] = a0; sP0[3 * i + 1] = a1; sP0[3 * i + 2] = a2;
+            sP1[3 * i] = b0; sP1[3 * i + 1] = b1; sP1[3 * i + 2] = b2;
+            if (cert) sN[i] = make_float2(1.0001f * sqrtf(b0 * b0 + b1 * b1 + b2 * b2), 1.0001f * RB_G * sqrtf(a0 * a0 + a1 * a1 + a2 * a2));
         }
     }
     __syncthreads();
@@ -693,7 +878,8 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp(const caelo_pair_s
         }
         return;
     }
-    four_hypotheses(sP0, sP1, N, P.rand, trial0, 0.4f, lane, ps.faults, ws->counts);
+    if (cert) four_hypotheses<true>(sP0, sP1, N, P.rand, trial0, 0.4f, lane, ps.faults, ws->counts, sN, cert);
+    else four_hypotheses<false>(sP0, sP1, N, P.rand, trial0, 0.4f, lane, ps.faults, ws->counts);
 }
 
 #define RF_WAVES 8   // the accept rules, the mask and the refit use four of them; all eight evaluate a next level's hypotheses
@@ -736,6 +922,18 @@ __global__ void __launch_bounds__(64 * RF_WAVES, 4) k_ransac_finish(const caelo_
     // ---- accept rules, level by level (:207-214: thr doubles while no hypothesis reaches leastInliers, up to 1.6)
     if (tid < 64) ransac_replay(N, ws->counts, &s_v, c0);
     __syncthreads();  // also the end of the staging above
+    if (P.cert) {  // the certificate's header and the matched pairs (k_ransac_hyp wrote `hi` and `idx`)
+        caelo_ransac_cert *cert = P.cert;
+        if (in_lds) {
+            float *d0 = &cert->p0[0][0], *d1 = &cert->p1[0][0];
+            for (int i = tid; i < 3 * N; i += 64 * RF_WAVES) { d0[i] = sP0[i]; d1[i] = sP1[i]; }
+        }
+        if (tid == 0) {
+            cert->n_pairs = N;
+            cert->flags = in_lds ? 0 : CAELO_CERT_NO_BOUNDS;
+            cert->magic = CAELO_CERT_MAGIC;
+        }
+    }
     int level = 0;
     while (!s_v.success && level < CAELO_RANSAC_LEVELS - 1) {  // rare: the next level's 500 hypotheses, four per wavefront like k_ransac_hyp
         __syncthreads();  // everyone has read s_v before it is overwritten
@@ -744,7 +942,7 @@ __global__ void __launch_bounds__(64 * RF_WAVES, 4) k_ransac_finish(const caelo_
         const double *rnd_l = rnd + (size_t)level * CAELO_RANSAC_MAX_TRIALS * 4;
         if (in_lds) {
             for (int trial0 = wave * RH_PER_WAVE; trial0 < CAELO_RANSAC_MAX_TRIALS; trial0 += RF_WAVES * RH_PER_WAVE)
-                four_hypotheses(sP0, sP1, N, rnd_l, trial0, thr_l, lane, ps.faults, ws->counts);
+                four_hypotheses<false>(sP0, sP1, N, rnd_l, trial0, thr_l, lane, ps.faults, ws->counts);
         } else {
             for (int trial = wave; trial < CAELO_RANSAC_MAX_TRIALS; trial += RF_WAVES) {
                 const int cnt = hypothesis_count(pc0, ld0, pair_idx, pc1, ld1, N, rnd_l + (size_t)trial * 4, thr_l, lane, ps.faults);
@@ -847,14 +1045,15 @@ __global__ void __launch_bounds__(64 * RF_WAVES, 4) k_ransac_finish(const caelo_
 
 CAELO_API int caelo_ransac(caelo_ctx *c, const float *pc0, int ld0, const float *pc1, int ld1, const int64_t *pair_idx,
                            int64_t k1_max, const int32_t *n1, const double *rnd, caelo_pose_result *result,
-                           uint8_t *inlier_mask, void *wsv, void *stream) {
+                           uint8_t *inlier_mask, void *wsv, caelo_ransac_cert *cert, void *stream) {
     CAELO_REQUIRE(c && pc0 && pc1 && pair_idx && rnd && result && inlier_mask && wsv, "null argument");
+    CAELO_REQUIRE((((uintptr_t)cert) & 15u) == 0, "certificate not 16-byte aligned");
     caelo_pair_set ps = {};
     ps.n = 1;
     ps.faults = c->faults;
     caelo_pair_dev &p = ps.p[0];
     p.pc0 = pc0; p.pc1 = pc1; p.pair_idx = const_cast<int64_t *>(pair_idx); p.n1 = n1; p.rand = rnd; p.result = result;
-    p.mask = inlier_mask; p.ws_ransac = wsv;
+    p.mask = inlier_mask; p.ws_ransac = wsv; p.cert = cert;
     return ransac_set(ps, ld0, ld1, k1_max, caelo_stream(stream));
 }
 

@@ -135,7 +135,7 @@ int issue_batch_impl(caelo_pipeline *p) {
         d.f0 = prev_rows; d.n0 = prev_n; d.f1 = j.rows; d.n1 = j.n_key;
         d.pc0 = prev_rows + 60; d.pc1 = j.rows + 60;
         d.pair_idx = j.pair_idx; d.ws_match = p->ws_match[ps.n]; d.ws_ransac = p->ws_ransac[ps.n];
-        d.rand = j.rand; d.result = j.result; d.mask = j.inlier_mask;
+        d.rand = j.rand; d.result = j.result; d.mask = j.inlier_mask; d.cert = j.cert;
         ++ps.n;
     }
     if (ps.n > 0) {

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CAELO_ABI_VERSION 2   /* 2: caelo_match workspace sized by max(k0, k1) and holds the fragment image; caelo_encode_profile writes 6 floats */
+#define CAELO_ABI_VERSION 3   /* 3: caelo_ransac / caelo_frame_job carry a certificate pointer; host half of the exact RANSAC (caelo_host_*) */
 
 /* geometry fixed by the reference: SphericalRing.py:28-58, Voxel.py:15-52 */
 #define CAELO_RING_H 69
@@ -222,10 +222,51 @@ typedef struct {
     int32_t best_trial;   /* index into rand of the winning hypothesis, -1 if none */
     int32_t n_pairs;
 } caelo_pose_result;
+/* The certificate a RANSAC call leaves for the host half (optional, device memory, 16-byte aligned): for each of the 500
+ * hypotheses of the first threshold level an UPPER BOUND `hi` on the inlier count the reference's own arithmetic can give it --
+ * NumPy forms the 4-point covariance, R, T and the residuals in float32 through its BLAS (Match.py:141-157,:190-193), so a
+ * count depends on that BLAS's rounding; the kernels fit in float64 and count the pairs whose residual lies below the
+ * threshold PLUS a bound on that difference -- the four sample indices of each hypothesis, and the matched pairs
+ * (P0[pair_idx[i]], P1[i]).  caelo_host_certify replays Match.py:181-214 over the bounds and re-evaluates the deciding
+ * hypotheses through NumPy's BLAS / LAPACK entry points: inlier sets, R_star / T_star and the refit are then the reference's
+ * bits on this host. */
+#define CAELO_CERT_MAX_PAIRS 1024
+#define CAELO_CERT_MAGIC 0x43455254
+#define CAELO_CERT_NO_BOUNDS 1    /* flags: more than CAELO_CERT_MAX_PAIRS pairs -- no bounds, no pairs stored */
+typedef struct {
+    int32_t magic;        /* CAELO_CERT_MAGIC once k_ransac_finish has written the record */
+    int32_t n_pairs;      /* N */
+    int32_t flags;
+    int32_t reserved[13];
+    int32_t hi[512];      /* [500] used */
+    int32_t idx[512][4];  /* sample indices int32(u * N) (Match.py:182-184) of the first level's hypotheses */
+    float p0[CAELO_CERT_MAX_PAIRS][3]; /* Pairs0 = PC0[pairIdx] (Match.py:260) */
+    float p1[CAELO_CERT_MAX_PAIRS][3]; /* Pairs1 */
+} caelo_ransac_cert;
+int64_t caelo_cert_bytes(void);
 int64_t caelo_ransac_ws_bytes(void);
 int caelo_ransac(caelo_ctx *ctx, const float *pc0, int ld0, const float *pc1, int ld1, const int64_t *pair_idx,
                  int64_t k1_max, const int32_t *n1, const double *rand, caelo_pose_result *result,
-                 uint8_t *inlier_mask, void *ws, void *stream);
+                 uint8_t *inlier_mask, void *ws, caelo_ransac_cert *cert, void *stream);
+
+/* Host half of the exact RANSAC (csrc/certify.hip; every pointer below is HOST memory, no device is touched).
+ * caelo_host_bind_blas: the cblas_sgemm / cblas_sgemv / dgesdd (Fortran) entry points of the BLAS the process's NumPy is
+ *   linked against (caelo/hostblas.py finds them), ilp64 = 1 when their integers are 64 bits wide.  Process-wide.
+ * caelo_host_solve_rt: SolveRT (Match.py:138-158) by NumPy's own call sequence -- float32 row sums, cblas_sgemm for the
+ *   covariance, dgesdd on its float64 copy, U / Vh cast to float32, cblas_sgemm for R, cblas_sgemv for T.
+ * caelo_host_ransac: RANSAC4RT + the refit of SolveRelativePose (Match.py:162-218,:269-283) on pairs [n][3]; with `hi`
+ *   (the first level's bounds) only the deciding hypotheses are evaluated, without it all of them, like the reference.
+ * caelo_host_certify: k certificates (copied from the device) -> k results + masks [k][mask_ld]; rand_host [k] (nullable, as
+ *   may be its entries) = the pairs' draws, needed only when a pair escalates beyond 0.4 m; evals [k] (nullable) = hypotheses
+ *   evaluated; status [k] (nullable): 0 exact, 1 the draws were needed and missing, 2 no bounds in the record (more than
+ *   1024 pairs: use caelo_host_ransac), 3 no record.  `threads` host threads share the k records. */
+int caelo_host_bind_blas(void *cblas_sgemm, void *cblas_sgemv, void *dgesdd, int ilp64);
+int caelo_host_blas_bound(void);
+int caelo_host_solve_rt(const float *p0_host, const float *p1_host, int64_t n, float *R_host, float *T_host, int32_t *credible_host);
+int caelo_host_ransac(const float *pairs0_host, const float *pairs1_host, int64_t n, const double *rand_host, const int32_t *hi_host,
+                      caelo_pose_result *result_host, uint8_t *mask_host, int32_t *evals_host);
+int caelo_host_certify(const void *certs_host, int64_t k, const double *const *rand_host, caelo_pose_result *results_host,
+                       uint8_t *masks_host, int64_t mask_ld, int32_t *evals_host, int32_t *status_host, int threads);
 
 /* Fused per-scan hot path: ProjectPC2SphericalRing -> RespondLayer.predict -> GetKeyPtsByAE ->
  * Voxelization -> GetPatchesList -> GetFeaturesFromPatches in one call, one stream, no host sync.
@@ -329,6 +370,7 @@ typedef struct caelo_frame_job {
     caelo_pose_result *result;  /* out */
     uint8_t *inlier_mask;       /* [1024] out */
     int64_t *pair_idx;          /* [1024] out */
+    caelo_ransac_cert *cert;    /* out, nullable: the pair's certificate for caelo_host_certify */
 } caelo_frame_job;
 int caelo_pipeline_create(caelo_ctx *ctx, int batch, int n_buffers, int64_t max_points, caelo_pipeline **out);
 void caelo_pipeline_destroy(caelo_pipeline *pipe);

@@ -1497,3 +1497,162 @@ def test_ransac_pair_count_sweep_vs_oracle(api, orc):
         assert np.array_equal(mask, np.asarray(omask, bool)), (n, int(mask.sum()), int(np.asarray(omask).sum()))
         if ok and mask.sum() >= 4:
             assert np.abs(np.asarray(R, np.float64) - oR).max() <= 1e-4 and np.abs(np.asarray(T, np.float64) - oT).max() <= 1e-3, n
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Exact RANSAC: the device's certificate (upper bounds) + the host half (csrc/certify.hip) = the oracle, bit for bit
+# ---------------------------------------------------------------------------------------------------------------------
+def _golden_pairs(a, b, p):
+    f0 = np.load(os.path.join(GOLDEN, "frame_%s.npz" % a))
+    f1 = np.load(os.path.join(GOLDEN, "frame_%s.npz" % b))
+    pr = np.load(os.path.join(GOLDEN, "pair_%s.npz" % p))
+    return f0, f1, pr["pair_idx"].astype(np.int64)
+
+
+def _oracle_counts(orc, P0, P1, draws, thr=0.4):
+    """The reference's inlier count of each of the 500 first-level hypotheses (Match.py:182-194), NumPy statement by statement."""
+    N = len(P0)
+    cnt = np.zeros(500, np.int32)
+    for t in range(500):
+        idx = (draws[4 * t:4 * t + 4] * N).astype(np.int32)
+        R, T, _ = orc.SolveRT(P0[idx], P1[idx])
+        cnt[t] = int((np.linalg.norm(P0 - (np.dot(R, P1.T) + T).T, axis=1) < thr).sum())
+    return cnt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("a,b,p", [("0", "1", "0_1"), ("q0", "q1", "q0_q1"), ("c0", "c1", "c0_c1")])
+def test_ransac_certificate_bounds_hold_and_results_are_the_oracles_bits(engine, orc, a, b, p):
+    """(1) the certificate's `hi` is an upper bound of the reference's count for EVERY hypothesis -- rank-deficient samples
+    (repeated points: a quarter of the many-to-one matched samples) included --, its indices and pairs are the reference's;
+    (2) with it the host half returns the oracle's RANSAC4RT and SolveRelativePose refit bit for bit after a handful of
+    hypothesis evaluations."""
+    import torch
+    from caelo import _ffi
+    f0, f1, pair_idx = _golden_pairs(a, b, p)
+    kp0 = torch.from_numpy(np.ascontiguousarray(f0["keypts_demo"])).to(engine.device)
+    kp1 = torch.from_numpy(np.ascontiguousarray(f1["keypts_demo"])).to(engine.device)
+    pidx = torch.from_numpy(pair_idx).to(engine.device)
+    P0, P1 = np.ascontiguousarray(f0["keypts_demo"][pair_idx]), np.ascontiguousarray(f1["keypts_demo"])
+    N = len(P1)
+    slack, evals_all = [], []
+    for seed in (21, 22, 23, 24):
+        draws = np.random.RandomState(seed).random_sample(6000)
+        cert = engine.new_cert(1)
+        res, mask = engine.ransac(kp0, kp1, pidx, torch.from_numpy(draws).to(engine.device), cert=cert[0])
+        rec = cert.cpu().numpy().view(_ffi.CERT_DTYPE)[0]
+        assert rec["magic"] == _ffi.CERT_MAGIC and rec["n_pairs"] == N and rec["flags"] == 0
+        assert np.array_equal(rec["idx"][:500], (draws[:2000].reshape(500, 4) * N).astype(np.int32))
+        assert np.array_equal(rec["p0"][:N], P0) and np.array_equal(rec["p1"][:N], P1)
+        cnt = _oracle_counts(orc, P0, P1, draws)
+        hi = rec["hi"][:500]
+        assert (hi >= cnt).all(), (seed, np.flatnonzero(hi < cnt)[:5], cnt[hi < cnt][:5], hi[hi < cnt][:5])
+        slack.append(hi - cnt)
+        results, masks, evals, status = engine.certify(cert, [draws])
+        assert status[0] == 0
+        r = results[0]
+        R, T, ok, m, thr = orc.RANSAC4RT(P0, P1, rng=np.random.RandomState(seed))
+        assert bool(r["success"]) == ok and abs(float(r["threshold"]) - thr) < 1e-6
+        assert np.array_equal(masks[0, :N].astype(bool), m), seed                              # the inlier set, bit-exact
+        assert np.array_equal(r["R_ransac"].reshape(3, 3), R) and np.array_equal(r["T_ransac"].reshape(3, 1), T)
+        Rf, Tf, _ = orc.SolveRT(P0[m], P1[m])
+        assert np.array_equal(r["R"].reshape(3, 3), Rf) and np.array_equal(r["T"].reshape(3, 1), Tf)   # the final pose, bit-exact
+        evals_all.append(int(evals[0]))
+        # the kernels' own result (float64 fits, no host half) stays within the pose tolerance of it
+        rk = engine.pose_result(res)
+        if np.array_equal(mask.cpu().numpy()[:N].astype(bool), m):
+            assert np.abs(np.array(rk.R) - r["R"]).max() <= REL_TOL
+    slack = np.concatenate(slack)
+    # the bounds are tight enough to prune: most hypotheses within a few counts, the host evaluates a handful
+    assert np.median(slack) <= 2 and np.percentile(slack, 90) <= 40, (np.median(slack), np.percentile(slack, 90), slack.max())
+    assert max(evals_all) <= 12, evals_all
+
+
+@pytest.mark.gpu
+def test_ransac_certificate_on_degenerate_and_edge_inputs(engine, orc):
+    """Certificates on inputs made of rank-deficient samples: every point repeated (rank-2 and rank-1 covariances),
+    exactly coplanar clouds (mm-quantised ground), tiny N, and more than 1024 pairs (no certificate: the API falls back to
+    the reference's loop on the host arrays)."""
+    import torch
+    from caelo import _ffi, api
+    rs = np.random.RandomState(4)
+    base = (rs.standard_normal((1000, 3)) * [30, 30, 1]).astype(np.float32)
+    ang = 0.02
+    rot = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+    cases = {}
+    P1 = base.copy()
+    P0 = (P1 @ rot.T + np.float32([0.9, 0.05, 0.0])).astype(np.float32)
+    P0[rs.uniform(size=1000) < 0.5] = P0[0]                       # half of frame 0's matches are ONE point
+    cases["many_to_one"] = (P0, P1)
+    P1 = np.round(base * 1000) / 1000
+    P1[:, 2] = np.float32(-1.73)                                   # an exactly planar cloud
+    P1 = P1.astype(np.float32)
+    P0 = (P1 @ rot.T + np.float32([0.9, 0.05, 0.0])).astype(np.float32)
+    out = rs.uniform(size=1000) < 0.6
+    P0[out] = (rs.standard_normal((int(out.sum()), 3)) * [30, 30, 0]).astype(np.float32) + np.float32([0, 0, -1.73])
+    cases["coplanar"] = (np.ascontiguousarray(P0, np.float32), P1)
+    cases["tiny"] = (base[:7] + np.float32(0.01), base[:7].copy())
+    for name, (P0, P1) in cases.items():
+        N = len(P1)
+        d0, d1 = torch.from_numpy(P0).to(engine.device), torch.from_numpy(P1).to(engine.device)
+        ident = torch.arange(N, device=engine.device, dtype=torch.int64)
+        for seed in (1, 2):
+            draws = np.random.RandomState(seed).random_sample(6000)
+            cert = engine.new_cert(1)
+            engine.ransac(d0, d1, ident, torch.from_numpy(draws).to(engine.device), cert=cert[0])
+            rec = cert.cpu().numpy().view(_ffi.CERT_DTYPE)[0]
+            cnt = _oracle_counts(orc, P0, P1, draws)
+            assert (rec["hi"][:500] >= cnt).all(), (name, seed, np.flatnonzero(rec["hi"][:500] < cnt)[:5])
+            results, masks, evals, status = engine.certify(cert, [draws])
+            R, T, ok, m, thr = orc.RANSAC4RT(P0, P1, rng=np.random.RandomState(seed))
+            assert status[0] == 0 and bool(results[0]["success"]) == ok and abs(float(results[0]["threshold"]) - thr) < 1e-6, (name, seed)
+            assert np.array_equal(masks[0, :N].astype(bool), m), (name, seed)
+            if ok and m.any():
+                assert np.array_equal(results[0]["R_ransac"].reshape(3, 3), R.astype(np.float32)), (name, seed)
+    # more than 1024 pairs: api.RANSAC4RT = the oracle all the same (status 2 -> caelo_host_ransac on the host arrays)
+    big1 = (rs.standard_normal((1500, 3)) * [30, 30, 1]).astype(np.float32)
+    big0 = (big1 @ rot.T + np.float32([0.9, 0.05, 0.0])).astype(np.float32)
+    bad = rs.uniform(size=1500) < 0.5
+    big0[bad] = (rs.standard_normal((int(bad.sum()), 3)) * 30).astype(np.float32)
+    R, T, ok, mask, thr = api.RANSAC4RT(big0, big1, None, None, rng=np.random.RandomState(3))
+    oR, oT, ook, om, othr = orc.RANSAC4RT(big0, big1, rng=np.random.RandomState(3))
+    assert ok == ook and thr == othr and np.array_equal(mask, om) and np.array_equal(R, oR) and np.array_equal(T, oT)
+
+
+@pytest.mark.gpu
+def test_pipeline_certified_poses_equal_the_oracle_on_the_pipelines_own_matches(engine, orc, scans):
+    """Pipeline.run(certify=True) + Engine.certify_batch: for every pair of a run, inlier set, R_star / T_star and the refit
+    equal the oracle's SolveRelativePose tail on the pairs the pipeline matched (its key points, its argmin), bit for bit;
+    the device tensors hold the exact results afterwards."""
+    import torch
+    from caelo.engine import ransac_draws
+    from caelo import _ffi
+    n = 11
+    pcs = [scans(200 + i, quantum=1e-3) for i in range(n)]
+    dpcs = [torch.from_numpy(pc).to(engine.device) for pc in pcs]
+    draws = [ransac_draws(900 + i) for i in range(n)]
+    rnd = [torch.from_numpy(d).to(engine.device) for d in draws]
+    out = engine.pipeline(4).run(dpcs, rnd, certify=True)
+    kernels_result = out.result.clone()
+    res, masks, evals, status = engine.certify_batch(out, draws)
+    assert status[0] == 3 and (status[1:] == 0).all()            # frame 0 has no predecessor
+    rows = out.rows.cpu().numpy()
+    pidx = out.pair_idx.cpu().numpy()
+    nk = out.n_key.cpu().numpy()
+    dev_res = out.result.cpu().numpy().view(_ffi.POSE_DTYPE).reshape(-1)
+    dev_mask = out.inlier_mask.cpu().numpy()
+    for i in range(1, n):
+        N = int(nk[i])
+        P0 = np.ascontiguousarray(rows[i - 1][pidx[i][:N], 60:63])
+        P1 = np.ascontiguousarray(rows[i][:N, 60:63])
+        R, T, ok, m, thr = orc.RANSAC4RT(P0, P1, rng=np.random.RandomState(900 + i))
+        assert bool(res[i]["success"]) == ok and np.array_equal(masks[i, :N].astype(bool), m), i
+        assert np.array_equal(res[i]["R_ransac"].reshape(3, 3), R) and np.array_equal(res[i]["T_ransac"].reshape(3, 1), T), i
+        Rf, Tf, _ = orc.SolveRT(P0[m], P1[m])
+        assert np.array_equal(res[i]["R"].reshape(3, 3), Rf) and np.array_equal(res[i]["T"].reshape(3, 1), Tf), i
+        assert dev_res[i].tobytes() == res[i].tobytes() and np.array_equal(dev_mask[i], masks[i])
+        assert 1 <= evals[i] <= 12
+    # the kernels' own poses (no host half) are within tolerance of the exact ones wherever the inlier sets agree
+    kr = kernels_result.cpu().numpy().view(_ffi.POSE_DTYPE).reshape(-1)
+    close = [np.abs(kr[i]["R"] - res[i]["R"]).max() <= REL_TOL for i in range(1, n) if kr[i]["n_inliers"] == res[i]["n_inliers"]]
+    assert len(close) >= n // 2 and all(close)
