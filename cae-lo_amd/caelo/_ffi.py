@@ -39,7 +39,8 @@ class FrameJob(C.Structure):
     _fields_ = [("pc", c_vp), ("n", c_i64), ("dist_channels", c_i32), ("mode", c_i32), ("rows", c_vp),
                 ("key_pixels", c_vp), ("n_key", c_vp), ("flags", c_vp), ("status", c_vp), ("pair", c_i32),
                 ("reserved", c_i32), ("prev_rows", c_vp), ("prev_n_key", c_vp), ("rand", c_vp), ("result", c_vp),
-                ("inlier_mask", c_vp), ("pair_idx", c_vp), ("cert", c_vp)]
+                ("inlier_mask", c_vp), ("pair_idx", c_vp), ("cert", c_vp), ("result_host", c_vp), ("mask_host", c_vp),
+                ("rand_host", c_vp), ("info_host", c_vp)]
 
 
 PAIR_NONE, PAIR_CHAIN, PAIR_EXPLICIT = 0, 1, 2
@@ -50,7 +51,8 @@ BUILD_PACKED_F32, BUILD_PROF, BUILD_STAMPED = 1, 2, 256   # caelo_build_flags() 
 import numpy as _np
 JOB_DTYPE = _np.dtype([("pc", "u8"), ("n", "i8"), ("dist_channels", "i4"), ("mode", "i4"), ("rows", "u8"), ("key_pixels", "u8"),
                        ("n_key", "u8"), ("flags", "u8"), ("status", "u8"), ("pair", "i4"), ("reserved", "i4"), ("prev_rows", "u8"),
-                       ("prev_n_key", "u8"), ("rand", "u8"), ("result", "u8"), ("inlier_mask", "u8"), ("pair_idx", "u8"), ("cert", "u8")], align=True)
+                       ("prev_n_key", "u8"), ("rand", "u8"), ("result", "u8"), ("inlier_mask", "u8"), ("pair_idx", "u8"), ("cert", "u8"),
+                       ("result_host", "u8"), ("mask_host", "u8"), ("rand_host", "u8"), ("info_host", "u8")], align=True)
 assert JOB_DTYPE.itemsize == C.sizeof(FrameJob) and all(JOB_DTYPE.fields[n][1] == getattr(FrameJob, n).offset for n, _ in FrameJob._fields_)
 # caelo_ransac_cert (include/caelo.h): what a RANSAC call leaves for the host half (csrc/certify.hip)
 CERT_MAX_PAIRS, CERT_MAGIC, CERT_NO_BOUNDS = 1024, 0x43455254, 1
@@ -96,6 +98,7 @@ SIGNATURES = [
     ("caelo_encode32_profile", c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     ("caelo_match_ws_bytes", c_i64, [c_i64]),
     ("caelo_match", c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_vp, c_vp]),
+    ("caelo_match_profile", c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     ("caelo_solve_rt", c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     ("caelo_ransac_ws_bytes", c_i64, []),
     ("caelo_ransac", c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -116,6 +119,7 @@ SIGNATURES = [
     ("caelo_icp", c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, C.POINTER(IcpParams), c_vp, c_vp, c_vp]),
     ("caelo_pipeline_create", c_int, [c_vp, c_int, c_int, c_i64, C.POINTER(c_vp)]),
     ("caelo_pipeline_destroy", None, [c_vp]),
+    ("caelo_pipeline_cert_stats", c_int, [c_vp, C.POINTER(c_i64)]),
     ("caelo_pipeline_batch", c_int, [c_vp]),
     ("caelo_pipeline_begin", c_int, [c_vp, c_vp]),
     ("caelo_pipeline_submit", c_int, [c_vp, C.POINTER(FrameJob)]),

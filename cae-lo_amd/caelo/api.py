@@ -302,7 +302,7 @@ def _ransac(pc0, pc1, pair_idx, rng):
     reference's own float32 / BLAS arithmetic can reach); the host half (caelo.hostexact, csrc/certify.hip) replays
     Match.py:181-214 over the bounds and re-evaluates the deciding hypotheses through NumPy's BLAS / LAPACK entry points:
     the inlier mask, R_star / T_star and the refit are the reference's bits on this host."""
-    from . import hostexact
+    from . import hostexact, _ffi
     e = default_engine()
     rs = np.random.mtrand._rand if rng is None else rng
     state = rs.get_state()
@@ -315,12 +315,12 @@ def _ransac(pc0, pc1, pair_idx, rng):
         p0 = pc0[:, :3][pair_idx].detach().cpu().numpy()
         p1 = pc1[:, :3].detach().cpu().numpy()
         r, m, _ = hostexact.ransac(p0, p1, draws)
-        r = np.array([r], dtype=results.dtype).view(np.recarray)[0]
         mask = torch.from_numpy(m.astype(np.uint8)).to(e.device)
     else:
         assert status[0] == 0
-        r = results.view(np.recarray)[0]
+        r = results[0]
         mask = torch.from_numpy(masks[0, :n].copy()).to(e.device)
+    r = _ffi.PoseResult.from_buffer_copy(r.tobytes())   # (attribute access like Engine.pose_result)
     used = 4 * (r.best_trial // 500 * 500 + r.iterations if r.success else 1500)
     rs.set_state(state)
     rs.random_sample(used)

@@ -117,7 +117,9 @@ class FrameBatch:
         self.inlier_mask = eng.zeros((k, MAX_K), torch.uint8)
         self.pair_idx = eng.zeros((k, MAX_K), torch.int64)
         self.cert = None       # [k, sizeof(caelo_ransac_cert)] u8 once a run asked for certificates (Pipeline.run(certify=True))
-        self.exact = None      # host copy of the certified results (Engine.certify_batch)
+        self.exact = None      # host copy of the certified results: (results [k], masks [k,1024], evals [k], status [k])
+        self._rands_host = None
+        self._exact_buf = None
 
     def ensure_cert(self, eng):
         if self.cert is None:
@@ -134,7 +136,9 @@ class FrameBatch:
         for f in ("rows", "key_pixels", "n_key", "flags", "status", "result", "inlier_mask", "pair_idx"):
             setattr(v, f, getattr(self, f)[start:start + n])
         v.cert = self.cert[start:start + n] if self.cert is not None else None
-        v.exact = None
+        v.exact = None if self.exact is None else tuple(a[start:start + n] for a in self.exact)
+        v._rands_host = None
+        v._exact_buf = None
         return v
 
 
@@ -166,7 +170,7 @@ class Pipeline:
         return {"jobs": int(out[0]), "issue_us_per_frame": out[1] / n / 1e3, "batches": int(out[2]), "batch": int(out[3]),
                 "buffers": int(out[4]), "streams": int(out[5])}
 
-    def _jobs(self, ptrs, counts, rands, prev, out, pairs, dist_channels, exact_voxels, dedup, certify=False):
+    def _jobs(self, ptrs, counts, rands, prev, out, pairs, dist_channels, exact_voxels, dedup, certify=False, rands_host=None):
         """The run's jobs as one record array, filled column-wise, handed over in ONE foreign call (a ctypes call per frame
         costs ~10 us: 380 us for a 20-frame run, most of it before the first launch)."""
         k = len(ptrs)
@@ -194,7 +198,36 @@ class Pipeline:
         jobs["inlier_mask"] = out.inlier_mask.data_ptr() + idx * MAX_K
         jobs["pair_idx"] = out.pair_idx.data_ptr() + idx * (MAX_K * 8)
         if certify and pairs and k > 0:
+            # the exact RANSAC: certificates on the device, and (certify = "host", the default meaning of True) the pipeline's
+            # certifier thread writes the exact results to host arrays while later batches run (include/caelo.h)
+            if not getattr(self.eng, "_blas_bound", False):
+                self.eng.host_blas()
+                self.eng._blas_bound = True
             jobs["cert"] = out.ensure_cert(self.eng).data_ptr() + idx * _ffi.CERT_DTYPE.itemsize
+            if certify != "device":
+                if out._exact_buf is None:   # host arrays of the exact results: allocated once per FrameBatch
+                    out._exact_buf = (np.zeros(out.k, dtype=_ffi.POSE_DTYPE), np.zeros((out.k, MAX_K), dtype=np.uint8),
+                                      np.zeros((out.k, 2), dtype=np.int32))
+                res, masks, info = out._exact_buf
+                info[:k, 0] = 0
+                info[:k, 1] = 3                                  # "no record" until the certifier says otherwise
+                has = jobs["pair"] != _ffi.PAIR_NONE
+                jobs["result_host"] = np.where(has, res.ctypes.data + idx * _ffi.POSE_DTYPE.itemsize, 0)
+                jobs["mask_host"] = np.where(has, masks.ctypes.data + idx * MAX_K, 0)
+                jobs["info_host"] = np.where(has, info.ctypes.data + idx * 8, 0)
+                if rands_host is not None:   # (float64, contiguous, >= 6000 draws each: checked once per distinct array)
+                    seen = {}
+                    ptrs = np.empty(k, dtype=np.uint64)
+                    for i in range(k):
+                        r = rands_host[i]
+                        a = seen.get(id(r))
+                        if a is None:
+                            assert isinstance(r, np.ndarray) and r.dtype == np.float64 and r.flags["C_CONTIGUOUS"] and r.size >= 6000
+                            a = seen[id(r)] = r.ctypes.data
+                        ptrs[i] = a
+                    jobs["rand_host"] = ptrs
+                    out._rands_host = rands_host
+                out.exact = (res, masks, info[:, 0], info[:, 1])
         return jobs
 
     def wait_encoded(self, stream):
@@ -207,12 +240,17 @@ class Pipeline:
         _ffi.check(self.eng.lib.caelo_pipeline_sync_encoded(self.h, int(lag)))
 
     def run(self, scans, rands=None, prev=None, dist_channels=5, exact_voxels=False, out=None, pairs=True, dedup=True, on_batch=None,
-            on_encoded=None, certify=False):
+            on_encoded=None, certify=False, rands_host=None):
         """scans: K device tensors [n,4] f32; rands: K device tensors of RANSAC draws ([1500,4] f64).
         Frame i is matched against frame i-1 (pose in ``result[i]``); frame 0 against ``prev``
         (FrameFeatures) when given; ``pairs=False`` extracts only (BASELINE configs[1]).  Returns a FrameBatch; the
-        current stream has waited for all lanes.  ``certify=True``: every pair also leaves its certificate (``out.cert``) for
-        ``Engine.certify_batch`` -- the host half that makes inlier sets and poses the reference's bits.  ``on_encoded(lo, hi)`` is called, in order, once the rows of frames [lo, hi) are
+        current stream has waited for all lanes.  ``certify=True``: the exact RANSAC -- every pair leaves its certificate
+        (``out.cert``) and the pipeline's certifier thread runs the host half (csrc/certify.hip) on it while later batches are on
+        the GPU; when ``run`` returns, ``out.exact`` = (results record array [k], masks [k,1024] u8, evals [k], status [k]) holds
+        the reference's inlier sets, R_star / T_star and refits bit for bit (frames without a pair: status 3) and
+        ``out.result`` / ``out.inlier_mask`` on the device are overwritten with them.  ``rands_host``: host copies of the draws
+        (only read for a pair that escalates beyond 0.4 m; fetched from the device otherwise).  ``certify="device"``: certificates
+        only (``Engine.certify_batch`` runs the host half later).  ``on_encoded(lo, hi)`` is called, in order, once the rows of frames [lo, hi) are
         WRITTEN (the calling thread has waited for them: caelo_pipeline_sync_encoded, one batch behind the issue) -- what it
         enqueues on any stream may read them at once; a caller ships finished rows that way while later batches run.
         ``on_batch(lo, hi)`` is called right after frames [lo, hi) have been issued (with ``wait_encoded`` the device-side form of
@@ -227,8 +265,11 @@ class Pipeline:
         _ffi.check(lib.caelo_pipeline_begin(self.h, stream))
         for pc in scans:
             assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] == 4 and pc.is_contiguous()
+        import time as _t
+        _t0 = _t.perf_counter()
         jobs = self._jobs([pc.data_ptr() for pc in scans], [pc.shape[0] for pc in scans], rands, prev, out, pairs, dist_channels,
-                          exact_voxels, dedup, certify)
+                          exact_voxels, dedup, certify, rands_host)
+        _t1 = _t.perf_counter()
         tail = None   # a partial last batch is only issued by the flush: its callbacks come after that
         issued = []   # batches issued, not yet reported to on_encoded
         try:
@@ -259,7 +300,36 @@ class Pipeline:
             self.sync_encoded(0)
             for lo, hi in issued:
                 on_encoded(lo, hi)
+        _t2 = _t.perf_counter()
+        self._publish_exact(out, k, certify, pairs)
+        self.last_times = {"jobs_ms": 1e3 * (_t1 - _t0), "submit_flush_ms": 1e3 * (_t2 - _t1), "publish_ms": 1e3 * (_t.perf_counter() - _t2)}
         return out
+
+    def _publish_exact(self, out, k, certify, pairs):
+        """After the flush of a certified run: the certifier thread has written every exact result (caelo_pipeline_flush waits
+        for it); put them into the device tensors too."""
+        if not (certify and certify != "device" and pairs and k > 0):
+            return
+        res, masks, evals, status = out.exact
+        if (status[:k] == 2).any():
+            raise _ffi.CaeloError("a pair holds more than 1024 matches: no certificate")
+        ok = status[:k] == 0
+        if ok.any():
+            with torch.cuda.stream(torch.cuda.current_stream(self.eng.device)):
+                if ok.all():
+                    out.result[:k].copy_(torch.from_numpy(res[:k].view(np.uint8).reshape(k, -1)))
+                    out.inlier_mask[:k].copy_(torch.from_numpy(masks[:k]))
+                else:
+                    sel = torch.from_numpy(np.flatnonzero(ok)).to(self.eng.device)
+                    out.result[sel] = torch.from_numpy(np.ascontiguousarray(res[:k].view(np.uint8).reshape(k, -1)[ok])).to(self.eng.device)
+                    out.inlier_mask[sel] = torch.from_numpy(np.ascontiguousarray(masks[:k][ok])).to(self.eng.device)
+
+    def cert_stats(self):
+        """Host half inside the pipeline since the last call: pairs certified, hypotheses evaluated per pair, certifier-thread us per pair."""
+        o = (C.c_int64 * 4)()
+        _ffi.check(self.eng.lib.caelo_pipeline_cert_stats(self.h, o))
+        n = max(int(o[0]), 1)
+        return {"pairs": int(o[0]), "evals_per_pair": o[1] / n, "host_us_per_pair": o[2] / n / 1e3, "handover_us_per_pair": o[3] / n / 1e3}
 
     def set_pace(self, lag):
         """caelo_pipeline_set_pace: after issuing a batch the calling thread waits for the encoder of the batch ``lag`` before it
@@ -267,7 +337,8 @@ class Pipeline:
         _ffi.check(self.eng.lib.caelo_pipeline_set_pace(self.h, int(lag)))
         self.pace = int(lag)
 
-    def run_uploading(self, host_scans, rands=None, prev=None, dist_channels=5, out=None, pairs=True, dedup=True, ahead=4, certify=False):
+    def run_uploading(self, host_scans, rands=None, prev=None, dist_channels=5, out=None, pairs=True, dedup=True, ahead=4, certify=False,
+                      rands_host=None):
         """``run`` for scans that live in (pinned) HOST memory: a copy stream uploads batch b + ``ahead`` while the pipeline works on
         batch b, into ``ahead + 2`` sets of device buffers -- the overlap of the reference's producer process, which prepares
         frame i + 1 while frame i is matched (PoseEstimation.py:214-245).  The hand-overs are paced by the calling thread, not by
@@ -294,7 +365,7 @@ class Pipeline:
         stream = eng.stream
         nb = (k + B - 1) // B
         jobs = self._jobs([bufs[(i // B) % slots][i % B].data_ptr() for i in range(k)], [int(pc.shape[0]) for pc in host_scans], rands, prev, out,
-                          pairs, dist_channels, False, dedup, certify)
+                          pairs, dist_channels, False, dedup, certify, rands_host)
         arrived = [torch.cuda.Event() for _ in range(nb)]
 
         # the copies of a batch go out behind ONE native call (caelo_upload_many): eight sliced torch copies cost the issuing thread
@@ -335,6 +406,7 @@ class Pipeline:
             rc = lib.caelo_pipeline_flush(self.h, stream)
             lib.caelo_pipeline_set_pace(self.h, pace)
         _ffi.check(rc)
+        self._publish_exact(out, k, certify, pairs)
         return out
 
 
@@ -685,6 +757,19 @@ class Engine:
                                         f1.shape[0], _ptr(n1), f0.shape[1], _ptr(idx), _ptr(ws), self.stream))
         return idx
 
+    def match_profile(self, frames, repeats=20):
+        """The pipeline's launch shape of the NN match: len(frames) - 1 pairs of consecutive FrameFeatures behind one k_match_prep +
+        one k_match_screen launch, timed with HIP events (caelo_match_profile).  -> (ms both kernels, ms prep alone, pair_idx [n,1024])."""
+        n = len(frames) - 1
+        assert 1 <= n <= 8 and all(f.rows.is_contiguous() for f in frames)
+        rows = (C.c_void_p * (n + 1))(*[f.rows.data_ptr() for f in frames])
+        nk = (C.c_void_p * (n + 1))(*[f.n_key.data_ptr() for f in frames])
+        idx = self.zeros((n, MAX_K), torch.int64)
+        ws = self._ws("match_profile", n * int(self.lib.caelo_match_ws_bytes(MAX_K)))
+        ms = (C.c_float * 2)()
+        _ffi.check(self.lib.caelo_match_profile(self.ctx, rows, n, nk, _ptr(idx), _ptr(ws), int(repeats), self.stream, C.cast(ms, C.c_void_p)))
+        return float(ms[0]), float(ms[1]), idx
+
     def solve_rt(self, p0, p1):
         assert p0.shape == p1.shape and p0.dtype == torch.float32 and p0.is_contiguous() and p1.is_contiguous()
         R = self.empty((3, 3), torch.float32)
@@ -710,6 +795,11 @@ class Engine:
         return self.zeros((k, _ffi.CERT_DTYPE.itemsize), torch.uint8)
 
     # ---- the host half of the exact RANSAC (csrc/certify.hip, caelo/hostexact.py) ------------------------------------
+    def host_blas(self):
+        """Bind libcaelo's host half to the BLAS / LAPACK of this process's NumPy (once; caelo/hostblas.py)."""
+        from . import hostblas
+        return hostblas.bind(self.lib)
+
     def certify(self, certs, rands=None, threads=None):
         """certs: [k, sizeof(caelo_ransac_cert)] u8 device tensor.  Copies the records to the host (synchronises) and runs
         caelo_host_certify: Match.py:181-214 replayed over the device's bounds, the deciding hypotheses re-evaluated through
@@ -819,6 +909,21 @@ class Engine:
         idx = self.match(fa.features, fb.features, fa.n_key, fb.n_key)
         res, mask = self.ransac(fa.key_pts, fb.key_pts, idx, rand, fb.n_key)
         return res, mask, idx
+
+
+    def match_pose_exact(self, fa, fb, rand, rand_host=None):
+        """match_pose + the host half: -> (result record (_ffi.POSE_DTYPE), mask [1024] u8 (host), pair_idx (device)).  Synchronises."""
+        cur = torch.cuda.current_stream(self.device)
+        for f in (fa, fb):
+            f.rows.record_stream(cur)
+            f.n_key.record_stream(cur)
+        idx = self.match(fa.features, fb.features, fa.n_key, fb.n_key)
+        cert = self.new_cert(1)
+        self.ransac(fa.key_pts, fb.key_pts, idx, rand, fb.n_key, cert=cert[0])
+        results, masks, _, status = self.certify(cert, [rand_host if rand_host is not None else rand])
+        if status[0] != 0:
+            raise _ffi.CaeloError("pair could not be certified (status %d)" % status[0])
+        return results[0], masks[0], idx
 
 
 _default = None

@@ -189,6 +189,9 @@ struct caelo_pair_set {
 };
 int match_set(const caelo_pair_set &ps, int ld0, int64_t k0_max, int ld1, int64_t k1_max, int dim, hipStream_t s);
 int ransac_set(const caelo_pair_set &ps, int pld0, int pld1, int64_t k1_max, hipStream_t s);
+// the host half of the exact RANSAC on one certificate record (certify.hip): 0 exact, 1 the draws are needed (an escalation, rnd null),
+// 2 no bounds in the record, 3 no record, -1 failure
+int certify_record(const caelo_ransac_cert &c, const double *rnd, caelo_pose_result *res, uint8_t *mask, int64_t mask_len, int32_t *evals);
 
 // a (pointer, bytes, byte value) triple for the multi-buffer clear kernel (frame.hip)
 struct caelo_clear_item {

@@ -323,6 +323,18 @@ int certify_one(const float *P0, const float *P1, int64_t n, const double *rnd, 
 
 }  // namespace
 
+// one record (caelo_pipeline's certifier thread, caelo_host_certify): -> 0 exact, 1 the draws are needed, 2 no bounds in the record,
+// 3 no record, -1 LAPACK failure / no BLAS bound
+int certify_record(const caelo_ransac_cert &c, const double *rnd, caelo_pose_result *res, uint8_t *mask, int64_t mask_len, int32_t *evals) {
+    static thread_local Scratch S;
+    if (!g_blas.sgemm) return -1;
+    if (c.magic != CAELO_CERT_MAGIC) return 3;
+    if (c.n_pairs < 0 || c.n_pairs > CAELO_CERT_MAX_PAIRS || (c.flags & CAELO_CERT_NO_BOUNDS) || c.n_pairs > mask_len) return 2;
+    const int rc = certify_one(&c.p0[0][0], &c.p1[0][0], c.n_pairs, rnd, c.hi, c.idx, S, res, mask, evals);
+    if (rc == 0 && c.n_pairs < mask_len) memset(mask + c.n_pairs, 0, (size_t)(mask_len - c.n_pairs));
+    return rc;
+}
+
 CAELO_API int caelo_host_bind_blas(void *cblas_sgemm, void *cblas_sgemv, void *dgesdd, int ilp64) {
     CAELO_REQUIRE(cblas_sgemm && cblas_sgemv && dgesdd, "null BLAS entry point");
     g_blas.sgemm = cblas_sgemm; g_blas.sgemv = cblas_sgemv; g_blas.dgesdd = dgesdd; g_blas.ilp64 = ilp64 ? 1 : 0;
@@ -369,25 +381,13 @@ CAELO_API int caelo_host_certify(const void *certs_host, int64_t k, const double
     std::atomic<int64_t> next(0);
     std::atomic<int> failed(0);
     auto work = [&]() {
-        Scratch S;
         for (;;) {
             const int64_t i = next.fetch_add(1);
             if (i >= k) break;
-            const caelo_ransac_cert &c = certs[i];
-            int st = 0;
-            if (c.magic != CAELO_CERT_MAGIC) {
-                st = 3;  // the device wrote no certificate for this slot (a frame without a pair): nothing to do
-            } else if (c.n_pairs < 0 || c.n_pairs > CAELO_CERT_MAX_PAIRS || (c.flags & CAELO_CERT_NO_BOUNDS)) {
-                st = 2;  // more pairs than a certificate holds: the caller evaluates from its own arrays (caelo_host_ransac)
-            } else {
-                const double *rnd = rand_host ? rand_host[i] : nullptr;
-                const int rc = certify_one(&c.p0[0][0], &c.p1[0][0], c.n_pairs, rnd, c.hi, c.idx, S, results_host + i, masks_host + i * mask_ld,
-                                           evals_host ? evals_host + i : nullptr);
-                if (rc < 0) failed.store(1);
-                st = rc == 1 ? 1 : 0;  // 1: an escalation needs the draws and none were given
-                if (rc == 0 && c.n_pairs < mask_ld) memset(masks_host + i * mask_ld + c.n_pairs, 0, (size_t)(mask_ld - c.n_pairs));
-            }
-            if (status_host) status_host[i] = st;
+            const int st = certify_record(certs[i], rand_host ? rand_host[i] : nullptr, results_host + i, masks_host + i * mask_ld, mask_ld,
+                                          evals_host ? evals_host + i : nullptr);
+            if (st < 0) failed.store(1);
+            if (status_host) status_host[i] = st < 0 ? 0 : st;
         }
     };
     int nt = threads > 0 ? threads : 1;

@@ -67,7 +67,9 @@ __global__ void __launch_bounds__(256) k_kd_build(caelo_kd kd) {
     const caelo_kd_scale T = kd.s[blockIdx.x];
     if (kd.state[blockIdx.x] == 0 || kd.state[4 + blockIdx.x] != 0) return;   // no tie-split patch of this scale / tree already built
     __shared__ int s_lo[256][3], s_hi[256][3];
+    __shared__ int s_gave_up;   // a node's quickselect exceeded its budget (below): the tree is not built, the canonical rule stays
     const int tid = threadIdx.x;
+    if (tid == 0) s_gave_up = 0;
     const int64_t n = T.n;
     for (int64_t i = tid; i < n; i += 256) T.idx[i] = (int32_t)i;
     for (int i = tid; i < T.n_nodes; i += 256) { T.start[i] = 0; T.end[i] = 0; }   // (children of a node that did not split stay empty)
@@ -126,7 +128,13 @@ __global__ void __launch_bounds__(256) k_kd_build(caelo_kd kd) {
                 unsigned long long *a = T.keys + s;
                 const int m = e - s, nmid = m / 2;
                 int left = 0, right = m - 1;
+                // Lomuto with the last element as the pivot is quadratic on a list that is sorted along the split dimension
+                // (np.unique / argwhere output; lists in first-touch order are not): the library pays that too, a single GPU thread
+                // would run for seconds.  Budget: 48 passes' worth of the node's length, far above the ~3 an unsorted list needs.
+                long long budget = 48ll * m + 4096;
                 for (;;) {
+                    budget -= right - left + 1;
+                    if (budget < 0) { s_gave_up = 1; break; }
                     int mid = left;
                     const unsigned long long pv = a[right];
                     const unsigned pvv = (unsigned)(pv >> 32);
@@ -162,7 +170,7 @@ __global__ void __launch_bounds__(256) k_kd_build(caelo_kd kd) {
             __syncthreads();
         }
     }
-    if (tid == 0) kd.state[4 + blockIdx.x] = 1;
+    if (tid == 0) kd.state[4 + blockIdx.x] = s_gave_up ? 2 : 1;   // 2: not built (the queries leave flag 2 and the canonical rule in place)
 }
 
 // (A swap `a[i] <-> a[mid]` inside an 8-element chunk can touch a position of the SAME chunk that was fetched before it was
@@ -194,7 +202,7 @@ __global__ void __launch_bounds__(64) k_kd_query(caelo_kd kd, const float *__res
     const int sc = blockIdx.y;
     const caelo_kd_scale T = kd.s[sc];
     const int cnt = min(kd.state[sc], (int)kd.k_cap);
-    if ((int)blockIdx.x >= cnt) return;
+    if ((int)blockIdx.x >= cnt || kd.state[4 + sc] != 1) return;
     __shared__ KdHeapLds L;
     const int lane = threadIdx.x;
     const int kp = T.queue[blockIdx.x];

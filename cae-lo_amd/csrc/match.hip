@@ -343,6 +343,46 @@ CAELO_API int caelo_match(caelo_ctx *c, const float *f0, int ld0, int64_t k0_max
     return match_set(ps, ld0, k0_max, ld1, k1_max, dim, caelo_stream(stream));
 }
 
+// The pipeline's launch shape of the NN match -- `n_pairs` pairs of consecutive frame rows ([1024][64] f32: descriptor 0:60) behind
+// ONE k_match_prep + ONE k_match_screen launch -- repeated between HIP events on `stream`: ms_host[0] = both kernels, [1] =
+// k_match_prep alone, averaged over `repeats` (bench.py's second roofline object; tools/roofline_launch.py for rocprofv3).
+CAELO_API int caelo_match_profile(caelo_ctx *c, const float *const *rows, int n_pairs, const int32_t *const *n_key, int64_t *pair_idx,
+                                  void *ws, int repeats, void *stream, float *ms_host) {
+    CAELO_REQUIRE(c && rows && pair_idx && ws && ms_host && n_pairs >= 1 && n_pairs <= CAELO_FB_MAX && repeats >= 1, "bad argument");
+    hipStream_t s = caelo_stream(stream);
+    caelo_pair_set ps = {};
+    ps.n = n_pairs;
+    const size_t wsb = (size_t)caelo_match_ws_bytes(CAELO_MAX_KEYPTS);
+    for (int i = 0; i < n_pairs; ++i) {
+        ps.p[i].f0 = rows[i]; ps.p[i].f1 = rows[i + 1];
+        ps.p[i].n0 = n_key ? n_key[i] : nullptr; ps.p[i].n1 = n_key ? n_key[i + 1] : nullptr;
+        ps.p[i].pair_idx = pair_idx + (size_t)i * CAELO_MAX_KEYPTS;
+        ps.p[i].ws_match = (char *)ws + (size_t)i * wsb;
+    }
+    hipEvent_t ev[3];
+    for (hipEvent_t &e : ev) CAELO_HIP(hipEventCreate(&e));
+    const int64_t kpad = ms_pad16(CAELO_MAX_KEYPTS);
+    int rc = CAELO_OK;
+    float both = 0.f, prep = 0.f;
+    for (int r = 0; r < repeats && rc == CAELO_OK; ++r) {
+        CAELO_HIP(hipEventRecord(ev[0], s));
+        k_match_prep<<<dim3((unsigned)((kpad / 16 + 3) / 4), 1, ps.n), 256, 0, s>>>(ps, 64, CAELO_MAX_KEYPTS, 60, kpad, 1);
+        CAELO_HIP(hipEventRecord(ev[1], s));
+        k_match_screen<<<dim3((unsigned)((CAELO_MAX_KEYPTS + 16 * MS_CT - 1) / (16 * MS_CT)), 1, ps.n), 64 * MS_NW, 0, s>>>(ps, 64, CAELO_MAX_KEYPTS, 64,
+                                                                                                                 CAELO_MAX_KEYPTS, 60, kpad, 1);
+        CAELO_HIP(hipEventRecord(ev[2], s));
+        CAELO_HIP(hipEventSynchronize(ev[2]));
+        float a = 0.f, b = 0.f;
+        CAELO_HIP(hipEventElapsedTime(&a, ev[0], ev[2]));
+        CAELO_HIP(hipEventElapsedTime(&b, ev[0], ev[1]));
+        both += a; prep += b;
+    }
+    for (hipEvent_t &e : ev) (void)hipEventDestroy(e);
+    ms_host[0] = both / (float)repeats;
+    ms_host[1] = prep / (float)repeats;
+    return rc;
+}
+
 int match_set(const caelo_pair_set &ps, int ld0, int64_t k0_max, int ld1, int64_t k1_max, int dim, hipStream_t s) {
     CAELO_REQUIRE(ps.n >= 1 && ps.n <= CAELO_FB_MAX, "bad pair count");
     CAELO_REQUIRE(dim > 0 && dim <= MT_MAXDIM && ld0 >= dim && ld1 >= dim && k0_max > 0 && k1_max > 0, "bad shape");

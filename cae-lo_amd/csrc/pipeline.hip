@@ -18,6 +18,11 @@
 // Host protocol:   begin(stream) -> submit(job) ... -> flush(stream)
 #include "caelo_internal.h"
 
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
 #include <stdlib.h>
 
 #include <chrono>
@@ -74,9 +79,178 @@ struct caelo_pipeline {
                           // pace on or wait for "the batch before" until caelo_pipeline_begin starts a new run
     caelo_frame_job last = {};
     int64_t stat_jobs = 0, stat_issue_ns = 0, stat_batches = 0;
+    // ---- the host half of the exact RANSAC inside the pipeline (jobs with result_host): a batch's certificates are copied to
+    // pinned host memory once its pair stage is through -- the ISSUING thread finds that out two batches later, when it has
+    // nothing to wait for (no device-side wait in any queue) -- and a certifier thread runs certify_record on them while the GPU
+    // works on later batches (three threads, a record each: a batch's eight pairs are through in ~40 us, which is what the last
+    // batches of a run cost after the GPU is done).
+    static constexpr int CERT_RING = 6;
+    struct CertItem {
+        const caelo_ransac_cert *dev;
+        caelo_pose_result *res;
+        uint8_t *mask;
+        const double *rand_host, *rand_dev;
+        int32_t *info;
+    };
+    struct CertTask {
+        CertItem item[CAELO_FB_MAX];
+        int n = 0, remaining = 0;
+        uint64_t batch_no = 0;
+        caelo_ransac_cert *host = nullptr;   // pinned [batch]
+        hipEvent_t pair_done = nullptr, copied = nullptr;
+        int state = 0;                       // 0 free, 1 issued (pair stage queued), 2 copy queued / being certified
+    };
+    CertTask cert_ring[CERT_RING];
+    hipStream_t sC = nullptr;                // the certificates' copy stream
+    uint64_t cert_seq = 0;                   // tasks created
+    std::deque<int> cert_issued;             // (issuing thread) slots in state 1, oldest first
+    std::deque<std::pair<int, int>> cert_queue;   // (slot, record) handed to the certifier threads
+    std::mutex cert_mu;
+    std::condition_variable cert_cv;
+    static constexpr int CERT_THREADS = 3;
+    std::thread cert_thread[CERT_THREADS];
+    bool cert_stop = false, cert_started = false;
+    int cert_failed = 0;                     // a record could not be certified (no BLAS bound, LAPACK failure): reported by the flush
+    int64_t stat_cert_pairs = 0, stat_cert_evals = 0, stat_cert_ns = 0, stat_cert_drain_ns = 0;
 };
 
 namespace {
+
+// one record of a task: wait for the task's copy, run the host half on the record; the last record of a task frees its slot
+// (certifier threads; at a flush the issuing thread too)
+void cert_process(caelo_pipeline *p, int slot, int i, std::vector<double> &draws) {
+    caelo_pipeline::CertTask &t = p->cert_ring[slot];
+    int failed = hipEventSynchronize(t.copied) != hipSuccess;
+    const int64_t t0 = now_ns();
+    int32_t evals = 0;
+    if (!failed) {
+        const caelo_pipeline::CertItem &it = t.item[i];
+        int st = certify_record(t.host[i], it.rand_host, it.res, it.mask, CAELO_MAX_KEYPTS, &evals);
+        if (st == 1) {   // the pair escalates beyond 0.4 m and no host copy of its draws was given: fetch them (rare)
+            draws.resize((size_t)CAELO_RANSAC_LEVELS * CAELO_RANSAC_MAX_TRIALS * 4);
+            if (hipMemcpy(draws.data(), it.rand_dev, draws.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) st = -1;
+            else st = certify_record(t.host[i], draws.data(), it.res, it.mask, CAELO_MAX_KEYPTS, &evals);
+        }
+        if (st < 0) failed = 1;
+        if (it.info) { it.info[0] = evals; it.info[1] = st; }
+    }
+    bool last;
+    {
+        std::lock_guard<std::mutex> lk(p->cert_mu);
+        if (failed) p->cert_failed = 1;
+        p->stat_cert_pairs += 1;
+        p->stat_cert_evals += evals;
+        p->stat_cert_ns += now_ns() - t0;
+        last = --t.remaining == 0;
+        if (last) t.state = 0;
+    }
+    if (last) p->cert_cv.notify_all();
+}
+
+void cert_worker(caelo_pipeline *p) {
+    (void)hipSetDevice(p->ctx->device);
+    std::vector<double> draws;
+    for (;;) {
+        std::pair<int, int> w;
+        {
+            std::unique_lock<std::mutex> lk(p->cert_mu);
+            p->cert_cv.wait(lk, [&] { return p->cert_stop || !p->cert_queue.empty(); });
+            if (p->cert_queue.empty()) return;   // (stop)
+            w = p->cert_queue.front();
+            p->cert_queue.pop_front();
+        }
+        cert_process(p, w.first, w.second, draws);
+    }
+}
+
+// (issuing thread) the certificates of every issued batch except the newest `keep`: wait for the pair stage (long finished when
+// keep = 2: the thread has just waited for the encoder of the batch before the newest), queue the copy, hand the task over
+int cert_drain(caelo_pipeline *p, size_t keep) {
+    const int64_t t_in = now_ns();
+    struct Acc { caelo_pipeline *p; int64_t t; ~Acc() { p->stat_cert_drain_ns += now_ns() - t; } } acc{p, t_in};
+    while (p->cert_issued.size() > keep) {
+        const int slot = p->cert_issued.front();
+        p->cert_issued.pop_front();
+        caelo_pipeline::CertTask &t = p->cert_ring[slot];
+        CAELO_HIP(hipEventSynchronize(t.pair_done));
+        for (int i = 0; i < t.n;) {   // records that lie back to back on the device leave in one copy
+            int j = i + 1;
+            while (j < t.n && t.item[j].dev == t.item[j - 1].dev + 1) ++j;
+            CAELO_HIP(hipMemcpyAsync(t.host + i, t.item[i].dev, (size_t)(j - i) * sizeof(caelo_ransac_cert), hipMemcpyDeviceToHost, p->sC));
+            i = j;
+        }
+        CAELO_HIP(hipEventRecord(t.copied, p->sC));
+        {
+            std::lock_guard<std::mutex> lk(p->cert_mu);
+            t.state = 2;
+            t.remaining = t.n;
+            for (int i = 0; i < t.n; ++i) p->cert_queue.emplace_back(slot, i);
+        }
+        p->cert_cv.notify_all();
+    }
+    return CAELO_OK;
+}
+
+// a free task for the batch being issued (blocks while the certifier is CERT_RING batches behind)
+int cert_task(caelo_pipeline *p, caelo_pipeline::CertTask **out, int *slot_out) {
+    if (!p->cert_started) {
+        CAELO_REQUIRE(certify_record(caelo_ransac_cert(), nullptr, nullptr, nullptr, 0, nullptr) != -1,
+                      "result_host given but no BLAS is bound (caelo_host_bind_blas)");
+        CAELO_HIP(hipStreamCreateWithFlags(&p->sC, hipStreamNonBlocking));
+        for (caelo_pipeline::CertTask &t : p->cert_ring) {
+            CAELO_HIP(hipHostMalloc((void **)&t.host, (size_t)p->batch * sizeof(caelo_ransac_cert), hipHostMallocDefault));
+            CAELO_HIP(hipEventCreateWithFlags(&t.pair_done, hipEventDisableTiming));
+            CAELO_HIP(hipEventCreateWithFlags(&t.copied, hipEventDisableTiming));
+        }
+        for (std::thread &th : p->cert_thread) th = std::thread(cert_worker, p);
+        p->cert_started = true;
+    }
+    const int slot = (int)(p->cert_seq % caelo_pipeline::CERT_RING);
+    caelo_pipeline::CertTask &t = p->cert_ring[slot];
+    if (t.state == 1) {   // (only with more than CERT_RING batches issued and never drained: cannot happen, the drain runs per batch)
+        const int rc = cert_drain(p, 0);
+        if (rc) return rc;
+    }
+    {
+        std::unique_lock<std::mutex> lk(p->cert_mu);
+        p->cert_cv.wait(lk, [&] { return t.state == 0; });
+    }
+    ++p->cert_seq;
+    t.n = 0;
+    *out = &t;
+    *slot_out = slot;
+    return CAELO_OK;
+}
+
+int cert_wait_idle(caelo_pipeline *p) {
+    if (!p->cert_started) return CAELO_OK;
+    const int rc = cert_drain(p, 0);
+    {   // the last batches of a run: this thread has nothing else to do and takes its share of the queue
+        std::vector<double> draws;
+        for (;;) {
+            std::pair<int, int> w(-1, -1);
+            {
+                std::lock_guard<std::mutex> lk(p->cert_mu);
+                if (!p->cert_queue.empty()) { w = p->cert_queue.back(); p->cert_queue.pop_back(); }
+            }
+            if (w.first < 0) break;
+            cert_process(p, w.first, w.second, draws);
+        }
+    }
+    std::unique_lock<std::mutex> lk(p->cert_mu);
+    p->cert_cv.wait(lk, [&] {
+        for (const caelo_pipeline::CertTask &t : p->cert_ring)
+            if (t.state != 0) return false;
+        return true;
+    });
+    if (rc) return rc;
+    if (p->cert_failed) {
+        p->cert_failed = 0;
+        caelo_set_error("caelo_pipeline: a certificate could not be evaluated on the host (dgesdd failed or the copy did)");
+        return CAELO_ERR_HIP;
+    }
+    return CAELO_OK;
+}
 
 int issue_batch_impl(caelo_pipeline *p) {
     const int n = (int)p->pending.size();
@@ -104,6 +278,14 @@ int issue_batch_impl(caelo_pipeline *p) {
     int rc = extract_front_set(xa, n, p->sF, p->sV, p->vox_fork, p->vox_join);
     if (rc) return rc;
     CAELO_HIP(hipEventRecord(p->front_done[nb], p->sF));
+    // The certificates of the batches whose pair stage has long finished go to the host half HERE: the front stage of this batch is
+    // queued (what the encoder waits for next -- between the pacing wait at the end of the previous call and these launches every
+    // microsecond of the issuing thread is a microsecond of the batch), the rest of the call has slack.  All but the two newest
+    // issued batches: the thread waited for the encoder of the batch before the newest at the end of the previous call (a caller
+    // that paces itself -- pace -1, Pipeline.run_uploading -- waits AFTER the call: one more batch of slack).
+    if (!p->cert_issued.empty()) {
+        if ((rc = cert_drain(p, p->pace >= 0 ? 1 : 2))) return rc;
+    }
     const int64_t t1 = now_ns();
     // ---- encoder: one launch set for the batch; only the distinct patches of each frame are encoded
     CAELO_HIP(hipStreamWaitEvent(p->sE, p->front_done[nb], 0));
@@ -121,6 +303,8 @@ int issue_batch_impl(caelo_pipeline *p) {
     // ---- pairs: frame i against its predecessor (the previous batch's last frame for i = 0) or an explicit one
     caelo_pair_set ps = {};
     ps.faults = p->ctx->faults;
+    caelo_pipeline::CertTask *ctask = nullptr;
+    int cslot = -1;
     for (int i = 0; i < n; ++i) {
         const caelo_frame_job &j = jobs[i];
         if (j.pair == CAELO_PAIR_NONE) continue;
@@ -137,11 +321,21 @@ int issue_batch_impl(caelo_pipeline *p) {
         d.pair_idx = j.pair_idx; d.ws_match = p->ws_match[ps.n]; d.ws_ransac = p->ws_ransac[ps.n];
         d.rand = j.rand; d.result = j.result; d.mask = j.inlier_mask; d.cert = j.cert;
         ++ps.n;
+        if (j.result_host) {   // the host half for this pair (certifier thread)
+            if (!ctask && (rc = cert_task(p, &ctask, &cslot))) return rc;
+            ctask->item[ctask->n++] = {j.cert, j.result_host, j.mask_host, j.rand_host, j.rand, j.info_host};
+        }
     }
     if (ps.n > 0) {
         CAELO_HIP(hipStreamWaitEvent(p->sP, p->enc_done[nb], 0));  // this batch's descriptors; the predecessor's came earlier on sE
         if ((rc = match_set(ps, 64, CAELO_MAX_KEYPTS, 64, CAELO_MAX_KEYPTS, 60, p->sP))) return rc;
         if ((rc = ransac_set(ps, 64, 64, CAELO_MAX_KEYPTS, p->sP))) return rc;
+        if (ctask) {
+            ctask->batch_no = k;
+            CAELO_HIP(hipEventRecord(ctask->pair_done, p->sP));
+            ctask->state = 1;
+            p->cert_issued.push_back(cslot);
+        }
     }
     p->last = jobs[n - 1];
     p->have_last = true;
@@ -156,6 +350,7 @@ int issue_batch_impl(caelo_pipeline *p) {
     // the more of them: a 20-batch run 16.5 k -> 17.3 k frames/s with the pacing, a 120-batch run 18.2 k -> 18.5 k
     if (p->pace >= 0 && p->since_begin > p->pace)
         CAELO_HIP(hipEventSynchronize(p->enc_done[(int)((k - (uint64_t)p->pace) % (uint64_t)p->n_buffers)]));
+
     static const bool verbose = getenv("CAELO_PIPE_VERBOSE") != nullptr;
     if (verbose) fprintf(stderr, "batch %llu n=%d issue us: front %.1f enc %.1f pair %.1f\n", (unsigned long long)k, n, (t1 - t0) / 1e3, (t2 - t1) / 1e3, (t3 - t2) / 1e3);
     return CAELO_OK;
@@ -183,6 +378,22 @@ CAELO_API void caelo_pipeline_destroy(caelo_pipeline *p) {
     if (!p) return;
     for (hipStream_t s : {p->sF, p->sE, p->sP, p->sV})
         if (s) (void)hipStreamSynchronize(s);
+    if (p->cert_started) {
+        (void)cert_wait_idle(p);
+        {
+            std::lock_guard<std::mutex> lk(p->cert_mu);
+            p->cert_stop = true;
+        }
+        p->cert_cv.notify_all();
+        for (std::thread &th : p->cert_thread)
+            if (th.joinable()) th.join();
+        for (caelo_pipeline::CertTask &t : p->cert_ring) {
+            if (t.host) (void)hipHostFree(t.host);
+            if (t.pair_done) (void)hipEventDestroy(t.pair_done);
+            if (t.copied) (void)hipEventDestroy(t.copied);
+        }
+        if (p->sC) (void)hipStreamDestroy(p->sC);
+    }
     for (int i = 0; i < CAELO_FB_MAX; ++i) {
         if (p->maps[i]) caelo_voxmap_destroy(p->maps[i]);
         for (void *w : {p->ws_extract[i], p->ws_match[i], p->ws_ransac[i]})
@@ -315,10 +526,22 @@ CAELO_API int caelo_pipeline_stats(caelo_pipeline *p, int64_t *out_host) {
     return CAELO_OK;
 }
 
+CAELO_API int caelo_pipeline_cert_stats(caelo_pipeline *p, int64_t *out_host) {
+    CAELO_REQUIRE(p && out_host, "null argument");
+    std::lock_guard<std::mutex> lk(p->cert_mu);
+    out_host[0] = p->stat_cert_pairs;   // pairs the host half has finished since the last call
+    out_host[1] = p->stat_cert_evals;   // hypotheses it evaluated for them
+    out_host[2] = p->stat_cert_ns;      // certifier-thread time spent on them
+    out_host[3] = p->stat_cert_drain_ns;  // issuing-thread time spent handing certificates over (event waits, copies queued)
+    p->stat_cert_pairs = p->stat_cert_evals = p->stat_cert_ns = p->stat_cert_drain_ns = 0;
+    return CAELO_OK;
+}
+
 CAELO_API int caelo_pipeline_begin(caelo_pipeline *p, void *stream) {
     CAELO_REQUIRE(p, "null argument");
     p->pending.clear();
     p->since_begin = 0;
+    if (p->cert_started) (void)cert_wait_idle(p);
     if (p->failed) {   // the stage streams may hold half a batch: drain them, forget the chain
         for (hipStream_t s : {p->sF, p->sE, p->sP, p->sV})
             if (s) (void)hipStreamSynchronize(s);
@@ -371,6 +594,8 @@ CAELO_API int caelo_pipeline_submit(caelo_pipeline *p, const caelo_frame_job *jo
     if (job->pair != CAELO_PAIR_NONE)
         CAELO_REQUIRE(job->rand && job->result && job->inlier_mask && job->pair_idx, "null pair buffer");
     if (job->pair == CAELO_PAIR_EXPLICIT) CAELO_REQUIRE(job->prev_rows, "explicit pair without prev_rows");
+    if (job->pair != CAELO_PAIR_NONE && job->result_host) CAELO_REQUIRE(job->cert && job->mask_host, "result_host needs cert and mask_host");
+    CAELO_REQUIRE((((uintptr_t)job->cert) & 15u) == 0, "certificate not 16-byte aligned");
     if (job->pair == CAELO_PAIR_CHAIN && !p->have_last && p->pending.empty()) {
         caelo_set_error("caelo_pipeline_submit: the first job has no predecessor to chain to");
         return CAELO_ERR_ARG;
@@ -463,5 +688,6 @@ CAELO_API int caelo_pipeline_flush(caelo_pipeline *p, void *stream) {
         CAELO_HIP(hipEventRecord(p->joined[i], ss[i]));
         CAELO_HIP(hipStreamWaitEvent(caelo_stream(stream), p->joined[i], 0));
     }
-    return rc;
+    const int rc2 = cert_wait_idle(p);   // exact results requested: they are all written when this returns
+    return rc ? rc : rc2;
 }

@@ -487,7 +487,9 @@ __global__ void __launch_bounds__(256) k_kp_score(const caelo_frame_set fs, int 
                                           __fadd_rn(__fadd_rn(s4, s5), __fadd_rn(s6, s7)));
                 // the square root is monotone (correctly rounded): min over sqrt(t) = sqrt(min t), taken once below
                 const bool o = (win >> (5 * (oy + 2) + ox + 2)) & 1u;
-                best = (o && t < best) ? t : best;
+                // (NaN propagates like np.min over the norms, SphericalRing.py:159: a NaN neighbour -- a NaN intensity reaches the ring
+                // image, NaN coordinates are refused earlier -- makes the score NaN and `score > 0.2` false)
+                best = (o && (t < best || t != t)) ? t : best;   // (once NaN, `t < NaN` keeps it)
             }
         }
         best = cnt > 0 ? sqrtf(best) : 0.0f;

@@ -437,14 +437,14 @@ __global__ void __launch_bounds__(256) k_vox_points(const caelo_frame_set fs) {
     int st = (v.oob ? CAELO_ST_VOXEL_OOB : 0) | (v.nonfinite ? CAELO_ST_NONFINITE : 0);
     unsigned long long key = CAELO_EMPTY_KEY;
     // every point's scale-0 voxel, for k_vox_suspects_first (the fused build leaves the exact build's first-touch key table
-    // free; it holds >= 2 entries per point)
+    // free; it holds >= 1.5 entries per point, checked against the point count by the caller: indexed by the point here)
     if (i < n) F.vkeys[0][i] = v.ok ? caelo_pack3(v.g[0], v.g[1], v.g[2]) : CAELO_EMPTY_KEY;
     if (v.ok) {
         bool consistent = true;
 #pragma unroll
         for (int a = 0; a < 3; ++a) consistent &= (v.v1[a] == (v.g[a] >> 3)) && (v.v2[a] == (v.g[a] >> 5));
         key = caelo_pack3(v.g[0] >> 3, v.g[1] >> 3, v.g[2] >> 3);
-        if (!consistent) {  // rare: its voxel becomes a suspect (tables hold >= 2 slots per point: never full)
+        if (!consistent) {  // rare: its voxel becomes a suspect (tables hold >= 1.5 slots per point and at most one entry per point: load <= 0.67, never full)
             bool sp_new = false;
             const int ss = table_insert_new(sp.sp_keys, sp.mask, caelo_pack3(v.g[0], v.g[1], v.g[2]), &sp_new);
             uint32_t sb = 0xFFFFFFFFu;

@@ -49,7 +49,7 @@ def _parse_poses(raw, k):
 
 
 def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, keep=None, strict_ties=True, tie_log=None, host_times=None,
-              loader_threads=4):
+              loader_threads=4, certify=True):
     """Frames [lo, hi) of this rank.  Returns per-pair rows for pairs (i-1, i), i in (lo, hi) -- the pair (lo-1, lo)
     is the caller's (it needs the previous rank's last frame) -- plus the first and last frame's features.
 
@@ -153,7 +153,11 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
         c0, c1, scans, draws = item
         t_ = time.time()
         draws_d = draws.to(eng.device, non_blocking=True)
-        batch = pipe.run_uploading(scans, [draws_d[i] for i in range(c1 - c0)], prev=prev, dist_channels=dist_channels)
+        # certify: the exact RANSAC (the pipeline's certifier thread runs the host half on every pair while later batches are on the
+        # GPU; the call returns when this chunk's inlier sets and poses -- the reference's bits -- are in batch.result / inlier_mask)
+        dn_ = draws.numpy()
+        batch = pipe.run_uploading(scans, [draws_d[i] for i in range(c1 - c0)], prev=prev, dist_channels=dist_channels,
+                                   certify=certify, rands_host=[dn_[i] for i in range(c1 - c0)] if certify else None)
         ht["pipeline"] += time.time() - t_
         t_ = time.time()
         if strict_ties:
@@ -166,7 +170,11 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
                 if tie_log is not None:
                     tie_log.append((c0 + j, n_t))
             for j in sorted({t for u in tied for t in (u, u + 1) if t < c1 - c0 and (t > 0 or prev is not None)}):
-                r_, m_, x_ = eng.match_pose(prev if j == 0 else batch.frame(j - 1), batch.frame(j), draws_d[j])
+                if certify:
+                    r_, m_, x_ = eng.match_pose_exact(prev if j == 0 else batch.frame(j - 1), batch.frame(j), draws_d[j], dn_[j])
+                    r_, m_ = torch.from_numpy(np.frombuffer(r_.tobytes(), np.uint8).copy()), torch.from_numpy(m_)
+                else:
+                    r_, m_, x_ = eng.match_pose(prev if j == 0 else batch.frame(j - 1), batch.frame(j), draws_d[j])
                 batch.result[j].copy_(r_); batch.inlier_mask[j].copy_(m_); batch.pair_idx[j].copy_(x_)
         ht["ties"] += time.time() - t_
         # read this chunk's small outputs back without stalling the stream that issues the next chunk
@@ -216,6 +224,8 @@ def main():
     ap.add_argument("--save-artifacts", action="store_true", help="write Features/*.mat and InliersIdx/*.mat next to the scans")
     ap.add_argument("--no-strict-ties", action="store_true", help="keep the fused path's canonical rule where the 496-nearest cut splits a "
                                                                   "tie class (default: such frames are redone in scikit-learn's kd-tree order)")
+    ap.add_argument("--no-certify", action="store_true", help="the kernels' own RANSAC results (float64 fits) without the host half that makes "
+                                                              "inlier sets and poses the reference's bits (csrc/certify.hip)")
     ap.add_argument("--gpus", type=int, default=int(os.environ.get("WORLD_SIZE", "1")),
                     help="ranks = GPUs; without a launcher the script starts them itself (caelo.dist.ensure_ranks)")
     args = ap.parse_args()
@@ -288,7 +298,7 @@ def main():
     host_times = {}
     rel, ok, thr, nin, first, last = run_local(eng, load, lo, hi, args.seed_base, args.chunk, args.dist_channels,
                                                args.batch, keep, strict_ties=not args.no_strict_ties, tie_log=tie_log, host_times=host_times,
-                                               loader_threads=args.loader_threads)
+                                               loader_threads=args.loader_threads, certify=not args.no_certify)
     if tie_log:
         print("rank %d: %d frame(s) redone in scikit-learn's tie order (%d patches): %s" % (
             rank, len(tie_log), sum(n for _, n in tie_log), [f for f, _ in tie_log][:20]), file=sys.stderr)
@@ -296,8 +306,11 @@ def main():
         gathered = cdist.all_gather_boundary(last.rows)
         if rank > 0:
             prev = FrameFeatures.from_rows(gathered[rank - 1])
-            res = eng.match_pose(prev, first, torch.from_numpy(ransac_draws(args.seed_base + lo - 1)).to(eng.device))[0]
-            r = eng.pose_result(res)
+            bd = ransac_draws(args.seed_base + lo - 1)
+            if args.no_certify:
+                r = eng.pose_result(eng.match_pose(prev, first, torch.from_numpy(bd).to(eng.device))[0])
+            else:   # exact like every other pair
+                r = _ffi.PoseResult.from_buffer_copy(eng.match_pose_exact(prev, first, torch.from_numpy(bd).to(eng.device), bd)[0].tobytes())
             row = np.r_[np.array(r.R, np.float32), np.array(r.T, np.float32)][None]
             rel = np.concatenate([row, rel]); ok = np.r_[bool(r.success), ok]; thr = np.r_[np.float32(r.threshold), thr]
             nin = np.r_[np.int32(r.n_inliers), nin]

@@ -199,6 +199,13 @@ int64_t caelo_match_ws_bytes(int64_t k_max);
 int caelo_match(caelo_ctx *ctx, const float *f0, int ld0, int64_t k0_max, const int32_t *n0, const float *f1, int ld1,
                 int64_t k1_max, const int32_t *n1, int dim, int64_t *pair_idx, void *ws, void *stream);
 
+/* Measurement aid (no reference counterpart): the pipeline's launch shape of the NN match -- n_pairs (<= 8) pairs of consecutive
+ * frame rows (rows [n_pairs + 1] device pointers to [1024][64] f32, descriptor in columns 0:60; n_key [n_pairs + 1] device counts
+ * or NULL) behind one k_match_prep + one k_match_screen launch, `repeats` times between HIP events on `stream`.
+ * pair_idx [n_pairs][1024] out; ws: n_pairs * caelo_match_ws_bytes(1024) bytes; ms_host[2] = both kernels / the prep alone, averaged. */
+int caelo_match_profile(caelo_ctx *ctx, const float *const *rows, int n_pairs, const int32_t *const *n_key, int64_t *pair_idx,
+                        void *ws, int repeats, void *stream, float *ms_host);
+
 /* SolveRT  (Match.py:138-158): p0 ~ R p1 + T over n point pairs.  R [9], T [3] f32 (device);
  * credible [1] i32 (optional): the reference's isCredible, -1 when det(R) < 0 was met. */
 int caelo_solve_rt(caelo_ctx *ctx, const float *p0, const float *p1, int64_t n, float *R, float *T,
@@ -371,8 +378,18 @@ typedef struct caelo_frame_job {
     uint8_t *inlier_mask;       /* [1024] out */
     int64_t *pair_idx;          /* [1024] out */
     caelo_ransac_cert *cert;    /* out, nullable: the pair's certificate for caelo_host_certify */
+    /* The host half inside the pipeline (needs cert and caelo_host_bind_blas): when result_host is given, a certifier thread of
+     * the pipeline copies the pair's certificate to the host once its pair stage is through (paced by the issuing thread, no
+     * device-side wait), runs the host half while later batches are on the GPU and writes the EXACT result -- the reference's
+     * inlier set, R_star / T_star, refit, bit for bit -- to these HOST buffers; caelo_pipeline_flush returns when all are written. */
+    caelo_pose_result *result_host; /* out, nullable */
+    uint8_t *mask_host;             /* [1024] out (required with result_host) */
+    const double *rand_host;        /* nullable: host copy of `rand` (only read when the pair escalates beyond 0.4 m; fetched from `rand` otherwise) */
+    int32_t *info_host;             /* nullable: [2] = hypotheses evaluated on the host, status (0 exact, 2 no bounds, 3 no record) */
 } caelo_frame_job;
 int caelo_pipeline_create(caelo_ctx *ctx, int batch, int n_buffers, int64_t max_points, caelo_pipeline **out);
+/* host half inside the pipeline: out_host[4] = pairs certified, hypotheses evaluated for them, nanoseconds of the certifier thread, nanoseconds the issuing thread spent handing certificates over -- since the last call */
+int caelo_pipeline_cert_stats(caelo_pipeline *pipe, int64_t *out_host);
 void caelo_pipeline_destroy(caelo_pipeline *pipe);
 int caelo_pipeline_batch(const caelo_pipeline *pipe);
 int caelo_pipeline_begin(caelo_pipeline *pipe, void *stream);

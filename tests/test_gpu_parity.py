@@ -569,17 +569,21 @@ def test_shuffled_file_order_vs_reference_golden(engine, api, scans):
 
 @pytest.mark.parametrize("scene,frames", [("boxes", 18), ("clutter", 18), ("boxes_mm", 18), ("shuffled", 6)])
 def test_parity_soak_short(engine, orc, models, scene, frames):
-    """A short leg of tools/parity_soak.py (the committed 200-frame report is profiles/r04_parity_soak.txt): consecutive frames
-    through the batched pipeline against the oracle -- key pixels, voxel sets, patch bits bit-exact; descriptors within 1e-4;
-    caelo_match and caelo_ransac on the oracle's inputs bit-exact; the pipeline's own argmin columns equal to the oracle's except
-    where the float64 margin is below what the pair's descriptor error can move a distance by (listed), and every pair without such
-    a column has the oracle's inlier set bit for bit and its pose within 1e-4."""
+    """A short leg of tools/parity_soak.py (the committed 200- and 600-frame reports are profiles/r05_parity_soak*.txt): consecutive
+    frames through the batched pipeline against the oracle -- key pixels, voxel sets, patch bits bit-exact; descriptors within 1e-4;
+    caelo_match on the oracle's descriptors bit-exact; caelo_ransac + the host half on the oracle's pairs: inlier set, success,
+    threshold, R_star / T_star and the refit BIT-EXACT for every pair (a strict gate: nothing about RANSAC is ever 'explained');
+    the pipeline's own argmin columns equal to the oracle's except where the float64 margin is below what the pair's descriptor
+    error can move a distance by (listed), and every pair without such a column has the oracle's inlier set and pose bit for bit."""
     sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
     import parity_soak
     rep = parity_soak.soak(engine, orc, models, scene, frames, workers=min(frames, 16))
     assert parity_soak.clean(rep), parity_soak.render(rep)
     assert rep["columns"] == (frames - 1) * 1024 and rep["patches"] == frames * 3072
     assert rep["success_mismatch"] == 0 and rep["flips"] <= rep["columns"] // 1000   # flips stay rare (measured: a few per 100 k columns)
+    assert rep["ransac_kernel_mismatch_pairs"] == 0 and rep["ransac_kernel_bitexact_pairs"] == rep["pairs_compared"] == frames - 1
+    assert rep["exact_pairs_inlier_mismatch"] == 0 and rep["exact_pairs_bitexact_pose"] == rep["exact_pairs"] >= (frames - 1) // 2
+    assert rep["ransac_kernel_evals_max"] <= 40 and rep["host_hypotheses_per_pair"] <= 6
 
 
 @pytest.mark.parametrize("batch,buffers", [(1, 2), (3, 2), (4, 3), (8, 2)])
@@ -1540,7 +1544,7 @@ def test_ransac_certificate_bounds_hold_and_results_are_the_oracles_bits(engine,
         draws = np.random.RandomState(seed).random_sample(6000)
         cert = engine.new_cert(1)
         res, mask = engine.ransac(kp0, kp1, pidx, torch.from_numpy(draws).to(engine.device), cert=cert[0])
-        rec = cert.cpu().numpy().view(_ffi.CERT_DTYPE)[0]
+        rec = cert.cpu().numpy().view(_ffi.CERT_DTYPE).reshape(-1)[0]
         assert rec["magic"] == _ffi.CERT_MAGIC and rec["n_pairs"] == N and rec["flags"] == 0
         assert np.array_equal(rec["idx"][:500], (draws[:2000].reshape(500, 4) * N).astype(np.int32))
         assert np.array_equal(rec["p0"][:N], P0) and np.array_equal(rec["p1"][:N], P1)
@@ -1600,7 +1604,7 @@ def test_ransac_certificate_on_degenerate_and_edge_inputs(engine, orc):
             draws = np.random.RandomState(seed).random_sample(6000)
             cert = engine.new_cert(1)
             engine.ransac(d0, d1, ident, torch.from_numpy(draws).to(engine.device), cert=cert[0])
-            rec = cert.cpu().numpy().view(_ffi.CERT_DTYPE)[0]
+            rec = cert.cpu().numpy().view(_ffi.CERT_DTYPE).reshape(-1)[0]
             cnt = _oracle_counts(orc, P0, P1, draws)
             assert (rec["hi"][:500] >= cnt).all(), (name, seed, np.flatnonzero(rec["hi"][:500] < cnt)[:5])
             results, masks, evals, status = engine.certify(cert, [draws])
@@ -1632,10 +1636,17 @@ def test_pipeline_certified_poses_equal_the_oracle_on_the_pipelines_own_matches(
     dpcs = [torch.from_numpy(pc).to(engine.device) for pc in pcs]
     draws = [ransac_draws(900 + i) for i in range(n)]
     rnd = [torch.from_numpy(d).to(engine.device) for d in draws]
-    out = engine.pipeline(4).run(dpcs, rnd, certify=True)
-    kernels_result = out.result.clone()
-    res, masks, evals, status = engine.certify_batch(out, draws)
+    pipe = engine.pipeline(4)
+    kernels_result = pipe.run(dpcs, rnd).result.clone()           # the kernels' own results (float64 fits, no host half)
+    out = pipe.run(dpcs, rnd, certify=True)                       # the certifier thread of the pipeline runs the host half
+    res, masks, evals, status = out.exact
     assert status[0] == 3 and (status[1:] == 0).all()            # frame 0 has no predecessor
+    st = pipe.cert_stats()
+    assert st["pairs"] == n - 1 and 1 <= st["evals_per_pair"] <= 12
+    # the same certificates through the stand-alone entry point (Engine.certify_batch -> caelo_host_certify): identical
+    out2 = pipe.run(dpcs, rnd, certify="device")
+    res2, masks2, evals2, status2 = engine.certify_batch(out2, draws)
+    assert res2[1:].tobytes() == res[1:].tobytes() and np.array_equal(masks2[1:], masks[1:]) and (status2[1:] == 0).all()
     rows = out.rows.cpu().numpy()
     pidx = out.pair_idx.cpu().numpy()
     nk = out.n_key.cpu().numpy()

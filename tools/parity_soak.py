@@ -16,17 +16,15 @@ What must hold (the bars of BASELINE.json's north_star):
   key pixels, key points, voxel sets, patch bits        bit-exact, every frame
   descriptors                                           |got - want| <= 1e-4 max(|want|, 0.1), every element
   NN match on the ORACLE's descriptors (caelo_match)    pair_idx bit-exact, every column    (the match kernel on its own)
-  RANSAC on the ORACLE's pairs (caelo_ransac)           inlier set, threshold, success bit-exact; R, T <= 1e-4   (the pose kernels on their own);
-                                                        a pair that differs is listed with the trial that won on either side and must
-                                                        come from the reference's FLOAT32 SVD of an ill-conditioned 4-point sample:
-                                                        the HIP mask equals a float64 evaluation of its winning trial, or the sample
-                                                        is rank deficient (coplanar points: the null singular vector is the SVD
-                                                        routine's choice -- LAPACK's, NumPy's and the kernel's differ legitimately)
+  RANSAC on the ORACLE's pairs (caelo_ransac +     inlier set, threshold, success, R_star / T_star and the refit BIT-EXACT, every pair, no
+  the host half, Engine.certify)                        exception: the kernels score the 500 hypotheses and bound what the reference's float32 /
+                                                        BLAS arithmetic can give each, the host half re-evaluates the deciding ones through
+                                                        NumPy's own BLAS / LAPACK calls (csrc/certify.hip)
   the pipeline end to end                               pair_idx equal to the oracle's EXCEPT where the float64 margin between
                                                         the two candidates (oracle descriptors) is below what the descriptor
                                                         error of that pair can move a distance by (triangle inequality:
                                                         |d'(a,b) - d(a,b)| <= |da| + |db|); every exception is listed with both
-                                                        numbers.  Pairs without exception: inlier sets bit-exact, R/T <= 1e-4;
+                                                        numbers.  Pairs without exception: inlier sets AND poses bit-exact (same pairs in, same bits out);
                                                         pairs with one: inlier-set difference and pose difference listed.
 
 The descriptor -> argmin -> inlier-set chain is float -> integer: a descriptor that differs in the 7th digit may flip an argmin
@@ -86,59 +84,6 @@ def oracle_frame(orc, models, pc, dist_channels=5):
     return dict(kp=kp, kpix=kpix, vox=[v[6], v[7], v[8]], bits=np.stack(bits, 1), flags=np.stack(flags, 1), feats=feats)
 
 
-def _hyp64(p0, p1, sample):
-    """One RANSAC hypothesis in float64 (Match.py:138-158 on float64 copies of the four sampled pairs) -> residuals [N] f64."""
-    a, b = p0[sample].astype(np.float64), p1[sample].astype(np.float64)
-    m0, m1 = a.mean(0), b.mean(0)
-    U, S, Vt = np.linalg.svd((b - m1).T @ (a - m0))
-    R = Vt.T @ U.T
-    if np.linalg.det(R) < 0:
-        Vt[:, 2] *= -1
-        R = Vt.T @ U.T
-    T = m0 - R @ m1
-    return np.linalg.norm(p0.astype(np.float64) - (p1.astype(np.float64) @ R.T + T), axis=1), S
-
-
-def explain_ransac(p0, p1, trace, pr, got_in, want_in, thr):
-    """Why a pair's inlier set differs from the oracle's: which trial won on either side, their counts, and how close to the
-    threshold (float64 residuals of a float64 Kabsch fit) the points sit that decide -- the reference fits every hypothesis with
-    LAPACK's float32 SVD (Match.py:148), the HIP kernel with a float64 polar iteration; a residual within ~1e-5 m of the
-    threshold can fall on either side, and `nInliers > curNumInliers` (Match.py:199) turns one such point into another winner."""
-    level = [t for t in trace if t[2] == thr]
-    counts = np.array([t[1] for t in level])
-    least = min(100, int(0.2 * len(p0)))
-    best, t_o = 0, -1
-    for t, c in enumerate(counts):
-        if c >= least and c > best:
-            best, t_o = c, t
-    t_g = int(pr.best_trial) % 500 if pr.best_trial >= 0 else -1
-    out = dict(oracle_trial=t_o, oracle_count=int(best), hip_trial=t_g, hip_count_by_oracle=int(counts[t_g]) if 0 <= t_g < len(counts) else None,
-               trials_run_oracle=len(level), trials_run_hip=int(pr.iterations), sym_diff=int(len(np.setxor1d(got_in, want_in))))
-    near = []
-    for t in sorted({t_o, t_g} - {-1}):
-        if t < len(level):
-            res, S = _hyp64(p0, p1, level[t][0])
-            near.append((t, int((res < thr).sum()), float(np.abs(res - thr).min()), float(S[2] / max(S[0], 1e-300)), len(set(level[t][0].tolist()))))
-    out["trials_f64"] = near      # (trial, float64 count, min |res - thr|, sigma3 / sigma1 of the sample's covariance, distinct sample points)
-    # the HIP side agrees with the float64 evaluation of ITS winning trial (mask for mask): then the difference is the reference's
-    # float32 SVD of an ill-conditioned sample (sigma3 / sigma1 small: the third singular vectors' signs -- hence det(R) and the
-    # reflection branch of Match.py:151-155 -- or a residual within the fit's float32 error of the threshold), not the kernel
-    out["hip_equals_f64"] = bool(0 <= t_g < len(level) and np.array_equal(np.flatnonzero(_hyp64(p0, p1, level[t_g][0])[0] < thr), got_in))
-    # ... or a deciding trial's sample is rank deficient (four coplanar points: sigma3 = 0 up to rounding, common on mm-quantised ground
-    # points): the third singular vectors are then ANY unit vectors of the null space, their signs -- and with them det(R) and the
-    # reflection branch -- are whatever the SVD routine returns, in LAPACK, in NumPy's float64 and in the kernel's polar iteration alike
-    out["rank_deficient_sample"] = bool(any(t[3] < 1e-6 for t in near))
-    # ... or the sample is merely ILL conditioned and the deciding residual sits closer to the threshold than a float32 fit can
-    # resolve: the reference's LAPACK float32 SVD (Match.py:148) determines the third singular direction to about eps32 * s1 / s3, a
-    # pose error that moves a residual at distance |p| from the centroid by eps32 * (s1 / s3) * |p|; the kernel fits in float64.
-    # (frame 45 of the 600-frame boxes soak: s3 / s1 = 5e-5, |p| ~ 30 m -> reach 0.07 m, the deciding point 3.3e-6 m from the threshold)
-    scale = float(max(np.abs(p0).max(), np.abs(p1).max()))
-    out["f32_fit_reach"] = [float(1.2e-7 * scale / max(t[3], 1e-12)) for t in near]
-    out["within_f32_fit_error"] = bool(any(t[2] < r for t, r in zip(near, out["f32_fit_reach"])))
-    out["explained"] = out["hip_equals_f64"] or out["rank_deficient_sample"] or out["within_f32_fit_error"]
-    return out
-
-
 def _sorted_rows(a):
     a = np.asarray(a, np.int32)
     return a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
@@ -157,16 +102,18 @@ def soak(engine, orc, models, scene, n_frames, seed_base=5000, batch=8, log=None
     dpcs = [torch.from_numpy(pc).to(dev) for pc in scans]
     draws = [ransac_draws(seed_base + i) for i in range(n_frames)]
     rnd = [torch.from_numpy(d).to(dev) for d in draws]
-    out = engine.pipeline(batch).run(dpcs, rnd, dist_channels=dist_channels)
+    pipe = engine.pipeline(batch)
+    out = pipe.run(dpcs, rnd, dist_channels=dist_channels, certify=True, rands_host=draws)   # exact RANSAC: certifier thread of the pipeline
     torch.cuda.synchronize()
+    cstat = pipe.cert_stats()
     # frames whose 496-nearest cut splits a tie class: the fused path used its canonical rule there (flag bit 2); redone the
     # reference's way (Engine.resolve_ties: ordered voxel lists, scikit-learn's kd-tree order), then the two pairs they are part of
     fl = out.flags.cpu().numpy()
     tied = [i for i in range(n_frames) if (fl[i] & 2).any()]
     n_tied_patches = sum(engine.resolve_ties(out.frame(i), dpcs[i]) for i in tied)
     for i in sorted({j for t in tied for j in (t, t + 1) if 1 <= j < n_frames}):
-        r_, m_, x_ = engine.match_pose(out.frame(i - 1), out.frame(i), rnd[i])
-        out.result[i].copy_(r_); out.inlier_mask[i].copy_(m_); out.pair_idx[i].copy_(x_)
+        r_, m_, x_ = engine.match_pose_exact(out.frame(i - 1), out.frame(i), rnd[i], draws[i])
+        out.result[i].copy_(torch.from_numpy(np.frombuffer(r_.tobytes(), np.uint8).copy())); out.inlier_mask[i].copy_(torch.from_numpy(m_)); out.pair_idx[i].copy_(x_)
     torch.cuda.synchronize()
     rows = out.rows.cpu().numpy(); kpix = out.key_pixels.cpu().numpy(); nkey = out.n_key.cpu().numpy()
     pidx = out.pair_idx.cpu().numpy(); mask = out.inlier_mask.cpu().numpy().astype(bool); res = out.result.cpu().numpy()
@@ -176,8 +123,9 @@ def soak(engine, orc, models, scene, n_frames, seed_base=5000, batch=8, log=None
                desc_max_abs=0.0, desc_max_rel=0.0, desc_over_tol=0, status_or=int(np.bitwise_or.reduce(status[:, 0])),
                match_kernel_mismatch_cols=0, ransac_kernel_mismatch_pairs=0, ransac_kernel_max_rt=0.0,
                columns=0, flips=0, flips_unexplained=0, pairs_with_flip=0, exact_pairs_inlier_mismatch=0, exact_pairs_max_rt=0.0,
-               flip_pairs_inlier_diff=[], flip_pairs_max_rt=0.0, ransac_notes=[], success_mismatch=0, threshold_mismatch=0, exceptions=[],
-               lane_faults=0)
+               flip_pairs_inlier_diff=[], flip_pairs_max_rt=0.0, success_mismatch=0, threshold_mismatch=0, exceptions=[],
+               lane_faults=0, host_hypotheses_per_pair=round(cstat["evals_per_pair"], 2), certifier_us_per_pair=round(cstat["host_us_per_pair"], 1),
+               ransac_kernel_evals_max=0, ransac_kernel_bitexact_pairs=0, pairs_compared=0, success_mismatch_exact_pairs=0, exact_pairs_bitexact_pose=0, exact_pairs=0)
     prev = None
     vm = engine.voxmap(max(engine.max_points, max(p.shape[0] for p in scans)), slot=6)
     for i in range(n_frames):
@@ -218,15 +166,18 @@ def soak(engine, orc, models, scene, n_frames, seed_base=5000, batch=8, log=None
             g_idx = engine.match(f0, f1)
             rep["match_kernel_mismatch_cols"] += int((g_idx.cpu().numpy() != o_idx).sum())
             p0 = torch.from_numpy(np.ascontiguousarray(prev["kp"])).to(dev); p1 = torch.from_numpy(np.ascontiguousarray(o["kp"])).to(dev)
-            r_, m_ = engine.ransac(p0, p1, torch.from_numpy(o_idx).to(dev), rnd[i])
-            pr = engine.pose_result(r_); m_ = m_.cpu().numpy().astype(bool)
-            rt = max(np.abs(np.array(pr.R).reshape(3, 3) - R).max(), np.abs(np.array(pr.T) - T.ravel()).max() / max(1.0, np.abs(T).max()))
-            if not (np.array_equal(np.flatnonzero(m_), i1) and bool(pr.success) == bool(ok) and pr.threshold == np.float32(thr)) or rt > REL_TOL:
-                rep["ransac_kernel_mismatch_pairs"] += 1
-                trace = []
-                orc.RANSAC4RT(prev["kp"][o_idx], o["kp"], rng=np.random.RandomState(seed_base + i), trace=trace)
-                rep["ransac_notes"].append(dict(frame=i, rt=float(rt), **explain_ransac(prev["kp"][o_idx], o["kp"], trace, pr, np.flatnonzero(m_), i1, float(thr))))
+            rep["pairs_compared"] += 1
+            cert = engine.new_cert(1)
+            engine.ransac(p0, p1, torch.from_numpy(o_idx).to(dev), rnd[i], cert=cert[0])
+            cres, cmask, cev, cst = engine.certify(cert, [draws[i]])
+            pr = cres[0]; m_ = cmask[0, :k].astype(bool)
+            assert cst[0] == 0
+            rt = max(np.abs(pr["R"].reshape(3, 3) - R).max(), np.abs(pr["T"] - T.ravel()).max() / max(1.0, np.abs(T).max()))
+            same = (np.array_equal(np.flatnonzero(m_), i1) and bool(pr["success"]) == bool(ok) and pr["threshold"] == np.float32(thr))
+            rep["ransac_kernel_mismatch_pairs"] += 0 if (same and rt <= REL_TOL) else 1
+            rep["ransac_kernel_bitexact_pairs"] += int(same and np.array_equal(pr["R"].reshape(3, 3), R) and np.array_equal(pr["T"].reshape(3, 1), T))
             rep["ransac_kernel_max_rt"] = max(rep["ransac_kernel_max_rt"], float(rt))
+            rep["ransac_kernel_evals_max"] = max(rep["ransac_kernel_evals_max"], int(cev[0]))
             # --- the pipeline end to end (its own descriptors)
             rep["columns"] += k
             flips = np.flatnonzero(pidx[i, :k] != o_idx)
@@ -247,8 +198,11 @@ def soak(engine, orc, models, scene, n_frames, seed_base=5000, batch=8, log=None
             rep["success_mismatch"] += int(bool(pr.success) != bool(ok)); rep["threshold_mismatch"] += int(pr.threshold != np.float32(thr))
             got_in = np.flatnonzero(mask[i, :k])
             if len(flips) == 0:
+                rep["exact_pairs"] += 1
                 rep["exact_pairs_inlier_mismatch"] += 0 if np.array_equal(got_in, i1) else 1
                 rep["exact_pairs_max_rt"] = max(rep["exact_pairs_max_rt"], float(rt))
+                rep["success_mismatch_exact_pairs"] += int(bool(pr.success) != bool(ok) or pr.threshold != np.float32(thr))
+                rep["exact_pairs_bitexact_pose"] += int(np.array_equal(np.array(pr.R, np.float32).reshape(3, 3), R) and np.array_equal(np.array(pr.T, np.float32).reshape(3, 1), T))
             else:
                 rep["pairs_with_flip"] += 1
                 rep["flip_pairs_inlier_diff"].append((i, len(flips), len(np.setxor1d(got_in, i1)), len(i1)))
@@ -262,12 +216,14 @@ def soak(engine, orc, models, scene, n_frames, seed_base=5000, batch=8, log=None
 
 
 def clean(rep):
-    """True iff everything that must be bit-exact / within tolerance is, and every flip is explained."""
+    """True iff everything that must be bit-exact / within tolerance is: integers and RANSAC results exactly, descriptors within 1e-4,
+    every argmin flip within the reach of the descriptor error.  No RANSAC difference is ever 'explained'."""
     return (rep["keypixel_mismatch_frames"] == 0 and rep["keypoint_mismatch_frames"] == 0 and sum(rep["voxel_set_mismatch"]) == 0
             and rep["patch_mismatch"] == 0 and rep["desc_over_tol"] == 0 and rep["status_or"] == 0
-            and rep["match_kernel_mismatch_cols"] == 0 and all(n["explained"] for n in rep["ransac_notes"])
-            and rep["flips_unexplained"] == 0 and rep["exact_pairs_inlier_mismatch"] <= len(rep["ransac_notes"])
-            and (rep["exact_pairs_max_rt"] <= REL_TOL or rep["ransac_notes"]) and rep["lane_faults"] == 0)
+            and rep["match_kernel_mismatch_cols"] == 0 and rep["ransac_kernel_mismatch_pairs"] == 0
+            and rep["ransac_kernel_bitexact_pairs"] == rep["pairs_compared"]
+            and rep["flips_unexplained"] == 0 and rep["exact_pairs_inlier_mismatch"] == 0 and rep["exact_pairs_max_rt"] <= REL_TOL
+            and rep["success_mismatch_exact_pairs"] == 0 and rep["lane_faults"] == 0)
 
 
 def render(rep):
@@ -280,20 +236,16 @@ def render(rep):
              rep["patch_mismatch"], rep["patches"], rep["patches_truncated"], rep["tie_split_patches"], rep["frames_with_tie_split"],
              rep["patch_mismatch_canonical_rule"]),
          "  descriptors: max |err| %.3g, max relative (0.1 floor) %.3g, elements over 1e-4: %d" % (rep["desc_max_abs"], rep["desc_max_rel"], rep["desc_over_tol"]),
-         "  kernels on the oracle's inputs: caelo_match %d wrong columns; caelo_ransac %d pairs differ (max R/T err %.2g)" % (
-             rep["match_kernel_mismatch_cols"], rep["ransac_kernel_mismatch_pairs"], rep["ransac_kernel_max_rt"]),
-         "  pipeline end to end: %d of %d argmin columns differ from the oracle's (%d pairs); unexplained by the descriptor error: %d" % (
-             rep["flips"], rep["columns"], rep["pairs_with_flip"], rep["flips_unexplained"]),
-         "    pairs without a flip: inlier sets differing %d, max R/T err %.2g; success flags differing %d, thresholds %d" % (
-             rep["exact_pairs_inlier_mismatch"], rep["exact_pairs_max_rt"], rep["success_mismatch"], rep["threshold_mismatch"]),
+         "  kernels on the oracle's inputs: caelo_match %d wrong columns; caelo_ransac + host half: %d of %d pairs differ in inlier set / success / threshold / pose beyond 1e-4; "
+         "%d of %d bit-exact incl. R_star, T_star and the refit (max R/T err %.2g; at most %d hypotheses re-evaluated on the host for a pair)" % (
+             rep["match_kernel_mismatch_cols"], rep["ransac_kernel_mismatch_pairs"], rep["pairs_compared"], rep["ransac_kernel_bitexact_pairs"], rep["pairs_compared"],
+             rep["ransac_kernel_max_rt"], rep["ransac_kernel_evals_max"]),
+         "  pipeline end to end (exact RANSAC inside the pipeline: %.2f hypotheses per pair on the host, %.1f us of the certifier thread per pair): %d of %d argmin columns differ from the oracle's (%d pairs); unexplained by the descriptor error: %d" % (
+             rep["host_hypotheses_per_pair"], rep["certifier_us_per_pair"], rep["flips"], rep["columns"], rep["pairs_with_flip"], rep["flips_unexplained"]),
+         "    pairs without a flip (%d): inlier sets differing %d, success / threshold differing %d, poses bit-identical to the oracle's %d, max R/T err %.2g" % (
+             rep["exact_pairs"], rep["exact_pairs_inlier_mismatch"], rep["success_mismatch_exact_pairs"], rep["exact_pairs_bitexact_pose"], rep["exact_pairs_max_rt"]),
          "    pairs with a flip: max R/T err %.2g; (frame, flips, inlier-set symmetric difference, oracle inliers): %s" % (
              rep["flip_pairs_max_rt"], rep["flip_pairs_inlier_diff"])]
-    for n in rep["ransac_notes"]:
-        L.append("    ransac %s frame %4d: oracle trial %d (%d inliers, %d trials run), HIP trial %d (oracle counts %s for it, %d trials run), inlier sets differ in %d, R/T %.2g; "
-                 "float64 refits (trial, count, min |res - thr| m, s3/s1, distinct sample points): %s; HIP mask == float64 mask of its trial: %s; rank-deficient sample: %s; deciding residual within a float32 fit's reach %s: %s -> %s" % (
-                     rep["scene"], n["frame"], n["oracle_trial"], n["oracle_count"], n["trials_run_oracle"], n["hip_trial"], n["hip_count_by_oracle"],
-                     n["trials_run_hip"], n["sym_diff"], n["rt"], ["(%d, %d, %.2g, %.2g, %d)" % t for t in n["trials_f64"]], n["hip_equals_f64"], n["rank_deficient_sample"],
-                     ["%.2g" % r for r in n.get("f32_fit_reach", [])], n.get("within_f32_fit_error"), "explained" if n["explained"] else "UNEXPLAINED"))
     for e in rep["exceptions"]:
         L.append("    flip %s frame %4d col %4d: oracle row %4d, HIP row %4d, float64 margin %.3g, descriptor reach %.3g  %s" % (
             e["scene"], e["frame"], e["col"], e["oracle_row"], e["hip_row"], e["margin"], e["reach"], "explained" if e["explained"] else "UNEXPLAINED"))
