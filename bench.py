@@ -348,7 +348,8 @@ def main():
             # on the hypotheses that decide) on every pair while later batches are on the GPU; run() returns when all are written
             batch = pipe.run(scans if scans is not None else [self.pool[j] for j in o], [rand[j % POOL] for j in o],
                              prev=self.prev if pairs else None, pairs=pairs, out=out, on_encoded=on_encoded,
-                             certify=pairs and CERTIFY, rands_host=[rand_host[j % POOL] for j in o] if pairs and CERTIFY else None, **self.kw)
+                             certify=pairs and CERTIFY, rands_host=[rand_host[j % POOL] for j in o] if pairs and CERTIFY else None,
+                             publish=False, **self.kw)   # (the exact poses / inlier sets are delivered in host arrays, like the reference's: batch.exact)
             self.last_order = o
             self.prev = batch.frame(n - 1)
             return batch

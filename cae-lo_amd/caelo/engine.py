@@ -240,7 +240,7 @@ class Pipeline:
         _ffi.check(self.eng.lib.caelo_pipeline_sync_encoded(self.h, int(lag)))
 
     def run(self, scans, rands=None, prev=None, dist_channels=5, exact_voxels=False, out=None, pairs=True, dedup=True, on_batch=None,
-            on_encoded=None, certify=False, rands_host=None):
+            on_encoded=None, certify=False, rands_host=None, publish=True):
         """scans: K device tensors [n,4] f32; rands: K device tensors of RANSAC draws ([1500,4] f64).
         Frame i is matched against frame i-1 (pose in ``result[i]``); frame 0 against ``prev``
         (FrameFeatures) when given; ``pairs=False`` extracts only (BASELINE configs[1]).  Returns a FrameBatch; the
@@ -250,7 +250,8 @@ class Pipeline:
         the reference's inlier sets, R_star / T_star and refits bit for bit (frames without a pair: status 3) and
         ``out.result`` / ``out.inlier_mask`` on the device are overwritten with them.  ``rands_host``: host copies of the draws
         (only read for a pair that escalates beyond 0.4 m; fetched from the device otherwise).  ``certify="device"``: certificates
-        only (``Engine.certify_batch`` runs the host half later).  ``on_encoded(lo, hi)`` is called, in order, once the rows of frames [lo, hi) are
+        only (``Engine.certify_batch`` runs the host half later).  ``publish=False``: the exact results stay in ``out.exact`` (host
+        arrays, where the reference's own results live) and ``out.result`` / ``out.inlier_mask`` keep the kernels' figures.  ``on_encoded(lo, hi)`` is called, in order, once the rows of frames [lo, hi) are
         WRITTEN (the calling thread has waited for them: caelo_pipeline_sync_encoded, one batch behind the issue) -- what it
         enqueues on any stream may read them at once; a caller ships finished rows that way while later batches run.
         ``on_batch(lo, hi)`` is called right after frames [lo, hi) have been issued (with ``wait_encoded`` the device-side form of
@@ -301,7 +302,10 @@ class Pipeline:
             for lo, hi in issued:
                 on_encoded(lo, hi)
         _t2 = _t.perf_counter()
-        self._publish_exact(out, k, certify, pairs)
+        if publish:
+            self._publish_exact(out, k, certify, pairs)
+        elif certify and certify != "device" and pairs and k > 0 and (out.exact[3][:k] == 2).any():
+            raise _ffi.CaeloError("a pair holds more than 1024 matches: no certificate")
         self.last_times = {"jobs_ms": 1e3 * (_t1 - _t0), "submit_flush_ms": 1e3 * (_t2 - _t1), "publish_ms": 1e3 * (_t.perf_counter() - _t2)}
         return out
 
