@@ -130,8 +130,10 @@ __global__ void __launch_bounds__(256) k_kd_build(caelo_kd kd) {
                 int left = 0, right = m - 1;
                 // Lomuto with the last element as the pivot is quadratic on a list that is sorted along the split dimension
                 // (np.unique / argwhere output; lists in first-touch order are not): the library pays that too, a single GPU thread
-                // would run for seconds.  Budget: 48 passes' worth of the node's length, far above the ~3 an unsorted list needs.
-                long long budget = 48ll * m + 4096;
+                // would run for minutes.  Budget: 256 passes' worth of the node's length.  Lists in first-touch order are PARTLY sorted
+                // (a scan line sweeps the azimuth): measured on the clutter scene's lists, the worst node of a tree needs 87 passes' worth
+                // (a first budget of 48 gave up on real frames -- the 600-frame soak caught it by the descriptors of the patches it left).
+                long long budget = 256ll * m + 65536;
                 for (;;) {
                     budget -= right - left + 1;
                     if (budget < 0) { s_gave_up = 1; break; }

@@ -115,6 +115,26 @@ def test_keypoints_ragged_and_too_few(api, orc, f0):
         api.GetKeyPtsByAE(f0["ring"], cnt, f0["resp"])
 
 
+def test_keypoints_with_nan_in_the_response_or_the_intensity(api, orc, f0):
+    """a NaN neighbour makes a pixel's score NaN (np.min over the norms, SphericalRing.py:159) and `score > 0.2`
+    false; a NaN intensity reaches the ring image without raising (only NaN coordinates are refused) and makes the five-channel
+    range test of SphericalRing.py:197-198 false.  Key pixels equal the oracle's in both cases."""
+    kpix0 = f0["g"]["keypixels_demo"].astype(np.int64)
+    resp = f0["resp"].copy()
+    for (r, c) in kpix0[::97][:8]:               # NaNs next to and on top of key pixels of the clean frame
+        resp[r, c + 1, 3] = np.nan
+        resp[r - 2, c, 0] = np.nan
+    o = orc.GetKeyPtsByAE(f0["ring"], f0["cnt"], resp)
+    kp, kpix, _ = api.GetKeyPtsByAE(f0["ring"], f0["cnt"], resp)
+    assert np.array_equal(kpix, o[1].astype(np.int64)) and not np.array_equal(kpix, kpix0)
+    ring = f0["ring"].copy()
+    for (r, c) in kpix0[5::101][:8]:
+        ring[r, c, 3] = np.nan                    # intensity
+    o = orc.GetKeyPtsByAE(ring, f0["cnt"], f0["resp"])
+    kp, kpix, _ = api.GetKeyPtsByAE(ring, f0["cnt"], f0["resp"])
+    assert np.array_equal(kpix, o[1].astype(np.int64)) and not np.array_equal(kpix, kpix0)
+
+
 def test_keypoints_with_thousands_of_equal_scores(api, orc, f0):
     """A response image quantised so coarsely that thousands of candidates share one score: more than 2048 keys from the cut
     bin upwards, which the multi-workgroup selection (k_kp_hist / _gather / _emit) hands to the single-workgroup kernel and its
