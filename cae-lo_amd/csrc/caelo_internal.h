@@ -136,7 +136,9 @@ inline SuspectTables suspect_tables(const caelo_voxmap *m) {
 // kernels that leave most of the 256 CUs idle.  Every such kernel therefore takes a caelo_frame_set -- up to
 // CAELO_FB_MAX frames, blockIdx.z = frame -- so that a batch of frames costs the launches (and the tails, and the
 // single-workgroup stretches) of one.  The single-frame C-ABI entry points pass a set of one.
+#ifndef CAELO_FB_MAX
 #define CAELO_FB_MAX 8
+#endif
 struct DedupScratch;
 struct caelo_frame_dev {
     const float *pc;              // [n][pc_stride] f32
@@ -266,7 +268,7 @@ int dedup_launch(uint64_t *frame_bits, void *scratch, bool enabled, hipStream_t 
 
 // patches of up to CAELO_ENC_MAX_FRAMES frames encoded by one launch set (the fixed costs of the four encoder
 // kernels are ~47 us per launch set): frame f = patch / per_frame gets its descriptors in base[f]
-#define CAELO_ENC_MAX_FRAMES 8
+#define CAELO_ENC_MAX_FRAMES CAELO_FB_MAX
 struct caelo_enc_out {
     float *base[CAELO_ENC_MAX_FRAMES];
     int64_t per_frame;
