@@ -34,6 +34,8 @@ struct caelo_kd_scale {
     int16_t *vox;             // [cap][3] the list in the caller's (= the reference's) order
     int32_t *idx;             // [cap]
     unsigned long long *keys; // [cap] quickselect scratch: (coordinate + 32768) << 32 | index
+    unsigned long long *keys2;// [cap] the partition's output before it is copied back
+    int32_t *ev;              // [cap] the partition's event list (see k_kd_build)
     int32_t *start, *end;     // [KD_MAX_NODES]
     int16_t *lo, *hi;         // [KD_MAX_NODES][3]
     int32_t *queue;           // [k_cap] key points whose patch of this scale is tie-split
@@ -62,12 +64,14 @@ __global__ void __launch_bounds__(256) k_kd_collect(const uint8_t *__restrict__ 
 }
 
 // One workgroup per scale.  Level by level; `tpn` threads share a node of the upper levels for the parallel parts (bounding box,
-// key array), the node's first thread runs the quickselect.
+// key array) and for the quickselect's partitions.
 __global__ void __launch_bounds__(256) k_kd_build(caelo_kd kd) {
     const caelo_kd_scale T = kd.s[blockIdx.x];
     if (kd.state[blockIdx.x] == 0 || kd.state[4 + blockIdx.x] != 0) return;   // no tie-split patch of this scale / tree already built
     __shared__ int s_lo[256][3], s_hi[256][3];
     __shared__ int s_gave_up;   // a node's quickselect exceeded its budget (below): the tree is not built, the canonical rule stays
+    __shared__ int q_left[256], q_right[256], q_act[256], q_lf[256], s_cl[256], s_cg[256];   // per node of a pass / per thread
+    __shared__ long long q_budget[256];
     const int tid = threadIdx.x;
     if (tid == 0) s_gave_up = 0;
     const int64_t n = T.n;
@@ -122,47 +126,114 @@ __global__ void __launch_bounds__(256) k_kd_build(caelo_kd kd) {
                     T.keys[i] = ((unsigned long long)(unsigned)((int)T.vox[3 * (int64_t)p + jmax] + 32768) << 32) | (unsigned)p;
                 }
             __syncthreads();
-            // ---- quickselect around position n / 2: Lomuto, last element as the pivot, strict <  (one thread: the order it leaves
-            // behind is what the library's tree has)
-            if (split && sub == 0) {
-                unsigned long long *a = T.keys + s;
-                const int m = e - s, nmid = m / 2;
-                int left = 0, right = m - 1;
-                // Lomuto with the last element as the pivot is quadratic on a list that is sorted along the split dimension
-                // (np.unique / argwhere output; lists in first-touch order are not): the library pays that too, a single GPU thread
-                // would run for minutes.  Budget: 256 passes' worth of the node's length.  Lists in first-touch order are PARTLY sorted
-                // (a scan line sweeps the azimuth): measured on the clutter scene's lists, the worst node of a tree needs 87 passes' worth
-                // (a first budget of 48 gave up on real frames -- the 600-frame soak caught it by the descriptors of the patches it left).
-                long long budget = 256ll * m + 65536;
-                for (;;) {
-                    budget -= right - left + 1;
-                    if (budget < 0) { s_gave_up = 1; break; }
-                    int mid = left;
-                    const unsigned long long pv = a[right];
-                    const unsigned pvv = (unsigned)(pv >> 32);
-                    int i = left;
-                    for (; i + 8 <= right; i += 8) {          // positions > i are never written before they are read: fetch ahead
-                        unsigned long long v[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) v[u] = a[i + u];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if ((unsigned)(v[u] >> 32) < pvv) {
-                                if (mid != i + u) { a[i + u] = a[mid]; a[mid] = v[u]; }
-                                ++mid;
-                            }
-                    }
-                    for (; i < right; ++i) {
+            // ---- quickselect around position n / 2: Lomuto, last element as the pivot, strict <.  The ORDER the partition leaves behind
+            // is the contract (the library's tree has it), and Lomuto's swaps have a closed form: the elements below the pivot end up in
+            // front in their original order; the others form a QUEUE between `mid` and the scan position -- an element >= pivot is
+            // appended to it, an element < pivot rotates it (the front element goes to the back) when it is not empty -- and the final
+            // swap with the pivot is one more rotation.  Number the enqueue events in time order (a push of element i, or the re-enqueue
+            // of whatever rotation r dequeued = the element of enqueue event r): with G pushes and R + 1 rotations the queue at the end
+            // holds the events R + 1 .. G + R, in that order, and an event that is a re-enqueue is resolved by following its reference
+            // (strictly decreasing) to a push.  Every event index is a prefix sum, so the node's `tpn` threads partition it together:
+            // count (chunk per thread), scan, write the stable front and the event list, resolve, copy back.  (Rounds 4's one thread per
+            // node took 9 ms for a 9 k-voxel list -- 85 % of what re-doing a frame's tie-split patches cost; validated against the serial
+            // form on random cases in Python and by the patches of the truncation fixtures.)
+            unsigned long long *a = T.keys + s, *kb = T.keys2 + s;
+            int32_t *ev = T.ev + s;
+            const int m = e - s, nmid = m / 2;
+            if (sub == 0) {
+                q_left[local] = 0; q_right[local] = m - 1; q_act[local] = split ? 1 : 0;
+                // Lomuto with the last element as the pivot is quadratic on a list sorted along the split dimension (the library pays
+                // that too).  Lists in first-touch order are PARTLY sorted (a scan line sweeps the azimuth): measured on the clutter
+                // scene's lists the worst node needs 87 passes' worth of its length (a first budget of 48 gave up on real frames -- the
+                // 600-frame soak caught it by the descriptors of the patches it left on the canonical rule).  256 passes' worth.
+                q_budget[local] = 256ll * m + 65536;
+            }
+            for (;;) {
+                __syncthreads();   // (the reduction below is a barrier, not a fence: the q_* words written at the end of the previous pass must have landed)
+                if (!__syncthreads_or(sub == 0 && q_act[local] != 0)) break;
+                const bool act = q_act[local] != 0;
+                const int left = act ? q_left[local] : 0, right = act ? q_right[local] : -1;
+                const int len = right - left;                            // elements in front of the pivot
+                const int chunk = len > 0 ? (len + tpn - 1) / tpn : 0;
+                const int i0 = left + sub * chunk, i1 = min(i0 + chunk, right);
+                const unsigned pvv = act ? (unsigned)(a[right] >> 32) : 0u;
+                int cl = 0, fg = -1;
+                for (int i = i0; i < i1; ++i) {
+                    const bool less = (unsigned)(a[i] >> 32) < pvv;
+                    cl += less ? 1 : 0;
+                    if (!less && fg < 0) fg = i;
+                }
+                const int cg = (i1 > i0 ? i1 - i0 : 0) - cl;
+                s_cl[tid] = cl; s_cg[tid] = cg;
+                __syncthreads();
+                for (int o = 1; o < tpn; o <<= 1) {                      // inclusive scans over the node's threads (tpn is the same for all)
+                    int x = 0, y = 0;
+                    if (sub >= o) { x = s_cl[tid - o]; y = s_cg[tid - o]; }
+                    __syncthreads();
+                    s_cl[tid] += x; s_cg[tid] += y;
+                    __syncthreads();
+                }
+                const int lead2 = tid - sub;
+                const int lb = s_cl[tid] - cl, gb = s_cg[tid] - cg;      // below / not below the pivot in front of this thread's chunk
+                const int L = s_cl[lead2 + tpn - 1], G = s_cg[lead2 + tpn - 1];
+                if (act && fg >= 0 && gb == 0) q_lf[local] = lb + (fg - i0);   // elements below the pivot in front of the FIRST one that is not
+                __syncthreads();
+                const int Lf = G > 0 ? q_lf[local] : L, R = L - Lf;
+                {
+                    int pq = gb, l = lb;
+                    for (int i = i0; i < i1; ++i) {
                         const unsigned long long v = a[i];
                         if ((unsigned)(v >> 32) < pvv) {
-                            if (mid != i) { a[i] = a[mid]; a[mid] = v; }
-                            ++mid;
+                            kb[left + l] = v;
+                            if (pq > 0) ev[left + pq + (l - Lf)] = -((l - Lf) + 1);   // rotation l - Lf: re-enqueue of the element of event l - Lf
+                            ++l;
+                        } else {
+                            ev[left + pq + (l - Lf)] = i;                            // push of element i
+                            ++pq;
                         }
                     }
-                    { const unsigned long long t = a[mid]; a[mid] = a[right]; a[right] = t; }
-                    if (mid == nmid) break;
-                    if (mid < nmid) left = mid + 1; else right = mid - 1;
                 }
+                if (act && sub == 0) {
+                    kb[left + L] = a[right];
+                    if (G > 0) ev[left + G + R] = -(R + 1);                          // the final swap with the pivot
+                }
+                __syncthreads();
+                for (int k = sub; act && k < G; k += tpn) {
+                    int ee = R + 1 + k, x, steps = 0;
+                    while ((x = ev[left + ee]) < 0) {
+                        ee = -x - 1;
+                        if (++steps > (1 << 22)) { s_gave_up = 1; x = left; break; }
+                    }
+                    kb[left + L + 1 + k] = a[x];
+                }
+                __syncthreads();
+                for (int i = left + sub; act && i <= right; i += tpn) a[i] = kb[i];
+                __syncthreads();
+#ifdef KD_DEBUG
+                if (act && sub == 0) {
+                    int bad = 0;
+                    for (int i = left; i <= right; ++i) {
+                        const unsigned long long v = a[i];
+                        const unsigned kv = (unsigned)(v >> 32), id = (unsigned)v;
+                        if (id >= (unsigned)n) bad |= 1;
+                        if (i < left + L && !(kv < pvv)) bad |= 2;
+                        if (i > left + L && (kv < pvv)) bad |= 4;
+                        if (i == left + L && kv != pvv) bad |= 8;
+                    }
+                    if (bad) printf("kd build: level %d node %d tpn %d left %d right %d L %d G %d R %d Lf %d bad %d\n", level, node, tpn, left, right, L, G, R, Lf, bad);
+                }
+                __syncthreads();
+#endif
+                if (act && sub == 0) {
+                    const int mid = left + L;
+                    q_budget[local] -= (long long)len + 1;
+                    if (mid == nmid) q_act[local] = 0;
+                    else if (q_budget[local] < 0) { s_gave_up = 1; q_act[local] = 0; }
+                    else if (mid < nmid) q_left[local] = mid + 1;
+                    else q_right[local] = mid - 1;
+                }
+            }
+            if (split && sub == 0) {
                 T.start[2 * node + 1] = s; T.end[2 * node + 1] = s + nmid;
                 T.start[2 * node + 2] = s + nmid; T.end[2 * node + 2] = e;
             }
@@ -174,11 +245,6 @@ __global__ void __launch_bounds__(256) k_kd_build(caelo_kd kd) {
     }
     if (tid == 0) kd.state[4 + blockIdx.x] = s_gave_up ? 2 : 1;   // 2: not built (the queries leave flag 2 and the canonical rule in place)
 }
-
-// (A swap `a[i] <-> a[mid]` inside an 8-element chunk can touch a position of the SAME chunk that was fetched before it was
-// written: mid >= i of the chunk start is possible only when every element before it was "less", in which case mid == position
-// and the swap is the identity or moves an element that was already consumed -- positions mid < i + u have all been processed,
-// so the prefetched copy of a[i + u] is never stale.)
 
 struct KdHeapLds {
     int dist[KD_K];
@@ -302,7 +368,7 @@ int kd_store_lists(caelo_voxmap *m, const int16_t *const lists[3], const int64_t
         caelo_kd *kd = new caelo_kd();
         kd->cap = m->max_points;
         kd->k_cap = CAELO_MAX_KEYPTS;
-        const size_t per = (size_t)kd->cap * (6 + 4 + 8) + 256 * 3;
+        const size_t per = (size_t)kd->cap * (6 + 4 + 8 + 8 + 4) + 256 * 5;
         const size_t nodes = (size_t)KD_MAX_NODES * (4 + 4 + 6 + 6) + 256 * 4;
         const size_t total = 3 * (per + nodes + (size_t)kd->k_cap * 4 + 256) + 256;
         if (hipMalloc((void **)&kd->base, total) != hipSuccess) {
@@ -316,6 +382,8 @@ int kd_store_lists(caelo_voxmap *m, const int16_t *const lists[3], const int64_t
         for (int i = 0; i < 3; ++i) {
             caelo_kd_scale &T = kd->s[i];
             T.keys = (unsigned long long *)take((size_t)kd->cap * 8);
+            T.keys2 = (unsigned long long *)take((size_t)kd->cap * 8);
+            T.ev = (int32_t *)take((size_t)kd->cap * 4);
             T.idx = (int32_t *)take((size_t)kd->cap * 4);
             T.vox = (int16_t *)take((size_t)kd->cap * 6);
             T.start = (int32_t *)take((size_t)KD_MAX_NODES * 4);

@@ -487,9 +487,10 @@ __global__ void __launch_bounds__(256) k_kp_score(const caelo_frame_set fs, int 
                                           __fadd_rn(__fadd_rn(s4, s5), __fadd_rn(s6, s7)));
                 // the square root is monotone (correctly rounded): min over sqrt(t) = sqrt(min t), taken once below
                 const bool o = (win >> (5 * (oy + 2) + ox + 2)) & 1u;
-                // (NaN propagates like np.min over the norms, SphericalRing.py:159: a NaN neighbour -- a NaN intensity reaches the ring
-                // image, NaN coordinates are refused earlier -- makes the score NaN and `score > 0.2` false)
-                best = (o && (t < best || t != t)) ? t : best;   // (once NaN, `t < NaN` keeps it)
+                // (NaN propagates like cp.min over the 25 norms of SphericalRing.py:159,179: a NaN in the response of ANY window pixel,
+                // occupied or not -- the reference adds 1e10 to the unoccupied ones, which leaves a NaN a NaN -- makes the score NaN
+                // and `score > 0.2` false.  Once NaN, `t < NaN` keeps it.)
+                best = ((o && t < best) || t != t) ? t : best;
             }
         }
         best = cnt > 0 ? sqrtf(best) : 0.0f;

@@ -161,7 +161,7 @@ ORC_EXPORT int orc_keypoints(const float *ring, int ring_w, int ring_c, const in
                 for (int ox = -2; ox <= 2; ++ox) {
                     if (oy == 0 && ox == 0) continue; /* :170 */
                     const int yy = y + oy, xx = x + ox;
-                    if (!(counter[yy * cnt_w + xx] > 0)) continue; /* :156-158,:173 */
+                    const int occ = counter[yy * cnt_w + xx] > 0; /* :156-158,:173: an unoccupied neighbour gets + 1e10 ... */
                     const float *rq = resp + ((int64_t)yy * NET_W + xx) * 8;
                     float s[8];
                     for (int c = 0; c < 8; ++c) {
@@ -171,7 +171,11 @@ ORC_EXPORT int orc_keypoints(const float *ring, int ring_w, int ring_c, const in
                     /* :159 LA.norm axis=-1, f32: NumPy pairwise block for n == 8 */
                     const float t = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
                     const float nd = sqrtf(t);
-                    if (!have || nd < best) { best = nd; have = 1; } /* :179 min */
+                    /* :179 cp.min over ALL 25 window entries: ... but a NaN norm stays NaN under + 1e10 and makes the minimum NaN whether
+                     * the neighbour is occupied or not (so does a NaN in the pixel's own response: every difference is NaN) */
+                    if (nd != nd) { best = nd; have = 1; }
+                    if (!occ) continue;
+                    if (!have || nd < best) { best = nd; have = 1; }
                     ++cnt;                                           /* :182 */
                 }
             }
