@@ -107,7 +107,7 @@ struct caelo_pipeline {
     std::deque<std::pair<int, int>> cert_queue;   // (slot, record) handed to the certifier threads
     std::mutex cert_mu;
     std::condition_variable cert_cv;
-    static constexpr int CERT_THREADS = 3;
+    static constexpr int CERT_THREADS = 3, CERT_THREADS_DEFAULT = 3;
     std::thread cert_thread[CERT_THREADS];
     bool cert_stop = false, cert_started = false;
     int cert_failed = 0;                     // a record could not be certified (no BLAS bound, LAPACK failure): reported by the flush
@@ -202,7 +202,12 @@ int cert_task(caelo_pipeline *p, caelo_pipeline::CertTask **out, int *slot_out) 
             CAELO_HIP(hipEventCreateWithFlags(&t.pair_done, hipEventDisableTiming));
             CAELO_HIP(hipEventCreateWithFlags(&t.copied, hipEventDisableTiming));
         }
-        for (std::thread &th : p->cert_thread) th = std::thread(cert_worker, p);
+        {   // CAELO_CERT_THREADS (1 .. 3): certifier threads of every pipeline of the process (a scheduling knob, no arithmetic)
+            const char *e = getenv("CAELO_CERT_THREADS");
+            int nt = e ? atoi(e) : caelo_pipeline::CERT_THREADS_DEFAULT;
+            nt = nt < 1 ? 1 : (nt > caelo_pipeline::CERT_THREADS ? caelo_pipeline::CERT_THREADS : nt);
+            for (int i = 0; i < nt; ++i) p->cert_thread[i] = std::thread(cert_worker, p);
+        }
         p->cert_started = true;
     }
     const int slot = (int)(p->cert_seq % caelo_pipeline::CERT_RING);
