@@ -750,7 +750,8 @@ def secondary_legs(args, eng, pipe, dev, pool, rand, rand_host, Runner, frame_pa
     fps2, frames_redone, patches_redone, pairs_redone = leg_exact_ties(r2)
     ob = r2.run(2 * B)
     torch.cuda.synchronize()
-    ok2 = sum(int(eng.pose_result(ob.result[i]).success) for i in range(2 * B))
+    ok2 = (int((ob.exact[0]["success"][:2 * B] != 0).sum()) if ob.exact is not None else
+           sum(int(eng.pose_result(ob.result[i]).success) for i in range(2 * B)))
     bits2 = [frame_patches(p) for p in pool2[:min(POOL, B)]]
     t2, ms2, _, share2, _ = encoder_table(torch.cat([bits2[i % len(bits2)].reshape(-1, 64) for i in range(B)], dim=0).contiguous())
     sec["scene_" + other] = {"frames_per_s": fps2, "poses_solved": "%d/%d" % (ok2, 2 * B),

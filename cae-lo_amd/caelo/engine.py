@@ -251,7 +251,8 @@ class Pipeline:
         ``out.result`` / ``out.inlier_mask`` on the device are overwritten with them.  ``rands_host``: host copies of the draws
         (only read for a pair that escalates beyond 0.4 m; fetched from the device otherwise).  ``certify="device"``: certificates
         only (``Engine.certify_batch`` runs the host half later).  ``publish=False``: the exact results stay in ``out.exact`` (host
-        arrays, where the reference's own results live) and ``out.result`` / ``out.inlier_mask`` keep the kernels' figures.  ``on_encoded(lo, hi)`` is called, in order, once the rows of frames [lo, hi) are
+        arrays, where the reference's own results live) and ``out.result`` / ``out.inlier_mask`` on the device are NOT written at all
+        (with the host half active the kernels stop at the certificate: no k_ransac_finish).  ``on_encoded(lo, hi)`` is called, in order, once the rows of frames [lo, hi) are
         WRITTEN (the calling thread has waited for them: caelo_pipeline_sync_encoded, one batch behind the issue) -- what it
         enqueues on any stream may read them at once; a caller ships finished rows that way while later batches run.
         ``on_batch(lo, hi)`` is called right after frames [lo, hi) have been issued (with ``wait_encoded`` the device-side form of

@@ -183,6 +183,7 @@ struct caelo_pair_dev {
     caelo_pose_result *result;
     uint8_t *mask;
     caelo_ransac_cert *cert;     // nullable: the certificate for the host half (certify.hip)
+    int32_t cert_only;           // the host half produces this pair's result (result / mask are not written by the kernels)
 };
 struct caelo_pair_set {
     caelo_pair_dev p[CAELO_FB_MAX];

@@ -909,6 +909,20 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp(const caelo_pair_s
         }
     }
     __syncthreads();
+    if (cert && P.cert_only && blockIdx.x == 0) {
+        // the host half takes the pair from here (caelo_pipeline with result_host): the certificate's pairs and header leave with
+        // this launch and k_ransac_finish is not launched at all -- what it computes (the kernels' own winner, mask and refit) is
+        // exactly what the host half replaces
+        if (in_lds) {
+            float *d0 = &cert->p0[0][0], *d1 = &cert->p1[0][0];
+            for (int i = tid; i < 3 * N; i += 64 * RE_WAVES) { d0[i] = sP0[i]; d1[i] = sP1[i]; }
+        }
+        if (tid == 0) {
+            cert->n_pairs = N;
+            cert->flags = in_lds ? 0 : CAELO_CERT_NO_BOUNDS;
+            cert->magic = CAELO_CERT_MAGIC;
+        }
+    }
     const int trial0 = (blockIdx.x * RE_WAVES + wave) * RH_PER_WAVE;  // wave-uniform
     if (trial0 >= CAELO_RANSAC_MAX_TRIALS) return;
     if (!in_lds) {  // more pairs than the LDS stage holds: one hypothesis at a time from global memory
@@ -925,6 +939,7 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp(const caelo_pair_s
 #define RF_WAVES 8   // the accept rules, the mask and the refit use four of them; all eight evaluate a next level's hypotheses
 __global__ void __launch_bounds__(64 * RF_WAVES, 4) k_ransac_finish(const caelo_pair_set ps, int ld0, int ld1, int64_t k1_max) {
     const caelo_pair_dev &P = ps.p[blockIdx.z];
+    if (P.cert && P.cert_only) return;   // (a mixed set: this pair's result comes from the host half)
     const float *__restrict__ pc0 = P.pc0, *__restrict__ pc1 = P.pc1;
     const int64_t *__restrict__ pair_idx = P.pair_idx;
     const double *__restrict__ rnd = P.rand;
@@ -1102,6 +1117,9 @@ int ransac_set(const caelo_pair_set &ps, int ld0, int ld1, int64_t k1_max, hipSt
     CAELO_REQUIRE(k1_max > 0 && ld0 >= 3 && ld1 >= 3, "bad shape");
     k_ransac_hyp<<<dim3((CAELO_RANSAC_MAX_TRIALS + RE_WAVES * RH_PER_WAVE - 1) / (RE_WAVES * RH_PER_WAVE), 1, ps.n), 64 * RE_WAVES, 0, s>>>(ps, ld0, ld1, k1_max);
     CAELO_LAUNCH_CHECK();
+    bool all_cert_only = true;
+    for (int i = 0; i < ps.n; ++i) all_cert_only = all_cert_only && ps.p[i].cert && ps.p[i].cert_only;
+    if (all_cert_only) return CAELO_OK;   // the host half decides every pair of the set: no finishing kernel
     k_ransac_finish<<<dim3(1, 1, ps.n), 64 * RF_WAVES, 0, s>>>(ps, ld0, ld1, k1_max);
     CAELO_LAUNCH_CHECK();
     return CAELO_OK;

@@ -107,7 +107,7 @@ struct caelo_pipeline {
     std::deque<std::pair<int, int>> cert_queue;   // (slot, record) handed to the certifier threads
     std::mutex cert_mu;
     std::condition_variable cert_cv;
-    static constexpr int CERT_THREADS = 3, CERT_THREADS_DEFAULT = 3;
+    static constexpr int CERT_THREADS = 8, CERT_THREADS_DEFAULT = 3;
     std::thread cert_thread[CERT_THREADS];
     bool cert_stop = false, cert_started = false;
     int cert_failed = 0;                     // a record could not be certified (no BLAS bound, LAPACK failure): reported by the flush
@@ -229,7 +229,10 @@ int cert_task(caelo_pipeline *p, caelo_pipeline::CertTask **out, int *slot_out) 
 
 int cert_wait_idle(caelo_pipeline *p) {
     if (!p->cert_started) return CAELO_OK;
+    static const bool verbose = getenv("CAELO_PIPE_VERBOSE") != nullptr;
+    const int64_t tv0 = now_ns();
     const int rc = cert_drain(p, 0);
+    const int64_t tv1 = now_ns();
     {   // the last batches of a run: this thread has nothing else to do and takes its share of the queue
         std::vector<double> draws;
         for (;;) {
@@ -242,12 +245,15 @@ int cert_wait_idle(caelo_pipeline *p) {
             cert_process(p, w.first, w.second, draws);
         }
     }
+    const int64_t tv2 = now_ns();
     std::unique_lock<std::mutex> lk(p->cert_mu);
     p->cert_cv.wait(lk, [&] {
         for (const caelo_pipeline::CertTask &t : p->cert_ring)
             if (t.state != 0) return false;
         return true;
     });
+    if (verbose) fprintf(stderr, "cert_wait_idle: drain (pair stages + copies queued) %.1f us, own share %.1f us, wait for the others %.1f us\n",
+                         (tv1 - tv0) / 1e3, (tv2 - tv1) / 1e3, (now_ns() - tv2) / 1e3);
     if (rc) return rc;
     if (p->cert_failed) {
         p->cert_failed = 0;
@@ -325,6 +331,7 @@ int issue_batch_impl(caelo_pipeline *p) {
         d.pc0 = prev_rows + 60; d.pc1 = j.rows + 60;
         d.pair_idx = j.pair_idx; d.ws_match = p->ws_match[ps.n]; d.ws_ransac = p->ws_ransac[ps.n];
         d.rand = j.rand; d.result = j.result; d.mask = j.inlier_mask; d.cert = j.cert;
+        d.cert_only = j.result_host ? 1 : 0;   // the certifier threads produce this pair's result: no k_ransac_finish for it
         ++ps.n;
         if (j.result_host) {   // the host half for this pair (certifier thread)
             if (!ctask && (rc = cert_task(p, &ctask, &cslot))) return rc;

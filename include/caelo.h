@@ -381,7 +381,9 @@ typedef struct caelo_frame_job {
     /* The host half inside the pipeline (needs cert and caelo_host_bind_blas): when result_host is given, a certifier thread of
      * the pipeline copies the pair's certificate to the host once its pair stage is through (paced by the issuing thread, no
      * device-side wait), runs the host half while later batches are on the GPU and writes the EXACT result -- the reference's
-     * inlier set, R_star / T_star, refit, bit for bit -- to these HOST buffers; caelo_pipeline_flush returns when all are written. */
+     * inlier set, R_star / T_star, refit, bit for bit -- to these HOST buffers; caelo_pipeline_flush returns when all are written.
+     * The kernels then stop at the certificate: `result` and `inlier_mask` (device) are NOT written for such a pair -- the winner,
+     * mask and refit k_ransac_finish would compute are exactly what the host half replaces. */
     caelo_pose_result *result_host; /* out, nullable */
     uint8_t *mask_host;             /* [1024] out (required with result_host) */
     const double *rand_host;        /* nullable: host copy of `rand` (only read when the pair escalates beyond 0.4 m; fetched from `rand` otherwise) */
