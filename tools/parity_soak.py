@@ -125,7 +125,8 @@ def soak(engine, orc, models, scene, n_frames, seed_base=5000, batch=8, log=None
                columns=0, flips=0, flips_unexplained=0, pairs_with_flip=0, exact_pairs_inlier_mismatch=0, exact_pairs_max_rt=0.0,
                flip_pairs_inlier_diff=[], flip_pairs_max_rt=0.0, success_mismatch=0, threshold_mismatch=0, exceptions=[],
                lane_faults=0, host_hypotheses_per_pair=round(cstat["evals_per_pair"], 2), certifier_us_per_pair=round(cstat["host_us_per_pair"], 1),
-               ransac_kernel_evals_max=0, ransac_kernel_bitexact_pairs=0, pairs_compared=0, success_mismatch_exact_pairs=0, exact_pairs_bitexact_pose=0, exact_pairs=0)
+               ransac_kernel_evals_max=0, ransac_kernel_bitexact_pairs=0, pairs_compared=0, success_mismatch_exact_pairs=0, exact_pairs_bitexact_pose=0, exact_pairs=0,
+               bound_checks=0, bound_violations=0, bound_slack_sum=0, bound_slack_max=0)
     prev = None
     vm = engine.voxmap(max(engine.max_points, max(p.shape[0] for p in scans)), slot=6)
     for i in range(n_frames):
@@ -169,6 +170,13 @@ def soak(engine, orc, models, scene, n_frames, seed_base=5000, batch=8, log=None
             rep["pairs_compared"] += 1
             cert = engine.new_cert(1)
             engine.ransac(p0, p1, torch.from_numpy(o_idx).to(dev), rnd[i], cert=cert[0])
+            # the certificate itself: every hypothesis the oracle's loop evaluated at the first level has a count <= the kernel's bound
+            trace = []
+            orc.RANSAC4RT(prev["kp"][o_idx], o["kp"], rng=np.random.RandomState(seed_base + i), trace=trace)
+            lvl0 = np.array([t[1] for t in trace if t[2] == 0.4], np.int64)
+            hi = cert.cpu().numpy().view(_ffi.CERT_DTYPE).reshape(-1)[0]["hi"][:len(lvl0)].astype(np.int64)
+            rep["bound_checks"] += len(lvl0); rep["bound_violations"] += int((hi < lvl0).sum())
+            rep["bound_slack_sum"] += int((hi - lvl0).sum()); rep["bound_slack_max"] = max(rep["bound_slack_max"], int((hi - lvl0).max()) if len(lvl0) else 0)
             cres, cmask, cev, cst = engine.certify(cert, [draws[i]])
             pr = cres[0]; m_ = cmask[0, :k].astype(bool)
             assert cst[0] == 0
@@ -221,7 +229,7 @@ def clean(rep):
     return (rep["keypixel_mismatch_frames"] == 0 and rep["keypoint_mismatch_frames"] == 0 and sum(rep["voxel_set_mismatch"]) == 0
             and rep["patch_mismatch"] == 0 and rep["desc_over_tol"] == 0 and rep["status_or"] == 0
             and rep["match_kernel_mismatch_cols"] == 0 and rep["ransac_kernel_mismatch_pairs"] == 0
-            and rep["ransac_kernel_bitexact_pairs"] == rep["pairs_compared"]
+            and rep["ransac_kernel_bitexact_pairs"] == rep["pairs_compared"] and rep["bound_violations"] == 0
             and rep["flips_unexplained"] == 0 and rep["exact_pairs_inlier_mismatch"] == 0 and rep["exact_pairs_max_rt"] <= REL_TOL
             and rep["success_mismatch_exact_pairs"] == 0 and rep["lane_faults"] == 0)
 
@@ -240,6 +248,8 @@ def render(rep):
          "%d of %d bit-exact incl. R_star, T_star and the refit (max R/T err %.2g; at most %d hypotheses re-evaluated on the host for a pair)" % (
              rep["match_kernel_mismatch_cols"], rep["ransac_kernel_mismatch_pairs"], rep["pairs_compared"], rep["ransac_kernel_bitexact_pairs"], rep["pairs_compared"],
              rep["ransac_kernel_max_rt"], rep["ransac_kernel_evals_max"]),
+         "    certificates: %d hypothesis counts of the oracle's first-level loops checked against the kernel's upper bounds: %d violations; mean slack %.2f, largest %d" % (
+             rep["bound_checks"], rep["bound_violations"], rep["bound_slack_sum"] / max(1, rep["bound_checks"]), rep["bound_slack_max"]),
          "  pipeline end to end (exact RANSAC inside the pipeline: %.2f hypotheses per pair on the host, %.1f us of the certifier thread per pair): %d of %d argmin columns differ from the oracle's (%d pairs); unexplained by the descriptor error: %d" % (
              rep["host_hypotheses_per_pair"], rep["certifier_us_per_pair"], rep["flips"], rep["columns"], rep["pairs_with_flip"], rep["flips_unexplained"]),
          "    pairs without a flip (%d): inlier sets differing %d, success / threshold differing %d, poses bit-identical to the oracle's %d, max R/T err %.2g" % (
