@@ -203,8 +203,9 @@ class Pipeline:
             if not getattr(self.eng, "_blas_bound", False):
                 self.eng.host_blas()
                 self.eng._blas_bound = True
-            jobs["cert"] = out.ensure_cert(self.eng).data_ptr() + idx * _ffi.CERT_DTYPE.itemsize
-            if certify != "device":
+            if certify == "device" or os.environ.get("CAELO_CERT_ZEROCOPY") == "0":
+                jobs["cert"] = out.ensure_cert(self.eng).data_ptr() + idx * _ffi.CERT_DTYPE.itemsize
+            if certify != "device":   # (the kernels write these pairs' certificates straight into the pipeline's pinned host memory)
                 if out._exact_buf is None:   # host arrays of the exact results: allocated once per FrameBatch
                     out._exact_buf = (np.zeros(out.k, dtype=_ffi.POSE_DTYPE), np.zeros((out.k, MAX_K), dtype=np.uint8),
                                       np.zeros((out.k, 2), dtype=np.int32))

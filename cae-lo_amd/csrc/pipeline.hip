@@ -96,7 +96,8 @@ struct caelo_pipeline {
         CertItem item[CAELO_FB_MAX];
         int n = 0, remaining = 0;
         uint64_t batch_no = 0;
-        caelo_ransac_cert *host = nullptr;   // pinned [batch]
+        caelo_ransac_cert *host = nullptr;   // pinned, coherent [batch]: the certifier reads the records here
+        caelo_ransac_cert *host_dev = nullptr;   // the same memory as the kernels address it (zero-copy mode)
         hipEvent_t pair_done = nullptr, copied = nullptr;
         int state = 0;                       // 0 free, 1 issued (pair stage queued), 2 copy queued / being certified
     };
@@ -110,6 +111,7 @@ struct caelo_pipeline {
     static constexpr int CERT_THREADS = 8, CERT_THREADS_DEFAULT = 3;
     std::thread cert_thread[CERT_THREADS];
     bool cert_stop = false, cert_started = false;
+    bool cert_zero_copy = true;   // the kernels write the records straight into pinned host memory (no copy command, no copy stream)
     int cert_failed = 0;                     // a record could not be certified (no BLAS bound, LAPACK failure): reported by the flush
     int64_t stat_cert_pairs = 0, stat_cert_evals = 0, stat_cert_ns = 0, stat_cert_drain_ns = 0;
 };
@@ -120,7 +122,7 @@ namespace {
 // (certifier threads; at a flush the issuing thread too)
 void cert_process(caelo_pipeline *p, int slot, int i, std::vector<double> &draws) {
     caelo_pipeline::CertTask &t = p->cert_ring[slot];
-    int failed = hipEventSynchronize(t.copied) != hipSuccess;
+    int failed = !p->cert_zero_copy && hipEventSynchronize(t.copied) != hipSuccess;
     const int64_t t0 = now_ns();
     int32_t evals = 0;
     if (!failed) {
@@ -173,13 +175,13 @@ int cert_drain(caelo_pipeline *p, size_t keep) {
         p->cert_issued.pop_front();
         caelo_pipeline::CertTask &t = p->cert_ring[slot];
         CAELO_HIP(hipEventSynchronize(t.pair_done));
-        for (int i = 0; i < t.n;) {   // records that lie back to back on the device leave in one copy
+        for (int i = 0; i < t.n && !p->cert_zero_copy;) {   // records that lie back to back on the device leave in one copy
             int j = i + 1;
             while (j < t.n && t.item[j].dev == t.item[j - 1].dev + 1) ++j;
             CAELO_HIP(hipMemcpyAsync(t.host + i, t.item[i].dev, (size_t)(j - i) * sizeof(caelo_ransac_cert), hipMemcpyDeviceToHost, p->sC));
             i = j;
         }
-        CAELO_HIP(hipEventRecord(t.copied, p->sC));
+        if (!p->cert_zero_copy) CAELO_HIP(hipEventRecord(t.copied, p->sC));
         {
             std::lock_guard<std::mutex> lk(p->cert_mu);
             t.state = 2;
@@ -197,8 +199,13 @@ int cert_task(caelo_pipeline *p, caelo_pipeline::CertTask **out, int *slot_out) 
         CAELO_REQUIRE(certify_record(caelo_ransac_cert(), nullptr, nullptr, nullptr, 0, nullptr) != -1,
                       "result_host given but no BLAS is bound (caelo_host_bind_blas)");
         CAELO_HIP(hipStreamCreateWithFlags(&p->sC, hipStreamNonBlocking));
+        {   // CAELO_CERT_ZEROCOPY=0: certificates in device memory (the job's `cert`), copied to the host by a copy command
+            const char *e = getenv("CAELO_CERT_ZEROCOPY");
+            p->cert_zero_copy = !(e && atoi(e) == 0);
+        }
         for (caelo_pipeline::CertTask &t : p->cert_ring) {
-            CAELO_HIP(hipHostMalloc((void **)&t.host, (size_t)p->batch * sizeof(caelo_ransac_cert), hipHostMallocDefault));
+            CAELO_HIP(hipHostMalloc((void **)&t.host, (size_t)p->batch * sizeof(caelo_ransac_cert), hipHostMallocCoherent | hipHostMallocMapped));
+            CAELO_HIP(hipHostGetDevicePointer((void **)&t.host_dev, t.host, 0));
             CAELO_HIP(hipEventCreateWithFlags(&t.pair_done, hipEventDisableTiming));
             CAELO_HIP(hipEventCreateWithFlags(&t.copied, hipEventDisableTiming));
         }
@@ -335,6 +342,14 @@ int issue_batch_impl(caelo_pipeline *p) {
         ++ps.n;
         if (j.result_host) {   // the host half for this pair (certifier thread)
             if (!ctask && (rc = cert_task(p, &ctask, &cslot))) return rc;
+            if (p->cert_zero_copy) {
+                // the kernels write the record straight into the task's pinned host memory: no copy command, nothing for a copy to
+                // flush.  (A caller that also wants the record on the device -- job.cert -- gets it only in the copy mode.)
+                ps.p[ps.n - 1].cert = ctask->host_dev + ctask->n;
+                ctask->host[ctask->n].magic = 0;
+            } else {
+                CAELO_REQUIRE(j.cert, "result_host needs cert (CAELO_CERT_ZEROCOPY=0)");
+            }
             ctask->item[ctask->n++] = {j.cert, j.result_host, j.mask_host, j.rand_host, j.rand, j.info_host};
         }
     }
@@ -606,7 +621,7 @@ CAELO_API int caelo_pipeline_submit(caelo_pipeline *p, const caelo_frame_job *jo
     if (job->pair != CAELO_PAIR_NONE)
         CAELO_REQUIRE(job->rand && job->result && job->inlier_mask && job->pair_idx, "null pair buffer");
     if (job->pair == CAELO_PAIR_EXPLICIT) CAELO_REQUIRE(job->prev_rows, "explicit pair without prev_rows");
-    if (job->pair != CAELO_PAIR_NONE && job->result_host) CAELO_REQUIRE(job->cert && job->mask_host, "result_host needs cert and mask_host");
+    if (job->pair != CAELO_PAIR_NONE && job->result_host) CAELO_REQUIRE(job->mask_host, "result_host needs mask_host");
     CAELO_REQUIRE((((uintptr_t)job->cert) & 15u) == 0, "certificate not 16-byte aligned");
     if (job->pair == CAELO_PAIR_CHAIN && !p->have_last && p->pending.empty()) {
         caelo_set_error("caelo_pipeline_submit: the first job has no predecessor to chain to");

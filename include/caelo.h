@@ -378,9 +378,10 @@ typedef struct caelo_frame_job {
     uint8_t *inlier_mask;       /* [1024] out */
     int64_t *pair_idx;          /* [1024] out */
     caelo_ransac_cert *cert;    /* out, nullable: the pair's certificate for caelo_host_certify */
-    /* The host half inside the pipeline (needs cert and caelo_host_bind_blas): when result_host is given, a certifier thread of
-     * the pipeline copies the pair's certificate to the host once its pair stage is through (paced by the issuing thread, no
-     * device-side wait), runs the host half while later batches are on the GPU and writes the EXACT result -- the reference's
+    /* The host half inside the pipeline (needs caelo_host_bind_blas): when result_host is given, the kernels write the pair's
+     * certificate straight into pinned host memory of the pipeline (`cert` is not used; CAELO_CERT_ZEROCOPY=0: into `cert`, copied by
+     * a copy command), the issuing thread finds the pair stage finished two batches later (no device-side wait), certifier threads
+     * run the host half while later batches are on the GPU and write the EXACT result -- the reference's
      * inlier set, R_star / T_star, refit, bit for bit -- to these HOST buffers; caelo_pipeline_flush returns when all are written.
      * The kernels then stop at the certificate: `result` and `inlier_mask` (device) are NOT written for such a pair -- the winner,
      * mask and refit k_ransac_finish would compute are exactly what the host half replaces. */

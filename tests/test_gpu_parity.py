@@ -1324,7 +1324,7 @@ def test_library_reads_no_arithmetic_switch_from_the_environment():
             seen |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(os.path.join(src, fn)).read()))
     allowed = {"CAELO_D1_WIDE_FROM", "CAELO_S1X_SLOTS", "CAELO_ENC_YIELD", "CAELO_DEDUP_HASH_BITS", "CAELO_NO_DEDUP",
                "CAELO_PIPE_SYSTEM_FENCES", "CAELO_PIPE_VERBOSE", "CAELO_PIPE_PACE", "CAELO_PIPE_STREAMS", "CAELO_PIPE_ENC_PRIO",
-               "CAELO_PIPE_VOX_STREAM", "CAELO_PIPE_PLAN", "CAELO_CERT_THREADS", "GPU_MAX_HW_QUEUES"}
+               "CAELO_PIPE_VOX_STREAM", "CAELO_PIPE_PLAN", "CAELO_CERT_THREADS", "CAELO_CERT_ZEROCOPY", "GPU_MAX_HW_QUEUES"}
     assert seen <= allowed, sorted(seen - allowed)
     # the scripts under tools/ may only set knobs that still exist (a removed switch would silently measure the default
     # kernel under another label); CAELO_LIB / CAELO_ENC_S1 / CAELO_DIST_BACKEND are read by Python, not by the library
