@@ -1692,6 +1692,27 @@ def test_pipeline_certified_poses_equal_the_oracle_on_the_pipelines_own_matches(
         assert np.array_equal(res[i]["R"].reshape(3, 3), Rf) and np.array_equal(res[i]["T"].reshape(3, 1), Tf), i
         assert dev_res[i].tobytes() == res[i].tobytes() and np.array_equal(dev_mask[i], masks[i])
         assert 1 <= evals[i] <= 12
+    # a pair that ESCALATES (a scan of ANOTHER scene in between: nothing matches, Match.py:207-214 doubles the threshold and finally gives up):
+    # no certificate exists beyond 0.4 m, the host half runs those levels like the reference's loop -- with the draws handed over
+    # (rands_host) and with the draws fetched from the device by the certifier thread
+    far = [dpcs[0], torch.from_numpy(scans(5, quantum=1e-3, scene_kind="clutter")).to(engine.device), dpcs[1]]   # another world
+    fd = [ransac_draws(77 + i) for i in range(3)]
+    frd = [torch.from_numpy(d).to(engine.device) for d in fd]
+    outs = [pipe.run(far, frd, certify=True, rands_host=fd), pipe.run(far, frd, certify=True)]
+    frows = outs[0].rows.cpu().numpy(); fpidx = outs[0].pair_idx.cpu().numpy(); fnk = outs[0].n_key.cpu().numpy()
+    escalated = 0
+    for i in (1, 2):
+        N = int(fnk[i])
+        P0 = np.ascontiguousarray(frows[i - 1][fpidx[i][:N], 60:63]); P1 = np.ascontiguousarray(frows[i][:N, 60:63])
+        R, T, ok, m, thr = orc.RANSAC4RT(P0, P1, rng=np.random.RandomState(77 + i))
+        escalated += thr > 0.4
+        for o_ in outs:
+            r_ = o_.exact[0][i]
+            assert o_.exact[3][i] == 0 and bool(r_["success"]) == ok and abs(float(r_["threshold"]) - thr) < 1e-6, (i, thr)
+            assert np.array_equal(o_.exact[1][i, :N].astype(bool), m)
+            if ok:
+                assert np.array_equal(r_["R_ransac"].reshape(3, 3), R) and np.array_equal(r_["T_ransac"].reshape(3, 1), T)
+    assert escalated >= 1
     # the kernels' own poses (no host half) are within tolerance of the exact ones wherever the inlier sets agree
     kr = kernels_result.cpu().numpy().view(_ffi.POSE_DTYPE).reshape(-1)
     close = [np.abs(kr[i]["R"] - res[i]["R"]).max() <= REL_TOL for i in range(1, n) if kr[i]["n_inliers"] == res[i]["n_inliers"]]
