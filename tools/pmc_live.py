@@ -42,7 +42,7 @@ def _averages(db_path):
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
 
 
-def collect(repeats=6, frames=8, timeout=240, keep_dir=None):
+def collect(repeats=6, frames=8, timeout=90, keep_dir=None):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None
