@@ -739,20 +739,22 @@ def secondary_legs(args, eng, pipe, dev, pool, rand, rand_host, Runner, frame_pa
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ob_ = runner.run(n)
-        tied = torch.nonzero((ob_.flags[:n] & 2).reshape(n, -1).any(dim=1)).reshape(-1).tolist()
-        patches = 0
-        for j in tied:
-            patches += eng.resolve_ties(ob_.frame(j), runner.pool[runner.last_order[j]])
+        tied, patches = eng.resolve_ties_many([(ob_.frame(j), runner.pool[runner.last_order[j]]) for j in range(n)])
+        patches = sum(patches)
         redo = sorted({t for u in tied for t in (u, u + 1) if 0 < t < n})
-        for j in redo:
-            o_j = runner.last_order[j]
+        if redo:
+            o_ = [runner.last_order[j] % POOL for j in redo]
             if CERTIFY:
-                r_, m_, x_ = eng.match_pose_exact(ob_.frame(j - 1), ob_.frame(j), rand[o_j % POOL], rand_host[o_j % POOL])
-                ob_.result[j].copy_(torch.from_numpy(np.frombuffer(r_.tobytes(), np.uint8).copy())); ob_.inlier_mask[j].copy_(torch.from_numpy(m_))
+                rs_, ms_, xs_ = eng.match_pose_exact_many([(ob_.frame(j - 1), ob_.frame(j)) for j in redo], [rand[o] for o in o_], [rand_host[o] for o in o_])
+                sel = torch.tensor(redo, device=dev)
+                ob_.result[sel] = torch.from_numpy(rs_.view(np.uint8).reshape(len(redo), -1).copy()).to(dev)
+                ob_.inlier_mask[sel] = torch.from_numpy(ms_).to(dev)
+                for j, x_ in zip(redo, xs_):
+                    ob_.pair_idx[j].copy_(x_)
             else:
-                r_, m_, x_ = eng.match_pose(ob_.frame(j - 1), ob_.frame(j), rand[o_j % POOL])
-                ob_.result[j].copy_(r_); ob_.inlier_mask[j].copy_(m_)
-            ob_.pair_idx[j].copy_(x_)
+                for j, o in zip(redo, o_):
+                    r_, m_, x_ = eng.match_pose(ob_.frame(j - 1), ob_.frame(j), rand[o])
+                    ob_.result[j].copy_(r_); ob_.inlier_mask[j].copy_(m_); ob_.pair_idx[j].copy_(x_)
         torch.cuda.synchronize()
         return round(n / (time.perf_counter() - t0), 1), len(tied), patches, len(redo)
 
@@ -766,7 +768,7 @@ def secondary_legs(args, eng, pipe, dev, pool, rand, rand_host, Runner, frame_pa
     sec["scene_" + other] = {"frames_per_s": fps2, "poses_solved": "%d/%d" % (ok2, 2 * B),
                              "frames_redone": frames_redone, "tie_split_patches_redone": patches_redone, "pairs_rematched": pairs_redone,
                              "frames_redone_note": "frames whose 496-nearest cut splits a tie class, redone in scikit-learn's kd-tree order inside the timed "
-                                                   "stretch (Engine.resolve_ties; Voxel.py:195-196): the figure is a reference-exact one",
+                                                   "stretch on 8 side streams (Engine.resolve_ties_many; Voxel.py:195-196), their pairs matched and certified again: a reference-exact figure",
                              "workload": "configs[2] on the other synthetic scene (%s)" % other,
                              "dedup_share": round(1.0 - len(torch.unique(torch.cat([b.reshape(-1, 64) for b in bits2]), dim=0)) / float(3072 * len(bits2)), 4),
                              "dedup_share_within_frames": round(1.0 - float(np.mean([len(torch.unique(b.reshape(-1, 64), dim=0)) for b in bits2])) / 3072.0, 4),

@@ -622,7 +622,9 @@ class Engine:
         counts = self.empty((3,), torch.int64)
         _ffi.check(self.lib.caelo_voxmap_export(self.ctx, vmap.h, _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]),
                                                 capacity, _ptr(counts), self.stream))
-        n = counts.cpu().tolist()
+        n = counts.cpu().tolist()          # (the call itself does not wait for the device; this read does)
+        if max(n) > capacity:
+            raise _ffi.CaeloError("caelo_voxmap_export: %d voxels exceed the output capacity %d" % (max(n), capacity))
         return [o[:k] for o, k in zip(outs, n)]
 
     def voxmap_from_lists(self, a0, a1, a2, vmap=None, status=None):
@@ -900,6 +902,90 @@ class Engine:
         ff.rows[:k, 0:60] = self.encode(bits.reshape(-1, 64), group=3)
         ff.flags[:k] = flags
         return n_tie
+
+    def resolve_ties_many(self, items, lanes=8):
+        """resolve_ties over many frames at once: ``items`` = [(FrameFeatures, scan), ...].  One read of the flags and key
+        point counts for all of them, then each tied frame's redo goes to one of ``lanes`` side streams (own voxel maps and
+        scratch per stream), so the single-workgroup kd-tree builds of different frames overlap instead of queueing.  Three
+        host reads in all (flags, list lengths, status words) however many frames are tied.  The current stream waits for the
+        lanes.  -> (indices into ``items`` that were redone, their numbers of tie-split patches)."""
+        import time
+        t0_ = time.perf_counter()
+        if not items:
+            return [], []
+        tie = torch.stack([((ff.flags & 2) != 0).sum() for ff, _ in items])
+        nk = torch.stack([ff.n_key.reshape(()) for ff, _ in items])
+        both = torch.stack([tie, nk.to(tie.dtype)]).cpu().numpy()
+        tied = [i for i in range(len(items)) if both[0, i] > 0]
+        if not tied:
+            return [], []
+        if not hasattr(self, "_tie_lanes") or len(self._tie_lanes) < lanes:
+            self._tie_lanes = [torch.cuda.Stream(self.device) for _ in range(lanes)]
+        cur = torch.cuda.current_stream(self.device)
+        start = torch.cuda.Event()
+        start.record(cur)
+        t1_ = time.perf_counter()
+        statuses, staged = [], []
+        # phase 1 on the lanes: first-touch voxel lists of every tied frame (the list lengths are device words)
+        for j, i in enumerate(tied):
+            ff, pc = items[i]
+            lane = self._tie_lanes[j % lanes]
+            if j < lanes:
+                lane.wait_event(start)
+            with torch.cuda.stream(lane):
+                cap = max(self.max_points, pc.shape[0])
+                vm, st = self.voxelize(pc, self.voxmap(cap, slot=2))
+                outs = [self.empty((cap, 3), torch.int16) for _ in range(3)]
+                counts = self.empty((3,), torch.int64)
+                _ffi.check(self.lib.caelo_voxmap_export(self.ctx, vm.h, _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), cap, _ptr(counts), self.stream))
+                statuses.append(st)
+                staged.append((outs, counts, cap))
+        for lane in self._tie_lanes[:min(lanes, len(tied))]:
+            cur.wait_stream(lane)
+        t2_ = time.perf_counter()
+        lens = torch.stack([c for _, c, _ in staged]).cpu().numpy()          # one read for all the frames
+        t3_ = time.perf_counter()
+        # phase 2: the lists as a map, patches in the kd-tree order (one workgroup builds a tree: the lanes overlap them), encoder
+        for j, i in enumerate(tied):
+            ff, pc = items[i]
+            lane = self._tie_lanes[j % lanes]
+            outs, _, cap = staged[j]
+            with torch.cuda.stream(lane):
+                lists = [o[:int(n_)] for o, n_ in zip(outs, lens[j])]
+                vm2, st2 = self.voxmap_from_lists(*lists, vmap=self.voxmap(cap, slot=3))
+                k = int(both[1, i])
+                bits, flags = self.patches(vm2, ff.key_pts[:k].contiguous())
+                ff.rows[:k, 0:60] = self.encode(bits.reshape(-1, 64), group=3)
+                ff.flags[:k] = flags
+                statuses.append(st2)
+        for lane in self._tie_lanes[:min(lanes, len(tied))]:
+            cur.wait_stream(lane)
+        t4_ = time.perf_counter()
+        raise_status(int(np.bitwise_or.reduce(torch.stack([s.reshape(()) for s in statuses]).cpu().numpy())))
+        t5_ = time.perf_counter()
+        self.last_tie_times = dict(find_ms=1e3 * (t1_ - t0_), lists_issue_ms=1e3 * (t2_ - t1_), lists_wait_ms=1e3 * (t3_ - t2_),
+                                   redo_issue_ms=1e3 * (t4_ - t3_), redo_wait_ms=1e3 * (t5_ - t4_))
+        return tied, [int(both[0, i]) for i in tied]
+
+    def match_pose_exact_many(self, pairs, rands, rands_host=None, threads=None):
+        """match_pose_exact over many pairs [(fa, fb), ...]: every match and hypothesis launch is issued first, the certificates
+        come back in one copy and the host half runs over them on ``threads`` threads.  -> (results [k] (_ffi.POSE_DTYPE),
+        masks [k,1024] u8 (host), [pair_idx (device)] * k).  Synchronises once."""
+        k = len(pairs)
+        cur = torch.cuda.current_stream(self.device)
+        cert = self.new_cert(k)
+        idxs = []
+        for j, (fa, fb) in enumerate(pairs):
+            for f in (fa, fb):
+                f.rows.record_stream(cur)
+                f.n_key.record_stream(cur)
+            idx = self.match(fa.features, fb.features, fa.n_key, fb.n_key)
+            self.ransac(fa.key_pts, fb.key_pts, idx, rands[j], fb.n_key, cert=cert[j])
+            idxs.append(idx)
+        results, masks, _, status = self.certify(cert, list(rands_host) if rands_host is not None else list(rands), threads)
+        if (status != 0).any():
+            raise _ffi.CaeloError("pairs %s could not be certified (status %s)" % (np.flatnonzero(status != 0).tolist(), status[status != 0].tolist()))
+        return results, masks, idxs
 
     def checked(self, ff, pc, dist_channels=5):
         """Synchronising status check of an extract() result: raises what the reference would raise."""

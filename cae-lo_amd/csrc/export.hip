@@ -65,10 +65,13 @@ __global__ void __launch_bounds__(256) k_exp_compact(const unsigned long long *_
     svals[p] = k;
 }
 
-__global__ void __launch_bounds__(256) k_exp_write(const unsigned long long *__restrict__ svals, int n,
-                                                   int16_t *__restrict__ out) {
+// the sorted run is `*count` long (a device word: the call never waits for it); the rest of the padded sort is 0xFF.. keys
+__global__ void __launch_bounds__(256) k_exp_write(const unsigned long long *__restrict__ svals, const int32_t *__restrict__ count,
+                                                   int64_t capacity, int16_t *__restrict__ out, int64_t *__restrict__ count_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int n = *count;
+    if (i == 0) *count_out = n;
+    if (i >= n || i >= capacity) return;
     const unsigned long long k = svals[i];
     out[3 * i] = (int16_t)((k >> 40) & 0xFFFFF);
     out[3 * i + 1] = (int16_t)((k >> 20) & 0xFFFFF);
@@ -98,9 +101,12 @@ CAELO_API int caelo_voxmap_export(caelo_ctx *c, caelo_voxmap *m, int16_t *all0, 
     int32_t *count = (int32_t *)(bfirst + vs);
     void *temp = (void *)(count + 16);
     int16_t *outs[3] = {all0, all1, all2};
-    int64_t host_counts[3];
-    const unsigned grid = (unsigned)((vs + 255) / 256);
+    // No host round trip: every scale is sorted at its table's size with 0xFF.. keys behind the `count` real ones (a few hundred
+    // microseconds of sorting more than the exact length would take, against four stream synchronisations per call -- which is what
+    // serialised the tie redo of many frames on side streams, Engine.resolve_ties_many).
     for (int sc = 0; sc < 3; ++sc) {
+        const size_t vsc = (size_t)m->vmask[sc] + 1;
+        const unsigned grid = (unsigned)((vsc + 255) / 256);
         CAELO_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), s));
         if (sc == 0) {
             CAELO_HIP(hipMemsetAsync(bkeys, 0xFF, vs * 8, s));
@@ -108,24 +114,13 @@ CAELO_API int caelo_voxmap_export(caelo_ctx *c, caelo_voxmap *m, int16_t *all0, 
             k_exp_block_first<<<grid, 256, 0, s>>>(m->vkeys[0], m->vfirst[0], m->vmask[0], bkeys, bfirst);
             CAELO_LAUNCH_CHECK();
         }
+        CAELO_HIP(hipMemsetAsync(k_in, 0xFF, vsc * 8, s));
         k_exp_compact<<<grid, 256, 0, s>>>(m->vkeys[sc], m->vfirst[sc], m->vmask[sc], bkeys, bfirst, sc == 0, k_in, v_in, count);
         CAELO_LAUNCH_CHECK();
-        int32_t n = 0;
-        CAELO_HIP(hipMemcpyAsync(&n, count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        CAELO_HIP(hipStreamSynchronize(s));
-        if (n > capacity) {
-            caelo_set_error("caelo_voxmap_export: %d voxels exceed the output capacity %lld", n, (long long)capacity);
-            return CAELO_ERR_CAPACITY;
-        }
-        host_counts[sc] = n;
-        if (n > 0) {
-            size_t tb = temp_bytes;
-            CAELO_HIP(rocprim::radix_sort_pairs(temp, tb, k_in, k_out, v_in, v_out, (size_t)n, 0, 64, s));
-            k_exp_write<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(v_out, n, outs[sc]);
-            CAELO_LAUNCH_CHECK();
-        }
+        size_t tb = temp_bytes;
+        CAELO_HIP(rocprim::radix_sort_pairs(temp, tb, k_in, k_out, v_in, v_out, vsc, 0, 64, s));
+        k_exp_write<<<grid, 256, 0, s>>>(v_out, count, capacity, outs[sc], counts + sc);
+        CAELO_LAUNCH_CHECK();
     }
-    CAELO_HIP(hipMemcpyAsync(counts, host_counts, sizeof(host_counts), hipMemcpyHostToDevice, s));
-    CAELO_HIP(hipStreamSynchronize(s));
     return CAELO_OK;
 }

@@ -65,27 +65,38 @@ __global__ void __launch_bounds__(256) k_kd_collect(const uint8_t *__restrict__ 
 
 // One workgroup per scale.  Level by level; `tpn` threads share a node of the upper levels for the parallel parts (bounding box,
 // key array) and for the quickselect's partitions.
-__global__ void __launch_bounds__(256) k_kd_build(caelo_kd kd) {
+constexpr int KD_T = 1024;   // threads of the build's workgroup: the upper levels' partitions are chains of dependent L2 reads, more of them in flight
+
+__global__ void __launch_bounds__(KD_T) k_kd_build(caelo_kd kd) {
     const caelo_kd_scale T = kd.s[blockIdx.x];
     if (kd.state[blockIdx.x] == 0 || kd.state[4 + blockIdx.x] != 0) return;   // no tie-split patch of this scale / tree already built
-    __shared__ int s_lo[256][3], s_hi[256][3];
+    __shared__ int s_lo[KD_T][3], s_hi[KD_T][3];
     __shared__ int s_gave_up;   // a node's quickselect exceeded its budget (below): the tree is not built, the canonical rule stays
-    __shared__ int q_left[256], q_right[256], q_act[256], q_lf[256], s_cl[256], s_cg[256];   // per node of a pass / per thread
-    __shared__ long long q_budget[256];
+    __shared__ int q_left[KD_T], q_right[KD_T], q_act[KD_T], q_lf[KD_T], s_cl[KD_T], s_cg[KD_T];   // per node of a pass / per thread
+    __shared__ long long q_budget[KD_T];
     const int tid = threadIdx.x;
     if (tid == 0) s_gave_up = 0;
     const int64_t n = T.n;
-    for (int64_t i = tid; i < n; i += 256) T.idx[i] = (int32_t)i;
-    for (int i = tid; i < T.n_nodes; i += 256) { T.start[i] = 0; T.end[i] = 0; }   // (children of a node that did not split stay empty)
+    for (int64_t i = tid; i < n; i += KD_T) T.idx[i] = (int32_t)i;
+    for (int i = tid; i < T.n_nodes; i += KD_T) { T.start[i] = 0; T.end[i] = 0; }   // (children of a node that did not split stay empty)
     __syncthreads();
     if (tid == 0) { T.start[0] = 0; T.end[0] = (int32_t)n; }
     __syncthreads();
     for (int level = 0; level < T.n_levels; ++level) {
+#ifdef KD_PROFILE
+        const long long t_level = wall_clock64();
+        int n_pass = 0;
+        long long t_count = 0, t_write = 0, t_resolve = 0, t_copy = 0;
+#endif
         const int first = (1 << level) - 1, count = 1 << level;
-        const int tpn = count >= 256 ? 1 : 256 >> level;      // threads per node
-        const int per_pass = 256 / tpn;                       // nodes in flight
+        const int tpn = count >= KD_T ? 1 : KD_T >> level;      // threads per node
+        const int per_pass = KD_T / tpn;                       // nodes in flight
         for (int base = 0; base < count; base += per_pass) {
             const int local = tid / tpn, sub = tid % tpn;
+            const int W = tpn < 64 ? tpn : 64, nu = tpn / W;          // lanes per unit, units per node (see the partition below)
+            const int u = sub / W, lu = sub % W, ug = tid / W;
+            const int ushift = (tid & 63) / W * W;
+            const unsigned long long umask = W == 64 ? ~0ull : (1ull << W) - 1ull;
             const int node = first + base + local;
             const bool live = base + local < count;
             const int s = live ? T.start[node] : 0, e = live ? T.end[node] : 0;
@@ -151,46 +162,64 @@ __global__ void __launch_bounds__(256) k_kd_build(caelo_kd kd) {
             for (;;) {
                 __syncthreads();   // (the reduction below is a barrier, not a fence: the q_* words written at the end of the previous pass must have landed)
                 if (!__syncthreads_or(sub == 0 && q_act[local] != 0)) break;
+#ifdef KD_PROFILE
+                ++n_pass;
+                long long t_ph = wall_clock64();
+#endif
                 const bool act = q_act[local] != 0;
                 const int left = act ? q_left[local] : 0, right = act ? q_right[local] : -1;
                 const int len = right - left;                            // elements in front of the pivot
-                const int chunk = len > 0 ? (len + tpn - 1) / tpn : 0;
-                const int i0 = left + sub * chunk, i1 = min(i0 + chunk, right);
+                // The node's threads work in UNITS of W = min(tpn, 64) lanes of one wavefront: a unit owns a contiguous chunk and walks it
+                // W consecutive elements at a time (coalesced; a thread walking its own chunk element by element made every load of a
+                // wavefront touch 64 cache lines), positions inside a step come from the ballot, positions across steps are carried.
+                const int chunk = len > 0 ? (len + nu - 1) / nu : 0;
+                const int i0 = left + u * chunk, i1 = min(i0 + chunk, right);
                 const unsigned pvv = act ? (unsigned)(a[right] >> 32) : 0u;
                 int cl = 0, fg = -1;
-                for (int i = i0; i < i1; ++i) {
-                    const bool less = (unsigned)(a[i] >> 32) < pvv;
-                    cl += less ? 1 : 0;
-                    if (!less && fg < 0) fg = i;
+                for (int b0 = i0; b0 < i1; b0 += W) {
+                    const int i = b0 + lu;
+                    const bool valid = i < i1;
+                    const bool less = valid && (unsigned)(a[valid ? i : i0] >> 32) < pvv;
+                    const unsigned long long ml = (__ballot(less) >> ushift) & umask, mg = (__ballot(valid && !less) >> ushift) & umask;
+                    cl += __popcll(ml);
+                    if (fg < 0 && mg) fg = b0 + (int)__builtin_ctzll(mg);
                 }
                 const int cg = (i1 > i0 ? i1 - i0 : 0) - cl;
-                s_cl[tid] = cl; s_cg[tid] = cg;
+                if (lu == 0) { s_cl[ug] = cl; s_cg[ug] = cg; }
                 __syncthreads();
-                for (int o = 1; o < tpn; o <<= 1) {                      // inclusive scans over the node's threads (tpn is the same for all)
+#ifdef KD_PROFILE
+                t_count += wall_clock64() - t_ph; t_ph = wall_clock64();
+#endif
+                for (int o = 1; o < nu; o <<= 1) {                       // inclusive scans over the node's units (nu is the same for all)
                     int x = 0, y = 0;
-                    if (sub >= o) { x = s_cl[tid - o]; y = s_cg[tid - o]; }
+                    if (u >= o) { x = s_cl[ug - o]; y = s_cg[ug - o]; }
                     __syncthreads();
-                    s_cl[tid] += x; s_cg[tid] += y;
+                    if (lu == 0) { s_cl[ug] += x; s_cg[ug] += y; }
                     __syncthreads();
                 }
-                const int lead2 = tid - sub;
-                const int lb = s_cl[tid] - cl, gb = s_cg[tid] - cg;      // below / not below the pivot in front of this thread's chunk
-                const int L = s_cl[lead2 + tpn - 1], G = s_cg[lead2 + tpn - 1];
-                if (act && fg >= 0 && gb == 0) q_lf[local] = lb + (fg - i0);   // elements below the pivot in front of the FIRST one that is not
+                const int lead2 = ug - u;
+                const int lb = s_cl[ug] - cl, gb = s_cg[ug] - cg;        // below / not below the pivot in front of this unit's chunk
+                const int L = s_cl[lead2 + nu - 1], G = s_cg[lead2 + nu - 1];
+                if (act && fg >= 0 && gb == 0 && lu == 0) q_lf[local] = lb + (fg - i0);   // elements below the pivot in front of the FIRST one that is not
                 __syncthreads();
                 const int Lf = G > 0 ? q_lf[local] : L, R = L - Lf;
                 {
-                    int pq = gb, l = lb;
-                    for (int i = i0; i < i1; ++i) {
-                        const unsigned long long v = a[i];
-                        if ((unsigned)(v >> 32) < pvv) {
+                    int pq0 = gb, l0 = lb;
+                    const unsigned long long below = (1ull << lu) - 1ull;
+                    for (int b0 = i0; b0 < i1; b0 += W) {
+                        const int i = b0 + lu;
+                        const bool valid = i < i1;
+                        const unsigned long long v = a[valid ? i : i0];
+                        const bool less = valid && (unsigned)(v >> 32) < pvv;
+                        const unsigned long long ml = (__ballot(less) >> ushift) & umask, mg = (__ballot(valid && !less) >> ushift) & umask;
+                        const int l = l0 + __popcll(ml & below), pq = pq0 + __popcll(mg & below);   // of the elements in front of i
+                        if (less) {
                             kb[left + l] = v;
                             if (pq > 0) ev[left + pq + (l - Lf)] = -((l - Lf) + 1);   // rotation l - Lf: re-enqueue of the element of event l - Lf
-                            ++l;
-                        } else {
+                        } else if (valid) {
                             ev[left + pq + (l - Lf)] = i;                            // push of element i
-                            ++pq;
                         }
+                        l0 += __popcll(ml); pq0 += __popcll(mg);
                     }
                 }
                 if (act && sub == 0) {
@@ -198,6 +227,9 @@ __global__ void __launch_bounds__(256) k_kd_build(caelo_kd kd) {
                     if (G > 0) ev[left + G + R] = -(R + 1);                          // the final swap with the pivot
                 }
                 __syncthreads();
+#ifdef KD_PROFILE
+                t_write += wall_clock64() - t_ph; t_ph = wall_clock64();
+#endif
                 for (int k = sub; act && k < G; k += tpn) {
                     int ee = R + 1 + k, x, steps = 0;
                     while ((x = ev[left + ee]) < 0) {
@@ -207,8 +239,14 @@ __global__ void __launch_bounds__(256) k_kd_build(caelo_kd kd) {
                     kb[left + L + 1 + k] = a[x];
                 }
                 __syncthreads();
+#ifdef KD_PROFILE
+                t_resolve += wall_clock64() - t_ph; t_ph = wall_clock64();
+#endif
                 for (int i = left + sub; act && i <= right; i += tpn) a[i] = kb[i];
                 __syncthreads();
+#ifdef KD_PROFILE
+                t_copy += wall_clock64() - t_ph;
+#endif
 #ifdef KD_DEBUG
                 if (act && sub == 0) {
                     int bad = 0;
@@ -242,6 +280,10 @@ __global__ void __launch_bounds__(256) k_kd_build(caelo_kd kd) {
                 for (int i = s + sub; i < e; i += tpn) T.idx[i] = (int32_t)(unsigned)T.keys[i];
             __syncthreads();
         }
+#ifdef KD_PROFILE
+        if (tid == 0) printf("kd build scale %d n %d level %2d: %7.1f us, %4d passes (count %.1f write %.1f resolve %.1f copy %.1f us)\n", (int)blockIdx.x, (int)n, level,
+                             (wall_clock64() - t_level) * 0.01, n_pass, t_count * 0.01, t_write * 0.01, t_resolve * 0.01, t_copy * 0.01);
+#endif
     }
     if (tid == 0) kd.state[4 + blockIdx.x] = s_gave_up ? 2 : 1;   // 2: not built (the queries leave flag 2 and the canonical rule in place)
 }
@@ -418,7 +460,7 @@ int kd_resolve(const caelo_voxmap *m, const float *pts, int pts_ld, int64_t k_ma
         CAELO_HIP(hipMemsetAsync(kd.state, 0, 12, s));   // queue lengths (the built flags stay)
         k_kd_collect<<<(unsigned)((kd.k_cap * 3 + 255) / 256), 256, 0, s>>>(flags, k0, k_max, n_key, kd);
         CAELO_LAUNCH_CHECK();
-        k_kd_build<<<3, 256, 0, s>>>(kd);
+        k_kd_build<<<3, KD_T, 0, s>>>(kd);
         CAELO_LAUNCH_CHECK();
         k_kd_query<<<dim3((unsigned)kd.k_cap, 3), 64, 0, s>>>(kd, pts, pts_ld, (unsigned long long *)bits, flags);
         CAELO_LAUNCH_CHECK();

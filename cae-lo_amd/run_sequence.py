@@ -164,18 +164,24 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
             # Frames whose 496-nearest cut (Voxel.py:195-196) splits a class of equidistant voxels: the fused path's canonical rule is
             # replaced by scikit-learn's kd-tree order (Engine.resolve_ties: ordered voxel lists, all on the device), then the pairs
             # such a frame is part of are matched again.  One synchronisation per chunk; rare (none on KITTI-shaped scans).
-            tied = torch.nonzero((batch.flags[:c1 - c0] & 2).reshape(c1 - c0, -1).any(dim=1)).reshape(-1).tolist()
-            for j in tied:
-                n_t = eng.resolve_ties(batch.frame(j), scans[j].to(eng.device))
+            if bool((batch.flags[:c1 - c0] & 2).any().item()):
+                items = [(batch.frame(j), scans[j].to(eng.device)) for j in range(c1 - c0)]
+                tied, n_t = eng.resolve_ties_many(items)         # the redos overlap on side streams
                 if tie_log is not None:
-                    tie_log.append((c0 + j, n_t))
-            for j in sorted({t for u in tied for t in (u, u + 1) if t < c1 - c0 and (t > 0 or prev is not None)}):
-                if certify:
-                    r_, m_, x_ = eng.match_pose_exact(prev if j == 0 else batch.frame(j - 1), batch.frame(j), draws_d[j], dn_[j])
-                    r_, m_ = torch.from_numpy(np.frombuffer(r_.tobytes(), np.uint8).copy()), torch.from_numpy(m_)
+                    tie_log.extend((c0 + j, n_) for j, n_ in zip(tied, n_t))
+                redo = sorted({t for u in tied for t in (u, u + 1) if t < c1 - c0 and (t > 0 or prev is not None)})
+                pairs_ = [(prev if j == 0 else batch.frame(j - 1), batch.frame(j)) for j in redo]
+                if certify and redo:
+                    rs_, ms_, xs_ = eng.match_pose_exact_many(pairs_, [draws_d[j] for j in redo], [dn_[j] for j in redo])
+                    sel = torch.tensor(redo, device=eng.device)
+                    batch.result[sel] = torch.from_numpy(rs_.view(np.uint8).reshape(len(redo), -1).copy()).to(eng.device)
+                    batch.inlier_mask[sel] = torch.from_numpy(ms_).to(eng.device)
+                    for j, x_ in zip(redo, xs_):
+                        batch.pair_idx[j].copy_(x_)
                 else:
-                    r_, m_, x_ = eng.match_pose(prev if j == 0 else batch.frame(j - 1), batch.frame(j), draws_d[j])
-                batch.result[j].copy_(r_); batch.inlier_mask[j].copy_(m_); batch.pair_idx[j].copy_(x_)
+                    for j, (fa_, fb_) in zip(redo, pairs_):
+                        r_, m_, x_ = eng.match_pose(fa_, fb_, draws_d[j])
+                        batch.result[j].copy_(r_); batch.inlier_mask[j].copy_(m_); batch.pair_idx[j].copy_(x_)
         ht["ties"] += time.time() - t_
         # read this chunk's small outputs back without stalling the stream that issues the next chunk
         done = torch.cuda.Event()

@@ -130,7 +130,8 @@ int caelo_voxelize_fast(caelo_ctx *ctx, caelo_voxmap *map, const float *pc, int6
 int caelo_voxmap_dump(caelo_ctx *ctx, const caelo_voxmap *map, int scale, uint64_t *keys, uint64_t *bits, int64_t capacity,
                       int32_t *count, void *stream);
 /* AllVoxels0/1/2 in the reference's order (first touch; scale 0 block-grouped, Voxel.py:161-165).
- * out [capacity][3] i16 per scale, counts [3] i64 (device).  Valid after caelo_voxelize. */
+ * out [capacity][3] i16 per scale, counts [3] i64 (device).  Valid after caelo_voxelize.  Asynchronous on `stream`: a count
+ * above `capacity` means only the first `capacity` voxels of that scale were written (the caller checks after reading counts). */
 int caelo_voxmap_export(caelo_ctx *ctx, caelo_voxmap *map, int16_t *all0, int16_t *all1, int16_t *all2,
                         int64_t capacity, int64_t *counts, void *stream);
 /* Build the map from reference-format lists instead (GetPatchesList called with arrays). */

@@ -587,6 +587,38 @@ def test_shuffled_file_order_vs_reference_golden(engine, api, scans):
     assert all(torch.equal(out.rows[i], ff.rows) for i in range(3)) and int(out.status[:, 0].abs().sum().item()) == 0
 
 
+def test_tie_redo_on_side_streams_equals_the_serial_redo(engine, scans):
+    """Engine.resolve_ties_many (tied frames' redos on side streams, one status read) against Engine.resolve_ties frame by frame:
+    same frames found, same tie-split patch counts, descriptor rows and flags bit-identical; match_pose_exact_many against
+    match_pose_exact pair by pair.  Clutter frames 20..27 hold tie-split patches (frame 23: 11, tests/golden/frame_c23.npz)."""
+    import torch
+    from caelo.engine import ransac_draws
+    ids = list(range(20, 28))
+    pcs = [torch.from_numpy(scans(i, quantum=1e-3, scene_kind="clutter")).to(engine.device) for i in ids]
+    draws = [ransac_draws(70 + i) for i in ids]
+    rnd = [torch.from_numpy(d).to(engine.device) for d in draws]
+    pipe = engine.pipeline(4)
+    a = pipe.run(pcs, rnd, certify=True, rands_host=draws)
+    b = pipe.run(pcs, rnd, certify=True, rands_host=draws)
+    torch.cuda.synchronize()
+    assert torch.equal(a.rows, b.rows)
+    want_tied, want_n = [], []
+    for j in range(len(ids)):
+        n_t = engine.resolve_ties(a.frame(j), pcs[j])
+        if n_t:
+            want_tied.append(j); want_n.append(n_t)
+    tied, counts = engine.resolve_ties_many([(b.frame(j), pcs[j]) for j in range(len(ids))], lanes=3)
+    torch.cuda.synchronize()
+    assert tied == want_tied and counts == want_n and 3 in tied and counts[tied.index(3)] == 11
+    assert torch.equal(a.rows, b.rows) and torch.equal(a.flags, b.flags)
+    assert engine.resolve_ties_many([], lanes=3) == ([], [])
+    redo = sorted({t for u in tied for t in (u, u + 1) if 0 < t < len(ids)})
+    rs, ms, xs = engine.match_pose_exact_many([(b.frame(j - 1), b.frame(j)) for j in redo], [rnd[j] for j in redo], [draws[j] for j in redo])
+    for k_, j in enumerate(redo):
+        r1, m1, x1 = engine.match_pose_exact(a.frame(j - 1), a.frame(j), rnd[j], draws[j])
+        assert r1.tobytes() == rs[k_].tobytes() and np.array_equal(m1, ms[k_]) and torch.equal(x1, xs[k_])
+
+
 @pytest.mark.parametrize("scene,frames", [("boxes", 18), ("clutter", 18), ("boxes_mm", 18), ("shuffled", 6)])
 def test_parity_soak_short(engine, orc, models, scene, frames):
     """A short leg of tools/parity_soak.py (the committed 200- and 600-frame reports are profiles/r05_parity_soak*.txt): consecutive

@@ -110,10 +110,14 @@ def soak(engine, orc, models, scene, n_frames, seed_base=5000, batch=8, log=None
     # reference's way (Engine.resolve_ties: ordered voxel lists, scikit-learn's kd-tree order), then the two pairs they are part of
     fl = out.flags.cpu().numpy()
     tied = [i for i in range(n_frames) if (fl[i] & 2).any()]
-    n_tied_patches = sum(engine.resolve_ties(out.frame(i), dpcs[i]) for i in tied)
-    for i in sorted({j for t in tied for j in (t, t + 1) if 1 <= j < n_frames}):
-        r_, m_, x_ = engine.match_pose_exact(out.frame(i - 1), out.frame(i), rnd[i], draws[i])
-        out.result[i].copy_(torch.from_numpy(np.frombuffer(r_.tobytes(), np.uint8).copy())); out.inlier_mask[i].copy_(torch.from_numpy(m_)); out.pair_idx[i].copy_(x_)
+    tied2, n_tied_patches = engine.resolve_ties_many([(out.frame(i), dpcs[i]) for i in range(n_frames)])
+    assert tied2 == tied
+    n_tied_patches = sum(n_tied_patches)
+    redo = sorted({j for t in tied for j in (t, t + 1) if 1 <= j < n_frames})
+    if redo:
+        rs_, ms_, xs_ = engine.match_pose_exact_many([(out.frame(i - 1), out.frame(i)) for i in redo], [rnd[i] for i in redo], [draws[i] for i in redo])
+        for k_, i in enumerate(redo):
+            out.result[i].copy_(torch.from_numpy(np.frombuffer(rs_[k_].tobytes(), np.uint8).copy())); out.inlier_mask[i].copy_(torch.from_numpy(ms_[k_])); out.pair_idx[i].copy_(xs_[k_])
     torch.cuda.synchronize()
     rows = out.rows.cpu().numpy(); kpix = out.key_pixels.cpu().numpy(); nkey = out.n_key.cpu().numpy()
     pidx = out.pair_idx.cpu().numpy(); mask = out.inlier_mask.cpu().numpy().astype(bool); res = out.result.cpu().numpy()
