@@ -739,7 +739,7 @@ def secondary_legs(args, eng, pipe, dev, pool, rand, rand_host, Runner, frame_pa
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ob_ = runner.run(n)
-        tied, patches = eng.resolve_ties_many([(ob_.frame(j), runner.pool[runner.last_order[j]]) for j in range(n)])
+        tied, patches = eng.resolve_ties_many([(ob_.frame(j), runner.pool[runner.last_order[j]]) for j in range(n)], batch=ob_)
         patches = sum(patches)
         redo = sorted({t for u in tied for t in (u, u + 1) if 0 < t < n})
         if redo:
@@ -756,8 +756,11 @@ def secondary_legs(args, eng, pipe, dev, pool, rand, rand_host, Runner, frame_pa
                     r_, m_, x_ = eng.match_pose(ob_.frame(j - 1), ob_.frame(j), rand[o])
                     ob_.result[j].copy_(r_); ob_.inlier_mask[j].copy_(m_); ob_.pair_idx[j].copy_(x_)
         torch.cuda.synchronize()
+        if os.environ.get("CAELO_BENCH_VERBOSE"):
+            print("leg_exact_ties: total %.1f ms, tie redo %s" % (1e3 * (time.perf_counter() - t0), getattr(eng, "last_tie_times", None)), file=sys.stderr)
         return round(n / (time.perf_counter() - t0), 1), len(tied), patches, len(redo)
 
+    leg_exact_ties(r2)          # (first use of the redo path: the side streams' voxel maps are allocated here, like any warm-up)
     fps2, frames_redone, patches_redone, pairs_redone = leg_exact_ties(r2)
     ob = r2.run(2 * B)
     torch.cuda.synchronize()

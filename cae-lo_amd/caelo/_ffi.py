@@ -44,7 +44,7 @@ class FrameJob(C.Structure):
 
 
 PAIR_NONE, PAIR_CHAIN, PAIR_EXPLICIT = 0, 1, 2
-ABI_VERSION = 3   # include/caelo.h CAELO_ABI_VERSION
+ABI_VERSION = 4   # include/caelo.h CAELO_ABI_VERSION
 BUILD_PACKED_F32, BUILD_PROF, BUILD_STAMPED = 1, 2, 256   # caelo_build_flags() bits (include/caelo.h)
 
 # the same layout as a NumPy record (a run's jobs are filled column-wise and handed over in one call)
@@ -83,6 +83,7 @@ SIGNATURES = [
     ("caelo_voxelize_fast", c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
     ("caelo_voxmap_dump", c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_vp]),
     ("caelo_voxmap_export", c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    ("caelo_voxmap_order", c_int, [c_vp, c_vp, c_int, c_vp]),
     ("caelo_voxmap_from_lists", c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     ("caelo_patches", c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("caelo_unpack_patches", c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),

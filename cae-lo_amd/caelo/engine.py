@@ -627,6 +627,12 @@ class Engine:
             raise _ffi.CaeloError("caelo_voxmap_export: %d voxels exceed the output capacity %d" % (max(n), capacity))
         return [o[:k] for o, k in zip(outs, n)]
 
+    def voxmap_order(self, vmap, scale_mask=7):
+        """caelo_voxmap_order: the map (filled by ``voxelize``) records its voxel lists' first-touch order on the device, so that
+        ``patches`` on it redoes tie-split patches of the scales in ``scale_mask`` in scikit-learn's kd-tree order.  No sync."""
+        _ffi.check(self.lib.caelo_voxmap_order(self.ctx, vmap.h, int(scale_mask), self.stream))
+        return vmap
+
     def voxmap_from_lists(self, a0, a1, a2, vmap=None, status=None):
         for a in (a0, a1, a2):
             assert a.dtype == torch.int16 and a.dim() == 2 and a.shape[1] == 3 and a.is_contiguous()
@@ -885,38 +891,44 @@ class Engine:
     def resolve_ties(self, ff, pc):
         """The fused path (extract / Pipeline.run) builds voxel SETS; where the 496-nearest cut of Voxel.py:195-196 splits a class
         of equidistant voxels it uses a canonical rule and sets flag bit 2, because scikit-learn's choice depends on the ORDER of
-        the voxel lists.  This redoes such a frame's patches the reference's way -- first-touch voxel lists (caelo_voxelize +
-        caelo_voxmap_export), the lists as a map (caelo_voxmap_from_lists), caelo_patches with the kd-tree order (kdorder.hip),
-        caelo_encode -- and writes the descriptors into ``ff.rows`` in place.  Synchronises; returns the number of tie-split
-        patches it found (0: nothing done).  Rare: 0 of 614 400 patches on the KITTI-shaped scene, 115 on the clutter scene."""
-        n_tie = int(((ff.flags & 2) != 0).sum().item())
+        the voxel lists.  This redoes such a frame's patches the reference's way -- the exact voxelization (caelo_voxelize: first
+        touch recorded), the lists of the scales that need it ordered on the device (caelo_voxmap_order), caelo_patches with the
+        kd-tree order (kdorder.hip), caelo_encode -- and writes the descriptors into ``ff.rows`` in place.  Synchronises; returns
+        the number of tie-split patches it found (0: nothing done).  Rare: 0 of 614 400 patches on the KITTI-shaped scene, 115 on
+        the clutter scene.  Many frames at once: ``resolve_ties_many``."""
+        per = ((ff.flags & 2) != 0).sum(dim=0).cpu().tolist()          # tie-split patches per scale
+        n_tie = int(sum(per))
         if n_tie == 0:
             return 0
         cap = max(self.max_points, pc.shape[0])
         vm, st = self.voxelize(pc, self.voxmap(cap, slot=2))
-        lists = [a.contiguous() for a in self.voxmap_export(vm, cap)]
-        vm2, st2 = self.voxmap_from_lists(*lists, vmap=self.voxmap(cap, slot=3))
+        self.voxmap_order(vm, sum(1 << s_ for s_ in range(3) if per[s_]))
         k = int(ff.n_key.item())
-        bits, flags = self.patches(vm2, ff.key_pts[:k].contiguous())
-        raise_status(int(st.item()) | int(st2.item()))
+        bits, flags = self.patches(vm, ff.key_pts[:k].contiguous())
+        raise_status(int(st.item()))
         ff.rows[:k, 0:60] = self.encode(bits.reshape(-1, 64), group=3)
         ff.flags[:k] = flags
         return n_tie
 
-    def resolve_ties_many(self, items, lanes=8):
-        """resolve_ties over many frames at once: ``items`` = [(FrameFeatures, scan), ...].  One read of the flags and key
-        point counts for all of them, then each tied frame's redo goes to one of ``lanes`` side streams (own voxel maps and
-        scratch per stream), so the single-workgroup kd-tree builds of different frames overlap instead of queueing.  Three
-        host reads in all (flags, list lengths, status words) however many frames are tied.  The current stream waits for the
-        lanes.  -> (indices into ``items`` that were redone, their numbers of tie-split patches)."""
+    def resolve_ties_many(self, items, lanes=8, batch=None):
+        """resolve_ties over many frames at once: ``items`` = [(FrameFeatures, scan), ...] (``batch``: the FrameBatch whose frames
+        0 .. len(items) - 1 they are, if so).  One read of the flags and key point counts for all of them, then each tied frame's
+        redo is issued -- without any further host read -- to one of ``lanes`` side streams (own voxel maps and scratch per stream),
+        so the kd-tree builds and queries of different frames, a few workgroups each, overlap instead of queueing (more lanes than
+        hardware queues, 8, buy nothing).  The current stream waits for the lanes; one read of the status words at the end.
+        -> (indices into ``items`` that were redone, their numbers of tie-split patches)."""
         import time
         t0_ = time.perf_counter()
         if not items:
             return [], []
-        tie = torch.stack([((ff.flags & 2) != 0).sum() for ff, _ in items])
-        nk = torch.stack([ff.n_key.reshape(()) for ff, _ in items])
-        both = torch.stack([tie, nk.to(tie.dtype)]).cpu().numpy()
-        tied = [i for i in range(len(items)) if both[0, i] > 0]
+        if batch is not None:          # the frames are frames 0 .. len(items) - 1 of a FrameBatch: two reductions instead of two per frame
+            tie = ((batch.flags[:len(items)] & 2) != 0).sum(dim=1)
+            nk = batch.n_key[:len(items)].reshape(-1)
+        else:
+            tie = torch.stack([((ff.flags & 2) != 0).sum(dim=0) for ff, _ in items])      # [frames, 3 scales]
+            nk = torch.stack([ff.n_key.reshape(()) for ff, _ in items])
+        both = torch.cat([tie.to(torch.int64), nk.to(torch.int64).reshape(-1, 1)], dim=1).cpu().numpy()
+        tied = [i for i in range(len(items)) if both[i, :3].any()]
         if not tied:
             return [], []
         if not hasattr(self, "_tie_lanes") or len(self._tie_lanes) < lanes:
@@ -925,8 +937,7 @@ class Engine:
         start = torch.cuda.Event()
         start.record(cur)
         t1_ = time.perf_counter()
-        statuses, staged = [], []
-        # phase 1 on the lanes: first-touch voxel lists of every tied frame (the list lengths are device words)
+        statuses = []
         for j, i in enumerate(tied):
             ff, pc = items[i]
             lane = self._tie_lanes[j % lanes]
@@ -934,38 +945,22 @@ class Engine:
                 lane.wait_event(start)
             with torch.cuda.stream(lane):
                 cap = max(self.max_points, pc.shape[0])
-                vm, st = self.voxelize(pc, self.voxmap(cap, slot=2))
-                outs = [self.empty((cap, 3), torch.int16) for _ in range(3)]
-                counts = self.empty((3,), torch.int64)
-                _ffi.check(self.lib.caelo_voxmap_export(self.ctx, vm.h, _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), cap, _ptr(counts), self.stream))
-                statuses.append(st)
-                staged.append((outs, counts, cap))
-        for lane in self._tie_lanes[:min(lanes, len(tied))]:
-            cur.wait_stream(lane)
-        t2_ = time.perf_counter()
-        lens = torch.stack([c for _, c, _ in staged]).cpu().numpy()          # one read for all the frames
-        t3_ = time.perf_counter()
-        # phase 2: the lists as a map, patches in the kd-tree order (one workgroup builds a tree: the lanes overlap them), encoder
-        for j, i in enumerate(tied):
-            ff, pc = items[i]
-            lane = self._tie_lanes[j % lanes]
-            outs, _, cap = staged[j]
-            with torch.cuda.stream(lane):
-                lists = [o[:int(n_)] for o, n_ in zip(outs, lens[j])]
-                vm2, st2 = self.voxmap_from_lists(*lists, vmap=self.voxmap(cap, slot=3))
-                k = int(both[1, i])
-                bits, flags = self.patches(vm2, ff.key_pts[:k].contiguous())
+                vm, st = self.voxelize(pc, self.voxmap(cap, slot=2))      # exact build: first touch recorded
+                self.voxmap_order(vm, sum(1 << s_ for s_ in range(3) if both[i, s_]))
+                k = int(both[i, 3])
+                bits, flags = self.patches(vm, ff.key_pts[:k].contiguous())   # canonical rule + the tie-split ones in the kd-tree order
                 ff.rows[:k, 0:60] = self.encode(bits.reshape(-1, 64), group=3)
                 ff.flags[:k] = flags
-                statuses.append(st2)
+                statuses.append(st)
+                for t in (bits, flags):
+                    t.record_stream(lane)
         for lane in self._tie_lanes[:min(lanes, len(tied))]:
             cur.wait_stream(lane)
         t4_ = time.perf_counter()
         raise_status(int(np.bitwise_or.reduce(torch.stack([s.reshape(()) for s in statuses]).cpu().numpy())))
         t5_ = time.perf_counter()
-        self.last_tie_times = dict(find_ms=1e3 * (t1_ - t0_), lists_issue_ms=1e3 * (t2_ - t1_), lists_wait_ms=1e3 * (t3_ - t2_),
-                                   redo_issue_ms=1e3 * (t4_ - t3_), redo_wait_ms=1e3 * (t5_ - t4_))
-        return tied, [int(both[0, i]) for i in tied]
+        self.last_tie_times = dict(find_ms=1e3 * (t1_ - t0_), issue_ms=1e3 * (t4_ - t1_), wait_ms=1e3 * (t5_ - t4_))
+        return tied, [int(both[i, :3].sum()) for i in tied]
 
     def match_pose_exact_many(self, pairs, rands, rands_host=None, threads=None):
         """match_pose_exact over many pairs [(fa, fb), ...]: every match and hypothesis launch is issued first, the certificates

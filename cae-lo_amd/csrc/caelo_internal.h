@@ -82,8 +82,8 @@ struct caelo_brick_table {
 struct caelo_kd;   // kdorder.hip: the voxel lists in the reference's order + scikit-learn's kd-tree over them
 struct caelo_voxmap {
     int64_t max_points;
-    caelo_kd *kd;      // allocated by the first caelo_voxmap_from_lists
-    bool kd_lists;     // the map's contents came from ordered lists (caelo_voxmap_from_lists) that kd holds
+    caelo_kd *kd;      // allocated by the first caelo_voxmap_from_lists / caelo_voxmap_order
+    bool kd_lists;     // kd holds the map's voxel lists in the reference's order (caelo_voxmap_from_lists, caelo_voxmap_order)
     caelo_brick_table brick[3];
     // voxel-level first-touch tables (value = smallest inserting point index, 0xFFFFFFFF = none)
     unsigned long long *vkeys[3];
@@ -118,6 +118,7 @@ struct caelo_voxmap {
 
 void kd_destroy(caelo_voxmap *m);
 int kd_store_lists(caelo_voxmap *m, const int16_t *const lists[3], const int64_t ns[3], hipStream_t s);
+int kd_begin_device_lists(caelo_voxmap *m, int16_t *vox_out[3], int32_t **n_out, hipStream_t s);
 int kd_resolve(const caelo_voxmap *m, const float *pts, int pts_ld, int64_t k_max, const int32_t *n_key, uint64_t *bits, uint8_t *flags,
                hipStream_t s);
 

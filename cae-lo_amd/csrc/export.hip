@@ -67,10 +67,14 @@ __global__ void __launch_bounds__(256) k_exp_compact(const unsigned long long *_
 
 // the sorted run is `*count` long (a device word: the call never waits for it); the rest of the padded sort is 0xFF.. keys
 __global__ void __launch_bounds__(256) k_exp_write(const unsigned long long *__restrict__ svals, const int32_t *__restrict__ count,
-                                                   int64_t capacity, int16_t *__restrict__ out, int64_t *__restrict__ count_out) {
+                                                   int64_t capacity, int16_t *__restrict__ out, int64_t *__restrict__ count_out64,
+                                                   int32_t *__restrict__ count_out32) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = *count;
-    if (i == 0) *count_out = n;
+    if (i == 0) {
+        if (count_out64) *count_out64 = n;
+        if (count_out32) *count_out32 = n;
+    }
     if (i >= n || i >= capacity) return;
     const unsigned long long k = svals[i];
     out[3 * i] = (int16_t)((k >> 40) & 0xFFFFF);
@@ -78,10 +82,11 @@ __global__ void __launch_bounds__(256) k_exp_write(const unsigned long long *__r
     out[3 * i + 2] = (int16_t)(k & 0xFFFFF);
 }
 
-CAELO_API int caelo_voxmap_export(caelo_ctx *c, caelo_voxmap *m, int16_t *all0, int16_t *all1, int16_t *all2,
-                                  int64_t capacity, int64_t *counts, void *stream) {
-    CAELO_REQUIRE(c && m && all0 && all1 && all2 && counts, "null argument");
-    hipStream_t s = caelo_stream(stream);
+// The lists of the scales in `mask`, each in first-touch order, written to outs[scale] (device), their lengths to counts64[scale] /
+// counts32[scale] (device; either may be null).  No host round trip: every scale is sorted at its table's size with 0xFF.. keys
+// behind the `count` real ones (a few hundred microseconds of sorting more than the exact length would take, against four stream
+// synchronisations per call -- which is what serialised the tie redo of many frames on side streams, Engine.resolve_ties_many).
+static int export_scales(caelo_voxmap *m, int mask, int16_t *const outs[3], int64_t capacity, int64_t *counts64, int32_t *counts32, hipStream_t s) {
     const size_t vs = (size_t)m->vmask[0] + 1;
     // scratch: block table (keys + first) | sort keys in/out | sort vals in/out | count | rocprim temp
     size_t temp_bytes = 0;
@@ -100,11 +105,8 @@ CAELO_API int caelo_voxmap_export(caelo_ctx *c, caelo_voxmap *m, int16_t *all0, 
     uint32_t *bfirst = (uint32_t *)(v_out + vs);
     int32_t *count = (int32_t *)(bfirst + vs);
     void *temp = (void *)(count + 16);
-    int16_t *outs[3] = {all0, all1, all2};
-    // No host round trip: every scale is sorted at its table's size with 0xFF.. keys behind the `count` real ones (a few hundred
-    // microseconds of sorting more than the exact length would take, against four stream synchronisations per call -- which is what
-    // serialised the tie redo of many frames on side streams, Engine.resolve_ties_many).
     for (int sc = 0; sc < 3; ++sc) {
+        if (!(mask >> sc & 1)) continue;
         const size_t vsc = (size_t)m->vmask[sc] + 1;
         const unsigned grid = (unsigned)((vsc + 255) / 256);
         CAELO_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), s));
@@ -119,8 +121,25 @@ CAELO_API int caelo_voxmap_export(caelo_ctx *c, caelo_voxmap *m, int16_t *all0, 
         CAELO_LAUNCH_CHECK();
         size_t tb = temp_bytes;
         CAELO_HIP(rocprim::radix_sort_pairs(temp, tb, k_in, k_out, v_in, v_out, vsc, 0, 64, s));
-        k_exp_write<<<grid, 256, 0, s>>>(v_out, count, capacity, outs[sc], counts + sc);
+        k_exp_write<<<grid, 256, 0, s>>>(v_out, count, capacity, outs[sc], counts64 ? counts64 + sc : nullptr, counts32 ? counts32 + sc : nullptr);
         CAELO_LAUNCH_CHECK();
     }
     return CAELO_OK;
+}
+
+CAELO_API int caelo_voxmap_export(caelo_ctx *c, caelo_voxmap *m, int16_t *all0, int16_t *all1, int16_t *all2,
+                                  int64_t capacity, int64_t *counts, void *stream) {
+    CAELO_REQUIRE(c && m && all0 && all1 && all2 && counts, "null argument");
+    int16_t *const outs[3] = {all0, all1, all2};
+    return export_scales(m, 7, outs, capacity, counts, nullptr, caelo_stream(stream));
+}
+
+CAELO_API int caelo_voxmap_order(caelo_ctx *c, caelo_voxmap *m, int scale_mask, void *stream) {
+    CAELO_REQUIRE(c && m, "null argument");
+    hipStream_t s = caelo_stream(stream);
+    int16_t *outs[3];
+    int32_t *n_out = nullptr;
+    const int rc = kd_begin_device_lists(m, outs, &n_out, s);
+    if (rc != CAELO_OK) return rc;
+    return export_scales(m, scale_mask & 7, outs, m->max_points, nullptr, n_out, s);
 }

@@ -39,12 +39,10 @@ struct caelo_kd_scale {
     int32_t *start, *end;     // [KD_MAX_NODES]
     int16_t *lo, *hi;         // [KD_MAX_NODES][3]
     int32_t *queue;           // [k_cap] key points whose patch of this scale is tie-split
-    int64_t n;
-    int n_nodes, n_levels;
-};
+};   // (the list's length is a device word, kd.state[16 + scale]: a list ordered on the device never tells the host)
 struct caelo_kd {
     caelo_kd_scale s[3];
-    int32_t *state;           // device: [0..2] queue lengths, [4..6] tree built for the current lists
+    int32_t *state;           // device words: see k_kd_build_top
     int64_t cap, k_cap;
     char *base;
 };
@@ -58,39 +56,60 @@ __global__ void __launch_bounds__(256) k_kd_collect(const uint8_t *__restrict__ 
     const int64_t kp = k0 + pw / 3;
     const int sc = (int)(pw % 3);
     const int64_t K = n_key ? min((int64_t)*n_key, k_max) : k_max;
-    if (kp >= K || !(flags[kp * 3 + sc] & 2) || kd.s[sc].n < KD_MIN_N) return;
+    if (kp >= K || !(flags[kp * 3 + sc] & 2) || kd.state[16 + sc] < KD_MIN_N) return;
     const int q = atomicAdd(&kd.state[sc], 1);
     kd.s[sc].queue[q] = (int32_t)kp;   // (at most k_cap entries per scale and chunk)
 }
 
-// One workgroup per scale.  Level by level; `tpn` threads share a node of the upper levels for the parallel parts (bounding box,
-// key array) and for the quickselect's partitions.
-constexpr int KD_T = 1024;   // threads of the build's workgroup: the upper levels' partitions are chains of dependent L2 reads, more of them in flight
+// The build.  Level by level; `tpn` threads share a node of the upper levels for the parallel parts (bounding box, key array) and
+// for the quickselect's partitions.  Two kernels: k_kd_build_top runs the levels whose nodes are long (one workgroup of 1024 threads
+// per scale, key arrays in global memory) down to the level LT where every node holds at most KD_SUBCAP voxels; from there the 2^LT
+// subtrees are independent and k_kd_build_sub gives each its own workgroup with the key arrays in LDS.  (One workgroup for the whole
+// tree took 9 ms for a 35 k-voxel list, three quarters of it below level 4: dozens of quickselect passes per level, each a handful of
+// barriers and dependent L2 round trips.)
+constexpr int KD_T = 1024;        // threads of the top kernel: the upper levels' partitions are chains of dependent L2 reads, more of them in flight
+constexpr int KD_TS = 256;        // threads of a subtree's workgroup
+constexpr int KD_SUBCAP = 2048;   // voxels of a subtree (keys + keys2 + ev in LDS: 40 KB)
 
-__global__ void __launch_bounds__(KD_T) k_kd_build(caelo_kd kd) {
-    const caelo_kd_scale T = kd.s[blockIdx.x];
-    if (kd.state[blockIdx.x] == 0 || kd.state[4 + blockIdx.x] != 0) return;   // no tie-split patch of this scale / tree already built
-    __shared__ int s_lo[KD_T][3], s_hi[KD_T][3];
-    __shared__ int s_gave_up;   // a node's quickselect exceeded its budget (below): the tree is not built, the canonical rule stays
-    __shared__ int q_left[KD_T], q_right[KD_T], q_act[KD_T], q_lf[KD_T], s_cl[KD_T], s_cg[KD_T];   // per node of a pass / per thread
-    __shared__ long long q_budget[KD_T];
+template <int NT>
+struct KdShared {
+    int lo[NT][3], hi[NT][3];
+    int left[NT], right[NT], act[NT], lf[NT], cl[NT], cg[NT];   // per node of a pass / per unit
+    long long budget[NT];
+    int gave_up;   // a node's quickselect exceeded its budget (below): the tree is not built, the canonical rule stays
+};
+
+// n_levels = int(log2(max(1, (n - 1) / 30)) + 1) in integers: the largest L with 30 * 2^L <= n - 1, plus one
+__host__ __device__ inline int kd_levels_of(int64_t n) {
+    if (n < KD_MIN_N) return 0;
+    int L = 0;
+    while (((int64_t)KD_LEAF << (L + 1)) <= n - 1) ++L;
+    return L + 1;
+}
+// the first level whose nodes hold at most KD_SUBCAP voxels (a node of level L holds at most ceil(n / 2^L))
+__host__ __device__ inline int kd_top_levels_of(int64_t n) {
+    int L = 0;
+    while (((n + ((int64_t)1 << L) - 1) >> L) > KD_SUBCAP) ++L;
+    return L;
+}
+
+// levels [level0, level1) of the subtree under node `root` of level0 (root = its index among that level's nodes); the key arrays
+// A0 / KB0 / EV0 are addressed by (position in idx) - off
+template <int NT>
+__device__ __forceinline__ void kd_build_levels(const caelo_kd_scale &T, const int n_nodes, KdShared<NT> &S, const int level0, const int level1,
+                                                const int root, unsigned long long *A0, unsigned long long *KB0, int32_t *EV0, const int off,
+                                                const int scale_for_print, const int n_for_print) {
     const int tid = threadIdx.x;
-    if (tid == 0) s_gave_up = 0;
-    const int64_t n = T.n;
-    for (int64_t i = tid; i < n; i += KD_T) T.idx[i] = (int32_t)i;
-    for (int i = tid; i < T.n_nodes; i += KD_T) { T.start[i] = 0; T.end[i] = 0; }   // (children of a node that did not split stay empty)
-    __syncthreads();
-    if (tid == 0) { T.start[0] = 0; T.end[0] = (int32_t)n; }
-    __syncthreads();
-    for (int level = 0; level < T.n_levels; ++level) {
+    for (int level = level0; level < level1; ++level) {
 #ifdef KD_PROFILE
         const long long t_level = wall_clock64();
         int n_pass = 0;
         long long t_count = 0, t_write = 0, t_resolve = 0, t_copy = 0;
 #endif
-        const int first = (1 << level) - 1, count = 1 << level;
-        const int tpn = count >= KD_T ? 1 : KD_T >> level;      // threads per node
-        const int per_pass = KD_T / tpn;                       // nodes in flight
+        const int d = level - level0, count = 1 << d;           // nodes of this (sub)tree on the level
+        const int first = (1 << level) - 1 + (root << d);
+        const int tpn = count >= NT ? 1 : NT >> d;              // threads per node
+        const int per_pass = NT / tpn;                       // nodes in flight
         for (int base = 0; base < count; base += per_pass) {
             const int local = tid / tpn, sub = tid % tpn;
             const int W = tpn < 64 ? tpn : 64, nu = tpn / W;          // lanes per unit, units per node (see the partition below)
@@ -108,14 +127,14 @@ __global__ void __launch_bounds__(KD_T) k_kd_build(caelo_kd kd) {
                 for (int j = 0; j < 3; ++j) { lo[j] = min(lo[j], (int)p[j]); hi[j] = max(hi[j], (int)p[j]); }
             }
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { s_lo[tid][j] = lo[j]; s_hi[tid][j] = hi[j]; }
+            for (int j = 0; j < 3; ++j) { S.lo[tid][j] = lo[j]; S.hi[tid][j] = hi[j]; }
             __syncthreads();
             for (int o = tpn >> 1; o > 0; o >>= 1) {
                 if (sub < o)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
-                        s_lo[tid][j] = min(s_lo[tid][j], s_lo[tid + o][j]);
-                        s_hi[tid][j] = max(s_hi[tid][j], s_hi[tid + o][j]);
+                        S.lo[tid][j] = min(S.lo[tid][j], S.lo[tid + o][j]);
+                        S.hi[tid][j] = max(S.hi[tid][j], S.hi[tid + o][j]);
                     }
                 __syncthreads();
             }
@@ -123,18 +142,18 @@ __global__ void __launch_bounds__(KD_T) k_kd_build(caelo_kd kd) {
             int jmax = 0, spread = 0;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                lo[j] = s_lo[lead][j]; hi[j] = s_hi[lead][j];
+                lo[j] = S.lo[lead][j]; hi[j] = S.hi[lead][j];
                 if (hi[j] - lo[j] > spread) { spread = hi[j] - lo[j]; jmax = j; }
             }
             if (live && sub == 0)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) { T.lo[3 * node + j] = (int16_t)lo[j]; T.hi[3 * node + j] = (int16_t)hi[j]; }
-            const bool split = live && 2 * node + 1 < T.n_nodes && e - s >= 2;
+            const bool split = live && 2 * node + 1 < n_nodes && e - s >= 2;
             // ---- the node's (coordinate, index) keys, consecutive
             if (split)
                 for (int i = s + sub; i < e; i += tpn) {
                     const int32_t p = T.idx[i];
-                    T.keys[i] = ((unsigned long long)(unsigned)((int)T.vox[3 * (int64_t)p + jmax] + 32768) << 32) | (unsigned)p;
+                    A0[i - off] = ((unsigned long long)(unsigned)((int)T.vox[3 * (int64_t)p + jmax] + 32768) << 32) | (unsigned)p;
                 }
             __syncthreads();
             // ---- quickselect around position n / 2: Lomuto, last element as the pivot, strict <.  The ORDER the partition leaves behind
@@ -148,26 +167,26 @@ __global__ void __launch_bounds__(KD_T) k_kd_build(caelo_kd kd) {
             // count (chunk per thread), scan, write the stable front and the event list, resolve, copy back.  (Rounds 4's one thread per
             // node took 9 ms for a 9 k-voxel list -- 85 % of what re-doing a frame's tie-split patches cost; validated against the serial
             // form on random cases in Python and by the patches of the truncation fixtures.)
-            unsigned long long *a = T.keys + s, *kb = T.keys2 + s;
-            int32_t *ev = T.ev + s;
+            unsigned long long *a = A0 + (s - off), *kb = KB0 + (s - off);
+            int32_t *ev = EV0 + (s - off);
             const int m = e - s, nmid = m / 2;
             if (sub == 0) {
-                q_left[local] = 0; q_right[local] = m - 1; q_act[local] = split ? 1 : 0;
+                S.left[local] = 0; S.right[local] = m - 1; S.act[local] = split ? 1 : 0;
                 // Lomuto with the last element as the pivot is quadratic on a list sorted along the split dimension (the library pays
                 // that too).  Lists in first-touch order are PARTLY sorted (a scan line sweeps the azimuth): measured on the clutter
                 // scene's lists the worst node needs 87 passes' worth of its length (a first budget of 48 gave up on real frames -- the
                 // 600-frame soak caught it by the descriptors of the patches it left on the canonical rule).  256 passes' worth.
-                q_budget[local] = 256ll * m + 65536;
+                S.budget[local] = 256ll * m + 65536;
             }
             for (;;) {
                 __syncthreads();   // (the reduction below is a barrier, not a fence: the q_* words written at the end of the previous pass must have landed)
-                if (!__syncthreads_or(sub == 0 && q_act[local] != 0)) break;
+                if (!__syncthreads_or(sub == 0 && S.act[local] != 0)) break;
 #ifdef KD_PROFILE
                 ++n_pass;
                 long long t_ph = wall_clock64();
 #endif
-                const bool act = q_act[local] != 0;
-                const int left = act ? q_left[local] : 0, right = act ? q_right[local] : -1;
+                const bool act = S.act[local] != 0;
+                const int left = act ? S.left[local] : 0, right = act ? S.right[local] : -1;
                 const int len = right - left;                            // elements in front of the pivot
                 // The node's threads work in UNITS of W = min(tpn, 64) lanes of one wavefront: a unit owns a contiguous chunk and walks it
                 // W consecutive elements at a time (coalesced; a thread walking its own chunk element by element made every load of a
@@ -185,24 +204,24 @@ __global__ void __launch_bounds__(KD_T) k_kd_build(caelo_kd kd) {
                     if (fg < 0 && mg) fg = b0 + (int)__builtin_ctzll(mg);
                 }
                 const int cg = (i1 > i0 ? i1 - i0 : 0) - cl;
-                if (lu == 0) { s_cl[ug] = cl; s_cg[ug] = cg; }
+                if (lu == 0) { S.cl[ug] = cl; S.cg[ug] = cg; }
                 __syncthreads();
 #ifdef KD_PROFILE
                 t_count += wall_clock64() - t_ph; t_ph = wall_clock64();
 #endif
                 for (int o = 1; o < nu; o <<= 1) {                       // inclusive scans over the node's units (nu is the same for all)
                     int x = 0, y = 0;
-                    if (u >= o) { x = s_cl[ug - o]; y = s_cg[ug - o]; }
+                    if (u >= o) { x = S.cl[ug - o]; y = S.cg[ug - o]; }
                     __syncthreads();
-                    if (lu == 0) { s_cl[ug] += x; s_cg[ug] += y; }
+                    if (lu == 0) { S.cl[ug] += x; S.cg[ug] += y; }
                     __syncthreads();
                 }
                 const int lead2 = ug - u;
-                const int lb = s_cl[ug] - cl, gb = s_cg[ug] - cg;        // below / not below the pivot in front of this unit's chunk
-                const int L = s_cl[lead2 + nu - 1], G = s_cg[lead2 + nu - 1];
-                if (act && fg >= 0 && gb == 0 && lu == 0) q_lf[local] = lb + (fg - i0);   // elements below the pivot in front of the FIRST one that is not
+                const int lb = S.cl[ug] - cl, gb = S.cg[ug] - cg;        // below / not below the pivot in front of this unit's chunk
+                const int L = S.cl[lead2 + nu - 1], G = S.cg[lead2 + nu - 1];
+                if (act && fg >= 0 && gb == 0 && lu == 0) S.lf[local] = lb + (fg - i0);   // elements below the pivot in front of the FIRST one that is not
                 __syncthreads();
-                const int Lf = G > 0 ? q_lf[local] : L, R = L - Lf;
+                const int Lf = G > 0 ? S.lf[local] : L, R = L - Lf;
                 {
                     int pq0 = gb, l0 = lb;
                     const unsigned long long below = (1ull << lu) - 1ull;
@@ -234,7 +253,7 @@ __global__ void __launch_bounds__(KD_T) k_kd_build(caelo_kd kd) {
                     int ee = R + 1 + k, x, steps = 0;
                     while ((x = ev[left + ee]) < 0) {
                         ee = -x - 1;
-                        if (++steps > (1 << 22)) { s_gave_up = 1; x = left; break; }
+                        if (++steps > (1 << 22)) { S.gave_up = 1; x = left; break; }
                     }
                     kb[left + L + 1 + k] = a[x];
                 }
@@ -253,7 +272,7 @@ __global__ void __launch_bounds__(KD_T) k_kd_build(caelo_kd kd) {
                     for (int i = left; i <= right; ++i) {
                         const unsigned long long v = a[i];
                         const unsigned kv = (unsigned)(v >> 32), id = (unsigned)v;
-                        if (id >= (unsigned)n) bad |= 1;
+                        if (id >= (unsigned)n_for_print) bad |= 1;
                         if (i < left + L && !(kv < pvv)) bad |= 2;
                         if (i > left + L && (kv < pvv)) bad |= 4;
                         if (i == left + L && kv != pvv) bad |= 8;
@@ -264,11 +283,11 @@ __global__ void __launch_bounds__(KD_T) k_kd_build(caelo_kd kd) {
 #endif
                 if (act && sub == 0) {
                     const int mid = left + L;
-                    q_budget[local] -= (long long)len + 1;
-                    if (mid == nmid) q_act[local] = 0;
-                    else if (q_budget[local] < 0) { s_gave_up = 1; q_act[local] = 0; }
-                    else if (mid < nmid) q_left[local] = mid + 1;
-                    else q_right[local] = mid - 1;
+                    S.budget[local] -= (long long)len + 1;
+                    if (mid == nmid) S.act[local] = 0;
+                    else if (S.budget[local] < 0) { S.gave_up = 1; S.act[local] = 0; }
+                    else if (mid < nmid) S.left[local] = mid + 1;
+                    else S.right[local] = mid - 1;
                 }
             }
             if (split && sub == 0) {
@@ -277,15 +296,69 @@ __global__ void __launch_bounds__(KD_T) k_kd_build(caelo_kd kd) {
             }
             __syncthreads();
             if (split)
-                for (int i = s + sub; i < e; i += tpn) T.idx[i] = (int32_t)(unsigned)T.keys[i];
+                for (int i = s + sub; i < e; i += tpn) T.idx[i] = (int32_t)(unsigned)A0[i - off];
             __syncthreads();
         }
 #ifdef KD_PROFILE
-        if (tid == 0) printf("kd build scale %d n %d level %2d: %7.1f us, %4d passes (count %.1f write %.1f resolve %.1f copy %.1f us)\n", (int)blockIdx.x, (int)n, level,
-                             (wall_clock64() - t_level) * 0.01, n_pass, t_count * 0.01, t_write * 0.01, t_resolve * 0.01, t_copy * 0.01);
+        if (tid == 0 && root == 0) printf("kd build scale %d n %d level %2d (from %d): %7.1f us, %4d passes (count %.1f write %.1f resolve %.1f copy %.1f us)\n",
+                                          scale_for_print, n_for_print, level, level0, (wall_clock64() - t_level) * 0.01, n_pass, t_count * 0.01,
+                                          t_write * 0.01, t_resolve * 0.01, t_copy * 0.01);
 #endif
     }
-    if (tid == 0) kd.state[4 + blockIdx.x] = s_gave_up ? 2 : 1;   // 2: not built (the queries leave flag 2 and the canonical rule in place)
+}
+
+// kd.state: [0..2] queue lengths | [4..6] 0 no tree, 1 built, 2 not built (a quickselect gave up / too many nodes: the canonical rule stays),
+// 3 upper levels built, subtrees pending | [8..10] a subtree gave up | [12..14] subtrees done | [16..18] list lengths
+__global__ void __launch_bounds__(KD_T) k_kd_build_top(caelo_kd kd) {
+    const int sc = blockIdx.x;
+    const caelo_kd_scale T = kd.s[sc];
+    if (kd.state[sc] == 0 || kd.state[4 + sc] != 0) return;   // no tie-split patch of this scale / tree already built (or given up)
+    __shared__ KdShared<KD_T> S;
+    const int tid = threadIdx.x;
+    const int n = kd.state[16 + sc];
+    const int n_levels = kd_levels_of(n), n_nodes = (1 << n_levels) - 1;
+    if (n_nodes > KD_MAX_NODES || n > kd.cap) { if (tid == 0) kd.state[4 + sc] = 2; return; }
+    if (tid == 0) S.gave_up = 0;
+    for (int i = tid; i < n; i += KD_T) T.idx[i] = i;
+    for (int i = tid; i < n_nodes; i += KD_T) { T.start[i] = 0; T.end[i] = 0; }   // (children of a node that did not split stay empty)
+    __syncthreads();
+    if (tid == 0) { T.start[0] = 0; T.end[0] = n; }
+    __syncthreads();
+    const int lt = min(kd_top_levels_of(n), n_levels);
+    kd_build_levels<KD_T>(T, n_nodes, S, 0, lt, 0, T.keys, T.keys2, T.ev, 0, sc, n);
+    __syncthreads();
+    __threadfence();
+    if (tid == 0) kd.state[4 + sc] = S.gave_up ? 2 : 3;
+}
+
+__global__ void __launch_bounds__(KD_TS) k_kd_build_sub(caelo_kd kd) {
+    const int sc = blockIdx.y;
+    const caelo_kd_scale T = kd.s[sc];
+    if (kd.state[4 + sc] != 3) return;   // (stays 3 until the LAST subtree of this scale is done)
+    const int n = kd.state[16 + sc];
+    const int n_levels = kd_levels_of(n), n_nodes = (1 << n_levels) - 1;
+    const int lt = min(kd_top_levels_of(n), n_levels), n_sub = 1 << lt;
+    const int root = blockIdx.x;
+    if (root >= n_sub) return;
+    __shared__ KdShared<KD_TS> S;
+    __shared__ unsigned long long s_a[KD_SUBCAP], s_kb[KD_SUBCAP];
+    __shared__ int32_t s_ev[KD_SUBCAP];
+    const int tid = threadIdx.x;
+    if (tid == 0) S.gave_up = 0;
+    __syncthreads();
+    const int node0 = (1 << lt) - 1 + root;
+    const int s0 = lt < n_levels ? T.start[node0] : 0, e0 = lt < n_levels ? T.end[node0] : 0;
+    if (e0 - s0 > KD_SUBCAP) { if (tid == 0) S.gave_up = 1; }           // (cannot happen: ceil(n / 2^lt) <= KD_SUBCAP)
+    else if (e0 > s0) kd_build_levels<KD_TS>(T, n_nodes, S, lt, n_levels, root, s_a, s_kb, s_ev, s0, sc, n);
+    __syncthreads();
+    if (tid == 0) {
+        if (S.gave_up) atomicOr(&kd.state[8 + sc], 1);
+        __threadfence();
+        if (atomicAdd(&kd.state[12 + sc], 1) == n_sub - 1) {
+            __threadfence();
+            kd.state[4 + sc] = atomicOr(&kd.state[8 + sc], 0) ? 2 : 1;
+        }
+    }
 }
 
 struct KdHeapLds {
@@ -314,6 +387,7 @@ __global__ void __launch_bounds__(64) k_kd_query(caelo_kd kd, const float *__res
     const int cnt = min(kd.state[sc], (int)kd.k_cap);
     if ((int)blockIdx.x >= cnt || kd.state[4 + sc] != 1) return;
     __shared__ KdHeapLds L;
+    const int n_nodes = (1 << kd_levels_of(kd.state[16 + sc])) - 1;
     const int lane = threadIdx.x;
     const int kp = T.queue[blockIdx.x];
     const double vs = sc == 0 ? 0.02 : (sc == 1 ? 0.02 * 8 : 0.02 * 32);                    // Voxel.py:31
@@ -331,7 +405,7 @@ __global__ void __launch_bounds__(64) k_kd_query(caelo_kd kd, const float *__res
         const int node = st_node[sp], lb = st_lb[sp];
         if (lb > L.dist[0]) continue;
         const int s = T.start[node], e = T.end[node];
-        const bool leaf = 2 * node + 1 >= T.n_nodes || e - s < 2;
+        const bool leaf = 2 * node + 1 >= n_nodes || e - s < 2;
         if (leaf) {
             for (int c0 = s; c0 < e; c0 += 64) {
                 const int i = c0 + lane;
@@ -404,49 +478,68 @@ void kd_destroy(caelo_voxmap *m) {
     }
 }
 
+static int kd_alloc(caelo_voxmap *m) {
+    if (m->kd) return CAELO_OK;
+    caelo_kd *kd = new caelo_kd();
+    kd->cap = m->max_points;
+    kd->k_cap = CAELO_MAX_KEYPTS;
+    const size_t per = (size_t)kd->cap * (6 + 4 + 8 + 8 + 4) + 256 * 5;
+    const size_t nodes = (size_t)KD_MAX_NODES * (4 + 4 + 6 + 6) + 256 * 4;
+    const size_t total = 3 * (per + nodes + (size_t)kd->k_cap * 4 + 256) + 256;
+    if (hipMalloc((void **)&kd->base, total) != hipSuccess) {
+        delete kd;
+        caelo_set_error("kd_alloc: out of device memory");
+        return CAELO_ERR_HIP;
+    }
+    char *p = kd->base;
+    auto take = [&p](size_t bytes) { char *r = p; p += (bytes + 255) / 256 * 256; return r; };
+    kd->state = (int32_t *)take(256);
+    for (int i = 0; i < 3; ++i) {
+        caelo_kd_scale &T = kd->s[i];
+        T.keys = (unsigned long long *)take((size_t)kd->cap * 8);
+        T.keys2 = (unsigned long long *)take((size_t)kd->cap * 8);
+        T.ev = (int32_t *)take((size_t)kd->cap * 4);
+        T.idx = (int32_t *)take((size_t)kd->cap * 4);
+        T.vox = (int16_t *)take((size_t)kd->cap * 6);
+        T.start = (int32_t *)take((size_t)KD_MAX_NODES * 4);
+        T.end = (int32_t *)take((size_t)KD_MAX_NODES * 4);
+        T.lo = (int16_t *)take((size_t)KD_MAX_NODES * 6);
+        T.hi = (int16_t *)take((size_t)KD_MAX_NODES * 6);
+        T.queue = (int32_t *)take((size_t)kd->k_cap * 4);
+    }
+    m->kd = kd;
+    return CAELO_OK;
+}
+
+namespace {
+__global__ void k_kd_set_n(int32_t *state, int n0, int n1, int n2) { state[16] = n0; state[17] = n1; state[18] = n2; }
+}
+
 // caelo_voxmap_from_lists: keep the three lists in the caller's order (device copies), forget any tree of older lists
 int kd_store_lists(caelo_voxmap *m, const int16_t *const lists[3], const int64_t ns[3], hipStream_t s) {
-    if (!m->kd) {
-        caelo_kd *kd = new caelo_kd();
-        kd->cap = m->max_points;
-        kd->k_cap = CAELO_MAX_KEYPTS;
-        const size_t per = (size_t)kd->cap * (6 + 4 + 8 + 8 + 4) + 256 * 5;
-        const size_t nodes = (size_t)KD_MAX_NODES * (4 + 4 + 6 + 6) + 256 * 4;
-        const size_t total = 3 * (per + nodes + (size_t)kd->k_cap * 4 + 256) + 256;
-        if (hipMalloc((void **)&kd->base, total) != hipSuccess) {
-            delete kd;
-            caelo_set_error("kd_store_lists: out of device memory");
-            return CAELO_ERR_HIP;
-        }
-        char *p = kd->base;
-        auto take = [&p](size_t bytes) { char *r = p; p += (bytes + 255) / 256 * 256; return r; };
-        kd->state = (int32_t *)take(256);
-        for (int i = 0; i < 3; ++i) {
-            caelo_kd_scale &T = kd->s[i];
-            T.keys = (unsigned long long *)take((size_t)kd->cap * 8);
-            T.keys2 = (unsigned long long *)take((size_t)kd->cap * 8);
-            T.ev = (int32_t *)take((size_t)kd->cap * 4);
-            T.idx = (int32_t *)take((size_t)kd->cap * 4);
-            T.vox = (int16_t *)take((size_t)kd->cap * 6);
-            T.start = (int32_t *)take((size_t)KD_MAX_NODES * 4);
-            T.end = (int32_t *)take((size_t)KD_MAX_NODES * 4);
-            T.lo = (int16_t *)take((size_t)KD_MAX_NODES * 6);
-            T.hi = (int16_t *)take((size_t)KD_MAX_NODES * 6);
-            T.queue = (int32_t *)take((size_t)kd->k_cap * 4);
-        }
-        m->kd = kd;
-    }
+    const int rc = kd_alloc(m);
+    if (rc != CAELO_OK) return rc;
     caelo_kd *kd = m->kd;
     CAELO_HIP(hipMemsetAsync(kd->state, 0, 256, s));
     for (int i = 0; i < 3; ++i) {
-        caelo_kd_scale &T = kd->s[i];
-        T.n = ns[i];
-        const double q = (double)(ns[i] - 1) / (double)KD_LEAF;
-        T.n_levels = ns[i] >= KD_MIN_N ? (int)(log2(q > 1.0 ? q : 1.0) + 1.0) : 0;
-        T.n_nodes = (1 << T.n_levels) - 1;
-        if (T.n_nodes > KD_MAX_NODES) { caelo_set_error("kd_store_lists: list too long for the node table"); return CAELO_ERR_CAPACITY; }
-        if (ns[i] > 0) CAELO_HIP(hipMemcpyAsync(T.vox, lists[i], (size_t)ns[i] * 6, hipMemcpyDeviceToDevice, s));
+        if ((1 << kd_levels_of(ns[i])) - 1 > KD_MAX_NODES || ns[i] > kd->cap) { caelo_set_error("kd_store_lists: list too long for the node table"); return CAELO_ERR_CAPACITY; }
+        if (ns[i] > 0) CAELO_HIP(hipMemcpyAsync(kd->s[i].vox, lists[i], (size_t)ns[i] * 6, hipMemcpyDeviceToDevice, s));
     }
+    k_kd_set_n<<<1, 1, 0, s>>>(kd->state, (int)ns[0], (int)ns[1], (int)ns[2]);
+    CAELO_LAUNCH_CHECK();
+    m->kd_lists = true;
+    return CAELO_OK;
+}
+
+// caelo_voxmap_order: the lists are written on the device (export.hip) straight into the tree's storage -- vox_out[scale] [cap][3],
+// n_out [3] (device words the build reads); every word of the state is wiped first
+int kd_begin_device_lists(caelo_voxmap *m, int16_t *vox_out[3], int32_t **n_out, hipStream_t s) {
+    const int rc = kd_alloc(m);
+    if (rc != CAELO_OK) return rc;
+    caelo_kd *kd = m->kd;
+    CAELO_HIP(hipMemsetAsync(kd->state, 0, 256, s));
+    for (int i = 0; i < 3; ++i) vox_out[i] = kd->s[i].vox;
+    *n_out = kd->state + 16;
     m->kd_lists = true;
     return CAELO_OK;
 }
@@ -460,7 +553,9 @@ int kd_resolve(const caelo_voxmap *m, const float *pts, int pts_ld, int64_t k_ma
         CAELO_HIP(hipMemsetAsync(kd.state, 0, 12, s));   // queue lengths (the built flags stay)
         k_kd_collect<<<(unsigned)((kd.k_cap * 3 + 255) / 256), 256, 0, s>>>(flags, k0, k_max, n_key, kd);
         CAELO_LAUNCH_CHECK();
-        k_kd_build<<<3, KD_T, 0, s>>>(kd);
+        k_kd_build_top<<<3, KD_T, 0, s>>>(kd);
+        CAELO_LAUNCH_CHECK();
+        k_kd_build_sub<<<dim3(1u << kd_top_levels_of(kd.cap), 3), KD_TS, 0, s>>>(kd);
         CAELO_LAUNCH_CHECK();
         k_kd_query<<<dim3((unsigned)kd.k_cap, 3), 64, 0, s>>>(kd, pts, pts_ld, (unsigned long long *)bits, flags);
         CAELO_LAUNCH_CHECK();

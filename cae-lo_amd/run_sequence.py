@@ -166,7 +166,7 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
             # such a frame is part of are matched again.  One synchronisation per chunk; rare (none on KITTI-shaped scans).
             if bool((batch.flags[:c1 - c0] & 2).any().item()):
                 items = [(batch.frame(j), scans[j].to(eng.device)) for j in range(c1 - c0)]
-                tied, n_t = eng.resolve_ties_many(items)         # the redos overlap on side streams
+                tied, n_t = eng.resolve_ties_many(items, batch=batch)         # the redos overlap on side streams
                 if tie_log is not None:
                     tie_log.extend((c0 + j, n_) for j, n_ in zip(tied, n_t))
                 redo = sorted({t for u in tied for t in (u, u + 1) if t < c1 - c0 and (t > 0 or prev is not None)})

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CAELO_ABI_VERSION 3   /* 3: caelo_ransac / caelo_frame_job carry a certificate pointer; host half of the exact RANSAC (caelo_host_*) */
+#define CAELO_ABI_VERSION 4   /* 4: caelo_voxmap_export never waits for the device (a count above capacity is the overflow report), caelo_voxmap_order; 3: certificates, caelo_host_* */
 
 /* geometry fixed by the reference: SphericalRing.py:28-58, Voxel.py:15-52 */
 #define CAELO_RING_H 69
@@ -134,6 +134,12 @@ int caelo_voxmap_dump(caelo_ctx *ctx, const caelo_voxmap *map, int scale, uint64
  * above `capacity` means only the first `capacity` voxels of that scale were written (the caller checks after reading counts). */
 int caelo_voxmap_export(caelo_ctx *ctx, caelo_voxmap *map, int16_t *all0, int16_t *all1, int16_t *all2,
                         int64_t capacity, int64_t *counts, void *stream);
+/* Records the first-touch order of the map's voxel lists (scales in `scale_mask`, bit s = scale s) on the device, so that
+ * caelo_patches on THIS map redoes its tie-split patches in scikit-learn's kd-tree order (csrc/kdorder.hip) -- what
+ * caelo_voxmap_export + caelo_voxmap_from_lists + caelo_patches give, without the lists leaving the map and without a host
+ * round trip for their lengths.  Valid after caelo_voxelize (which records first touch); asynchronous on `stream`.  A tie-split
+ * patch of a scale outside the mask keeps the canonical rule and flag bit 2. */
+int caelo_voxmap_order(caelo_ctx *ctx, caelo_voxmap *map, int scale_mask, void *stream);
 /* Build the map from reference-format lists instead (GetPatchesList called with arrays). */
 int caelo_voxmap_from_lists(caelo_ctx *ctx, caelo_voxmap *map, const int16_t *all0, int64_t n0, const int16_t *all1,
                             int64_t n1, const int16_t *all2, int64_t n2, int32_t *status, void *stream);

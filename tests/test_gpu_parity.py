@@ -608,6 +608,8 @@ def test_tie_redo_on_side_streams_equals_the_serial_redo(engine, scans):
         if n_t:
             want_tied.append(j); want_n.append(n_t)
     tied, counts = engine.resolve_ties_many([(b.frame(j), pcs[j]) for j in range(len(ids))], lanes=3)
+    c = pipe.run(pcs, rnd, certify=True, rands_host=draws)
+    assert engine.resolve_ties_many([(c.frame(j), pcs[j]) for j in range(len(ids))], batch=c) == (tied, counts) and torch.equal(c.rows, b.rows)
     torch.cuda.synchronize()
     assert tied == want_tied and counts == want_n and 3 in tied and counts[tied.index(3)] == 11
     assert torch.equal(a.rows, b.rows) and torch.equal(a.flags, b.flags)
@@ -1699,6 +1701,7 @@ def test_pipeline_certified_poses_equal_the_oracle_on_the_pipelines_own_matches(
     rnd = [torch.from_numpy(d).to(engine.device) for d in draws]
     pipe = engine.pipeline(4)
     kernels_result = pipe.run(dpcs, rnd).result.clone()           # the kernels' own results (float64 fits, no host half)
+    pipe.cert_stats()                                             # (counts since the last call: another test may share this pipeline object)
     out = pipe.run(dpcs, rnd, certify=True)                       # the certifier thread of the pipeline runs the host half
     res, masks, evals, status = out.exact
     assert status[0] == 3 and (status[1:] == 0).all()            # frame 0 has no predecessor

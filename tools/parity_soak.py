@@ -110,7 +110,7 @@ def soak(engine, orc, models, scene, n_frames, seed_base=5000, batch=8, log=None
     # reference's way (Engine.resolve_ties: ordered voxel lists, scikit-learn's kd-tree order), then the two pairs they are part of
     fl = out.flags.cpu().numpy()
     tied = [i for i in range(n_frames) if (fl[i] & 2).any()]
-    tied2, n_tied_patches = engine.resolve_ties_many([(out.frame(i), dpcs[i]) for i in range(n_frames)])
+    tied2, n_tied_patches = engine.resolve_ties_many([(out.frame(i), dpcs[i]) for i in range(n_frames)], batch=out)
     assert tied2 == tied
     n_tied_patches = sum(n_tied_patches)
     redo = sorted({j for t in tied for j in (t, t + 1) if 1 <= j < n_frames})
