@@ -8,7 +8,7 @@ from caelo.engine import Engine, raise_status
 eng = Engine()
 def T(label, fn):
     torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize()
-    print("   %-34s %8.1f us" % (label, 1e6 * (time.perf_counter() - t))); return r
+    print("   %-58s %8.1f us" % (label, 1e6 * (time.perf_counter() - t))); return r
 n_done = 0
 for f in range(40):
     pc = torch.from_numpy(synth.make_scan(f, quantum=1e-3, scene_kind="clutter")).to(eng.device)
@@ -20,9 +20,9 @@ for f in range(40):
     for rep in range(2):
         cap = max(eng.max_points, pc.shape[0])
         vm, st = T("voxelize (exact, first touch)", lambda: eng.voxelize(pc, eng.voxmap(cap, slot=2)))
-        lists = T("voxmap_export (radix sort)", lambda: [a.contiguous() for a in eng.voxmap_export(vm, cap)])
-        print("      list lengths", [len(a) for a in lists])
-        vm2, st2 = T("voxmap_from_lists", lambda: eng.voxmap_from_lists(*lists, vmap=eng.voxmap(cap, slot=3)))
+        mask = sum(1 << s for s in range(3) if (fl[:, s] & 2).any())
+        T("voxmap_order (scales %s: compaction + padded sort)" % [s for s in range(3) if mask >> s & 1], lambda: eng.voxmap_order(vm, mask))
+        vm2 = vm
         k = int(ff.n_key.item())
         kp = ff.key_pts[:k].contiguous()
         bits, flags = T("patches (+ kd collect/build/query)", lambda: eng.patches(vm2, kp))
