@@ -362,9 +362,6 @@ __global__ void __launch_bounds__(KD_TS) k_kd_build_sub(caelo_kd kd) {
 }
 
 struct KdHeapLds {
-    int dist[KD_K];
-    int ind[KD_K];
-    int leaf_d[64];
     unsigned long long patch[64];
 };
 
@@ -379,7 +376,61 @@ __device__ inline int kd_min_rdist(const caelo_kd_scale &T, int node, const int 
     return r;
 }
 
-// One wavefront per tie-split patch: lane 0 walks the tree and owns the heap (LDS); a leaf's distances are computed by all lanes.
+// The query's max-heap of 496 (distance, index) pairs lives in REGISTERS, 1-based: position p (root = 1, children 2p and 2p + 1) is
+// lane p & 63 of register p >> 6, so that heap level L sits in compile-time registers (levels 0-5: register 0, level 6: register 1,
+// level 7: registers 2-3, level 8: registers 4-7).  Every position of the sift-down is uniform and the sift-down is unrolled by
+// level: a read is a v_readlane (plus scalar selects on the two deepest levels), a write a one-lane select -- a few tens of cycles
+// per level where an LDS round trip plus the hop to a scalar register took ~400: a push cost 1.65 us with the heap in LDS (~750
+// pushes per patch: 1.25 of the query's 1.35 ms).  (A run-time switch over the register compiled to branch chains and was SLOWER.)
+template <int L>
+__device__ __forceinline__ int kd_heap_get(const int (&a)[8], int pos) {   // pos uniform, on heap level L
+    const int l = pos & 63;
+    if constexpr (L <= 5) return __builtin_amdgcn_readlane(a[0], l);
+    else if constexpr (L == 6) return __builtin_amdgcn_readlane(a[1], l);
+    else if constexpr (L == 7) {
+        const int x = __builtin_amdgcn_readlane(a[2], l), y = __builtin_amdgcn_readlane(a[3], l);
+        return (pos & 64) ? y : x;
+    } else {
+        const int x0 = __builtin_amdgcn_readlane(a[4], l), x1 = __builtin_amdgcn_readlane(a[5], l);
+        const int x2 = __builtin_amdgcn_readlane(a[6], l), x3 = __builtin_amdgcn_readlane(a[7], l);
+        const int r = (pos >> 6) & 3;
+        return r == 0 ? x0 : (r == 1 ? x1 : (r == 2 ? x2 : x3));
+    }
+}
+template <int L>
+__device__ __forceinline__ void kd_heap_set(int (&a)[8], int pos, int v, int lane) {   // pos, v uniform
+    if constexpr (L <= 5) a[0] = lane == pos ? v : a[0];
+    else if constexpr (L == 6) a[1] = lane + 64 == pos ? v : a[1];
+    else if constexpr (L == 7) { a[2] = lane + 128 == pos ? v : a[2]; a[3] = lane + 192 == pos ? v : a[3]; }
+    else { a[4] = lane + 256 == pos ? v : a[4]; a[5] = lane + 320 == pos ? v : a[5]; a[6] = lane + 384 == pos ? v : a[6]; a[7] = lane + 448 == pos ? v : a[7]; }
+}
+// heap push of (val, iv) at the root, the library's sift-down: the larger child moves up while it is larger than val (the FIRST child
+// when the two are equal); position p is on level L
+template <int L>
+__device__ __forceinline__ void kd_heap_sift(int (&hd)[8], int (&hx)[8], int p, int val, int iv, int lane) {
+    if constexpr (L < 8) {
+        const int c1 = 2 * p, c2 = c1 + 1;
+        if (c1 <= KD_K) {
+            int sw = 0, dsw = 0;
+            const int d1 = kd_heap_get<L + 1>(hd, c1);
+            if (c2 > KD_K) { if (d1 > val) { sw = c1; dsw = d1; } }
+            else {
+                const int d2 = kd_heap_get<L + 1>(hd, c2);
+                if (d1 >= d2) { if (val < d1) { sw = c1; dsw = d1; } }
+                else { if (val < d2) { sw = c2; dsw = d2; } }
+            }
+            if (sw) {
+                const int isw = kd_heap_get<L + 1>(hx, sw);
+                kd_heap_set<L>(hd, p, dsw, lane); kd_heap_set<L>(hx, p, isw, lane);
+                kd_heap_sift<L + 1>(hd, hx, sw, val, iv, lane);
+                return;
+            }
+        }
+    }
+    kd_heap_set<L>(hd, p, val, lane); kd_heap_set<L>(hx, p, iv, lane);
+}
+
+// One wavefront per tie-split patch: the walk and the heap operations are uniform; a leaf's distances are computed by all lanes.
 __global__ void __launch_bounds__(64) k_kd_query(caelo_kd kd, const float *__restrict__ pts, int pts_ld, unsigned long long *__restrict__ bits,
                                                  uint8_t *__restrict__ flags) {
     const int sc = blockIdx.y;
@@ -393,9 +444,15 @@ __global__ void __launch_bounds__(64) k_kd_query(caelo_kd kd, const float *__res
     const double vs = sc == 0 ? 0.02 : (sc == 1 ? 0.02 * 8 : 0.02 * 32);                    // Voxel.py:31
     const int q[3] = {(int)(((double)pts[(size_t)pts_ld * kp] + 99.84) / vs), (int)(((double)pts[(size_t)pts_ld * kp + 1] + 99.84) / vs),
                       (int)(((double)pts[(size_t)pts_ld * kp + 2] + 14.72) / vs)};        // :185,:193 (float64 division, truncation)
-    for (int i = lane; i < KD_K; i += 64) { L.dist[i] = KD_INF; L.ind[i] = 0; }
+    int hd[8], hx[8];   // the heap (see above)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { hd[r] = KD_INF; hx[r] = 0; }
     L.patch[lane] = 0ull;
     __syncthreads();
+#ifdef KD_PROFILE
+    long long tq0 = wall_clock64(), t_inner = 0, t_leafload = 0, t_push = 0;
+    int n_inner = 0, n_leaf = 0, n_push = 0, n_skip = 0;
+#endif
     int st_node[32], st_lb[32];
     int sp = 0;
     st_node[0] = 0; st_lb[0] = kd_min_rdist(T, 0, q);
@@ -403,44 +460,46 @@ __global__ void __launch_bounds__(64) k_kd_query(caelo_kd kd, const float *__res
     while (sp > 0) {                                // (uniform: every lane keeps the same stack)
         --sp;
         const int node = st_node[sp], lb = st_lb[sp];
-        if (lb > L.dist[0]) continue;
+#ifdef KD_PROFILE
+        long long tp = wall_clock64();
+        if (lb > __builtin_amdgcn_readlane(hd[0], 1)) { ++n_skip; continue; }
+#else
+        if (lb > __builtin_amdgcn_readlane(hd[0], 1)) continue;
+#endif
         const int s = T.start[node], e = T.end[node];
         const bool leaf = 2 * node + 1 >= n_nodes || e - s < 2;
         if (leaf) {
+            // A leaf's distances are computed by all lanes; the candidates are the lanes whose distance is below the heap's largest --
+            // a ballot, taken again after every push (the largest shrinks), instead of one dependent test per point; the sift-down
+            // runs on scalar registers.  Same pushes in the same order as the library's loop over the leaf.
             for (int c0 = s; c0 < e; c0 += 64) {
                 const int i = c0 + lane;
-                int p = 0;
+                int p = 0, myval = KD_INF;
                 if (i < e) {
                     p = T.idx[i];
                     const int16_t *v = T.vox + 3 * (int64_t)p;
                     const int dx = q[0] - v[0], dy = q[1] - v[1], dz = q[2] - v[2];
-                    L.leaf_d[lane] = dx * dx + dy * dy + dz * dz;
+                    myval = dx * dx + dy * dy + dz * dz;
                 }
-                __syncthreads();
-                const int m = min(64, e - c0);
-                if (lane == 0) {
-                    for (int u = 0; u < m; ++u) {
-                        const int val = L.leaf_d[u];
-                        if (val >= L.dist[0]) continue;
-                        const int iv = T.idx[c0 + u];
-                        int i2 = 0;
-                        for (;;) {
-                            const int c1 = 2 * i2 + 1, c2 = c1 + 1;
-                            int sw;
-                            if (c1 >= KD_K) break;
-                            else if (c2 >= KD_K) { if (L.dist[c1] > val) sw = c1; else break; }
-                            else {
-                                const int d1 = L.dist[c1], d2 = L.dist[c2];
-                                if (d1 >= d2) { if (val < d1) sw = c1; else break; }
-                                else { if (val < d2) sw = c2; else break; }
-                            }
-                            L.dist[i2] = L.dist[sw]; L.ind[i2] = L.ind[sw];
-                            i2 = sw;
-                        }
-                        L.dist[i2] = val; L.ind[i2] = iv;
-                    }
+#ifdef KD_PROFILE
+                if (c0 == s) ++n_leaf;
+                { const long long tn = wall_clock64() + (myval & 0); t_leafload += tn - tp; tp = tn; }
+#endif
+                int dist0 = __builtin_amdgcn_readlane(hd[0], 1);
+                unsigned long long cand = __ballot(myval < dist0);
+                while (cand) {
+                    const int u = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(cand));
+                    const int val = __builtin_amdgcn_readlane(myval, u), iv = __builtin_amdgcn_readlane(p, u);
+                    kd_heap_sift<0>(hd, hx, 1, val, iv, lane);
+                    dist0 = __builtin_amdgcn_readlane(hd[0], 1);
+                    cand = __ballot(myval < dist0) & ((~0ull << u) << 1);
+#ifdef KD_PROFILE
+                    ++n_push;
+#endif
                 }
-                __syncthreads();
+#ifdef KD_PROFILE
+                { const long long tn = wall_clock64(); t_push += tn - tp; tp = tn; }
+#endif
             }
         } else {
             const int i1 = 2 * node + 1, i2 = i1 + 1;
@@ -449,13 +508,21 @@ __global__ void __launch_bounds__(64) k_kd_query(caelo_kd kd, const float *__res
             if (l1 <= l2) { st_node[sp] = i2; st_lb[sp] = l2; st_node[sp + 1] = i1; st_lb[sp + 1] = l1; }
             else { st_node[sp] = i1; st_lb[sp] = l1; st_node[sp + 1] = i2; st_lb[sp + 1] = l2; }
             sp += 2;
+#ifdef KD_PROFILE
+            ++n_inner; t_inner += wall_clock64() - tp;
+#endif
         }
     }
+#ifdef KD_PROFILE
+    if (lane == 0) printf("kd query scale %d: %.1f us; %d inner nodes %.1f us, %d leaves (load %.1f us), %d pushes %.1f us, %d popped nodes skipped\n", sc,
+                          (wall_clock64() - tq0) * 0.01, n_inner, t_inner * 0.01, n_leaf, t_leafload * 0.01, n_push, t_push * 0.01, n_skip);
+#endif
     __syncthreads();
     // ---- the 496 kept voxels -> the 16^3 window with the reference's wrap-around placement (Voxel.py:204-214)
-    for (int i = lane; i < KD_K; i += 64) {
-        if (L.dist[i] == KD_INF) continue;
-        const int16_t *v = T.vox + 3 * (int64_t)L.ind[i];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r * 64 + lane < 1 || r * 64 + lane > KD_K || hd[r] == KD_INF) continue;   // (positions 1 .. 496)
+        const int16_t *v = T.vox + 3 * (int64_t)hx[r];
         const int dx = v[0] - q[0], dy = v[1] - q[1], dz = v[2] - q[2];
         if (dx >= -8 && dx < 8 && dy >= -8 && dy < 8 && dz >= -8 && dz < 8) {
             const int lin = ((dx & 15) << 8) | ((dy & 15) << 4) | (dz & 15);
