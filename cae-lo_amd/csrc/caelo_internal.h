@@ -83,6 +83,7 @@ struct caelo_kd;   // kdorder.hip: the voxel lists in the reference's order + sc
 struct caelo_voxmap {
     int64_t max_points;
     caelo_kd *kd;      // allocated by the first caelo_voxmap_from_lists / caelo_voxmap_order
+    bool order_tracked;  // the first-touch tables are valid: the map was filled by caelo_voxelize (what caelo_voxmap_export / _order read)
     bool kd_lists;     // kd holds the map's voxel lists in the reference's order (caelo_voxmap_from_lists, caelo_voxmap_order)
     caelo_brick_table brick[3];
     // voxel-level first-touch tables (value = smallest inserting point index, 0xFFFFFFFF = none)

@@ -130,12 +130,14 @@ static int export_scales(caelo_voxmap *m, int mask, int16_t *const outs[3], int6
 CAELO_API int caelo_voxmap_export(caelo_ctx *c, caelo_voxmap *m, int16_t *all0, int16_t *all1, int16_t *all2,
                                   int64_t capacity, int64_t *counts, void *stream) {
     CAELO_REQUIRE(c && m && all0 && all1 && all2 && counts, "null argument");
+    CAELO_REQUIRE(m->order_tracked, "caelo_voxmap_export: the map was not filled by caelo_voxelize (no first-touch order)");
     int16_t *const outs[3] = {all0, all1, all2};
     return export_scales(m, 7, outs, capacity, counts, nullptr, caelo_stream(stream));
 }
 
 CAELO_API int caelo_voxmap_order(caelo_ctx *c, caelo_voxmap *m, int scale_mask, void *stream) {
     CAELO_REQUIRE(c && m, "null argument");
+    CAELO_REQUIRE(m->order_tracked, "caelo_voxmap_order: the map was not filled by caelo_voxelize (no first-touch order)");
     hipStream_t s = caelo_stream(stream);
     int16_t *outs[3];
     int32_t *n_out = nullptr;

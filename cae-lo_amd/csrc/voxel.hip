@@ -185,7 +185,8 @@ int vox_clear_for_fast_build_set(caelo_voxmap *const *maps, int n, caelo_clear_l
 
 static int voxmap_clear(caelo_voxmap *m, bool track_order, hipStream_t s) {
     m->lists_valid = false;
-    m->kd_lists = false;   // (whatever fills the map next: only caelo_voxmap_from_lists knows the reference's list order)
+    m->order_tracked = track_order;
+    m->kd_lists = false;   // (whatever fills the map next: only caelo_voxmap_from_lists / caelo_voxmap_order know the reference's list order)
     caelo_clear_list list;
     list.n = 0;
     vox_clear_items(m, track_order ? 2 : 1, list);
@@ -694,7 +695,7 @@ int vox_build_fast_launch(caelo_voxmap *m, const float *pc, int64_t n, int strid
 
 // fused build of every frame of the set (fs.f[i] carries map i's tables, the scan and the status word)
 int vox_build_fast_set(caelo_voxmap *const *maps, const caelo_frame_set &fs, hipStream_t s) {
-    for (int i = 0; i < fs.n; ++i) { maps[i]->lists_valid = false; maps[i]->kd_lists = false; }  // until every kernel of the build is enqueued
+    for (int i = 0; i < fs.n; ++i) { maps[i]->lists_valid = false; maps[i]->kd_lists = false; maps[i]->order_tracked = false; }  // until every kernel of the build is enqueued
     const unsigned gp = (unsigned)((vox_set_max_points(fs) + 255) / 256);
     k_vox_points<<<dim3(gp, 1, fs.n), 256, 0, s>>>(fs);
     CAELO_LAUNCH_CHECK();
@@ -717,7 +718,7 @@ int vox_build_launch(caelo_voxmap *m, const float *pc, int64_t n, int stride, bo
 }
 
 int vox_build_set(caelo_voxmap *const *maps, const caelo_frame_set &fs, bool track_order, hipStream_t s) {
-    for (int i = 0; i < fs.n; ++i) { maps[i]->lists_valid = false; maps[i]->kd_lists = false; }
+    for (int i = 0; i < fs.n; ++i) { maps[i]->lists_valid = false; maps[i]->kd_lists = false; maps[i]->order_tracked = track_order; }
     const unsigned grid = (unsigned)((vox_set_max_points(fs) + 255) / 256);
     k_vox_first<<<dim3(grid, 1, fs.n), 256, 0, s>>>(fs);
     CAELO_LAUNCH_CHECK();

@@ -519,6 +519,14 @@ def test_fast_voxelization_is_exact_on_voxel_face_points(engine, orc, scans):
                 got = engine.voxmap_voxels(vm_fast, s)
                 assert np.array_equal(got, want[s]), "fast build, scale %d" % s
                 assert np.array_equal(engine.voxmap_voxels(vm_exact, s), want[s]), "exact build, scale %d" % s
+            if rep == 0 and pc is clouds[0]:      # first-touch order exists only after the exact build: the fast one must refuse to export / order
+                from caelo import _ffi
+                with pytest.raises(_ffi.CaeloError):
+                    engine.voxmap_export(vm_fast, len(pc))
+                with pytest.raises(_ffi.CaeloError):
+                    engine.voxmap_order(vm_fast, 7)
+                lists = engine.voxmap_export(vm_exact, len(pc))
+                assert [len(a) for a in lists] == [len(w) for w in want]
             derived = np.unique(want[0] >> 3, axis=0)
             n_face.append(len(derived) != len(want[1]) or not np.array_equal(derived[np.lexsort((derived[:, 2], derived[:, 1], derived[:, 0]))], want[1]))
     assert sum(n_face) >= 8    # the face points really change the scale-1 set in most of these clouds
