@@ -354,6 +354,8 @@ class Pipeline:
         event on the copy stream).  ``ahead``: 13.5 / 15.3 / 15.9 / 16.1 k frames/s for 1 / 2 / 3 / 4 (18.6 k resident; an arrival is
         late by up to 0.3 ms now and then, and a batch of scans is 17 MB of device memory).  Device-side waits for the same hand-overs (caelo_pipeline_wait_stream / _release_scans) cost
         8 - 15 % of the resident rate EACH, however rarely they were issued."""
+        import time as _t
+        te0_ = _t.perf_counter()
         eng, lib, k, B = self.eng, self.eng.lib, len(host_scans), self.batch
         out = out or FrameBatch(eng, k)
         assert out.k >= k and (not pairs or len(rands) >= k) and ahead >= 1
@@ -361,15 +363,35 @@ class Pipeline:
             assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] == 4 and pc.is_contiguous()   # (host tensors, pinned for overlap; device tensors work too)
         big = max(int(pc.shape[0]) for pc in host_scans)
         slots = ahead + 2
-        key = ("upload", B, slots)
+        nb = (k + B - 1) // B
+        src_p = np.array([pc.data_ptr() for pc in host_scans], dtype=np.uint64)
+        nbytes = np.array([int(pc.shape[0]) * 16 for pc in host_scans], dtype=np.uint64)
+        on_host = all(not pc.is_cuda for pc in host_scans)
+        # A producer that leaves the scans of a batch in ONE pinned block at a fixed pitch (run_sequence.py's loader does) gets one
+        # copy command per batch: the device slots mirror the pitch.  Measured (tools/upload_contention_probe.py): eight 2 MB copies per
+        # batch cost a resident pipeline running beside them 20 % (41 GB/s), one 16 MB copy 0-3 % (54 GB/s) -- the commands, not the
+        # bytes, are what the copies cost.
+        pitch = 0
+        if on_host and k > 1:
+            d = np.diff(src_p.astype(np.int64))
+            inside = np.ones(k - 1, bool); inside[B - 1::B] = False          # (the step from one batch to the next may be anything)
+            if inside.any() and (d[inside] == d[inside][0]).all() and int(d[inside][0]) >= int(nbytes.max()) and int(d[inside][0]) % 16 == 0:
+                pitch = int(d[inside][0])
+        key = ("upload", B, slots, pitch)
         st = self._upload.get(key) if hasattr(self, "_upload") else None
         if st is None or st[1] < big:
-            bufs = [[torch.empty((big, 4), dtype=torch.float32, device=eng.device) for _ in range(B)] for _ in range(slots)]
-            st = (bufs, big, torch.cuda.Stream(device=eng.device))
+            # (sized once: by the pitch, or by the engine's scan capacity -- a later call with a slightly longer scan must not find
+            # itself allocating device memory behind the caller's clock)
+            rows = pitch // 16 if pitch else max(big, int(eng.max_points))
+            if pitch:
+                blocks = [torch.empty((B * pitch,), dtype=torch.uint8, device=eng.device) for _ in range(slots)]
+                bufs = [[blk[i * pitch:(i + 1) * pitch] for i in range(B)] for blk in blocks]
+            else:
+                bufs = [[torch.empty((rows, 4), dtype=torch.float32, device=eng.device) for _ in range(B)] for _ in range(slots)]
+            st = (bufs, rows, torch.cuda.Stream(device=eng.device))
             self._upload = {key: st}
         bufs, _, copy = st
         stream = eng.stream
-        nb = (k + B - 1) // B
         jobs = self._jobs([bufs[(i // B) % slots][i % B].data_ptr() for i in range(k)], [int(pc.shape[0]) for pc in host_scans], rands, prev, out,
                           pairs, dist_channels, False, dedup, certify, rands_host)
         arrived = [torch.cuda.Event() for _ in range(nb)]
@@ -377,14 +399,19 @@ class Pipeline:
         # the copies of a batch go out behind ONE native call (caelo_upload_many): eight sliced torch copies cost the issuing thread
         # ~150 us per batch, and that thread's time per batch is what bounds this mode
         dst_p = np.array([bufs[(i // B) % slots][i % B].data_ptr() for i in range(k)], dtype=np.uint64)
-        src_p = np.array([pc.data_ptr() for pc in host_scans], dtype=np.uint64)
-        nbytes = np.array([int(pc.shape[0]) * 16 for pc in host_scans], dtype=np.uint64)
-        on_host = all(not pc.is_cuda for pc in host_scans)
         copy_h = C.c_void_p(copy.cuda_stream)
+        if pitch:   # per batch: (first frame's slot, first frame's source, bytes up to the end of the last frame)
+            one_n = np.array([int(src_p[min(k, (b + 1) * B) - 1] + nbytes[min(k, (b + 1) * B) - 1] - src_p[b * B]) for b in range(nb)], dtype=np.uint64)
+
+        up_calls = []
 
         def upload(b):   # into the slot batch b - slots used
             lo, hi = b * B, min(k, (b + 1) * B)
-            if on_host:
+            if pitch:
+                tu0_ = _t.perf_counter()
+                _ffi.check(lib.caelo_upload_many(dst_p[lo:lo + 1].ctypes.data, src_p[lo:lo + 1].ctypes.data, one_n[b:b + 1].ctypes.data, 1, copy_h))
+                up_calls.append(1e6 * (_t.perf_counter() - tu0_))
+            elif on_host:
                 _ffi.check(lib.caelo_upload_many(dst_p[lo:hi].ctypes.data, src_p[lo:hi].ctypes.data, nbytes[lo:hi].ctypes.data, hi - lo, copy_h))
             else:   # (device sources: the probe that separates the protocol's cost from PCIe's)
                 with torch.cuda.stream(copy):
@@ -396,23 +423,37 @@ class Pipeline:
         copy.wait_stream(torch.cuda.current_stream(eng.device))   # (an earlier run may still read the slots)
         pace = self.pace
         _ffi.check(lib.caelo_pipeline_set_pace(self.h, -1))       # this loop paces itself: the copies go out BEFORE the thread waits
+        te1_ = _t.perf_counter()
         _ffi.check(lib.caelo_pipeline_begin(self.h, stream))
+        te2_ = _t.perf_counter()
         try:
             for b in range(min(ahead, nb)):
                 upload(b)
+            tw = [0.0, 0.0, 0.0, 0.0]
             for b in range(nb):
+                t0_ = _t.perf_counter()
                 arrived[b].synchronize()                 # batch b's scans are in device memory
+                t1_ = _t.perf_counter()
                 lo, hi = b * B, min(k, (b + 1) * B)
                 _ffi.check(lib.caelo_pipeline_submit_many(self.h, jobs[lo:hi].ctypes.data, hi - lo))
+                t2_ = _t.perf_counter()
                 if b + ahead < nb:
                     upload(b + ahead)                    # slot of batch b - 2: encoded (hence read) before batch b was issued
+                t3_ = _t.perf_counter()
                 if hi - lo == B:
                     self.sync_encoded(1)                 # (a partial last batch is only issued by the flush)
+                t4_ = _t.perf_counter()
+                tw[0] += t1_ - t0_; tw[1] += t2_ - t1_; tw[2] += t3_ - t2_; tw[3] += t4_ - t3_
+            self.last_upload_times = dict(wait_arrival_ms=1e3 * tw[0], submit_ms=1e3 * tw[1], upload_issue_ms=1e3 * tw[2], wait_encoded_ms=1e3 * tw[3])
         finally:
+            tf0_ = _t.perf_counter()
             rc = lib.caelo_pipeline_flush(self.h, stream)
             lib.caelo_pipeline_set_pace(self.h, pace)
         _ffi.check(rc)
+        tf1_ = _t.perf_counter()
         self._publish_exact(out, k, certify, pairs)
+        self.last_upload_times['copy_call_us'] = [round(x) for x in up_calls[:40]]
+        self.last_upload_times.update(flush_ms=1e3 * (tf1_ - tf0_), publish_ms=1e3 * (_t.perf_counter() - tf1_), prepare_ms=1e3 * (te1_ - te0_), begin_ms=1e3 * (te2_ - te1_))
         return out
 
 

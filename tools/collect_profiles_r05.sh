@@ -27,6 +27,8 @@ timeout 900 bash $R/tools/collect_roofline_table.sh > /dev/null 2>&1; cp $R/gpur
 ( cd $R && T=600 py cae-lo_amd/run_sequence.py --synthetic 4541 --pool 49 --quantum 0.001 --chunk 240 --out $O/poses_kitti00_sized.txt 2>&1 | tail -2 ) > $O/run_sequence_4541.txt
 ( cd $R && timeout 300 python tools/stress_pairs.py 12 2>&1 | tail -1 ) > $O/stress_pairs.txt
 rm -f $O/poses_kitti00_sized.txt
+# what the upload mode loses and why: unrelated H2D copies beside the resident pipeline (8 x 2 MB commands vs one 16 MB command), per-stream H2D rates
+( cd $R && py tools/upload_contention_probe.py 2>&1 | grep -v amdgpu.ids; py tools/h2d_stream_probe.py 2>&1 | grep -v amdgpu.ids ) > $O/upload_overlap.txt
 # the tie redo (clutter scene): many frames on side streams, one frame's stages, the kd-tree build level by level (a -DKD_PROFILE build)
 ( cd $R && py tools/ties_many_probe.py 64 2>&1 | grep -v amdgpu.ids ) > $O/ties_many.txt
 ( cd $R && py tools/ties_probe.py 2>&1 | grep -v amdgpu.ids ) > $O/ties_probe.txt
