@@ -1306,6 +1306,12 @@ def test_run_sequence_from_files_equals_the_synthetic_run(tmp_path):
     env = dict(os.environ, CAELO_RUN_NO_PINNED_RING="1")
     subprocess.run([sys.executable, script, "--scans", str(d), "--chunk", "3", "--out", c], check=True, capture_output=True, timeout=300, env=env)
     assert open(a).read() == open(b).read() == open(c).read() and len(open(a).read().splitlines()) == 11
+    # whole batches out of one pinned block: one copy command per batch (Pipeline.run_uploading finds the pitch), files and synthetic ring
+    e, f = str(tmp_path / "e.txt"), str(tmp_path / "f.txt")
+    subprocess.run([sys.executable, script, "--scans", str(d), "--chunk", "16", "--out", e], check=True, capture_output=True, timeout=300)
+    subprocess.run([sys.executable, script, "--synthetic", "11", "--chunk", "16", "--out", f], check=True, capture_output=True, timeout=300,
+                   env=dict(os.environ, CAELO_RUN_SYNTH_RING="1"))
+    assert open(e).read() == open(f).read() == open(a).read()
 
 
 # ---- round 2: the variants that claim bit-identical results, and the pipeline's batch plan -------------------------------------
