@@ -737,7 +737,7 @@ class Staging:
         period = 2 * (P - 1)
         self.L = period * batch // math.gcd(period, batch)
         cap = max(int(p.shape[0]) for p in host_pool)
-        self.block = torch.empty((self.L, cap, 4), dtype=torch.float32).pin_memory()
+        self.block = torch.empty((self.L, cap, 4), dtype=torch.float32, pin_memory=True)
         self.rows = []
         for s_ in range(self.L):
             src = host_pool[walk_fn(s_ + 1, P)]

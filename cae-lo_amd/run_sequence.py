@@ -88,7 +88,7 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
     from concurrent.futures import ThreadPoolExecutor
     n_thr = max(1, loader_threads)
     workers = ThreadPoolExecutor(max_workers=n_thr)
-    draw_ring = [torch.empty((min(chunk, hi - lo), 6000), dtype=torch.float64).pin_memory() for _ in range(4)]   # queue of 2 + one in use + one being filled
+    draw_ring = [torch.empty((min(chunk, hi - lo), 6000), dtype=torch.float64, pin_memory=True) for _ in range(4)]   # queue of 2 + one in use + one being filled
 
     # Scans that come from files are read STRAIGHT into pinned slots that are allocated once and reused every fourth chunk (the queue
     # holds two chunks, one is in use, one is being filled): page-locking a fresh 2 MB buffer per scan cost 1.4 ms, three times the
@@ -108,7 +108,7 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
         with lk:
             blk = ring_slots.get(key)
             if blk is None:
-                blk = ring_slots[key] = torch.empty((batch_frames, cap, 4), dtype=torch.float32).pin_memory()
+                blk = ring_slots[key] = torch.empty((batch_frames, cap, 4), dtype=torch.float32, pin_memory=True)
         return blk[j % batch_frames]
 
     def loader():
@@ -198,8 +198,8 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
         done.record()
         if not back_ring:   # pinned read-back buffers, allocated once (three: one being parsed, one in flight, one being issued)
             for _i in range(3):
-                back_ring.append((torch.empty((min(chunk, hi - lo),) + tuple(batch.result.shape[1:]), dtype=batch.result.dtype).pin_memory(),
-                                  torch.empty((min(chunk, hi - lo),) + tuple(batch.status.shape[1:]), dtype=batch.status.dtype).pin_memory()))
+                back_ring.append((torch.empty((min(chunk, hi - lo),) + tuple(batch.result.shape[1:]), dtype=batch.result.dtype, pin_memory=True),
+                                  torch.empty((min(chunk, hi - lo),) + tuple(batch.status.shape[1:]), dtype=batch.status.dtype, pin_memory=True)))
         res_h, st_h = (t[:c1 - c0] for t in back_ring[n_back % 3])
         n_back += 1
         with torch.cuda.stream(side):

@@ -130,3 +130,20 @@ def test_multi_rank_request_fails_loudly_or_self_launches():
         if torch.cuda.device_count() < 64:
             r = subprocess.run([sys.executable, script, "--gpus", "64"] + extra, env=env, capture_output=True, timeout=300)
             assert r.returncode == 2 and r.stdout == b"" and b"visible" in r.stderr
+
+
+def test_ransac_draws_are_numpys_stream():
+    """engine.ransac_draws re-seeds a per-thread RandomState: the same doubles as a fresh RandomState(seed) (Match.py:182), from any thread"""
+    import threading
+    from caelo.engine import ransac_draws
+    want = {s: np.random.RandomState(s).random_sample(6000) for s in (0, 1, 999, 2 ** 31 - 1, 123456789)}
+    got = {}
+
+    def work(seeds):
+        for s in seeds:
+            got[s] = ransac_draws(s)
+    ts = [threading.Thread(target=work, args=(list(want)[i::2],)) for i in range(2)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert all(np.array_equal(got[s], want[s]) for s in want)
+    rng = np.random.RandomState(5)
+    assert np.array_equal(ransac_draws(rng), np.random.RandomState(5).random_sample(6000))

@@ -26,6 +26,7 @@ timeout 900 bash $R/tools/collect_roofline_table.sh > /dev/null 2>&1; cp $R/gpur
 ( py $R/tools/cert_cost_probe.py 120 2>&1 | grep -v amdgpu.ids; py $R/tools/cert_cost_probe.py 20 2>&1 | grep -v amdgpu.ids ) > $O/cert_cost.txt
 ( cd $R && T=600 py cae-lo_amd/run_sequence.py --synthetic 4541 --pool 49 --quantum 0.001 --chunk 240 --out $O/poses_kitti00_sized.txt 2>&1 | tail -2 ) > $O/run_sequence_4541.txt
 ( cd $R && timeout 300 python tools/stress_pairs.py 12 2>&1 | tail -1 ) > $O/stress_pairs.txt
+( THREADS="32 32" timeout 900 bash $R/tools/run_sequence_files_probe.sh 4541 2>&1 | grep -v amdgpu.ids | grep -E "wrote|frames/s|host seconds" ) > $O/run_sequence_files_4541.txt
 rm -f $O/poses_kitti00_sized.txt
 # what the upload mode loses and why: unrelated H2D copies beside the resident pipeline (8 x 2 MB commands vs one 16 MB command), per-stream H2D rates
 ( cd $R && py tools/upload_contention_probe.py 2>&1 | grep -v amdgpu.ids; py tools/h2d_stream_probe.py 2>&1 | grep -v amdgpu.ids ) > $O/upload_overlap.txt
