@@ -62,10 +62,7 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
     """
     import queue
     import threading
-    pipe = eng.pipeline(batch_frames)
-    import gc
-    gc.collect()
-    gc.freeze()       # what exists now is never scanned again: a full collection of this process (40-90 ms) no longer lands between two batches
+    t_setup = time.time()
     chunks = [(c0, min(hi, c0 + chunk)) for c0 in range(lo, hi, chunk)]
     q = queue.Queue(maxsize=2)
 
@@ -80,7 +77,7 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
         return t
 
     ht = host_times if host_times is not None else {}   # seconds per host activity (what a "frames/s incl. loading" figure is made of)
-    for k_ in ("load", "pin", "draws", "starved", "pipeline", "ties", "parse"):
+    for k_ in ("load", "pin", "draws", "starved", "pipeline", "ties", "parse", "setup"):
         ht.setdefault(k_, 0.0)
 
     # The loader works with a few threads (file reads, NumPy's Mersenne Twister and the ray caster all release the GIL for most of
@@ -137,7 +134,13 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
             q.put(e)
 
     threading.Thread(target=loader, daemon=True).start()
+    # (the loader is already at work on the first chunks while the pipeline's buffers are allocated)
+    pipe = eng.pipeline(batch_frames)
+    import gc
+    gc.collect()
+    gc.freeze()       # what exists now is never scanned again: a full collection of this process (40-90 ms) no longer lands between two batches
     side = torch.cuda.Stream(device=eng.device)
+    ht["setup"] = time.time() - t_setup
     rel, ok, thr, nin = [], [], [], []
     prev, first = None, None
     pending = None   # (k, has_prev, pinned result, pinned status, event)
@@ -154,6 +157,7 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
         rel.append(r[s:]); ok.append(o[s:]); thr.append(t[s:]); nin.append(n[s:])
         ht["parse"] += time.time() - t_
 
+    t_loop = time.time()
     for _ in chunks:
         t_ = time.time()
         item = q.get()
@@ -216,6 +220,8 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
         prev = batch.frame(c1 - c0 - 1)
         if keep is not None:
             keep(c0, batch)
+        del batch, item, scans      # (back to the caching allocator before the next chunk asks for the same sizes)
+    ht["loop"] = time.time() - t_loop
     if pending is not None:
         collect(pending)
     cat = (lambda xs, d: np.concatenate(xs) if xs else np.zeros((0,) + d))
@@ -355,8 +361,8 @@ def main():
             n, len(rel), world, dt, n / dt, int(np.sum(ok)), len(rel), args.out))
         h = host_times
         print("rank 0 host seconds -- loader thread: reading / synthesising scans %.2f, pinning %.2f, RANSAC draws %.2f; issuing thread: "
-              "waiting for the loader (%d threads) %.2f, pipeline calls (uploads paced, %d frames) %.2f, tie check + read-back issue %.2f, parsing results %.2f"
-              % (h["load"], h["pin"], h["draws"], args.loader_threads, h["starved"], hi - lo, h["pipeline"], h["ties"], h["parse"]))
+              "pipeline creation + heap freeze %.2f, waiting for the loader (%d threads) %.2f, pipeline calls (uploads paced, %d frames) %.2f, tie check + read-back issue %.2f, "
+              "parsing results %.2f (the chunk loop as a whole %.2f)" % (h["load"], h["pin"], h["draws"], h["setup"], args.loader_threads, h["starved"], hi - lo, h["pipeline"], h["ties"], h["parse"], h.get("loop", 0.0)))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
