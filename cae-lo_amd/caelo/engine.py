@@ -10,6 +10,7 @@ PyTorch is used for device memory and streams only.
 import ctypes as C
 import os
 import threading
+import time
 
 import numpy as np
 import torch
@@ -269,11 +270,10 @@ class Pipeline:
         _ffi.check(lib.caelo_pipeline_begin(self.h, stream))
         for pc in scans:
             assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[1] == 4 and pc.is_contiguous()
-        import time as _t
-        _t0 = _t.perf_counter()
+        _t0 = time.perf_counter()
         jobs = self._jobs([pc.data_ptr() for pc in scans], [pc.shape[0] for pc in scans], rands, prev, out, pairs, dist_channels,
                           exact_voxels, dedup, certify, rands_host)
-        _t1 = _t.perf_counter()
+        _t1 = time.perf_counter()
         tail = None   # a partial last batch is only issued by the flush: its callbacks come after that
         issued = []   # batches issued, not yet reported to on_encoded
         try:
@@ -304,12 +304,12 @@ class Pipeline:
             self.sync_encoded(0)
             for lo, hi in issued:
                 on_encoded(lo, hi)
-        _t2 = _t.perf_counter()
+        _t2 = time.perf_counter()
         if publish:
             self._publish_exact(out, k, certify, pairs)
         elif certify and certify != "device" and pairs and k > 0 and (out.exact[3][:k] == 2).any():
             raise _ffi.CaeloError("a pair holds more than 1024 matches: no certificate")
-        self.last_times = {"jobs_ms": 1e3 * (_t1 - _t0), "submit_flush_ms": 1e3 * (_t2 - _t1), "publish_ms": 1e3 * (_t.perf_counter() - _t2)}
+        self.last_times = {"jobs_ms": 1e3 * (_t1 - _t0), "submit_flush_ms": 1e3 * (_t2 - _t1), "publish_ms": 1e3 * (time.perf_counter() - _t2)}
         return out
 
     def _publish_exact(self, out, k, certify, pairs):
@@ -355,8 +355,7 @@ class Pipeline:
         event on the copy stream).  ``ahead``: 13.5 / 15.3 / 15.9 / 16.1 k frames/s for 1 / 2 / 3 / 4 (18.6 k resident; an arrival is
         late by up to 0.3 ms now and then, and a batch of scans is 17 MB of device memory).  Device-side waits for the same hand-overs (caelo_pipeline_wait_stream / _release_scans) cost
         8 - 15 % of the resident rate EACH, however rarely they were issued."""
-        import time as _t
-        te0_ = _t.perf_counter()
+        te0_ = time.perf_counter()
         eng, lib, k, B = self.eng, self.eng.lib, len(host_scans), self.batch
         out = out or FrameBatch(eng, k)
         assert out.k >= k and (not pairs or len(rands) >= k) and ahead >= 1
@@ -409,9 +408,9 @@ class Pipeline:
         def upload(b):   # into the slot batch b - slots used
             lo, hi = b * B, min(k, (b + 1) * B)
             if pitch:
-                tu0_ = _t.perf_counter()
+                tu0_ = time.perf_counter()
                 _ffi.check(lib.caelo_upload_many(dst_p[lo:lo + 1].ctypes.data, src_p[lo:lo + 1].ctypes.data, one_n[b:b + 1].ctypes.data, 1, copy_h))
-                up_calls.append(1e6 * (_t.perf_counter() - tu0_))
+                up_calls.append(1e6 * (time.perf_counter() - tu0_))
             elif on_host:
                 _ffi.check(lib.caelo_upload_many(dst_p[lo:hi].ctypes.data, src_p[lo:hi].ctypes.data, nbytes[lo:hi].ctypes.data, hi - lo, copy_h))
             else:   # (device sources: the probe that separates the protocol's cost from PCIe's)
@@ -424,37 +423,37 @@ class Pipeline:
         copy.wait_stream(torch.cuda.current_stream(eng.device))   # (an earlier run may still read the slots)
         pace = self.pace
         _ffi.check(lib.caelo_pipeline_set_pace(self.h, -1))       # this loop paces itself: the copies go out BEFORE the thread waits
-        te1_ = _t.perf_counter()
+        te1_ = time.perf_counter()
         _ffi.check(lib.caelo_pipeline_begin(self.h, stream))
-        te2_ = _t.perf_counter()
+        te2_ = time.perf_counter()
         try:
             for b in range(min(ahead, nb)):
                 upload(b)
             tw = [0.0, 0.0, 0.0, 0.0]
             for b in range(nb):
-                t0_ = _t.perf_counter()
+                t0_ = time.perf_counter()
                 arrived[b].synchronize()                 # batch b's scans are in device memory
-                t1_ = _t.perf_counter()
+                t1_ = time.perf_counter()
                 lo, hi = b * B, min(k, (b + 1) * B)
                 _ffi.check(lib.caelo_pipeline_submit_many(self.h, jobs[lo:hi].ctypes.data, hi - lo))
-                t2_ = _t.perf_counter()
+                t2_ = time.perf_counter()
                 if b + ahead < nb:
                     upload(b + ahead)                    # slot of batch b - 2: encoded (hence read) before batch b was issued
-                t3_ = _t.perf_counter()
+                t3_ = time.perf_counter()
                 if hi - lo == B:
                     self.sync_encoded(1)                 # (a partial last batch is only issued by the flush)
-                t4_ = _t.perf_counter()
+                t4_ = time.perf_counter()
                 tw[0] += t1_ - t0_; tw[1] += t2_ - t1_; tw[2] += t3_ - t2_; tw[3] += t4_ - t3_
             self.last_upload_times = dict(wait_arrival_ms=1e3 * tw[0], submit_ms=1e3 * tw[1], upload_issue_ms=1e3 * tw[2], wait_encoded_ms=1e3 * tw[3])
         finally:
-            tf0_ = _t.perf_counter()
+            tf0_ = time.perf_counter()
             rc = lib.caelo_pipeline_flush(self.h, stream)
             lib.caelo_pipeline_set_pace(self.h, pace)
         _ffi.check(rc)
-        tf1_ = _t.perf_counter()
+        tf1_ = time.perf_counter()
         self._publish_exact(out, k, certify, pairs)
         self.last_upload_times['copy_call_us'] = [round(x) for x in up_calls[:40]]
-        self.last_upload_times.update(flush_ms=1e3 * (tf1_ - tf0_), publish_ms=1e3 * (_t.perf_counter() - tf1_), prepare_ms=1e3 * (te1_ - te0_), begin_ms=1e3 * (te2_ - te1_))
+        self.last_upload_times.update(flush_ms=1e3 * (tf1_ - tf0_), publish_ms=1e3 * (time.perf_counter() - tf1_), prepare_ms=1e3 * (te1_ - te0_), begin_ms=1e3 * (te2_ - te1_))
         return out
 
 
@@ -959,7 +958,6 @@ class Engine:
         so the kd-tree builds and queries of different frames, a few workgroups each, overlap instead of queueing (more lanes than
         hardware queues, 8, buy nothing).  The current stream waits for the lanes; one read of the status words at the end.
         -> (indices into ``items`` that were redone, their numbers of tie-split patches)."""
-        import time
         t0_ = time.perf_counter()
         if not items:
             return [], []
