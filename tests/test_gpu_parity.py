@@ -527,6 +527,8 @@ def test_fast_voxelization_is_exact_on_voxel_face_points(engine, orc, scans):
                     engine.voxmap_order(vm_fast, 7)
                 lists = engine.voxmap_export(vm_exact, len(pc))
                 assert [len(a) for a in lists] == [len(w) for w in want]
+                with pytest.raises(_ffi.CaeloError):      # a count above the capacity is the overflow report (the call itself never waits)
+                    engine.voxmap_export(vm_exact, 100)
             derived = np.unique(want[0] >> 3, axis=0)
             n_face.append(len(derived) != len(want[1]) or not np.array_equal(derived[np.lexsort((derived[:, 2], derived[:, 1], derived[:, 0]))], want[1]))
     assert sum(n_face) >= 8    # the face points really change the scale-1 set in most of these clouds
