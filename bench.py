@@ -424,6 +424,8 @@ def main():
 
     gc.collect()
     gc.freeze()          # (before the warm-up: a pause here would let the GPU's clocks drop right in front of a 9 ms timed region)
+    timed_out = FrameBatch(eng, K)   # the timed frames' output rows / poses: allocated like any other resident buffer, before the warm-up (an
+                                     # allocation between warm-up and clock start is milliseconds of an idle GPU in front of a 9 ms region)
     # one-time initialisation, not a warm-up step: the stage streams and every hand-off buffer are touched once (a
     # HIP stream allocates its hardware queue on first use, ~ms), so that a run with a small --warmup does not time that
     gstats = []
@@ -443,7 +445,6 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     pipe.stats()
-    timed_out = FrameBatch(eng, K)   # the timed frames' output rows / poses: allocated like any other resident buffer, before the clock starts
     # Python's cycle collector stays out of the timed region (like timeit): a full collection of this process's objects takes 40-90 ms --
     # five to ten batches -- and used to land in one run of the upload mode out of three (its loop creates a few hundred objects)
     gc.disable()
