@@ -1002,7 +1002,7 @@ class Engine:
         self.last_tie_times = dict(find_ms=1e3 * (t1_ - t0_), issue_ms=1e3 * (t4_ - t1_), wait_ms=1e3 * (t5_ - t4_))
         return tied, [int(both[i, :3].sum()) for i in tied]
 
-    def match_pose_exact_many(self, pairs, rands, rands_host=None, threads=None):
+    def match_pose_exact_many(self, pairs, rands, rands_host=None, threads=None, lanes=8):
         """match_pose_exact over many pairs [(fa, fb), ...]: every match and hypothesis launch is issued first, the certificates
         come back in one copy and the host half runs over them on ``threads`` threads.  -> (results [k] (_ffi.POSE_DTYPE),
         masks [k,1024] u8 (host), [pair_idx (device)] * k).  Synchronises once."""
@@ -1010,13 +1010,30 @@ class Engine:
         cur = torch.cuda.current_stream(self.device)
         cert = self.new_cert(k)
         idxs = []
+        # pair j goes to side stream j % lanes (match and hypothesis kernels of one pair are ~0.1 ms of dependent launches that
+        # leave most of the GPU idle; the workspaces are per stream)
+        lanes = min(int(lanes), k)
+        if lanes > 1:
+            if not hasattr(self, "_tie_lanes") or len(self._tie_lanes) < lanes:
+                self._tie_lanes = [torch.cuda.Stream(self.device) for _ in range(max(lanes, 8))]
+            start = torch.cuda.Event()
+            start.record(cur)
         for j, (fa, fb) in enumerate(pairs):
+            s_ = self._tie_lanes[j % lanes] if lanes > 1 else cur
+            if lanes > 1 and j < lanes:
+                s_.wait_event(start)
             for f in (fa, fb):
-                f.rows.record_stream(cur)
-                f.n_key.record_stream(cur)
-            idx = self.match(fa.features, fb.features, fa.n_key, fb.n_key)
-            self.ransac(fa.key_pts, fb.key_pts, idx, rands[j], fb.n_key, cert=cert[j])
+                f.rows.record_stream(s_)
+                f.n_key.record_stream(s_)
+            with torch.cuda.stream(s_):
+                idx = self.match(fa.features, fb.features, fa.n_key, fb.n_key)
+                res_, mask_ = self.ransac(fa.key_pts, fb.key_pts, idx, rands[j], fb.n_key, cert=cert[j])
+            for t in (idx, res_, mask_):
+                t.record_stream(cur)
             idxs.append(idx)
+        if lanes > 1:
+            for s_ in self._tie_lanes[:lanes]:
+                cur.wait_stream(s_)
         results, masks, _, status = self.certify(cert, list(rands_host) if rands_host is not None else list(rands), threads)
         if (status != 0).any():
             raise _ffi.CaeloError("pairs %s could not be certified (status %s)" % (np.flatnonzero(status != 0).tolist(), status[status != 0].tolist()))
