@@ -50,6 +50,17 @@ POOL = 17  # distinct consecutive synthetic frames per rank, walked back and for
            # turning points fall on batch boundaries, so NO BATCH HOLDS A SCAN TWICE -- equal patches are looked for across
            # the frames of a batch, and a repeated scan would be encoded for free (a pool of 6 did that: 20.4 k frames/s
            # instead of 18.x k; a real sequence never repeats a scan)
+TRAJECTORY = "circuit"  # caelo.synth.sensor_pose: 0.9 m per frame through a world that repeats every 54 m -- structure (>= 22 % non-ground
+                        # returns) at EVERY frame index, closed after 600 frames.  Rounds 1-5 used the "line" law of the goldens, on which the
+                        # sensor has left the scene by frame ~150: every scan past ~200 was the same bare ground plane (missing 1)
+
+
+def scan_at(index, **kw):
+    """synthetic scan number `index` of the endless sequence: pose = the circuit's at index mod 600 (closed: 599 -> 0 is a pair of neighbours
+    like any other), range noise / intensities seeded by the index itself (no two scans are equal)"""
+    return synth.make_scan(index % synth.CIRCUIT_PERIOD, seed=index, trajectory=TRAJECTORY, **kw)
+
+
 CERTIFY = True  # exact RANSAC (device certificates + the host half inside the pipeline) in every leg; --no-certify turns it off
 QUANTUM = 1e-3  # coordinates in whole millimetres, like the metrically quantised values of real scans: every frame then
                 # holds points exactly on voxel faces (tests/golden/frame_q0.npz: 14 of 126 k), which the voxelization
@@ -76,7 +87,7 @@ def cpu_baseline(n_frames=16, max_seconds=30.0):
     resp_m, enc_m = orc.load_models(os.path.join(REPO, "weights", "SphericalRingPCRespondLayer.h5"),
                                     os.path.join(REPO, "weights", "EncoderModel4VoxelPatch.h5"))
     cores = orc.num_threads()
-    clouds = [synth.make_scan(f, quantum=QUANTUM) for f in range(n_frames + 1)]
+    clouds = [scan_at(f, quantum=QUANTUM) for f in range(n_frames + 1)]
 
     def extract(pc):
         ring, cnt = orc.ProjectPC2SphericalRing(pc)
@@ -107,7 +118,7 @@ def bench_dense128(args, eng, world, rank, backend, dev):
     stress; DESIGN.md 4.5 states the definition).  A step = one scan: key points by the 16^3 path, 3 x 1024 patches of
     32^3 voxels, the encoder stack on them.  One stream; every rank runs its own frames (weak scaling)."""
     K, W = args.steps, args.warmup
-    pool = [torch.from_numpy(synth.make_scan((rank * 7 + i) % 997, n_beams=128, n_az=4000, quantum=QUANTUM)).to(dev) for i in range(2)]
+    pool = [torch.from_numpy(scan_at(rank * 7 + i, n_beams=128, n_az=4000, quantum=QUANTUM)).to(dev) for i in range(2)]
     wd1, bd1 = eng.seeded_dense1_32()
     eng.set_encoder32_dense(wd1, bd1)
     big = max(p.shape[0] for p in pool)
@@ -203,7 +214,7 @@ def cpu_baseline_dense128(n_patches=96):
     from caelo.engine import Engine as _E
     wd1, bd1 = _E.seeded_dense1_32()
     enc32 = orc.PatchEncoder32(enc_m.w, wd1, bd1)
-    pc = synth.make_scan(0, n_beams=128, n_az=4000, quantum=QUANTUM)
+    pc = scan_at(0, n_beams=128, n_az=4000, quantum=QUANTUM)
     t0 = time.time()
     ring, cnt = orc.ProjectPC2SphericalRing(pc)
     resp = resp_m.predict(ring[None, 0:64, 0:1792, 0:3])[0]
@@ -325,7 +336,7 @@ def main():
     K, W = steps_rank * B, args.warmup * B          # frames per rank in the timed region / in the warm-up
 
     def make_pool(scene_kind, base):
-        return [torch.from_numpy(synth.make_scan((base + i) % 997, quantum=QUANTUM, scene_kind=scene_kind)).to(dev) for i in range(POOL)]
+        return [torch.from_numpy(scan_at(base + i, quantum=QUANTUM, scene_kind=scene_kind)).to(dev) for i in range(POOL)]
 
     # synthetic scans of this rank's stretch of the trajectory, uploaded before the clock starts
     base = rank * K
@@ -693,6 +704,11 @@ def main():
                        "value_no_dedup_note": "the same workload with every patch encoded (secondary.no_dedup): the rate to expect from a scene without "
                                               "equal patches; `value` exploits that %.0f %% of this scene's patches are copies of another patch of their batch" % (100.0 * dedup_share),
                        "uploads_in_timed_region": bool(args.include_h2d),
+                       "trajectory": TRAJECTORY + " (caelo.synth.sensor_pose: structure at every frame index; closed after %d frames)" % synth.CIRCUIT_PERIOD,
+                       "scan_indices_per_rank": [[r * K, r * K + POOL - 1] for r in range(world)],
+                       "scan_indices_note": "rank r's pool = the %d consecutive scans [r K, r K + %d] of the endless synthetic sequence (K = frames per "
+                                            "rank), walked back and forth; every one of them has >= 22 %% non-ground returns "
+                                            "(tests/test_synth_world.py)" % (POOL, POOL - 1),
                        "points_per_frame": n_points, "keypoints": 1024, "patches_per_frame": 3072,
                        "frames_per_gpu": K, "hip_streams_per_gpu": host["streams"], "hip_streams_note": streams_note,
                        "frames_per_launch": B, "host_issue_us_per_frame": round(host["issue_us_per_frame"], 1),
@@ -721,7 +737,7 @@ def _make_scan_job(job):
     """(worker process of the resident_4541 leg) one synthetic scan"""
     from caelo import synth as _synth
     frame, quantum, scene = job
-    return _synth.make_scan(frame, quantum=quantum, scene_kind=scene)
+    return _synth.make_scan(frame % _synth.CIRCUIT_PERIOD, seed=frame, quantum=quantum, scene_kind=scene, trajectory=TRAJECTORY)
 
 
 class Staging:
@@ -805,7 +821,7 @@ def secondary_legs(args, eng, pipe, dev, pool, rand, rand_host, Runner, frame_pa
                                       "ahead; best of three identical runs (all listed: one copy call of an early run stalls ~7 ms inside the runtime)"}
     del staged
     other = "clutter" if args.scene == "boxes" else "boxes"
-    pool2 = [torch.from_numpy(synth.make_scan(i, quantum=QUANTUM, scene_kind=other)).to(dev) for i in range(POOL)]
+    pool2 = [torch.from_numpy(scan_at(i, quantum=QUANTUM, scene_kind=other)).to(dev) for i in range(POOL)]
     r2 = Runner(pool2)
 
     def leg_exact_ties(runner):
@@ -886,7 +902,7 @@ def secondary_legs(args, eng, pipe, dev, pool, rand, rand_host, Runner, frame_pa
         sec["resident_4541"] = {"error": str(e)[:200]}
     # configs[4]: one frame's time through the 32^3 path (bench.py --config dense128 gives its own full line)
     try:
-        pc128 = torch.from_numpy(synth.make_scan(0, n_beams=128, n_az=4000, quantum=QUANTUM)).to(dev)
+        pc128 = torch.from_numpy(scan_at(0, n_beams=128, n_az=4000, quantum=QUANTUM)).to(dev)
         wd1, bd1 = eng.seeded_dense1_32()
         eng.set_encoder32_dense(wd1, bd1)
         for _ in range(2):

@@ -109,22 +109,88 @@ def scene(seed=SCENE_SEED):
     return _SCENE_CACHE[seed]
 
 
-def sensor_pose(frame, step=(0.9, 0.05, 0.0), yaw_step=0.01):
-    """World pose of the sensor at frame index ``frame`` (translation, yaw)."""
-    return (step[0] * frame, step[1] * frame, step[2] * frame), yaw_step * frame
+TRAJECTORIES = ("line", "circuit")
+TILE = 54.0            # metres: the period of the "circuit" world along x = 60 frames of 0.9 m
+TILE_X0 = -7.0         # a tile holds the scene's objects whose centre has x in [TILE_X0, TILE_X0 + TILE)
+CIRCUIT_PERIOD = 600   # frames: lcm(60 frames per tile, 200 per lateral weave, 150 per yaw swing) -- frame f and f + 600 see the same world
+
+
+def sensor_pose(frame, step=(0.9, 0.05, 0.0), yaw_step=0.01, trajectory="line"):
+    """World pose of the sensor at frame index ``frame`` (translation, yaw).
+
+    "line" (rounds 1-5; every golden of tests/golden was made with it): a straight line with a steady lateral drift and yaw --
+    the sensor LEAVES the ~100 m scene: from frame ~150 on a scan holds a few hundred non-ground returns, from ~200 on none.
+    "circuit" (round 6): 0.9 m per frame along x through a world that repeats every TILE metres (see ``tiled``), a +-1.5 m
+    lateral weave and a +-0.2 rad yaw swing -- KITTI-like frame-to-frame motion (0.9 m, <= 0.047 m sideways, <= 0.0084 rad)
+    with structure on both sides at EVERY frame index, and closed: the world seen from frame f + 600 is the one seen from f."""
+    if trajectory == "line":
+        return (step[0] * frame, step[1] * frame, step[2] * frame), yaw_step * frame
+    assert trajectory == "circuit", trajectory
+    return ((0.9 * frame, 1.5 * math.sin(2.0 * math.pi * frame / 200.0 + 0.7), 0.0),
+            0.2 * math.sin(2.0 * math.pi * frame / 150.0 + 0.3))
+
+
+_TILE_CACHE = {}
+
+
+def tiled(scene_kind, seed=SCENE_SEED):
+    """One period of the "circuit" world: the objects of ``scene(seed)`` / ``clutter(seed)`` whose centre has x in
+    [TILE_X0, TILE_X0 + TILE) and that stay >= 4 m (boxes, poles, trunks) / >= 2.5 m (spheres) clear of the track's axis y = 0.
+    The world is this set repeated at every multiple of TILE along x.  Returns (boxes [n,6], spheres [m,4])."""
+    key = (scene_kind, seed)
+    if key not in _TILE_CACHE:
+        if scene_kind == "clutter":
+            solids, balls = clutter(seed)
+        else:
+            solids, balls = scene(seed), np.zeros((0, 4))
+        cx = 0.5 * (solids[:, 0] + solids[:, 1])
+        clear = np.minimum(np.abs(solids[:, 2]), np.abs(solids[:, 3]))
+        straddles = (solids[:, 2] < 0.0) & (solids[:, 3] > 0.0)
+        keep = (cx >= TILE_X0) & (cx < TILE_X0 + TILE) & (clear >= 4.0) & ~straddles
+        solids = solids[keep]
+        if len(balls):
+            keepb = (balls[:, 0] >= TILE_X0) & (balls[:, 0] < TILE_X0 + TILE) & (np.abs(balls[:, 1]) - balls[:, 3] >= 2.5)
+            balls = balls[keepb]
+        _TILE_CACHE[key] = (solids, balls)
+    return _TILE_CACHE[key]
+
+
+def _circuit_world(scene_kind, seed, tx):
+    """The tiles of the periodic world within reach (80 m range + the largest half extent) of a sensor at x = ``tx``, in
+    coordinates RELATIVE to the sensor's own tile (so that float64 magnitudes stay small for any frame index): returns
+    (local tx, boxes, spheres)."""
+    solids, balls = tiled(scene_kind, seed)
+    k0 = math.floor(tx / TILE)
+    local = tx - k0 * TILE
+    bs, ss = [], []
+    for k in range(-2, 3):
+        off = k * TILE
+        b = solids.copy(); b[:, 0] += off; b[:, 1] += off
+        bs.append(b[(b[:, 0] - local < MAX_RANGE) & (local - b[:, 1] < MAX_RANGE)])      # (out of range: cannot return a point)
+        if len(balls):
+            s_ = balls.copy(); s_[:, 0] += off
+            ss.append(s_[np.abs(s_[:, 0] - local) - s_[:, 3] < MAX_RANGE])
+    return local, np.concatenate(bs), (np.concatenate(ss) if ss else np.zeros((0, 4)))
 
 
 def make_scan(frame=0, n_beams=64, n_az=2000, seed=None, scene_seed=SCENE_SEED,
-              pose=None, noise_sigma=0.01, quantum=None, scene_kind="boxes"):
+              pose=None, noise_sigma=0.01, quantum=None, scene_kind="boxes", trajectory="line"):
     """Return a [N,4] float32 cloud (x,y,z,intensity) in the sensor frame, file order
     beam-major (all azimuths of beam 0, then beam 1, ...).  ``quantum`` (metres, e.g. 1e-3): coordinates rounded to
     multiples of it, like the metrically quantised values real scanners deliver -- such clouds put points exactly on
     voxel faces (x = 4.0), the case the reference's float64 index arithmetic (Voxel.py:118-152) resolves in its own
     way and a voxelization has to reproduce.  ``scene_kind``: "boxes" (ground, boxes, poles: the scene of rounds 1-2) or
-    "clutter" (ground, trees and bushes made of spheres)."""
+    "clutter" (ground, trees and bushes made of spheres).  ``trajectory``: see ``sensor_pose``; "circuit" ray-casts the periodic
+    world of ``tiled``."""
     if seed is None:
         seed = frame
-    (tx, ty, tz), yaw = sensor_pose(frame) if pose is None else pose
+    (tx, ty, tz), yaw = sensor_pose(frame, trajectory=trajectory) if pose is None else pose
+    world = None
+    if trajectory == "circuit":
+        assert scene_kind in ("boxes", "clutter")
+        tx, *world = _circuit_world(scene_kind, scene_seed, tx)
+    else:
+        assert trajectory == "line", trajectory
     cy_, sy_ = math.cos(yaw), math.sin(yaw)
     # direction table in the sensor frame via scalar libm
     elev = [math.radians(2.0 + (-24.8 - 2.0) * i / (n_beams - 1)) for i in range(n_beams)]
@@ -147,7 +213,9 @@ def make_scan(frame=0, n_beams=64, n_az=2000, seed=None, scene_seed=SCENE_SEED,
     t = np.minimum(t, tg)
     big = 1e30
     balls = np.zeros((0, 4))
-    if scene_kind == "clutter":
+    if world is not None:
+        solids, balls = world
+    elif scene_kind == "clutter":
         solids, balls = clutter(scene_seed)
     else:
         assert scene_kind == "boxes"
@@ -218,9 +286,9 @@ def cloud_sha256(pc):
     return hashlib.sha256(np.ascontiguousarray(pc).tobytes()).hexdigest()
 
 
-def relative_pose_gt(frame0, frame1):
+def relative_pose_gt(frame0, frame1, trajectory="line"):
     """Ground-truth (R, T) with P0 ~ R @ P1 + T for clouds of frame0 / frame1."""
-    (t0, y0), (t1, y1) = sensor_pose(frame0), sensor_pose(frame1)
+    (t0, y0), (t1, y1) = sensor_pose(frame0, trajectory=trajectory), sensor_pose(frame1, trajectory=trajectory)
 
     def rot(a):
         c, s = math.cos(a), math.sin(a)

@@ -240,6 +240,9 @@ def main():
     ap.add_argument("--dist-channels", type=int, default=5, choices=(3, 5), help="5 = demo mode, 3 = batch mode (SURVEY 8a-3')")
     ap.add_argument("--batch", type=int, default=8, help="frames per launch (caelo_pipeline)")
     ap.add_argument("--scene", default="boxes", choices=("boxes", "clutter"), help="synthetic scene (caelo.synth)")
+    ap.add_argument("--trajectory", default="circuit", choices=synth.TRAJECTORIES,
+                    help="synthetic sensor path (caelo.synth.sensor_pose): 'circuit' = a periodic world with structure at every frame index; "
+                         "'line' = the law of the goldens, which leaves the scene after ~150 frames")
     ap.add_argument("--pool", type=int, default=0, help="synthesise only this many distinct scans and walk them back and forth (0 1 .. P-1 "
                                                         "P-2 .. 0 1 ..: every pair stays a pair of neighbours); ray casting a scan costs ~0.5 s of CPU")
     ap.add_argument("--loader-threads", type=int, default=min(16, os.cpu_count() or 1), help="threads that read / synthesise scans and draw RANSAC's random numbers")
@@ -286,14 +289,14 @@ def main():
 
         def load(i):   # (called from the loader's threads: a pooled scan is synthesised once, by whoever asks first)
             if args.pool <= 1:
-                return synth.make_scan(i, quantum=args.quantum or None, scene_kind=args.scene)
+                return synth.make_scan(i, quantum=args.quantum or None, scene_kind=args.scene, trajectory=args.trajectory)
             i %= 2 * (args.pool - 1)
             i = i if i < args.pool else 2 * (args.pool - 1) - i
             with guard:
                 lk = locks.setdefault(i, threading.Lock())
             with lk:
                 if i not in cache:
-                    cache[i] = synth.make_scan(i, quantum=args.quantum or None, scene_kind=args.scene)
+                    cache[i] = synth.make_scan(i, quantum=args.quantum or None, scene_kind=args.scene, trajectory=args.trajectory)
             return cache[i]
         load.repeats = args.pool > 1
 

@@ -1300,7 +1300,7 @@ def test_run_sequence_from_files_equals_the_synthetic_run(tmp_path):
     d = tmp_path / "velodyne"
     d.mkdir()
     for i in range(11):
-        synth.make_scan(i).astype(np.float32).tofile(str(d / ("%06d.bin" % i)))
+        synth.make_scan(i, trajectory="circuit").astype(np.float32).tofile(str(d / ("%06d.bin" % i)))   # (run_sequence.py's default law)
     script = os.path.join(REPO, "cae-lo_amd", "run_sequence.py")
     a, b, c = str(tmp_path / "a.txt"), str(tmp_path / "b.txt"), str(tmp_path / "c.txt")
     subprocess.run([sys.executable, script, "--scans", str(d), "--chunk", "2", "--out", a], check=True, capture_output=True, timeout=300)

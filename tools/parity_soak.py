@@ -46,6 +46,9 @@ for p in (os.path.join(REPO, "cae-lo_amd"), os.path.join(REPO, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# every family on the closed "circuit" trajectory (caelo.synth.sensor_pose): structure at EVERY frame index -- on the "line" law of
+# rounds 1-5 the sensor left the scene by frame ~150 and every later scan was the same bare ground plane in every family
+TRAJECTORY = os.environ.get("CAELO_SOAK_TRAJECTORY", "circuit")
 SCENES = {"boxes": dict(scene_kind="boxes", quantum=None), "clutter": dict(scene_kind="clutter", quantum=1e-3),
           "boxes_mm": dict(scene_kind="boxes", quantum=1e-3), "shuffled": dict(scene_kind="boxes", quantum=1e-3, shuffle=True)}
 REL_TOL, FLOOR = 1e-4, 0.1
@@ -56,7 +59,7 @@ def _make(args):
     frame, kw = args
     kw = dict(kw)
     shuffle = kw.pop("shuffle", False)
-    pc = synth.make_scan(frame, **kw)
+    pc = synth.make_scan(frame, trajectory=TRAJECTORY, **kw)
     return synth.shuffle_scan(pc, 1000 + frame) if shuffle else pc
 
 
