@@ -724,7 +724,8 @@ def main():
                                    "re-evaluate the deciding hypotheses through NumPy's own cblas_sgemm / cblas_sgemv / dgesdd while later batches run: "
                                    "inlier sets, R_star / T_star and refits are the reference's bits; inside the timed region",
                            "pairs": cert["pairs"], "host_hypotheses_per_pair": round(cert["evals_per_pair"], 2),
-                           "certifier_thread_us_per_pair": round(cert["host_us_per_pair"], 1), "blas": (eng.host_blas() or {}).get("library")}},
+                           "certifier_thread_us_per_pair": round(cert["host_us_per_pair"], 1), "bound_violations": eng.bound_violations(),
+                           "blas": (eng.host_blas() or {}).get("library")}},
             "roofline": roofline, "roofline_match": roofline_match, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(out), flush=True)

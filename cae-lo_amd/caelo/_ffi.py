@@ -44,7 +44,7 @@ class FrameJob(C.Structure):
 
 
 PAIR_NONE, PAIR_CHAIN, PAIR_EXPLICIT = 0, 1, 2
-ABI_VERSION = 4   # include/caelo.h CAELO_ABI_VERSION
+ABI_VERSION = 5   # include/caelo.h CAELO_ABI_VERSION
 BUILD_PACKED_F32, BUILD_PROF, BUILD_STAMPED = 1, 2, 256   # caelo_build_flags() bits (include/caelo.h)
 
 # the same layout as a NumPy record (a run's jobs are filled column-wise and handed over in one call)
@@ -106,6 +106,9 @@ SIGNATURES = [
     ("caelo_cert_bytes", c_i64, []),
     ("caelo_host_bind_blas", c_int, [c_vp, c_vp, c_vp, c_int]),
     ("caelo_host_blas_bound", c_int, []),
+    ("caelo_host_unbind_blas", c_int, []),
+    ("caelo_host_blas_probe", c_int, [c_int, c_vp, c_vp, c_i64, c_vp]),
+    ("caelo_host_bound_violations", c_i64, []),
     ("caelo_host_solve_rt", c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     ("caelo_host_ransac", c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("caelo_host_certify", c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int]),

@@ -215,6 +215,8 @@ class Pipeline:
                 info[:k, 0] = 0
                 info[:k, 1] = 3                                  # "no record" until the certifier says otherwise
                 has = jobs["pair"] != _ffi.PAIR_NONE
+                out._has_pair = np.zeros(out.k, dtype=bool)
+                out._has_pair[:k] = has
                 jobs["result_host"] = np.where(has, res.ctypes.data + idx * _ffi.POSE_DTYPE.itemsize, 0)
                 jobs["mask_host"] = np.where(has, masks.ctypes.data + idx * MAX_K, 0)
                 jobs["info_host"] = np.where(has, info.ctypes.data + idx * 8, 0)
@@ -320,6 +322,10 @@ class Pipeline:
         res, masks, evals, status = out.exact
         if (status[:k] == 2).any():
             raise _ffi.CaeloError("a pair holds more than 1024 matches: no certificate")
+        has = getattr(out, "_has_pair", None)
+        if has is not None and (status[:k][has[:k]] != 0).any():   # (the flush reports it too: a job WITH a pair must come back exact)
+            bad = np.flatnonzero(has[:k] & (status[:k] != 0))
+            raise _ffi.CaeloError("pairs of frames %s came back without an exact result (status %s)" % (bad.tolist(), status[:k][bad].tolist()))
         ok = status[:k] == 0
         if ok.any():
             with torch.cuda.stream(torch.cuda.current_stream(self.eng.device)):
@@ -376,7 +382,14 @@ class Pipeline:
             d = np.diff(src_p.astype(np.int64))
             inside = np.ones(k - 1, bool); inside[B - 1::B] = False          # (the step from one batch to the next may be anything)
             if inside.any() and (d[inside] == d[inside][0]).all() and int(d[inside][0]) >= int(nbytes.max()) and int(d[inside][0]) % 16 == 0:
-                pitch = int(d[inside][0])
+                # ... and the scans of a batch must be views of ONE allocation that spans the whole copy: equal spacing alone would also
+                # be true of separately pinned tensors that happen to sit at a fixed distance, and one copy over them would read the gaps
+                stor = [(pc.untyped_storage().data_ptr(), pc.untyped_storage().nbytes()) for pc in host_scans]
+                one_block = all(len({stor[i][0] for i in range(lo, min(k, lo + B))}) == 1 and
+                                int(src_p[min(k, lo + B) - 1] + nbytes[min(k, lo + B) - 1]) <= stor[lo][0] + stor[lo][1]
+                                for lo in range(0, k, B))
+                if one_block:
+                    pitch = int(d[inside][0])
         key = ("upload", B, slots, pitch)
         st = self._upload.get(key) if hasattr(self, "_upload") else None
         if st is None or st[1] < big:
@@ -850,6 +863,11 @@ class Engine:
         return self.zeros((k, _ffi.CERT_DTYPE.itemsize), torch.uint8)
 
     # ---- the host half of the exact RANSAC (csrc/certify.hip, caelo/hostexact.py) ------------------------------------
+    def bound_violations(self):
+        """caelo_host_bound_violations: exact hypothesis counts the host half found above the device's upper bound since the process
+        started (such a pair is decided by the reference's loop without bounds: still exact).  0 on every run so far."""
+        return int(self.lib.caelo_host_bound_violations())
+
     def host_blas(self):
         """Bind libcaelo's host half to the BLAS / LAPACK of this process's NumPy (once; caelo/hostblas.py)."""
         from . import hostblas

@@ -69,31 +69,14 @@ def _addresses(path):
     return None
 
 
-def _numpy_solve_rt(p0, p1):
-    """Match.py:138-158 in NumPy, statement by statement (the check of a binding; also the host half's pure-NumPy form)."""
-    mean0 = np.mean(p0, axis=0).reshape(1, 3)
-    mean1 = np.mean(p1, axis=0).reshape(1, 3)
-    a0 = p0 - mean0
-    a1 = p1 - mean1
-    H = np.dot(a1.T, a0)
-    U, S, V = np.linalg.svd(H)
-    R = np.dot(V.T, U.T)
-    cred = 1
-    if np.linalg.det(R) < 0:
-        cred = -1
-        V[:, 2] = V[:, 2] * (-1)
-        R = np.dot(V.T, U.T)
-    T = mean0.T - np.dot(R, mean1.T)
-    return R, T, cred
-
-
 def _verify(lib, n_samples=400):
-    """The bound entry points must give NumPy's bits: SolveRT on random 4- and many-point samples (sgemm with k = 4 and k = n,
-    dgesdd, sgemm 3x3x3, sgemv), nearly planar and rank-deficient ones included."""
+    """The bound entry points must give NumPy's bits, call by call: the five BLAS / LAPACK calls the host half makes
+    (caelo_host_blas_probe issues each exactly as csrc/certify.hip does) against ``np.dot`` / ``np.linalg.svd`` on the same
+    operands -- covariance products with k = 4 and k = n, 3 x 3 SVDs of well-conditioned, nearly planar and rank-deficient
+    matrices, the 3 x 3 products, the matrix-vector product and the residual product.  (That the host half COMPOSES these calls
+    the way Match.py:138-158 does is a test's business: tests/test_host_exact.py compares it with the oracle's SolveRT.)"""
     rng = np.random.RandomState(20240229)
-    R_ = np.empty(9, np.float32)
-    T_ = np.empty(3, np.float32)
-    cred = C.c_int32(0)
+    vp = lambda x: C.c_void_p(x.ctypes.data)
     for t in range(n_samples):
         n = 4 if t % 4 else int(rng.randint(5, 400))
         p1 = (rng.standard_normal((n, 3)) * [30.0, 30.0, 0.5 if t % 3 else 1e-3]).astype(np.float32)
@@ -104,10 +87,24 @@ def _verify(lib, n_samples=400):
             p0[1] = p0[0]          # a repeated point: rank-2 covariance
         if t % 11 == 0:
             p0[:, 2] = p0[0, 2]    # exactly coplanar
-        if lib.caelo_host_solve_rt(p0.ctypes.data, p1.ctypes.data, n, R_.ctypes.data, T_.ctypes.data, C.byref(cred)) != 0:
+        a0 = np.ascontiguousarray(p0 - np.mean(p0, axis=0).reshape(1, 3))
+        a1 = np.ascontiguousarray(p1 - np.mean(p1, axis=0).reshape(1, 3))
+        H = np.empty((3, 3), np.float32)
+        if lib.caelo_host_blas_probe(0, vp(a1), vp(a0), n, vp(H)) != 0 or not np.array_equal(H, np.dot(a1.T, a0)):
             return False
-        Rn, Tn, cn = _numpy_solve_rt(p0, p1)
-        if Rn.dtype != np.float32 or not (np.array_equal(Rn.ravel(), R_) and np.array_equal(Tn.ravel(), T_) and cn == cred.value):
+        uv = np.empty((2, 3, 3), np.float32)
+        U, _, V = np.linalg.svd(H)
+        if lib.caelo_host_blas_probe(1, vp(H), None, 1, vp(uv)) != 0 or U.dtype != np.float32 or not (np.array_equal(uv[0], U) and np.array_equal(uv[1], V)):
+            return False
+        R = np.empty((3, 3), np.float32)
+        if lib.caelo_host_blas_probe(2, vp(uv[1]), vp(uv[0]), 1, vp(R)) != 0 or not np.array_equal(R, np.dot(V.T, U.T)):
+            return False
+        m1 = np.ascontiguousarray(np.mean(p1, axis=0).reshape(1, 3))
+        y = np.empty(3, np.float32)
+        if lib.caelo_host_blas_probe(3, vp(R), vp(m1), 1, vp(y)) != 0 or not np.array_equal(y, np.dot(R, m1.T).ravel()):
+            return False
+        x = np.empty((3, n), np.float32)
+        if lib.caelo_host_blas_probe(4, vp(R), vp(p1), n, vp(x)) != 0 or not np.array_equal(x, np.dot(R, p1.T)):
             return False
     return True
 
@@ -132,6 +129,7 @@ def bind(lib):
         if _verify(lib):
             _bound = {"library": path, "ilp64": bool(ilp), "handle": keep}
             return _bound
+        lib.caelo_host_unbind_blas()   # a library that does not reproduce NumPy must not stay bound behind the exception
         tried.append((path, "results differ from np.dot / np.linalg.svd"))
     raise CaeloError("no BLAS of this process reproduces NumPy bit for bit: %s" % (tried,))
 

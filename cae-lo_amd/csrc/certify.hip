@@ -46,6 +46,7 @@ struct HostBlas {
     int lwork = 0;  // dgesdd's own answer to the workspace query for a 3 x 3 matrix (what NumPy allocates)
 };
 HostBlas g_blas;
+std::atomic<int64_t> g_bound_violations{0};   // exact counts above the device's bound (ransac_host)
 
 inline void gemm(int ta, int tb, int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
                  int64_t ldc) {
@@ -226,6 +227,7 @@ int ransac_host(const float *P0, const float *P1, int64_t n, const double *rnd, 
             if (!idx0 && !rnd) return 1;
             for (int t = 0; t < CAELO_RANSAC_MAX_TRIALS; ++t) { c[t] = hi[t]; ex[t] = 0; }
             int held = -1;  // the hypothesis whose mask / pose S.m_best / f hold
+            bool violated = false;
             for (;;) {
                 replay(c, n, &w, &it);
                 if (w < 0 || ex[w]) break;
@@ -234,9 +236,21 @@ int ransac_host(const float *P0, const float *P1, int64_t n, const double *rnd, 
                 int cnt = 0;
                 if (!hypothesis(P0, P1, n, idx, thr, S, &f, S.m_best.data(), &cnt)) return -1;
                 ++out.evals;
+                // The argument above stands on hi[t] >= the reference's count.  The bound's constant is calibrated, not proven
+                // (match.hip, hypothesis_bound): every exact count this loop sees is checked against it, and ONE count above its bound
+                // discards the bounds of the pair -- the level is redone as the reference's loop stands -- and is counted
+                // (caelo_host_bound_violations; the parity soak and bench.py print the counter).
+                if (cnt > hi[w]) { violated = true; break; }
                 c[w] = cnt;
                 ex[w] = 1;
                 held = w;
+            }
+            if (violated) {
+                g_bound_violations.fetch_add(1);
+                hi = nullptr;
+                --level;
+                thr *= 0.5f;   // (exact: the loop header doubles it again)
+                continue;
             }
             if (w >= 0 && held != w) {  // the winner was evaluated before another candidate: once more for its mask
                 int32_t idx[4];
@@ -348,6 +362,36 @@ CAELO_API int caelo_host_bind_blas(void *cblas_sgemm, void *cblas_sgemv, void *d
 }
 
 CAELO_API int caelo_host_blas_bound(void) { return g_blas.sgemm != nullptr ? 1 : 0; }
+
+// The five BLAS / LAPACK calls of the host half, one at a time, exactly as solve_rt_rows / score issue them (same transposition
+// flags and leading dimensions): what caelo/hostblas.py compares with np.dot / np.linalg.svd before it accepts a binding.
+//   0: out[9]  = np.dot(a.T, b)            a, b [n][3]          (cblas_sgemm Trans, NoTrans, k = n)
+//   1: out[18] = U | Vh of np.linalg.svd(a), a [3][3]           (dgesdd on a float64 copy, cast back)
+//   2: out[9]  = np.dot(a.T, b.T)          a, b [3][3]          (cblas_sgemm Trans, Trans)
+//   3: out[3]  = np.dot(a, b)              a [3][3], b [3]      (cblas_sgemv)
+//   4: out[3n] = np.dot(a, b.T)            a [3][3], b [n][3]   (cblas_sgemm NoTrans, Trans)
+CAELO_API int caelo_host_blas_probe(int op, const float *a_host, const float *b_host, int64_t n, float *out_host) {
+    CAELO_REQUIRE(g_blas.sgemm, "caelo_host_bind_blas was not called");
+    CAELO_REQUIRE(a_host && out_host && (b_host || op == 1) && op >= 0 && op <= 4 && n > 0, "bad argument");
+    switch (op) {
+    case 0: gemm(kTrans, kNoTrans, 3, 3, n, a_host, 3, b_host, 3, out_host, 3); break;
+    case 1: CAELO_REQUIRE(svd3(a_host, out_host, out_host + 9), "dgesdd failed"); break;
+    case 2: gemm(kTrans, kTrans, 3, 3, 3, a_host, 3, b_host, 3, out_host, 3); break;
+    case 3: gemv3(a_host, b_host, out_host); break;
+    default: gemm(kNoTrans, kTrans, 3, n, 3, a_host, 3, b_host, 3, out_host, n); break;
+    }
+    return CAELO_OK;
+}
+
+// forget the bound entry points (caelo/hostblas.py: a candidate library that failed the bit-for-bit verification must not stay bound)
+CAELO_API int caelo_host_unbind_blas(void) {
+    g_blas = HostBlas();
+    return CAELO_OK;
+}
+
+// exact counts found ABOVE the device's upper bound since the process started (0 on every run so far; a pair where it happens is
+// decided by the reference's loop without bounds, so its result is still exact)
+CAELO_API int64_t caelo_host_bound_violations(void) { return g_bound_violations.load(); }
 
 CAELO_API int caelo_host_solve_rt(const float *p0_host, const float *p1_host, int64_t n, float *R_host, float *T_host, int32_t *credible_host) {
     CAELO_REQUIRE(g_blas.sgemm, "caelo_host_bind_blas was not called");

@@ -133,7 +133,10 @@ void cert_process(caelo_pipeline *p, int slot, int i, std::vector<double> &draws
             if (hipMemcpy(draws.data(), it.rand_dev, draws.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) st = -1;
             else st = certify_record(t.host[i], draws.data(), it.res, it.mask, CAELO_MAX_KEYPTS, &evals);
         }
-        if (st < 0) failed = 1;
+        // st 3: the kernels left no record for a job that HAS a pair (every item of a task has one) -- with cert_only they wrote no
+        // result either, so nothing valid exists for this pair: a failure of the run, not a value.  (st 2, more than 1024 matches,
+        // stays a status: the caller is told which pair and uses caelo_host_ransac.)
+        if (st < 0 || st == 3) failed = 1;
         if (it.info) { it.info[0] = evals; it.info[1] = st; }
     }
     bool last;
@@ -170,18 +173,39 @@ void cert_worker(caelo_pipeline *p) {
 int cert_drain(caelo_pipeline *p, size_t keep) {
     const int64_t t_in = now_ns();
     struct Acc { caelo_pipeline *p; int64_t t; ~Acc() { p->stat_cert_drain_ns += now_ns() - t; } } acc{p, t_in};
+    // A HIP failure here must not leave a task in state 1 with nothing queued: cert_task / cert_wait_idle wait for state 0 and the
+    // flush, begin and destroy calls would hang instead of returning the error.  The popped task and every task still issued are
+    // given back (their results are never written; the flush reports cert_failed).
+    auto abandon = [&](caelo_pipeline::CertTask &cur, hipError_t e, const char *what) {
+        {
+            std::lock_guard<std::mutex> lk(p->cert_mu);
+            cur.state = 0;
+            cur.remaining = 0;
+            for (const int s : p->cert_issued) {
+                p->cert_ring[s].state = 0;
+                p->cert_ring[s].remaining = 0;
+            }
+            p->cert_failed = 1;
+        }
+        p->cert_issued.clear();
+        p->cert_cv.notify_all();
+        caelo_set_error("caelo_pipeline: %s failed while handing certificates to the host half: %s", what, hipGetErrorString(e));
+        return CAELO_ERR_HIP;
+    };
     while (p->cert_issued.size() > keep) {
         const int slot = p->cert_issued.front();
         p->cert_issued.pop_front();
         caelo_pipeline::CertTask &t = p->cert_ring[slot];
-        CAELO_HIP(hipEventSynchronize(t.pair_done));
+        hipError_t e = hipEventSynchronize(t.pair_done);
+        if (e != hipSuccess) return abandon(t, e, "hipEventSynchronize");
         for (int i = 0; i < t.n && !p->cert_zero_copy;) {   // records that lie back to back on the device leave in one copy
             int j = i + 1;
             while (j < t.n && t.item[j].dev == t.item[j - 1].dev + 1) ++j;
-            CAELO_HIP(hipMemcpyAsync(t.host + i, t.item[i].dev, (size_t)(j - i) * sizeof(caelo_ransac_cert), hipMemcpyDeviceToHost, p->sC));
+            e = hipMemcpyAsync(t.host + i, t.item[i].dev, (size_t)(j - i) * sizeof(caelo_ransac_cert), hipMemcpyDeviceToHost, p->sC);
+            if (e != hipSuccess) return abandon(t, e, "hipMemcpyAsync");
             i = j;
         }
-        if (!p->cert_zero_copy) CAELO_HIP(hipEventRecord(t.copied, p->sC));
+        if (!p->cert_zero_copy && (e = hipEventRecord(t.copied, p->sC)) != hipSuccess) return abandon(t, e, "hipEventRecord");
         {
             std::lock_guard<std::mutex> lk(p->cert_mu);
             t.state = 2;
@@ -209,7 +233,7 @@ int cert_task(caelo_pipeline *p, caelo_pipeline::CertTask **out, int *slot_out) 
             CAELO_HIP(hipEventCreateWithFlags(&t.pair_done, hipEventDisableTiming));
             CAELO_HIP(hipEventCreateWithFlags(&t.copied, hipEventDisableTiming));
         }
-        {   // CAELO_CERT_THREADS (1 .. 3): certifier threads of every pipeline of the process (a scheduling knob, no arithmetic)
+        {   // CAELO_CERT_THREADS (1 .. 8, default 3): certifier threads of every pipeline of the process (a scheduling knob, no arithmetic)
             const char *e = getenv("CAELO_CERT_THREADS");
             int nt = e ? atoi(e) : caelo_pipeline::CERT_THREADS_DEFAULT;
             nt = nt < 1 ? 1 : (nt > caelo_pipeline::CERT_THREADS ? caelo_pipeline::CERT_THREADS : nt);

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CAELO_ABI_VERSION 4   /* 4: caelo_voxmap_export never waits for the device (a count above capacity is the overflow report), caelo_voxmap_order; 3: certificates, caelo_host_* */
+#define CAELO_ABI_VERSION 5   /* 5: caelo_host_unbind_blas / _blas_probe / _bound_violations; 4: caelo_voxmap_export never waits for the device (a count above capacity is the overflow report), caelo_voxmap_order; 3: certificates, caelo_host_* */
 
 /* geometry fixed by the reference: SphericalRing.py:28-58, Voxel.py:15-52 */
 #define CAELO_RING_H 69
@@ -276,6 +276,15 @@ int caelo_ransac(caelo_ctx *ctx, const float *pc0, int ld0, const float *pc1, in
  *   1024 pairs: use caelo_host_ransac), 3 no record.  `threads` host threads share the k records. */
 int caelo_host_bind_blas(void *cblas_sgemm, void *cblas_sgemv, void *dgesdd, int ilp64);
 int caelo_host_blas_bound(void);
+int caelo_host_unbind_blas(void);   /* forget the bound entry points (a library that failed the binder's bit-for-bit check) */
+/* one BLAS / LAPACK call of the host half, issued exactly as the host half issues it (flags, leading dimensions): what a binder
+ * compares with np.dot / np.linalg.svd.  op 0: out[9] = a^T b, a, b [n][3]; 1: out[18] = U | Vh of svd(a [3][3]); 2: out[9] = a^T b^T,
+ * [3][3] each; 3: out[3] = a b, a [3][3], b [3]; 4: out[3][n] = a b^T, a [3][3], b [n][3] */
+int caelo_host_blas_probe(int op, const float *a_host, const float *b_host, int64_t n, float *out_host);
+/* exact hypothesis counts the host half found ABOVE the device's upper bound since the process started.  The bound's constant is
+ * calibrated, not proven: the host half checks every count it evaluates, and on a violation decides the pair by the reference's
+ * loop without bounds (still exact) and counts it here.  0 on every run so far. */
+int64_t caelo_host_bound_violations(void);
 int caelo_host_solve_rt(const float *p0_host, const float *p1_host, int64_t n, float *R_host, float *T_host, int32_t *credible_host);
 int caelo_host_ransac(const float *pairs0_host, const float *pairs1_host, int64_t n, const double *rand_host, const int32_t *hi_host,
                       caelo_pose_result *result_host, uint8_t *mask_host, int32_t *evals_host);

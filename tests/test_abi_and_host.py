@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == typed, "header vs ctypes table: %s" % sorted(declared ^ typed)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.caelo_abi_version() == _ffi.ABI_VERSION == 4
+    assert lib.caelo_abi_version() == _ffi.ABI_VERSION == 5
     assert ctypes.sizeof(_ffi.PoseResult) == (9 + 3 + 9 + 3 + 1) * 4 + 5 * 4
 
 

@@ -48,7 +48,7 @@ def test_host_ransac_equals_the_oracle_with_and_without_bounds(orc, a, b, p):
     """caelo_host_ransac: (1) without bounds = the reference's loop, every hypothesis evaluated; (2) with ANY valid upper
     bounds on the first level's counts the same result from a handful of evaluations -- the exact counts themselves, the
     counts plus slack, and 'no information' (N everywhere)."""
-    from caelo import hostexact
+    from caelo import hostexact, _ffi
     P0, P1, _ = _pairs(a, b, p)
     N = len(P0)
     for seed in (11, 12, 13):
@@ -75,10 +75,19 @@ def test_host_ransac_equals_the_oracle_with_and_without_bounds(orc, a, b, p):
             assert ev2 <= 501      # (+1: the winner once more for its mask when another candidate was evaluated after it)
         r3, _, ev3 = hostexact.ransac(P0, P1, draws, hi=cnt)
         assert ev3 <= 3                                 # tight bounds: the winner (and a tie) is all that is evaluated
+        # an INVALID bound (below the true count of the hypothesis the replay lands on): the host half notices -- every count it
+        # evaluates is compared with its bound -- decides the pair by the reference's loop without bounds, and counts the event
+        lib = _ffi.load()
+        v0 = int(lib.caelo_host_bound_violations())
+        bad = cnt.copy()
+        bad[int(r["best_trial"])] -= 1
+        r4, mask4, ev4 = hostexact.ransac(P0, P1, draws, hi=bad)
+        assert np.array_equal(mask4, m) and r4.tobytes() == r.tobytes() and ev4 > len(trace)
+        assert int(lib.caelo_host_bound_violations()) == v0 + 1
 
 
 def test_host_ransac_escalation_failure_and_tiny_inputs(orc):
-    from caelo import hostexact
+    from caelo import hostexact, _ffi
     pr = np.load(os.path.join(GOLDEN, "pair_0_1.npz"))
     for k in ("esc", "fail"):
         P0, P1 = np.ascontiguousarray(pr[k + "_P0"]), np.ascontiguousarray(pr[k + "_P1"])
