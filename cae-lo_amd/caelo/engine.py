@@ -527,6 +527,11 @@ class Engine:
             t = self._wss[key] = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
         return t
 
+    def set_encoder_sparse(self, max_cells):
+        """caelo_set_encoder_sparse: patches with at most ``max_cells`` (0 .. 64) non-background cells after conv1 + pool1 are encoded a
+        wavefront each (k_enc_stage1s), the rest a workgroup each (k_enc_stage1x); 0 = all by the workgroup kernel.  Same bits either way."""
+        _ffi.check(self.lib.caelo_set_encoder_sparse(self.ctx, int(max_cells)))
+
     def set_encoder_reference(self, on=True):
         """caelo_set_encoder_reference: stage 1 of this engine's encoder = the exact-f32 kernel (precision reference; slower)."""
         _ffi.check(self.lib.caelo_set_encoder_reference(self.ctx, 1 if on else 0))

@@ -147,3 +147,69 @@ def test_ransac_draws_are_numpys_stream():
     assert all(np.array_equal(got[s], want[s]) for s in want)
     rng = np.random.RandomState(5)
     assert np.array_equal(ransac_draws(rng), np.random.RandomState(5).random_sample(6000))
+
+
+def test_native_random_sample_is_numpys_stream():
+    """caelo_host_random_sample == numpy.random.RandomState(seed).random_sample(n), bit for bit (MT19937, init_genrand seeding, 53-bit
+    doubles): the stream RANSAC4RT's samples come from (Match.py:182-184) -- seeds 0, 1, the largest, and the run_sequence.py range."""
+    import ctypes as C
+    from caelo import _ffi
+    lib = _ffi.load()
+    for seed in (0, 1, 5, 999, 1000, 1001, 5540, 123456789, 2 ** 31 - 1, 2 ** 31, 2 ** 32 - 1):
+        for n in (1, 4, 6000, 6001):
+            out = np.empty(n, np.float64)
+            assert lib.caelo_host_random_sample(C.c_uint32(seed), n, C.c_void_p(out.ctypes.data)) == 0
+            assert np.array_equal(out, np.random.RandomState(seed).random_sample(n)), (seed, n)
+
+
+def test_seqloader_reads_files_and_draws(tmp_path):
+    """caelo_seqloader on host buffers: 21 scan files of ragged lengths through a ring of 3 batches of 4 on 5 threads -- every batch's
+    bytes and point counts equal the files', the draws equal RandomState(seed_base + first_frame + i - 1), slots are only reused after
+    their release; a truncated file fails the wait with an error that names it."""
+    import ctypes as C
+    from caelo import _ffi
+    lib = _ffi.load()
+    rs = np.random.RandomState(3)
+    n, batch, ring, cap = 21, 4, 3, 700
+    scans = [rs.standard_normal((int(rs.randint(1, cap + 1)), 4)).astype(np.float32) for _ in range(n)]
+    scans[7] = np.zeros((0, 4), np.float32)     # an empty file is a scan without points
+    paths = []
+    for i, a in enumerate(scans):
+        p = tmp_path / ("%06d.bin" % i)
+        a.tofile(str(p))
+        paths.append(str(p).encode())
+
+    def run(paths_, first=40, seed_base=1000):
+        arr = (C.c_char_p * len(paths_))(*paths_)
+        ring_h = np.full((ring, batch, cap, 4), np.nan, np.float32)
+        draws_h = np.zeros((ring, batch, 6000), np.float64)
+        h = C.c_void_p()
+        _ffi.check(lib.caelo_seqloader_create(arr, len(paths_), first, batch, ring, cap, C.c_void_p(ring_h.ctypes.data), C.c_void_p(draws_h.ctypes.data),
+                                              seed_base, 5, C.byref(h)))
+        try:
+            slot = C.c_int32(-1)
+            npts = (C.c_int64 * batch)()
+            nb = (len(paths_) + batch - 1) // batch
+            for b in range(nb):
+                _ffi.check(lib.caelo_seqloader_wait(h, b, C.byref(slot), npts))
+                assert slot.value == b % ring
+                for j in range(batch):
+                    i = b * batch + j
+                    if i >= len(paths_):
+                        assert npts[j] == 0
+                        continue
+                    assert npts[j] == len(scans[i])
+                    assert np.array_equal(ring_h[slot.value, j, :npts[j]], scans[i])
+                    assert np.array_equal(draws_h[slot.value, j], np.random.RandomState(seed_base + first + i - 1).random_sample(6000))
+                ring_h[slot.value] = np.nan       # (a slot handed back may be overwritten at once)
+                _ffi.check(lib.caelo_seqloader_release(h, b))
+            st = (C.c_int64 * 3)()
+            _ffi.check(lib.caelo_seqloader_stats(h, st))
+        finally:
+            lib.caelo_seqloader_destroy(h)
+
+    run(paths)
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(b"\0" * 24)
+    with pytest.raises(_ffi.CaeloError, match="bad.bin"):
+        run(paths[:5] + [str(bad).encode()] + paths[5:])

@@ -920,6 +920,41 @@ def test_two_ranks_equal_one_rank(tmp_path):
     assert d["scaling"] == "strong" and d["steps"] == 2 and d["config"]["poses_solved"] == "16/16" and d["n_gpus"] == 2
 
 
+def test_eight_ranks_on_one_gpu(tmp_path):
+    """BASELINE configs[3] as far as one GPU can show it: EIGHT ranks (gloo; RCCL wants a device per rank), each
+    with its own pipeline -- 8 x 4 HIP streams beside 8 process groups on one device: the hardware-queue exhaustion an 8-GPU node
+    cannot produce but a mis-sized pipeline would -- two batches each.  bench.py's 8-rank line: every pose solved, eight per-rank
+    rates, the collective's world size and byte count, the chunked gathers equal to one gather, each rank's scan indices.
+    run_sequence.py over 8 ranks: the pose file byte-identical to the one-rank run (the straddling pairs of seven boundaries)."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    from conftest import REPO
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, CAELO_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1"]
+    r = subprocess.run(launch + ["--master-port", "29551", os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "2",
+                                 "--warmup", "1", "--no-cpu-baseline"], check=True, env=env, capture_output=True, timeout=600)
+    d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith('{"metric"')][-1])
+    c = d["config"]
+    assert d["n_gpus"] == 8 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert c["poses_solved"] == "16/16" and c["status_bits"] == 0 and c["lane_faults"] == 0
+    assert len(c["per_rank_frames_per_s"]) == 8 and all(v > 0 for v in c["per_rank_frames_per_s"])
+    col = c["collective"]
+    assert col["world_size"] == 8 and col["backend"] == "gloo" and col["chunks_equal_one_gather"]
+    assert col["bytes_received_per_rank"] == 8 * 16 * 1024 * 64 * 4          # --gather all: 16 frames of every rank
+    assert c["scan_indices_per_rank"] == [[16 * r_, 16 * r_ + 16] for r_ in range(8)]   # rank r's pool: 17 scans from r K on
+    assert c["hip_streams_per_gpu"] >= 1    # (four where the runtime grants them; the fallback is reported, not fatal)
+    script = os.path.join(REPO, "cae-lo_amd", "run_sequence.py")
+    one, eight = str(tmp_path / "w1.txt"), str(tmp_path / "w8.txt")
+    subprocess.run([sys.executable, script, "--synthetic", "41", "--out", one], check=True, env=env, capture_output=True, timeout=300)
+    subprocess.run(launch + ["--master-port", "29552", script, "--synthetic", "41", "--out", eight], check=True, env=env,
+                   capture_output=True, timeout=600)
+    assert open(one).read() == open(eight).read() and len(open(one).read().splitlines()) == 41
+
+
 def test_icp_vs_reference_golden(api, orc, models, scans):
     """caelo.api.ICP (nearest neighbours, inlier selection, SolveRT and the point update on the GPU, the
     reference's loop control on the host) against MyICP.ICP run by the reference itself: same number of iterations,
@@ -1452,6 +1487,52 @@ def test_stage1x_agrees_with_the_f32_kernel(engine):
     assert ref[0].shape == lay[0].shape and 0 < np.abs(ref[0] - lay[0]).max() <= 1e-6, np.abs(ref[0] - lay[0]).max()
     assert np.abs(ref[3] - lay[3]).max() <= 2e-6
     assert all(np.array_equal(a, b) for a, b in zip(lay, again))
+
+
+@pytest.mark.gpu
+def test_sparse_stage1_is_bitwise_invisible(engine, scans):
+    """Round 6: k_enc_stage1s (a wavefront per sparse patch) and k_enc_stage1x (a workgroup per patch) must give every patch the same
+    bits -- the threshold between them (caelo_set_encoder_sparse) is a scheduling knob.  Checked on the golden frame's 3072 patches
+    (plain launch: every layer's output), on crafted patches (empty, one voxel in every corner / on every face, a full patch, random
+    densities around every threshold), and through the de-duplicated launches of the pipeline (rows and poses of a 10-frame run)."""
+    import torch
+    from caelo.engine import Pipeline, ransac_draws
+    bits = np.ascontiguousarray(np.load(os.path.join(GOLDEN, "frame_q0.npz"))["patch_bits"].reshape(-1, 64))
+    rs = np.random.RandomState(7)
+    crafted = []
+    crafted.append(np.zeros((16, 16, 16), bool))
+    for c in [(0, 0, 0), (15, 15, 15), (0, 15, 7), (8, 0, 15), (7, 7, 7), (15, 0, 0), (1, 1, 1), (14, 2, 9)]:
+        d = np.zeros((16, 16, 16), bool); d[c] = True; crafted.append(d)
+    crafted.append(np.ones((16, 16, 16), bool))
+    for share in (0.0005, 0.001, 0.002, 0.004, 0.008, 0.015, 0.03, 0.06, 0.12, 0.3):
+        for _ in range(12):
+            crafted.append(rs.random_sample((16, 16, 16)) < share)
+    for _ in range(24):   # clustered voxels: a few cells only, many voxels each
+        d = np.zeros((16, 16, 16), bool)
+        o = rs.randint(0, 12, 3)
+        d[o[0]:o[0] + 4, o[1]:o[1] + 4, o[2]:o[2] + 4] = rs.random_sample((4, 4, 4)) < 0.5
+        crafted.append(d)
+    cb = np.packbits(np.stack(crafted).reshape(len(crafted), -1), axis=-1, bitorder="little").view(np.uint64).reshape(-1, 64)
+    pad = (-len(cb)) % 3
+    allbits = np.concatenate([bits, cb, np.zeros((pad, 64), np.uint64)])
+    t = torch.from_numpy(allbits.view(np.int64)).to(engine.device)
+    pcs = [torch.from_numpy(scans(i, quantum=1e-3)).to(engine.device) for i in range(10)]
+    rnd = [torch.from_numpy(ransac_draws(40 + i)).to(engine.device) for i in range(10)]
+    pipe = Pipeline(engine, 8, 3)
+    outs = {}
+    try:
+        for thr in (0, 1, 5, 16, 32, 64):
+            engine.set_encoder_sparse(thr)
+            lay = [x.cpu().numpy() for x in engine.encode_layers(t)]
+            a = pipe.run(pcs, rnd)
+            torch.cuda.synchronize()
+            outs[thr] = lay + [a.rows.cpu().numpy(), a.result.cpu().numpy(), a.pair_idx.cpu().numpy()]
+    finally:
+        engine.set_encoder_sparse(32)
+    for thr in (1, 5, 16, 32, 64):
+        for i, (x, y) in enumerate(zip(outs[0], outs[thr])):
+            assert np.array_equal(x, y), (thr, i, np.abs(x.astype(np.float64) - y.astype(np.float64)).max())
+    assert engine.lane_faults() == 0
 
 
 @pytest.mark.gpu
