@@ -72,7 +72,6 @@ SIGNATURES = [
     ("caelo_set_respond_weights", c_int, [c_vp] + [c_vp] * 4),
     ("caelo_set_encoder_weights", c_int, [c_vp] + [c_vp] * 10),
     ("caelo_set_encoder_reference", c_int, [c_vp, c_int]),
-    ("caelo_set_encoder_sparse", c_int, [c_vp, c_int]),
     ("caelo_project", c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("caelo_respond", c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     ("caelo_keypoints_ws_bytes", c_i64, []),
@@ -138,7 +137,8 @@ SIGNATURES = [
     ("caelo_pipeline_get_pace", c_int, [c_vp]),
     ("caelo_upload_many", c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
     ("caelo_host_random_sample", c_int, [C.c_uint32, c_i64, c_vp]),
-    ("caelo_seqloader_create", c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_i64, c_vp, c_vp, c_i64, c_int, c_vp]),
+    ("caelo_seqloader_slot_bytes", c_i64, [c_int, c_i64]),
+    ("caelo_seqloader_create", c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_i64, c_vp, c_vp, c_int, c_i64, c_int, c_vp]),
     ("caelo_seqloader_wait", c_int, [c_vp, c_i64, c_vp, c_vp]),
     ("caelo_seqloader_release", c_int, [c_vp, c_i64]),
     ("caelo_seqloader_stats", c_int, [c_vp, c_vp]),

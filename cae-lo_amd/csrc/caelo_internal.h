@@ -39,7 +39,6 @@ void caelo_set_error(const char *fmt, ...);
     } while (0)
 
 // ---- context -----------------------------------------------------------------------------------
-#define CAELO_ENC_SPARSE_DEFAULT 0   // caelo_set_encoder_sparse's default (swept on MI355X: profiles/r06_stage1_sparse_sweep.txt)
 struct caelo_ctx {
     int device;
     // response layer (SphericalRingPCRespondLayer.h5)
@@ -65,7 +64,6 @@ struct caelo_ctx {
     float *enc32_bd1;  // [208]
     bool has_enc;
     bool enc_reference;   // caelo_set_encoder_reference: stage 1 = the exact-f32 k_enc_stage1 (precision reference)
-    int enc_sparse;       // caelo_set_encoder_sparse: patches with at most this many non-background cells go to k_enc_stage1s (0: none)
     int32_t *faults;  // device counter of the pair kernels' lane-agreement checks (match.hip); 0 on healthy hardware
 };
 

@@ -60,7 +60,6 @@ static void head_weight_fragments(const float *wd2, float *out);
 
 #define S1X_BGO_OFF (512 * 16 + 16)
 __global__ void k_enc_bgo_table(float *c0g);
-__global__ void k_enc_bg_image(float *c0g);
 
 CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const float *b1, const float *w2,
                                         const float *b2, const float *w3, const float *b3, const float *wd1,
@@ -91,11 +90,9 @@ CAELO_API int caelo_set_encoder_weights(caelo_ctx *c, const float *w1, const flo
         for (int ch = 0; ch < 8; ++ch) c0[512 * 16 + ch] = bg[ch];
         // + the pooled outputs of a tile pair that sees nothing but background, per pair and lane of k_enc_stage1x (S1X_BGO_OFF floats
         // in: [16 pairs][64 lanes] float2), computed on the DEVICE with the kernel's own tanh (k_enc_bgo_table)
-        if (!c->enc_c0) CAELO_HIP(hipMalloc(&c->enc_c0, (S1X_BGO_OFF + 16 * 64 * 2 + 1024) * sizeof(float)));
+        if (!c->enc_c0) CAELO_HIP(hipMalloc(&c->enc_c0, (S1X_BGO_OFF + 16 * 64 * 2) * sizeof(float)));
         CAELO_HIP(hipMemcpy(c->enc_c0, c0, sizeof(c0), hipMemcpyHostToDevice));
         k_enc_bgo_table<<<16, 64>>>(c->enc_c0);
-        CAELO_LAUNCH_CHECK();
-        k_enc_bg_image<<<1, 1024>>>(c->enc_c0);   // ... and P2 of the all-background patch (k_enc_stage1s writes inactive pairs from it)
         CAELO_LAUNCH_CHECK();
         CAELO_HIP(hipDeviceSynchronize());
     }
@@ -524,9 +521,7 @@ __global__ void __launch_bounds__(256, 3) k_enc_stage1(const caelo_enc_in in, in
 }
 
 #include "enc_stage1x.inc"
-#include "enc_stage1s.inc"
 
-#define S1S_OVF_INT 512      // k_enc_stage1s' eight overflow list lengths: ints 512 + 32 x behind the stage-1 queue counters (workspace bytes 3072 + 128 x)
 #define ENC_XCD_CSTRIDE 32   // ints between two per-XCD work counters (one 128-byte line each)
 // ------------------------------------------------------------------------------------------------
 // conv3 (16->32) implicit GEMM: M = 64 positions/patch, N = 32, K = 27*16 -- f32 products on the bf16 matrix pipe
@@ -641,7 +636,6 @@ __global__ void __launch_bounds__(256, C3X_WGS) k_enc_conv3(const float *__restr
     // memset launch sits on the encoder stream's critical path
     if (blockIdx.x == 0 && threadIdx.x == 0) *stage1_counter = 0;
     if (blockIdx.x == 0 && threadIdx.x < 8) xcd_counters[threadIdx.x * ENC_XCD_CSTRIDE] = 0;  // stage 1's per-XCD queues, for the next launch set
-    if (blockIdx.x == 0 && threadIdx.x < 8) xcd_counters[S1S_OVF_INT + threadIdx.x * ENC_XCD_CSTRIDE] = 0;  // ... and k_enc_stage1s' overflow list lengths
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -1334,52 +1328,14 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
         // = 20.0 / 20.4 / 20.2 / 19.6 / 19.2 / 17.8 k, profiles/r04_pipe_sweep.txt); alone, all three (207 against 248 us)
         const int64_t capx = slots_env > 0 ? slots_env : ((ein.yield & 1) ? (int64_t)slots1x * 2 / 3 : slots1x);
         const unsigned gx = (unsigned)(n_patches < capx ? n_patches : capx);
-        // Round 6: sparse patches (at most `enc_sparse` non-background cells after conv1 + pool1) are encoded a WAVEFRONT each by
-        // k_enc_stage1s, which leaves the others in eight per-XCD lists for k_enc_stage1x (enc_stage1s.inc).  Both kernels give a patch
-        // the same bits, so the threshold is a scheduling knob: caelo_set_encoder_sparse (0 = every patch to k_enc_stage1x).
-        const int sparse = c->enc_sparse;
-        const int2 *ovf = nullptr;
-        const int *ovf_n = nullptr;
-        const int ovf_cap = (int)((n_patches + 7) / 8);
-        if (sparse > 0) {
-            static bool attr_set[CAELO_MAX_DEVICES];
-            static std::mutex attr_mu;
-            {
-                std::lock_guard<std::mutex> lk(attr_mu);
-                if (!attr_set[c->device]) {
-                    CAELO_HIP(hipFuncSetAttribute((const void *)k_enc_stage1s<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S1S_LDS_BYTES));
-                    CAELO_HIP(hipFuncSetAttribute((const void *)k_enc_stage1s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S1S_LDS_BYTES));
-                    attr_set[c->device] = true;
-                }
-            }
-            // the lists live where conv3 will write F3 (dead until stage 1 is through): [8][ovf_cap] (bits offset, row)
-            int2 *ovf_w = (int2 *)f3;
-            int *ovf_nw = xcd_counters + S1S_OVF_INT;
-            static const int sslots_env = getenv("CAELO_S1S_SLOTS") ? atoi(getenv("CAELO_S1S_SLOTS")) : 0;
-            const int64_t caps = sslots_env > 0 ? sslots_env : ((ein.yield & 1) ? 384 : 512);   // two 8-wave workgroups per CU
-            const int64_t wgs = (n_patches + S1S_WAVES - 1) / S1S_WAVES;
-            const unsigned gs = (unsigned)(wgs < caps ? wgs : caps);
-            if (ev) {
-                CAELO_HIP(hipMemsetAsync(mfma_count, 0, sizeof(unsigned long long), s));
-                CAELO_HIP(hipEventRecord(ev[0], s));
-                k_enc_stage1s<true><<<gs, 64 * S1S_WAVES, S1S_LDS_BYTES, s>>>(ein, n_patches, order_group, sparse, (const uint4 *)c->enc_w1f, c->enc_b1,
-                                                                             (const uint4 *)c->enc_w2x, c->enc_c0, p2, ovf_w, ovf_nw, ovf_cap, mfma_count);
-            } else
-                k_enc_stage1s<false><<<gs, 64 * S1S_WAVES, S1S_LDS_BYTES, s>>>(ein, n_patches, order_group, sparse, (const uint4 *)c->enc_w1f, c->enc_b1,
-                                                                              (const uint4 *)c->enc_w2x, c->enc_c0, p2, ovf_w, ovf_nw, ovf_cap, mfma_count);
-            CAELO_LAUNCH_CHECK();
-            ovf = ovf_w;
-            ovf_n = ovf_nw;
-        } else if (ev) {   // profiling calls count the MFMAs the kernel executes (bench.py's roofline); same code otherwise
+        if (ev) {   // profiling calls count the MFMAs the kernel executes (bench.py's roofline); same code otherwise
             CAELO_HIP(hipMemsetAsync(mfma_count, 0, sizeof(unsigned long long), s));
             CAELO_HIP(hipEventRecord(ev[0], s));
-        }
-        if (ev)
             k_enc_stage1x<true><<<gx, 256, 0, s>>>(ein, n_patches, order_group, work_counter, (const uint4 *)c->enc_w1f, c->enc_b1,
-                                                   (const uint4 *)c->enc_w2x, c->enc_c0, p2, mfma_count, ovf, ovf_n, ovf_cap);
-        else
+                                                   (const uint4 *)c->enc_w2x, c->enc_c0, p2, mfma_count);
+        } else
             k_enc_stage1x<false><<<gx, 256, 0, s>>>(ein, n_patches, order_group, work_counter, (const uint4 *)c->enc_w1f, c->enc_b1,
-                                                    (const uint4 *)c->enc_w2x, c->enc_c0, p2, mfma_count, ovf, ovf_n, ovf_cap);
+                                                    (const uint4 *)c->enc_w2x, c->enc_c0, p2, mfma_count);
         CAELO_LAUNCH_CHECK();
     } else {
         if (ev) CAELO_HIP(hipMemsetAsync(mfma_count, 0, sizeof(unsigned long long), s));   // (the f32 kernel has no register left to count)
@@ -1455,15 +1411,6 @@ CAELO_API int caelo_encode_profile(caelo_ctx *c, const uint64_t *bits, int64_t n
 // The exact-f32 stage 1 of round 2 (k_enc_stage1: f32-input MFMAs for conv2, conv1 on the VALU) as this context's stage 1: the
 // precision reference the f16 x 2 kernel is measured against (tests, tools/enc_layer_errors.py).  Slower (346 vs 224 us per
 // 24 576 patches); everything behind stage 1 is unchanged.
-// Patches with at most `max_cells` non-background cells after conv1 + pool1 are encoded one wavefront each (k_enc_stage1s), the
-// others a workgroup each (k_enc_stage1x).  0: every patch to k_enc_stage1x.  The two kernels give a patch the same bits: a scheduling
-// knob (default S1S_DEFAULT), not an arithmetic one.
-CAELO_API int caelo_set_encoder_sparse(caelo_ctx *c, int max_cells) {
-    CAELO_REQUIRE(c && max_cells >= 0 && max_cells <= S1S_CAP, "caelo_set_encoder_sparse: 0 .. 64 cells");
-    c->enc_sparse = max_cells;
-    return CAELO_OK;
-}
-
 CAELO_API int caelo_set_encoder_reference(caelo_ctx *c, int on) {
     CAELO_REQUIRE(c, "null argument");
     c->enc_reference = on != 0;

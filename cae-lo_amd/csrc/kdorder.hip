@@ -175,8 +175,11 @@ __device__ __forceinline__ void kd_build_levels(const caelo_kd_scale &T, const i
                 // Lomuto with the last element as the pivot is quadratic on a list sorted along the split dimension (the library pays
                 // that too).  Lists in first-touch order are PARTLY sorted (a scan line sweeps the azimuth): measured on the clutter
                 // scene's lists the worst node needs 87 passes' worth of its length (a first budget of 48 gave up on real frames -- the
-                // 600-frame soak caught it by the descriptors of the patches it left on the canonical rule).  256 passes' worth.
-                S.budget[local] = 256ll * m + 65536;
+                // 600-frame soak caught it by the descriptors of the patches it left on the canonical rule; round 6's soak over 600
+                // STRUCTURED clutter frames caught 256 the same way: frame 103's 16 cm list, 25 326 voxels, one patch).  A give-up is a
+                // WRONG patch (flag 2 stays set, the caller can see it), a long build is only slow: 4096 passes' worth -- tens of
+                // milliseconds for the longest node of a scan's list in the worst case, which the library would pay as well.
+                S.budget[local] = 4096ll * m + 65536;
             }
             for (;;) {
                 __syncthreads();   // (the reduction below is a barrier, not a fence: the q_* words written at the end of the previous pass must have landed)

@@ -39,7 +39,6 @@ CAELO_API int caelo_create(caelo_ctx **out, int device) {
     caelo_ctx *c = new caelo_ctx();
     memset(c, 0, sizeof(*c));
     c->device = device;
-    c->enc_sparse = CAELO_ENC_SPARSE_DEFAULT;
     CAELO_HIP(hipMalloc((void **)&c->faults, sizeof(int32_t)));
     CAELO_HIP(hipMemset(c->faults, 0, sizeof(int32_t)));
     *out = c;

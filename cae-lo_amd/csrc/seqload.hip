@@ -11,8 +11,10 @@
 // round 5's run_sequence.py did both in Python threads (readinto + RandomState.seed / random_sample per frame under the GIL):
 // 0.75-0.94 s of loader time and as much again of per-frame Python on the issuing thread for 4 541 frames, 3.8-4.6 k frames/s from
 // page-cache files against 15 k for the pipeline with uploads.  caelo_seqloader: `threads` native threads pread() batch after batch
-// into a caller-provided (pinned) ring [ring_batches][batch][cap_points][4] f32 and fill [ring_batches][batch][6000] f64 draws; the
-// issuing thread waits for a batch, uploads it behind one copy command and releases the slot when the copy is through.
+// into a caller-provided (pinned) ring of slots -- a slot = [batch][cap_points][4] f32 scans, then [batch][6000] f64 draws, so that ONE
+// copy command moves a batch's scans and draws to a device slot of the same layout -- and keep a second copy of the draws in a longer
+// host ring for the host half of the exact RANSAC (which reads a pair's draws, if it escalates, batches after the slot was reused); the
+// issuing thread waits for a batch, uploads it and releases the slot when the copy is through.
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -90,8 +92,10 @@ struct caelo_seqloader {
     int64_t n = 0;           // frames
     int batch = 8, ring = 4;
     int64_t cap = 0;         // points per ring slot
-    float *scans = nullptr;  // [ring][batch][cap][4]
-    double *draws = nullptr; // [ring][batch][CAELO_SEQ_DRAWS]
+    char *slots = nullptr;   // [ring] slots of slot_bytes: [batch][cap][4] f32 | [batch][CAELO_SEQ_DRAWS] f64
+    double *keep = nullptr;  // nullable: [keep_ring][batch][CAELO_SEQ_DRAWS], batch b's draws at b % keep_ring
+    int keep_ring = 0;
+    int64_t slot_bytes = 0;
     int64_t seed_base = 0, first_frame = 0;
     int64_t n_batches = 0;
     // per batch: points of its frames (-1 = not loaded yet; -2 = failed), written by the workers
@@ -130,7 +134,8 @@ void seq_worker(caelo_seqloader *L) {
             if (L->stop) break;
         }
         const int slot = (int)(b % L->ring), j = (int)(i - b * L->batch);
-        float *dst = L->scans + ((size_t)slot * L->batch + j) * (size_t)L->cap * 4;
+        char *const sbase = L->slots + (size_t)slot * (size_t)L->slot_bytes;
+        float *dst = (float *)sbase + (size_t)j * (size_t)L->cap * 4;
         int64_t np = -2;
         const int64_t t0 = now_ns_();
         const int fd = open(L->paths[i].c_str(), O_RDONLY);
@@ -149,7 +154,10 @@ void seq_worker(caelo_seqloader *L) {
         }
         const int64_t t1 = now_ns_();
         // the draws of pair (frame - 1, frame): RandomState(seed_base + frame - 1).random_sample(CAELO_SEQ_DRAWS)
-        random_sample((uint32_t)(L->seed_base + L->first_frame + i - 1 > 0 ? L->seed_base + L->first_frame + i - 1 : 0), CAELO_SEQ_DRAWS, L->draws + ((size_t)slot * L->batch + j) * CAELO_SEQ_DRAWS);
+        const int64_t seed = L->seed_base + L->first_frame + i - 1;
+        double *dr = (double *)(sbase + (size_t)L->batch * (size_t)L->cap * 16) + (size_t)j * CAELO_SEQ_DRAWS;
+        random_sample((uint32_t)(seed > 0 ? seed : 0), CAELO_SEQ_DRAWS, dr);
+        if (L->keep) memcpy(L->keep + ((size_t)(b % L->keep_ring) * L->batch + j) * CAELO_SEQ_DRAWS, dr, sizeof(double) * CAELO_SEQ_DRAWS);
         t_read += t1 - t0;
         t_draw += now_ns_() - t1;
         bool done;
@@ -172,14 +180,19 @@ void seq_worker(caelo_seqloader *L) {
 
 }  // namespace
 
+CAELO_API int64_t caelo_seqloader_slot_bytes(int batch, int64_t cap_points) {
+    return (int64_t)batch * cap_points * 16 + (int64_t)batch * CAELO_SEQ_DRAWS * 8;
+}
+
 CAELO_API int caelo_seqloader_create(const char *const *paths, int64_t n, int64_t first_frame, int batch, int ring_batches, int64_t cap_points,
-                                     float *ring_host, double *draws_host, int64_t seed_base, int threads, caelo_seqloader **out) {
-    CAELO_REQUIRE(paths && out && ring_host && draws_host && n > 0 && batch >= 1 && batch <= CAELO_FB_MAX && ring_batches >= 2 && cap_points > 0 &&
-                  threads >= 1 && threads <= 256, "caelo_seqloader_create: bad argument");
+                                     void *ring_host, double *draws_keep_host, int keep_batches, int64_t seed_base, int threads, caelo_seqloader **out) {
+    CAELO_REQUIRE(paths && out && ring_host && n > 0 && batch >= 1 && batch <= CAELO_FB_MAX && ring_batches >= 2 && cap_points > 0 &&
+                  threads >= 1 && threads <= 256 && (!draws_keep_host || keep_batches >= ring_batches), "caelo_seqloader_create: bad argument");
     caelo_seqloader *L = new caelo_seqloader();
     L->paths.assign(paths, paths + n);
     L->n = n; L->batch = batch; L->ring = ring_batches; L->cap = cap_points;
-    L->scans = ring_host; L->draws = draws_host; L->seed_base = seed_base; L->first_frame = first_frame;
+    L->slots = (char *)ring_host; L->keep = draws_keep_host; L->keep_ring = keep_batches; L->slot_bytes = caelo_seqloader_slot_bytes(batch, cap_points);
+    L->seed_base = seed_base; L->first_frame = first_frame;
     L->n_batches = (n + batch - 1) / batch;
     L->n_points.assign((size_t)n, -1);
     L->left = new std::vector<std::atomic<int>>((size_t)L->n_batches);

@@ -228,6 +228,117 @@ def run_local(eng, load, lo, hi, seed_base, chunk, dist_channels, batch_frames, 
     return cat(rel, (12,)), cat(ok, ()), cat(thr, ()), cat(nin, ()), first, prev
 
 
+def _parse_poses_fast(raw, k):
+    """_parse_poses without per-frame Python: the pinned read-back viewed as the record type of caelo_pose_result."""
+    r = np.frombuffer(raw[:k].tobytes(), dtype=_ffi.POSE_DTYPE, count=k)
+    out = np.concatenate([r["R"].reshape(k, 9), r["T"].reshape(k, 3)], axis=1).astype(np.float32)
+    return out, r["success"] != 0, r["threshold"].astype(np.float32), r["n_inliers"].astype(np.int32)
+
+
+def run_local_files(eng, files, lo, hi, seed_base, chunk, dist_channels, batch_frames, keep=None, strict_ties=True, tie_log=None, host_times=None,
+                    loader_threads=16, certify=True):
+    """run_local for scans that are FILES (round 6): the native loader (caelo_seqloader: pread into a pinned ring + the RANSAC draws,
+    csrc/seqload.hip) works ahead on its own threads, a chunk of batches goes through Pipeline.run_loaded (one copy command per batch
+    for scans and draws, jobs built column-wise), results come back through pinned buffers and are parsed as one record array.
+    Same returns as run_local; same bits (the draws are NumPy's stream, the pipeline is the same)."""
+    from caelo.engine import SeqLoader
+    t_setup = time.time()
+    ht = host_times if host_times is not None else {}
+    for k_ in ("load", "pin", "draws", "starved", "pipeline", "ties", "parse", "setup"):
+        ht.setdefault(k_, 0.0)
+    B = batch_frames
+    loader = SeqLoader(eng, files[lo:hi], first_frame=lo, batch=B, seed_base=seed_base, threads=loader_threads)
+    pipe = eng.pipeline(B)
+    import gc
+    gc.collect()
+    gc.freeze()
+    side = torch.cuda.Stream(device=eng.device)
+    per_chunk = max(1, chunk // B)
+    outs = [FrameBatch(eng, per_chunk * B) for _ in range(2)]
+    back = [(torch.empty((per_chunk * B,) + tuple(outs[0].result.shape[1:]), dtype=outs[0].result.dtype, pin_memory=True),
+             torch.empty((per_chunk * B,) + tuple(outs[0].status.shape[1:]), dtype=outs[0].status.dtype, pin_memory=True)) for _ in range(3)]
+    ht["setup"] = time.time() - t_setup
+    rel, ok, thr, nin = [], [], [], []
+    prev, first, pending = None, None, None
+
+    def collect(p):
+        k, has_prev, res_h, st_h, ev = p
+        ev.synchronize()
+        t_ = time.time()
+        st = st_h.numpy()[:k, 0]
+        if st.any():
+            for v in st[st != 0]:
+                raise_status(int(v))
+        r, o, t, n = _parse_poses_fast(res_h.numpy(), k)
+        s_ = 0 if has_prev else 1
+        rel.append(r[s_:]); ok.append(o[s_:]); thr.append(t[s_:]); nin.append(n[s_:])
+        ht["parse"] += time.time() - t_
+
+    t_loop = time.time()
+    for ci, b0 in enumerate(range(0, loader.n_batches, per_chunk)):
+        nb = min(per_chunk, loader.n_batches - b0)
+        t_ = time.time()
+        batch, k = pipe.run_loaded(loader, b0, nb, prev=prev, out=outs[ci % 2], dist_channels=dist_channels, certify=certify)
+        ht["pipeline"] += time.time() - t_
+        ht["starved"] += pipe.last_loaded_times["starved_s"]
+        c0 = lo + b0 * B
+        t_ = time.time()
+        if strict_ties and bool((batch.flags[:k] & 2).any().item()):
+            # (as run_local: the tied frames' scans are read again -- rare -- and redone in scikit-learn's kd-tree order, their pairs matched again)
+            fl = (batch.flags[:k] & 2).reshape(k, -1).any(dim=1).cpu().numpy()
+            items = [(batch.frame(j), torch.from_numpy(stageio.read_scan(files[c0 + j])).to(eng.device) if fl[j] else None) for j in range(k)]
+            tied, n_t = eng.resolve_ties_many(items, batch=batch)
+            if tie_log is not None:
+                tie_log.extend((c0 + j, n_) for j, n_ in zip(tied, n_t))
+            redo = sorted({t for u in tied for t in (u, u + 1) if t < k and (t > 0 or prev is not None)})
+            pairs_ = [(prev if j == 0 else batch.frame(j - 1), batch.frame(j)) for j in redo]
+            if redo:
+                dn_ = [np.frombuffer(_draws_of(seed_base + c0 + j - 1)) for j in redo]
+                dd_ = [torch.from_numpy(d_).to(eng.device) for d_ in dn_]
+                if certify:
+                    rs_, ms_, xs_ = eng.match_pose_exact_many(pairs_, dd_, dn_)
+                    sel = torch.tensor(redo, device=eng.device)
+                    batch.result[sel] = torch.from_numpy(rs_.view(np.uint8).reshape(len(redo), -1).copy()).to(eng.device)
+                    batch.inlier_mask[sel] = torch.from_numpy(ms_).to(eng.device)
+                    for j, x_ in zip(redo, xs_):
+                        batch.pair_idx[j].copy_(x_)
+                else:
+                    for j, (fa_, fb_), d_ in zip(redo, pairs_, dd_):
+                        r_, m_, x_ = eng.match_pose(fa_, fb_, d_)
+                        batch.result[j].copy_(r_); batch.inlier_mask[j].copy_(m_); batch.pair_idx[j].copy_(x_)
+        ht["ties"] += time.time() - t_
+        done = torch.cuda.Event()
+        done.record()
+        res_h, st_h = back[ci % 3]
+        with torch.cuda.stream(side):
+            side.wait_event(done)
+            res_h[:k].copy_(batch.result[:k], non_blocking=True)
+            st_h[:k].copy_(batch.status[:k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        if pending is not None:
+            collect(pending)
+        pending = (k, prev is not None, res_h, st_h, ev)
+        if first is None:
+            first = FrameFeatures.from_rows(batch.rows[0].clone())      # (the chunk buffers are reused two chunks later)
+        last_rows = batch.rows[k - 1].clone()
+        prev = FrameFeatures.from_rows(last_rows)
+        if keep is not None:
+            keep(c0, batch.view(0, k))
+    ht["loop"] = time.time() - t_loop
+    if pending is not None:
+        collect(pending)
+    ls = loader.stats()
+    ht["load"], ht["draws"] = ls["read_s"], ls["draws_s"]      # (summed over the loader's threads)
+    loader.close()
+    cat = (lambda xs, d: np.concatenate(xs) if xs else np.zeros((0,) + d))
+    return cat(rel, (12,)), cat(ok, ()), cat(thr, ()), cat(nin, ()), first, prev
+
+
+def _draws_of(seed):
+    return ransac_draws(seed)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--synthetic", type=int, default=0, help="number of synthetic 64x2000 scans (caelo.synth)")
@@ -236,7 +347,7 @@ def main():
     ap.add_argument("--calib", help="calib_.txt (PoseEstimation.py:199-203) or KITTI calib.txt; identity if omitted")
     ap.add_argument("--out", default="poses_/00.txt")
     ap.add_argument("--seed-base", type=int, default=1000)
-    ap.add_argument("--chunk", type=int, default=120, help="frames resident on the GPU at a time")
+    ap.add_argument("--chunk", type=int, default=240, help="frames resident on the GPU at a time")
     ap.add_argument("--dist-channels", type=int, default=5, choices=(3, 5), help="5 = demo mode, 3 = batch mode (SURVEY 8a-3')")
     ap.add_argument("--batch", type=int, default=8, help="frames per launch (caelo_pipeline)")
     ap.add_argument("--scene", default="boxes", choices=("boxes", "clutter"), help="synthetic scene (caelo.synth)")
@@ -246,6 +357,7 @@ def main():
     ap.add_argument("--pool", type=int, default=0, help="synthesise only this many distinct scans and walk them back and forth (0 1 .. P-1 "
                                                         "P-2 .. 0 1 ..: every pair stays a pair of neighbours); ray casting a scan costs ~0.5 s of CPU")
     ap.add_argument("--loader-threads", type=int, default=min(16, os.cpu_count() or 1), help="threads that read / synthesise scans and draw RANSAC's random numbers")
+    ap.add_argument("--python-loader", action="store_true", help="--scans through round 5's Python loader threads instead of the native loader (caelo_seqloader)")
     ap.add_argument("--save-artifacts", action="store_true", help="write Features/*.mat and InliersIdx/*.mat next to the scans")
     ap.add_argument("--no-strict-ties", action="store_true", help="keep the fused path's canonical rule where the 496-nearest cut splits a "
                                                                   "tie class (default: such frames are redone in scikit-learn's kd-tree order)")
@@ -332,9 +444,14 @@ def main():
 
     tie_log = []
     host_times = {}
-    rel, ok, thr, nin, first, last = run_local(eng, load, lo, hi, args.seed_base, args.chunk, args.dist_channels,
-                                               args.batch, keep, strict_ties=not args.no_strict_ties, tie_log=tie_log, host_times=host_times,
-                                               loader_threads=args.loader_threads, certify=not args.no_certify)
+    if args.scans and not args.python_loader:
+        rel, ok, thr, nin, first, last = run_local_files(eng, files, lo, hi, args.seed_base, args.chunk, args.dist_channels,
+                                                         args.batch, keep, strict_ties=not args.no_strict_ties, tie_log=tie_log, host_times=host_times,
+                                                         loader_threads=args.loader_threads, certify=not args.no_certify)
+    else:
+        rel, ok, thr, nin, first, last = run_local(eng, load, lo, hi, args.seed_base, args.chunk, args.dist_channels,
+                                                   args.batch, keep, strict_ties=not args.no_strict_ties, tie_log=tie_log, host_times=host_times,
+                                                   loader_threads=args.loader_threads, certify=not args.no_certify)
     if tie_log:
         print("rank %d: %d frame(s) redone in scikit-learn's tie order (%d patches): %s" % (
             rank, len(tie_log), sum(n for _, n in tie_log), [f for f, _ in tie_log][:20]), file=sys.stderr)

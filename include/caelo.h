@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CAELO_ABI_VERSION 5   /* 5: caelo_host_unbind_blas / _blas_probe / _bound_violations, caelo_set_encoder_sparse, caelo_host_random_sample, caelo_seqloader_*; 4: caelo_voxmap_export never waits for the device (a count above capacity is the overflow report), caelo_voxmap_order; 3: certificates, caelo_host_* */
+#define CAELO_ABI_VERSION 5   /* 5: caelo_host_unbind_blas / _blas_probe / _bound_violations, caelo_host_random_sample, caelo_seqloader_*; 4: caelo_voxmap_export never waits for the device (a count above capacity is the overflow report), caelo_voxmap_order; 3: certificates, caelo_host_* */
 
 /* geometry fixed by the reference: SphericalRing.py:28-58, Voxel.py:15-52 */
 #define CAELO_RING_H 69
@@ -92,11 +92,6 @@ int caelo_set_encoder_weights(caelo_ctx *ctx, const float *w1_host /*[27][1][8]*
  * An explicit, per-context choice: the library reads NO environment variable that changes arithmetic (no reference counterpart:
  * PatchEncoder.predict, Match.py:131-133, has one arithmetic). */
 int caelo_set_encoder_reference(caelo_ctx *ctx, int on);
-/* Stage 1 of the encoder (conv1 + pool1 + conv2 + pool2) has two kernels that give a patch the same bits: a WAVEFRONT per patch for
- * patches with at most `max_cells` (0 .. 64) non-background cells after conv1 + pool1 -- every 2 cm patch and the thin ones of the
- * coarser scales -- and a WORKGROUP per patch for the rest.  0 sends every patch to the workgroup kernel.  A scheduling knob (the
- * default was swept on MI355X), not an arithmetic one; no reference counterpart (Match.py:131-133). */
-int caelo_set_encoder_sparse(caelo_ctx *ctx, int max_cells);
 
 /* ProjectPC2SphericalRing  (SphericalRing.py:72-94)
  * pc [n][4] f32 -> ring [69][1800][5] f32, counter [69][1800] i32.  workspace: winner [69*1800] i32. */
@@ -453,15 +448,18 @@ int caelo_upload_many(void *const *dst, const void *const *src, const size_t *by
  * caelo_host_random_sample: numpy.random.RandomState(seed).random_sample(n) bit for bit (MT19937, init_genrand seeding, 53-bit doubles):
  * the stream RANSAC4RT draws its samples from (Match.py:182-184), CAELO_SEQ_DRAWS doubles per pair (3 levels x 500 trials x 4).
  * caelo_seqloader: `threads` native threads read the n KITTI .bin files of `paths` ([points][4] f32) batch after batch into the caller's
- * (pinned) ring  ring_host [ring_batches][batch][cap_points][4] f32  and fill  draws_host [ring_batches][batch][CAELO_SEQ_DRAWS] f64  with
- * the draws of pair (frame - 1, frame) = RandomState(seed_base + first_frame + i - 1) for file i.  _wait blocks until batch b (files
- * b * batch ..) sits in slot b % ring_batches and reports the point counts; _release hands the slot back (in order).  A file that
- * is missing, not a multiple of 16 bytes or larger than a slot fails the wait with an error naming it.  Host code only. */
+ * (pinned) ring of `ring_batches` slots.  A slot (caelo_seqloader_slot_bytes) = [batch][cap_points][4] f32 scans, then
+ * [batch][CAELO_SEQ_DRAWS] f64 draws -- file i's are those of pair (frame - 1, frame) = RandomState(seed_base + first_frame + i - 1) -- so
+ * that one copy command moves a batch to a device slot of the same layout; draws_keep_host (nullable) [keep_batches][batch][CAELO_SEQ_DRAWS]
+ * keeps batch b's draws at b % keep_batches for the host half (caelo_frame_job::rand_host).  _wait blocks until batch b (files b * batch ..)
+ * sits in slot b % ring_batches and reports the point counts; _release hands the slot back (in order).  A file that is missing, not a
+ * multiple of 16 bytes or larger than a slot fails the wait with an error naming it.  Host code only. */
 #define CAELO_SEQ_DRAWS (CAELO_RANSAC_LEVELS * CAELO_RANSAC_MAX_TRIALS * 4)
 typedef struct caelo_seqloader caelo_seqloader;
 int caelo_host_random_sample(uint32_t seed, int64_t n, double *out_host);
+int64_t caelo_seqloader_slot_bytes(int batch, int64_t cap_points);
 int caelo_seqloader_create(const char *const *paths, int64_t n, int64_t first_frame, int batch, int ring_batches, int64_t cap_points,
-                           float *ring_host, double *draws_host, int64_t seed_base, int threads, caelo_seqloader **out);
+                           void *ring_host, double *draws_keep_host, int keep_batches, int64_t seed_base, int threads, caelo_seqloader **out);
 int caelo_seqloader_wait(caelo_seqloader *loader, int64_t b, int32_t *slot_host, int64_t *n_points_host);
 int caelo_seqloader_release(caelo_seqloader *loader, int64_t b);
 int caelo_seqloader_stats(caelo_seqloader *loader, int64_t *out_host);   /* [3]: ns reading, drawing, waiting for a slot (summed over threads) */

@@ -181,10 +181,12 @@ def test_seqloader_reads_files_and_draws(tmp_path):
 
     def run(paths_, first=40, seed_base=1000):
         arr = (C.c_char_p * len(paths_))(*paths_)
-        ring_h = np.full((ring, batch, cap, 4), np.nan, np.float32)
-        draws_h = np.zeros((ring, batch, 6000), np.float64)
+        sb = int(lib.caelo_seqloader_slot_bytes(batch, cap))
+        assert sb == batch * cap * 16 + batch * 6000 * 8
+        ring_h = np.full((ring, sb), 0xFF, np.uint8)
+        keep_h = np.zeros((5, batch, 6000), np.float64)      # a longer ring for the host half's copy of the draws
         h = C.c_void_p()
-        _ffi.check(lib.caelo_seqloader_create(arr, len(paths_), first, batch, ring, cap, C.c_void_p(ring_h.ctypes.data), C.c_void_p(draws_h.ctypes.data),
+        _ffi.check(lib.caelo_seqloader_create(arr, len(paths_), first, batch, ring, cap, C.c_void_p(ring_h.ctypes.data), C.c_void_p(keep_h.ctypes.data), 5,
                                               seed_base, 5, C.byref(h)))
         try:
             slot = C.c_int32(-1)
@@ -193,15 +195,18 @@ def test_seqloader_reads_files_and_draws(tmp_path):
             for b in range(nb):
                 _ffi.check(lib.caelo_seqloader_wait(h, b, C.byref(slot), npts))
                 assert slot.value == b % ring
+                sc = ring_h[slot.value, :batch * cap * 16].view(np.float32).reshape(batch, cap, 4)
+                dr = ring_h[slot.value, batch * cap * 16:].view(np.float64).reshape(batch, 6000)
                 for j in range(batch):
                     i = b * batch + j
                     if i >= len(paths_):
                         assert npts[j] == 0
                         continue
                     assert npts[j] == len(scans[i])
-                    assert np.array_equal(ring_h[slot.value, j, :npts[j]], scans[i])
-                    assert np.array_equal(draws_h[slot.value, j], np.random.RandomState(seed_base + first + i - 1).random_sample(6000))
-                ring_h[slot.value] = np.nan       # (a slot handed back may be overwritten at once)
+                    assert np.array_equal(sc[j, :npts[j]], scans[i])
+                    want = np.random.RandomState(seed_base + first + i - 1).random_sample(6000)
+                    assert np.array_equal(dr[j], want) and np.array_equal(keep_h[b % 5, j], want)
+                ring_h[slot.value] = 0xFF       # (a slot handed back may be overwritten at once)
                 _ffi.check(lib.caelo_seqloader_release(h, b))
             st = (C.c_int64 * 3)()
             _ffi.check(lib.caelo_seqloader_stats(h, st))

@@ -1326,8 +1326,8 @@ def test_run_sequence_saves_consistent_artifacts_on_quantised_scans(tmp_path):
 @pytest.mark.gpu
 def test_run_sequence_from_files_equals_the_synthetic_run(tmp_path):
     """run_sequence.py --scans DIR (KITTI velodyne layout, BatchPreprocess.py:46-47): every .bin file is read straight into a reused
-    page-locked slot, in chunks smaller than the sequence so that slots ARE reused; the pose file equals the one of the run that
-    takes the same scans from memory, and a scan that does not fit a slot takes the per-scan path."""
+    page-locked slot (native loader; --python-loader: round 5's threads), in chunks smaller than the sequence so that slots ARE reused; the
+    pose file equals the one of the run that takes the same scans from memory."""
     import subprocess
     import sys
     from conftest import REPO
@@ -1341,7 +1341,7 @@ def test_run_sequence_from_files_equals_the_synthetic_run(tmp_path):
     subprocess.run([sys.executable, script, "--scans", str(d), "--chunk", "2", "--out", a], check=True, capture_output=True, timeout=300)
     subprocess.run([sys.executable, script, "--synthetic", "11", "--out", b], check=True, capture_output=True, timeout=300)
     env = dict(os.environ, CAELO_RUN_NO_PINNED_RING="1")
-    subprocess.run([sys.executable, script, "--scans", str(d), "--chunk", "3", "--out", c], check=True, capture_output=True, timeout=300, env=env)
+    subprocess.run([sys.executable, script, "--scans", str(d), "--chunk", "3", "--python-loader", "--out", c], check=True, capture_output=True, timeout=300, env=env)
     assert open(a).read() == open(b).read() == open(c).read() and len(open(a).read().splitlines()) == 11
     # whole batches out of one pinned block: one copy command per batch (Pipeline.run_uploading finds the pitch), files and synthetic ring
     e, f = str(tmp_path / "e.txt"), str(tmp_path / "f.txt")
@@ -1349,6 +1349,11 @@ def test_run_sequence_from_files_equals_the_synthetic_run(tmp_path):
     subprocess.run([sys.executable, script, "--synthetic", "11", "--chunk", "16", "--out", f], check=True, capture_output=True, timeout=300,
                    env=dict(os.environ, CAELO_RUN_SYNTH_RING="1"))
     assert open(e).read() == open(f).read() == open(a).read()
+    # round 6: --scans goes through the NATIVE loader by default (caelo_seqloader: pread + NumPy's MT19937 stream on native threads,
+    # Pipeline.run_loaded); round 5's Python loader threads must give the same file, whole batches out of one pinned block included
+    g = str(tmp_path / "g.txt")
+    subprocess.run([sys.executable, script, "--scans", str(d), "--chunk", "16", "--python-loader", "--out", g], check=True, capture_output=True, timeout=300)
+    assert open(g).read() == open(a).read()
 
 
 # ---- round 2: the variants that claim bit-identical results, and the pipeline's batch plan -------------------------------------
@@ -1487,52 +1492,6 @@ def test_stage1x_agrees_with_the_f32_kernel(engine):
     assert ref[0].shape == lay[0].shape and 0 < np.abs(ref[0] - lay[0]).max() <= 1e-6, np.abs(ref[0] - lay[0]).max()
     assert np.abs(ref[3] - lay[3]).max() <= 2e-6
     assert all(np.array_equal(a, b) for a, b in zip(lay, again))
-
-
-@pytest.mark.gpu
-def test_sparse_stage1_is_bitwise_invisible(engine, scans):
-    """Round 6: k_enc_stage1s (a wavefront per sparse patch) and k_enc_stage1x (a workgroup per patch) must give every patch the same
-    bits -- the threshold between them (caelo_set_encoder_sparse) is a scheduling knob.  Checked on the golden frame's 3072 patches
-    (plain launch: every layer's output), on crafted patches (empty, one voxel in every corner / on every face, a full patch, random
-    densities around every threshold), and through the de-duplicated launches of the pipeline (rows and poses of a 10-frame run)."""
-    import torch
-    from caelo.engine import Pipeline, ransac_draws
-    bits = np.ascontiguousarray(np.load(os.path.join(GOLDEN, "frame_q0.npz"))["patch_bits"].reshape(-1, 64))
-    rs = np.random.RandomState(7)
-    crafted = []
-    crafted.append(np.zeros((16, 16, 16), bool))
-    for c in [(0, 0, 0), (15, 15, 15), (0, 15, 7), (8, 0, 15), (7, 7, 7), (15, 0, 0), (1, 1, 1), (14, 2, 9)]:
-        d = np.zeros((16, 16, 16), bool); d[c] = True; crafted.append(d)
-    crafted.append(np.ones((16, 16, 16), bool))
-    for share in (0.0005, 0.001, 0.002, 0.004, 0.008, 0.015, 0.03, 0.06, 0.12, 0.3):
-        for _ in range(12):
-            crafted.append(rs.random_sample((16, 16, 16)) < share)
-    for _ in range(24):   # clustered voxels: a few cells only, many voxels each
-        d = np.zeros((16, 16, 16), bool)
-        o = rs.randint(0, 12, 3)
-        d[o[0]:o[0] + 4, o[1]:o[1] + 4, o[2]:o[2] + 4] = rs.random_sample((4, 4, 4)) < 0.5
-        crafted.append(d)
-    cb = np.packbits(np.stack(crafted).reshape(len(crafted), -1), axis=-1, bitorder="little").view(np.uint64).reshape(-1, 64)
-    pad = (-len(cb)) % 3
-    allbits = np.concatenate([bits, cb, np.zeros((pad, 64), np.uint64)])
-    t = torch.from_numpy(allbits.view(np.int64)).to(engine.device)
-    pcs = [torch.from_numpy(scans(i, quantum=1e-3)).to(engine.device) for i in range(10)]
-    rnd = [torch.from_numpy(ransac_draws(40 + i)).to(engine.device) for i in range(10)]
-    pipe = Pipeline(engine, 8, 3)
-    outs = {}
-    try:
-        for thr in (0, 1, 5, 16, 32, 64):
-            engine.set_encoder_sparse(thr)
-            lay = [x.cpu().numpy() for x in engine.encode_layers(t)]
-            a = pipe.run(pcs, rnd)
-            torch.cuda.synchronize()
-            outs[thr] = lay + [a.rows.cpu().numpy(), a.result.cpu().numpy(), a.pair_idx.cpu().numpy()]
-    finally:
-        engine.set_encoder_sparse(32)
-    for thr in (1, 5, 16, 32, 64):
-        for i, (x, y) in enumerate(zip(outs[0], outs[thr])):
-            assert np.array_equal(x, y), (thr, i, np.abs(x.astype(np.float64) - y.astype(np.float64)).max())
-    assert engine.lane_faults() == 0
 
 
 @pytest.mark.gpu
