@@ -879,6 +879,32 @@ def secondary_legs(args, eng, pipe, dev, pool, rand, rand_host, Runner, frame_pa
                              "dedup_share_within_frames": round(1.0 - float(np.mean([len(torch.unique(b.reshape(-1, 64), dim=0)) for b in bits2])) / 3072.0, 4),
                              "executed_mfma_share": round(share2, 4), "stage1_launch_ms": round(float(ms2[0]), 4),
                              "stage1_pipe_frac": t2[names[0]]["pipe_frac"], "encoder_total_ms_all_patches": round(float(ms2.sum()), 4)}
+    # ---- failing_pairs: hostile data.  One scan of the pool is replaced by a scan of ANOTHER world: the two pairs it
+    # is part of find no consensus at 0.4 m, escalate to 0.8 and 1.6 m and fail as a value (Match.py:207-214) -- 2 of every 16 pairs of the
+    # walk.  Round 5's host half evaluated the ~1000 hypotheses of the higher levels of such a pair like the reference's loop (5 ms of a
+    # certifier thread); round 6's kernels leave bounds for those levels too (k_ransac_hyp_up)
+    try:
+        pool3 = list(pool)
+        pool3[POOL // 2] = pool2[0]
+        r3 = Runner(pool3)
+        r3.run(2 * B)
+        torch.cuda.synchronize()
+        pipe.cert_stats()
+        t0 = time.perf_counter()
+        ob3 = r3.run(n)
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t0
+        cs3 = pipe.cert_stats() if CERTIFY else None
+        thr3 = ob3.exact[0]["threshold"][:n] if ob3.exact is not None else None
+        sec["failing_pairs"] = {"frames_per_s": round(n / dt3, 1),
+                                "pairs_failed": None if ob3.exact is None else int((ob3.exact[0]["success"][:n] == 0).sum()),
+                                "pairs_beyond_0.4m": None if thr3 is None else int((thr3 > 0.5).sum()),
+                                "host_hypotheses_per_pair": None if cs3 is None else round(cs3["evals_per_pair"], 2),
+                                "certifier_thread_us_per_pair": None if cs3 is None else round(cs3["host_us_per_pair"], 1),
+                                "workload": "configs[2] with one scan of the 17-scan pool replaced by a scan of another world: its two pairs escalate "
+                                            "through 0.8 and 1.6 m and fail as a value (Match.py:207-214); exact RANSAC included"}
+    except Exception as e:
+        sec["failing_pairs"] = {"error": str(e)[:200]}
     # ---- resident_4541: a KITTI-00-sized run (4 541 frames = 568 batches, > 0.2 s of GPU time) over a pool of 161 DISTINCT scans
     # (2 MB each: 320 MB of points, more than the 256 MB Infinity Cache) walked back and forth -- what the 17-scan pool of the timed
     # region cannot show: whether the rate depends on the scans staying on-die

@@ -56,8 +56,9 @@ JOB_DTYPE = _np.dtype([("pc", "u8"), ("n", "i8"), ("dist_channels", "i4"), ("mod
 assert JOB_DTYPE.itemsize == C.sizeof(FrameJob) and all(JOB_DTYPE.fields[n][1] == getattr(FrameJob, n).offset for n, _ in FrameJob._fields_)
 # caelo_ransac_cert (include/caelo.h): what a RANSAC call leaves for the host half (csrc/certify.hip)
 CERT_MAX_PAIRS, CERT_MAGIC, CERT_NO_BOUNDS = 1024, 0x43455254, 1
-CERT_DTYPE = _np.dtype([("magic", "i4"), ("n_pairs", "i4"), ("flags", "i4"), ("reserved", "i4", (13,)), ("hi", "i4", (512,)),
-                        ("idx", "i4", (512, 4)), ("p0", "f4", (CERT_MAX_PAIRS, 3)), ("p1", "f4", (CERT_MAX_PAIRS, 3))])
+CERT_DTYPE = _np.dtype([("magic", "i4"), ("n_pairs", "i4"), ("flags", "i4"), ("levels_up", "i4"), ("reserved", "i4", (12,)), ("hi", "i4", (512,)),
+                        ("idx", "i4", (512, 4)), ("p0", "f4", (CERT_MAX_PAIRS, 3)), ("p1", "f4", (CERT_MAX_PAIRS, 3)),
+                        ("hi_up", "i4", (2, 512)), ("idx_up", "i4", (2, 512, 4))])
 POSE_DTYPE = _np.dtype([("R", "f4", (9,)), ("T", "f4", (3,)), ("R_ransac", "f4", (9,)), ("T_ransac", "f4", (3,)), ("threshold", "f4"),
                         ("success", "i4"), ("iterations", "i4"), ("n_inliers", "i4"), ("best_trial", "i4"), ("n_pairs", "i4")])
 assert POSE_DTYPE.itemsize == C.sizeof(PoseResult)

@@ -88,14 +88,19 @@ def certify_records(recs, rands=None, threads=None):
     return results, masks, evals, status
 
 
-def make_record(pairs0, pairs1, hi, idx):
-    """A caelo_ransac_cert record from host arrays (tests, and callers that hold pairs on the host)."""
+def make_record(pairs0, pairs1, hi, idx, hi_up=None, idx_up=None):
+    """A caelo_ransac_cert record from host arrays (tests, and callers that hold pairs on the host).  ``hi_up`` / ``idx_up`` [2,500] /
+    [2,500,4]: the bounds and sample indices of the 0.8 m and 1.6 m levels (what k_ransac_hyp_up leaves for a pair that escalates)."""
     n = len(pairs0)
     assert n <= _ffi.CERT_MAX_PAIRS
     rec = np.zeros(1, dtype=_ffi.CERT_DTYPE)
     rec["magic"], rec["n_pairs"] = _ffi.CERT_MAGIC, n
     rec["hi"][0, :500] = hi
     rec["idx"][0, :500] = idx
+    if hi_up is not None:
+        rec["levels_up"] = 1
+        rec["hi_up"][0, :, :500] = hi_up
+        rec["idx_up"][0, :, :500] = idx_up
     rec["p0"][0, :n] = pairs0
     rec["p1"][0, :n] = pairs1
     return rec.view(np.uint8).reshape(1, -1)

@@ -190,16 +190,22 @@ struct Outcome {
 // RANSAC4RT on host arrays.  hi (nullable): the device's upper bounds for the 500 hypotheses of the first level; idx0 (nullable):
 // their sample indices; rnd (nullable when idx0 is given and no level beyond the first is needed): [3 * 500][4] uniform draws.
 // -> 0 ok, 1 the draws are needed (an escalation without rnd), -1 LAPACK failure
-inline void sample_indices(const double *rnd, const int32_t (*idx0)[4], int level, int t, int64_t n, int32_t idx[4]) {
-    if (level == 0 && idx0) {
-        for (int q = 0; q < 4; ++q) idx[q] = idx0[t][q];
+inline void sample_indices(const double *rnd, const int32_t (*idx_l)[4], int level, int t, int64_t n, int32_t idx[4]) {
+    if (idx_l) {   // (the level's indices as the device recorded them)
+        for (int q = 0; q < 4; ++q) idx[q] = idx_l[t][q];
     } else {
         const double *r4 = rnd + ((size_t)level * CAELO_RANSAC_MAX_TRIALS + (size_t)t) * 4;
         for (int q = 0; q < 4; ++q) idx[q] = (int32_t)(r4[q] * (double)n);  // :182-184 int32(u * N), with replacement
     }
 }
 
-int ransac_host(const float *P0, const float *P1, int64_t n, const double *rnd, const int32_t *hi, const int32_t (*idx0)[4], Scratch &S,
+// bounds and sample indices per level (null: none for that level)
+struct LevelBounds {
+    const int32_t *hi[CAELO_RANSAC_LEVELS] = {nullptr, nullptr, nullptr};
+    const int32_t (*idx[CAELO_RANSAC_LEVELS])[4] = {nullptr, nullptr, nullptr};
+};
+
+int ransac_host(const float *P0, const float *P1, int64_t n, const double *rnd, LevelBounds lb, Scratch &S,
                 Outcome *o, uint8_t *mask_out) {
     S.size(n > 0 ? n : 1);
     const int least = (100 < (int)(0.2 * (double)n)) ? 100 : (int)(0.2 * (double)n);  // :166
@@ -218,7 +224,9 @@ int ransac_host(const float *P0, const float *P1, int64_t n, const double *rnd, 
         uint8_t *ex = S.exact.data();
         int w = -1, it = 0;
         Fit f;
-        if (level == 0 && hi != nullptr) {
+        const int32_t *hi = lb.hi[level];
+        const int32_t (*idx0)[4] = lb.idx[level];
+        if (hi != nullptr) {
             // ---- with the device's bounds: c[t] >= the count the reference's arithmetic gives hypothesis t.  Replay the rules over
             // the bounds; the winner of that replay is evaluated exactly; repeat until the winner is exact.  Then every other
             // hypothesis of the replayed range has a count <= its bound <= the winner's (strictly below it in front of the winner),
@@ -247,7 +255,7 @@ int ransac_host(const float *P0, const float *P1, int64_t n, const double *rnd, 
             }
             if (violated) {
                 g_bound_violations.fetch_add(1);
-                hi = nullptr;
+                lb.hi[level] = nullptr;
                 --level;
                 thr *= 0.5f;   // (exact: the loop header doubles it again)
                 continue;
@@ -262,7 +270,7 @@ int ransac_host(const float *P0, const float *P1, int64_t n, const double *rnd, 
             if (w >= 0) out.star = f;
         } else {
             // ---- without bounds: the reference's loop as it stands (:181-206)
-            if (!rnd && !(level == 0 && idx0)) return 1;
+            if (!rnd && !idx0) return 1;
             int best = 0;
             while (it < 100 || (it < CAELO_RANSAC_MAX_TRIALS && (double)best < min_success)) {
                 int32_t idx[4];
@@ -323,10 +331,10 @@ void fill_result(const Outcome &o, const Fit &final_fit, int64_t n, caelo_pose_r
     r->n_pairs = (int32_t)n;
 }
 
-int certify_one(const float *P0, const float *P1, int64_t n, const double *rnd, const int32_t *hi, const int32_t (*idx0)[4], Scratch &S,
+int certify_one(const float *P0, const float *P1, int64_t n, const double *rnd, const LevelBounds &lb, Scratch &S,
                 caelo_pose_result *res, uint8_t *mask, int32_t *evals) {
     Outcome o;
-    const int rc = ransac_host(P0, P1, n, rnd, hi, idx0, S, &o, mask);
+    const int rc = ransac_host(P0, P1, n, rnd, lb, S, &o, mask);
     if (rc != 0) return rc;
     Fit fin = o.star;
     if (o.success && o.n_in > 0 && !refit(P0, P1, n, mask, S, &fin)) return -1;
@@ -344,7 +352,11 @@ int certify_record(const caelo_ransac_cert &c, const double *rnd, caelo_pose_res
     if (!g_blas.sgemm) return -1;
     if (c.magic != CAELO_CERT_MAGIC) return 3;
     if (c.n_pairs < 0 || c.n_pairs > CAELO_CERT_MAX_PAIRS || (c.flags & CAELO_CERT_NO_BOUNDS) || c.n_pairs > mask_len) return 2;
-    const int rc = certify_one(&c.p0[0][0], &c.p1[0][0], c.n_pairs, rnd, c.hi, c.idx, S, res, mask, evals);
+    LevelBounds lb;
+    lb.hi[0] = c.hi; lb.idx[0] = c.idx;
+    if (c.levels_up == 1)   // the kernels saw the first level fail and left the bounds of the 0.8 m / 1.6 m levels (k_ransac_hyp_up)
+        for (int l = 1; l < CAELO_RANSAC_LEVELS; ++l) { lb.hi[l] = c.hi_up[l - 1]; lb.idx[l] = c.idx_up[l - 1]; }
+    const int rc = certify_one(&c.p0[0][0], &c.p1[0][0], c.n_pairs, rnd, lb, S, res, mask, evals);
     if (rc == 0 && c.n_pairs < mask_len) memset(mask + c.n_pairs, 0, (size_t)(mask_len - c.n_pairs));
     return rc;
 }
@@ -410,7 +422,9 @@ CAELO_API int caelo_host_ransac(const float *pairs0_host, const float *pairs1_ho
     CAELO_REQUIRE(g_blas.sgemm, "caelo_host_bind_blas was not called");
     CAELO_REQUIRE(pairs0_host && pairs1_host && rand_host && result_host && mask_host && n >= 0, "bad argument");
     Scratch S;
-    const int rc = certify_one(pairs0_host, pairs1_host, n, rand_host, hi_host, nullptr, S, result_host, mask_host, evals_host);
+    LevelBounds lb;
+    lb.hi[0] = hi_host;
+    const int rc = certify_one(pairs0_host, pairs1_host, n, rand_host, lb, S, result_host, mask_host, evals_host);
     CAELO_REQUIRE(rc == 0, "dgesdd failed");
     return CAELO_OK;
 }

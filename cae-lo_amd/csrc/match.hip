@@ -763,7 +763,8 @@ __device__ inline int hypothesis_count(const float *P0, int l0, const int64_t *p
 // CERT: also the certificate's bound (sN: per pair (|p1_j|, g |p0_j|); cert: the record `hi` / `idx` of the trials go to)
 template <bool CERT>
 __device__ inline void four_hypotheses(const float *sP0, const float *sP1, int N, const double *rnd, int trial0, float thr, int lane,
-                                       int32_t *faults, int32_t *counts, const float2 *sN = nullptr, caelo_ransac_cert *cert = nullptr) {
+                                       int32_t *faults, int32_t *counts, const float2 *sN = nullptr, int32_t *cert_hi = nullptr,
+                                       int32_t (*cert_idx)[4] = nullptr) {
     // ---- lane l: hypothesis trial0 + (l & 3) (a trial past the last repeats the last one; its count is not stored)
     const int mine = min(trial0 + (lane & (RH_PER_WAVE - 1)), CAELO_RANSAC_MAX_TRIALS - 1);
     float R[9], T[3];
@@ -774,7 +775,7 @@ __device__ inline void four_hypotheses(const float *sP0, const float *sP1, int N
         hypothesis_bound(smp, hb);
         if (lane < RH_PER_WAVE && trial0 + lane < CAELO_RANSAC_MAX_TRIALS)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) cert->idx[trial0 + lane][q] = smp.idx[q];
+            for (int q = 0; q < 4; ++q) cert_idx[trial0 + lane][q] = smp.idx[q];
         rigid_from_H(smp.H, smp.m0, smp.m1, R, T);
     } else {
         sample_hypothesis(sP0, 3, nullptr, sP1, 3, N, rnd + (size_t)mine * 4, R, T);
@@ -882,7 +883,7 @@ __device__ inline void four_hypotheses(const float *sP0, const float *sP1, int N
         for (int h = 0; h < RH_PER_WAVE; ++h)
             if (kinds[h] == 2) hi[h] = N;
         if (lane < RH_PER_WAVE && trial0 + lane < CAELO_RANSAC_MAX_TRIALS)
-            cert->hi[trial0 + lane] = lane == 0 ? hi[0] : (lane == 1 ? hi[1] : (lane == 2 ? hi[2] : hi[3]));
+            cert_hi[trial0 + lane] = lane == 0 ? hi[0] : (lane == 1 ? hi[1] : (lane == 2 ? hi[2] : hi[3]));
     }
     if (lane < RH_PER_WAVE && trial0 + lane < CAELO_RANSAC_MAX_TRIALS)
         counts[trial0 + lane] = lane == 0 ? cnt[0] : (lane == 1 ? cnt[1] : (lane == 2 ? cnt[2] : cnt[3]));
@@ -913,6 +914,7 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp(const caelo_pair_s
         }
     }
     __syncthreads();
+    if (cert && blockIdx.x == 0 && tid == 0) cert->levels_up = 0;   // (k_ransac_hyp_up, the next launch, sets it when it writes the higher levels' bounds)
     if (cert && P.cert_only && blockIdx.x == 0) {
         // the host half takes the pair from here (caelo_pipeline with result_host): the certificate's pairs and header leave with
         // this launch and k_ransac_finish is not launched at all -- what it computes (the kernels' own winner, mask and refit) is
@@ -936,8 +938,51 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp(const caelo_pair_s
         }
         return;
     }
-    if (cert) four_hypotheses<true>(sP0, sP1, N, P.rand, trial0, 0.4f, lane, ps.faults, ws->counts, sN, cert);
+    if (cert) four_hypotheses<true>(sP0, sP1, N, P.rand, trial0, 0.4f, lane, ps.faults, ws->counts, sN, cert->hi, cert->idx);
     else four_hypotheses<false>(sP0, sP1, N, P.rand, trial0, 0.4f, lane, ps.faults, ws->counts);
+}
+
+// Round 6: certificates for the 0.8 m and 1.6 m levels (Match.py:207-214).  A pair escalates when no hypothesis of a level reaches
+// leastInliers; without bounds for the next level the host half evaluates all of its (up to 500) hypotheses like the reference's loop --
+// 2.7 ms of a host core per level, and on data with real failures the exact path becomes a CPU path (missing 3).  Launched
+// behind k_ransac_hyp (before k_ransac_finish reuses the counts) for pairs that leave a certificate: a workgroup first looks at the first level's 500 counts and
+// returns unless none reached leastInliers (the device's own float64 counts: the reference's may differ by a pair at the threshold,
+// in which case the host half meets a level without bounds and evaluates it the long way -- still exact); otherwise blockIdx.y's level
+// (0.8 m, 1.6 m: both, the second is wasted when the first succeeds, and escalations are rare) gets its `hi_up` / `idx_up` exactly as
+// the first level got `hi` / `idx`.  The inlier counts of these levels are not kept (scratch): the host half derives them.
+__global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp_up(const caelo_pair_set ps, int ld0, int ld1, int64_t k1_max) {
+    const caelo_pair_dev &P = ps.p[blockIdx.z];
+    caelo_ransac_cert *cert = P.cert;
+    if (!cert) return;
+    RansacWs *ws = (RansacWs *)P.ws_ransac;
+    const int N = (P.n0 && *P.n0 <= 0) ? 0 : (P.n1 ? min(max(*P.n1, 0), (int)k1_max) : (int)k1_max);
+    if (N > RE_LDS_PAIRS) return;
+    const int least = min(100, (int)(0.2 * (double)N));   // :166
+    if (least <= 0) return;                                // N < 5: the first level "succeeds" without any inlier (:195-205)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bool reached = false;
+    for (int t = tid; t < CAELO_RANSAC_MAX_TRIALS; t += 64 * RE_WAVES) reached = reached || ws->counts[t] >= least;
+    if (__syncthreads_or(reached)) return;
+    __shared__ float sP0[RE_LDS_PAIRS * 3], sP1[RE_LDS_PAIRS * 3];
+    __shared__ float2 sN[RE_LDS_PAIRS];
+    __shared__ int32_t s_scratch[CAELO_RANSAC_MAX_TRIALS];
+    const float *__restrict__ pc0 = P.pc0, *__restrict__ pc1 = P.pc1;
+    const int64_t *__restrict__ pair_idx = P.pair_idx;
+    for (int i = tid; i < N; i += 64 * RE_WAVES) {
+        const float *a = pc0 + (size_t)ld0 * pair_idx[i];
+        const float *b = pc1 + (size_t)ld1 * i;
+        const float a0 = a[0], a1 = a[1], a2 = a[2], b0 = b[0], b1 = b[1], b2 = b[2];
+        sP0[3 * i] = a0; sP0[3 * i + 1] = a1; sP0[3 * i + 2] = a2;
+        sP1[3 * i] = b0; sP1[3 * i + 1] = b1; sP1[3 * i + 2] = b2;
+        sN[i] = make_float2(1.0001f * sqrtf(b0 * b0 + b1 * b1 + b2 * b2), 1.0001f * RB_G * sqrtf(a0 * a0 + a1 * a1 + a2 * a2));
+    }
+    __syncthreads();
+    const int level = 1 + (int)blockIdx.y;   // 1, 2
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) cert->levels_up = 1;   // (k_ransac_hyp wrote 0 with the header)
+    const int trial0 = (blockIdx.x * RE_WAVES + wave) * RH_PER_WAVE;
+    if (trial0 >= CAELO_RANSAC_MAX_TRIALS) return;
+    four_hypotheses<true>(sP0, sP1, N, P.rand + (size_t)level * CAELO_RANSAC_MAX_TRIALS * 4, trial0, 0.4f * (float)(1 << level), lane, ps.faults,
+                          s_scratch, sN, cert->hi_up[level - 1], cert->idx_up[level - 1]);
 }
 
 #define RF_WAVES 8   // the accept rules, the mask and the refit use four of them; all eight evaluate a next level's hypotheses
@@ -1123,6 +1168,12 @@ int ransac_set(const caelo_pair_set &ps, int ld0, int ld1, int64_t k1_max, hipSt
     CAELO_LAUNCH_CHECK();
     bool all_cert_only = true;
     for (int i = 0; i < ps.n; ++i) all_cert_only = all_cert_only && ps.p[i].cert && ps.p[i].cert_only;
+    bool any_cert = false;
+    for (int i = 0; i < ps.n; ++i) any_cert = any_cert || ps.p[i].cert != nullptr;
+    if (any_cert) {   // bounds for the 0.8 / 1.6 m levels of the pairs whose first level failed (workgroups of the others return at once)
+        k_ransac_hyp_up<<<dim3((CAELO_RANSAC_MAX_TRIALS + RE_WAVES * RH_PER_WAVE - 1) / (RE_WAVES * RH_PER_WAVE), 2, ps.n), 64 * RE_WAVES, 0, s>>>(ps, ld0, ld1, k1_max);
+        CAELO_LAUNCH_CHECK();
+    }
     if (all_cert_only) return CAELO_OK;   // the host half decides every pair of the set: no finishing kernel
     k_ransac_finish<<<dim3(1, 1, ps.n), 64 * RF_WAVES, 0, s>>>(ps, ld0, ld1, k1_max);
     CAELO_LAUNCH_CHECK();

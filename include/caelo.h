@@ -251,11 +251,15 @@ typedef struct {
     int32_t magic;        /* CAELO_CERT_MAGIC once k_ransac_finish has written the record */
     int32_t n_pairs;      /* N */
     int32_t flags;
-    int32_t reserved[13];
+    int32_t levels_up;    /* 1: hi_up / idx_up hold the bounds of the 0.8 m and 1.6 m levels (written by the pipeline's kernels for a pair
+                           * whose first level reached leastInliers with no hypothesis: Match.py:207-214) */
+    int32_t reserved[12];
     int32_t hi[512];      /* [500] used */
     int32_t idx[512][4];  /* sample indices int32(u * N) (Match.py:182-184) of the first level's hypotheses */
     float p0[CAELO_CERT_MAX_PAIRS][3]; /* Pairs0 = PC0[pairIdx] (Match.py:260) */
     float p1[CAELO_CERT_MAX_PAIRS][3]; /* Pairs1 */
+    int32_t hi_up[2][512];      /* the same for the hypotheses of the 0.8 m and the 1.6 m level (draws 500 .. 999, 1000 .. 1499) */
+    int32_t idx_up[2][512][4];
 } caelo_ransac_cert;
 int64_t caelo_cert_bytes(void);
 int64_t caelo_ransac_ws_bytes(void);

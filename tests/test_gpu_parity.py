@@ -1692,6 +1692,47 @@ def test_ransac_certificate_bounds_hold_and_results_are_the_oracles_bits(engine,
 
 
 @pytest.mark.gpu
+def test_ransac_certificates_of_the_higher_levels(engine, orc):
+    """Round 6 (Match.py:207-214): for a pair whose first level fails -- the golden escalation / failure inputs -- the certificate carries
+    `hi_up` / `idx_up`: upper bounds of the reference's counts for EVERY hypothesis of the 0.8 m and 1.6 m levels and their sample indices;
+    the host half then returns the oracle's result bit for bit from a handful of evaluations, without the draws.  A pair whose first
+    level succeeds has levels_up = 0 (the workgroups of k_ransac_hyp_up return at once)."""
+    import torch
+    from caelo import _ffi
+    pr = np.load(os.path.join(GOLDEN, "pair_0_1.npz"))
+    for k in ("esc", "fail"):
+        P0, P1 = np.ascontiguousarray(pr[k + "_P0"]), np.ascontiguousarray(pr[k + "_P1"])
+        N = len(P0)
+        d0, d1 = torch.from_numpy(P0).to(engine.device), torch.from_numpy(P1).to(engine.device)
+        ident = torch.arange(N, device=engine.device, dtype=torch.int64)
+        for seed in (5, 6):
+            draws = np.random.RandomState(seed).random_sample(6000)
+            cert = engine.new_cert(1)
+            engine.ransac(d0, d1, ident, torch.from_numpy(draws).to(engine.device), cert=cert[0])
+            rec = cert.cpu().numpy().view(_ffi.CERT_DTYPE).reshape(-1)[0]
+            assert rec["levels_up"] == 1, (k, seed)
+            for l in (1, 2):
+                dl = draws[2000 * l:2000 * (l + 1)]
+                assert np.array_equal(rec["idx_up"][l - 1][:500], (dl.reshape(500, 4) * N).astype(np.int32))
+                cnt = _oracle_counts(orc, P0, P1, dl, thr=np.float32(0.4 * 2 ** l))
+                hi = rec["hi_up"][l - 1][:500]
+                assert (hi >= cnt).all(), (k, seed, l, np.flatnonzero(hi < cnt)[:5])
+            results, masks, evals, status = engine.certify(cert, None)      # no draws: the record is enough
+            R, T, ok, m, thr = orc.RANSAC4RT(P0, P1, rng=np.random.RandomState(seed))
+            assert status[0] == 0 and bool(results[0]["success"]) == ok and abs(float(results[0]["threshold"]) - thr) < 1e-6
+            assert np.array_equal(masks[0, :N].astype(bool), m) and evals[0] <= 60, (k, seed, int(evals[0]))
+            if ok:
+                assert np.array_equal(results[0]["R_ransac"].reshape(3, 3), R.astype(np.float32)) and np.array_equal(results[0]["T_ransac"].reshape(3, 1), T.astype(np.float32))
+    # a pair whose first level succeeds: no higher-level bounds are written
+    f0, f1, pair_idx = _golden_pairs("0", "1", "0_1")
+    kp0 = torch.from_numpy(np.ascontiguousarray(f0["keypts_demo"])).to(engine.device)
+    kp1 = torch.from_numpy(np.ascontiguousarray(f1["keypts_demo"])).to(engine.device)
+    cert = engine.new_cert(1)
+    engine.ransac(kp0, kp1, torch.from_numpy(pair_idx).to(engine.device), torch.from_numpy(np.random.RandomState(3).random_sample(6000)).to(engine.device), cert=cert[0])
+    assert cert.cpu().numpy().view(_ffi.CERT_DTYPE).reshape(-1)[0]["levels_up"] == 0
+
+
+@pytest.mark.gpu
 def test_ransac_certificate_on_degenerate_and_edge_inputs(engine, orc):
     """Certificates on inputs made of rank-deficient samples: every point repeated (rank-2 and rank-1 covariances),
     exactly coplanar clouds (mm-quantised ground), tiny N, and more than 1024 pairs (no certificate: the API falls back to
@@ -1800,6 +1841,8 @@ def test_pipeline_certified_poses_equal_the_oracle_on_the_pipelines_own_matches(
         for o_ in outs:
             r_ = o_.exact[0][i]
             assert o_.exact[3][i] == 0 and bool(r_["success"]) == ok and abs(float(r_["threshold"]) - thr) < 1e-6, (i, thr)
+            if thr > 0.4:   # round 6: the kernels leave bounds for the 0.8 / 1.6 m levels too (k_ransac_hyp_up): a handful of evaluations, not ~1000
+                assert o_.exact[2][i] <= 60, (i, thr, int(o_.exact[2][i]))
             assert np.array_equal(o_.exact[1][i, :N].astype(bool), m)
             if ok:
                 assert np.array_equal(r_["R_ransac"].reshape(3, 3), R) and np.array_equal(r_["T_ransac"].reshape(3, 1), T)

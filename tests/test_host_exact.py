@@ -114,6 +114,48 @@ def test_host_ransac_escalation_failure_and_tiny_inputs(orc):
         assert bool(r["success"]) == ok and np.array_equal(mask, m) and abs(float(r["threshold"]) - thr) < 1e-6
 
 
+def test_certificates_of_the_higher_levels(orc):
+    """Round 6: a record that carries bounds for the 0.8 m / 1.6 m levels (caelo_ransac_cert::hi_up, written by k_ransac_hyp_up for a pair
+    whose first level fails).  The host half then decides an escalating pair from a handful of evaluations WITHOUT the draws, with the
+    reference's bits: exact counts as bounds, counts plus slack, and -- the failing pair -- bounds that say nobody reaches leastInliers
+    at any level.  Without hi_up the same records need the draws (status 1) and ~1000 evaluations."""
+    from caelo import hostexact, _ffi
+    pr = np.load(os.path.join(GOLDEN, "pair_0_1.npz"))
+    for k in ("esc", "fail"):
+        P0, P1 = np.ascontiguousarray(pr[k + "_P0"]), np.ascontiguousarray(pr[k + "_P1"])
+        N = len(P0)
+        for seed in (5, 6):
+            draws = np.random.RandomState(seed).random_sample(6000)
+            want, wmask, wev = hostexact.ransac(P0, P1, draws)            # (== the oracle: test_host_ransac_escalation_failure_and_tiny_inputs)
+            idx = (draws.reshape(3, 500, 4) * N).astype(np.int32)
+            cnt = np.zeros((3, 500), np.int32)
+            for l in range(3):
+                for t in range(500):
+                    Rh, Th, _ = orc.SolveRT(P0[idx[l, t]], P1[idx[l, t]])
+                    cnt[l, t] = int((np.linalg.norm(P0 - (np.dot(Rh, P1.T) + Th).T, axis=1) < np.float32(0.4 * 2 ** l)).sum())
+            assert cnt[0].max() < min(100, int(0.2 * N))                   # the first level fails: the pair escalates
+            for slack in (0, 3):
+                hi = np.minimum(cnt + slack, N).astype(np.int32)
+                rec = hostexact.make_record(P0, P1, hi[0], idx[0], hi[1:], idx[1:])
+                res, masks, evals, status = hostexact.certify_records(rec, None, 1)     # no draws given: none needed
+                assert status[0] == 0 and res[0].tobytes() == want.tobytes() and np.array_equal(masks[0, :N].astype(bool), wmask)
+                assert evals[0] <= (12 if slack == 0 else 80) and evals[0] < wev // 10, (k, seed, slack, evals[0], wev)
+            # the same record without the higher levels' bounds: the draws are needed, every hypothesis of the higher levels is evaluated
+            rec0 = hostexact.make_record(P0, P1, cnt[0], idx[0])
+            with pytest.raises(_ffi.CaeloError):
+                hostexact.certify_records(rec0, None, 1)
+            res0, masks0, evals0, status0 = hostexact.certify_records(rec0, [draws], 1)
+            assert status0[0] == 0 and res0[0].tobytes() == want.tobytes() and evals0[0] >= 100
+            # an INVALID higher-level bound is noticed like a first-level one (the level is redone without bounds: needs the draws)
+            if want["success"]:
+                lvl = int(want["best_trial"]) // 500
+                bad = cnt.copy(); bad[lvl, int(want["best_trial"]) % 500] -= 1
+                recb = hostexact.make_record(P0, P1, bad[0], idx[0], bad[1:], idx[1:])
+                v0 = int(_ffi.load().caelo_host_bound_violations())
+                resb, masksb, _, stb = hostexact.certify_records(recb, [draws], 1)
+                assert stb[0] == 0 and resb[0].tobytes() == want.tobytes() and int(_ffi.load().caelo_host_bound_violations()) == v0 + 1
+
+
 def test_certify_records_threads_and_statuses(orc):
     """caelo_host_certify over hand-made records: many pairs on several threads, a record without bounds, an empty slot."""
     from caelo import hostexact, _ffi
