@@ -247,7 +247,12 @@ def run_local_files(eng, files, lo, hi, seed_base, chunk, dist_channels, batch_f
     for k_ in ("load", "pin", "draws", "starved", "pipeline", "ties", "parse", "setup"):
         ht.setdefault(k_, 0.0)
     B = batch_frames
-    loader = SeqLoader(eng, files[lo:hi], first_frame=lo, batch=B, seed_base=seed_base, threads=loader_threads)
+    # a ring slot holds the LARGEST scan of this rank's files, not the engine's capacity: a batch goes up as one copy of the whole slot, and
+    # what the copy engine moves beside the pipeline is what the upload mode costs (20.5 MB per batch at 160 000 points, 16.2 MB at 126 k)
+    biggest = max(os.path.getsize(f_) for f_ in files[lo:hi]) // 16
+    assert biggest <= eng.max_points, "a scan holds %d points, the engine was created for %d" % (biggest, eng.max_points)
+    cap = min(int(eng.max_points), (int(biggest) + 1023) // 1024 * 1024)
+    loader = SeqLoader(eng, files[lo:hi], first_frame=lo, batch=B, seed_base=seed_base, threads=loader_threads, ring=7, cap=cap)
     pipe = eng.pipeline(B)
     import gc
     gc.collect()
