@@ -830,7 +830,9 @@ def secondary_legs(args, eng, pipe, dev, pool, rand, rand_host, Runner, frame_pa
                                       "ahead; MEDIAN of three identical runs (all listed: one copy call of an early run stalls ~7 ms inside the runtime)"}
     del staged
     other = "clutter" if args.scene == "boxes" else "boxes"
-    pool2 = [torch.from_numpy(scan_at(i, quantum=QUANTUM, scene_kind=other)).to(dev) for i in range(POOL)]
+    # (from scan 96 on: a stretch of the circuit where the clutter family's 496-nearest cuts DO split tie classes -- 7 of the frames 98..107,
+    # profiles/r06_tie_redo_check_clutter_600.txt -- so that the leg exercises the redo; scans 0..16 hold none)
+    pool2 = [torch.from_numpy(scan_at(96 + i, quantum=QUANTUM, scene_kind=other)).to(dev) for i in range(POOL)]
     r2 = Runner(pool2)
 
     def leg_exact_ties(runner):

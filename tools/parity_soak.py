@@ -115,6 +115,7 @@ def soak(engine, orc, models, scene, n_frames, seed_base=5000, batch=8, log=None
     tied = [i for i in range(n_frames) if (fl[i] & 2).any()]
     tied2, n_tied_patches = engine.resolve_ties_many([(out.frame(i), dpcs[i]) for i in range(n_frames)], batch=out)
     assert tied2 == tied
+    unresolved = int(getattr(engine, "last_tie_unresolved", 0))   # tie-split patches the kd-tree redo LEFT on the canonical rule (a quickselect gave up)
     n_tied_patches = sum(n_tied_patches)
     redo = sorted({j for t in tied for j in (t, t + 1) if 1 <= j < n_frames})
     if redo:
@@ -125,7 +126,7 @@ def soak(engine, orc, models, scene, n_frames, seed_base=5000, batch=8, log=None
     rows = out.rows.cpu().numpy(); kpix = out.key_pixels.cpu().numpy(); nkey = out.n_key.cpu().numpy()
     pidx = out.pair_idx.cpu().numpy(); mask = out.inlier_mask.cpu().numpy().astype(bool); res = out.result.cpu().numpy()
     status = out.status.cpu().numpy()
-    rep = dict(scene=scene, frames=n_frames, pairs=n_frames - 1, frames_with_tie_split=len(tied), tie_split_patches=n_tied_patches, keypixel_mismatch_frames=0, keypoint_mismatch_frames=0,
+    rep = dict(scene=scene, frames=n_frames, pairs=n_frames - 1, frames_with_tie_split=len(tied), tie_split_patches=n_tied_patches, tie_redo_unresolved=unresolved, keypixel_mismatch_frames=0, keypoint_mismatch_frames=0,
                voxel_set_mismatch=[0, 0, 0], patch_mismatch=0, patch_mismatch_canonical_rule=0, patches=0, patches_truncated=0, patches_tie_ambiguous=0,
                desc_max_abs=0.0, desc_max_rel=0.0, desc_over_tol=0, status_or=int(np.bitwise_or.reduce(status[:, 0])),
                match_kernel_mismatch_cols=0, ransac_kernel_mismatch_pairs=0, ransac_kernel_max_rt=0.0,
@@ -237,6 +238,7 @@ def clean(rep):
             and rep["patch_mismatch"] == 0 and rep["desc_over_tol"] == 0 and rep["status_or"] == 0
             and rep["match_kernel_mismatch_cols"] == 0 and rep["ransac_kernel_mismatch_pairs"] == 0
             and rep["ransac_kernel_bitexact_pairs"] == rep["pairs_compared"] and rep["bound_violations"] == 0
+            and rep.get("tie_redo_unresolved", 0) == 0
             and rep["flips_unexplained"] == 0 and rep["exact_pairs_inlier_mismatch"] == 0 and rep["exact_pairs_max_rt"] <= REL_TOL
             and rep["success_mismatch_exact_pairs"] == 0 and rep["lane_faults"] == 0)
 
@@ -247,9 +249,10 @@ def render(rep):
              rep["keypixel_mismatch_frames"], rep["keypoint_mismatch_frames"], rep["status_or"], rep["lane_faults"]),
          "  voxel sets differing (frames, scale 0/1/2): %s" % rep["voxel_set_mismatch"],
          "  patches: %d of %d differ (truncated at the 496-NN cut: %d; cut inside a tie class: %d in %d frames -- the set-based fused build "
-         "uses a canonical rule there (%d of them differ from the reference's choice) and Engine.resolve_ties redid those frames from ordered lists in scikit-learn's kd-tree order)" % (
+         "uses a canonical rule there (%d of them differ from the reference's choice) and Engine.resolve_ties redid those frames from ordered lists in scikit-learn's kd-tree order; "
+         "%d left on the canonical rule by the redo)" % (
              rep["patch_mismatch"], rep["patches"], rep["patches_truncated"], rep["tie_split_patches"], rep["frames_with_tie_split"],
-             rep["patch_mismatch_canonical_rule"]),
+             rep["patch_mismatch_canonical_rule"], rep.get("tie_redo_unresolved", 0)),
          "  descriptors: max |err| %.3g, max relative (0.1 floor) %.3g, elements over 1e-4: %d" % (rep["desc_max_abs"], rep["desc_max_rel"], rep["desc_over_tol"]),
          "  kernels on the oracle's inputs: caelo_match %d wrong columns; caelo_ransac + host half: %d of %d pairs differ in inlier set / success / threshold / pose beyond 1e-4; "
          "%d of %d bit-exact incl. R_star, T_star and the refit (max R/T err %.2g; at most %d hypotheses re-evaluated on the host for a pair)" % (
