@@ -762,9 +762,12 @@ __device__ inline int hypothesis_count(const float *P0, int l0, const int64_t *p
 #define RH_PER_WAVE 4
 // CERT: also the certificate's bound (sN: per pair (|p1_j|, g |p0_j|); cert: the record `hi` / `idx` of the trials go to)
 template <bool CERT>
-__device__ inline void four_hypotheses(const float *sP0, const float *sP1, int N, const double *rnd, int trial0, float thr, int lane,
-                                       int32_t *faults, int32_t *counts, const float2 *sN = nullptr, int32_t *cert_hi = nullptr,
-                                       int32_t (*cert_idx)[4] = nullptr) {
+__device__ __forceinline__ void four_hypotheses(const float *sP0, const float *sP1, int N, const double *rnd, int trial0, float thr, int lane,
+                                       int32_t *faults, int32_t *counts, const float2 *sN = nullptr, caelo_ransac_cert *cert = nullptr,
+                                       int level = 0) {
+    // (__forceinline__: with a second caller -- k_ransac_hyp_up -- hipcc stopped inlining this function, and a CALL costs the callers
+    // the full register budget: k_ransac_hyp went from 168 to 248 registers, no longer fitted beside two stage-1 workgroups, and its
+    // launch stretched from 74 to 199 us inside the pipeline, profiles/r06_kernel_stats_bench.txt)
     // ---- lane l: hypothesis trial0 + (l & 3) (a trial past the last repeats the last one; its count is not stored)
     const int mine = min(trial0 + (lane & (RH_PER_WAVE - 1)), CAELO_RANSAC_MAX_TRIALS - 1);
     float R[9], T[3];
@@ -775,7 +778,7 @@ __device__ inline void four_hypotheses(const float *sP0, const float *sP1, int N
         hypothesis_bound(smp, hb);
         if (lane < RH_PER_WAVE && trial0 + lane < CAELO_RANSAC_MAX_TRIALS)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) cert_idx[trial0 + lane][q] = smp.idx[q];
+            for (int q = 0; q < 4; ++q) (level ? cert->idx_up[level - 1] : cert->idx)[trial0 + lane][q] = smp.idx[q];
         rigid_from_H(smp.H, smp.m0, smp.m1, R, T);
     } else {
         sample_hypothesis(sP0, 3, nullptr, sP1, 3, N, rnd + (size_t)mine * 4, R, T);
@@ -883,7 +886,7 @@ __device__ inline void four_hypotheses(const float *sP0, const float *sP1, int N
         for (int h = 0; h < RH_PER_WAVE; ++h)
             if (kinds[h] == 2) hi[h] = N;
         if (lane < RH_PER_WAVE && trial0 + lane < CAELO_RANSAC_MAX_TRIALS)
-            cert_hi[trial0 + lane] = lane == 0 ? hi[0] : (lane == 1 ? hi[1] : (lane == 2 ? hi[2] : hi[3]));
+            (level ? cert->hi_up[level - 1] : cert->hi)[trial0 + lane] = lane == 0 ? hi[0] : (lane == 1 ? hi[1] : (lane == 2 ? hi[2] : hi[3]));
     }
     if (lane < RH_PER_WAVE && trial0 + lane < CAELO_RANSAC_MAX_TRIALS)
         counts[trial0 + lane] = lane == 0 ? cnt[0] : (lane == 1 ? cnt[1] : (lane == 2 ? cnt[2] : cnt[3]));
@@ -938,7 +941,7 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp(const caelo_pair_s
         }
         return;
     }
-    if (cert) four_hypotheses<true>(sP0, sP1, N, P.rand, trial0, 0.4f, lane, ps.faults, ws->counts, sN, cert->hi, cert->idx);
+    if (cert) four_hypotheses<true>(sP0, sP1, N, P.rand, trial0, 0.4f, lane, ps.faults, ws->counts, sN, cert, 0);
     else four_hypotheses<false>(sP0, sP1, N, P.rand, trial0, 0.4f, lane, ps.faults, ws->counts);
 }
 
@@ -982,7 +985,7 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp_up(const caelo_pai
     const int trial0 = (blockIdx.x * RE_WAVES + wave) * RH_PER_WAVE;
     if (trial0 >= CAELO_RANSAC_MAX_TRIALS) return;
     four_hypotheses<true>(sP0, sP1, N, P.rand + (size_t)level * CAELO_RANSAC_MAX_TRIALS * 4, trial0, 0.4f * (float)(1 << level), lane, ps.faults,
-                          s_scratch, sN, cert->hi_up[level - 1], cert->idx_up[level - 1]);
+                          s_scratch, sN, cert, level);
 }
 
 #define RF_WAVES 8   // the accept rules, the mask and the refit use four of them; all eight evaluate a next level's hypotheses
