@@ -953,6 +953,7 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp(const caelo_pair_s
 // in which case the host half meets a level without bounds and evaluates it the long way -- still exact); otherwise blockIdx.y's level
 // (0.8 m, 1.6 m: both, the second is wasted when the first succeeds, and escalations are rare) gets its `hi_up` / `idx_up` exactly as
 // the first level got `hi` / `idx`.  The inlier counts of these levels are not kept (scratch): the host half derives them.
+#define RU_BLOCKS 8
 __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp_up(const caelo_pair_set ps, int ld0, int ld1, int64_t k1_max) {
     const caelo_pair_dev &P = ps.p[blockIdx.z];
     caelo_ransac_cert *cert = P.cert;
@@ -982,10 +983,11 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp_up(const caelo_pai
     __syncthreads();
     const int level = 1 + (int)blockIdx.y;   // 1, 2
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) cert->levels_up = 1;   // (k_ransac_hyp wrote 0 with the header)
-    const int trial0 = (blockIdx.x * RE_WAVES + wave) * RH_PER_WAVE;
-    if (trial0 >= CAELO_RANSAC_MAX_TRIALS) return;
-    four_hypotheses<true>(sP0, sP1, N, P.rand + (size_t)level * CAELO_RANSAC_MAX_TRIALS * 4, trial0, 0.4f * (float)(1 << level), lane, ps.faults,
-                          s_scratch, sN, cert, level);
+    // (RU_BLOCKS workgroups per level and pair, each walking its share of the 500 trials: 512 workgroups of 33 KB of LDS that only
+    // look at 500 counts and leave took 48 us of the pair stream per batch to be scheduled beside the encoder's persistent grids)
+    for (int trial0 = (blockIdx.x * RE_WAVES + wave) * RH_PER_WAVE; trial0 < CAELO_RANSAC_MAX_TRIALS; trial0 += RU_BLOCKS * RE_WAVES * RH_PER_WAVE)
+        four_hypotheses<true>(sP0, sP1, N, P.rand + (size_t)level * CAELO_RANSAC_MAX_TRIALS * 4, trial0, 0.4f * (float)(1 << level), lane, ps.faults,
+                              s_scratch, sN, cert, level);
 }
 
 #define RF_WAVES 8   // the accept rules, the mask and the refit use four of them; all eight evaluate a next level's hypotheses
@@ -1174,7 +1176,7 @@ int ransac_set(const caelo_pair_set &ps, int ld0, int ld1, int64_t k1_max, hipSt
     bool any_cert = false;
     for (int i = 0; i < ps.n; ++i) any_cert = any_cert || ps.p[i].cert != nullptr;
     if (any_cert) {   // bounds for the 0.8 / 1.6 m levels of the pairs whose first level failed (workgroups of the others return at once)
-        k_ransac_hyp_up<<<dim3((CAELO_RANSAC_MAX_TRIALS + RE_WAVES * RH_PER_WAVE - 1) / (RE_WAVES * RH_PER_WAVE), 2, ps.n), 64 * RE_WAVES, 0, s>>>(ps, ld0, ld1, k1_max);
+        k_ransac_hyp_up<<<dim3(RU_BLOCKS, 2, ps.n), 64 * RE_WAVES, 0, s>>>(ps, ld0, ld1, k1_max);
         CAELO_LAUNCH_CHECK();
     }
     if (all_cert_only) return CAELO_OK;   // the host half decides every pair of the set: no finishing kernel

@@ -8,7 +8,8 @@ from caelo import synth
 from caelo.engine import Engine, ransac_draws
 eng = Engine(); eng.host_blas()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-pcs = [torch.from_numpy(synth.make_scan(f, quantum=1e-3, scene_kind="clutter")).to(eng.device) for f in range(N)]
+FIRST = int(sys.argv[2]) if len(sys.argv) > 2 else 96      # (scans 96.. of the circuit: about half of them split a tie class)
+pcs = [torch.from_numpy(synth.make_scan(FIRST + f, quantum=1e-3, scene_kind="clutter", trajectory="circuit")).to(eng.device) for f in range(N)]
 draws = [ransac_draws(f) for f in range(N)]; rnd = [torch.from_numpy(d).to(eng.device) for d in draws]
 pipe = eng.pipeline(8)
 def fresh():
@@ -20,7 +21,7 @@ _, ms = T(lambda: [eng.resolve_ties(o.frame(j), pcs[j]) for j in range(N)])
 o = fresh()
 r, ms = T(lambda: [eng.resolve_ties(o.frame(j), pcs[j]) for j in range(N)])
 print("%d frames, %d tied: frame by frame %.1f ms" % (N, sum(1 for x in r if x), ms))
-for lanes in (1, 2, 4, 8, 16, 32):
+for lanes in [int(x) for x in os.environ.get("PROBE_LANES", "1,2,4,8,16,32").split(",")]:
     for rep in range(3):
         o = fresh()
         (tied, cnt), ms = T(lambda: eng.resolve_ties_many([(o.frame(j), pcs[j]) for j in range(N)], lanes=lanes))
