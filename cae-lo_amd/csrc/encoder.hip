@@ -809,7 +809,10 @@ __global__ void __launch_bounds__(256, C3X_WGS) k_enc_conv3(const float *__restr
 // one frame still fills the chip (48 x 4 workgroups, 29 us either way), a batch of 8 frames writes and re-reads half the partial
 // sums (10.3 -> 10.6 k frames/s; 2 slices: 10.7 k but 48 us for a single frame).  One value for every launch size: the head adds
 // the slices in order, so the descriptors' low bits depend on it and single calls must equal batched ones bit for bit.
-#define D1_SPLIT_OF(KTOT) ((KTOT) > 2048 ? 8 : 4)
+#ifndef D1_SPLIT_2048
+#define D1_SPLIT_2048 2   // k slices of Dense(200) (K = 2048).  Round 6: 4 -> 2 (half the partial sums written and read back by the head: head 22 -> 15 us, Dense(200) 83 -> 90 us per 24 576 rows, +1.5-3 % frames/s in 11 of 11 A/B runs, profiles/r06_dense1_split.txt; `make EXTRA=-DD1_SPLIT_2048=4 ...` builds the old one)
+#endif
+#define D1_SPLIT_OF(KTOT) ((KTOT) > 2048 ? 8 : D1_SPLIT_2048)
 #define D1_THREADS 512
 #define D1_NT (DENSE_NP / 16)          // 13 n-tiles
 // Round 3: like conv3, Dense(200) evaluates its f32 products from TWO f16 terms per operand and three partial products
