@@ -87,6 +87,7 @@ SIGNATURES = [
     ("caelo_voxmap_order", c_int, [c_vp, c_vp, c_int, c_vp]),
     ("caelo_voxmap_from_lists", c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     ("caelo_patches", c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    ("caelo_patches_many", c_int, [c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("caelo_unpack_patches", c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     ("caelo_pack_patches", c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     ("caelo_encode_ws_bytes", c_i64, [c_i64]),

@@ -1124,23 +1124,46 @@ class Engine:
         start.record(cur)
         t1_ = time.perf_counter()
         statuses = []
-        for j, i in enumerate(tied):
-            ff, pc = items[i]
-            lane = self._tie_lanes[j % lanes]
-            if j < lanes:
+        # Groups of up to eight tied frames per side stream (round 6): each frame's exact voxelization and list ordering one after the
+        # other, then ONE caelo_patches_many -- the kd-tree builds and queries of the whole group behind one launch of each kd kernel
+        # (a redo's chain of ~150 dependent quickselect passes costs a millisecond or two whatever the GPU has free: eight side by side
+        # cost what one does) -- and ONE encoder launch set over the group's patches.  Frame by frame on eight lanes this took 1.2 ms per
+        # tied frame (profiles/r05_ties_many.txt, r06_ties_many.txt).
+        G = 8
+        groups = [tied[g0:g0 + G] for g0 in range(0, len(tied), G)]
+        n_lanes = min(lanes, len(groups))
+        for gi, grp in enumerate(groups):
+            lane = self._tie_lanes[gi % lanes]
+            if gi < lanes:
                 lane.wait_event(start)
             with torch.cuda.stream(lane):
-                cap = max(self.max_points, pc.shape[0])
-                vm, st = self.voxelize(pc, self.voxmap(cap, slot=2))      # exact build: first touch recorded
-                self.voxmap_order(vm, sum(1 << s_ for s_ in range(3) if both[i, s_]))
-                k = int(both[i, 3])
-                bits, flags = self.patches(vm, ff.key_pts[:k].contiguous())   # canonical rule + the tie-split ones in the kd-tree order
-                ff.rows[:k, 0:60] = self.encode(bits.reshape(-1, 64), group=3)
-                ff.flags[:k] = flags
-                statuses.append(st)
-                for t in (bits, flags):
+                n = len(grp)
+                gbits = self.empty((n, MAX_K, 3, 64), torch.int64)
+                gflags = self.empty((n, MAX_K, 3), torch.uint8)
+                gpts = self.empty((n, MAX_K, 3), torch.float32)
+                maps, sts = [], []
+                for q, i in enumerate(grp):
+                    ff, pc = items[i]
+                    cap = max(self.max_points, pc.shape[0])
+                    vm, st = self.voxelize(pc, self.voxmap(cap, slot=10 + q))      # exact build: first touch recorded
+                    self.voxmap_order(vm, sum(1 << s_ for s_ in range(3) if both[i, s_]))
+                    gpts[q].copy_(ff.key_pts)
+                    maps.append(vm)
+                    sts.append(st)
+                    statuses.append(st)
+                arr = lambda xs: (C.c_void_p * n)(*xs)
+                _ffi.check(self.lib.caelo_patches_many(self.ctx, n, arr([m.h for m in maps]), arr([gpts[q].data_ptr() for q in range(n)]), MAX_K,
+                                                       arr([items[i][0].n_key.data_ptr() for i in grp]), arr([gbits[q].data_ptr() for q in range(n)]),
+                                                       arr([gflags[q].data_ptr() for q in range(n)]), arr([st.data_ptr() for st in sts]), self.stream))
+                feats = self.encode(gbits.reshape(-1, 64), group=3).reshape(n, MAX_K, 60)
+                for q, i in enumerate(grp):
+                    ff = items[i][0]
+                    k = int(both[i, 3])
+                    ff.rows[:k, 0:60] = feats[q, :k]
+                    ff.flags[:k] = gflags[q, :k]
+                for t in (gbits, gflags, gpts, feats):
                     t.record_stream(lane)
-        for lane in self._tie_lanes[:min(lanes, len(tied))]:
+        for lane in self._tie_lanes[:n_lanes]:
             cur.wait_stream(lane)
         t4_ = time.perf_counter()
         raise_status(int(np.bitwise_or.reduce(torch.stack([s.reshape(()) for s in statuses]).cpu().numpy())))

@@ -122,6 +122,8 @@ int kd_store_lists(caelo_voxmap *m, const int16_t *const lists[3], const int64_t
 int kd_begin_device_lists(caelo_voxmap *m, int16_t *vox_out[3], int32_t **n_out, hipStream_t s);
 int kd_resolve(const caelo_voxmap *m, const float *pts, int pts_ld, int64_t k_max, const int32_t *n_key, uint64_t *bits, uint8_t *flags,
                hipStream_t s);
+int kd_resolve_many(int n, const caelo_voxmap *const *maps, const float *const *pts, int pts_ld, int64_t k_max, const int32_t *const *n_key,
+                    uint64_t *const *bits, uint8_t *const *flags, hipStream_t s);
 
 struct SuspectTables {
     unsigned long long *sp_keys, *sb_keys;

@@ -47,10 +47,25 @@ struct caelo_kd {
     char *base;
 };
 
+// Up to CAELO_FB_MAX maps behind ONE launch of each kd kernel (blockIdx.z = map): a redone frame is a chain of ~150 dependent quickselect
+// passes, a millisecond or two whatever the GPU has free -- eight frames' chains side by side cost what one does (round 6; the tie redo
+// of many frames used to issue the four kernels frame by frame on side streams: Engine.resolve_ties_many).
+struct caelo_kd_set {
+    caelo_kd k[CAELO_FB_MAX];
+    const float *pts[CAELO_FB_MAX];
+    const int32_t *n_key[CAELO_FB_MAX];
+    unsigned long long *bits[CAELO_FB_MAX];
+    uint8_t *flags[CAELO_FB_MAX];
+    int n, pts_ld;
+};
+static_assert(sizeof(caelo_kd_set) <= 3800, "caelo_kd_set must fit the kernel argument segment");
+
 namespace {
 
-__global__ void __launch_bounds__(256) k_kd_collect(const uint8_t *__restrict__ flags, int64_t k0, int64_t k_max, const int32_t *__restrict__ n_key,
-                                                    caelo_kd kd) {
+__global__ void __launch_bounds__(256) k_kd_collect(const caelo_kd_set S, int64_t k0, int64_t k_max) {
+    const caelo_kd &kd = S.k[blockIdx.z];
+    const uint8_t *__restrict__ flags = S.flags[blockIdx.z];
+    const int32_t *__restrict__ n_key = S.n_key[blockIdx.z];
     const int64_t pw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (key point of this chunk, scale)
     if (pw >= kd.k_cap * 3) return;
     const int64_t kp = k0 + pw / 3;
@@ -312,7 +327,8 @@ __device__ __forceinline__ void kd_build_levels(const caelo_kd_scale &T, const i
 
 // kd.state: [0..2] queue lengths | [4..6] 0 no tree, 1 built, 2 not built (a quickselect gave up / too many nodes: the canonical rule stays),
 // 3 upper levels built, subtrees pending | [8..10] a subtree gave up | [12..14] subtrees done | [16..18] list lengths
-__global__ void __launch_bounds__(KD_T) k_kd_build_top(caelo_kd kd) {
+__global__ void __launch_bounds__(KD_T) k_kd_build_top(const caelo_kd_set S_) {
+    const caelo_kd &kd = S_.k[blockIdx.z];
     const int sc = blockIdx.x;
     const caelo_kd_scale T = kd.s[sc];
     if (kd.state[sc] == 0 || kd.state[4 + sc] != 0) return;   // no tie-split patch of this scale / tree already built (or given up)
@@ -334,7 +350,8 @@ __global__ void __launch_bounds__(KD_T) k_kd_build_top(caelo_kd kd) {
     if (tid == 0) kd.state[4 + sc] = S.gave_up ? 2 : 3;
 }
 
-__global__ void __launch_bounds__(KD_TS) k_kd_build_sub(caelo_kd kd) {
+__global__ void __launch_bounds__(KD_TS) k_kd_build_sub(const caelo_kd_set S_) {
+    const caelo_kd &kd = S_.k[blockIdx.z];
     const int sc = blockIdx.y;
     const caelo_kd_scale T = kd.s[sc];
     if (kd.state[4 + sc] != 3) return;   // (stays 3 until the LAST subtree of this scale is done)
@@ -434,8 +451,12 @@ __device__ __forceinline__ void kd_heap_sift(int (&hd)[8], int (&hx)[8], int p, 
 }
 
 // One wavefront per tie-split patch: the walk and the heap operations are uniform; a leaf's distances are computed by all lanes.
-__global__ void __launch_bounds__(64) k_kd_query(caelo_kd kd, const float *__restrict__ pts, int pts_ld, unsigned long long *__restrict__ bits,
-                                                 uint8_t *__restrict__ flags) {
+__global__ void __launch_bounds__(64) k_kd_query(const caelo_kd_set S_) {
+    const caelo_kd &kd = S_.k[blockIdx.z];
+    const float *__restrict__ pts = S_.pts[blockIdx.z];
+    const int pts_ld = S_.pts_ld;
+    unsigned long long *__restrict__ bits = S_.bits[blockIdx.z];
+    uint8_t *__restrict__ flags = S_.flags[blockIdx.z];
     const int sc = blockIdx.y;
     const caelo_kd_scale T = kd.s[sc];
     const int cnt = min(kd.state[sc], (int)kd.k_cap);
@@ -617,17 +638,41 @@ int kd_begin_device_lists(caelo_voxmap *m, int16_t *vox_out[3], int32_t **n_out,
 // caelo_patches, after k_patches: the tie-split patches again, in the library's order
 int kd_resolve(const caelo_voxmap *m, const float *pts, int pts_ld, int64_t k_max, const int32_t *n_key, uint64_t *bits, uint8_t *flags,
                hipStream_t s) {
-    if (!m->kd || !m->kd_lists) return CAELO_OK;
-    caelo_kd kd = *m->kd;
-    for (int64_t k0 = 0; k0 < k_max; k0 += kd.k_cap) {   // (the queues hold k_cap key points: longer point lists go chunk by chunk)
-        CAELO_HIP(hipMemsetAsync(kd.state, 0, 12, s));   // queue lengths (the built flags stay)
-        k_kd_collect<<<(unsigned)((kd.k_cap * 3 + 255) / 256), 256, 0, s>>>(flags, k0, k_max, n_key, kd);
+    const caelo_voxmap *maps[1] = {m};
+    const float *ptss[1] = {pts};
+    const int32_t *nks[1] = {n_key};
+    uint64_t *bitss[1] = {bits};
+    uint8_t *flagss[1] = {flags};
+    return kd_resolve_many(1, maps, ptss, pts_ld, k_max, nks, bitss, flagss, s);
+}
+
+// the same for n maps (each with its own lists) behind one launch of each kernel; maps without lists are skipped
+int kd_resolve_many(int n, const caelo_voxmap *const *maps, const float *const *pts, int pts_ld, int64_t k_max, const int32_t *const *n_key,
+                    uint64_t *const *bits, uint8_t *const *flags, hipStream_t s) {
+    CAELO_REQUIRE(n >= 1 && n <= CAELO_FB_MAX, "kd_resolve_many: 1 .. 8 maps");
+    caelo_kd_set S = {};
+    int64_t cap = 0, k_cap = 0;
+    for (int i = 0; i < n; ++i) {
+        const caelo_voxmap *m = maps[i];
+        if (!m->kd || !m->kd_lists) continue;
+        S.k[S.n] = *m->kd;
+        S.pts[S.n] = pts[i]; S.n_key[S.n] = n_key[i]; S.bits[S.n] = (unsigned long long *)bits[i]; S.flags[S.n] = flags[i];
+        cap = m->kd->cap > cap ? m->kd->cap : cap;
+        CAELO_REQUIRE(k_cap == 0 || k_cap == m->kd->k_cap, "kd_resolve_many: maps of one set share the queue capacity");
+        k_cap = m->kd->k_cap;
+        ++S.n;
+    }
+    if (S.n == 0) return CAELO_OK;
+    S.pts_ld = pts_ld;
+    for (int64_t k0 = 0; k0 < k_max; k0 += k_cap) {   // (the queues hold k_cap key points: longer point lists go chunk by chunk)
+        for (int i = 0; i < S.n; ++i) CAELO_HIP(hipMemsetAsync(S.k[i].state, 0, 12, s));   // queue lengths (the built flags stay)
+        k_kd_collect<<<dim3((unsigned)((k_cap * 3 + 255) / 256), 1, S.n), 256, 0, s>>>(S, k0, k_max);
         CAELO_LAUNCH_CHECK();
-        k_kd_build_top<<<3, KD_T, 0, s>>>(kd);
+        k_kd_build_top<<<dim3(3, 1, S.n), KD_T, 0, s>>>(S);
         CAELO_LAUNCH_CHECK();
-        k_kd_build_sub<<<dim3(1u << kd_top_levels_of(kd.cap), 3), KD_TS, 0, s>>>(kd);
+        k_kd_build_sub<<<dim3(1u << kd_top_levels_of(cap), 3, S.n), KD_TS, 0, s>>>(S);
         CAELO_LAUNCH_CHECK();
-        k_kd_query<<<dim3((unsigned)kd.k_cap, 3), 64, 0, s>>>(kd, pts, pts_ld, (unsigned long long *)bits, flags);
+        k_kd_query<<<dim3((unsigned)k_cap, 3, S.n), 64, 0, s>>>(S);
         CAELO_LAUNCH_CHECK();
     }
     return CAELO_OK;

@@ -1171,6 +1171,19 @@ CAELO_API int caelo_patches(caelo_ctx *c, const caelo_voxmap *m, const float *pt
     return kd_resolve(m, pts, 3, k_max, n_key, bits, flags, caelo_stream(stream));   // tie-split patches in the library's order (kdorder.hip)
 }
 
+// caelo_patches for n maps / key point sets (n <= 8): the patch gathers one after the other, then the kd-tree redo of ALL of them behind
+// one launch of each kd kernel (kdorder.hip, kd_resolve_many) -- the tie redo of the frames of a chunk
+CAELO_API int caelo_patches_many(caelo_ctx *c, int n, const caelo_voxmap *const *maps, const float *const *pts, int64_t k_max,
+                                 const int32_t *const *n_key, uint64_t *const *bits, uint8_t *const *flags, int32_t *const *status, void *stream) {
+    CAELO_REQUIRE(c && maps && pts && n_key && bits && flags && status && n >= 1 && n <= CAELO_FB_MAX && k_max > 0, "caelo_patches_many: bad argument");
+    for (int i = 0; i < n; ++i) {
+        CAELO_REQUIRE(maps[i] && pts[i] && bits[i] && flags[i] && status[i], "caelo_patches_many: null entry");
+        const int rc = vox_patches_launch(maps[i], pts[i], 3, k_max, n_key[i], bits[i], flags[i], status[i], false, caelo_stream(stream));
+        if (rc) return rc;
+    }
+    return kd_resolve_many(n, maps, pts, 3, k_max, n_key, bits, flags, caelo_stream(stream));
+}
+
 // ------------------------------------------------------------------------------------------------
 // dense <-> packed patches (API parity with the reference's [K,16,16,16,1] f32 arrays)
 // ------------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CAELO_ABI_VERSION 5   /* 5: caelo_host_unbind_blas / _blas_probe / _bound_violations, caelo_host_random_sample, caelo_seqloader_*; 4: caelo_voxmap_export never waits for the device (a count above capacity is the overflow report), caelo_voxmap_order; 3: certificates, caelo_host_* */
+#define CAELO_ABI_VERSION 5   /* 5: caelo_host_unbind_blas / _blas_probe / _bound_violations, caelo_host_random_sample, caelo_seqloader_*, caelo_patches_many; 4: caelo_voxmap_export never waits for the device (a count above capacity is the overflow report), caelo_voxmap_order; 3: certificates, caelo_host_* */
 
 /* geometry fixed by the reference: SphericalRing.py:28-58, Voxel.py:15-52 */
 #define CAELO_RING_H 69
@@ -149,6 +149,11 @@ int caelo_voxmap_from_lists(caelo_ctx *ctx, caelo_voxmap *map, const int16_t *al
  * falls inside an equidistant class: kd-tree tie order dependent). */
 int caelo_patches(caelo_ctx *ctx, const caelo_voxmap *map, const float *pts, int64_t k_max, const int32_t *n_key,
                   uint64_t *bits, uint8_t *flags, int32_t *status, void *stream);
+/* The same for n <= 8 maps / key point sets (arrays of n HOST pointers to the device buffers of caelo_patches): the gathers one after the
+ * other, then the kd-tree redo of the tie-split patches of ALL of them behind one launch of each kd kernel -- the chain of a redo (a
+ * millisecond or two of dependent quickselect passes, Voxel.py:195-196 in scikit-learn's order) is paid once per set, not per frame. */
+int caelo_patches_many(caelo_ctx *ctx, int n, const caelo_voxmap *const *maps, const float *const *pts, int64_t k_max,
+                       const int32_t *const *n_key, uint64_t *const *bits, uint8_t *const *flags, int32_t *const *status, void *stream);
 /* dense <-> packed conversion for callers that want the reference's [K,16,16,16,1] f32 arrays */
 int caelo_unpack_patches(caelo_ctx *ctx, const uint64_t *bits, int64_t n_patches, float *dense, void *stream);
 int caelo_pack_patches(caelo_ctx *ctx, const float *dense, int64_t n_patches, uint64_t *bits, void *stream);
