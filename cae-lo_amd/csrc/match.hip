@@ -953,7 +953,7 @@ __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp(const caelo_pair_s
 // in which case the host half meets a level without bounds and evaluates it the long way -- still exact); otherwise blockIdx.y's level
 // (0.8 m, 1.6 m: both, the second is wasted when the first succeeds, and escalations are rare) gets its `hi_up` / `idx_up` exactly as
 // the first level got `hi` / `idx`.  The inlier counts of these levels are not kept (scratch): the host half derives them.
-#define RU_BLOCKS 8
+#define RU_BLOCKS 32   // (8 workgroups per level were tried for the sake of the launches that only look and leave: those took as long as before, 43 us on the pair stream, and a batch with a failing pair 4 x longer -- the failing_pairs leg fell from 17.5 k to 9.9 k frames/s)
 __global__ void __launch_bounds__(64 * RE_WAVES) k_ransac_hyp_up(const caelo_pair_set ps, int ld0, int ld1, int64_t k1_max) {
     const caelo_pair_dev &P = ps.p[blockIdx.z];
     caelo_ransac_cert *cert = P.cert;

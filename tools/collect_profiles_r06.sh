@@ -21,3 +21,6 @@ T=400 py $R/tools/pmc_live.py $O/pmc_live.json > /dev/null 2>&1
 ( THREADS="16 16" timeout 900 bash $R/tools/run_sequence_files_probe.sh 4541 2>&1 | grep -v amdgpu.ids | grep -E "wrote|frames/s|host seconds|loader threads" ) > $O/run_sequence_files_4541.txt
 rm -f $O/poses_kitti00_sized.txt
 ls -la $O
+# registers / LDS / scratch of every kernel (a device function that stops being inlined shows here first: DESIGN.md 6)
+( cd $R && for f in ring voxel encoder match icp export frame pipeline extend config5 dedup kdorder; do bash tools/kernel_resources.sh $f.hip 2>/dev/null | grep -v rocprim; done ) > $O/kernel_resources.txt 2>&1
+( cd $R && PROBE_LANES=1,4,8 timeout 300 python tools/ties_many_probe.py 64 96 2>&1 | grep -v amdgpu.ids | grep -E "tied|lanes|match_pose" ) > $O/ties_many_probe.txt
