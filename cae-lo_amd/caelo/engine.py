@@ -519,7 +519,7 @@ class SeqLoader:
             pass
 
 
-def _run_loaded(self, loader, b0, nb, prev=None, out=None, pairs=True, dist_channels=5, dedup=True, certify=True, ahead=4):
+def _run_loaded(self, loader, b0, nb, prev=None, out=None, pairs=True, dist_channels=5, dedup=True, certify=True, ahead=4, publish=True):
     """Batches [b0, b0 + nb) of a SeqLoader through the pipeline: a batch's scans AND draws go up behind ONE copy command (the loader's
     slot layout, mirrored on the device), the jobs are built column-wise for the whole call, and nothing here is per-frame Python.
     Paced like ``run_uploading`` (the copies go out before the thread waits for the encoder).  -> (FrameBatch, frames)."""
@@ -544,7 +544,9 @@ def _run_loaded(self, loader, b0, nb, prev=None, out=None, pairs=True, dist_chan
     if not getattr(eng, "_blas_bound", False) and certify:
         eng.host_blas()
         eng._blas_bound = True
+    tj0_ = time.perf_counter()
     jobs = self._jobs(pcs, np.zeros(k, np.int64), rnd, prev, out, pairs, dist_channels, False, dedup, certify, rnd_h if certify else None)
+    tj1_ = time.perf_counter()
     stream = eng.stream
     copy_h = C.c_void_p(copy.cuda_stream)
     arrived = [torch.cuda.Event() for _ in range(nb)]
@@ -587,11 +589,20 @@ def _run_loaded(self, loader, b0, nb, prev=None, out=None, pairs=True, dist_chan
             t3_ = time.perf_counter()
             tw[1] += t1_ - t0_; tw[2] += t2_ - t1_; tw[3] += t3_ - t2_
     finally:
+        tf0_ = time.perf_counter()
         rc = lib.caelo_pipeline_flush(self.h, stream)
         lib.caelo_pipeline_set_pace(self.h, pace)
     _ffi.check(rc)
-    self._publish_exact(out, k, certify, pairs)
-    self.last_loaded_times = dict(starved_s=tw[0], wait_arrival_s=tw[1], submit_s=tw[2], upload_and_pace_s=tw[3])
+    tf1_ = time.perf_counter()
+    if publish:
+        self._publish_exact(out, k, certify, pairs)
+    elif certify and pairs and k > 0:   # (the exact results stay on the host, where the caller reads them: out.exact)
+        has = getattr(out, "_has_pair", None)
+        st_ = out.exact[3][:k]
+        if (st_ == 2).any() or (has is not None and (st_[has[:k]] != 0).any()):
+            raise _ffi.CaeloError("pairs of frames %s came back without an exact result" % np.flatnonzero(st_ != 0).tolist()[:8])
+    self.last_loaded_times = dict(starved_s=tw[0], wait_arrival_s=tw[1], submit_s=tw[2], upload_and_pace_s=tw[3], jobs_s=tj1_ - tj0_,
+                                  flush_s=tf1_ - tf0_, publish_s=time.perf_counter() - tf1_)
     return out, k
 
 

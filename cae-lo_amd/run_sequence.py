@@ -236,7 +236,7 @@ def _parse_poses_fast(raw, k):
 
 
 def run_local_files(eng, files, lo, hi, seed_base, chunk, dist_channels, batch_frames, keep=None, strict_ties=True, tie_log=None, host_times=None,
-                    loader_threads=16, certify=True):
+                    loader_threads=16, certify=True, device_results=False):
     """run_local for scans that are FILES (round 6): the native loader (caelo_seqloader: pread into a pinned ring + the RANSAC draws,
     csrc/seqload.hip) works ahead on its own threads, a chunk of batches goes through Pipeline.run_loaded (one copy command per batch
     for scans and draws, jobs built column-wise), results come back through pinned buffers and are parsed as one record array.
@@ -252,8 +252,22 @@ def run_local_files(eng, files, lo, hi, seed_base, chunk, dist_channels, batch_f
     biggest = max(os.path.getsize(f_) for f_ in files[lo:hi]) // 16
     assert biggest <= eng.max_points, "a scan holds %d points, the engine was created for %d" % (biggest, eng.max_points)
     cap = min(int(eng.max_points), (int(biggest) + 1023) // 1024 * 1024)
-    loader = SeqLoader(eng, files[lo:hi], first_frame=lo, batch=B, seed_base=seed_base, threads=loader_threads, ring=7, cap=cap)
+    # (page-locking the ring takes tens of milliseconds: on a thread of its own, beside the allocation of the pipeline's buffers)
+    import threading
+    box = {}
+
+    def make_loader():
+        try:
+            box["loader"] = SeqLoader(eng, files[lo:hi], first_frame=lo, batch=B, seed_base=seed_base, threads=loader_threads, ring=7, cap=cap)
+        except BaseException as e:
+            box["error"] = e
+    th = threading.Thread(target=make_loader)
+    th.start()
     pipe = eng.pipeline(B)
+    th.join()
+    if "error" in box:
+        raise box["error"]
+    loader = box["loader"]
     import gc
     gc.collect()
     gc.freeze()
@@ -274,7 +288,7 @@ def run_local_files(eng, files, lo, hi, seed_base, chunk, dist_channels, batch_f
         if st.any():
             for v in st[st != 0]:
                 raise_status(int(v))
-        r, o, t, n = _parse_poses_fast(res_h.numpy(), k)
+        r, o, t, n = _parse_poses_fast(res_h if isinstance(res_h, np.ndarray) else res_h.numpy(), k)
         s_ = 0 if has_prev else 1
         rel.append(r[s_:]); ok.append(o[s_:]); thr.append(t[s_:]); nin.append(n[s_:])
         ht["parse"] += time.time() - t_
@@ -283,9 +297,16 @@ def run_local_files(eng, files, lo, hi, seed_base, chunk, dist_channels, batch_f
     for ci, b0 in enumerate(range(0, loader.n_batches, per_chunk)):
         nb = min(per_chunk, loader.n_batches - b0)
         t_ = time.time()
-        batch, k = pipe.run_loaded(loader, b0, nb, prev=prev, out=outs[ci % 2], dist_channels=dist_channels, certify=certify)
+        # certified runs: the exact results are written by the host half into host arrays (batch.exact) -- they are read THERE, not
+        # published to the device and copied back (publish=False: 51 ms of 0.40 s for 4 541 frames)
+        # (device_results -- the artefact writer reads masks and pair indices from the device tensors -- publishes them as before)
+        batch, k = pipe.run_loaded(loader, b0, nb, prev=prev, out=outs[ci % 2], dist_channels=dist_channels, certify=certify,
+                                   publish=device_results or not certify)
+        host_res = batch.exact[0][:k].copy().view(np.uint8).reshape(k, -1) if certify else None
         ht["pipeline"] += time.time() - t_
         ht["starved"] += pipe.last_loaded_times["starved_s"]
+        for k_, v_ in pipe.last_loaded_times.items():
+            ht["loaded_" + k_] = ht.get("loaded_" + k_, 0.0) + v_
         c0 = lo + b0 * B
         t_ = time.time()
         if strict_ties and bool((batch.flags[:k] & 2).any().item()):
@@ -302,11 +323,12 @@ def run_local_files(eng, files, lo, hi, seed_base, chunk, dist_channels, batch_f
                 dd_ = [torch.from_numpy(d_).to(eng.device) for d_ in dn_]
                 if certify:
                     rs_, ms_, xs_ = eng.match_pose_exact_many(pairs_, dd_, dn_)
-                    sel = torch.tensor(redo, device=eng.device)
-                    batch.result[sel] = torch.from_numpy(rs_.view(np.uint8).reshape(len(redo), -1).copy()).to(eng.device)
-                    batch.inlier_mask[sel] = torch.from_numpy(ms_).to(eng.device)
-                    for j, x_ in zip(redo, xs_):
-                        batch.pair_idx[j].copy_(x_)
+                    host_res[redo] = rs_.view(np.uint8).reshape(len(redo), -1)
+                    if device_results:
+                        sel = torch.tensor(redo, device=eng.device)
+                        batch.inlier_mask[sel] = torch.from_numpy(ms_).to(eng.device)
+                        for j, x_ in zip(redo, xs_):
+                            batch.pair_idx[j].copy_(x_)
                 else:
                     for j, (fa_, fb_), d_ in zip(redo, pairs_, dd_):
                         r_, m_, x_ = eng.match_pose(fa_, fb_, d_)
@@ -317,13 +339,14 @@ def run_local_files(eng, files, lo, hi, seed_base, chunk, dist_channels, batch_f
         res_h, st_h = back[ci % 3]
         with torch.cuda.stream(side):
             side.wait_event(done)
-            res_h[:k].copy_(batch.result[:k], non_blocking=True)
+            if not certify:
+                res_h[:k].copy_(batch.result[:k], non_blocking=True)
             st_h[:k].copy_(batch.status[:k], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(side)
         if pending is not None:
             collect(pending)
-        pending = (k, prev is not None, res_h, st_h, ev)
+        pending = (k, prev is not None, host_res if certify else res_h, st_h, ev)
         if first is None:
             first = FrameFeatures.from_rows(batch.rows[0].clone())      # (the chunk buffers are reused two chunks later)
         last_rows = batch.rows[k - 1].clone()
@@ -352,7 +375,7 @@ def main():
     ap.add_argument("--calib", help="calib_.txt (PoseEstimation.py:199-203) or KITTI calib.txt; identity if omitted")
     ap.add_argument("--out", default="poses_/00.txt")
     ap.add_argument("--seed-base", type=int, default=1000)
-    ap.add_argument("--chunk", type=int, default=240, help="frames resident on the GPU at a time")
+    ap.add_argument("--chunk", type=int, default=960, help="frames resident on the GPU at a time (the rows of a chunk: 0.26 MB per frame)")
     ap.add_argument("--dist-channels", type=int, default=5, choices=(3, 5), help="5 = demo mode, 3 = batch mode (SURVEY 8a-3')")
     ap.add_argument("--batch", type=int, default=8, help="frames per launch (caelo_pipeline)")
     ap.add_argument("--scene", default="boxes", choices=("boxes", "clutter"), help="synthetic scene (caelo.synth)")
@@ -452,7 +475,7 @@ def main():
     if args.scans and not args.python_loader:
         rel, ok, thr, nin, first, last = run_local_files(eng, files, lo, hi, args.seed_base, args.chunk, args.dist_channels,
                                                          args.batch, keep, strict_ties=not args.no_strict_ties, tie_log=tie_log, host_times=host_times,
-                                                         loader_threads=args.loader_threads, certify=not args.no_certify)
+                                                         loader_threads=args.loader_threads, certify=not args.no_certify, device_results=args.save_artifacts)
     else:
         rel, ok, thr, nin, first, last = run_local(eng, load, lo, hi, args.seed_base, args.chunk, args.dist_channels,
                                                    args.batch, keep, strict_ties=not args.no_strict_ties, tie_log=tie_log, host_times=host_times,
@@ -488,6 +511,8 @@ def main():
         print("rank 0 host seconds -- loader thread: reading / synthesising scans %.2f, pinning %.2f, RANSAC draws %.2f; issuing thread: "
               "pipeline creation + heap freeze %.2f, waiting for the loader (%d threads) %.2f, pipeline calls (uploads paced, %d frames) %.2f, tie check + read-back issue %.2f, "
               "parsing results %.2f (the chunk loop as a whole %.2f)" % (h["load"], h["pin"], h["draws"], h["setup"], args.loader_threads, h["starved"], hi - lo, h["pipeline"], h["ties"], h["parse"], h.get("loop", 0.0)))
+        if any(k_.startswith("loaded_") for k_ in h):
+            print("        inside the pipeline calls (Pipeline.run_loaded): " + ", ".join("%s %.3f" % (k_[7:], v_) for k_, v_ in sorted(h.items()) if k_.startswith("loaded_")))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

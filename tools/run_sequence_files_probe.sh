@@ -17,5 +17,5 @@ def wr(i): scans[walk(i)].tofile("/tmp/velo/%06d.bin" % i)
 with ThreadPoolExecutor(16) as ex: list(ex.map(wr, range($N)))
 print("wrote", $N)
 P
-for thr in ${THREADS:-16 16 32 64}; do echo "loader threads $thr"; ( cd $R && timeout 600 python cae-lo_amd/run_sequence.py --scans /tmp/velo --chunk ${CHUNK:-240} --loader-threads $thr --out /tmp/poses_files.txt 2>&1 | tail -2 ); done
+for thr in ${THREADS:-16 16 32 64}; do echo "loader threads $thr"; ( cd $R && timeout 600 python cae-lo_amd/run_sequence.py --scans /tmp/velo --chunk ${CHUNK:-960} --loader-threads $thr --out /tmp/poses_files.txt 2>&1 | tail -3 ); done
 rm -rf /tmp/velo
