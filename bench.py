@@ -503,7 +503,7 @@ def main():
                     d_.copy_(flat[off:off + (1 << 22)], non_blocking=True)
                 sc_.synchronize()
             print("staging block, 16 MB at element %d: %.1f GB/s" % (off, 4 * (1 << 24) / (time.perf_counter() - t_) / 1e9), file=sys.stderr)
-        print("timed region: %.2f ms (run_with_uploads returned at %.2f, finish_ranks at %.2f) for %d frames  %s" % (1e3 * dt, 1e3 * t_ru, 1e3 * t_fr, K, {k_: round(v_, 1) for k_, v_ in pipe.last_upload_times.items()}), pipe.cert_stats(), file=sys.stderr)
+        print("timed region: %.2f ms (run_with_uploads returned at %.2f, finish_ranks at %.2f) for %d frames  %s" % (1e3 * dt, 1e3 * t_ru, 1e3 * t_fr, K, {k_: (round(v_, 1) if isinstance(v_, float) else v_) for k_, v_ in pipe.last_upload_times.items()}), pipe.cert_stats(), file=sys.stderr)
     host = pipe.stats()
     cert = pipe.cert_stats() if (CERTIFY and not args.extract_only) else None
     # sanity: every pose solved (not timed)

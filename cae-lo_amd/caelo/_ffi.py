@@ -138,6 +138,7 @@ SIGNATURES = [
     ("caelo_pipeline_set_pace", c_int, [c_vp, c_int]),
     ("caelo_pipeline_get_pace", c_int, [c_vp]),
     ("caelo_upload_many", c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
+    ("caelo_pipeline_run_uploading", c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
     ("caelo_host_random_sample", c_int, [C.c_uint32, c_i64, c_vp]),
     ("caelo_seqloader_slot_bytes", c_i64, [c_int, c_i64]),
     ("caelo_seqloader_create", c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_i64, c_vp, c_vp, c_int, c_i64, c_int, c_vp]),

@@ -434,6 +434,19 @@ class Pipeline:
                         bufs[b % slots][i % B][:host_scans[i].shape[0]].copy_(host_scans[i], non_blocking=True)
             arrived[b].record(copy)
 
+        if pitch:
+            # one copy command per batch: the whole paced loop natively (caelo_pipeline_run_uploading, round 6 -- from Python the
+            # interpreter's time between the pacing wait and the next batch's front launches cost the mode 20 % of its rate)
+            dstb, srcb = np.ascontiguousarray(dst_p[::B]), np.ascontiguousarray(src_p[::B])
+            tns = (C.c_int64 * 4)()
+            tf0_ = time.perf_counter()
+            _ffi.check(lib.caelo_pipeline_run_uploading(self.h, C.c_void_p(jobs.ctypes.data), k, nb, None, 0, C.c_void_p(dstb.ctypes.data),
+                                                        C.c_void_p(srcb.ctypes.data), C.c_void_p(one_n.ctypes.data), slots, None, 0, int(ahead), copy_h, stream, tns))
+            tf1_ = time.perf_counter()
+            self._publish_exact(out, k, certify, pairs)
+            self.last_upload_times = dict(wait_arrival_ms=tns[1] / 1e6, submit_ms=tns[2] / 1e6, upload_issue_and_wait_encoded_ms=tns[3] / 1e6, native_loop_ms=1e3 * (tf1_ - tf0_),
+                                          publish_ms=1e3 * (time.perf_counter() - tf1_), prepare_ms=1e3 * (tf0_ - te0_))
+            return out
         _ffi.check(lib.caelo_pipeline_expect(self.h, 0))   # full batches, the remainder last: the slots are laid out that way
         copy.wait_stream(torch.cuda.current_stream(eng.device))   # (an earlier run may still read the slots)
         pace = self.pace
@@ -456,7 +469,7 @@ class Pipeline:
                     upload(b + ahead)                    # slot of batch b - 2: encoded (hence read) before batch b was issued
                 t3_ = time.perf_counter()
                 if hi - lo == B:
-                    self.sync_encoded(1)                 # (a partial last batch is only issued by the flush)
+                    self.sync_encoded(1)       # (a partial last batch is only issued by the flush)
                 t4_ = time.perf_counter()
                 tw[0] += t1_ - t0_; tw[1] += t2_ - t1_; tw[2] += t3_ - t2_; tw[3] += t4_ - t3_
             self.last_upload_times = dict(wait_arrival_ms=1e3 * tw[0], submit_ms=1e3 * tw[1], upload_issue_ms=1e3 * tw[2], wait_encoded_ms=1e3 * tw[3])
@@ -548,51 +561,14 @@ def _run_loaded(self, loader, b0, nb, prev=None, out=None, pairs=True, dist_chan
     jobs = self._jobs(pcs, np.zeros(k, np.int64), rnd, prev, out, pairs, dist_channels, False, dedup, certify, rnd_h if certify else None)
     tj1_ = time.perf_counter()
     stream = eng.stream
-    copy_h = C.c_void_p(copy.cuda_stream)
-    arrived = [torch.cuda.Event() for _ in range(nb)]
-    ring_p = loader.ring_h.data_ptr()
-    dst1, src1, n1 = np.zeros(1, np.uint64), np.zeros(1, np.uint64), np.zeros(1, np.uint64)
-    n1[0] = loader.slot_bytes
-    tw = [0.0, 0.0, 0.0, 0.0]
-
-    def upload(b):
-        t0_ = time.perf_counter()
-        slot, npts = loader.wait(b0 + b)                  # (blocks while the loader is behind: "starved")
-        tw[0] += time.perf_counter() - t0_
-        lo, hi = b * B, min(k, (b + 1) * B)
-        jobs["n"][lo:hi] = npts[:hi - lo]
-        dst1[0] = dslots[(b0 + b) % slots].data_ptr()
-        src1[0] = ring_p + slot * loader.slot_bytes
-        _ffi.check(lib.caelo_upload_many(dst1.ctypes.data, src1.ctypes.data, n1.ctypes.data, 1, copy_h))
-        arrived[b].record(copy)
-
-    _ffi.check(lib.caelo_pipeline_expect(self.h, 0))
-    copy.wait_stream(torch.cuda.current_stream(eng.device))
-    pace = self.pace
-    _ffi.check(lib.caelo_pipeline_set_pace(self.h, -1))
-    _ffi.check(lib.caelo_pipeline_begin(self.h, stream))
-    try:
-        for b in range(min(ahead, nb)):
-            upload(b)
-        for b in range(nb):
-            t0_ = time.perf_counter()
-            arrived[b].synchronize()
-            loader.release(b0 + b)                        # the copy is through: the loader may refill the slot
-            t1_ = time.perf_counter()
-            lo, hi = b * B, min(k, (b + 1) * B)
-            _ffi.check(lib.caelo_pipeline_submit_many(self.h, jobs[lo:hi].ctypes.data, hi - lo))
-            t2_ = time.perf_counter()
-            if b + ahead < nb:
-                upload(b + ahead)
-            if hi - lo == B:
-                self.sync_encoded(1)
-            t3_ = time.perf_counter()
-            tw[1] += t1_ - t0_; tw[2] += t2_ - t1_; tw[3] += t3_ - t2_
-    finally:
-        tf0_ = time.perf_counter()
-        rc = lib.caelo_pipeline_flush(self.h, stream)
-        lib.caelo_pipeline_set_pace(self.h, pace)
-    _ffi.check(rc)
+    # the whole paced loop natively (caelo_pipeline_run_uploading: wait for a batch's arrival, submit it, queue the copy `ahead` further
+    # on, stay one batch behind the encoder) -- from Python the ~60 us between the pacing wait and the next front launches cost 20 %
+    dst = (C.c_void_p * slots)(*[d.data_ptr() for d in dslots])
+    tns = (C.c_int64 * 4)()
+    tf0_ = time.perf_counter()
+    _ffi.check(lib.caelo_pipeline_run_uploading(self.h, C.c_void_p(jobs.ctypes.data), k, nb, loader.h, int(b0), dst, None, None, slots,
+                                                C.c_void_p(loader.ring_h.data_ptr()), loader.slot_bytes, int(ahead), C.c_void_p(copy.cuda_stream), stream, tns))
+    tw = [tns[0] / 1e9, tns[1] / 1e9, tns[2] / 1e9, tns[3] / 1e9]
     tf1_ = time.perf_counter()
     if publish:
         self._publish_exact(out, k, certify, pairs)

@@ -67,6 +67,7 @@ struct caelo_pipeline {
     // while a wait on its previous record may still sit in a queue
     static constexpr int EXT_RING = 16;
     hipEvent_t ext_in[EXT_RING] = {nullptr}, ext_out[EXT_RING] = {nullptr}, ext_enc[EXT_RING] = {nullptr};
+    std::vector<hipEvent_t> up_arrived;   // caelo_pipeline_run_uploading: a batch's scans are in device memory
     unsigned n_ext_in = 0, n_ext_out = 0, n_ext_enc = 0;
     // host state
     std::vector<caelo_frame_job> pending;
@@ -459,6 +460,7 @@ CAELO_API void caelo_pipeline_destroy(caelo_pipeline *p) {
     if (p->begun) (void)hipEventDestroy(p->begun);
     for (hipEvent_t e : p->joined)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->up_arrived) (void)hipEventDestroy(e);
     for (hipEvent_t e : {p->vox_fork, p->vox_join})
         if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < caelo_pipeline::EXT_RING; ++i)
@@ -618,6 +620,78 @@ CAELO_API int caelo_upload_many(void *const *dst, const void *const *src, const 
         if (bytes[i]) CAELO_HIP(hipMemcpyAsync(dst[i], src[i], bytes[i], hipMemcpyHostToDevice, caelo_stream(stream)));
     }
     return CAELO_OK;
+}
+
+// The loop of the upload modes in native code (round 6).  Pipeline.run_uploading / run_loaded paced themselves from Python: wait for a
+// batch's scans, submit it, queue the copy of the batch `ahead` further on, wait for the encoder of the batch before -- and between
+// that wait and the next batch's front launches sat ~60 us of interpreter (event objects, slices, ctypes), every one of them a
+// microsecond of the batch (the front stream started 81 us behind the encoder's stage 1 instead of 14: 15-16 k frames/s with uploads
+// against 19.9 k resident, profiles/r06_upload_native.txt).  One copy command per batch: batch b of the call (jobs [b * batch, ...)) goes
+// from src[b] to dst[b], bytes[b] -- or, with a loader (caelo_seqloader), from its ring slot to dev_slots[(b0 + b) % n_slots], the
+// point counts of the batch's jobs filled in from the loader.  Between caelo_pipeline_begin and the flush, both done here.
+CAELO_API int caelo_pipeline_run_uploading(caelo_pipeline *p, caelo_frame_job *jobs, int64_t k, int64_t nb, caelo_seqloader *loader, int64_t b0,
+                                           void *const *dst, const void *const *src, const size_t *bytes, int n_slots, const void *ring_host,
+                                           int64_t slot_bytes, int ahead, void *copy_stream, void *stream, int64_t *times_ns_host) {
+    CAELO_REQUIRE(p && jobs && k > 0 && nb > 0 && dst && ahead >= 1 && copy_stream, "caelo_pipeline_run_uploading: bad argument");
+    CAELO_REQUIRE(loader ? (n_slots >= ahead + 2 && ring_host && slot_bytes > 0) : (src && bytes), "caelo_pipeline_run_uploading: bad copy description");
+    CAELO_REQUIRE((k + p->batch - 1) / p->batch == nb, "caelo_pipeline_run_uploading: k frames do not make nb batches");
+    const int B = p->batch;
+    hipStream_t copy = caelo_stream(copy_stream);
+    const int n_ev = ahead + 2;
+    while ((int)p->up_arrived.size() < n_ev) {
+        hipEvent_t e;
+        CAELO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        p->up_arrived.push_back(e);
+    }
+    int64_t tw[4] = {0, 0, 0, 0};
+    auto upload = [&](int64_t b) -> int {
+        const int64_t lo = b * B, hi = lo + B < k ? lo + B : k;
+        void *d = dst[loader ? (b0 + b) % n_slots : b];
+        const void *sp;
+        size_t nbytes;
+        if (loader) {
+            int32_t slot = 0;
+            int64_t npts[CAELO_FB_MAX];
+            const int64_t t0 = now_ns();
+            const int rc = caelo_seqloader_wait(loader, b0 + b, &slot, npts);
+            tw[0] += now_ns() - t0;
+            if (rc) return rc;
+            for (int64_t i = lo; i < hi; ++i) jobs[i].n = npts[i - lo];
+            sp = (const char *)ring_host + (size_t)slot * (size_t)slot_bytes;
+            nbytes = (size_t)slot_bytes;
+        } else {
+            sp = src[b];
+            nbytes = bytes[b];
+        }
+        if (nbytes) CAELO_HIP(hipMemcpyAsync(d, sp, nbytes, hipMemcpyHostToDevice, copy));
+        CAELO_HIP(hipEventRecord(p->up_arrived[(size_t)(b % n_ev)], copy));
+        return CAELO_OK;
+    };
+    int rc = caelo_pipeline_expect(p, 0);   // full batches, the remainder last: the slots are laid out that way
+    if (rc) return rc;
+    const int pace = p->pace;
+    p->pace = -1;                            // this loop paces itself: the copies go out BEFORE the thread waits
+    rc = caelo_pipeline_begin(p, stream);
+    if (rc == CAELO_OK && hipStreamWaitEvent(copy, p->begun, 0) != hipSuccess) rc = CAELO_ERR_HIP;   // (an earlier run may still read the slots)
+    for (int64_t b = 0; rc == CAELO_OK && b < (ahead < nb ? ahead : nb); ++b) rc = upload(b);
+    for (int64_t b = 0; rc == CAELO_OK && b < nb; ++b) {
+        const int64_t lo = b * B, hi = lo + B < k ? lo + B : k;
+        int64_t t0 = now_ns();
+        if (hipEventSynchronize(p->up_arrived[(size_t)(b % n_ev)]) != hipSuccess) { caelo_set_error("caelo_pipeline_run_uploading: a copy failed"); rc = CAELO_ERR_HIP; break; }
+        if (loader && (rc = caelo_seqloader_release(loader, b0 + b))) break;   // the copy is through: the loader may refill the slot
+        int64_t t1 = now_ns();
+        tw[1] += t1 - t0;
+        if ((rc = caelo_pipeline_submit_many(p, jobs + lo, hi - lo))) break;
+        t0 = now_ns();
+        tw[2] += t0 - t1;
+        if (b + ahead < nb && (rc = upload(b + ahead))) break;
+        if (hi - lo == B && (rc = caelo_pipeline_sync_encoded(p, 1))) break;   // (a partial last batch is only issued by the flush)
+        tw[3] += now_ns() - t0;
+    }
+    const int rc2 = caelo_pipeline_flush(p, stream);
+    p->pace = pace;
+    if (times_ns_host) for (int i = 0; i < 4; ++i) times_ns_host[i] = tw[i];   // waiting for the loader, for arrivals, submitting, copy issue + pacing
+    return rc ? rc : rc2;
 }
 
 CAELO_API int caelo_pipeline_set_pace(caelo_pipeline *p, int lag) {

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CAELO_ABI_VERSION 5   /* 5: caelo_host_unbind_blas / _blas_probe / _bound_violations, caelo_host_random_sample, caelo_seqloader_*, caelo_patches_many; 4: caelo_voxmap_export never waits for the device (a count above capacity is the overflow report), caelo_voxmap_order; 3: certificates, caelo_host_* */
+#define CAELO_ABI_VERSION 5   /* 5: caelo_host_unbind_blas / _blas_probe / _bound_violations, caelo_host_random_sample, caelo_seqloader_*, caelo_patches_many, caelo_pipeline_run_uploading; 4: caelo_voxmap_export never waits for the device (a count above capacity is the overflow report), caelo_voxmap_order; 3: certificates, caelo_host_* */
 
 /* geometry fixed by the reference: SphericalRing.py:28-58, Voxel.py:15-52 */
 #define CAELO_RING_H 69
@@ -452,6 +452,18 @@ int caelo_pipeline_get_pace(const caelo_pipeline *p);   /* the pacing in effect 
  * PoseEstimation.py:214-245): dst[i] <- src[i], bytes[i] each, asynchronous like hipMemcpyAsync.  The pipeline does not take part --
  * the caller orders the copies against it (caelo_pipeline_wait_stream / an event of its own / caelo_pipeline_sync_encoded). */
 int caelo_upload_many(void *const *dst, const void *const *src, const size_t *bytes, int n, void *stream);
+/* A whole run of the upload mode behind ONE call: jobs [k] (in nb batches of the pipeline's batch size, the remainder last) whose
+ * scans arrive by ONE copy command per batch on `copy_stream`, `ahead` batches ahead of the batch being issued; the calling thread waits
+ * for a batch's arrival, submits it, queues the next copy and paces itself one batch behind the encoder -- natively: the interpreter's
+ * ~60 us between that wait and the next batch's front launches were 20 % of the rate.  Includes caelo_pipeline_begin and the flush.
+ * Without a loader: batch b is copied from src[b] to dst[b], bytes[b] (host arrays of nb entries).  With one (caelo_seqloader, below):
+ * batch b0 + b comes from its ring slot (ring_host, slot_bytes) into dst[(b0 + b) % n_slots] (n_slots >= ahead + 2 device slots of
+ * slot_bytes), and the point counts of its jobs (job.n) are filled in from the loader, which gets its slot back as soon as the copy is
+ * through.  times_ns_host (nullable) [4]: waiting for the loader / for arrivals, submitting, copy issue + pacing. */
+struct caelo_seqloader;
+int caelo_pipeline_run_uploading(caelo_pipeline *pipe, caelo_frame_job *jobs, int64_t k, int64_t nb, struct caelo_seqloader *loader, int64_t b0,
+                                 void *const *dst, const void *const *src, const size_t *bytes, int n_slots, const void *ring_host,
+                                 int64_t slot_bytes, int ahead, void *copy_stream, void *stream, int64_t *times_ns_host);
 
 /* ---- a sequence from files (PoseEstimation.py:173-245: the generator process that prepares frame i + 1 while frame i is matched) ----
  * caelo_host_random_sample: numpy.random.RandomState(seed).random_sample(n) bit for bit (MT19937, init_genrand seeding, 53-bit doubles):
