@@ -28,14 +28,10 @@ for rep in range(3):
         vm, st = eng.voxelize(pcs[q], eng.voxmap(max(eng.max_points, pcs[q].shape[0]), slot=10 + q)); maps.append(vm); sts.append(st)
     e1 = ev()
     for q in range(n):
-        fl = ffs[q].flags.cpu().numpy() if rep == 0 else None
         eng.voxmap_order(maps[q], 7)
         gpts[q].copy_(ffs[q].key_pts)
     e2 = ev()
     arr = lambda xs: (C.c_void_p * n)(*xs)
-    # the gathers alone, then gathers + kd
-    for q in range(n):
-        eng.patches(eng.voxelize_fast(pcs[q], eng.voxmap(max(eng.max_points, pcs[q].shape[0]), slot=30)), gpts[q].contiguous()) if False else None
     _ffi.check(eng.lib.caelo_patches_many(eng.ctx, n, arr([m.h for m in maps]), arr([gpts[q].data_ptr() for q in range(n)]), MAX_K,
                                           arr([ffs[q].n_key.data_ptr() for q in range(n)]), arr([gbits[q].data_ptr() for q in range(n)]),
                                           arr([gflags[q].data_ptr() for q in range(n)]), arr([st.data_ptr() for st in sts]), eng.stream))
