@@ -313,7 +313,7 @@ static int64_t lower_bound_u64(const uint64_t *a, int64_t n, uint64_t key) {
  * compares the tree's index array and every truncated patch with the library's own).  Restated from the library's
  * documented algorithm and validated against it (it is a third-party dependency, not part of /root/reference):
  *   fit     'auto' -> kd_tree iff n_samples // 2 > n_neighbors, i.e. n >= 994; otherwise brute force, whose tie order is
- *           NumPy's argpartition (introselect) -- NOT restated: such patches keep the canonical rule and flag bit 2.
+ *           NumPy's argpartition (introselect), restated further down (orc_brute_query).
  *   build   leaf_size 30; n_levels = int(log2(max(1, (n - 1) / 30)) + 1), n_nodes = 2^n_levels - 1; node i owns
  *           idx[start, end); a node with children 2i+1, 2i+2 splits on the dimension of largest spread (first of equals)
  *           at n / 2 by a quickselect whose partition is Lomuto's with the LAST element as pivot (strict <) -- the
@@ -445,10 +445,117 @@ ORC_EXPORT void orc_kdtree_query(const int16_t *vox, int64_t n, const int32_t *q
     kd_free(t);
 }
 
+/* ---- the same cut on a list too short for the kd-tree (496 <= n < 994: `auto` = brute force) -------------------------------
+ * scikit-learn 0.24.2 NearestNeighbors.kneighbors, brute branch: squared euclidean distances of the query to every list entry
+ * (euclidean_distances(squared=True): XX + YY - 2 X.Y^T in float64 -- voxel indices are small integers, so every term and the
+ * sum are exact: the row IS the integer squared distances, in list order), then `np.argpartition(dist, 495, axis=1)[:, :496]`.
+ * The later sort by distance only reorders the 496; the patch is a SET.  Which members of the cut class are among the first
+ * 496 is decided by NumPy's argpartition = introselect on the index array (NumPy 1.18 .. 1.26: npysort/selection: median of
+ * three with the 3-lowest moved to low + 1, unguarded Hoare partition, median of medians of five when 2 * msb(n) partitions
+ * made no end of it, selection sort for kth - low < 3).  A third-party dependency, not part of /root/reference: restated from
+ * its algorithm and pinned by tools/make_goldens.py against the library itself (np.argpartition of NumPy 1.26.4 on tie-heavy
+ * rows, and scikit-learn's brute kneighbors on the truncation fixtures); tests/golden/argpartition_rows.npz holds the vectors.
+ * (NumPy >= 2.0 on AVX-512 hosts selects with another algorithm: the contract here is the reference's NumPy.) */
+#define ISEL_SWAP(a, b) do { const int32_t t_ = ts[a]; ts[a] = ts[b]; ts[b] = t_; } while (0)
+#define ISEL_V(i) v[ts[i]]
+static void isel_dumb(const int64_t *v, int32_t *ts, int64_t num, int64_t kth) {
+    for (int64_t i = 0; i <= kth; ++i) {
+        int64_t minidx = i, minval = ISEL_V(i);
+        for (int64_t k = i + 1; k < num; ++k)
+            if (ISEL_V(k) < minval) { minidx = k; minval = ISEL_V(k); }
+        ISEL_SWAP(i, minidx);
+    }
+}
+static int64_t isel_median5(const int64_t *v, int32_t *ts) {
+    if (ISEL_V(1) < ISEL_V(0)) ISEL_SWAP(1, 0);
+    if (ISEL_V(4) < ISEL_V(3)) ISEL_SWAP(4, 3);
+    if (ISEL_V(3) < ISEL_V(0)) ISEL_SWAP(3, 0);
+    if (ISEL_V(4) < ISEL_V(1)) ISEL_SWAP(4, 1);
+    if (ISEL_V(2) < ISEL_V(1)) ISEL_SWAP(2, 1);
+    if (ISEL_V(3) < ISEL_V(2)) return ISEL_V(3) < ISEL_V(1) ? 1 : 3;
+    return 2;
+}
+static void isel_select(const int64_t *v, int32_t *ts, int64_t num, int64_t kth);
+static int64_t isel_mom_calls = 0;   /* test coverage only: how often the median-of-medians fallback ran */
+ORC_EXPORT int64_t orc_argpartition_fallbacks(void) { return isel_mom_calls; }
+static int64_t isel_median_of_median5(const int64_t *v, int32_t *ts, int64_t num) {
+    const int64_t nmed = num / 5;
+#pragma omp atomic
+    ++isel_mom_calls;
+    for (int64_t i = 0, subleft = 0; i < nmed; ++i, subleft += 5) {
+        const int64_t m = isel_median5(v, ts + subleft);
+        ISEL_SWAP(subleft + m, i);
+    }
+    if (nmed > 2) isel_select(v, ts, nmed, nmed / 2);
+    return nmed / 2;
+}
+/* one call on a fresh pivot stack (argpartition gives every row its own): the stack is written, never read -- left out */
+static void isel_select(const int64_t *v, int32_t *ts, int64_t num, int64_t kth) {
+    int64_t low = 0, high = num - 1;
+    if (kth - low < 3) { isel_dumb(v, ts + low, high - low + 1, kth - low); return; }
+    /* (the "kth == num - 1" shortcut exists for floating point rows only to find NaNs; it is a full scan for the maximum) */
+    if (kth == num - 1) {
+        int64_t maxidx = low, maxval = ISEL_V(low);
+        for (int64_t k = low + 1; k < num; ++k)
+            if (!(ISEL_V(k) < maxval)) { maxidx = k; maxval = ISEL_V(k); }
+        ISEL_SWAP(kth, maxidx);
+        return;
+    }
+    int depth_limit = 0;
+    for (uint64_t n_ = (uint64_t)num; n_ >>= 1;) ++depth_limit;
+    depth_limit *= 2;
+    for (; low + 1 < high;) {
+        int64_t ll = low + 1, hh = high;
+        if (depth_limit > 0 || hh - ll < 5) {
+            const int64_t mid = low + (high - low) / 2;
+            if (ISEL_V(high) < ISEL_V(mid)) ISEL_SWAP(high, mid);
+            if (ISEL_V(high) < ISEL_V(low)) ISEL_SWAP(high, low);
+            if (ISEL_V(low) < ISEL_V(mid)) ISEL_SWAP(low, mid);   /* the median to low */
+            ISEL_SWAP(mid, low + 1);                              /* the 3-lowest to low + 1 */
+        } else {
+            const int64_t mid = ll + isel_median_of_median5(v, ts + ll, hh - ll);
+            ISEL_SWAP(mid, low);
+            --ll; ++hh;
+        }
+        --depth_limit;
+        const int64_t pivot = ISEL_V(low);
+        for (;;) {
+            do ++ll; while (ISEL_V(ll) < pivot);
+            do --hh; while (pivot < ISEL_V(hh));
+            if (hh < ll) break;
+            ISEL_SWAP(hh, ll);
+        }
+        ISEL_SWAP(low, hh);
+        if (hh >= kth) high = hh - 1;
+        if (hh <= kth) low = ll;
+    }
+    if (high == low + 1 && ISEL_V(high) < ISEL_V(low)) ISEL_SWAP(high, low);
+}
+/* np.argpartition(v, kth) of one row of integers (as float64 in the library: the same order): idx_out [num] */
+ORC_EXPORT void orc_argpartition(const int64_t *v, int64_t num, int64_t kth, int32_t *idx_out) {
+    for (int64_t i = 0; i < num; ++i) idx_out[i] = (int32_t)i;
+    isel_select(v, idx_out, num, kth);
+}
+/* the brute branch for queries q [nq][3]: out [nq][496] = argpartition(dist row, 495)[:496] (unsorted: a set) */
+ORC_EXPORT void orc_brute_query(const int16_t *vox, int64_t n, const int32_t *q, int64_t nq, int32_t *out) {
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t i = 0; i < nq; ++i) {
+        int64_t *d = (int64_t *)malloc(sizeof(int64_t) * n);
+        int32_t *ts = (int32_t *)malloc(sizeof(int32_t) * n);
+        for (int64_t j = 0; j < n; ++j) {
+            const int64_t dx = vox[3 * j] - q[3 * i], dy = vox[3 * j + 1] - q[3 * i + 1], dz = vox[3 * j + 2] - q[3 * i + 2];
+            d[j] = dx * dx + dy * dy + dz * dz;
+        }
+        orc_argpartition(d, n, KD_K - 1, ts);
+        memcpy(out + KD_K * i, ts, sizeof(int32_t) * KD_K);
+        free(d); free(ts);
+    }
+}
+
 /* flags per patch: 1 = truncated (an in-window voxel lost to the 496-nearest cut); 2 = the cut splits a class of equidistant
- * voxels that has in-window members AND the list is too short for scikit-learn's kd-tree (n < 994: brute force, NumPy's
- * argpartition order -- not restated): canonical rule (ascending (x, y, z)), may differ from the reference; 4 = such a split
- * resolved in scikit-learn's kd-tree order: equal to the reference. */
+ * voxels that has in-window members and the patch is still on the canonical rule (ascending (x, y, z)) -- never left set by this
+ * function; 4 = such a split resolved in the library's own order (scikit-learn's kd-tree from 994 voxels on, NumPy's argpartition
+ * below): equal to the reference. */
 ORC_EXPORT int orc_patches(const float *pts, int64_t k, const int16_t *vox, int64_t nvox, int scale,
                            uint64_t *bits, uint8_t *flags) {
     if (nvox < 496) return -1;
@@ -532,19 +639,21 @@ ORC_EXPORT int orc_patches(const float *pts, int64_t k, const int16_t *vox, int6
         flags[p] = fl;
     }
     free(keys);
-    /* ---- tie-ambiguous patches in the library's own order (n >= 994: 'auto' picks the kd-tree) */
-    if (nvox / 2 > KD_K) {
+    /* ---- tie-ambiguous patches in the library's own order (n >= 994: 'auto' picks the kd-tree; below: brute force) */
+    {
         int any = 0;
         for (int64_t p = 0; p < k; ++p) any |= flags[p] & 2;
         if (any) {
-            orc_kdtree_t *t = kd_build(vox, nvox);
+            const int tree = nvox / 2 > KD_K;
+            orc_kdtree_t *t = tree ? kd_build(vox, nvox) : NULL;
 #pragma omp parallel for schedule(dynamic, 1)
             for (int64_t p = 0; p < k; ++p) {
                 if (!(flags[p] & 2)) continue;
                 const int q[3] = {(int)(((double)pts[3 * p] + VIS_L) / vs), (int)(((double)pts[3 * p + 1] + VIS_W) / vs),
                                   (int)(((double)pts[3 * p + 2] + VIS_H) / vs)};
                 int32_t nb[KD_K];
-                kd_query(t, q, nb);
+                if (tree) kd_query(t, q, nb);
+                else { const int32_t q32[3] = {q[0], q[1], q[2]}; orc_brute_query(vox, nvox, q32, 1, nb); }
                 uint64_t *w = bits + p * 64; memset(w, 0, 64 * sizeof(uint64_t));
                 for (int i = 0; i < KD_K; ++i) {
                     const int dx = vox[3 * (int64_t)nb[i]] - q[0], dy = vox[3 * (int64_t)nb[i] + 1] - q[1], dz = vox[3 * (int64_t)nb[i] + 2] - q[2];
@@ -555,7 +664,7 @@ ORC_EXPORT int orc_patches(const float *pts, int64_t k, const int16_t *vox, int6
                 }
                 flags[p] = (uint8_t)((flags[p] & ~2) | 4);
             }
-            kd_free(t);
+            if (t) kd_free(t);
         }
     }
     return 0;

@@ -44,6 +44,7 @@ def lib():
         build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_argpartition_fallbacks.restype = C.c_int64
     return _lib
 
 
@@ -338,6 +339,24 @@ def patches_bits(Pts, AllVoxels, scale):
         raise ValueError("Expected n_neighbors <= n_samples,  but n_samples = %d, n_neighbors = 496"
                          % vox.shape[0])
     return bits, flags
+
+
+def argpartition(row, kth):
+    """np.argpartition(row, kth) of NumPy 1.18 .. 1.26 (introselect) on one row of integers: the full index permutation [n] int32.
+    scikit-learn's brute-force kneighbors (lists of fewer than 994 voxels at Voxel.py:195) keeps its first 496 entries."""
+    v = np.ascontiguousarray(row, dtype=np.int64)
+    out = np.empty(v.shape[0], np.int32)
+    lib().orc_argpartition(_p(v), C.c_int64(v.shape[0]), C.c_int64(kth), _p(out))
+    return out
+
+
+def brute_query(AllVoxels, KeyVoxels):
+    """kneighbors(KeyVoxels, 496) of the brute-force branch as SETS of list indices: [Q, 496] int32 (argpartition order)."""
+    vox = np.ascontiguousarray(AllVoxels, dtype=np.int16)
+    q = np.ascontiguousarray(KeyVoxels, dtype=np.int32)
+    out = np.empty((q.shape[0], 496), np.int32)
+    lib().orc_brute_query(_p(vox), C.c_int64(vox.shape[0]), _p(q), C.c_int64(q.shape[0]), _p(out))
+    return out
 
 
 def kdtree_idx(AllVoxels):

@@ -300,11 +300,78 @@ def trunc_golden():
         n_q += len(Q); n_same += sum(set(a.tolist()) == set(b.tolist()) for a, b in zip(ref, got))
     assert n_q == n_same and n_q >= 400, "oracle kd-tree query != scikit-learn's kneighbors (as sets)"
     g["kdtree_checked_queries"] = n_q
-    # below 994 voxels 'auto' is brute force (argpartition order: not restated)
+    # below 994 voxels 'auto' is brute force (np.argpartition's order: brute_golden)
     small = NearestNeighbors(n_neighbors=496, radius=14, algorithm="auto").fit(g["sparse_vox"][:993])
     assert small._fit_method == "brute" and NearestNeighbors(n_neighbors=496, algorithm="auto").fit(g["sparse_vox"][:994])._fit_method == "kd_tree"
     print("  kd-tree: %d lattice queries equal to scikit-learn %s as sets; index arrays equal" % (n_q, __import__("sklearn").__version__))
     np.savez_compressed(os.path.join(GOLD, "patch_truncation.npz"), **g)
+
+
+def brute_golden():
+    """Round 6 (missing 4): voxel lists of 496 .. 993 entries, where NearestNeighbors(algorithm='auto') is brute force and
+    the members of a split tie class are chosen by np.argpartition (Voxel.py:182,195-196).  (1) the oracle's introselect against
+    np.argpartition of THIS interpreter's NumPy (1.26: the reference's algorithm) as full permutations; (2) the oracle's raw
+    496-neighbour sets against scikit-learn's brute kneighbors; (3) the reference's GetPatchesList on crafted short lists."""
+    from sklearn.neighbors import NearestNeighbors
+    assert np.__version__.startswith("1."), "np.argpartition of NumPy >= 2 is another algorithm on AVX-512 hosts"
+    g = {}
+    rs = np.random.RandomState(11)
+    rows, perms = [], []
+    for it in range(36):
+        n = int(rs.randint(496, 994)) if it else 993
+        mode = it % 6
+        if mode == 0: v = rs.randint(0, 8, n)
+        elif mode == 1: v = rs.randint(0, 200, n)
+        elif mode == 2: v = np.sort(rs.randint(0, 50, n))
+        elif mode == 3: v = np.sort(rs.randint(0, 50, n))[::-1]
+        elif mode == 4: v = (rs.randint(-9, 10, (n, 3)) ** 2).sum(1)
+        else: v = np.r_[np.arange(n // 2), np.arange(n - n // 2)[::-1]]   # organ pipe: the median-of-medians fallback runs
+        ref = np.argpartition(v.astype(np.float64), 495)
+        assert np.array_equal(ref, orc.argpartition(v, 495)), "oracle introselect != np.argpartition"
+        rows.append(np.asarray(v, np.int16)); perms.append(ref.astype(np.int16))
+    n_any = 0
+    for it in range(4000):   # not stored: any kth, any length
+        n = int(rs.randint(2, 3000)); kth = int(rs.randint(0, n))
+        v = (rs.randint(0, 5, n), rs.randint(0, 10 ** 6, n), np.r_[np.arange(n // 2), np.arange(n - n // 2)[::-1]], np.arange(n)[::-1] // 3)[it % 4]
+        assert np.array_equal(np.argpartition(v.astype(np.float64), kth), orc.argpartition(v, kth))
+        n_any += 1
+    g["rows"] = np.concatenate(rows); g["perms"] = np.concatenate(perms); g["row_len"] = np.array([len(r) for r in rows], np.int32)
+    g["checked_rows_any_kth"] = n_any
+    c = np.array([600, 640, 90])
+    n_q = n_same = 0
+    for name, n_vox, side in (("ball", 990, 0), ("cube", 729, 9), ("slab", 993, 0), ("min", 496, 0)):
+        if name == "ball":      # the 990 nearest cells of a dense lattice: every distance class is large
+            lat = np.argwhere(np.ones((15, 15, 15), bool)) - 7
+            lat = lat[np.argsort((lat ** 2).sum(1), kind="stable")[:n_vox]]
+        elif name == "cube":
+            lat = np.argwhere(np.ones((side, side, side), bool)) - side // 2
+        elif name == "slab":    # two dense layers: what a wall is at 64 cm
+            lat = np.argwhere(np.ones((24, 24, 2), bool)) - np.array([12, 12, 0])
+            lat = lat[rs.permutation(len(lat))[:n_vox]]
+        else:
+            lat = np.argwhere(rs.uniform(size=(12, 12, 12)) < 0.5) - 6
+            lat = lat[:n_vox]
+        vox = (lat[rs.permutation(len(lat))] + c).astype(np.int16)
+        assert len(vox) == n_vox
+        nn = NearestNeighbors(n_neighbors=496, radius=14, algorithm="auto").fit(vox)
+        assert nn._fit_method == "brute"
+        kv = c + rs.randint(-3, 4, size=(48, 3))
+        ref = nn.kneighbors(kv.astype(np.int32), return_distance=False)
+        got = orc.brute_query(vox, kv)
+        n_q += len(kv); n_same += sum(set(a.tolist()) == set(b.tolist()) for a, b in zip(ref, got))
+        pts = (kv * 0.16 - orc.VIS + rs.uniform(0.01, 0.15, size=(48, 3))).astype(np.float32)
+        _, plist = RefVoxel.GetPatchesList(pts, vox, vox, vox)
+        bits = orc.pack_patches(plist[1])
+        ob, of = orc.patches_bits(pts, vox, 1)
+        assert np.array_equal(ob, bits) and not (of & 2).any(), "oracle patches != reference on a brute-force sized list"
+        print("  brute %-5s: nvox=%d truncated=%d argpartition-ordered=%d setbits %d" % (
+            name, len(vox), int(((of & 1) != 0).sum()), int(((of & 4) != 0).sum()), int(np.unpackbits(bits.view(np.uint8)).sum())))
+        g[name + "_vox"] = vox; g[name + "_pts"] = pts; g[name + "_bits"] = bits; g[name + "_flags"] = of
+    assert n_q == n_same, "oracle brute query != scikit-learn's kneighbors (as sets)"
+    g["brute_checked_queries"] = n_q
+    print("  brute force: %d rows equal to np.argpartition %s (+%d of any kth), %d queries equal to scikit-learn %s as sets" % (
+        len(rows), np.__version__, n_any, n_q, __import__("sklearn").__version__))
+    np.savez_compressed(os.path.join(GOLD, "patch_brute.npz"), **g)
 
 
 def extend_golden():
@@ -665,6 +732,9 @@ if __name__ == "__main__":
         trunc_golden()
         tie_golden()
         sys.exit(0)
+    if "--brute-only" in sys.argv:
+        brute_golden()
+        sys.exit(0)
     if "--shuffled-only" in sys.argv:
         shuffled_golden()
         sys.exit(0)
@@ -690,6 +760,7 @@ if __name__ == "__main__":
         icp_golden()
         sys.exit(0)
     trunc_golden()
+    brute_golden()
     f0 = frame_golden(0)
     f1 = frame_golden(1)
     pair_golden(f0, f1)
