@@ -271,10 +271,10 @@ def GetPatchesList(Pts, AllVoxels0, AllVoxels1, AllVoxels2):
     bits, flags = GetPatchesBits(Pts, AllVoxels0, AllVoxels1, AllVoxels2)
     n_tie = int(((flags & 2) != 0).sum().item())
     if n_tie:
-        # the 496-nearest cut of Voxel.py:195-196 splits a class of equidistant voxels AND the list is shorter than 994 voxels, where
-        # scikit-learn's 'auto' is brute force (NumPy's argpartition order, not reproduced): the canonical rule was used
-        warnings.warn("GetPatchesList: %d patch(es) truncated inside a tie of equidistant voxels on a voxel list too short for "
-                      "scikit-learn's kd-tree; they may differ from the reference's in the cut class (flags & 2)" % n_tie, RuntimeWarning)
+        # the 496-nearest cut of Voxel.py:195-196 splits a class of equidistant voxels and the redo in the library's order (kd-tree from
+        # 994 voxels on, np.argpartition below) did not happen: the kd build gave up on its work budget (kdorder.hip) -- canonical rule
+        warnings.warn("GetPatchesList: %d patch(es) truncated inside a tie of equidistant voxels could not be redone in the library's "
+                      "order; they may differ from the reference's in the cut class (flags & 2)" % n_tie, RuntimeWarning)
     out = [_out(e.unpack_patches(bits[:, s, :].contiguous()), as_np) for s in range(3)]
     return Pts, out
 

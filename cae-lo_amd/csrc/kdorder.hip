@@ -22,6 +22,14 @@
 // instead of 2.  Rare by construction: 0 of 614 400 patches on the KITTI-shaped scene, 115 on the clutter scene (200 frames each).
 // The fused path (caelo_extract, caelo_pipeline) builds voxel SETS, not lists in first-touch order: its flagged patches keep the
 // canonical rule and bit 2 (INTEGRATION.md says what a caller who needs them exact does).
+//
+// Lists of 496 .. 993 voxels (round 6): `auto` is BRUTE FORCE there -- squared distances to every list entry in list order (exact
+// integers), then np.argpartition(dist, 495)[:496] (scikit-learn 0.24.2 _kneighbors_reduce_func; the sort that follows only reorders
+// the 496, and a patch is a set).  Which members of a split tie class come out is decided by NumPy's introselect (1.18 .. 1.26:
+// median of three with the 3-lowest moved to low + 1, unguarded Hoare partition, median of medians of five after 2 * msb(n)
+// partitions, selection sort for kth - low < 3): k_brute_query runs it as written, one lane per tie-split patch over a packed
+// (distance, index) array in LDS -- at most 993 entries and a few thousand steps; such lists are a degenerate scan's.  Restated in
+// oracle/caelo_oracle.c (orc_argpartition) and pinned there against the library; tests/golden/patch_brute.npz.
 #include "caelo_internal.h"
 
 #define KD_K 496
@@ -71,7 +79,7 @@ __global__ void __launch_bounds__(256) k_kd_collect(const caelo_kd_set S, int64_
     const int64_t kp = k0 + pw / 3;
     const int sc = (int)(pw % 3);
     const int64_t K = n_key ? min((int64_t)*n_key, k_max) : k_max;
-    if (kp >= K || !(flags[kp * 3 + sc] & 2) || kd.state[16 + sc] < KD_MIN_N) return;
+    if (kp >= K || !(flags[kp * 3 + sc] & 2) || kd.state[16 + sc] < KD_K) return;   // (fewer than 496 voxels: an error of the call)
     const int q = atomicAdd(&kd.state[sc], 1);
     kd.s[sc].queue[q] = (int32_t)kp;   // (at most k_cap entries per scale and chunk)
 }
@@ -335,6 +343,7 @@ __global__ void __launch_bounds__(KD_T) k_kd_build_top(const caelo_kd_set S_) {
     __shared__ KdShared<KD_T> S;
     const int tid = threadIdx.x;
     const int n = kd.state[16 + sc];
+    if (n < KD_MIN_N) return;   // brute force in the library: k_brute_query
     const int n_levels = kd_levels_of(n), n_nodes = (1 << n_levels) - 1;
     if (n_nodes > KD_MAX_NODES || n > kd.cap) { if (tid == 0) kd.state[4 + sc] = 2; return; }
     if (tid == 0) S.gave_up = 0;
@@ -559,6 +568,122 @@ __global__ void __launch_bounds__(64) k_kd_query(const caelo_kd_set S_) {
     if (lane == 0) flags[pw] = (uint8_t)((flags[pw] & ~2) | 4);
 }
 
+// ---- lists too short for the tree: np.argpartition's introselect on (distance << 10 | list index) words; the order relation looks at
+// the distance alone (strict <, like the library's on the float64 row), a swap moves the pair
+#define BQ_LESS(a, b) (((a) >> 10) < ((b) >> 10))
+#define BQ_SWAP(i, j) do { const unsigned long long t_ = a[i]; a[i] = a[j]; a[j] = t_; } while (0)
+__device__ inline void bq_dumb_select(unsigned long long *a, int num, int kth) {
+    for (int i = 0; i <= kth; ++i) {
+        int minidx = i;
+        unsigned long long minval = a[i];
+        for (int k = i + 1; k < num; ++k)
+            if (BQ_LESS(a[k], minval)) { minidx = k; minval = a[k]; }
+        BQ_SWAP(i, minidx);
+    }
+}
+__device__ inline int bq_median5(unsigned long long *a) {
+    if (BQ_LESS(a[1], a[0])) BQ_SWAP(1, 0);
+    if (BQ_LESS(a[4], a[3])) BQ_SWAP(4, 3);
+    if (BQ_LESS(a[3], a[0])) BQ_SWAP(3, 0);
+    if (BQ_LESS(a[4], a[1])) BQ_SWAP(4, 1);
+    if (BQ_LESS(a[2], a[1])) BQ_SWAP(2, 1);
+    if (BQ_LESS(a[3], a[2])) return BQ_LESS(a[3], a[1]) ? 1 : 3;
+    return 2;
+}
+// DEPTH: the median-of-medians fallback selects among num / 5 medians with the same routine -- 993 -> 198 -> 39 -> 7, and seven
+// elements never fall back (hh - ll < 5): three nested instances, no recursion on the device
+template <int DEPTH>
+__device__ void bq_select(unsigned long long *a, const int num, const int kth) {
+    int low = 0, high = num - 1;
+    if (kth - low < 3) { bq_dumb_select(a, num, kth); return; }
+    if (kth == num - 1) {   // (the library's NaN probe for floating point rows: a scan for the LAST maximum)
+        int maxidx = low;
+        unsigned long long maxval = a[low];
+        for (int k = low + 1; k < num; ++k)
+            if (!BQ_LESS(a[k], maxval)) { maxidx = k; maxval = a[k]; }
+        BQ_SWAP(kth, maxidx);
+        return;
+    }
+    int depth_limit = 2 * (31 - __builtin_clz((unsigned)num));
+    while (low + 1 < high) {
+        int ll = low + 1, hh = high;
+        if (depth_limit > 0 || hh - ll < 5) {
+            const int mid = low + (high - low) / 2;
+            if (BQ_LESS(a[high], a[mid])) BQ_SWAP(high, mid);
+            if (BQ_LESS(a[high], a[low])) BQ_SWAP(high, low);
+            if (BQ_LESS(a[low], a[mid])) BQ_SWAP(low, mid);
+            BQ_SWAP(mid, low + 1);
+        } else {
+            int mid = ll;
+            if constexpr (DEPTH < 3) {
+                unsigned long long *b = a + ll;
+                const int nsub = hh - ll, nmed = nsub / 5;
+                for (int i = 0, subleft = 0; i < nmed; ++i, subleft += 5) {
+                    const int m = bq_median5(b + subleft);
+                    const unsigned long long t_ = b[subleft + m]; b[subleft + m] = b[i]; b[i] = t_;
+                }
+                if (nmed > 2) bq_select<DEPTH + 1>(b, nmed, nmed / 2);
+                mid = ll + nmed / 2;
+            }
+            BQ_SWAP(mid, low);
+            --ll; ++hh;
+        }
+        --depth_limit;
+        const unsigned long long pivot = a[low];
+        for (;;) {
+            do ++ll; while (BQ_LESS(a[ll], pivot));
+            do --hh; while (BQ_LESS(pivot, a[hh]));
+            if (hh < ll) break;
+            BQ_SWAP(hh, ll);
+        }
+        BQ_SWAP(low, hh);
+        if (hh >= kth) high = hh - 1;
+        if (hh <= kth) low = ll;
+    }
+    if (high == low + 1 && BQ_LESS(a[high], a[low])) BQ_SWAP(high, low);
+}
+
+__global__ void __launch_bounds__(64) k_brute_query(const caelo_kd_set S_) {
+    const caelo_kd &kd = S_.k[blockIdx.z];
+    const int sc = blockIdx.y;
+    const int cnt = min(kd.state[sc], (int)kd.k_cap);
+    const int n = kd.state[16 + sc];
+    if ((int)blockIdx.x >= cnt || n < KD_K || n >= KD_MIN_N) return;
+    const float *__restrict__ pts = S_.pts[blockIdx.z];
+    const int pts_ld = S_.pts_ld;
+    unsigned long long *__restrict__ bits = S_.bits[blockIdx.z];
+    uint8_t *__restrict__ flags = S_.flags[blockIdx.z];
+    const caelo_kd_scale T = kd.s[sc];
+    __shared__ unsigned long long a[1024];
+    __shared__ unsigned long long patch[64];
+    const int lane = threadIdx.x;
+    const int kp = T.queue[blockIdx.x];
+    const double vs = sc == 0 ? 0.02 : (sc == 1 ? 0.02 * 8 : 0.02 * 32);                    // Voxel.py:31
+    const int q[3] = {(int)(((double)pts[(size_t)pts_ld * kp] + 99.84) / vs), (int)(((double)pts[(size_t)pts_ld * kp + 1] + 99.84) / vs),
+                      (int)(((double)pts[(size_t)pts_ld * kp + 2] + 14.72) / vs)};        // :185,:193 (float64 division, truncation)
+    for (int i = lane; i < n; i += 64) {
+        const int16_t *v = T.vox + 3 * (int64_t)i;
+        const long long dx = q[0] - v[0], dy = q[1] - v[1], dz = q[2] - v[2];
+        a[i] = ((unsigned long long)(dx * dx + dy * dy + dz * dz) << 10) | (unsigned long long)i;
+    }
+    patch[lane] = 0ull;
+    __syncthreads();
+    if (lane == 0) bq_select<0>(a, n, KD_K - 1);
+    __syncthreads();
+    for (int i = lane; i < KD_K; i += 64) {
+        const int16_t *v = T.vox + 3 * (int64_t)(a[i] & 1023ull);
+        const int dx = v[0] - q[0], dy = v[1] - q[1], dz = v[2] - q[2];
+        if (dx >= -8 && dx < 8 && dy >= -8 && dy < 8 && dz >= -8 && dz < 8) {
+            const int lin = ((dx & 15) << 8) | ((dy & 15) << 4) | (dz & 15);
+            atomicOr(&patch[lin >> 6], 1ull << (lin & 63));
+        }
+    }
+    __syncthreads();
+    const int64_t pw = (int64_t)kp * 3 + sc;
+    bits[pw * 64 + lane] = patch[lane];
+    if (lane == 0) flags[pw] = (uint8_t)((flags[pw] & ~2) | 4);
+}
+
 }  // namespace
 
 void kd_destroy(caelo_voxmap *m) {
@@ -673,6 +798,8 @@ int kd_resolve_many(int n, const caelo_voxmap *const *maps, const float *const *
         k_kd_build_sub<<<dim3(1u << kd_top_levels_of(cap), 3, S.n), KD_TS, 0, s>>>(S);
         CAELO_LAUNCH_CHECK();
         k_kd_query<<<dim3((unsigned)k_cap, 3, S.n), 64, 0, s>>>(S);
+        CAELO_LAUNCH_CHECK();
+        k_brute_query<<<dim3((unsigned)k_cap, 3, S.n), 64, 0, s>>>(S);   // (lists of 496 .. 993 voxels; every other block leaves at once)
         CAELO_LAUNCH_CHECK();
     }
     return CAELO_OK;

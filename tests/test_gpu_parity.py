@@ -198,8 +198,9 @@ def test_patches_bit_exact(api, orc, f0):
 
 def test_patches_truncation_taxonomy(api, orc, scans):
     """The 496-nearest cut (Voxel.py:182,195-196) through the staged API.  Where it splits a class of equidistant voxels the
-    patch is redone in scikit-learn's kd-tree order (kdorder.hip, flag 4): bits AND flags equal the oracle's, and -- the oracle
-    being pinned to the library there -- EVERY patch equals what the reference returned (rounds 1-3: only the unflagged ones)."""
+    patch is redone in scikit-learn's kd-tree order (kdorder.hip, flag 4) or, on lists of fewer than 994 voxels, in np.argpartition's
+    (the library's brute-force branch): bits AND flags equal the oracle's, and -- the oracle being pinned to the libraries there --
+    EVERY patch equals what the reference returned (rounds 1-3: only the unflagged ones)."""
     import warnings
     g = np.load(os.path.join(GOLDEN, "patch_truncation.npz"))
     for name in ("sparse", "mid", "dense"):
@@ -216,14 +217,27 @@ def test_patches_truncation_taxonomy(api, orc, scans):
     many = np.tile(g["dense_pts"], (32, 1))
     bits, flags = api.GetPatchesBits(many, g["dense_vox"], g["dense_vox"], g["dense_vox"])
     assert np.array_equal(bits[:, 1].cpu().numpy().view(np.uint64), np.tile(g["dense_bits"], (32, 1))) and not (flags.cpu().numpy() & 2).any()
-    # a list too short for the library's kd-tree (brute force there, NumPy's argpartition order): canonical rule, flag 2, and the
-    # reference-named entry point says so
-    dv = g["dense_vox"].astype(np.int64)
-    short = g["dense_vox"][np.argsort(((dv - np.array([600, 640, 90])) ** 2).sum(1), kind="stable")[:990]]   # a dense ball of 990 voxels
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        api.GetPatchesList(g["dense_pts"], short, short, short)
-    assert any("tie" in str(x.message) for x in w)
+    # lists too short for the library's kd-tree (496 .. 993 voxels: brute force there, np.argpartition's order -- k_brute_query, round 6):
+    # the reference's own patches (tests/golden/patch_brute.npz), nothing left to warn about
+    gb = np.load(os.path.join(GOLDEN, "patch_brute.npz"))
+    n4 = 0
+    for name in ("ball", "cube", "slab", "min"):
+        vox, pts = gb[name + "_vox"], gb[name + "_pts"]
+        bits, flags = api.GetPatchesBits(pts, vox, vox, vox)
+        for s_ in range(3):   # (the same list at every scale: the scale only changes the key voxel)
+            ob, of = orc.patches_bits(pts, vox, s_)
+            assert np.array_equal(bits[:, s_].cpu().numpy().view(np.uint64), ob) and np.array_equal(flags[:, s_].cpu().numpy(), of)
+        assert np.array_equal(bits[:, 1].cpu().numpy().view(np.uint64), gb[name + "_bits"]) and not (flags.cpu().numpy() & 2).any()
+        n4 += int(((flags[:, 1].cpu().numpy() & 4) != 0).sum())
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            _, plist = api.GetPatchesList(pts, vox, vox, vox)
+        assert np.array_equal(orc.pack_patches(plist[1]), gb[name + "_bits"])
+    assert n4 == 115
+    # a short list beside long ones, and more key points than one queue holds
+    many = np.tile(gb["ball_pts"], (32, 1))
+    bits, flags = api.GetPatchesBits(many, g["dense_vox"], gb["ball_vox"], g["dense_vox"])
+    assert np.array_equal(bits[:, 1].cpu().numpy().view(np.uint64), np.tile(gb["ball_bits"], (32, 1))) and not (flags.cpu().numpy() & 2).any()
     # a real frame with 11 tie-split patches (clutter frame 23), lists from the reference-exact voxelization
     gc = np.load(os.path.join(GOLDEN, "frame_c23.npz"))
     pc = scans(23, quantum=1e-3, scene_kind="clutter")
