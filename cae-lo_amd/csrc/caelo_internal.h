@@ -286,6 +286,7 @@ struct caelo_enc_out {
 // last counting launch, [1024..2047] eight per-XCD queue counters of k_enc_stage1x (a 128-byte line each), [2048..3071] the same for
 // k_enc_conv3 (each kernel zeroes the other's).  Zero between calls.
 #define CAELO_ENC_WS_HEADER 4096
+#define CAELO_ENC_WS_MFMA 3072     // bytes 3072 .. 4095 of the header: stage 1's MFMA counters (profiling launches only)
 struct caelo_enc_in {
     const unsigned long long *bits;
     int64_t frame_stride;

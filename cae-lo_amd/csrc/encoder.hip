@@ -1277,10 +1277,10 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
     CAELO_REQUIRE(c->has_enc, "encoder weights not set (caelo_set_encoder_weights)");
     CAELO_REQUIRE(n_patches > 0 && n_patches < 0x7FFFFFFF && group >= 1 && out_stride >= group * 20, "bad shape");
     const int64_t np = pad64(n_patches);
-    // ws = [header (CAELO_ENC_WS_HEADER bytes): work counter, zero between calls (the owner zero-fills ws once, conv3 resets it); bytes 8..15
-    // = MFMA tap rows the last conv-2 launch executed] | P2 | F3 | dense-1 partial sums | conv-1 cell lists
+    // ws = [header (CAELO_ENC_WS_HEADER bytes): work counter, zero between calls (the owner zero-fills ws once, conv3 resets it); bytes 3072..4095
+    // = MFMA instructions the last profiled stage-1 launch executed, eight partial counts] | P2 | F3 | dense-1 partial sums | conv-1 cell lists
     int *work_counter = (int *)ws;
-    unsigned long long *mfma_count = (unsigned long long *)((char *)ws + 8);
+    unsigned long long *mfma_count = (unsigned long long *)((char *)ws + CAELO_ENC_WS_MFMA);   // eight counters, a 128-byte line each
     float *p2 = (float *)((char *)ws + CAELO_ENC_WS_HEADER);
     float *f3 = p2 + np * 1024;
     float *part = f3 + np * 2048;
@@ -1332,7 +1332,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
         const int64_t capx = slots_env > 0 ? slots_env : ((ein.yield & 1) ? (int64_t)slots1x * 2 / 3 : slots1x);
         const unsigned gx = (unsigned)(n_patches < capx ? n_patches : capx);
         if (ev) {   // profiling calls count the MFMAs the kernel executes (bench.py's roofline); same code otherwise
-            CAELO_HIP(hipMemsetAsync(mfma_count, 0, sizeof(unsigned long long), s));
+            CAELO_HIP(hipMemsetAsync(mfma_count, 0, 1024, s));
             CAELO_HIP(hipEventRecord(ev[0], s));
             k_enc_stage1x<true><<<gx, 256, 0, s>>>(ein, n_patches, order_group, work_counter, (const uint4 *)c->enc_w1f, c->enc_b1,
                                                    (const uint4 *)c->enc_w2x, c->enc_c0, p2, mfma_count);
@@ -1341,7 +1341,7 @@ int encode_batch_impl(caelo_ctx *c, const uint64_t *bits, int64_t n_patches, int
                                                     (const uint4 *)c->enc_w2x, c->enc_c0, p2, mfma_count);
         CAELO_LAUNCH_CHECK();
     } else {
-        if (ev) CAELO_HIP(hipMemsetAsync(mfma_count, 0, sizeof(unsigned long long), s));   // (the f32 kernel has no register left to count)
+        if (ev) CAELO_HIP(hipMemsetAsync(mfma_count, 0, 1024, s));   // (the f32 kernel has no register left to count)
         k_enc_stage1<<<g1, 256, 0, s>>>(ein, n_patches, order_group, work_counter, c->enc_w1, c->enc_b1, c->enc_w2, c->enc_c0, p2);
         CAELO_LAUNCH_CHECK();
     }
@@ -1400,8 +1400,9 @@ CAELO_API int caelo_encode_profile(caelo_ctx *c, const uint64_t *bits, int64_t n
     if (rc == CAELO_OK) {
         CAELO_HIP(hipEventSynchronize(ev[4]));
         for (int i = 0; i < 4; ++i) CAELO_HIP(hipEventElapsedTime(&ms_host[i], ev[i], ev[i + 1]));
-        unsigned long long rows = 0;  // conv2 tap rows executed (6 v_mfma_f32_16x16x4_f32 each), counted by the kernel itself
-        CAELO_HIP(hipMemcpy(&rows, (char *)ws + 8, sizeof(rows), hipMemcpyDeviceToHost));
+        unsigned long long rows = 0, part[128];  // MFMA instructions executed, counted by the kernel itself (eight partial counts, a line each)
+        CAELO_HIP(hipMemcpy(part, (char *)ws + CAELO_ENC_WS_MFMA, sizeof(part), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 8; ++i) rows += part[16 * i];
         // the f32 kernel counts tap rows (6 v_mfma_f32_16x16x4_f32 each), k_enc_stage1x its v_mfma_f32_16x16x32_f16 instructions
         const bool f32_kernel = c->enc_reference;   // (it does not count: 0 MFMAs reported)
         ms_host[4] = (float)((double)rows * (f32_kernel ? 6.0 : 1.0) / 1e6);
