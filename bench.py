@@ -659,8 +659,11 @@ def main():
                     "achieved_is": "FLOPs of the MFMA instructions the kernel EXECUTED (counted by the kernel: v_mfma_f32_16x16x32_f16, "
                                    "16 384 FLOP each) / launch time, against the dense peak of the f16 / bf16 matrix pipe; always <= 1.  "
                                    "Round 3 moved stage 1 from the f32 pipe (0.39 of 157 TFLOP/s, 341 us) to 2-way f16 splits (224 us), round 4 to "
-                                   "three workgroups per CU and plane-wise fragment fetches (195 us): the pipe is not what bounds the kernel (LDS "
-                                   "round trips and instruction issue do), the launch time is the figure to compare across rounds",
+                                   "three workgroups per CU and plane-wise fragment fetches (195 us).  Round 6 found 30 us of every one of those figures in "
+                                   "the MEASUREMENT: the profiled instantiation of the kernel ended each wavefront with an atomic on one counter word "
+                                   "(3 072 same-address atomics, ~12 ns each); counted per workgroup on eight lines the same kernel takes 155-170 us "
+                                   "(profiles/r06_s1x_ablation.txt), as the production instantiation always did.  The pipe is not what bounds the "
+                                   "kernel (LDS round trips and instruction issue do)",
                     "pipe_rate_in_a_bare_loop": {"tflops": 2420.0, "source": "profiles/r04_mfma_rates.txt (tools/micro/mfma_rates.hip): v_mfma_f32_16x16x32_f16 and "
                                                  "v_mfma_f32_32x32x16_f16 both sustain 2.41-2.44 PFLOP/s on this chip; `peak` stays the guide's dense figure"},
                     "algorithmic_tflops": round(float(alg_tf[dom]), 2),

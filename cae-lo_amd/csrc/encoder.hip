@@ -888,7 +888,7 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1p(const float *__re
     constexpr int BM = D1_BM * MTW, A16 = D1_NS * 4 * BM, NBUF = D1P_NBUF(MTW), NKS = KTOT / D1_SPLIT_OF(KTOT) / D1_BK;
     constexpr int DMA = 4;              // 1 KB pieces a wave copies per stage (8 waves x 4 = 32 >= 26)
     constexpr int PER_STAGE = DMA + MTW;  // loads a thread has in flight per stage: its DMA pieces + its rows
-    static_assert(MTW == 1 || MTW == 2, "two instances");
+    static_assert(MTW >= 1 && MTW <= 3, "three instances");
     static_assert(NKS % 2 == 0 && NKS >= 6, "stages are unrolled in pairs, the last ones peeled");
     // workgroup -> (row tile, k slice).  De-duplicated launch: only the tiles that hold distinct patches of their frame do work
     // (tiles never straddle frames), and they are numbered FIRST: with one workgroup per CU (LDS) an idle workgroup in the
@@ -972,10 +972,14 @@ __global__ void __launch_bounds__(D1_THREADS, 2) k_enc_dense1p(const float *__re
             __asm__ volatile("ds_write_b64 %0, %1 offset:%3\n\tds_write_b64 %0, %2 offset:%4"               \
                              : : "v"(a_lds), "v"(dh_), "v"(dl_), "n"((ABUF) * A16 * 16),                     \
                                  "n"((ABUF) * A16 * 16 + 4 * BM * 16) : "memory");                          \
-        else                                                                                               \
+        else if (r == 1)                                                                                   \
             __asm__ volatile("ds_write_b64 %0, %1 offset:%3\n\tds_write_b64 %0, %2 offset:%4"               \
                              : : "v"(a_lds), "v"(dh_), "v"(dl_), "n"((ABUF) * A16 * 16 + 1024),              \
                                  "n"((ABUF) * A16 * 16 + 4 * BM * 16 + 1024) : "memory");                   \
+        else                                                                                               \
+            __asm__ volatile("ds_write_b64 %0, %1 offset:%3\n\tds_write_b64 %0, %2 offset:%4"               \
+                             : : "v"(a_lds), "v"(dh_), "v"(dl_), "n"((ABUF) * A16 * 16 + 2048),              \
+                                 "n"((ABUF) * A16 * 16 + 4 * BM * 16 + 2048) : "memory");                   \
     }
 #define D1P_READ_A(AF, ABUF)                                                                               \
     _Pragma("unroll") for (int q = 0; q < MTW; ++q) {                                                      \
@@ -1097,12 +1101,23 @@ static int dense1_launch(int device, const float *f3, int64_t np, const void *wd
         hipError_t e = hipFuncSetAttribute((const void *)k_enc_dense1p<KTOT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, D1P_LDS_BYTES(1));
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)k_enc_dense1p<KTOT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, D1P_LDS_BYTES(2));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)k_enc_dense1p<KTOT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, D1P_LDS_BYTES(3));
         return e;
     });
     CAELO_HIP(attr);
     // CAELO_D1_WIDE_FROM: launch size (rows) from which the 128-row instance is used -- a tuning threshold, the partial sums of the two
     // instances are bit-identical (tests/test_gpu_parity.py::test_dense1_tile_sizes_are_bit_identical)
     static const int64_t wide_from = getenv("CAELO_D1_WIDE_FROM") ? atoll(getenv("CAELO_D1_WIDE_FROM")) : 4 * 3072;  // rows
+    // 192-row tiles (round 6) for launches of EVERY patch (no de-duplication) that 128-row tiles would take two rounds over (more than
+    // 256 x 64 rows): one and a half times the MFMAs per weight fragment, two thirds of the weight stream, one round -- 90 -> 68 us per
+    // 24 576 rows; 12 288 rows (one round either way) 45 -> 56 us, which is why de-duplicated launches (~13 k live rows of a batch, a
+    // number the host does not know) stay on 128-row tiles: 19.7 against 19.5 k frames/s (profiles/r06_dense1_tile192.txt).  Same partial sums.
+    static const int64_t tile3_from = getenv("CAELO_D1_TILE3_FROM") ? atoll(getenv("CAELO_D1_TILE3_FROM")) : 256 * 64 + 1;  // rows
+    if (KTOT == 2048 && !in.dedup && np % 192 == 0 && np >= tile3_from && np >= wide_from) {
+        dim3 gw((unsigned)(np / 192), D1_SPLIT_OF(KTOT));
+        k_enc_dense1p<KTOT, 3><<<gw, D1_THREADS, D1P_LDS_BYTES(3), s>>>(f3, np, (const uint4 *)wd1x, part, in);
+    } else
     if (np % 128 == 0 && (!in.dedup || in.per_frame % 128 == 0) && (np >= wide_from || KTOT > 2048)) {  // (tiles never straddle frames)
         // 128-row tiles once the launch fills the chip with them, and always for the long-K instance (8 k slices per row tile):
         // half the weight stream; same partial sums

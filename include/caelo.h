@@ -145,8 +145,9 @@ int caelo_voxmap_from_lists(caelo_ctx *ctx, caelo_voxmap *map, const int16_t *al
                             int64_t n1, const int16_t *all2, int64_t n2, int32_t *status, void *stream);
 
 /* GetPatchesList  (Voxel.py:177-216): pts [k][3] f32 (k read from n_key when non-null, else k_max)
- * -> bits [k_max][3][64] u64, flags [k_max][3] u8 (bit0 truncated by the 496-NN cap, bit1 cut
- * falls inside an equidistant class: kd-tree tie order dependent). */
+ * -> bits [k_max][3][64] u64, flags [k_max][3] u8 (bit0 truncated by the 496-NN cap; bit1 the cut falls inside a class of
+ * equidistant voxels and the patch is on the canonical rule -- the map has no ordered lists, or the kd build gave up; bit2 such a
+ * patch redone in the library's own order: scikit-learn's kd-tree from 994 voxels on, np.argpartition's below (csrc/kdorder.hip)). */
 int caelo_patches(caelo_ctx *ctx, const caelo_voxmap *map, const float *pts, int64_t k_max, const int32_t *n_key,
                   uint64_t *bits, uint8_t *flags, int32_t *status, void *stream);
 /* The same for n <= 8 maps / key point sets (arrays of n HOST pointers to the device buffers of caelo_patches): the gathers one after the

@@ -1383,6 +1383,12 @@ for i in range(2):
     f = eng.extract(pc)
     torch.cuda.synchronize()
     print(hashlib.sha256(f.rows.cpu().numpy().tobytes()).hexdigest())
+n = int(os.environ.get("CAELO_VARIANT_ENCODE_ROWS", "0"))   # (read by this test script, not by the library)
+if n:
+    import numpy as np
+    rs = np.random.RandomState(9)
+    bits = np.packbits(rs.random_sample((n, 512, 8)) < 0.01, axis=2, bitorder="little").reshape(n, 512).view(np.int64)
+    print(hashlib.sha256(eng.encode(torch.from_numpy(np.ascontiguousarray(bits)).to(eng.device), group=3).cpu().numpy().tobytes()).hexdigest())
 """
 
 
@@ -1413,6 +1419,13 @@ def test_dense1_tile_sizes_are_bit_identical(engine):
         want.append(hashlib.sha256(f.rows.cpu().numpy().tobytes()).hexdigest())
     got = _variant_hashes({"CAELO_D1_WIDE_FROM": "1"})
     assert len(want) == 2 and got == want
+    # round 6: 192-row tiles for launches of more than 16 384 rows without de-duplication (CAELO_D1_TILE3_FROM moves the threshold):
+    # 18 432 random patches through caelo_encode on 192-row tiles (this process) and on 128-row tiles (the variant process)
+    rs = np.random.RandomState(9)
+    bits = np.packbits(rs.random_sample((18432, 512, 8)) < 0.01, axis=2, bitorder="little").reshape(18432, 512).view(np.int64)
+    mine = hashlib.sha256(engine.encode(torch.from_numpy(np.ascontiguousarray(bits)).to(engine.device), group=3).cpu().numpy().tobytes()).hexdigest()
+    other = _variant_hashes({"CAELO_D1_TILE3_FROM": "100000000", "CAELO_VARIANT_ENCODE_ROWS": "18432"})
+    assert other[-1] == mine and len(other) == 3
 
 
 @pytest.mark.gpu
@@ -1426,7 +1439,7 @@ def test_library_reads_no_arithmetic_switch_from_the_environment():
     for fn in os.listdir(src):
         if fn.endswith((".hip", ".inc", ".h")):
             seen |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(os.path.join(src, fn)).read()))
-    allowed = {"CAELO_D1_WIDE_FROM", "CAELO_S1X_SLOTS", "CAELO_ENC_YIELD", "CAELO_DEDUP_HASH_BITS", "CAELO_NO_DEDUP",
+    allowed = {"CAELO_D1_WIDE_FROM", "CAELO_D1_TILE3_FROM", "CAELO_S1X_SLOTS", "CAELO_ENC_YIELD", "CAELO_DEDUP_HASH_BITS", "CAELO_NO_DEDUP",
                "CAELO_PIPE_SYSTEM_FENCES", "CAELO_PIPE_VERBOSE", "CAELO_PIPE_PACE", "CAELO_PIPE_STREAMS", "CAELO_PIPE_ENC_PRIO",
                "CAELO_PIPE_VOX_STREAM", "CAELO_PIPE_PLAN", "CAELO_CERT_THREADS", "CAELO_CERT_ZEROCOPY", "GPU_MAX_HW_QUEUES"}
     assert seen <= allowed, sorted(seen - allowed)
