@@ -1402,6 +1402,32 @@ def _variant_hashes(env):
 
 
 @pytest.mark.gpu
+def test_encode_profile_is_the_same_encoder_and_counts_its_mfmas(engine):
+    """caelo_encode_profile (bench.py's roofline, tools/roofline_launch.py) launches the COUNTING instantiation of stage 1: same
+    descriptors as caelo_encode bit for bit, and a count of executed MFMA instructions that is additive over the patches of a launch
+    (round 6: one atomic per workgroup on eight counter lines instead of one per wavefront on one word -- the sum must not care
+    which workgroup drew which patch)."""
+    import torch
+    rs = np.random.RandomState(21)
+    n = 3072
+    sparse = np.packbits(rs.random_sample((n, 512, 8)) < 0.002, axis=2, bitorder="little").reshape(n, 512).view(np.int64)
+    full = np.full((n, 64), -1, dtype=np.int64)
+    empty = np.zeros((n, 64), dtype=np.int64)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(engine.device)
+    counts = {}
+    for name, b in (("sparse", sparse), ("full", full), ("empty", empty), ("mixed", np.concatenate([sparse, full, empty]))):
+        out, ms = engine.encode_profile(dev(b), group=3)
+        assert torch.equal(out, engine.encode(dev(b), group=3)), name
+        out2, ms2 = engine.encode_profile(dev(b), group=3)
+        counts[name] = int(round(ms[4] * 1e6))
+        assert int(round(ms2[4] * 1e6)) == counts[name] and ms[5] == 2.0 * 16 * 16 * 32 and all(t > 0 for t in ms[:4])
+    assert counts["empty"] == 0
+    assert counts["full"] == n * 1304          # 32 conv1 tiles x 16 + every tap row of conv2 that has an input plane inside the patch
+    assert 0 < counts["sparse"] < counts["full"]
+    assert counts["mixed"] == counts["sparse"] + counts["full"]
+
+
+@pytest.mark.gpu
 def test_dense1_tile_sizes_are_bit_identical(engine):
     """The one tuning switch left in the encoder that picks between two instances of a kernel: k_enc_dense1p on 64-row tiles
     (launches below four frames) and on 128-row tiles (CAELO_D1_WIDE_FROM=1: also for one frame) must give the same partial sums,
