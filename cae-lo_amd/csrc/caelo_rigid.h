@@ -35,6 +35,9 @@
         }                                                                                                    \
     }
 #define JAC_SWAP(X, Y) { const double t_ = X; X = Y; Y = t_; }
+// SIGN3 = false: the rank-2 completion is right-handed whatever the sign of det H (the RANSAC hypothesis kernels: three live doubles
+// at their register peak; every rank-2 sample is a kind-1 hypothesis of the certificate there, both poses scored -- match.hip)
+template <bool SIGN3 = true>
 __device__ inline int rigid_from_H_jacobi(const double Hin[9], const double m0[3], const double m1[3], float R[9], float T[3]) {
     // A = H (columns 0, 1, 2 as a*0, a*1, a*2), V = I
     double a00 = Hin[0], a01 = Hin[1], a02 = Hin[2], a10 = Hin[3], a11 = Hin[4], a12 = Hin[5], a20 = Hin[6], a21 = Hin[7], a22 = Hin[8];
@@ -66,10 +69,22 @@ __device__ inline int rigid_from_H_jacobi(const double Hin[9], const double m0[3
         const double nv = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
         u01 = w0 / nv; u11 = w1 / nv; u21 = w2 / nv;
     }
-    if (s2 <= tiny) {  // rank 2: u3 = u1 x u2 (sign is LAPACK-specific in the reference)
-        u02 = u10 * u21 - u20 * u11;
-        u12 = u20 * u01 - u00 * u21;
-        u22 = u00 * u11 - u10 * u01;
+    if (s2 <= tiny) {
+        // rank 2 to working precision: u3 = +-(u1 x u2).  The SIGN is the one H v3 = s3 u3 still has while s3 is small but not zero
+        // (round 6: a sample of four ground points, s3 / s1 = 1e-13 and det H = +5.7e-3 safely positive, got the right-handed
+        // completion whatever the column swaps above had done to det V -- an improper V U^T, the reflection quirk of :151-155, and a
+        // pose 4.5e-5 rad away from the reference's, which had read the sign off its SVD: one inlier count above its "upper bound",
+        // tests/golden/ransac_bound_case.npz).  With s3 exactly zero the choice is free (the callers that care score both poses:
+        // rigid_two_candidates, kind 1 of the certificate).
+        // (the triple product first, then the cross product again into the three slots: three live doubles less than keeping it -- this
+        //  branch sits at the register peak of k_ransac_hyp, whose 168 registers are what fits beside two stage-1 workgroups)
+        double tp = u02 * (u10 * u21 - u20 * u11);   // u.2 = H v3 / s3 as far as it is known; zero when s3 is
+        tp += u12 * (u20 * u01 - u00 * u21);
+        tp += u22 * (u00 * u11 - u10 * u01);
+        const double sgn = (SIGN3 && tp < 0.0) ? -1.0 : 1.0;
+        u02 = sgn * (u10 * u21 - u20 * u11);
+        u12 = sgn * (u20 * u01 - u00 * u21);
+        u22 = sgn * (u00 * u11 - u10 * u01);
     }
     // R = W U^T
     double r0 = v00 * u00 + v01 * u01 + v02 * u02, r1 = v00 * u10 + v01 * u11 + v02 * u12, r2 = v00 * u20 + v01 * u21 + v02 * u22;
@@ -136,6 +151,7 @@ __device__ inline bool rigid_two_candidates(const double Hin[9], const double m0
 // X <- (g X + X^-T / g) / 2 (Higham) converges quadratically in f64 (5-7 steps, no sqrt/div chains of a
 // Jacobi SVD: ~10x shorter dependency chain, and every hypothesis wavefront runs this serially).
 // Rank-deficient or badly conditioned H (repeated sample indices) falls back to the Jacobi SVD above.
+template <bool SIGN3 = true>
 __device__ inline int rigid_from_H(const double H[9], const double m0[3], const double m1[3], float R[9], float T[3]) {
     double X[9] = {H[0], H[3], H[6], H[1], H[4], H[7], H[2], H[5], H[8]};  // X0 = H^T
     double fro = 0.0;
@@ -172,7 +188,7 @@ __device__ inline int rigid_from_H(const double H[9], const double m0[3], const 
         if (delta < 1e-30 * 3.0) break;  // |X_{k+1} - X_k|_F < 1e-15 |Q|_F
         if (it == 15) ok = false;
     }
-    if (!ok) return rigid_from_H_jacobi(H, m0, m1, R, T);
+    if (!ok) return rigid_from_H_jacobi<SIGN3>(H, m0, m1, R, T);
     if (det0 < 0) { X[6] = -X[6]; X[7] = -X[7]; X[8] = -X[8]; }  // Match.py:151-155: Vh[:,2] *= -1  <=>  negate row 2 of R
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = (float)X[i];

@@ -636,7 +636,7 @@ __device__ inline void sample_hypothesis(const float *P0, int l0, const int64_t 
             for (int q = 0; q < 4; ++q) h += (double)c1[q][i] * (double)c0[q][j];
             H[3 * i + j] = h;
         }
-    rigid_from_H(H, m0, m1, R, T);
+    rigid_from_H<false>(H, m0, m1, R, T);   // (hypotheses: see rigid_from_H_jacobi)
 }
 
 // ---- how far the reference's own arithmetic can move a residual of this hypothesis (the certificate of caelo.h) ----------
@@ -693,6 +693,9 @@ __device__ inline void hypothesis_bound(const Sample4 &s, HypBound &hb) {
     if (!(I2 > 1e-10 * I1 * I1) || !(I1 > 0.0)) { hb.kind = 2; return; }
     const double kappa = 1.41421356237309515 * I1 / sqrt(I2);
     if (fabs(det) <= 64.0 * 5.9604644775390625e-8 * 1.001 * (double)sumCA) hb.kind = 1;
+    // ... nor against the float64 SVD's own backward error (|E| ~ 1e2 eps64 |H|: det moves by <= |cof H|_F |E|_F) when the four points are
+    // coplanar to a part in 1e12 -- key points on the ground plane of a mm-quantised scan (round 6, tests/golden/ransac_bound_case.npz)
+    if (det * det <= 1e-24 * I1 * I2) hb.kind = 1;   // |det| <= 1e-12 |H|_F |cof H|_F
     const double nm0 = sqrt(s.m0[0] * s.m0[0] + s.m0[1] * s.m0[1] + s.m0[2] * s.m0[2]);
     const double nm1 = sqrt(s.m1[0] * s.m1[0] + s.m1[1] * s.m1[1] + s.m1[2] * s.m1[2]);
     // |T|_inf <= |mean0| + |R mean1| = |mean0| + |mean1| for every candidate pose (T = mean0 - R mean1, Match.py:157)
@@ -779,7 +782,7 @@ __device__ __forceinline__ void four_hypotheses(const float *sP0, const float *s
         if (lane < RH_PER_WAVE && trial0 + lane < CAELO_RANSAC_MAX_TRIALS)
 #pragma unroll
             for (int q = 0; q < 4; ++q) (level ? cert->idx_up[level - 1] : cert->idx)[trial0 + lane][q] = smp.idx[q];
-        rigid_from_H(smp.H, smp.m0, smp.m1, R, T);
+        rigid_from_H<false>(smp.H, smp.m0, smp.m1, R, T);   // (a rank-2 sample is kind 1: both poses are scored below)
     } else {
         sample_hypothesis(sP0, 3, nullptr, sP1, 3, N, rnd + (size_t)mine * 4, R, T);
     }

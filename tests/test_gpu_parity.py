@@ -1745,6 +1745,39 @@ def test_ransac_certificate_bounds_hold_and_results_are_the_oracles_bits(engine,
 
 
 @pytest.mark.gpu
+def test_ransac_bound_on_a_sample_coplanar_to_a_part_in_1e13(engine, orc):
+    """Round 6: the one violation a strict soak with fresh seeds found (clutter pair 114-115, trial 381: hi 64 against a reference count
+    of 65).  The four sampled key points lie on the ground plane of a mm-quantised scan, sigma_3 / sigma_1 = 1e-13 with det H = +5.7e-3 --
+    safely positive against the float32 rounding of H, so the hypothesis was kind 0, and the Jacobi fallback of the pose completed its
+    rank-2 SVD right-handed whatever the sign of det H: the reflection quirk of Match.py:151-155 fired on the device and not in the
+    reference, the poses 4.5e-5 rad apart.  Now: such a sample is kind 1 (both poses scored), and SolveRT follows the sign.
+    tests/golden/ransac_bound_case.npz holds the pair's matched points (tools/bound_violation_probe.py found and saved them)."""
+    import torch
+    from caelo import _ffi
+    from caelo.engine import ransac_draws
+    g = np.load(os.path.join(GOLDEN, "ransac_bound_case.npz"))
+    P0, P1, smp, t = np.ascontiguousarray(g["P0"]), np.ascontiguousarray(g["P1"]), g["sample"], int(g["trial"])
+    N = len(P0)
+    draws = ransac_draws(int(g["seed"]))
+    assert np.array_equal((draws[4 * t:4 * t + 4] * N).astype(np.int32), smp)
+    d0, d1 = torch.from_numpy(P0).to(engine.device), torch.from_numpy(P1).to(engine.device)
+    cert = engine.new_cert(1)
+    engine.ransac(d0, d1, torch.arange(N, device=engine.device, dtype=torch.int64), torch.from_numpy(draws).to(engine.device), cert=cert[0])
+    rec = cert.cpu().numpy().view(_ffi.CERT_DTYPE).reshape(-1)[0]
+    cnt = _oracle_counts(orc, P0, P1, draws)
+    assert cnt[t] == int(g["count"]) == 65
+    assert (rec["hi"][:500] >= cnt).all(), np.flatnonzero(rec["hi"][:500] < cnt)
+    results, masks, evals, status = engine.certify(cert, [draws])
+    R, T, ok, m, thr = orc.RANSAC4RT(P0, P1, rng=np.random.RandomState(int(g["seed"])))
+    assert status[0] == 0 and np.array_equal(masks[0, :N].astype(bool), m) and np.array_equal(results[0]["R_ransac"].reshape(3, 3), R)
+    # SolveRT on the sample itself: the device's float64 fit next to the reference's float32 / LAPACK one, no reflection
+    Rr, Tr, cred_r = orc.SolveRT(P0[smp], P1[smp])
+    Rd, Td, cred_d = engine.solve_rt(torch.from_numpy(np.ascontiguousarray(P0[smp])).to(engine.device), torch.from_numpy(np.ascontiguousarray(P1[smp])).to(engine.device))
+    assert int(cred_d.item()) == cred_r == 1
+    assert np.abs(Rd.cpu().numpy() - Rr).max() < 2e-6 and np.abs(Td.cpu().numpy().ravel() - Tr.ravel()).max() < 2e-5
+
+
+@pytest.mark.gpu
 def test_ransac_certificates_of_the_higher_levels(engine, orc):
     """Round 6 (Match.py:207-214): for a pair whose first level fails -- the golden escalation / failure inputs -- the certificate carries
     `hi_up` / `idx_up`: upper bounds of the reference's counts for EVERY hypothesis of the 0.8 m and 1.6 m levels and their sample indices;
