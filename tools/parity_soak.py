@@ -184,6 +184,8 @@ def soak(engine, orc, models, scene, n_frames, seed_base=5000, batch=8, log=None
             lvl0 = np.array([t[1] for t in trace if t[2] == 0.4], np.int64)
             hi = cert.cpu().numpy().view(_ffi.CERT_DTYPE).reshape(-1)[0]["hi"][:len(lvl0)].astype(np.int64)
             rep["bound_checks"] += len(lvl0); rep["bound_violations"] += int((hi < lvl0).sum())
+            for t_ in np.flatnonzero(hi < lvl0):   # (tools/bound_violation_probe.py isolates and saves such a hypothesis)
+                rep.setdefault("bound_violation_list", []).append((i, int(t_), int(hi[t_]), int(lvl0[t_])))
             rep["bound_slack_sum"] += int((hi - lvl0).sum()); rep["bound_slack_max"] = max(rep["bound_slack_max"], int((hi - lvl0).max()) if len(lvl0) else 0)
             cres, cmask, cev, cst = engine.certify(cert, [draws[i]])
             pr = cres[0]; m_ = cmask[0, :k].astype(bool)
@@ -259,7 +261,8 @@ def render(rep):
              rep["match_kernel_mismatch_cols"], rep["ransac_kernel_mismatch_pairs"], rep["pairs_compared"], rep["ransac_kernel_bitexact_pairs"], rep["pairs_compared"],
              rep["ransac_kernel_max_rt"], rep["ransac_kernel_evals_max"]),
          "    certificates: %d hypothesis counts of the oracle's first-level loops checked against the kernel's upper bounds: %d violations; mean slack %.2f, largest %d" % (
-             rep["bound_checks"], rep["bound_violations"], rep["bound_slack_sum"] / max(1, rep["bound_checks"]), rep["bound_slack_max"]),
+             rep["bound_checks"], rep["bound_violations"], rep["bound_slack_sum"] / max(1, rep["bound_checks"]), rep["bound_slack_max"])
+         + ("".join("\n      bound violated: frame %d trial %d: hi %d < reference count %d" % v for v in rep.get("bound_violation_list", []))),
          "  pipeline end to end (exact RANSAC inside the pipeline: %.2f hypotheses per pair on the host, %.1f us of the certifier thread per pair): %d of %d argmin columns differ from the oracle's (%d pairs); unexplained by the descriptor error: %d" % (
              rep["host_hypotheses_per_pair"], rep["certifier_us_per_pair"], rep["flips"], rep["columns"], rep["pairs_with_flip"], rep["flips_unexplained"]),
          "    pairs without a flip (%d): inlier sets differing %d, success / threshold differing %d, poses bit-identical to the oracle's %d, max R/T err %.2g" % (
