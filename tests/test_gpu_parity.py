@@ -251,6 +251,32 @@ def test_patches_truncation_taxonomy(api, orc, scans):
     assert np.array_equal(flags.cpu().numpy(), gc["patch_flags"]) and int(((gc["patch_flags"] & 4) != 0).sum()) == 11
 
 
+def test_brute_force_lists_in_adversarial_orders(api, orc):
+    """k_brute_query (lists of 496 .. 993 voxels) runs NumPy's introselect as written, median-of-medians fallback included: a dense ball
+    of 990 voxels listed in organ-pipe / ascending / descending / random order of distance from the key voxels (organ pipe is the
+    classic median-of-three killer: the oracle's fallback counter must move), 64 key points each -- bits and flags equal the oracle's,
+    which tests/test_oracle_golden.py pins to np.argpartition on exactly such rows."""
+    rs = np.random.RandomState(17)
+    c = np.array([600, 640, 90])
+    lat = np.argwhere(np.ones((15, 15, 15), bool)) - 7
+    lat = lat[np.argsort((lat ** 2).sum(1), kind="stable")[:990]]            # ascending distance from the centre
+    orders = {"ascending": np.arange(990), "descending": np.arange(990)[::-1],
+              "organ_pipe": np.r_[np.arange(0, 990, 2), np.arange(1, 990, 2)[::-1]], "random": rs.permutation(990)}
+    kv = c + rs.randint(-2, 3, size=(64, 3))
+    kv[0] = c
+    pts = (kv * 0.16 - orc.VIS + rs.uniform(0.01, 0.15, size=(64, 3))).astype(np.float32)
+    f0 = orc.lib().orc_argpartition_fallbacks()
+    n4 = 0
+    for name, o in orders.items():
+        vox = (lat[o] + c).astype(np.int16)
+        ob, of = orc.patches_bits(pts, vox, 1)
+        bits, flags = api.GetPatchesBits(pts, vox, vox, vox)
+        assert np.array_equal(bits[:, 1].cpu().numpy().view(np.uint64), ob), name
+        assert np.array_equal(flags[:, 1].cpu().numpy(), of) and not (of & 2).any(), name
+        n4 += int(((of & 4) != 0).sum())
+    assert n4 >= 100 and orc.lib().orc_argpartition_fallbacks() > f0
+
+
 def test_nan_points_raise_like_the_reference(api, engine, scans):
     """VERDICT r3 (missing 4): a NaN coordinate makes int(nan) raise ValueError at SphericalRing.py:86-88 and Voxel.py:122-124;
     an infinite x or y is a point like any other there (finite angle; dropped by the range filter of Voxel.py:90-96).  The
