@@ -63,10 +63,10 @@ def _make(args):
     return synth.shuffle_scan(pc, 1000 + frame) if shuffle else pc
 
 
-def make_scans(scene, n, workers=None):
+def make_scans(scene, n, workers=None, first=0):
     """n consecutive scans of a scene; ray casting is ~0.5 s of one core per scan, so in worker processes (spawn: the parent may
     hold a HIP context)."""
-    jobs = [(f, SCENES[scene]) for f in range(n)]
+    jobs = [(f, SCENES[scene]) for f in range(first, first + n)]   # (first: another stretch of the circuit -- other scans, not other seeds)
     workers = workers or min(n, max(1, (os.cpu_count() or 2) // 2), 48)
     if workers <= 1 or n <= 2:
         return [_make(j) for j in jobs]
@@ -282,11 +282,12 @@ def main():
     ap.add_argument("--shuffled-frames", type=int, default=24, help="frames of the `shuffled` scene (an order check, not a soak)")
     ap.add_argument("--out", default=None)
     ap.add_argument("--seed-base", type=int, default=5000)
+    ap.add_argument("--first-frame", type=int, default=0, help="frame index of the trajectory the soaked stretch starts at")
     ap.add_argument("--dist-channels", type=int, default=5, choices=(3, 5), help="5 = demo mode, 3 = batch mode of the key point rule (SURVEY 8a-3')")
     args = ap.parse_args()
     names = args.scenes.split(",")
     plan = {s: (args.shuffled_frames if s == "shuffled" else args.frames) for s in names}
-    all_scans = {s: make_scans(s, n) for s, n in plan.items()}      # before the HIP context exists
+    all_scans = {s: make_scans(s, n, first=args.first_frame) for s, n in plan.items()}      # before the HIP context exists
     import caelo
     caelo.configure_runtime()
     import oracle as orc
@@ -295,7 +296,8 @@ def main():
     models = orc.load_models(os.path.join(REPO, "weights", "SphericalRingPCRespondLayer.h5"), os.path.join(REPO, "weights", "EncoderModel4VoxelPatch.h5"))
     eng = Engine()
     text = ["parity soak: HIP pipeline vs CPU oracle, %s, oracle on %d threads, key point rule in %s mode (dist_channels %d)" % (
-        time.strftime("%Y-%m-%d"), orc.num_threads(), "demo" if args.dist_channels == 5 else "batch", args.dist_channels)]
+        time.strftime("%Y-%m-%d"), orc.num_threads(), "demo" if args.dist_channels == 5 else "batch", args.dist_channels)
+        + ("" if not args.first_frame else "  [frames %d .. of the trajectory, seed base %d]" % (args.first_frame, args.seed_base))]
     ok = True
     for s in names:
         rep = soak(eng, orc, models, s, plan[s], seed_base=args.seed_base, log=lambda m: print(m, file=sys.stderr, flush=True), scans=all_scans[s],
